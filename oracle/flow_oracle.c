@@ -1,0 +1,635 @@
+/*
+ * flow_oracle.c - CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ * See flow_oracle.h for scope and parity status ("rollup parity unpinned",
+ * decode pinned against upb-protobuf with the reference's schema).
+ *
+ * Decoder semantics = canonical proto3 parsing as exercised at
+ * inserter/inserter.go:122-126 (proto.Unmarshal) and by ClickHouse's Protobuf
+ * input format (create.sh:33-34), restated from the protobuf wire-format spec
+ * and pinned case-by-case against upb (SURVEY.md Appendix A.2 plus
+ * tests/golden/edge_cases.json):
+ *   - fields in any order; unknown fields skipped by wire type;
+ *   - duplicates: last one wins;  absent: 0 / empty;
+ *   - tag = varint32: at most 5 bytes, value <= 0xFFFFFFFF, field number != 0;
+ *   - varint value: at most 10 bytes, bits above 64 dropped; uint32 columns keep
+ *     the low 32 bits;
+ *   - LEN size = varint32 (<= 5 bytes) and must not run past the record;
+ *   - wire types 6,7 are errors; groups (3/4) are skipped with matching END
+ *     tags, nesting limit 100; a known field inside a group is NOT applied and
+ *     field number 0 is tolerated there (upb's skipper does not check it);
+ *   - a known field carried with the wrong wire type is treated as unknown.
+ * Projection (create.sh:7-27): bytes -> FixedString(16) right-padded with NUL;
+ * a value longer than 16 bytes is a bad record (ClickHouse raises; policy in
+ * SURVEY.md 8(a)-4).
+ */
+#include "flow_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------ decode */
+
+typedef struct {
+    const uint8_t* p;
+    const uint8_t* end;
+} rd;
+
+/* varint with a byte limit; returns 0 on success */
+static int rd_varint(rd* r, int max_bytes, uint64_t* out) {
+    uint64_t v = 0;
+    for (int i = 0; i < max_bytes; i++) {
+        if (r->p >= r->end) return -1;
+        uint8_t b = *r->p++;
+        if (i < 9)
+            v |= (uint64_t)(b & 0x7f) << (7 * i);
+        else
+            v |= (uint64_t)(b & 0x01) << 63; /* 10th byte: only bit 63 survives */
+        if (!(b & 0x80)) {
+            *out = v;
+            return 0;
+        }
+    }
+    return -1; /* too long */
+}
+
+/* tag inside an unknown group: upb's group skipper does not reject field 0 */
+static int rd_tag_raw(rd* r, uint32_t* field, uint32_t* wt) {
+    uint64_t t;
+    if (rd_varint(r, 5, &t)) return -1;
+    if (t > 0xFFFFFFFFull) return -1;
+    *field = (uint32_t)(t >> 3);
+    *wt = (uint32_t)(t & 7);
+    return 0;
+}
+
+/* top-level tag: field number 0 is an error */
+static int rd_tag(rd* r, uint32_t* field, uint32_t* wt) {
+    if (rd_tag_raw(r, field, wt)) return -1;
+    if (*field == 0) return -1;
+    return 0;
+}
+
+static int rd_size(rd* r, uint64_t* sz) {
+    if (rd_varint(r, 5, sz)) return -1;
+    if (*sz > 0x7FFFFFFFull) return -1;
+    if (*sz > (uint64_t)(r->end - r->p)) return -1;
+    return 0;
+}
+
+/* skip a value of wire type wt belonging to `field` (needed for group END match) */
+static int rd_skip(rd* r, uint32_t field, uint32_t wt, int depth) {
+    uint64_t v;
+    switch (wt) {
+    case 0: return rd_varint(r, 10, &v);
+    case 1:
+        if (r->end - r->p < 8) return -1;
+        r->p += 8;
+        return 0;
+    case 2:
+        if (rd_size(r, &v)) return -1;
+        r->p += v;
+        return 0;
+    case 5:
+        if (r->end - r->p < 4) return -1;
+        r->p += 4;
+        return 0;
+    case 3: {
+        if (depth >= 100) return -1;
+        for (;;) {
+            uint32_t f2, w2;
+            if (rd_tag_raw(r, &f2, &w2)) return -1; /* also catches running off the end */
+            if (w2 == 4) return f2 == field ? 0 : -1;
+            if (rd_skip(r, f2, w2, depth + 1)) return -1;
+        }
+    }
+    default: return -1; /* 4 (stray END), 6, 7 */
+    }
+}
+
+static int take_addr(rd* r, uint8_t dst[16]) {
+    uint64_t sz;
+    if (rd_size(r, &sz)) return -1;
+    if (sz > 16) return -1; /* FixedString(16) overflow -> bad record */
+    memset(dst, 0, 16);
+    memcpy(dst, r->p, sz);
+    r->p += sz;
+    return 0;
+}
+
+int fo_decode(const uint8_t* p, size_t n, fo_row* out) {
+    rd r = {p, p + n};
+    fo_row row;
+    memset(&row, 0, sizeof row);
+    while (r.p < r.end) {
+        uint32_t field, wt;
+        uint64_t v;
+        if (rd_tag(&r, &field, &wt)) return FO_BAD;
+        if (wt == 0) {
+            if (rd_varint(&r, 10, &v)) return FO_BAD;
+            switch (field) {
+            case 2: row.time_received = v; break;
+            case 3: row.sampling_rate = v; break;
+            case 4: row.sequence_num = (uint32_t)v; break;
+            case 9: row.bytes = v; break;
+            case 10: row.packets = v; break;
+            case 14: row.src_as = (uint32_t)v; break;
+            case 15: row.dst_as = (uint32_t)v; break;
+            case 20: row.proto = (uint32_t)v; break;
+            case 21: row.src_port = (uint32_t)v; break;
+            case 22: row.dst_port = (uint32_t)v; break;
+            case 30: row.etype = (uint32_t)v; break;
+            case 38: row.time_flow_start = v; break;
+            default: break;
+            }
+        } else if (wt == 2 && (field == 6 || field == 7 || field == 11)) {
+            uint8_t* dst = field == 6 ? row.src_addr : field == 7 ? row.dst_addr : row.sampler_address;
+            if (take_addr(&r, dst)) return FO_BAD;
+        } else {
+            if (rd_skip(&r, field, wt, 0)) return FO_BAD;
+        }
+    }
+    *out = row;
+    return FO_OK;
+}
+
+int fo_decode_framed(const uint8_t* p, size_t n, fo_row* out) {
+    rd r = {p, p + n};
+    uint64_t len;
+    if (rd_varint(&r, 10, &len)) return FO_BAD;
+    if (len != (uint64_t)(r.end - r.p)) return FO_BAD;
+    return fo_decode(r.p, (size_t)len, out);
+}
+
+size_t fo_frame_split(const uint8_t* buf, size_t len, uint64_t* offsets, size_t cap) {
+    rd r = {buf, buf + len};
+    size_t n = 0;
+    while (r.p < r.end) {
+        uint64_t l;
+        if (n + 1 >= cap) return (size_t)-1;
+        offsets[n] = (uint64_t)(r.p - buf);
+        if (rd_varint(&r, 10, &l)) return (size_t)-1;
+        if (l > (uint64_t)(r.end - r.p)) return (size_t)-1;
+        r.p += l;
+        n++;
+    }
+    if (n >= cap) return (size_t)-1;
+    offsets[n] = len;
+    return n;
+}
+
+/* ------------------------------------------------------------------ rollup */
+/* flows_raw_view (create.sh:64-68): Date = toDate(TimeReceived), TimeReceived
+ * narrowed UInt64 -> DateTime (u32 seconds).  flows_5m_view (create.sh:92-110):
+ * key (Date, toStartOfFiveMinute(TimeReceived), SrcAS, DstAS, [EType]),
+ * sum(Bytes), sum(Packets), count().  Server TZ = UTC.  Parity domain:
+ * 65536 <= TimeReceived < 2^32; outside it this oracle just
+ * applies the same arithmetic to the low 32 bits. */
+
+typedef struct {
+    uint32_t used;
+    uint32_t timeslot, src_as, dst_as, etype;
+    uint64_t bytes, packets, count;
+} slot;
+
+struct fo_rollup {
+    uint32_t gran;
+    size_t cap, n;
+    slot* t;
+};
+
+static uint64_t mix64(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xbf58476d1ce4e5b9ull;
+    z ^= z >> 27;
+    z *= 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return z;
+}
+
+fo_rollup* fo_rollup_new(uint32_t gran) {
+    fo_rollup* r = (fo_rollup*)calloc(1, sizeof *r);
+    r->gran = gran ? gran : 300;
+    r->cap = 1024;
+    r->t = (slot*)calloc(r->cap, sizeof(slot));
+    return r;
+}
+void fo_rollup_free(fo_rollup* r) {
+    if (!r) return;
+    free(r->t);
+    free(r);
+}
+size_t fo_rollup_size(const fo_rollup* r) { return r->n; }
+
+static void rollup_put(fo_rollup* r, uint32_t ts, uint32_t sa, uint32_t da, uint32_t et, uint64_t b,
+                       uint64_t p, uint64_t c);
+
+static void rollup_grow(fo_rollup* r) {
+    slot* old = r->t;
+    size_t oc = r->cap;
+    r->cap *= 2;
+    r->n = 0;
+    r->t = (slot*)calloc(r->cap, sizeof(slot));
+    for (size_t i = 0; i < oc; i++)
+        if (old[i].used)
+            rollup_put(r, old[i].timeslot, old[i].src_as, old[i].dst_as, old[i].etype, old[i].bytes,
+                       old[i].packets, old[i].count);
+    free(old);
+}
+
+static void rollup_put(fo_rollup* r, uint32_t ts, uint32_t sa, uint32_t da, uint32_t et, uint64_t b,
+                       uint64_t p, uint64_t c) {
+    if ((r->n + 1) * 2 > r->cap) rollup_grow(r);
+    uint64_t h = mix64(((uint64_t)sa << 32 | da) ^ mix64((uint64_t)ts << 32 | et));
+    size_t m = r->cap - 1, i = (size_t)h & m;
+    for (;;) {
+        slot* s = &r->t[i];
+        if (!s->used) {
+            s->used = 1;
+            s->timeslot = ts;
+            s->src_as = sa;
+            s->dst_as = da;
+            s->etype = et;
+            s->bytes = b;
+            s->packets = p;
+            s->count = c;
+            r->n++;
+            return;
+        }
+        if (s->timeslot == ts && s->src_as == sa && s->dst_as == da && s->etype == et) {
+            s->bytes += b; /* UInt64 sums wrap mod 2^64 */
+            s->packets += p;
+            s->count += c;
+            return;
+        }
+        i = (i + 1) & m;
+    }
+}
+
+void fo_rollup_add(fo_rollup* r, const fo_row* row) {
+    uint32_t t = (uint32_t)row->time_received; /* UInt64 -> DateTime */
+    uint32_t ts = t - t % r->gran;
+    rollup_put(r, ts, row->src_as, row->dst_as, row->etype, row->bytes, row->packets, 1);
+}
+
+uint64_t fo_rollup_ingest(fo_rollup* r, const uint8_t* buf, const uint64_t* off, size_t n,
+                          int framed) {
+    uint64_t bad = 0;
+    for (size_t k = 0; k < n; k++) {
+        fo_row row;
+        const uint8_t* p = buf + off[k];
+        size_t len = (size_t)(off[k + 1] - off[k]);
+        int rc = framed ? fo_decode_framed(p, len, &row) : fo_decode(p, len, &row);
+        if (rc != FO_OK) {
+            bad++;
+            continue;
+        }
+        fo_rollup_add(r, &row);
+    }
+    return bad;
+}
+
+void fo_rollup_merge(fo_rollup* dst, const fo_rollup* src) {
+    for (size_t i = 0; i < src->cap; i++)
+        if (src->t[i].used)
+            rollup_put(dst, src->t[i].timeslot, src->t[i].src_as, src->t[i].dst_as, src->t[i].etype,
+                       src->t[i].bytes, src->t[i].packets, src->t[i].count);
+}
+
+static int row5m_cmp(const void* a, const void* b) {
+    const fo_row5m* x = (const fo_row5m*)a;
+    const fo_row5m* y = (const fo_row5m*)b;
+#define CMP(f) \
+    if (x->f != y->f) return x->f < y->f ? -1 : 1
+    CMP(date);
+    CMP(timeslot);
+    CMP(src_as);
+    CMP(dst_as);
+    CMP(etype);
+#undef CMP
+    return 0;
+}
+
+size_t fo_rollup_rows(const fo_rollup* r, uint32_t filter, fo_row5m* out, size_t cap) {
+    size_t k = 0;
+    for (size_t i = 0; i < r->cap; i++) {
+        const slot* s = &r->t[i];
+        if (!s->used) continue;
+        if (filter != 0xFFFFFFFFu && s->timeslot != filter) continue;
+        if (k >= cap) return k;
+        fo_row5m* o = &out[k++];
+        o->date = s->timeslot / 86400u; /* == floor(t/86400) whenever 86400 % gran == 0 */
+        o->timeslot = s->timeslot;
+        o->src_as = s->src_as;
+        o->dst_as = s->dst_as;
+        o->etype = s->etype;
+        o->_pad = 0;
+        o->bytes = s->bytes;
+        o->packets = s->packets;
+        o->count = s->count;
+    }
+    qsort(out, k, sizeof *out, row5m_cmp);
+    return k;
+}
+
+/* --------------------------------------------------------------------- CMS */
+/* There is no Count-Min sketch in the reference; the exact contract is the
+ * dashboard query `GROUP BY SrcAddr ORDER BY sum(Bytes*SamplingRate) DESC`
+ * (compose/grafana/dashboards/viz-ch.json:233,479).  The sketch is defined by
+ * this repository: row r of key k hits column
+ * fo_hash_key16(k, seed, r) >> (64 - width_log2). */
+uint64_t fo_hash_key16(const uint8_t key[16], uint64_t seed, uint32_t row) {
+    uint64_t lo, hi;
+    memcpy(&lo, key, 8);
+    memcpy(&hi, key + 8, 8);
+    uint64_t h = mix64(lo ^ mix64(seed + 0x9E3779B97F4A7C15ull * (row + 1)));
+    h = mix64(h ^ hi);
+    return h;
+}
+void fo_cms_update(uint64_t* cms, uint32_t depth, uint32_t wl2, uint64_t seed, const uint8_t key[16],
+                   uint64_t w) {
+    for (uint32_t r = 0; r < depth; r++)
+        cms[((size_t)r << wl2) + (size_t)(fo_hash_key16(key, seed, r) >> (64 - wl2))] += w;
+}
+uint64_t fo_cms_query(const uint64_t* cms, uint32_t depth, uint32_t wl2, uint64_t seed,
+                      const uint8_t key[16]) {
+    uint64_t best = ~0ull;
+    for (uint32_t r = 0; r < depth; r++) {
+        uint64_t v = cms[((size_t)r << wl2) + (size_t)(fo_hash_key16(key, seed, r) >> (64 - wl2))];
+        if (v < best) best = v;
+    }
+    return best;
+}
+
+/* --------------------------------------------------------------- generator */
+/* Restates the value distribution of mocker/mocker.go:57-91 with a
+ * counter-based PRNG so any record index can be regenerated independently
+ * (the Go program uses an unseeded math/rand stream and is not reproducible).
+ * Spec (DESIGN.md "Synthetic generator"):
+ *   base(i)  = mix64(seed * 0x9E3779B97F4A7C15 + i + 1)
+ *   rnd(i,j) = mix64(base(i) ^ ((j + 1) * 0xD1B54A32D192ED03))
+ */
+static uint64_t gen_rnd(const fo_gen_params* g, uint64_t i, uint32_t j) {
+    uint64_t base = mix64(g->seed * 0x9E3779B97F4A7C15ull + i + 1);
+    return mix64(base ^ ((uint64_t)(j + 1) * 0xD1B54A32D192ED03ull));
+}
+
+/* Integer-only Zipf-like rank sampler over [0, 2^L): the universe is cut into
+ * octaves [2^k-1, 2^(k+1)-1); octave k is drawn with probability proportional
+ * to w_k = floor(2^32 * 2^(-k*(s-1))) (the integral of x^-s over an octave
+ * scales as 2^(-k(s-1))), computed in fixed point by repeated multiplication
+ * with q = round(2^32 * 2^-(s-1)) taken from a small table; ranks are uniform
+ * inside an octave.  Pure integer math => bit-identical on CPU and GPU. */
+static uint32_t zipf_q32(uint32_t s_x100) {
+    /* round(2^32 * 2^-((s_x100-100)/100)) for the exponents the configs use */
+    switch (s_x100) {
+    case 80: return 0xFFFFFFFFu;  /* s<1: handled by caller (weights grow) */
+    case 100: return 0xFFFFFFFFu; /* ~1.0 */
+    case 110: return 4007346185u; /* 2^-0.1 * 2^32 */
+    case 120: return 3738986199u; /* 2^-0.2 * 2^32 */
+    case 150: return 3037000500u; /* 2^-0.5 * 2^32 */
+    default: return 4007346185u;
+    }
+}
+static uint32_t zipf_g32(uint32_t s_x100) {
+    /* growth factor for s < 1: round(2^30 * 2^(0.2)) for s=0.8 */
+    return s_x100 == 80 ? 1233405467u : (1u << 30);
+}
+static uint64_t zipf_rank(const fo_gen_params* g, uint64_t r) {
+    uint32_t L = g->zipf_log2_universe ? g->zipf_log2_universe : 24;
+    uint32_t s = g->zipf_s_x100 ? g->zipf_s_x100 : 110;
+    /* octave weights in 2.30 fixed point, cumulative in u64 */
+    uint64_t w[40], tot = 0, cur = 1ull << 30;
+    for (uint32_t k = 0; k < L; k++) {
+        w[k] = cur ? cur : 1;
+        tot += w[k];
+        if (s >= 100)
+            cur = (cur * (uint64_t)zipf_q32(s)) >> 32;
+        else
+            cur = (cur * (uint64_t)zipf_g32(s)) >> 30;
+    }
+    uint64_t u = (r >> 11) % tot; /* modulo bias < 2^-20, identical on both sides */
+    uint32_t k = 0;
+    while (u >= w[k]) {
+        u -= w[k];
+        k++;
+    }
+    uint64_t lo = (1ull << k) - 1, span = 1ull << k;
+    uint64_t r2 = mix64(r ^ 0xA5A5A5A5A5A5A5A5ull);
+    return lo + (r2 & (span - 1));
+}
+/* fixed bijective map rank -> 16-byte key (SURVEY.md 8(d) cfg 3) */
+static void zipf_key(uint64_t rank, uint64_t salt, uint8_t out[16], int v4) {
+    uint64_t a = mix64(rank * 0x9E3779B97F4A7C15ull + salt);
+    uint64_t b = mix64(a ^ 0xD1B54A32D192ED03ull);
+    memset(out, 0, 16);
+    if (v4) {
+        memcpy(out, &a, 4);
+    } else {
+        memcpy(out, &a, 8);
+        memcpy(out + 8, &b, 8);
+    }
+}
+
+void fo_gen_row(const fo_gen_params* g, uint64_t i, fo_row* o) {
+    memset(o, 0, sizeof *o);
+    uint64_t r0 = gen_rnd(g, i, 0), r1 = gen_rnd(g, i, 1), r2 = gen_rnd(g, i, 2),
+             r3 = gen_rnd(g, i, 3), r4 = gen_rnd(g, i, 4), r5 = gen_rnd(g, i, 5);
+    static const uint8_t pfx[15] = {0x20, 0x01, 0x0d, 0xb8, 0, 0, 0, 0x01, 0, 0, 0, 0, 0, 0, 0};
+    o->sampling_rate = 1;                         /* mocker.go:77 */
+    o->bytes = r0 % 1500;                         /* mocker.go:59 */
+    o->packets = r1 % 100;                        /* mocker.go:60 */
+    o->src_port = (uint32_t)(r5 & 0xFFFF);        /* mocker.go:87 */
+    o->dst_port = (uint32_t)((r5 >> 16) & 0xFFFF);/* mocker.go:88 */
+    o->sequence_num = (uint32_t)i;                /* mocker.go:89-91 */
+    if (g->mode == FO_GEN_MOCKER) {
+        uint32_t ps = g->per_sec ? g->per_sec : 4;
+        o->time_received = g->t0 + i / ps;        /* mocker.go:57,85-86 */
+        o->src_as = 65000 + (uint32_t)(r2 % 3);   /* mocker.go:61,80 */
+        o->dst_as = 65000 + (uint32_t)(r3 % 3);   /* mocker.go:62,81 */
+        o->etype = 0x86dd;                        /* mocker.go:82 */
+        memcpy(o->src_addr, pfx, 15);             /* mocker.go:64-71 */
+        memcpy(o->dst_addr, pfx, 15);
+        o->src_addr[15] = (uint8_t)(r4 & 0xff);
+        o->dst_addr[15] = (uint8_t)((r4 >> 8) & 0xff);
+    } else {
+        uint64_t nt = g->n_total ? g->n_total : 1;
+        o->time_received = g->t0 + (uint64_t)g->span_secs * i / nt;
+        int v6 = (int)((r2 >> 16) & 1);
+        o->etype = v6 ? 0x86dd : 0x0800;
+        if (g->mode == FO_GEN_ASPAIRS) {
+            o->src_as = 64512 + (uint32_t)(r2 & 255);
+            o->dst_as = 64512 + (uint32_t)((r2 >> 8) & 255);
+            if (v6) {
+                memcpy(o->src_addr, pfx, 15);
+                memcpy(o->dst_addr, pfx, 15);
+                o->src_addr[15] = (uint8_t)(r4 & 0xff);
+                o->dst_addr[15] = (uint8_t)((r4 >> 8) & 0xff);
+            } else {
+                o->src_addr[0] = 10; o->src_addr[1] = (uint8_t)(r4 >> 16);
+                o->src_addr[2] = (uint8_t)(r4 >> 24); o->src_addr[3] = (uint8_t)(r4 & 0xff);
+                o->dst_addr[0] = 10; o->dst_addr[1] = (uint8_t)(r4 >> 32);
+                o->dst_addr[2] = (uint8_t)(r4 >> 40); o->dst_addr[3] = (uint8_t)((r4 >> 8) & 0xff);
+            }
+        } else { /* FO_GEN_ZIPF */
+            uint64_t rs = zipf_rank(g, r3), rd_ = zipf_rank(g, r4);
+            o->src_as = 64512 + (uint32_t)(rs & 255);
+            o->dst_as = 64512 + (uint32_t)(rd_ & 255);
+            zipf_key(rs, 0x1111, o->src_addr, !v6);
+            zipf_key(rd_, 0x2222, o->dst_addr, !v6);
+            o->sampling_rate = (r2 >> 17) & 1 ? 1000 : 1;
+            o->proto = (r2 >> 18) & 1 ? 6 : 17;
+        }
+    }
+    o->time_flow_start = o->time_received;
+}
+
+static size_t put_varint(uint8_t* p, uint64_t v) {
+    size_t n = 0;
+    while (v >= 0x80) {
+        p[n++] = (uint8_t)(v | 0x80);
+        v >>= 7;
+    }
+    p[n++] = (uint8_t)v;
+    return n;
+}
+static size_t put_vfield(uint8_t* p, uint32_t field, uint64_t v) {
+    if (!v) return 0; /* proto3 omits zero values */
+    size_t n = put_varint(p, (uint64_t)field << 3);
+    return n + put_varint(p + n, v);
+}
+static size_t put_bfield(uint8_t* p, uint32_t field, const uint8_t* d, size_t len) {
+    if (!len) return 0;
+    size_t n = put_varint(p, ((uint64_t)field << 3) | 2);
+    n += put_varint(p + n, len);
+    memcpy(p + n, d, len);
+    return n + len;
+}
+static size_t addr_len(const fo_row* r, const uint8_t* a) {
+    /* generator emits 16-byte addresses for IPv6 rows, 4-byte for IPv4 rows */
+    (void)a;
+    return r->etype == 0x0800 ? 4 : 16;
+}
+
+/* golang/protobuf marshals known fields in field-number order (mocker.go:97). */
+static size_t encode_row(const fo_row* r, uint8_t* p) {
+    size_t n = 0;
+    n += put_vfield(p + n, 2, r->time_received);
+    n += put_vfield(p + n, 3, r->sampling_rate);
+    n += put_vfield(p + n, 4, r->sequence_num);
+    n += put_bfield(p + n, 6, r->src_addr, addr_len(r, r->src_addr));
+    n += put_bfield(p + n, 7, r->dst_addr, addr_len(r, r->dst_addr));
+    n += put_vfield(p + n, 9, r->bytes);
+    n += put_vfield(p + n, 10, r->packets);
+    n += put_vfield(p + n, 14, r->src_as);
+    n += put_vfield(p + n, 15, r->dst_as);
+    n += put_vfield(p + n, 20, r->proto);
+    n += put_vfield(p + n, 21, r->src_port);
+    n += put_vfield(p + n, 22, r->dst_port);
+    n += put_vfield(p + n, 30, r->etype);
+    n += put_vfield(p + n, 38, r->time_flow_start);
+    return n;
+}
+
+static size_t gen_one(const fo_gen_params* g, uint64_t i, uint8_t* out) {
+    fo_row r;
+    uint8_t tmp[192];
+    fo_gen_row(g, i, &r);
+    size_t n = encode_row(&r, tmp);
+    size_t k = 0;
+    if (g->framed) k = put_varint(out, n); /* proto.Buffer.EncodeMessage, mocker.go:99-101 */
+    memcpy(out + k, tmp, n);
+    return k + n;
+}
+
+uint32_t fo_gen_record_len(const fo_gen_params* g, uint64_t i) {
+    uint8_t tmp[208];
+    return (uint32_t)gen_one(g, i, tmp);
+}
+
+size_t fo_gen_records(const fo_gen_params* g, uint64_t i0, uint64_t n, uint8_t* out, size_t cap,
+                      uint64_t* offsets) {
+    size_t pos = 0;
+    uint8_t tmp[208];
+    for (uint64_t k = 0; k < n; k++) {
+        size_t l = gen_one(g, i0 + k, tmp);
+        if (pos + l > cap) return (size_t)-1;
+        memcpy(out + pos, tmp, l);
+        if (offsets) offsets[k] = pos;
+        pos += l;
+    }
+    if (offsets) offsets[n] = pos;
+    return pos;
+}
+
+/* ------------------------------------------------------------- cpu bench */
+typedef struct {
+    const fo_gen_params* g;
+    const uint8_t* buf;
+    const uint64_t* off;
+    size_t n;
+    fo_rollup* r;
+    uint64_t bad;
+} job;
+
+static void* job_run(void* a) {
+    job* j = (job*)a;
+    j->bad = fo_rollup_ingest(j->r, j->buf, j->off, j->n, (int)j->g->framed);
+    return NULL;
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+double fo_bench_rollup(const fo_gen_params* g, uint64_t i0, uint64_t n, int threads,
+                       uint64_t* wire_out, uint64_t* groups_out, uint64_t* bad_out,
+                       uint64_t* checksum_out) {
+    if (threads < 1) threads = 1;
+    size_t cap = (size_t)n * 96 + 256;
+    uint8_t* buf = (uint8_t*)malloc(cap);
+    uint64_t* off = (uint64_t*)malloc((n + 1) * sizeof(uint64_t));
+    size_t wire = fo_gen_records(g, i0, n, buf, cap, off);
+    job* jobs = (job*)calloc(threads, sizeof(job));
+    pthread_t* th = (pthread_t*)calloc(threads, sizeof(pthread_t));
+    double t0 = now_s();
+    for (int t = 0; t < threads; t++) {
+        size_t a = (size_t)(n * t / threads), b = (size_t)(n * (t + 1) / threads);
+        jobs[t].g = g;
+        jobs[t].buf = buf;
+        jobs[t].off = off + a;
+        jobs[t].n = b - a;
+        jobs[t].r = fo_rollup_new(300);
+        pthread_create(&th[t], NULL, job_run, &jobs[t]);
+    }
+    uint64_t bad = 0;
+    for (int t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        bad += jobs[t].bad;
+        if (t) fo_rollup_merge(jobs[0].r, jobs[t].r);
+    }
+    double dt = now_s() - t0;
+    if (wire_out) *wire_out = wire;
+    if (groups_out) *groups_out = fo_rollup_size(jobs[0].r);
+    if (bad_out) *bad_out = bad;
+    if (checksum_out) {
+        uint64_t cs = 0;
+        for (size_t i = 0; i < jobs[0].r->cap; i++) {
+            const slot* s = &jobs[0].r->t[i];
+            if (s->used)
+                cs += mix64(((uint64_t)s->timeslot << 32 | s->etype) ^
+                            mix64((uint64_t)s->src_as << 32 | s->dst_as)) *
+                      (s->bytes * 3 + s->packets * 5 + s->count * 7 + 1);
+        }
+        *checksum_out = cs;
+    }
+    for (int t = 0; t < threads; t++) fo_rollup_free(jobs[t].r);
+    free(jobs);
+    free(th);
+    free(buf);
+    free(off);
+    return dt;
+}
