@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py - FlowMessages/s aggregated into flows_5m on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (decode -> project -> (SrcAS,DstAS) 5-minute
+rollup) over one batch of synthetic input that is already resident in HBM:
+BASELINE config 2 = 100 M mocker-shaped framed FlowMessages, 64 k SrcAS/DstAS
+pairs, 3 five-minute windows, 2 ETypes, per GPU (weak scaling: every rank is one
+Kafka partition with its own 100 M records).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see the contract in the task description) with
+`roofline` (wire bytes / tile-kernel time vs 8 TB/s HBM peak, hipEvent-timed on
+the library's own stream) and `cpu_baseline` (the C oracle on this box's cores
+on a bounded sample of the same workload; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import _pkg  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def mix64(z):
+    z = z.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xbf58476d1ce4e5b9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94d049bb133111eb)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+def rows_checksum(rows):
+    """Same order-independent checksum the oracle's bench helper computes."""
+    with np.errstate(over="ignore"):
+        a = (rows["timeslot"].astype(np.uint64) << np.uint64(32)) | rows["etype"].astype(np.uint64)
+        b = (rows["src_as"].astype(np.uint64) << np.uint64(32)) | rows["dst_as"].astype(np.uint64)
+        h = mix64(a ^ mix64(b))
+        v = rows["bytes"] * np.uint64(3) + rows["packets"] * np.uint64(5) + rows["count"] * np.uint64(7) + np.uint64(1)
+        return int((h * v).sum(dtype=np.uint64))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--records", type=int, default=100_000_000, help="records per GPU per step")
+    ap.add_argument("--chunk", type=int, default=25_000_000, help="records per ingest call (< 4 GiB of wire)")
+    ap.add_argument("--mode", default="aspairs", choices=["mocker", "aspairs", "zipf"])
+    ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="records timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    fa = _pkg.load()
+    fa.build()
+    mode = {"mocker": fa.MOCK_MOCKER, "aspairs": fa.MOCK_ASPAIRS, "zipf": fa.MOCK_ZIPF}[args.mode]
+    n_rec = args.records
+    # every rank = one Kafka partition with its own stream (seed 2 = config 2, + rank)
+    mp = fa.mock_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000)
+
+    agg = fa.FlowAgg(device=local_rank, framed=True, table_capacity_log2=20, key_sets=fa.FA_KEYS_AS_PAIR)
+    chunks = []
+    wire_bytes = 0
+    i0 = 0
+    while i0 < n_rec:
+        m = min(args.chunk, n_rec - i0)
+        cap = m * 96 + 4096
+        d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(m + 1, dtype=torch.int32, device=dev)
+        w = agg.mock_generate_device(mp, i0, m, d_buf.data_ptr(), cap, d_off.data_ptr())
+        chunks.append((d_buf, d_off, w, m))
+        wire_bytes += w
+        i0 += m
+
+    def step():
+        for d_buf, d_off, w, m in chunks:
+            agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
+
+    def fence():
+        agg.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    st0 = agg.stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    st1 = agg.stats()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    launches = st1["kernel_launches"] - st0["kernel_launches"]
+    kern_s = (st1["kernel_ns_total"] - st0["kernel_ns_total"]) * 1e-9
+    bytes_per_launch = wire_bytes / len(chunks)
+    avg_launch_s = kern_s / max(launches, 1)
+    achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+
+    # window close across ranks (the only exchange step): gather + merge flows_5m rows
+    t_merge = time.perf_counter()
+    if world > 1:
+        merged = fa.dist.close_window_merged(agg, fa.ALL_TIMESLOTS, device=dev)
+    else:
+        merged = agg.close_window(fa.ALL_TIMESLOTS)
+    merge_ms = (time.perf_counter() - t_merge) * 1e3
+    total_steps = args.warmup + args.steps
+    ok_total = int(merged["count"].sum())
+    expect = n_rec * total_steps * world
+    assert ok_total == expect, "merged count() %d != records ingested %d" % (ok_total, expect)
+
+    value = n_rec * args.steps * world / elapsed
+    out = {
+        "metric": "FlowMessages/sec aggregated into flows_5m",
+        "value": value,
+        "unit": "FlowMessages/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: 1xMI355X per rank, %d mocker-shaped framed FlowMessages, "
+                        "64k SrcAS/DstAS pairs x 2 ETypes x 3 five-minute windows, sum(Bytes,Packets)+count() group-by"
+                        % n_rec,
+            "records_per_gpu_per_step": n_rec,
+            "wire_bytes_per_gpu_per_step": wire_bytes,
+            "bytes_per_record": wire_bytes / n_rec,
+            "generator": args.mode,
+            "launches_per_step": len(chunks),
+            "partitioning": "one Kafka partition per GPU, no data-path collective; rows all-gathered at window close",
+            "window_close_merge_ms": merge_ms,
+            "groups": int(len(merged)),
+            "wire_GBps_whole_job": wire_bytes * args.steps * world / elapsed / 1e9,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "fa::tile_kernel<MODE_INGEST, AS_PAIR>",
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+            "avg_launch_ms": avg_launch_s * 1e3,
+            "launches_timed": int(launches),
+        },
+    }
+
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        po = _pkg.load_oracle()
+        sample = min(args.cpu_sample, n_rec)
+        gp = po.gen_params(mode=mode, framed=1, seed=2, n_total=n_rec, span_secs=900, per_sec=400_000)
+        cores = os.cpu_count() or 1
+        res = po.bench_rollup(gp, 0, sample, cores)
+        out["cpu_baseline"] = {
+            "value": sample / res["seconds"],
+            "unit": "FlowMessages/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": "first %d records of the same workload (%.2f GB wire), C oracle restatement "
+                      "(decode+project+hash rollup), one shard per thread + merge; the Go inserter + "
+                      "ClickHouse cannot run in this image" % (sample, res["wire_bytes"] / 1e9),
+            "seconds": res["seconds"],
+        }
+        if not args.no_verify:
+            # parity on the same sample: GPU rows checksum == oracle rows checksum
+            d_buf, d_off, w, m = chunks[0]
+            s = min(sample, m)
+            check = fa.FlowAgg(device=local_rank, framed=True, table_capacity_log2=20)
+            nbytes = int(d_off[s].item())
+            check.ingest_device(d_buf.data_ptr(), nbytes, d_off.data_ptr(), s)
+            rows = check.read_window()
+            check.close()
+            if s == sample:
+                out["parity_sample_ok"] = bool(rows_checksum(rows) == res["checksum"] and res["bad"] == 0)
+                assert out["parity_sample_ok"], "GPU rows differ from the oracle on the CPU sample"
+    if rank == 0:
+        print(json.dumps(out))
+    agg.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,317 @@
+"""flow-pipeline_amd - MI355X-native flow-aggregation stage (host binding).
+
+Thin ctypes binding over the C-ABI of ``libflowagg.so`` (``include/flowagg.h``).
+The library replaces one hot path of cloudflare/flow-pipeline: Kafka message
+bytes -> proto3 FlowMessage decode -> 15-column projection -> 5-minute
+(SrcAS, DstAS) sum(Bytes)/sum(Packets)/count() rollup, i.e. the ClickHouse chain
+``flows -> flows_raw -> flows_5m`` of ``compose/clickhouse/create.sh:5-110``.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present the
+calls raise.  (The directory name contains a hyphen; load it with
+``_pkg.load()`` from the repository root or ``importlib`` - see ``_pkg.py``.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import dist, schema  # noqa: F401  (re-export)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflowagg.so")
+
+FA_KEYS_AS_PAIR = 1
+FA_KEYS_SRCADDR_CMS = 2
+FA_KEYS_DSTADDR_CMS = 4
+ALL_TIMESLOTS = 0xFFFFFFFF
+
+MOCK_MOCKER, MOCK_ASPAIRS, MOCK_ZIPF = 0, 1, 2
+T0 = 1_600_000_200  # multiple of 300
+
+ERRORS = {
+    -1: "FA_ERR_ARG", -2: "FA_ERR_NO_DEVICE", -3: "FA_ERR_HIP", -4: "FA_ERR_NOMEM",
+    -5: "FA_ERR_TABLE_FULL", -6: "FA_ERR_CAPACITY", -7: "FA_ERR_FRAMING", -8: "FA_ERR_UNSUPPORTED",
+}
+
+
+class FlowAggError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "FA_ERR"), code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("window_secs", C.c_uint32), ("subwindow_secs", C.c_uint32),
+        ("table_capacity_log2", C.c_uint32), ("cms_depth", C.c_uint32),
+        ("cms_width_log2", C.c_uint32), ("cms_seed", C.c_uint64), ("key_sets", C.c_uint32),
+        ("framed", C.c_int32), ("max_batch_records", C.c_uint32), ("reserved", C.c_uint32 * 5),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "records_ok", "records_bad", "records_slow", "bytes_in", "batches", "table_used",
+        "table_capacity", "kernel_ns", "kernel_ns_total", "kernel_launches")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class MockParams(C.Structure):
+    _fields_ = [
+        ("mode", C.c_uint32), ("framed", C.c_uint32), ("seed", C.c_uint64),
+        ("n_total", C.c_uint64), ("t0", C.c_uint64), ("span_secs", C.c_uint32),
+        ("per_sec", C.c_uint32), ("zipf_log2_universe", C.c_uint32), ("zipf_s_x100", C.c_uint32),
+    ]
+
+
+class Columns(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "time_received", "time_flow_start", "sampling_rate", "bytes", "packets",
+        "sequence_num", "src_as", "dst_as", "etype", "proto", "src_port", "dst_port",
+        "sampler_address", "src_addr", "dst_addr", "status")]
+
+
+class DeviceState(C.Structure):
+    _fields_ = [("cms_src", C.c_void_p), ("cms_dst", C.c_void_p), ("cms_words", C.c_size_t)]
+
+
+ROW5M_DTYPE = np.dtype([
+    ("date", "<u4"), ("timeslot", "<u4"), ("src_as", "<u4"), ("dst_as", "<u4"),
+    ("etype", "<u4"), ("_pad", "<u4"), ("bytes", "<u8"), ("packets", "<u8"), ("count", "<u8"),
+])
+FLOW_ROW_DTYPE = np.dtype([
+    ("time_received", "<u8"), ("time_flow_start", "<u8"), ("sampling_rate", "<u8"),
+    ("bytes", "<u8"), ("packets", "<u8"), ("sequence_num", "<u4"), ("src_as", "<u4"),
+    ("dst_as", "<u4"), ("etype", "<u4"), ("proto", "<u4"), ("src_port", "<u4"),
+    ("dst_port", "<u4"), ("status", "<u4"), ("sampler_address", "u1", 16),
+    ("src_addr", "u1", 16), ("dst_addr", "u1", 16),
+])
+TOPK_DTYPE = np.dtype([("key", "u1", 16), ("weight", "<u8")])
+assert ROW5M_DTYPE.itemsize == 48 and FLOW_ROW_DTYPE.itemsize == 120
+
+# every symbol include/flowagg.h declares (checked by the CPU test-suite)
+EXPORTS = [
+    "fa_abi_version", "fa_create", "fa_destroy", "fa_last_error", "fa_ingest", "fa_ingest_device",
+    "fa_sync", "fa_decode", "fa_decode_device", "fa_open_timeslots", "fa_close_window",
+    "fa_read_window", "fa_topk", "fa_cms_query", "fa_cms_read", "fa_cms_reset",
+    "fa_device_state_get", "fa_merge_rows", "fa_merge_allreduce", "fa_stats",
+    "fa_mock_generate_device", "fa_mock_generate_host",
+]
+
+_LIB = None
+
+
+def build(force=False):
+    """Compile libflowagg.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcdir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(srcdir, f) for f in os.listdir(srcdir)] + [
+        os.path.join(_HERE, "..", "include", "flowagg.h")]
+    if (force or not os.path.exists(LIB_PATH)
+            or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)):
+        subprocess.check_call(["make", "-C", srcdir, "-B"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """Load libflowagg.so.  Raises (never falls back) when it is not built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise FlowAggError(-2, "libflowagg.so is not built (run `python -c 'import __graft_entry__ as g; "
+                               "g.build()'` or `make -C flow-pipeline_amd/csrc`); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u32, u64 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint64
+    szp = C.POINTER(C.c_size_t)
+    L.fa_abi_version.restype = u32
+    L.fa_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.fa_destroy.argtypes = [vp]
+    L.fa_destroy.restype = None
+    L.fa_last_error.argtypes = [vp]
+    L.fa_last_error.restype = C.c_char_p
+    L.fa_ingest.argtypes = [vp, vp, sz, vp, sz]
+    L.fa_ingest_device.argtypes = [vp, vp, sz, vp, sz]
+    L.fa_sync.argtypes = [vp]
+    L.fa_decode.argtypes = [vp, vp, sz, vp, sz, vp]
+    L.fa_decode_device.argtypes = [vp, vp, sz, vp, sz, C.POINTER(Columns)]
+    L.fa_open_timeslots.argtypes = [vp, vp, sz, szp]
+    L.fa_close_window.argtypes = [vp, u32, vp, sz, szp]
+    L.fa_read_window.argtypes = [vp, u32, vp, sz, szp]
+    L.fa_topk.argtypes = [vp, u32, sz, vp, sz, szp]
+    L.fa_cms_query.argtypes = [vp, u32, C.c_char_p, C.POINTER(u64)]
+    L.fa_cms_read.argtypes = [vp, u32, vp, sz]
+    L.fa_cms_reset.argtypes = [vp, u32]
+    L.fa_device_state_get.argtypes = [vp, C.POINTER(DeviceState)]
+    L.fa_merge_rows.argtypes = [vp, vp, sz]
+    L.fa_merge_allreduce.argtypes = [vp, vp]
+    L.fa_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.fa_mock_generate_device.argtypes = [vp, C.POINTER(MockParams), u64, u64, vp, sz, vp, C.POINTER(u64)]
+    L.fa_mock_generate_host.argtypes = [C.POINTER(MockParams), u64, u64, vp, sz, vp, C.POINTER(u64)]
+    _LIB = L
+    return L
+
+
+def mock_params(mode=MOCK_MOCKER, framed=1, seed=1, n_total=0, t0=T0, span_secs=900, per_sec=4,
+                zipf_log2_universe=24, zipf_s_x100=110):
+    return MockParams(mode, framed, seed, n_total, t0, span_secs, per_sec, zipf_log2_universe,
+                      zipf_s_x100)
+
+
+def mock_generate_host(mp: MockParams, i0: int, n: int):
+    """Host twin of the device producer -> (bytes uint8[], offsets uint64[n+1])."""
+    buf = np.empty(n * 96 + 256, dtype=np.uint8)
+    off = np.empty(n + 1, dtype=np.uint64)
+    w = C.c_uint64()
+    rc = lib().fa_mock_generate_host(C.byref(mp), i0, n, buf.ctypes.data, buf.size,
+                                     off.ctypes.data, C.byref(w))
+    if rc:
+        raise FlowAggError(rc, "fa_mock_generate_host")
+    return buf[:w.value].copy(), off
+
+
+class FlowAgg:
+    """One aggregation context = one (Kafka partition, GPU) pair."""
+
+    def __init__(self, device=0, window_secs=300, subwindow_secs=0, table_capacity_log2=20,
+                 key_sets=FA_KEYS_AS_PAIR, framed=True, cms_depth=4, cms_width_log2=20,
+                 cms_seed=0x5EED, max_batch_records=0):
+        self._L = lib()
+        self.cfg = Config(device, window_secs, subwindow_secs, table_capacity_log2, cms_depth,
+                          cms_width_log2, cms_seed, key_sets, 1 if framed else 0, max_batch_records)
+        h = C.c_void_p()
+        rc = self._L.fa_create(C.byref(self.cfg), C.byref(h))
+        if rc:
+            raise FlowAggError(rc, (self._L.fa_last_error(None) or b"").decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fa_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc:
+            raise FlowAggError(rc, (self._L.fa_last_error(self._h) or b"").decode())
+
+    # -- ingest ---------------------------------------------------------------
+    def ingest(self, buf, offsets=None):
+        """Host bytes (bytes / uint8 array) + uint64 offsets (n+1) or None (framed stream)."""
+        b = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else \
+            np.ascontiguousarray(buf, dtype=np.uint8)
+        if offsets is None:
+            self._chk(self._L.fa_ingest(self._h, b.ctypes.data, b.size, None, 0))
+        else:
+            o = np.ascontiguousarray(offsets, dtype=np.uint64)
+            self._chk(self._L.fa_ingest(self._h, b.ctypes.data, b.size, o.ctypes.data, len(o) - 1))
+
+    def ingest_device(self, d_buf_ptr: int, nbytes: int, d_off_ptr: int, n: int):
+        """Device-resident batch: raw device pointers (e.g. torch tensor .data_ptr())."""
+        self._chk(self._L.fa_ingest_device(self._h, d_buf_ptr, nbytes, d_off_ptr, n))
+
+    def sync(self):
+        self._chk(self._L.fa_sync(self._h))
+
+    # -- decode / projection -----------------------------------------------------
+    def decode(self, buf, offsets) -> np.ndarray:
+        b = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray)) else \
+            np.ascontiguousarray(buf, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(o) - 1
+        out = np.zeros(n, dtype=FLOW_ROW_DTYPE)
+        self._chk(self._L.fa_decode(self._h, b.ctypes.data, b.size, o.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def decode_device(self, d_buf_ptr: int, nbytes: int, d_off_ptr: int, n: int) -> Columns:
+        cols = Columns()
+        self._chk(self._L.fa_decode_device(self._h, d_buf_ptr, nbytes, d_off_ptr, n, C.byref(cols)))
+        return cols
+
+    # -- window close ---------------------------------------------------------------
+    def _rows_call(self, fn, timeslot):
+        n = C.c_size_t()
+        cap = 1 << 12
+        while True:
+            out = np.zeros(cap, dtype=ROW5M_DTYPE)
+            rc = fn(self._h, timeslot, out.ctypes.data, cap, C.byref(n))
+            if rc == -6:  # FA_ERR_CAPACITY: n holds the required size
+                cap = n.value
+                continue
+            self._chk(rc)
+            return out[:n.value].copy()
+
+    def read_window(self, timeslot=ALL_TIMESLOTS) -> np.ndarray:
+        return self._rows_call(self._L.fa_read_window, timeslot)
+
+    def close_window(self, timeslot=ALL_TIMESLOTS) -> np.ndarray:
+        return self._rows_call(self._L.fa_close_window, timeslot)
+
+    def open_timeslots(self) -> np.ndarray:
+        n = C.c_size_t()
+        cap = 1 << 10
+        while True:
+            out = np.zeros(cap, dtype=np.uint32)
+            rc = self._L.fa_open_timeslots(self._h, out.ctypes.data, cap, C.byref(n))
+            if rc == -6:
+                cap = n.value
+                continue
+            self._chk(rc)
+            return out[:n.value].copy()
+
+    def merge_rows(self, rows: np.ndarray):
+        r = np.ascontiguousarray(rows, dtype=ROW5M_DTYPE)
+        self._chk(self._L.fa_merge_rows(self._h, r.ctypes.data, len(r)))
+
+    # -- sketches -------------------------------------------------------------------
+    def cms_read(self, key_set) -> np.ndarray:
+        words = self.cfg.cms_depth << self.cfg.cms_width_log2
+        out = np.zeros(words, dtype=np.uint64)
+        self._chk(self._L.fa_cms_read(self._h, key_set, out.ctypes.data, words))
+        return out.reshape(self.cfg.cms_depth, -1)
+
+    def cms_query(self, key_set, key: bytes) -> int:
+        w = C.c_uint64()
+        self._chk(self._L.fa_cms_query(self._h, key_set, key, C.byref(w)))
+        return w.value
+
+    def cms_reset(self, key_set):
+        self._chk(self._L.fa_cms_reset(self._h, key_set))
+
+    def topk(self, key_set, k) -> np.ndarray:
+        out = np.zeros(k, dtype=TOPK_DTYPE)
+        n = C.c_size_t()
+        self._chk(self._L.fa_topk(self._h, key_set, k, out.ctypes.data, k, C.byref(n)))
+        return out[:n.value]
+
+    def device_state(self) -> DeviceState:
+        st = DeviceState()
+        self._chk(self._L.fa_device_state_get(self._h, C.byref(st)))
+        return st
+
+    def merge_allreduce(self, rccl_comm_ptr: int):
+        self._chk(self._L.fa_merge_allreduce(self._h, rccl_comm_ptr))
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._chk(self._L.fa_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    # -- synthetic producer ------------------------------------------------------------
+    def mock_generate_device(self, mp: MockParams, i0: int, n: int, d_buf_ptr: int, cap: int,
+                             d_off_ptr: int) -> int:
+        w = C.c_uint64()
+        self._chk(self._L.fa_mock_generate_device(self._h, C.byref(mp), i0, n, d_buf_ptr, cap,
+                                                  d_off_ptr, C.byref(w)))
+        return w.value

@@ -1,0 +1,914 @@
+// flowagg.hip - C-ABI implementation of libflowagg (include/flowagg.h).
+//
+// Host side of the MI355X flow-aggregation stage: owns the HIP stream, the
+// device group-by table, sketches, pinned staging and the SoA projection
+// buffers; launches the gfx950 kernels of kernels.cuh.  Mirrors the shape of
+// the reference sink (inserter/inserter.go:90-165: buffer -> flush) with the
+// ClickHouse semantics of compose/clickhouse/create.sh:5-110.
+// There is deliberately no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/flowagg.h"
+#include "kernels.cuh"
+
+using namespace fa;
+
+static thread_local std::string g_create_error;
+
+struct fa_ctx {
+    fa_config cfg{};
+    uint32_t gran = 300;
+    hipStream_t stream = nullptr;
+    // one (start, stop) event pair per ingest launch, bracketing the tile kernel only
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+
+    Slot* tab = nullptr;
+    uint32_t cap_log2 = 20;
+    SpillEntry* spill = nullptr;
+    uint32_t spill_cap = 1u << 18;
+    Counters* d_ctr = nullptr;
+    Counters* h_ctr = nullptr;  // pinned
+    uint32_t* d_exotic = nullptr;
+    size_t exotic_cap = 0;
+
+    // host-fed path: pinned staging (double buffered) + device input
+    uint8_t* h_stage[2] = {nullptr, nullptr};
+    size_t h_stage_cap[2] = {0, 0};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int stage_cur = 0;
+    uint8_t* d_in[2] = {nullptr, nullptr};
+    size_t d_in_cap[2] = {0, 0};
+
+    // SoA projection
+    void* col_block = nullptr;
+    size_t col_cap = 0;
+    ColumnPtrs cols{};
+
+    // window close
+    Row5m* d_rows = nullptr;
+    size_t d_rows_cap = 0;
+
+    unsigned long long* cms_src = nullptr;
+    unsigned long long* cms_dst = nullptr;
+    size_t cms_words = 0;
+
+    fa_stats_t stats{};
+    uint64_t used_base = 0;  // groups created before the current counter epoch
+    std::string err;
+    int sticky = 0;  // sticky error from async work
+    int num_cus = 256;
+};
+
+#define HIPCHK(ctx, expr)                                                                       \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                    \
+            return FA_ERR_HIP;                                                                  \
+        }                                                                                       \
+    } while (0)
+
+static int fail(fa_ctx* c, int code, const char* msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+extern "C" uint32_t fa_abi_version(void) { return FA_ABI_VERSION; }
+
+extern "C" const char* fa_last_error(const fa_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+static KArgs make_args(fa_ctx* c) {
+    KArgs a{};
+    a.framed = c->cfg.framed ? 1u : 0u;
+    a.gran = c->gran;
+    a.tab = c->tab;
+    a.mask = (1u << c->cap_log2) - 1;
+    a.spill = c->spill;
+    a.spill_cap = c->spill_cap;
+    a.ctr = c->d_ctr;
+    a.exotic_idx = c->d_exotic;
+    a.cms_src = c->cms_src;
+    a.cms_dst = c->cms_dst;
+    a.cms_depth = c->cfg.cms_depth;
+    a.cms_wl2 = c->cfg.cms_width_log2;
+    a.cms_seed = c->cfg.cms_seed;
+    a.cols = c->cols;
+    return a;
+}
+
+// Persistent grid: exactly the number of workgroups that are co-resident
+// (CUs x LDS/VGPR-limited workgroups per CU); tiles are grid-strided.
+template <class K>
+static int grid_for(fa_ctx* c, K kernel, uint32_t n) {
+    uint32_t tiles = (n + BLOCK - 1) / BLOCK;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1)
+        per_cu = 2;
+    uint32_t g = (uint32_t)c->num_cus * (uint32_t)per_cu;
+    return (int)std::max(1u, std::min(tiles, g));
+}
+
+extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
+    if (!cfg_in || !out) {
+        g_create_error = "fa_create: null argument";
+        return FA_ERR_ARG;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = "fa_create: no HIP device (libflowagg has no CPU fallback)";
+        return FA_ERR_NO_DEVICE;
+    }
+    fa_config cfg = *cfg_in;
+    if (cfg.window_secs == 0) cfg.window_secs = 300;
+    if (cfg.table_capacity_log2 == 0) cfg.table_capacity_log2 = 20;
+    if (cfg.cms_depth == 0) cfg.cms_depth = 4;
+    if (cfg.cms_width_log2 == 0) cfg.cms_width_log2 = 20;
+    if (cfg.key_sets == 0) cfg.key_sets = FA_KEYS_AS_PAIR;
+    if (cfg.max_batch_records == 0) cfg.max_batch_records = 1u << 24;
+    uint32_t gran = cfg.subwindow_secs ? cfg.subwindow_secs : cfg.window_secs;
+    if (cfg.device < 0 || cfg.device >= ndev || gran < 60 || 86400 % gran != 0 ||
+        cfg.window_secs % gran != 0 || 86400 % cfg.window_secs != 0 || cfg.table_capacity_log2 < 10 ||
+        cfg.table_capacity_log2 > 30 || cfg.cms_depth > 16 || cfg.cms_width_log2 < 4 ||
+        cfg.cms_width_log2 > 28 || (cfg.key_sets & ~7u)) {
+        g_create_error = "fa_create: invalid configuration";
+        return FA_ERR_ARG;
+    }
+    fa_ctx* c = new fa_ctx();
+    c->cfg = cfg;
+    c->gran = gran;
+    c->cap_log2 = cfg.table_capacity_log2;
+    auto bail = [&](const char* what, hipError_t e) {
+        g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
+        fa_destroy(c);
+        return e == hipErrorOutOfMemory ? FA_ERR_NOMEM : FA_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(cfg.device)) != hipSuccess) return bail("hipSetDevice", e);
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg.device) == hipSuccess && v > 0)
+            c->num_cus = v;
+    }
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    for (int i = 0; i < 2; i++)
+        if ((e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming)) != hipSuccess)
+            return bail("hipEventCreate", e);
+    size_t tab_bytes = sizeof(Slot) << c->cap_log2;
+    if ((e = hipMalloc(&c->tab, tab_bytes)) != hipSuccess) return bail("hipMalloc(table)", e);
+    if ((e = hipMemsetAsync(c->tab, 0, tab_bytes, c->stream)) != hipSuccess) return bail("memset", e);
+    if ((e = hipMalloc(&c->spill, sizeof(SpillEntry) * c->spill_cap)) != hipSuccess)
+        return bail("hipMalloc(spill)", e);
+    if ((e = hipMalloc(&c->d_ctr, sizeof(Counters))) != hipSuccess) return bail("hipMalloc(ctr)", e);
+    if ((e = hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream)) != hipSuccess)
+        return bail("memset", e);
+    if ((e = hipHostMalloc(&c->h_ctr, sizeof(Counters))) != hipSuccess) return bail("hipHostMalloc", e);
+    if (cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
+        c->cms_words = (size_t)cfg.cms_depth << cfg.cms_width_log2;
+        if (cfg.key_sets & FA_KEYS_SRCADDR_CMS) {
+            if ((e = hipMalloc(&c->cms_src, c->cms_words * 8)) != hipSuccess) return bail("hipMalloc(cms)", e);
+            if ((e = hipMemsetAsync(c->cms_src, 0, c->cms_words * 8, c->stream)) != hipSuccess)
+                return bail("memset", e);
+        }
+        if (cfg.key_sets & FA_KEYS_DSTADDR_CMS) {
+            if ((e = hipMalloc(&c->cms_dst, c->cms_words * 8)) != hipSuccess) return bail("hipMalloc(cms)", e);
+            if ((e = hipMemsetAsync(c->cms_dst, 0, c->cms_words * 8, c->stream)) != hipSuccess)
+                return bail("memset", e);
+        }
+    }
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("sync", e);
+    c->stats.table_capacity = 1ull << c->cap_log2;
+    *out = c;
+    return FA_OK;
+}
+
+extern "C" void fa_destroy(fa_ctx* c) {
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->tab);
+    (void)hipFree(c->spill);
+    (void)hipFree(c->d_ctr);
+    if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    (void)hipFree(c->d_exotic);
+    for (int i = 0; i < 2; i++) {
+        if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
+        (void)hipFree(c->d_in[i]);
+        if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
+    }
+    (void)hipFree(c->col_block);
+    (void)hipFree(c->d_rows);
+    (void)hipFree(c->cms_src);
+    (void)hipFree(c->cms_dst);
+    for (auto& p : c->ev_pool) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---- table maintenance -------------------------------------------------------------
+// Builds a fresh table of 2^new_log2 slots holding every row outside [tb_lo,tb_hi).
+static int rebuild_table(fa_ctx* c, uint32_t new_log2, uint32_t tb_lo, uint32_t tb_hi) {
+    Slot* nt = nullptr;
+    size_t bytes = sizeof(Slot) << new_log2;
+    hipError_t e = hipMalloc(&nt, bytes);
+    if (e != hipSuccess) return fail(c, FA_ERR_NOMEM, "rebuild_table: hipMalloc failed");
+    HIPCHK(c, hipMemsetAsync(nt, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr->used, 0, sizeof(unsigned long long), c->stream));
+    Slot* old = c->tab;
+    uint32_t old_slots = 1u << c->cap_log2;
+    c->tab = nt;
+    c->cap_log2 = new_log2;
+    KArgs a = make_args(c);
+    hipLaunchKernelGGL(rebuild_kernel, dim3(1024), dim3(256), 0, c->stream, old, old_slots, tb_lo, tb_hi, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(old));
+    c->used_base = 0;
+    c->stats.table_capacity = 1ull << c->cap_log2;
+    return FA_OK;
+}
+
+// Waits for the stream, folds device counters into stats, replays spills after growing.
+static int settle(fa_ctx* c) {
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->ev_used; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) {
+            c->stats.kernel_ns = (uint64_t)((double)ms * 1e6);
+            c->stats.kernel_ns_total += c->stats.kernel_ns;
+            c->stats.kernel_launches += 1;
+        }
+    }
+    c->ev_used = 0;
+    Counters h = *c->h_ctr;
+    c->stats.records_ok = h.ok;
+    c->stats.records_bad = h.bad;
+    c->stats.records_slow = h.slow;
+    c->stats.table_used = c->used_base + h.used;
+    if (h.spill_lost) {
+        c->sticky = FA_ERR_TABLE_FULL;
+        return fail(c, FA_ERR_TABLE_FULL, "group-by table and spill buffer overflowed; aggregates were lost");
+    }
+    int guard = 0;
+    while (h.spill_count || c->stats.table_used * 2 > (1ull << c->cap_log2)) {
+        if (c->cap_log2 >= 30 || ++guard > 8) return fail(c, FA_ERR_TABLE_FULL, "group-by table cannot grow further");
+        uint32_t nspill = h.spill_count;
+        int rc = rebuild_table(c, c->cap_log2 + 1, 1, 0 /* empty range: keep everything */);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(&c->d_ctr->spill_count, 0, sizeof(unsigned int), c->stream));
+        if (nspill) {
+            // replay parked aggregates from a private copy (the spill buffer may be re-filled)
+            SpillEntry* tmp = nullptr;
+            HIPCHK(c, hipMalloc(&tmp, sizeof(SpillEntry) * nspill));
+            HIPCHK(c, hipMemcpyAsync(tmp, c->spill, sizeof(SpillEntry) * nspill, hipMemcpyDeviceToDevice, c->stream));
+            KArgs a = make_args(c);
+            hipLaunchKernelGGL(replay_spill_kernel, dim3(256), dim3(256), 0, c->stream, tmp, nspill, a);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipFree(tmp));
+        }
+        HIPCHK(c, hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost));
+        h = *c->h_ctr;
+        c->stats.table_used = c->used_base + h.used;
+        if (h.spill_lost) return fail(c, FA_ERR_TABLE_FULL, "spill buffer overflowed during replay");
+    }
+    return FA_OK;
+}
+
+extern "C" int fa_sync(fa_ctx* c) {
+    if (!c) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    return settle(c);
+}
+
+// ---- ingest ---------------------------------------------------------------------------
+template <int MODE>
+static int launch_tiles(fa_ctx* c, const KArgs& a, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+    dim3 b(BLOCK);
+    dim3 ge(std::min(256u, (a.n + BLOCK - 1) / BLOCK));
+#define FA_LAUNCH(KS)                                                                           \
+    case KS: {                                                                                  \
+        dim3 g(grid_for(c, tile_kernel<MODE, KS>, a.n));                                        \
+        if (ev_start) (void)hipEventRecord(ev_start, c->stream);                                \
+        hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);                     \
+        if (ev_stop) (void)hipEventRecord(ev_stop, c->stream);                                  \
+        hipLaunchKernelGGL((exotic_kernel<MODE, KS>), ge, b, 0, c->stream, a);                  \
+        break;                                                                                  \
+    }
+    if constexpr (MODE == MODE_DECODE) {
+        switch (1u) { FA_LAUNCH(1u) }
+    } else {
+        switch (c->cfg.key_sets) {
+            FA_LAUNCH(1u) FA_LAUNCH(2u) FA_LAUNCH(3u) FA_LAUNCH(4u) FA_LAUNCH(5u) FA_LAUNCH(6u) FA_LAUNCH(7u)
+        default: return fail(c, FA_ERR_ARG, "bad key_sets");
+        }
+    }
+#undef FA_LAUNCH
+    HIPCHK(c, hipGetLastError());
+    return FA_OK;
+}
+
+static int ensure_exotic(fa_ctx* c, size_t n) {
+    if (c->exotic_cap >= n) return FA_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_exotic);
+    c->d_exotic = nullptr;
+    size_t cap = std::max<size_t>(n, 1 << 16);
+    if (hipMalloc(&c->d_exotic, cap * sizeof(uint32_t)) != hipSuccess)
+        return fail(c, FA_ERR_NOMEM, "hipMalloc(deferral list) failed");
+    c->exotic_cap = cap;
+    return FA_OK;
+}
+
+extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const void* d_off, size_t n) {
+    if (!c) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    if (n == 0) return FA_OK;
+    if (!d_buf || !d_off || len >= (1ull << 32) || n > c->cfg.max_batch_records ||
+        ((uintptr_t)d_buf & 15) || ((uintptr_t)d_off & 3))
+        return fail(c, FA_ERR_ARG, "fa_ingest_device: bad buffer (16-byte aligned, < 4 GiB, n <= max_batch_records)");
+    int rc = ensure_exotic(c, n);
+    if (rc) return rc;
+    KArgs a = make_args(c);
+    a.buf = (const uint8_t*)d_buf;
+    a.off = (const uint32_t*)d_off;
+    a.n = (uint32_t)n;
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr->exotic_count, 0, sizeof(unsigned int), c->stream));
+    if (c->ev_used == c->ev_pool.size()) {
+        if (c->ev_pool.size() >= 4096) {  // bound the pool: fold what is pending
+            rc = settle(c);
+            if (rc) return rc;
+        } else {
+            hipEvent_t e0, e1;
+            HIPCHK(c, hipEventCreate(&e0));
+            HIPCHK(c, hipEventCreate(&e1));
+            c->ev_pool.emplace_back(e0, e1);
+        }
+    }
+    auto& evp = c->ev_pool[c->ev_used++];
+    rc = launch_tiles<MODE_INGEST>(c, a, evp.first, evp.second);
+    if (rc) return rc;
+    c->stats.bytes_in += len;
+    c->stats.batches += 1;
+    return FA_OK;
+}
+
+// Splits a chain of framed records on the host (offsets == NULL).
+static int frame_split_host(const uint8_t* buf, size_t len, std::vector<uint64_t>& off) {
+    size_t p = 0;
+    off.clear();
+    while (p < len) {
+        off.push_back(p);
+        uint64_t v = 0;
+        int i = 0;
+        for (;; i++) {
+            if (i >= 10 || p >= len) return FA_ERR_FRAMING;
+            uint8_t b = buf[p++];
+            if (i < 9)
+                v |= (uint64_t)(b & 0x7f) << (7 * i);
+            else
+                v |= (uint64_t)(b & 1) << 63;
+            if (!(b & 0x80)) break;
+        }
+        if (v > len - p) return FA_ERR_FRAMING;
+        p += v;
+    }
+    off.push_back(len);
+    return FA_OK;
+}
+
+static int ensure_stage(fa_ctx* c, int s, size_t bytes) {
+    if (c->h_stage_cap[s] < bytes) {
+        if (c->h_stage[s]) (void)hipHostFree(c->h_stage[s]);
+        c->h_stage[s] = nullptr;
+        size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 20);
+        if (hipHostMalloc(&c->h_stage[s], cap) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipHostMalloc(staging) failed");
+        c->h_stage_cap[s] = cap;
+    }
+    if (c->d_in_cap[s] < bytes) {
+        (void)hipFree(c->d_in[s]);
+        c->d_in[s] = nullptr;
+        size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 20);
+        if (hipMalloc(&c->d_in[s], cap) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(input) failed");
+        c->d_in_cap[s] = cap;
+    }
+    return FA_OK;
+}
+
+// Copies [buf,len) + offsets into pinned staging slot and uploads.  On return the
+// caller's memory is no longer referenced.  Layout in the slot: bytes, pad to 16,
+// 32 B slack, then n+1 uint32 offsets.
+static int stage_and_upload(fa_ctx* c, const uint8_t* buf, size_t len, const uint64_t* off, size_t n,
+                            const uint8_t** d_buf, const uint32_t** d_off, int* slot) {
+    if (len >= (1ull << 32) - 64) return fail(c, FA_ERR_ARG, "batch larger than 4 GiB; split it");
+    int s = c->stage_cur;
+    c->stage_cur ^= 1;
+    size_t off_pos = ((len + 15) & ~(size_t)15) + 32;
+    size_t total = off_pos + (n + 1) * sizeof(uint32_t);
+    HIPCHK(c, hipEventSynchronize(c->stage_ev[s]));  // slot free again?
+    int rc = ensure_stage(c, s, total);
+    if (rc) return rc;
+    uint8_t* hs = c->h_stage[s];
+    memcpy(hs, buf, len);
+    memset(hs + len, 0, off_pos - len);
+    uint32_t* ho = reinterpret_cast<uint32_t*>(hs + off_pos);
+    uint64_t prev = 0;
+    for (size_t i = 0; i <= n; i++) {
+        uint64_t o = off[i];
+        if (o < prev || o > len) return fail(c, FA_ERR_ARG, "offsets must be non-decreasing and <= len");
+        prev = o;
+        ho[i] = (uint32_t)o;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_in[s], hs, total, hipMemcpyHostToDevice, c->stream));
+    *slot = s;  // caller records stage_ev[s] once the kernels reading d_in[s] are enqueued
+    *d_buf = c->d_in[s];
+    *d_off = reinterpret_cast<const uint32_t*>(c->d_in[s] + off_pos);
+    return FA_OK;
+}
+
+extern "C" int fa_ingest(fa_ctx* c, const uint8_t* buf, size_t len, const uint64_t* offsets, size_t n) {
+    if (!c) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    if (!buf && len) return fail(c, FA_ERR_ARG, "fa_ingest: null buffer");
+    std::vector<uint64_t> split;
+    if (!offsets) {
+        if (!c->cfg.framed) return fail(c, FA_ERR_ARG, "fa_ingest: offsets are required for bare (unframed) records");
+        int rc = frame_split_host(buf, len, split);
+        if (rc) return fail(c, rc, "fa_ingest: stream is not a chain of varint-framed records");
+        offsets = split.data();
+        n = split.size() - 1;
+    }
+    if (n == 0) return FA_OK;
+    // chunk so that each launch stays under max_batch_records and 1 GiB of wire bytes
+    size_t i = 0;
+    while (i < n) {
+        size_t j = std::min(n, i + (size_t)c->cfg.max_batch_records);
+        while (j > i + 1 && offsets[j] - offsets[i] > (1ull << 30)) j = i + (j - i) / 2;
+        std::vector<uint64_t> rel;
+        const uint64_t* o = offsets + i;
+        uint64_t base = offsets[i];
+        if (base) {
+            rel.resize(j - i + 1);
+            for (size_t k = 0; k <= j - i; k++) {
+                if (offsets[i + k] < base) return fail(c, FA_ERR_ARG, "offsets must be non-decreasing");
+                rel[k] = offsets[i + k] - base;
+            }
+            o = rel.data();
+        }
+        if (offsets[j] > len || offsets[j] < base) return fail(c, FA_ERR_ARG, "offsets exceed len");
+        const uint8_t* d_buf;
+        const uint32_t* d_off;
+        int slot = 0;
+        int rc = stage_and_upload(c, buf + base, (size_t)(offsets[j] - base), o, j - i, &d_buf, &d_off, &slot);
+        if (rc) return rc;
+        rc = fa_ingest_device(c, d_buf, (size_t)(offsets[j] - base), d_off, j - i);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(c->stage_ev[slot], c->stream));
+        i = j;
+    }
+    return FA_OK;
+}
+
+// ---- decode + project ---------------------------------------------------------------------
+static int ensure_columns(fa_ctx* c, size_t n) {
+    if (c->col_cap >= n) return FA_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->col_block);
+    c->col_block = nullptr;
+    size_t cap = std::max<size_t>(n, 1 << 16);
+    cap = (cap + 63) & ~(size_t)63;
+    size_t bytes = cap * (5 * 8 + 7 * 4 + 3 * 16 + 1);
+    if (hipMalloc(&c->col_block, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(columns) failed");
+    uint8_t* p = (uint8_t*)c->col_block;
+    auto take = [&](size_t elem) {
+        uint8_t* r = p;
+        p += cap * elem;
+        return r;
+    };
+    c->cols.sampler_address = (uint4*)take(16);
+    c->cols.src_addr = (uint4*)take(16);
+    c->cols.dst_addr = (uint4*)take(16);
+    c->cols.time_received = (uint64_t*)take(8);
+    c->cols.time_flow_start = (uint64_t*)take(8);
+    c->cols.sampling_rate = (uint64_t*)take(8);
+    c->cols.bytes = (uint64_t*)take(8);
+    c->cols.packets = (uint64_t*)take(8);
+    c->cols.sequence_num = (uint32_t*)take(4);
+    c->cols.src_as = (uint32_t*)take(4);
+    c->cols.dst_as = (uint32_t*)take(4);
+    c->cols.etype = (uint32_t*)take(4);
+    c->cols.proto = (uint32_t*)take(4);
+    c->cols.src_port = (uint32_t*)take(4);
+    c->cols.dst_port = (uint32_t*)take(4);
+    c->cols.status = (uint8_t*)take(1);
+    c->col_cap = cap;
+    return FA_OK;
+}
+
+extern "C" int fa_decode_device(fa_ctx* c, const void* d_buf, size_t len, const void* d_off, size_t n,
+                                fa_columns* out) {
+    if (!c || !out) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    if (!d_buf || !d_off || len >= (1ull << 32) || n > c->cfg.max_batch_records || ((uintptr_t)d_buf & 15))
+        return fail(c, FA_ERR_ARG, "fa_decode_device: bad buffer");
+    int rc = ensure_columns(c, std::max<size_t>(n, 1));
+    if (rc) return rc;
+    rc = ensure_exotic(c, std::max<size_t>(n, 1));
+    if (rc) return rc;
+    if (n) {
+        KArgs a = make_args(c);
+        a.buf = (const uint8_t*)d_buf;
+        a.off = (const uint32_t*)d_off;
+        a.n = (uint32_t)n;
+        HIPCHK(c, hipMemsetAsync(&c->d_ctr->exotic_count, 0, sizeof(unsigned int), c->stream));
+        rc = launch_tiles<MODE_DECODE>(c, a);
+        if (rc) return rc;
+    }
+    out->time_received = c->cols.time_received;
+    out->time_flow_start = c->cols.time_flow_start;
+    out->sampling_rate = c->cols.sampling_rate;
+    out->bytes = c->cols.bytes;
+    out->packets = c->cols.packets;
+    out->sequence_num = c->cols.sequence_num;
+    out->src_as = c->cols.src_as;
+    out->dst_as = c->cols.dst_as;
+    out->etype = c->cols.etype;
+    out->proto = c->cols.proto;
+    out->src_port = c->cols.src_port;
+    out->dst_port = c->cols.dst_port;
+    out->sampler_address = (const uint8_t*)c->cols.sampler_address;
+    out->src_addr = (const uint8_t*)c->cols.src_addr;
+    out->dst_addr = (const uint8_t*)c->cols.dst_addr;
+    out->status = c->cols.status;
+    return FA_OK;
+}
+
+extern "C" int fa_decode(fa_ctx* c, const uint8_t* buf, size_t len, const uint64_t* offsets, size_t n,
+                         fa_flow_row* out) {
+    if (!c || (!out && n)) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    if (!offsets) return fail(c, FA_ERR_ARG, "fa_decode: offsets required");
+    size_t done = 0;
+    while (done < n) {
+        size_t j = std::min(n, done + (size_t)std::min<uint32_t>(c->cfg.max_batch_records, 1u << 22));
+        while (j > done + 1 && offsets[j] - offsets[done] > (1ull << 30)) j = done + (j - done) / 2;
+        size_t m = j - done;
+        uint64_t base = offsets[done];
+        std::vector<uint64_t> rel(m + 1);
+        for (size_t k = 0; k <= m; k++) {
+            if (offsets[done + k] < base || offsets[done + k] > len) return fail(c, FA_ERR_ARG, "bad offsets");
+            rel[k] = offsets[done + k] - base;
+        }
+        const uint8_t* d_buf;
+        const uint32_t* d_off;
+        int slot = 0;
+        int rc = stage_and_upload(c, buf + base, (size_t)rel[m], rel.data(), m, &d_buf, &d_off, &slot);
+        if (rc) return rc;
+        fa_columns cols;
+        rc = fa_decode_device(c, d_buf, (size_t)rel[m], d_off, m, &cols);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        // gather SoA -> AoS on the host
+        std::vector<uint64_t> u64(m);
+        std::vector<uint32_t> u32(m);
+        std::vector<uint8_t> b16(m * 16), st(m);
+        fa_flow_row* o = out + done;
+        memset(o, 0, m * sizeof(fa_flow_row));
+#define GET64(member, src)                                                                  \
+    HIPCHK(c, hipMemcpy(u64.data(), src, m * 8, hipMemcpyDeviceToHost));                    \
+    for (size_t k = 0; k < m; k++) o[k].member = u64[k];
+#define GET32(member, src)                                                                  \
+    HIPCHK(c, hipMemcpy(u32.data(), src, m * 4, hipMemcpyDeviceToHost));                    \
+    for (size_t k = 0; k < m; k++) o[k].member = u32[k];
+#define GET16(member, src)                                                                  \
+    HIPCHK(c, hipMemcpy(b16.data(), src, m * 16, hipMemcpyDeviceToHost));                   \
+    for (size_t k = 0; k < m; k++) memcpy(o[k].member, &b16[k * 16], 16);
+        GET64(time_received, cols.time_received)
+        GET64(time_flow_start, cols.time_flow_start)
+        GET64(sampling_rate, cols.sampling_rate)
+        GET64(bytes, cols.bytes)
+        GET64(packets, cols.packets)
+        GET32(sequence_num, cols.sequence_num)
+        GET32(src_as, cols.src_as)
+        GET32(dst_as, cols.dst_as)
+        GET32(etype, cols.etype)
+        GET32(proto, cols.proto)
+        GET32(src_port, cols.src_port)
+        GET32(dst_port, cols.dst_port)
+        GET16(sampler_address, cols.sampler_address)
+        GET16(src_addr, cols.src_addr)
+        GET16(dst_addr, cols.dst_addr)
+#undef GET64
+#undef GET32
+#undef GET16
+        HIPCHK(c, hipMemcpy(st.data(), cols.status, m, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < m; k++) o[k].status = st[k];
+        done = j;
+    }
+    return FA_OK;
+}
+
+// ---- window close ------------------------------------------------------------------------
+static bool row_less(const fa_row5m& x, const fa_row5m& y) {
+    if (x.date != y.date) return x.date < y.date;
+    if (x.timeslot != y.timeslot) return x.timeslot < y.timeslot;
+    if (x.src_as != y.src_as) return x.src_as < y.src_as;
+    if (x.dst_as != y.dst_as) return x.dst_as < y.dst_as;
+    return x.etype < y.etype;
+}
+
+// Collects rows with time bucket in [tb_lo,tb_hi) into host vector (unsorted).
+static int collect_rows(fa_ctx* c, uint32_t tb_lo, uint32_t tb_hi, std::vector<fa_row5m>& rows) {
+    int rc = settle(c);
+    if (rc) return rc;
+    size_t need = std::max<uint64_t>(c->stats.table_used, 1024);
+    if (c->d_rows_cap < need) {
+        (void)hipFree(c->d_rows);
+        c->d_rows = nullptr;
+        if (hipMalloc(&c->d_rows, need * sizeof(Row5m)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(rows) failed");
+        c->d_rows_cap = need;
+    }
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr->rows_count, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(extract_kernel, dim3(1024), dim3(256), 0, c->stream, c->tab, 1u << c->cap_log2, c->gran,
+                       tb_lo, tb_hi, c->d_rows, (uint32_t)c->d_rows_cap, c->d_ctr);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    size_t nrows = c->h_ctr->rows_count;
+    if (nrows > c->d_rows_cap) return fail(c, FA_ERR_HIP, "internal: row buffer too small");
+    static_assert(sizeof(Row5m) == sizeof(fa_row5m), "row layout");
+    rows.resize(nrows);
+    if (nrows) HIPCHK(c, hipMemcpy(rows.data(), c->d_rows, nrows * sizeof(Row5m), hipMemcpyDeviceToHost));
+    return FA_OK;
+}
+
+// timeslot -> bucket range.  With sub-windows a window [timeslot, timeslot+window_secs)
+// is the sum of window_secs/gran consecutive sub-buckets (sliding windows share them).
+static bool bucket_range(const fa_ctx* c, uint32_t timeslot, uint32_t& lo, uint32_t& hi) {
+    if (timeslot == 0xFFFFFFFFu) {
+        lo = 0;
+        hi = 0xFFFFFFFFu;
+        return true;
+    }
+    if (timeslot % c->gran) return false;
+    lo = timeslot / c->gran;
+    hi = lo + c->cfg.window_secs / c->gran;
+    return true;
+}
+
+static int window_rows(fa_ctx* c, uint32_t timeslot, std::vector<fa_row5m>& rows, uint32_t& lo, uint32_t& hi) {
+    rows.clear();
+    if (!bucket_range(c, timeslot, lo, hi)) {
+        lo = hi = 0;
+        return FA_OK;  // not a bucket boundary: no rows
+    }
+    int rc = collect_rows(c, lo, hi, rows);
+    if (rc) return rc;
+    if (timeslot != 0xFFFFFFFFu && c->gran != c->cfg.window_secs) {
+        // fold the sub-buckets of this window into one row per (SrcAS,DstAS,EType)
+        for (auto& r : rows) {
+            r.timeslot = timeslot;
+            r.date = timeslot / 86400u;
+        }
+    }
+    std::sort(rows.begin(), rows.end(), row_less);
+    size_t w = 0;
+    for (size_t i = 0; i < rows.size(); i++) {
+        if (w && !row_less(rows[w - 1], rows[i]) && !row_less(rows[i], rows[w - 1])) {
+            rows[w - 1].bytes += rows[i].bytes;
+            rows[w - 1].packets += rows[i].packets;
+            rows[w - 1].count += rows[i].count;
+        } else {
+            rows[w++] = rows[i];
+        }
+    }
+    rows.resize(w);
+    return FA_OK;
+}
+
+extern "C" int fa_read_window(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out) {
+    if (!c || !n_out) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    std::vector<fa_row5m> rows;
+    uint32_t lo, hi;
+    int rc = window_rows(c, timeslot, rows, lo, hi);
+    if (rc) return rc;
+    *n_out = rows.size();
+    if (rows.size() > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
+    if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(fa_row5m));
+    return FA_OK;
+}
+
+extern "C" int fa_close_window(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out) {
+    if (!c || !n_out) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    std::vector<fa_row5m> rows;
+    uint32_t lo, hi;
+    int rc = window_rows(c, timeslot, rows, lo, hi);
+    if (rc) return rc;
+    *n_out = rows.size();
+    if (rows.size() > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
+    if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(fa_row5m));
+    if (lo == hi) return FA_OK;
+    // remove what no later window needs: everything for tumbling windows / close-all,
+    // only the oldest sub-bucket when windows slide over sub-buckets.
+    uint32_t rm_hi = (timeslot != 0xFFFFFFFFu && c->gran != c->cfg.window_secs) ? lo + 1 : hi;
+    return rebuild_table(c, c->cap_log2, lo, rm_hi);
+}
+
+extern "C" int fa_open_timeslots(fa_ctx* c, uint32_t* out, size_t cap, size_t* n_out) {
+    if (!c || !n_out) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    std::vector<fa_row5m> rows;
+    int rc = collect_rows(c, 0, 0xFFFFFFFFu, rows);
+    if (rc) return rc;
+    std::vector<uint32_t> ts;
+    ts.reserve(rows.size());
+    for (auto& r : rows) ts.push_back(r.timeslot);
+    std::sort(ts.begin(), ts.end());
+    ts.erase(std::unique(ts.begin(), ts.end()), ts.end());
+    *n_out = ts.size();
+    if (ts.size() > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
+    if (!ts.empty()) memcpy(out, ts.data(), ts.size() * 4);
+    return FA_OK;
+}
+
+extern "C" int fa_merge_rows(fa_ctx* c, const fa_row5m* rows, size_t n) {
+    if (!c || (!rows && n)) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    if (!n) return FA_OK;
+    for (size_t i = 0; i < n; i++)
+        if (rows[i].timeslot % c->gran) return fail(c, FA_ERR_ARG, "fa_merge_rows: timeslot not on this ctx's bucket grid");
+    Row5m* d = nullptr;
+    if (hipMalloc(&d, n * sizeof(Row5m)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc failed");
+    hipError_t e = hipMemcpyAsync(d, rows, n * sizeof(Row5m), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        KArgs a = make_args(c);
+        hipLaunchKernelGGL(merge_rows_kernel, dim3(256), dim3(256), 0, c->stream, d, (uint32_t)n, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        c->err = std::string("fa_merge_rows: ") + hipGetErrorString(e);
+        return FA_ERR_HIP;
+    }
+    return settle(c);
+}
+
+// ---- sketches -----------------------------------------------------------------------------------
+static unsigned long long* cms_of(fa_ctx* c, uint32_t key_set) {
+    if (key_set == FA_KEYS_SRCADDR_CMS) return c->cms_src;
+    if (key_set == FA_KEYS_DSTADDR_CMS) return c->cms_dst;
+    return nullptr;
+}
+
+extern "C" int fa_cms_read(fa_ctx* c, uint32_t key_set, uint64_t* out, size_t cap_words) {
+    if (!c || !out) return FA_ERR_ARG;
+    unsigned long long* p = cms_of(c, key_set);
+    if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
+    if (cap_words < c->cms_words) return fail(c, FA_ERR_CAPACITY, "sketch buffer too small");
+    int rc = settle(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(out, p, c->cms_words * 8, hipMemcpyDeviceToHost));
+    return FA_OK;
+}
+
+extern "C" int fa_cms_reset(fa_ctx* c, uint32_t key_set) {
+    if (!c) return FA_ERR_ARG;
+    unsigned long long* p = cms_of(c, key_set);
+    if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
+    HIPCHK(c, hipMemsetAsync(p, 0, c->cms_words * 8, c->stream));
+    return FA_OK;
+}
+
+static uint64_t cms_hash_host(const uint8_t key[16], uint64_t seed, uint32_t row) {
+    uint64_t lo, hi;
+    memcpy(&lo, key, 8);
+    memcpy(&hi, key + 8, 8);
+    uint64_t h = mix64(lo ^ mix64(seed + 0x9E3779B97F4A7C15ull * (row + 1)));
+    return mix64(h ^ hi);
+}
+
+extern "C" int fa_cms_query(fa_ctx* c, uint32_t key_set, const uint8_t key[16], uint64_t* weight) {
+    if (!c || !key || !weight) return FA_ERR_ARG;
+    unsigned long long* p = cms_of(c, key_set);
+    if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
+    int rc = settle(c);
+    if (rc) return rc;
+    uint64_t best = ~0ull;
+    for (uint32_t r = 0; r < c->cfg.cms_depth; r++) {
+        size_t idx = ((size_t)r << c->cfg.cms_width_log2) + (size_t)(cms_hash_host(key, c->cfg.cms_seed, r) >> (64 - c->cfg.cms_width_log2));
+        unsigned long long v;
+        HIPCHK(c, hipMemcpy(&v, p + idx, 8, hipMemcpyDeviceToHost));
+        best = std::min<uint64_t>(best, v);
+    }
+    *weight = best;
+    return FA_OK;
+}
+
+extern "C" int fa_topk(fa_ctx* c, uint32_t, size_t, fa_topk_row*, size_t, size_t*) {
+    return fail(c, FA_ERR_UNSUPPORTED, "fa_topk: candidate tracking lands with BASELINE config 3 (DESIGN.md, next)");
+}
+
+extern "C" int fa_device_state_get(fa_ctx* c, fa_device_state* out) {
+    if (!c || !out) return FA_ERR_ARG;
+    int rc = settle(c);
+    if (rc) return rc;
+    out->cms_src = c->cms_src;
+    out->cms_dst = c->cms_dst;
+    out->cms_words = c->cms_words;
+    return FA_OK;
+}
+
+// RCCL is bound lazily so that libflowagg.so loads on hosts without librccl.
+#include <dlfcn.h>
+extern "C" int fa_merge_allreduce(fa_ctx* c, void* comm) {
+    if (!c || !comm) return FA_ERR_ARG;
+    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static allreduce_fn fn = nullptr;
+    if (!fn) {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (h) fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+        if (!fn) return fail(c, FA_ERR_UNSUPPORTED, "librccl.so / ncclAllReduce not found");
+    }
+    int rc = settle(c);
+    if (rc) return rc;
+    const int ncclUint64 = 5, ncclSum = 0;  // rccl.h: ncclDataType_t / ncclRedOp_t
+    if (c->cms_src && fn(c->cms_src, c->cms_src, c->cms_words, ncclUint64, ncclSum, comm, c->stream) != 0)
+        return fail(c, FA_ERR_HIP, "ncclAllReduce(cms_src) failed");
+    if (c->cms_dst && fn(c->cms_dst, c->cms_dst, c->cms_words, ncclUint64, ncclSum, comm, c->stream) != 0)
+        return fail(c, FA_ERR_HIP, "ncclAllReduce(cms_dst) failed");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FA_OK;
+}
+
+extern "C" int fa_stats(fa_ctx* c, fa_stats_t* out) {
+    if (!c || !out) return FA_ERR_ARG;
+    int rc = settle(c);
+    *out = c->stats;
+    return rc;
+}
+
+// ---- synthetic producer ------------------------------------------------------------------------
+extern "C" int fa_mock_generate_device(fa_ctx* c, const fa_mock_params* g, uint64_t i0, uint64_t n, void* d_buf,
+                                       size_t cap, void* d_off, uint64_t* bytes_out) {
+    if (!c || !g || !d_buf || !d_off || n == 0 || n >= (1ull << 31)) return FA_ERR_ARG;
+    uint32_t* off = (uint32_t*)d_off;
+    uint32_t* len = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    HIPCHK(c, hipMalloc(&len, (n + 1) * sizeof(uint32_t)));
+    int rc = FA_OK;
+    do {
+        hipLaunchKernelGGL(gen_len_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, *g, i0, (uint32_t)n, len);
+        if (hipMemsetAsync(len + n, 0, 4, c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, len, off, (int)(n + 1), c->stream);
+        if (hipMalloc(&tmp, tmp_bytes) != hipSuccess) { rc = FA_ERR_NOMEM; break; }
+        if (hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, len, off, (int)(n + 1), c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
+        uint32_t total = 0;
+        if (hipMemcpyAsync(&total, off + n, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
+        if ((size_t)total + 32 > cap) { rc = FA_ERR_CAPACITY; if (bytes_out) *bytes_out = total; break; }
+        hipLaunchKernelGGL(gen_write_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, *g, i0, (uint32_t)n, off, (uint8_t*)d_buf);
+        if (hipMemsetAsync((uint8_t*)d_buf + total, 0, 32, c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
+        if (bytes_out) *bytes_out = total;
+    } while (0);
+    (void)hipFree(len);
+    (void)hipFree(tmp);
+    if (rc == FA_ERR_HIP) c->err = std::string("fa_mock_generate_device: ") + hipGetErrorString(hipGetLastError());
+    if (rc == FA_ERR_CAPACITY) c->err = "fa_mock_generate_device: buffer too small (needs bytes + 32 slack)";
+    return rc;
+}
+
+extern "C" int fa_mock_generate_host(const fa_mock_params* g, uint64_t i0, uint64_t n, uint8_t* buf, size_t cap,
+                                     uint64_t* offsets, uint64_t* bytes_out) {
+    if (!g || !buf) return FA_ERR_ARG;
+    size_t pos = 0;
+    uint8_t tmp[208];
+    for (uint64_t k = 0; k < n; k++) {
+        uint32_t l = gen_encode(*g, i0 + k, tmp);
+        if (pos + l > cap) return FA_ERR_CAPACITY;
+        memcpy(buf + pos, tmp, l);
+        if (offsets) offsets[k] = pos;
+        pos += l;
+    }
+    if (offsets) offsets[n] = pos;
+    if (bytes_out) *bytes_out = pos;
+    return FA_OK;
+}

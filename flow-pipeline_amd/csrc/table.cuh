@@ -1,0 +1,203 @@
+// table.cuh - flows_5m group-by state: open-addressed hash tables (gfx950).
+//
+// Replaces the ClickHouse aggregation of flows_5m_view
+// (compose/clickhouse/create.sh:92-110: GROUP BY Date, Timeslot, SrcAS, DstAS,
+// EType -> sum(Bytes), sum(Packets), count()) and the SummingMergeTree collapse
+// of partial rows (create.sh:70-90).  u64 wrap-around adds commute, so any
+// update order gives bit-identical sums.
+//
+// Key packing (lock-free two-word claim, no sentinel collisions):
+//   tb   = TimeReceived(u32) / granule      (granule >= 60 -> tb < 2^27)
+//   k0   = 1<<63 | (DstAS & 0x7fffffff) << 32 | SrcAS
+//   k1   = 1<<63 | (DstAS >> 31) << 59 | tb << 32 | EType
+// Both words always have bit 63 set, so 0 is a safe EMPTY for each.  A slot is
+// claimed word by word with 64-bit CAS (k0 then k1); a word is written once and
+// never changes, so a slot always ends up holding a real key, probing is
+// lock-free, and a (possibly stale) plain read can only ever show EMPTY or the
+// final value - never a false match.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+struct __attribute__((aligned(64))) Slot {
+    unsigned long long k0, k1;
+    unsigned long long bytes, packets, count;
+    unsigned long long pad[3];
+};
+static_assert(sizeof(Slot) == 64, "one slot per 64-byte line");
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xbf58476d1ce4e5b9ull;
+    z ^= z >> 27;
+    z *= 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return z;
+}
+
+__host__ __device__ __forceinline__ void pack_key(uint32_t tb, uint32_t src_as, uint32_t dst_as,
+                                                  uint32_t etype, uint64_t& k0, uint64_t& k1) {
+    k0 = (1ull << 63) | ((uint64_t)(dst_as & 0x7fffffffu) << 32) | src_as;
+    k1 = (1ull << 63) | ((uint64_t)(dst_as >> 31) << 59) | ((uint64_t)(tb & 0x7ffffffu) << 32) | etype;
+}
+__host__ __device__ __forceinline__ void unpack_key(uint64_t k0, uint64_t k1, uint32_t& tb,
+                                                    uint32_t& src_as, uint32_t& dst_as,
+                                                    uint32_t& etype) {
+    src_as = (uint32_t)k0;
+    dst_as = (uint32_t)((k0 >> 32) & 0x7fffffffu) | ((uint32_t)((k1 >> 59) & 1) << 31);
+    tb = (uint32_t)((k1 >> 32) & 0x7ffffffu);
+    etype = (uint32_t)k1;
+}
+__host__ __device__ __forceinline__ uint64_t key_hash(uint64_t k0, uint64_t k1) {
+    return mix64(k0 ^ mix64(k1));
+}
+
+#define FA_MAX_PROBES 128
+
+// Upsert into the device-wide table.  Returns false on overflow (probe limit).
+__device__ __forceinline__ bool table_upsert(Slot* tab, uint32_t mask, uint64_t k0, uint64_t k1,
+                                             uint64_t h, uint64_t bytes, uint64_t packets,
+                                             uint64_t count) {
+    uint32_t i = (uint32_t)h & mask;
+    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i + 1) & mask) {
+        Slot* s = &tab[i];
+        unsigned long long c0 = s->k0;  // may be stale-EMPTY; never a wrong non-empty value
+        if (c0 == 0) c0 = atomicCAS(&s->k0, 0ull, (unsigned long long)k0);
+        if (c0 != 0 && c0 != k0) continue;
+        unsigned long long c1 = s->k1;
+        if (c1 == 0) c1 = atomicCAS(&s->k1, 0ull, (unsigned long long)k1);
+        if (c1 != 0 && c1 != k1) continue;
+        if (bytes) atomicAdd(&s->bytes, (unsigned long long)bytes);
+        if (packets) atomicAdd(&s->packets, (unsigned long long)packets);
+        atomicAdd(&s->count, (unsigned long long)count);
+        return true;
+    }
+    return false;
+}
+
+// ---- per-workgroup LDS pre-aggregation table --------------------------------
+// Absorbs hot keys (mocker mode has 9 groups, mocker.go:61-62) before they reach
+// the device-wide table.  SoA in LDS; same two-word claim protocol with ds CAS.
+template <int SLOTS>
+struct LdsTable {
+    unsigned long long k0[SLOTS], k1[SLOTS], bytes[SLOTS], packets[SLOTS], count[SLOTS];
+};
+
+template <int SLOTS>
+__device__ __forceinline__ void lds_table_clear(LdsTable<SLOTS>& t) {
+    for (int i = threadIdx.x; i < SLOTS; i += blockDim.x) {
+        t.k0[i] = 0;
+        t.k1[i] = 0;
+        t.bytes[i] = 0;
+        t.packets[i] = 0;
+        t.count[i] = 0;
+    }
+}
+
+// Returns true if absorbed; false -> caller goes to the device-wide table.
+template <int SLOTS, int PROBES>
+__device__ __forceinline__ bool lds_table_add(LdsTable<SLOTS>& t, uint64_t k0, uint64_t k1, uint64_t h,
+                                              uint64_t bytes, uint64_t packets, uint64_t count) {
+    uint32_t i = (uint32_t)(h >> 32) & (SLOTS - 1);
+#pragma unroll 1
+    for (int probe = 0; probe < PROBES; probe++, i = (i + 1) & (SLOTS - 1)) {
+        unsigned long long c0 = t.k0[i];
+        if (c0 == 0) c0 = atomicCAS(&t.k0[i], 0ull, (unsigned long long)k0);
+        if (c0 != 0 && c0 != k0) continue;
+        unsigned long long c1 = t.k1[i];
+        if (c1 == 0) c1 = atomicCAS(&t.k1[i], 0ull, (unsigned long long)k1);
+        if (c1 != 0 && c1 != k1) continue;
+        if (bytes) atomicAdd(&t.bytes[i], (unsigned long long)bytes);
+        if (packets) atomicAdd(&t.packets[i], (unsigned long long)packets);
+        atomicAdd(&t.count[i], (unsigned long long)count);
+        return true;
+    }
+    return false;
+}
+
+// Flush every occupied LDS slot into the device-wide table; counts overflows.
+template <int SLOTS>
+__device__ __forceinline__ uint32_t lds_table_flush(LdsTable<SLOTS>& t, Slot* tab, uint32_t mask) {
+    uint32_t ovf = 0;
+    for (int i = threadIdx.x; i < SLOTS; i += blockDim.x) {
+        unsigned long long k0 = t.k0[i], k1 = t.k1[i], c = t.count[i];
+        if (k0 != 0 && k1 != 0 && c != 0) {
+            if (!table_upsert(tab, mask, k0, k1, key_hash(k0, k1), t.bytes[i], t.packets[i], c)) ovf++;
+        }
+    }
+    return ovf;
+}
+
+// ---- wavefront helpers -------------------------------------------------------
+// 64-lane sum of a u64 with DPP row shifts inside each 16-lane row and scalar
+// readlane across the four rows (wave64; no LDS traffic).
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_shr_u64(uint64_t v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    // bound_ctrl = true: lanes shifted in from outside the row read 0
+    lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, true);
+    hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true);
+    return (uint64_t)hi << 32 | lo;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+    v += dpp_shr_u64<0x111>(v);  // row_shr:1
+    v += dpp_shr_u64<0x112>(v);  // row_shr:2
+    v += dpp_shr_u64<0x114>(v);  // row_shr:4
+    v += dpp_shr_u64<0x118>(v);  // row_shr:8  -> lane 15 of every row holds the row sum
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    uint64_t tot = 0;
+#pragma unroll
+    for (int row = 0; row < 4; row++) {
+        uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lo, row * 16 + 15);
+        uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hi, row * 16 + 15);
+        tot += (uint64_t)h << 32 | l;
+    }
+    return tot;  // wave-uniform
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+    uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return (uint64_t)h << 32 | l;
+}
+
+// Wave-level duplicate combining before the tables are touched: lanes holding
+// the same key are folded into their lowest lane (leader).  Stops as soon as two
+// consecutive leaders have fewer than MIN_GROUP followers, so high-cardinality
+// batches pay ~2 rounds and 9-group mocker batches collapse to 9 updates/wave.
+template <int MAX_ROUNDS, int MIN_GROUP>
+__device__ __forceinline__ void wave_combine(bool& valid, uint64_t k0, uint64_t k1, uint64_t& bytes,
+                                             uint64_t& packets, uint64_t& count) {
+    uint64_t todo = __ballot(valid);
+    int small = 0;
+    const int lane = __lane_id();
+#pragma unroll 1
+    for (int round = 0; round < MAX_ROUNDS && todo != 0 && small < 2; round++) {
+        int leader = __builtin_ctzll(todo);
+        uint64_t l0 = readlane_u64(k0, leader), l1 = readlane_u64(k1, leader);
+        bool match = valid && ((todo >> lane) & 1) && k0 == l0 && k1 == l1;
+        uint64_t mm = __ballot(match);
+        todo &= ~mm;
+        int n = __builtin_popcountll(mm);
+        if (n < MIN_GROUP) {
+            small++;
+            continue;
+        }
+        small = 0;
+        uint64_t sb = wave_sum_u64(match ? bytes : 0);
+        uint64_t sp = wave_sum_u64(match ? packets : 0);
+        uint64_t sc = wave_sum_u64(match ? count : 0);
+        if (match) {
+            if (lane == leader) {
+                bytes = sb;
+                packets = sp;
+                count = sc;
+            } else {
+                valid = false;
+            }
+        }
+    }
+}
+
+}  // namespace fa

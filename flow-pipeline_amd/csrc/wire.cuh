@@ -1,0 +1,304 @@
+// wire.cuh - device-side proto3 FlowMessage parsers (gfx950).
+//
+// What is parsed: the record type of pb-ext/flow.proto:7-65 (and the 67-field
+// superset of pb-ext/flow.pb.go:57-147, whose extra fields are skipped by wire
+// type), projected onto the 15 ClickHouse `flows` columns
+// (compose/clickhouse/create.sh:7-27).  Decode semantics are the proto3 rules
+// listed in SURVEY.md Appendix A.2 (what proto.Unmarshal does at
+// inserter/inserter.go:122-126).
+//
+// Two tiers:
+//   parse_fast<>    - one record per lane, reads the record through 8-byte
+//                     sliding windows built from aligned dword loads (LDS tile
+//                     or global memory).  Handles every field whose tag is <= 2
+//                     bytes and whose varint is <= 6 bytes (values < 2^42), LEN /
+//                     fixed32 / fixed64 skips and <=16-byte address payloads.  It
+//                     only ever answers "decoded exactly" or "not sure".
+//   parse_generic   - byte-at-a-time parser with the complete semantics (10-byte
+//                     varints, 5-byte tags, groups with a 100-deep stack, every
+//                     error rule).  It is the single source of truth for "bad
+//                     record"; records parse_fast is not sure about are deferred
+//                     to a second kernel that runs it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fa {
+
+// Column selection bitmask (what a kernel variant needs; the rest is dead code).
+enum : uint32_t {
+    COL_TIME_RECEIVED = 1u << 0,
+    COL_TIME_FLOW_START = 1u << 1,
+    COL_SEQUENCE_NUM = 1u << 2,
+    COL_SAMPLING_RATE = 1u << 3,
+    COL_SAMPLER_ADDRESS = 1u << 4,
+    COL_SRC_ADDR = 1u << 5,
+    COL_DST_ADDR = 1u << 6,
+    COL_SRC_AS = 1u << 7,
+    COL_DST_AS = 1u << 8,
+    COL_ETYPE = 1u << 9,
+    COL_PROTO = 1u << 10,
+    COL_SRC_PORT = 1u << 11,
+    COL_DST_PORT = 1u << 12,
+    COL_BYTES = 1u << 13,
+    COL_PACKETS = 1u << 14,
+    COL_ALL = (1u << 15) - 1,
+    COLS_AS_ROLLUP = COL_TIME_RECEIVED | COL_SRC_AS | COL_DST_AS | COL_ETYPE | COL_BYTES | COL_PACKETS,
+};
+
+struct Rec {
+    uint64_t time_received, time_flow_start, sampling_rate, bytes, packets;
+    uint32_t sequence_num, src_as, dst_as, etype, proto, src_port, dst_port;
+    uint32_t sampler[4], src[4], dst[4];  // FixedString(16), little-endian dwords
+};
+
+__device__ __forceinline__ void rec_clear(Rec& r) {
+    r.time_received = r.time_flow_start = r.sampling_rate = r.bytes = r.packets = 0;
+    r.sequence_num = r.src_as = r.dst_as = r.etype = r.proto = r.src_port = r.dst_port = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.sampler[i] = r.src[i] = r.dst[i] = 0;
+}
+
+// ---- byte sources ---------------------------------------------------------
+struct LdsSrc {
+    const uint32_t* base;  // LDS, dword aligned
+    __device__ __forceinline__ uint32_t dw(uint32_t i) const { return base[i]; }
+};
+struct GlobalSrc {
+    const uint32_t* base;  // global, dword aligned
+    __device__ __forceinline__ uint32_t dw(uint32_t i) const { return base[i]; }
+};
+
+// 8 bytes starting at byte offset pos (little endian), from aligned dwords.
+template <class Src>
+__device__ __forceinline__ uint64_t window64(const Src& s, uint32_t pos) {
+    uint32_t i = pos >> 2, sh = pos & 3;
+    uint32_t d0 = s.dw(i), d1 = s.dw(i + 1), d2 = s.dw(i + 2);
+    uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return (uint64_t)hi << 32 | lo;
+}
+
+// Varint of 1..6 bytes sitting in the low bytes of v.  Returns false when the
+// stop byte is not within 6 bytes.  *len = encoded length, *val = value (< 2^42).
+__device__ __forceinline__ bool varint6(uint64_t v, uint32_t& len, uint64_t& val) {
+    uint64_t m = ~v & 0x0000808080808080ull;
+    if (m == 0) return false;
+    uint32_t stop = (uint32_t)__builtin_ctzll(m);  // 7,15,...,47
+    len = (stop >> 3) + 1;
+    uint64_t x = v & ((2ull << stop) - 1);
+    uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    xl = ((xl & 0x7f007f00u) >> 1) | (xl & 0x007f007fu);
+    xl = ((xl & 0x3fff0000u) >> 2) | (xl & 0x00003fffu);
+    xh = ((xh & 0x00007f00u) >> 1) | (xh & 0x0000007fu);
+    val = (uint64_t)xl | ((uint64_t)xh << 28);
+    return true;
+}
+
+// Up to 16 payload bytes at byte offset pos, zero padded beyond len (<= 16).
+template <class Src>
+__device__ __forceinline__ void load_fixed16(const Src& s, uint32_t pos, uint32_t len, uint32_t out[4]) {
+    uint32_t i = pos >> 2, sh = pos & 3;
+    uint32_t d0 = s.dw(i), d1 = s.dw(i + 1), d2 = s.dw(i + 2), d3 = s.dw(i + 3), d4 = s.dw(i + 4);
+    uint32_t w[4];
+    w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int rem = (int)len - 4 * k;  // bytes of this dword that belong to the value
+        uint32_t mask = rem >= 4 ? 0xffffffffu : rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u);
+        out[k] = w[k] & mask;
+    }
+}
+
+// Fast parser.  [pos,end) are byte offsets of the bare payload inside src.
+// Returns true iff the record was decoded exactly; false = defer to parse_generic.
+template <uint32_t COLS, class Src>
+__device__ __forceinline__ bool parse_fast(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
+    while (pos < end) {
+        uint64_t w = window64(s, pos);
+        uint32_t b0 = (uint32_t)w & 0xff;
+        uint32_t tag, tl;
+        if (!(b0 & 0x80)) {
+            tag = b0;
+            tl = 1;
+        } else if (!((uint32_t)w & 0x8000)) {
+            tag = (b0 & 0x7f) | (((uint32_t)w >> 1) & 0x3f80);
+            tl = 2;
+        } else {
+            return false;  // tag of 3+ bytes (field >= 2048)
+        }
+        uint32_t field = tag >> 3, wt = tag & 7;
+        if (field == 0) return false;
+        uint64_t v = w >> (8 * tl);  // >= 6 valid bytes after the tag
+        uint32_t vl;
+        uint64_t val;
+        if (wt == 0) {
+            if (!varint6(v, vl, val)) return false;
+            pos += tl + vl;
+            if (pos > end) return false;
+            switch (field) {
+            case 2: if (COLS & COL_TIME_RECEIVED) r.time_received = val; break;
+            case 3: if (COLS & COL_SAMPLING_RATE) r.sampling_rate = val; break;
+            case 4: if (COLS & COL_SEQUENCE_NUM) r.sequence_num = (uint32_t)val; break;
+            case 9: if (COLS & COL_BYTES) r.bytes = val; break;
+            case 10: if (COLS & COL_PACKETS) r.packets = val; break;
+            case 14: if (COLS & COL_SRC_AS) r.src_as = (uint32_t)val; break;
+            case 15: if (COLS & COL_DST_AS) r.dst_as = (uint32_t)val; break;
+            case 20: if (COLS & COL_PROTO) r.proto = (uint32_t)val; break;
+            case 21: if (COLS & COL_SRC_PORT) r.src_port = (uint32_t)val; break;
+            case 22: if (COLS & COL_DST_PORT) r.dst_port = (uint32_t)val; break;
+            case 30: if (COLS & COL_ETYPE) r.etype = (uint32_t)val; break;
+            case 38: if (COLS & COL_TIME_FLOW_START) r.time_flow_start = val; break;
+            default: break;
+            }
+        } else if (wt == 2) {
+            if (!varint6(v, vl, val)) return false;
+            if (vl > 5) return false;  // size is a varint32
+            pos += tl + vl;
+            if (pos > end || val > (uint64_t)(end - pos)) return false;
+            uint32_t sz = (uint32_t)val;
+            if (field == 6 || field == 7 || field == 11) {
+                if (sz > 16) return false;  // FixedString(16) overflow: generic path rules
+                if (field == 6) {
+                    if (COLS & COL_SRC_ADDR) load_fixed16(s, pos, sz, r.src);
+                } else if (field == 7) {
+                    if (COLS & COL_DST_ADDR) load_fixed16(s, pos, sz, r.dst);
+                } else {
+                    if (COLS & COL_SAMPLER_ADDRESS) load_fixed16(s, pos, sz, r.sampler);
+                }
+            }
+            pos += sz;
+        } else if (wt == 1) {
+            pos += tl + 8;
+            if (pos > end) return false;
+        } else if (wt == 5) {
+            pos += tl + 4;
+            if (pos > end) return false;
+        } else {
+            return false;  // groups, wire types 6/7
+        }
+    }
+    return true;
+}
+
+// ---- generic parser (complete semantics) -----------------------------------
+struct ByteRd {
+    const uint8_t* p;
+    const uint8_t* end;
+};
+
+__device__ inline bool g_varint(ByteRd& r, int max_bytes, uint64_t& out) {
+    uint64_t v = 0;
+    for (int i = 0; i < max_bytes; i++) {
+        if (r.p >= r.end) return false;
+        uint32_t b = *r.p++;
+        if (i < 9)
+            v |= (uint64_t)(b & 0x7f) << (7 * i);
+        else
+            v |= (uint64_t)(b & 1) << 63;
+        if (!(b & 0x80)) {
+            out = v;
+            return true;
+        }
+    }
+    return false;
+}
+
+#define FA_MAX_GROUP_DEPTH 100
+
+// Returns true = record OK (r filled), false = malformed.
+__device__ __noinline__ bool parse_generic(const uint8_t* p, const uint8_t* end, Rec& r) {
+    uint32_t stack[FA_MAX_GROUP_DEPTH];
+    int depth = 0;
+    ByteRd rd{p, end};
+    rec_clear(r);
+    while (rd.p < rd.end) {
+        uint64_t t;
+        if (!g_varint(rd, 5, t)) return false;
+        if (t > 0xFFFFFFFFull) return false;
+        uint32_t field = (uint32_t)(t >> 3), wt = (uint32_t)(t & 7);
+        if (depth == 0 && field == 0) return false;
+        uint64_t v;
+        switch (wt) {
+        case 0:
+            if (!g_varint(rd, 10, v)) return false;
+            if (depth == 0) {
+                switch (field) {
+                case 2: r.time_received = v; break;
+                case 3: r.sampling_rate = v; break;
+                case 4: r.sequence_num = (uint32_t)v; break;
+                case 9: r.bytes = v; break;
+                case 10: r.packets = v; break;
+                case 14: r.src_as = (uint32_t)v; break;
+                case 15: r.dst_as = (uint32_t)v; break;
+                case 20: r.proto = (uint32_t)v; break;
+                case 21: r.src_port = (uint32_t)v; break;
+                case 22: r.dst_port = (uint32_t)v; break;
+                case 30: r.etype = (uint32_t)v; break;
+                case 38: r.time_flow_start = v; break;
+                default: break;
+                }
+            }
+            break;
+        case 1:
+            if (rd.end - rd.p < 8) return false;
+            rd.p += 8;
+            break;
+        case 5:
+            if (rd.end - rd.p < 4) return false;
+            rd.p += 4;
+            break;
+        case 2: {
+            if (!g_varint(rd, 5, v)) return false;
+            if (v > 0x7FFFFFFFull || v > (uint64_t)(rd.end - rd.p)) return false;
+            if (depth == 0 && (field == 6 || field == 7 || field == 11)) {
+                if (v > 16) return false;
+                uint32_t* dst = field == 6 ? r.src : field == 7 ? r.dst : r.sampler;
+                uint8_t tmp[16];
+                for (int i = 0; i < 16; i++) tmp[i] = i < (int)v ? rd.p[i] : 0;
+                for (int k = 0; k < 4; k++)
+                    dst[k] = (uint32_t)tmp[4 * k] | (uint32_t)tmp[4 * k + 1] << 8 |
+                             (uint32_t)tmp[4 * k + 2] << 16 | (uint32_t)tmp[4 * k + 3] << 24;
+            }
+            rd.p += v;
+            break;
+        }
+        case 3:
+            if (depth >= FA_MAX_GROUP_DEPTH) return false;
+            stack[depth++] = field;
+            break;
+        case 4:
+            if (depth == 0) return false;
+            if (stack[--depth] != field) return false;
+            break;
+        default: return false;
+        }
+    }
+    return depth == 0;
+}
+
+// Strip the frame prefix of a framed record: varint(len) || payload with
+// len == remaining bytes (mocker.go:98-106: one record per Kafka message).
+// Fast form on a window; returns false when not sure.
+__device__ __forceinline__ bool frame_fast(uint64_t w, uint32_t rec_len, uint32_t& prefix_len) {
+    uint32_t vl;
+    uint64_t val;
+    if (!varint6(w, vl, val)) return false;
+    if (vl > rec_len || val != (uint64_t)(rec_len - vl)) return false;
+    prefix_len = vl;
+    return true;
+}
+
+__device__ inline bool frame_generic(const uint8_t*& p, const uint8_t* end) {
+    ByteRd rd{p, end};
+    uint64_t len;
+    if (!g_varint(rd, 10, len)) return false;
+    if (len != (uint64_t)(rd.end - rd.p)) return false;
+    p = rd.p;
+    return true;
+}
+
+}  // namespace fa

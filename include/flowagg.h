@@ -1,0 +1,208 @@
+/*
+ * flowagg.h - C-ABI of libflowagg: the MI355X (gfx950) flow-aggregation stage.
+ *
+ * The reference (cloudflare/flow-pipeline) has no plugin/FFI interface; this ABI
+ * is what a Go Kafka consumer binds through cgo to replace the
+ * ClickHouse path `flows -> flows_raw -> flows_5m`
+ * (compose/clickhouse/create.sh:5-110) while keeping the inserter's shape
+ * (inserter/inserter.go:113-196: buffer -> flush -> sink).
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in signatures; device pointers travel as
+ *    `const void*` / `void*` and are documented as such;
+ *  - every function returns 0 (FA_OK) or a negative fa_status; text via
+ *    fa_last_error();
+ *  - the library never keeps a caller pointer after a call returns (cgo rule):
+ *    fa_ingest copies into library-owned pinned staging before returning;
+ *  - one fa_ctx per (Kafka partition, GPU).  A ctx is not thread-safe; distinct
+ *    ctxs are independent (sarama runs one ConsumeClaim goroutine per claimed
+ *    partition, inserter.go:176);
+ *  - malformed records are counted and dropped, never fatal
+ *    (inserter.go:125-126); sink/resource errors are returned (the reference
+ *    log.Fatal()s on them, inserter.go:102-105);
+ *  - there is NO CPU fallback: without a HIP device fa_create fails.
+ */
+#ifndef FLOWAGG_H
+#define FLOWAGG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_ABI_VERSION 1
+
+typedef struct fa_ctx fa_ctx;
+
+typedef enum {
+    FA_OK = 0,
+    FA_ERR_ARG = -1,        /* bad argument */
+    FA_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime error at create */
+    FA_ERR_HIP = -3,        /* HIP runtime error (text in fa_last_error) */
+    FA_ERR_NOMEM = -4,
+    FA_ERR_TABLE_FULL = -5, /* group-by table overflow: rows were NOT lost, the
+                               call failed as a whole; recreate with a larger table */
+    FA_ERR_CAPACITY = -6,   /* caller's output buffer too small; *n_out = required */
+    FA_ERR_FRAMING = -7,    /* offsets==NULL and the stream is not a chain of framed records */
+    FA_ERR_UNSUPPORTED = -8
+} fa_status;
+
+/* key_sets bitmask */
+enum {
+    FA_KEYS_AS_PAIR = 1u,     /* flows_5m: (Date,Timeslot,SrcAS,DstAS,EType) - create.sh:92-110 */
+    FA_KEYS_SRCADDR_CMS = 2u, /* Count-Min sketch over SrcAddr, weight Bytes*SamplingRate (viz-ch.json:233) */
+    FA_KEYS_DSTADDR_CMS = 4u  /* same over DstAddr (viz-ch.json:479) */
+};
+
+typedef struct {
+    int32_t device;               /* HIP device ordinal */
+    uint32_t window_secs;         /* 300 = toStartOfFiveMinute (create.sh:96); must divide 86400 */
+    uint32_t subwindow_secs;      /* 0, or a divisor of window_secs (60 = toStartOfMinute, viz-ch.json:74):
+                                     rows are kept per sub-bucket so sliding windows can be formed */
+    uint32_t table_capacity_log2; /* slots of the device group-by table (64 B each); 0 -> 20 */
+    uint32_t cms_depth;           /* 0 -> 4 */
+    uint32_t cms_width_log2;      /* 0 -> 20 */
+    uint64_t cms_seed;
+    uint32_t key_sets;            /* 0 -> FA_KEYS_AS_PAIR */
+    int32_t framed;               /* 1: each record is varint(len)||payload (-proto.fixedlen=true,
+                                     mocker.go:98-101); 0: bare payload (mocker.go:96-97) */
+    uint32_t max_batch_records;   /* upper bound on n per ingest call; 0 -> 1<<24 */
+    uint32_t reserved[5];
+} fa_config;
+
+/* One flows_5m row, scalar columns (create.sh:70-90). */
+typedef struct {
+    uint32_t date;     /* toDate(TimeReceived), days since 1970-01-01 UTC (create.sh:66) */
+    uint32_t timeslot; /* start of the (sub)window, seconds (create.sh:96) */
+    uint32_t src_as, dst_as, etype, _pad;
+    uint64_t bytes, packets, count; /* sum(Bytes), sum(Packets), count() - wrap mod 2^64 */
+} fa_row5m;
+
+/* One row of the `flows` table (create.sh:7-27): the 15 projected columns. */
+typedef struct {
+    uint64_t time_received, time_flow_start, sampling_rate, bytes, packets;
+    uint32_t sequence_num, src_as, dst_as, etype, proto, src_port, dst_port;
+    uint32_t status; /* 0 = ok, 1 = malformed record (all other members 0) */
+    uint8_t sampler_address[16], src_addr[16], dst_addr[16]; /* FixedString(16) */
+} fa_flow_row;
+
+/* Device-resident struct-of-arrays projection (the flows_raw analogue in HBM).
+ * Every member is a DEVICE pointer to an array of n elements, owned by the ctx
+ * and valid until the next fa_decode_device / fa_destroy on that ctx. */
+typedef struct {
+    const uint64_t *time_received, *time_flow_start, *sampling_rate, *bytes, *packets;
+    const uint32_t *sequence_num, *src_as, *dst_as, *etype, *proto, *src_port, *dst_port;
+    const uint8_t *sampler_address, *src_addr, *dst_addr; /* 16 B per record */
+    const uint8_t* status;                                /* 0 ok, 1 malformed */
+} fa_columns;
+
+typedef struct {
+    uint64_t records_ok;     /* decoded and aggregated */
+    uint64_t records_bad;    /* malformed, dropped (inserter.go:125-126) */
+    uint64_t records_slow;   /* handled by the generic (non-LDS) device parser */
+    uint64_t bytes_in;       /* wire bytes ingested */
+    uint64_t batches;
+    uint64_t table_used;     /* occupied group-by slots */
+    uint64_t table_capacity;
+    uint64_t kernel_ns;        /* device time of the last ingest kernel launch (hipEvent) */
+    uint64_t kernel_ns_total;  /* summed over every ingest kernel launch */
+    uint64_t kernel_launches;
+} fa_stats_t;
+
+typedef struct {
+    uint8_t key[16]; /* FixedString(16) address */
+    uint64_t weight; /* Count-Min estimate of sum(Bytes*SamplingRate) (>= exact) */
+} fa_topk_row;
+
+uint32_t fa_abi_version(void);
+
+int fa_create(const fa_config* cfg, fa_ctx** out);
+void fa_destroy(fa_ctx*);
+const char* fa_last_error(const fa_ctx*); /* ctx may be NULL: last create error */
+
+/* ---- ingest: decode + project + aggregate (the hot path) ---------------- */
+/* Host buffers.  buf[0..len) holds n records back to back; offsets (n+1
+ * entries, offsets[n]==len) delimit them - one Kafka message value each
+ * (mocker.go:103-106).  offsets may be NULL when cfg.framed: the stream is then
+ * split on the host by walking the varint length prefixes. */
+int fa_ingest(fa_ctx*, const uint8_t* buf, size_t len, const uint64_t* offsets, size_t n);
+
+/* Device-resident buffers (inputs already in HBM).  d_buf: DEVICE pointer to
+ * len bytes, 16-byte aligned, followed by >= 32 readable slack bytes; d_offsets: DEVICE pointer to
+ * n+1 uint32 offsets relative to d_buf (so len < 4 GiB per call).  Asynchronous
+ * on the ctx stream; fa_sync() or any result call waits. */
+int fa_ingest_device(fa_ctx*, const void* d_buf, size_t len, const void* d_offsets, size_t n);
+
+int fa_sync(fa_ctx*);
+
+/* ---- decode + project only (flows / flows_raw columns) ------------------- */
+int fa_decode(fa_ctx*, const uint8_t* buf, size_t len, const uint64_t* offsets, size_t n,
+              fa_flow_row* out_rows /* host, n entries */);
+int fa_decode_device(fa_ctx*, const void* d_buf, size_t len, const void* d_offsets, size_t n,
+                     fa_columns* out);
+
+/* ---- window close: emit flows_5m rows ------------------------------------ */
+/* Lists the distinct timeslots currently held, ascending. */
+int fa_open_timeslots(fa_ctx*, uint32_t* out, size_t cap, size_t* n_out);
+/* Emits the rows of `timeslot` (0xFFFFFFFF = every row) sorted by
+ * (date,timeslot,src_as,dst_as,etype) and removes them from the device table.
+ * FA_ERR_CAPACITY (nothing removed) if cap is too small; *n_out = rows needed. */
+int fa_close_window(fa_ctx*, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out);
+/* Same, without removing (peek). */
+int fa_read_window(fa_ctx*, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out);
+
+/* ---- heavy hitters -------------------------------------------------------- */
+/* key_set: FA_KEYS_SRCADDR_CMS or FA_KEYS_DSTADDR_CMS.  Rows sorted by weight
+ * descending, ties by key ascending. */
+int fa_topk(fa_ctx*, uint32_t key_set, size_t k, fa_topk_row* out, size_t cap, size_t* n_out);
+int fa_cms_query(fa_ctx*, uint32_t key_set, const uint8_t key[16], uint64_t* weight);
+/* Copies the raw sketch (depth * 2^width_log2 uint64) to host. */
+int fa_cms_read(fa_ctx*, uint32_t key_set, uint64_t* out, size_t cap_words);
+int fa_cms_reset(fa_ctx*, uint32_t key_set);
+
+/* ---- multi-GPU merge at window close (one ctx per GPU / Kafka partition) --- */
+/* Exposes the device-resident mergeable state so the host can run collectives
+ * on it (RCCL all-reduce for the dense sketches).  DEVICE pointers. */
+typedef struct {
+    void* cms_src;      /* depth*2^width_log2 uint64, or NULL */
+    void* cms_dst;
+    size_t cms_words;
+} fa_device_state;
+int fa_device_state_get(fa_ctx*, fa_device_state* out);
+/* Adds partial rows produced by another ctx/rank (e.g. gathered over RCCL)
+ * into this ctx's table: sum is a commutative monoid, so the merged table
+ * equals the single-shard table bit for bit. */
+int fa_merge_rows(fa_ctx*, const fa_row5m* rows, size_t n);
+/* In-library RCCL path: comm is an `ncclComm_t`; all-reduces (sum, uint64) the
+ * sketches in place on the ctx stream. */
+int fa_merge_allreduce(fa_ctx*, void* rccl_comm);
+
+int fa_stats(fa_ctx*, fa_stats_t* out);
+
+/* ---- synthetic producer (mocker/mocker.go:57-106 distribution) ------------ */
+enum { FA_MOCK_MOCKER = 0, FA_MOCK_ASPAIRS = 1, FA_MOCK_ZIPF = 2 };
+typedef struct {
+    uint32_t mode;
+    uint32_t framed;    /* -proto.fixedlen */
+    uint64_t seed;
+    uint64_t n_total;
+    uint64_t t0;
+    uint32_t span_secs;
+    uint32_t per_sec;
+    uint32_t zipf_log2_universe;
+    uint32_t zipf_s_x100;
+} fa_mock_params;
+/* Generates records [i0,i0+n) straight into HBM.  d_buf: DEVICE buffer of cap
+ * bytes (needs 32 B slack beyond the bytes written); d_offsets: DEVICE n+1
+ * uint32.  *bytes_out = bytes written.  Synchronous. */
+int fa_mock_generate_device(fa_ctx*, const fa_mock_params*, uint64_t i0, uint64_t n, void* d_buf,
+                            size_t cap, void* d_offsets, uint64_t* bytes_out);
+/* Host-side twin (same bytes), for feeding fa_ingest. */
+int fa_mock_generate_host(const fa_mock_params*, uint64_t i0, uint64_t n, uint8_t* buf, size_t cap,
+                          uint64_t* offsets, uint64_t* bytes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

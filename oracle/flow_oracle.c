@@ -162,6 +162,23 @@ int fo_decode_framed(const uint8_t* p, size_t n, fo_row* out) {
     return fo_decode(r.p, (size_t)len, out);
 }
 
+uint64_t fo_decode_batch(const uint8_t* buf, const uint64_t* off, size_t n, int framed, fo_row* rows,
+                         uint32_t* status) {
+    uint64_t bad = 0;
+    for (size_t k = 0; k < n; k++) {
+        const uint8_t* p = buf + off[k];
+        size_t len = (size_t)(off[k + 1] - off[k]);
+        memset(&rows[k], 0, sizeof rows[k]);
+        int rc = framed ? fo_decode_framed(p, len, &rows[k]) : fo_decode(p, len, &rows[k]);
+        status[k] = rc == FO_OK ? 0 : 1;
+        if (rc != FO_OK) {
+            memset(&rows[k], 0, sizeof rows[k]);
+            bad++;
+        }
+    }
+    return bad;
+}
+
 size_t fo_frame_split(const uint8_t* buf, size_t len, uint64_t* offsets, size_t cap) {
     rd r = {buf, buf + len};
     size_t n = 0;

@@ -71,6 +71,11 @@ int fo_decode(const uint8_t* p, size_t n, fo_row* out);
  * varint(len) || payload with len == remaining bytes (mocker.go:98-106). */
 int fo_decode_framed(const uint8_t* p, size_t n, fo_row* out);
 
+/* Decode n records delimited by offsets[n+1]; rows[k] is zeroed and status[k]=1
+ * for a bad record.  Returns the number of bad records. */
+uint64_t fo_decode_batch(const uint8_t* buf, const uint64_t* offsets, size_t n, int framed,
+                         fo_row* rows, uint32_t* status);
+
 /* Split a concatenated stream of framed records into offsets (n+1 entries).
  * Returns the number of records, or (size_t)-1 if the stream is malformed /
  * cap too small.  offsets[k] is the start of record k's length prefix. */

@@ -84,6 +84,8 @@ def lib():
     L.fo_decode.restype = C.c_int
     L.fo_decode_framed.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(FoRow)]
     L.fo_decode_framed.restype = C.c_int
+    L.fo_decode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    L.fo_decode_batch.restype = C.c_uint64
     L.fo_frame_split.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     L.fo_frame_split.restype = C.c_size_t
     L.fo_rollup_new.argtypes = [C.c_uint32]
@@ -121,6 +123,17 @@ def decode(payload: bytes, framed=False):
     f = lib().fo_decode_framed if framed else lib().fo_decode
     rc = f(payload, len(payload), C.byref(row))
     return row.as_dict() if rc == 0 else None
+
+
+def decode_batch(buf: np.ndarray, off: np.ndarray, framed=0):
+    """-> (rows ROW_DTYPE[n], status uint32[n]); bad records are zeroed with status 1."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    off = np.ascontiguousarray(off, dtype=np.uint64)
+    n = len(off) - 1
+    rows = np.zeros(n, dtype=ROW_DTYPE)
+    status = np.zeros(n, dtype=np.uint32)
+    lib().fo_decode_batch(buf.ctypes.data, off.ctypes.data, n, framed, rows.ctypes.data, status.ctypes.data)
+    return rows, status
 
 
 def gen_params(mode=GEN_MOCKER, framed=1, seed=1, n_total=0, t0=T0, span_secs=900, per_sec=4,

@@ -1,0 +1,271 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the
+same seeded inputs.  Bit-exact everywhere (integer / byte work)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+COLS = ["time_received", "time_flow_start", "sampling_rate", "bytes", "packets", "sequence_num",
+        "src_as", "dst_as", "etype", "proto", "src_port", "dst_port", "sampler_address",
+        "src_addr", "dst_addr"]
+
+
+def oracle_rows(po, buf, off, framed):
+    """Decode every record with the oracle -> (structured array, status array)."""
+    return po.decode_batch(buf, off, framed)
+
+
+def assert_decode_equal(got, want, wstatus):
+    assert np.array_equal(got["status"], wstatus), np.nonzero(got["status"] != wstatus)[0][:10]
+    for c in COLS:
+        assert np.array_equal(got[c], want[c]), (c, np.nonzero(got[c] != want[c])[0][:10])
+
+
+def concat(records):
+    off = np.zeros(len(records) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in records])
+    return np.frombuffer(b"".join(records), dtype=np.uint8), off
+
+
+@pytest.mark.parametrize("mode,framed", [(0, 1), (0, 0), (1, 1), (1, 0), (2, 1)])
+def test_decode_matches_oracle(gpu_lib, fa, po, mode, framed):
+    n = 30000
+    gp = po.gen_params(mode=mode, framed=framed, seed=5 + mode, n_total=n)
+    buf, off = po.gen_records(gp, 0, n)
+    want, wstatus = oracle_rows(po, buf, off, framed)
+    assert wstatus.sum() == 0
+    # the generator's own truth table agrees too
+    truth = po.gen_rows(gp, 0, 64)
+    for c in COLS:
+        assert np.array_equal(truth[c], want[c][:64]), c
+    with fa.FlowAgg(framed=bool(framed)) as agg:
+        got = agg.decode(buf, off)
+    assert_decode_equal(got, want, wstatus)
+
+
+def test_edge_cases_golden(gpu_lib, fa, po):
+    """SURVEY Appendix A.2 + upb-pinned edge vectors: every record, bare and framed."""
+    cases = json.load(open(os.path.join(GOLDEN, "edge_cases.json")))["cases"]
+    recs = [bytes.fromhex(c["hex"]) for c in cases]
+    for framed in (0, 1):
+        rr = [fa.schema.frame(r) for r in recs] if framed else recs
+        buf, off = concat(rr)
+        with fa.FlowAgg(framed=bool(framed)) as agg:
+            got = agg.decode(buf, off)
+        for k, c in enumerate(cases):
+            if c["expect"] is None:
+                assert got["status"][k] == 1, (c["name"], "should be a bad record")
+                continue
+            assert got["status"][k] == 0, (c["name"], "should decode")
+            e = c["expect"]
+            assert int(got["time_received"][k]) == e["TimeReceived"], c["name"]
+            assert int(got["src_as"][k]) == e["SrcAS"], c["name"]
+            assert int(got["dst_as"][k]) == e["DstAS"], c["name"]
+            assert int(got["bytes"][k]) == e["Bytes"], c["name"]
+            assert int(got["packets"][k]) == e["Packets"], c["name"]
+            assert int(got["etype"][k]) == e["EType"], c["name"]
+            assert bytes(got["src_addr"][k]).hex() == e["SrcAddr"], c["name"]
+            assert bytes(got["dst_addr"][k]).hex() == e["DstAddr"], c["name"]
+            assert bytes(got["sampler_address"][k]).hex() == e["SamplerAddress"], c["name"]
+            for col, key in (("time_flow_start", "TimeFlowStart"), ("sequence_num", "SequenceNum"),
+                             ("sampling_rate", "SamplingRate"), ("proto", "Proto"),
+                             ("src_port", "SrcPort"), ("dst_port", "DstPort")):
+                assert int(got[col][k]) == e[key], (c["name"], key)
+
+
+def test_fuzzed_records_match_oracle(gpu_lib, fa, po):
+    """Mutation-fuzzed records (committed fixture): decode + status identical to the oracle."""
+    blob = np.load(os.path.join(GOLDEN, "fuzz_records.npz"))
+    buf, off = blob["buf"], blob["off"]
+    want, wstatus = oracle_rows(po, buf, off, 0)
+    assert 0 < wstatus.sum() < len(wstatus)
+    with fa.FlowAgg(framed=False) as agg:
+        got = agg.decode(buf, off)
+    assert_decode_equal(got, want, wstatus)
+    # and the expectations recorded from upb when the fixture was made
+    assert np.array_equal(wstatus, blob["upb_status"])
+
+
+@pytest.mark.parametrize("mode,n,per_sec", [(0, 10000, 4), (0, 200000, 300), (1, 300000, 0), (2, 100000, 0)])
+def test_rollup_matches_oracle(gpu_lib, fa, po, mode, n, per_sec):
+    gp = po.gen_params(mode=mode, framed=1, seed=21 + mode, n_total=n, per_sec=per_sec or 4)
+    buf, off = po.gen_records(gp, 0, n)
+    ref = po.Rollup(300)
+    assert ref.ingest(buf, off, 1) == 0
+    want = ref.rows()
+    with fa.FlowAgg(framed=True, table_capacity_log2=16) as agg:  # small table: exercises growth
+        agg.ingest(buf, off)
+        got = agg.read_window()
+        st = agg.stats()
+        assert st["records_ok"] == n and st["records_bad"] == 0
+        assert got.tobytes() == want.tobytes()
+        # per-window close returns the same rows and empties the table
+        slots = agg.open_timeslots()
+        assert list(slots) == sorted(set(want["timeslot"]))
+        parts = [agg.close_window(int(ts)) for ts in slots]
+        assert np.concatenate(parts).tobytes() == want.tobytes()
+        assert len(agg.read_window()) == 0
+
+
+def test_rollup_config1_bare_9_groups(gpu_lib, fa, po):
+    """BASELINE config 1 shape: 10k bare mocker records -> 9 (SrcAS,DstAS) groups."""
+    n = 10000
+    gp = po.gen_params(mode=0, framed=0, seed=1, n_total=n, per_sec=4)
+    buf, off = po.gen_records(gp, 0, n)
+    with fa.FlowAgg(framed=False) as agg:
+        agg.ingest(buf, off)
+        rows = agg.read_window()
+    pairs = {}
+    for r in rows:
+        k = (int(r["src_as"]), int(r["dst_as"]))
+        b, p, c = pairs.get(k, (0, 0, 0))
+        pairs[k] = (b + int(r["bytes"]), p + int(r["packets"]), c + int(r["count"]))
+    assert len(pairs) == 9
+    assert sum(v[2] for v in pairs.values()) == n
+    truth = po.gen_rows(gp, 0, n)
+    assert sum(v[0] for v in pairs.values()) == int(truth["bytes"].sum())
+    assert sum(v[1] for v in pairs.values()) == int(truth["packets"].sum())
+
+
+def test_rollup_with_bad_and_exotic_records(gpu_lib, fa, po):
+    """Malformed records are counted and dropped (inserter.go:125-126); exotic but valid
+    encodings (groups, 10-byte varints, long tags) take the generic device parser."""
+    blob = np.load(os.path.join(GOLDEN, "fuzz_records.npz"))
+    buf, off = blob["buf"], blob["off"]
+    ref = po.Rollup(300)
+    bad = ref.ingest(buf, off, 0)
+    with fa.FlowAgg(framed=False) as agg:
+        agg.ingest(buf, off)
+        got = agg.read_window()
+        st = agg.stats()
+    assert st["records_bad"] == bad
+    assert st["records_ok"] == len(off) - 1 - bad
+    assert st["records_slow"] >= bad
+    assert got.tobytes() == ref.rows().tobytes()
+
+
+def test_stream_without_offsets(gpu_lib, fa, po):
+    """offsets=NULL: the framed stream is split on the host by the varint prefixes."""
+    n = 5000
+    gp = po.gen_params(mode=1, framed=1, seed=9, n_total=n)
+    buf, off = po.gen_records(gp, 0, n)
+    ref = po.Rollup(300)
+    ref.ingest(buf, off, 1)
+    with fa.FlowAgg(framed=True) as agg:
+        agg.ingest(buf, None)
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+
+
+def test_large_records_beyond_lds_tile(gpu_lib, fa, po):
+    """Records bigger than the 32 KiB LDS tile (huge unknown LEN field) and tiles whose
+    256 records do not fit one pass."""
+    big_unknown = fa.schema.encode_varint((1000 << 3) | 2) + fa.schema.encode_varint(40000) + b"\xab" * 40000
+    mid_unknown = fa.schema.encode_varint((1001 << 3) | 2) + fa.schema.encode_varint(300) + b"\xcd" * 300
+    gp = po.gen_params(mode=1, framed=0, seed=33, n_total=2000)
+    buf, off = po.gen_records(gp, 0, 2000)
+    raw = bytes(buf)
+    recs = []
+    for k in range(2000):
+        r = raw[int(off[k]):int(off[k + 1])]
+        if k % 500 == 7:
+            r = big_unknown + r
+        elif k % 3 == 0:
+            r = r + mid_unknown
+        recs.append(fa.schema.frame(r))
+    b2, o2 = concat(recs)
+    ref = po.Rollup(300)
+    assert ref.ingest(b2, o2, 1) == 0
+    with fa.FlowAgg(framed=True) as agg:
+        agg.ingest(b2, o2)
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+        assert agg.stats()["records_ok"] == 2000
+
+
+def test_device_generator_matches_oracle(gpu_lib, fa, po):
+    import torch
+    for mode, framed in [(0, 1), (1, 1), (2, 1), (0, 0)]:
+        n = 50000
+        gp = po.gen_params(mode=mode, framed=framed, seed=77, n_total=n, per_sec=7)
+        want_buf, want_off = po.gen_records(gp, 1234, n)
+        mp = fa.mock_params(mode=mode, framed=framed, seed=77, n_total=n, per_sec=7)
+        d_buf = torch.empty(n * 96 + 256, dtype=torch.uint8, device="cuda")
+        d_off = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        with fa.FlowAgg(framed=bool(framed)) as agg:
+            w = agg.mock_generate_device(mp, 1234, n, d_buf.data_ptr(), d_buf.numel(), d_off.data_ptr())
+        assert w == len(want_buf)
+        assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), want_off)
+        assert np.array_equal(d_buf[:w].cpu().numpy(), want_buf)
+        hb, ho = fa.mock_generate_host(mp, 1234, n)
+        assert np.array_equal(hb, want_buf) and np.array_equal(ho, want_off)
+
+
+def test_cms_matches_oracle(gpu_lib, fa, po):
+    n = 60000
+    gp = po.gen_params(mode=2, framed=1, seed=3, n_total=n, zipf_log2_universe=16)
+    buf, off = po.gen_records(gp, 0, n)
+    truth = po.gen_rows(gp, 0, n)
+    depth, wl2, seed = 4, 12, 0xC0FFEE
+    want_src = np.zeros(depth << wl2, dtype=np.uint64)
+    want_dst = np.zeros(depth << wl2, dtype=np.uint64)
+    for k in range(n):
+        w = (int(truth["bytes"][k]) * int(truth["sampling_rate"][k])) & (2**64 - 1)
+        po.cms_update(want_src, depth, wl2, seed, bytes(truth["src_addr"][k]), w)
+        po.cms_update(want_dst, depth, wl2, seed, bytes(truth["dst_addr"][k]), w)
+    ks = fa.FA_KEYS_AS_PAIR | fa.FA_KEYS_SRCADDR_CMS | fa.FA_KEYS_DSTADDR_CMS
+    with fa.FlowAgg(framed=True, key_sets=ks, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed) as agg:
+        agg.ingest(buf, off)
+        got_src = agg.cms_read(fa.FA_KEYS_SRCADDR_CMS).reshape(-1)
+        got_dst = agg.cms_read(fa.FA_KEYS_DSTADDR_CMS).reshape(-1)
+        key = bytes(truth["src_addr"][0])
+        assert agg.cms_query(fa.FA_KEYS_SRCADDR_CMS, key) == po.cms_query(want_src, depth, wl2, seed, key)
+        ref = po.Rollup(300)
+        ref.ingest(buf, off, 1)
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+    assert np.array_equal(got_src, want_src)
+    assert np.array_equal(got_dst, want_dst)
+
+
+def test_merge_rows_equals_single_shard(gpu_lib, fa, po):
+    """Partition i mod P -> P contexts; merging their rows == the single-shard result."""
+    n, P = 80000, 4
+    gp = po.gen_params(mode=1, framed=1, seed=8, n_total=n)
+    buf, off = po.gen_records(gp, 0, n)
+    raw = bytes(buf)
+    recs = [raw[int(off[k]):int(off[k + 1])] for k in range(n)]
+    ref = po.Rollup(300)
+    ref.ingest(buf, off, 1)
+    with fa.FlowAgg(framed=True) as total:
+        for p in range(P):
+            b, o = concat(recs[p::P])
+            with fa.FlowAgg(framed=True) as shard:
+                shard.ingest(b, o)
+                total.merge_rows(shard.read_window())
+        assert total.read_window().tobytes() == ref.rows().tobytes()
+
+
+def test_sliding_subwindows(gpu_lib, fa, po):
+    """60 s sub-buckets: any 5-minute window starting on a minute boundary equals the
+    oracle's rollup of exactly those records (tumbling windows are the reference's case)."""
+    n = 120000
+    gp = po.gen_params(mode=1, framed=1, seed=12, n_total=n, span_secs=900)
+    buf, off = po.gen_records(gp, 0, n)
+    truth = po.gen_rows(gp, 0, n)
+    raw = bytes(buf)
+    with fa.FlowAgg(framed=True, window_secs=300, subwindow_secs=60) as agg:
+        agg.ingest(buf, off)
+        for start in (po.T0, po.T0 + 60, po.T0 + 420):
+            sel = np.nonzero((truth["time_received"] >= start) & (truth["time_received"] < start + 300))[0]
+            ref = po.Rollup(86400)  # one bucket: everything selected falls in one "window"
+            b, o = concat([raw[int(off[k]):int(off[k + 1])] for k in sel])
+            ref.ingest(b, o, 1)
+            want = ref.rows()
+            got = agg.read_window(start)
+            assert len(got) == len(want)
+            for col in ("src_as", "dst_as", "etype", "bytes", "packets", "count"):
+                assert np.array_equal(got[col], want[col]), col
+            assert (got["timeslot"] == start).all()

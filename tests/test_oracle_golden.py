@@ -1,0 +1,179 @@
+"""CPU tests: the oracle against the committed golden fixtures (upb-pinned), against
+live upb when the protobuf wheel is importable, and its own invariants."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_edge_cases(po):
+    cases = json.load(open(os.path.join(GOLDEN, "edge_cases.json")))["cases"]
+    assert len(cases) >= 60
+    for c in cases:
+        got = po.decode(bytes.fromhex(c["hex"]))
+        want = c["expect"]
+        if want is None:
+            assert got is None, c["name"]
+            continue
+        assert got is not None, c["name"]
+        for k, v in want.items():
+            g = got[k].hex() if isinstance(got[k], bytes) else got[k]
+            assert g == v, (c["name"], k, g, v)
+
+
+def test_kat1_flows_5m_contribution(po):
+    """key and contribution to flows_5m."""
+    cases = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "edge_cases.json")))["cases"]}
+    rec = bytes.fromhex(cases["KAT-1 all mocker fields"]["hex"])
+    framed = bytes([len(rec)]) + rec
+    assert framed[0] == 0x52
+    r = po.Rollup(300)
+    assert r.ingest(np.frombuffer(framed, dtype=np.uint8), np.array([0, len(framed)], dtype=np.uint64), 1) == 0
+    rows = r.rows()
+    assert len(rows) == 1
+    row = rows[0]
+    assert (row["date"], row["timeslot"], row["src_as"], row["dst_as"], row["etype"]) == (
+        19987, 1726899900, 65002, 65001, 34525)
+    assert (row["bytes"], row["packets"], row["count"]) == (1499, 99, 1)
+
+
+def test_fuzz_fixture_matches_upb(po):
+    z = np.load(os.path.join(GOLDEN, "fuzz_records.npz"))
+    rows, status = po.decode_batch(z["buf"], z["off"], 0)
+    assert np.array_equal(status, z["upb_status"])
+    assert status.sum() > 1000
+    colmap = {"time_received": "upb_TimeReceived", "time_flow_start": "upb_TimeFlowStart",
+              "sequence_num": "upb_SequenceNum", "sampling_rate": "upb_SamplingRate",
+              "src_as": "upb_SrcAS", "dst_as": "upb_DstAS", "etype": "upb_EType", "proto": "upb_Proto",
+              "src_port": "upb_SrcPort", "dst_port": "upb_DstPort", "bytes": "upb_Bytes",
+              "packets": "upb_Packets", "sampler_address": "upb_SamplerAddress",
+              "src_addr": "upb_SrcAddr", "dst_addr": "upb_DstAddr"}
+    for c, u in colmap.items():
+        assert np.array_equal(rows[c].astype(np.uint64) if rows[c].ndim == 1 else rows[c], z[u]), c
+    # the single-record entry point agrees with the batch one
+    raw = bytes(z["buf"])
+    for k in range(0, len(status), 97):
+        d = po.decode(raw[int(z["off"][k]):int(z["off"][k + 1])])
+        assert (d is None) == bool(status[k])
+
+
+def test_rollup_fixture(po):
+    fx = json.load(open(os.path.join(GOLDEN, "rollup_2000.json")))
+    recs = [bytes.fromhex(h) for h in fx["records_hex"]]
+    off = np.zeros(len(recs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in recs])
+    r = po.Rollup(300)
+    assert r.ingest(np.frombuffer(b"".join(recs), dtype=np.uint8), off, 0) == 0
+    rows = r.rows()
+    got = [[int(x[f]) for f in ("date", "timeslot", "src_as", "dst_as", "etype", "bytes", "packets", "count")]
+           for x in rows]
+    assert got == fx["rows"]
+    assert sum(x[7] for x in got) == len(recs)
+
+
+def test_live_upb_cross_check(po, fa):
+    pytest.importorskip("google.protobuf")
+    L = fa.schema.message_class("full")
+    rng = random.Random(99)
+    for i in range(500):
+        m = L()
+        m.TimeReceived = rng.randrange(2**34)
+        m.Bytes = rng.randrange(2**64)
+        m.Packets = rng.randrange(2**20)
+        m.SrcAS = rng.randrange(2**32)
+        m.DstAS = rng.randrange(2**32)
+        m.Etype = rng.choice([0x0800, 0x86DD, 0])
+        m.SrcAddr = bytes(rng.randrange(256) for _ in range(rng.choice([0, 4, 16])))
+        m.MPLS1Label = rng.randrange(2**20)
+        m.DstCountry = "FR"
+        d = po.decode(m.SerializeToString())
+        assert d["TimeReceived"] == m.TimeReceived and d["Bytes"] == m.Bytes
+        assert d["SrcAS"] == m.SrcAS and d["DstAS"] == m.DstAS and d["EType"] == m.Etype
+        assert d["SrcAddr"] == m.SrcAddr + b"\0" * (16 - len(m.SrcAddr))
+        assert d["Packets"] == m.Packets
+
+
+def test_generator_roundtrip_and_mocker_distribution(po):
+    """mocker.go:57-91: value ranges, 9 AS pairs, field set; decode(generate(i)) == truth(i)."""
+    n = 20000
+    for mode in (po.GEN_MOCKER, po.GEN_ASPAIRS, po.GEN_ZIPF):
+        for framed in (0, 1):
+            gp = po.gen_params(mode=mode, framed=framed, seed=4, n_total=n)
+            buf, off = po.gen_records(gp, 0, 2000)
+            truth = po.gen_rows(gp, 0, 2000)
+            raw = bytes(buf)
+            for k in range(2000):
+                d = po.decode(raw[int(off[k]):int(off[k + 1])], framed=bool(framed))
+                assert d is not None
+                assert d["TimeReceived"] == truth["time_received"][k]
+                assert d["Bytes"] == truth["bytes"][k] and d["Packets"] == truth["packets"][k]
+                assert d["SrcAddr"] == bytes(truth["src_addr"][k])
+                assert d["DstPort"] == truth["dst_port"][k]
+    gp = po.gen_params(mode=po.GEN_MOCKER, framed=1, seed=1, n_total=n, per_sec=4)
+    t = po.gen_rows(gp, 0, n)
+    assert t["bytes"].max() < 1500 and t["packets"].max() < 100
+    assert set(t["src_as"]) == {65000, 65001, 65002} and set(t["dst_as"]) == {65000, 65001, 65002}
+    assert (t["etype"] == 0x86DD).all() and (t["sampling_rate"] == 1).all()
+    assert (t["src_addr"][:, :15] == np.array([0x20, 1, 0x0d, 0xb8, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0])).all()
+    assert t["time_received"][0] == po.T0 and t["time_received"][n - 1] == po.T0 + (n - 1) // 4
+    lens = np.diff(po.gen_records(gp, 0, n)[1].astype(np.int64))
+    assert 64 <= lens.min() and lens.max() <= 85 and 82.5 < lens.mean() < 84.5
+
+
+def test_aspairs_config2_shape(po):
+    n = 400000
+    gp = po.gen_params(mode=po.GEN_ASPAIRS, framed=1, seed=2, n_total=n)
+    buf, off = po.gen_records(gp, 0, n)
+    r = po.Rollup(300)
+    assert r.ingest(buf, off, 1) == 0
+    rows = r.rows()
+    assert set(rows["timeslot"]) == {po.T0, po.T0 + 300, po.T0 + 600}
+    assert set(rows["etype"]) == {0x0800, 0x86DD}
+    assert rows["count"].sum() == n
+    assert 65000 < len({(a, b) for a, b in zip(rows["src_as"], rows["dst_as"])}) <= 65536
+
+
+def test_frame_split(po):
+    gp = po.gen_params(mode=po.GEN_MOCKER, framed=1, seed=6, n_total=100)
+    buf, off = po.gen_records(gp, 0, 100)
+    out = np.zeros(102, dtype=np.uint64)
+    n = po.lib().fo_frame_split(buf.ctypes.data, buf.size, out.ctypes.data, out.size)
+    assert n == 100 and np.array_equal(out[:101], off)
+    assert po.lib().fo_frame_split(buf.ctypes.data, buf.size - 1, out.ctypes.data, out.size) == 2**64 - 1
+
+
+def test_rollup_merge_is_shard_invariant(po):
+    """Kafka partitions are the shard unit; the merged rollup equals the single-shard one."""
+    n = 50000
+    gp = po.gen_params(mode=po.GEN_ASPAIRS, framed=1, seed=10, n_total=n)
+    buf, off = po.gen_records(gp, 0, n)
+    whole = po.Rollup(300)
+    whole.ingest(buf, off, 1)
+    raw = bytes(buf)
+    total = po.Rollup(300)
+    for p in range(8):
+        recs = [raw[int(off[k]):int(off[k + 1])] for k in range(p, n, 8)]
+        o = np.zeros(len(recs) + 1, dtype=np.uint64)
+        o[1:] = np.cumsum([len(r) for r in recs])
+        part = po.Rollup(300)
+        part.ingest(np.frombuffer(b"".join(recs), dtype=np.uint8), o, 1)
+        total.merge(part)
+    assert total.rows().tobytes() == whole.rows().tobytes()
+
+
+def test_cms_overestimates_only(po):
+    depth, wl2, seed = 4, 10, 1
+    cms = np.zeros(depth << wl2, dtype=np.uint64)
+    rng = random.Random(3)
+    exact = {}
+    for _ in range(5000):
+        key = bytes([rng.randrange(40)] + [0] * 15)
+        w = rng.randrange(1000)
+        exact[key] = exact.get(key, 0) + w
+        po.cms_update(cms, depth, wl2, seed, key, w)
+    for k, v in exact.items():
+        assert po.cms_query(cms, depth, wl2, seed, k) >= v
