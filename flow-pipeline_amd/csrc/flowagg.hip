@@ -66,6 +66,7 @@ struct fa_ctx {
     std::string err;
     int sticky = 0;  // sticky error from async work
     int num_cus = 256;
+    uint32_t dbg = 0;
 };
 
 #define HIPCHK(ctx, expr)                                                                       \
@@ -102,19 +103,33 @@ static KArgs make_args(fa_ctx* c) {
     a.cms_wl2 = c->cfg.cms_width_log2;
     a.cms_seed = c->cfg.cms_seed;
     a.cols = c->cols;
+    a.dbg = c->dbg;
+    a.tile_recs = BLOCK;
     return a;
 }
 
 // Persistent grid: exactly the number of workgroups that are co-resident
 // (CUs x LDS/VGPR-limited workgroups per CU); tiles are grid-strided.
 template <class K>
-static int grid_for(fa_ctx* c, K kernel, uint32_t n) {
-    uint32_t tiles = (n + BLOCK - 1) / BLOCK;
+static int grid_for(fa_ctx* c, K kernel, uint32_t n, uint32_t tile_recs) {
+    uint32_t tiles = (n + tile_recs - 1) / tile_recs;
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1)
         per_cu = 2;
     uint32_t g = (uint32_t)c->num_cus * (uint32_t)per_cu;
     return (int)std::max(1u, std::min(tiles, g));
+}
+
+// Records per LDS tile: as many as fit one tile buffer at the batch's mean record
+// size (one record per lane, at most BLOCK).  Tiles that still overflow (outliers)
+// take the multi-pass path inside the kernel.
+static uint32_t tile_recs_for(size_t len, size_t n) {
+    if (n == 0) return BLOCK;
+    double avg = (double)len / (double)n + 0.5;
+    double r = ((double)TILE_BYTES - 15.0) / avg;
+    if (r >= (double)BLOCK) return BLOCK;
+    if (r < 1.0) return 1;
+    return (uint32_t)r;
 }
 
 extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
@@ -147,6 +162,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     c->cfg = cfg;
     c->gran = gran;
     c->cap_log2 = cfg.table_capacity_log2;
+    if (const char* d = getenv("FA_DEBUG_FLAGS")) c->dbg = (uint32_t)strtoul(d, nullptr, 0);
     auto bail = [&](const char* what, hipError_t e) {
         g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
         fa_destroy(c);
@@ -301,7 +317,7 @@ static int launch_tiles(fa_ctx* c, const KArgs& a, hipEvent_t ev_start = nullptr
     dim3 ge(std::min(256u, (a.n + BLOCK - 1) / BLOCK));
 #define FA_LAUNCH(KS)                                                                           \
     case KS: {                                                                                  \
-        dim3 g(grid_for(c, tile_kernel<MODE, KS>, a.n));                                        \
+        dim3 g(grid_for(c, tile_kernel<MODE, KS>, a.n, a.tile_recs));                                        \
         if (ev_start) (void)hipEventRecord(ev_start, c->stream);                                \
         hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);                     \
         if (ev_stop) (void)hipEventRecord(ev_stop, c->stream);                                  \
@@ -346,6 +362,7 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     a.buf = (const uint8_t*)d_buf;
     a.off = (const uint32_t*)d_off;
     a.n = (uint32_t)n;
+    a.tile_recs = tile_recs_for(len, n);
     HIPCHK(c, hipMemsetAsync(&c->d_ctr->exotic_count, 0, sizeof(unsigned int), c->stream));
     if (c->ev_used == c->ev_pool.size()) {
         if (c->ev_pool.size() >= 4096) {  // bound the pool: fold what is pending
@@ -533,6 +550,7 @@ extern "C" int fa_decode_device(fa_ctx* c, const void* d_buf, size_t len, const 
         a.buf = (const uint8_t*)d_buf;
         a.off = (const uint32_t*)d_off;
         a.n = (uint32_t)n;
+        a.tile_recs = tile_recs_for(len, n);
         HIPCHK(c, hipMemsetAsync(&c->d_ctr->exotic_count, 0, sizeof(unsigned int), c->stream));
         rc = launch_tiles<MODE_DECODE>(c, a);
         if (rc) return rc;

@@ -1,7 +1,7 @@
 // kernels.cuh - the gfx950 kernels of libflowagg.
 //
 // Hot path (one launch per batch):  tile_kernel<MODE_INGEST,...>
-//   wire bytes in HBM --16 B/lane coalesced loads--> LDS tile (32 KiB)
+//   wire bytes in HBM --global_load_lds_dwordx4 (async DMA)--> LDS tile (21.25 KiB)
 //   -> one record per lane parsed out of LDS (wire.cuh, parse_fast)
 //   -> key = (TimeReceived/granule, SrcAS, DstAS, EType)   [create.sh:92-110]
 //   -> wave-level duplicate combining (DPP row shifts + readlane)
@@ -22,12 +22,16 @@
 namespace fa {
 
 constexpr int BLOCK = 256;
-constexpr int TILE_BYTES = 32768;  // staged wire bytes per workgroup pass
-constexpr int TILE_PAD = 64;       // readable slack behind the staged bytes
-constexpr int LDS_SLOTS = 512;     // per-workgroup pre-aggregation slots (20 KiB)
-constexpr int LDS_PROBES = 4;
+constexpr int TILE_BYTES = 21760;  // one LDS tile buffer: 256 records x 85 B (framed mocker records are <= 85)
+constexpr int TILE_PAD = 112;      // readable slack behind the staged bytes (window / address reads)
+constexpr int TILE_STRIDE = TILE_BYTES + TILE_PAD;
+constexpr int LDS_SLOTS = 128;     // per-workgroup pre-aggregation slots (5 KiB)
+constexpr int LDS_PROBES = 2;
+static_assert(TILE_STRIDE % 16 == 0, "LDS tile buffers must stay 16-byte aligned");
 
 enum { MODE_INGEST = 0, MODE_DECODE = 1 };
+// ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
+enum { DBG_NO_SINK = 1, DBG_NO_WAVE_COMBINE = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16 };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -62,6 +66,8 @@ struct KArgs {
     uint32_t cms_depth, cms_wl2;
     uint64_t cms_seed;
     ColumnPtrs cols;
+    uint32_t tile_recs;  // records per tile (<= BLOCK), chosen by the host from the mean record size
+    uint32_t dbg;  // FA_DEBUG_FLAGS ablation switches (0 in production)
 };
 
 // ---- sinks ------------------------------------------------------------------
@@ -136,102 +142,248 @@ constexpr uint32_t cols_for_keysets() {
     return c;
 }
 
+// ---- LDS DMA staging ------------------------------------------------------------
+// Copies nbytes (rounded up to 16) from 16-byte-aligned global memory into an LDS
+// buffer with `global_load_lds_dwordx4`: 1 KiB per wave-instruction, no VGPR round
+// trip, asynchronous (tracked by vmcnt).  Lanes past the end are masked off.
+__device__ __forceinline__ void dma_to_lds(const uint8_t* g, uint32_t nbytes, uint32_t* lds) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t npieces = (nbytes + 1023u) >> 10;
+    for (uint32_t p = wave; p < npieces; p += BLOCK / 64) {
+        const uint32_t o = p * 1024u + lane * 16u;
+        if (o < nbytes) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g + o),
+                (__attribute__((address_space(3))) void*)(lds + p * 256u), 16, 0, 0);
+        }
+    }
+}
+// vmcnt(0) through the builtin (not inline asm) so that the compiler's own waitcnt
+// scoreboard learns the DMA has landed and does not re-drain before LDS reads.
+__device__ __forceinline__ void dma_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+// ---- device-wide table probe ------------------------------------------------------
+// Finds or claims the slot of (k0,k1); returns nullptr when the probe limit is hit.
+__device__ __forceinline__ Slot* table_find_or_claim(const KArgs& a, uint64_t k0, uint64_t k1, uint64_t h) {
+    uint32_t i = (uint32_t)h & a.mask;
+    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i + 1) & a.mask) {
+        Slot* s = &a.tab[i];
+        const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(s);  // one 16-byte load: k0,k1
+        unsigned long long c0 = kk.x, c1 = kk.y;
+        if (c0 == k0 && c1 == k1) return s;  // common case: no atomics on the key words
+        if (c0 == 0) c0 = atomicCAS(&s->k0, 0ull, (unsigned long long)k0);
+        if (c0 != 0 && c0 != k0) continue;
+        if (c1 == 0) {
+            c1 = atomicCAS(&s->k1, 0ull, (unsigned long long)k1);
+            if (c1 == 0) atomicAdd(&a.ctr->used, 1ull);  // this lane created the group
+        }
+        if (c1 != 0 && c1 != k1) continue;
+        return s;
+    }
+    return nullptr;
+}
+
+// Broadcast lane Q of every quad to the 4 lanes of that quad (DPP quad_perm, VALU only).
+template <int Q>
+__device__ __forceinline__ uint64_t quad_bcast_u64(uint64_t v) {
+    constexpr int CTRL = Q | (Q << 2) | (Q << 4) | (Q << 6);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+    return (uint64_t)hi << 32 | lo;
+}
+
+// Quad-grouped atomics.  The memory side retires ~23.7 G atomic cache-line
+// transactions/s no matter how many lanes of one instruction hit the line
+// (tools/atomics_bench.hip), so the three sums of a slot are issued by three
+// adjacent lanes of ONE instruction: in round Q every quad works on the record of
+// its lane Q; lane w of the quad adds word w (bytes, packets, count).  One
+// transaction per record instead of three.  Must be called by the full wave.
+template <int Q>
+__device__ __forceinline__ void quad_round(uint64_t ptr, uint64_t b, uint64_t p, uint64_t c, uint32_t w) {
+    const uint64_t qp = quad_bcast_u64<Q>(ptr);
+    const uint64_t qb = quad_bcast_u64<Q>(b), qq = quad_bcast_u64<Q>(p), qc = quad_bcast_u64<Q>(c);
+    const uint64_t v = w == 0 ? qb : w == 1 ? qq : qc;
+    if (qp != 0 && w < 3 && v != 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(qp) + 2 + w, (unsigned long long)v);
+}
+__device__ __forceinline__ void quad_atomic_update(Slot* sp, uint64_t b, uint64_t p, uint64_t c) {
+    const uint64_t ptr = (uint64_t)sp;  // 0 = nothing to do for this lane
+    const uint32_t w = threadIdx.x & 3;
+    quad_round<0>(ptr, b, p, c, w);
+    quad_round<1>(ptr, b, p, c, w);
+    quad_round<2>(ptr, b, p, c, w);
+    quad_round<3>(ptr, b, p, c, w);
+}
+
+__device__ __forceinline__ void spill_park(const KArgs& a, uint64_t k0, uint64_t k1, uint64_t b, uint64_t p, uint64_t c) {
+    unsigned int j = atomicAdd(&a.ctr->spill_count, 1u);
+    if (j < a.spill_cap)
+        a.spill[j] = SpillEntry{k0, k1, b, p, c};
+    else
+        atomicAdd(&a.ctr->spill_lost, 1ull);
+}
+
+// ---- per-lane work on a staged record (called by every lane of the workgroup) ------
+template <int MODE, uint32_t KEYSETS, uint32_t COLS>
+__device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, const uint32_t* tile,
+                                          bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx,
+                                          uint32_t& n_ok) {
+    // ---- parse (divergent: only lanes that own a staged record) ----
+    bool sure = false;
+    Rec r;
+    rec_clear(r);
+    if (mine) {
+        LdsSrc src{tile};
+        sure = true;
+        if (a.framed) {
+            uint32_t pl = 0;
+            sure = frame_fast(window64(src, pos), end - pos, pl);
+            pos += pl;
+        }
+        if (sure && !(a.dbg & DBG_NO_PARSE)) sure = parse_fast<COLS>(src, pos, end, r);
+        if (!sure) {
+            unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
+            a.exotic_idx[j] = rec_idx;
+        }
+    }
+    // ---- sink (reconverged: the quad-grouped atomics need the whole wave) ----
+    if (MODE == MODE_DECODE) {
+        if (sure) store_columns(a.cols, rec_idx, r, 0);
+        return;
+    }
+    n_ok += sure ? 1 : 0;
+    if (a.dbg & DBG_NO_SINK) {
+        n_ok += (uint32_t)(r.time_received ^ r.bytes ^ r.packets ^ r.src_as ^ r.dst_as ^ r.etype) & 1;
+        return;
+    }
+    if (KEYSETS & FA_KEYS_AS_PAIR) {
+        const uint32_t t32 = (uint32_t)r.time_received;  // UInt64 -> DateTime (create.sh:39)
+        uint64_t k0, k1;
+        pack_key(t32 / a.gran, r.src_as, r.dst_as, r.etype, k0, k1);
+        const uint64_t h = key_hash(k0, k1);
+        const uint64_t b = r.bytes, p = r.packets, c = 1;
+        bool pending = sure;
+        if (pending && !(a.dbg & DBG_NO_LDS_TABLE)) pending = !lds_table_add<LDS_SLOTS, LDS_PROBES>(lt, k0, k1, h, b, p, c);
+        Slot* sp = nullptr;
+        if (pending && !(a.dbg & DBG_NO_GLOBAL)) {
+            sp = table_find_or_claim(a, k0, k1, h);
+            if (!sp) spill_park(a, k0, k1, b, p, c);
+        }
+        quad_atomic_update(sp, b, p, c);
+    }
+    if (sure && (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
+        const uint64_t w = r.bytes * r.sampling_rate;  // viz-ch.json:233 sum(Bytes*SamplingRate)
+        if (KEYSETS & FA_KEYS_SRCADDR_CMS) cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
+        if (KEYSETS & FA_KEYS_DSTADDR_CMS) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
+    }
+}
+
 // ---- the tile kernel ----------------------------------------------------------
+// Persistent workgroups; tile = 256 consecutive records (one per lane).  The wire
+// bytes of tile t+1 stream into the second LDS buffer (async DMA) while tile t is
+// parsed and aggregated, so the HBM latency hides behind the integer work.
+struct TileDesc {
+    uint32_t r0, nrec, lo, hi;  // records [r0,r0+nrec), wire bytes [lo,hi)
+    bool fits;                  // whole tile fits one LDS buffer (the normal case)
+};
+__device__ __forceinline__ TileDesc tile_desc(const KArgs& a, uint32_t t, uint32_t ntiles) {
+    TileDesc d{0, 0, 0, 0, false};
+    if (t < ntiles) {
+        d.r0 = t * a.tile_recs;
+        d.nrec = min(a.tile_recs, a.n - d.r0);
+        d.lo = a.off[d.r0];
+        d.hi = a.off[d.r0 + d.nrec];
+        d.fits = d.hi >= d.lo && (d.hi - (d.lo & ~15u)) <= (uint32_t)TILE_BYTES;
+    }
+    return d;
+}
+
+// Persistent workgroups; tile = up to 256 consecutive records (one per lane) staged
+// in ONE LDS buffer.  LDS bounds the number of records a CU can hold, and the parse
+// is a long dependent chain per record, so the LDS goes to as many co-resident
+// workgroups as possible (6 per CU = 6 waves/SIMD): while one workgroup waits for
+// its DMA, the others parse.  (A double-buffered variant with 3 workgroups/CU
+// staged at 4.0 TB/s but left the parse latency-bound at 3 waves/SIMD.)
 template <int MODE, uint32_t KEYSETS>
 __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     constexpr uint32_t COLS = MODE == MODE_DECODE ? (uint32_t)COL_ALL : cols_for_keysets<KEYSETS>();
-    __shared__ __attribute__((aligned(16))) uint32_t tile[(TILE_BYTES + TILE_PAD) / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[TILE_STRIDE / 4];
     __shared__ LdsTable<LDS_SLOTS> lt;
 
-    const int tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     if (MODE == MODE_INGEST && (KEYSETS & FA_KEYS_AS_PAIR)) lds_table_clear(lt);
-    __syncthreads();
 
     uint32_t n_ok = 0;
-    const uint32_t ntiles = (a.n + BLOCK - 1) / BLOCK;
-    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const uint32_t r0 = t * BLOCK;
-        const uint32_t nrec = min((uint32_t)BLOCK, a.n - r0);
-        const uint32_t last = a.off[r0 + nrec];
-        uint32_t cur = 0;
-        while (cur < nrec) {
-            const uint32_t cbase = a.off[r0 + cur] & ~15u;
-            const uint32_t climit = cbase + TILE_BYTES;  // staged window [cbase, climit)
-            const uint32_t stage_end = min(last, climit);
-            // cooperative, coalesced 16 B/lane copy of the wire bytes into LDS
-            {
-                const uint4* g = reinterpret_cast<const uint4*>(a.buf + cbase);
-                uint4* l = reinterpret_cast<uint4*>(tile);
-                const uint32_t nvec = (stage_end - cbase + 15) >> 4;
-                for (uint32_t v = tid; v < nvec; v += BLOCK) l[v] = g[v];
-            }
-            const uint32_t k = cur + tid;
-            uint32_t o0 = 0, o1 = 0;
-            bool mine = false;
-            if (k < nrec) {
-                o0 = a.off[r0 + k];
-                o1 = a.off[r0 + k + 1];
-                mine = o1 <= climit && o1 >= o0 && o0 >= cbase;
-            }
-            const int nfit = __syncthreads_count(mine);  // offsets are monotone: a prefix fits
-            if (nfit == 0) {
-                // a single record larger than the LDS tile (or broken offsets): generic path
-                if (tid == 0) {
-                    unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
-                    a.exotic_idx[j] = r0 + cur;
-                }
-                cur += 1;
-                __syncthreads();
-                continue;
-            }
-            // ---- parse (divergent: only lanes that own a staged record) ----
-            bool sure = false;
-            Rec r;
-            rec_clear(r);
-            if (mine) {
-                LdsSrc src{tile};
-                uint32_t pos = o0 - cbase, end = o1 - cbase;
-                sure = true;
-                if (a.framed) {
-                    uint32_t pl = 0;
-                    sure = frame_fast(window64(src, pos), end - pos, pl);
-                    pos += pl;
-                }
-                if (sure) sure = parse_fast<COLS>(src, pos, end, r);
-                if (!sure) {
-                    unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
-                    a.exotic_idx[j] = r0 + k;
-                }
-            }
-            // ---- sink (reconverged: the cross-lane combine needs the whole wave) ----
-            if (MODE == MODE_DECODE) {
-                if (sure) store_columns(a.cols, r0 + k, r, 0);
-            } else {
-                n_ok += sure ? 1 : 0;
-                if (KEYSETS & FA_KEYS_AS_PAIR) {
-                    uint32_t t32 = (uint32_t)r.time_received;  // UInt64 -> DateTime (create.sh:39)
-                    uint64_t k0, k1;
-                    pack_key(t32 / a.gran, r.src_as, r.dst_as, r.etype, k0, k1);
-                    uint64_t h = key_hash(k0, k1);
-                    uint64_t b = r.bytes, p = r.packets, c = 1;
-                    bool valid = sure;
-                    wave_combine<16, 4>(valid, k0, k1, b, p, c);
-                    if (valid) {
-                        if (!lds_table_add<LDS_SLOTS, LDS_PROBES>(lt, k0, k1, h, b, p, c))
-                            agg_global(a, k0, k1, h, b, p, c);
-                    }
-                }
-                if (sure && (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
-                    uint64_t w = r.bytes * r.sampling_rate;  // viz-ch.json:233 sum(Bytes*SamplingRate)
-                    if (KEYSETS & FA_KEYS_SRCADDR_CMS)
-                        cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
-                    if (KEYSETS & FA_KEYS_DSTADDR_CMS)
-                        cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
-                }
-            }
-            cur += nfit;
-            __syncthreads();  // tile is overwritten by the next pass
+    const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
+    const uint32_t stride = gridDim.x;
+    uint32_t t = blockIdx.x;
+    TileDesc cur = tile_desc(a, t, ntiles);
+    uint32_t o0 = 0, o1 = 0;  // this lane's record of the current tile
+    if (t < ntiles && tid < cur.nrec) {
+        o0 = a.off[cur.r0 + tid];
+        o1 = a.off[cur.r0 + tid + 1];
+    }
+    __syncthreads();  // LDS table cleared
+
+    for (; t < ntiles; t += stride) {
+        // (1) stream this tile's wire bytes into LDS (async DMA) ...
+        if (cur.fits) dma_to_lds(a.buf + (cur.lo & ~15u), cur.hi - (cur.lo & ~15u), tile);
+        // ... and meanwhile fetch the next tile's descriptor and offsets
+        const TileDesc nxt = tile_desc(a, t + stride, ntiles);
+        uint32_t n0 = 0, n1 = 0;
+        if (tid < nxt.nrec) {
+            n0 = a.off[nxt.r0 + tid];
+            n1 = a.off[nxt.r0 + tid + 1];
         }
+        dma_wait_all();
+        __syncthreads();
+
+        // (2) parse + aggregate out of LDS
+        if (cur.fits) {
+            const uint32_t cbase = cur.lo & ~15u;
+            const bool mine = tid < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
+            if (tid < cur.nrec && !mine) {  // broken offsets: let the generic path judge it
+                unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
+                a.exotic_idx[j] = cur.r0 + tid;
+            }
+            lane_work<MODE, KEYSETS, COLS>(a, lt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, n_ok);
+        } else {
+            // rare: the tile's bytes exceed the LDS buffer (big records): stage it in passes
+            uint32_t done = 0;
+            while (done < cur.nrec) {
+                const uint32_t first = a.off[cur.r0 + done];
+                const uint32_t cbase = first & ~15u;
+                const uint32_t climit = cbase + TILE_BYTES;
+                const uint32_t stage_end = min(cur.hi, climit);
+                if (stage_end > cbase) dma_to_lds(a.buf + cbase, stage_end - cbase, tile);
+                const uint32_t k = done + tid;
+                uint32_t p0 = 0, p1 = 0;
+                bool mine = false;
+                if (k < cur.nrec) {
+                    p0 = a.off[cur.r0 + k];
+                    p1 = a.off[cur.r0 + k + 1];
+                    mine = p1 <= climit && p1 >= p0 && p0 >= cbase && p1 <= cur.hi;
+                }
+                dma_wait_all();
+                const int nfit = __syncthreads_count(mine);  // offsets are monotone: a prefix fits
+                if (nfit == 0) {
+                    // one record larger than the LDS buffer (or broken offsets): generic path
+                    if (tid == 0) {
+                        unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
+                        a.exotic_idx[j] = cur.r0 + done;
+                    }
+                    done += 1;
+                } else {
+                    lane_work<MODE, KEYSETS, COLS>(a, lt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, n_ok);
+                    done += nfit;
+                }
+                __syncthreads();  // the buffer is restaged by the next pass
+            }
+        }
+        __syncthreads();  // everyone is done reading the tile
+        cur = nxt;
+        o0 = n0;
+        o1 = n1;
     }
     if (MODE == MODE_INGEST) {
         if (KEYSETS & FA_KEYS_AS_PAIR) {

@@ -82,17 +82,16 @@ __device__ __forceinline__ uint64_t window64(const Src& s, uint32_t pos) {
 // Varint of 1..6 bytes sitting in the low bytes of v.  Returns false when the
 // stop byte is not within 6 bytes.  *len = encoded length, *val = value (< 2^42).
 __device__ __forceinline__ bool varint6(uint64_t v, uint32_t& len, uint64_t& val) {
-    uint64_t m = ~v & 0x0000808080808080ull;
-    if (m == 0) return false;
-    uint32_t stop = (uint32_t)__builtin_ctzll(m);  // 7,15,...,47
+    const uint64_t m = ~v & 0x0000808080808080ull;
+    const uint32_t stop = (uint32_t)__builtin_ctzll(m | (1ull << 63));  // 7,15,...,47 (63: none)
     len = (stop >> 3) + 1;
-    uint64_t x = v & ((2ull << stop) - 1);
+    const uint64_t x = v & ((2ull << stop) - 1);
     uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
     xl = ((xl & 0x7f007f00u) >> 1) | (xl & 0x007f007fu);
     xl = ((xl & 0x3fff0000u) >> 2) | (xl & 0x00003fffu);
     xh = ((xh & 0x00007f00u) >> 1) | (xh & 0x0000007fu);
     val = (uint64_t)xl | ((uint64_t)xh << 28);
-    return true;
+    return m != 0;
 }
 
 // Up to 16 payload bytes at byte offset pos, zero padded beyond len (<= 16).
@@ -115,71 +114,63 @@ __device__ __forceinline__ void load_fixed16(const Src& s, uint32_t pos, uint32_
 
 // Fast parser.  [pos,end) are byte offsets of the bare payload inside src.
 // Returns true iff the record was decoded exactly; false = defer to parse_generic.
+// The loop body is straight-line (selects, no per-field branches): lanes of a wave
+// sit on different fields whenever a zero-valued field was omitted (proto3), so a
+// switch() would diverge on almost every iteration.  The only divergent control
+// flow is the loop trip count and the rare "not sure" exit.
 template <uint32_t COLS, class Src>
 __device__ __forceinline__ bool parse_fast(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
+    constexpr bool WANT_ADDR = (COLS & (COL_SRC_ADDR | COL_DST_ADDR | COL_SAMPLER_ADDRESS)) != 0;
     while (pos < end) {
-        uint64_t w = window64(s, pos);
-        uint32_t b0 = (uint32_t)w & 0xff;
-        uint32_t tag, tl;
-        if (!(b0 & 0x80)) {
-            tag = b0;
-            tl = 1;
-        } else if (!((uint32_t)w & 0x8000)) {
-            tag = (b0 & 0x7f) | (((uint32_t)w >> 1) & 0x3f80);
-            tl = 2;
-        } else {
-            return false;  // tag of 3+ bytes (field >= 2048)
-        }
-        uint32_t field = tag >> 3, wt = tag & 7;
-        if (field == 0) return false;
-        uint64_t v = w >> (8 * tl);  // >= 6 valid bytes after the tag
+        const uint64_t w = window64(s, pos);
+        const uint32_t w0 = (uint32_t)w;
+        const bool two = (w0 & 0x80u) != 0;  // 2-byte tag (fields 16..2047)
+        const uint32_t tag = two ? ((w0 & 0x7fu) | ((w0 >> 1) & 0x3f80u)) : (w0 & 0x7fu);
+        const uint32_t tl = two ? 2u : 1u;
+        const uint32_t wt = tag & 7u;
+        const uint64_t v = two ? (w >> 16) : (w >> 8);  // >= 6 valid bytes after the tag
         uint32_t vl;
         uint64_t val;
-        if (wt == 0) {
-            if (!varint6(v, vl, val)) return false;
-            pos += tl + vl;
-            if (pos > end) return false;
-            switch (field) {
-            case 2: if (COLS & COL_TIME_RECEIVED) r.time_received = val; break;
-            case 3: if (COLS & COL_SAMPLING_RATE) r.sampling_rate = val; break;
-            case 4: if (COLS & COL_SEQUENCE_NUM) r.sequence_num = (uint32_t)val; break;
-            case 9: if (COLS & COL_BYTES) r.bytes = val; break;
-            case 10: if (COLS & COL_PACKETS) r.packets = val; break;
-            case 14: if (COLS & COL_SRC_AS) r.src_as = (uint32_t)val; break;
-            case 15: if (COLS & COL_DST_AS) r.dst_as = (uint32_t)val; break;
-            case 20: if (COLS & COL_PROTO) r.proto = (uint32_t)val; break;
-            case 21: if (COLS & COL_SRC_PORT) r.src_port = (uint32_t)val; break;
-            case 22: if (COLS & COL_DST_PORT) r.dst_port = (uint32_t)val; break;
-            case 30: if (COLS & COL_ETYPE) r.etype = (uint32_t)val; break;
-            case 38: if (COLS & COL_TIME_FLOW_START) r.time_flow_start = val; break;
-            default: break;
-            }
-        } else if (wt == 2) {
-            if (!varint6(v, vl, val)) return false;
-            if (vl > 5) return false;  // size is a varint32
-            pos += tl + vl;
-            if (pos > end || val > (uint64_t)(end - pos)) return false;
-            uint32_t sz = (uint32_t)val;
-            if (field == 6 || field == 7 || field == 11) {
-                if (sz > 16) return false;  // FixedString(16) overflow: generic path rules
-                if (field == 6) {
-                    if (COLS & COL_SRC_ADDR) load_fixed16(s, pos, sz, r.src);
-                } else if (field == 7) {
-                    if (COLS & COL_DST_ADDR) load_fixed16(s, pos, sz, r.dst);
+        const bool vok = varint6(v, vl, val);
+        const bool isv = wt == 0, isl = wt == 2, f64 = wt == 1, f32 = wt == 5;
+        const bool has_varint = isv | isl;
+        const uint32_t npos = pos + tl + (has_varint ? vl : 0u) + (f64 ? 8u : 0u) + (f32 ? 4u : 0u);
+        const bool is_addr = isl & ((tag == 0x32u) | (tag == 0x3au) | (tag == 0x5au));  // fields 6, 7, 11
+        bool bad = (two & ((w0 & 0x8000u) != 0))            // tag of 3+ bytes
+                   | (tag < 8u)                              // field number 0
+                   | !(has_varint | f64 | f32)               // groups, wire types 6/7
+                   | (has_varint & !vok)                     // varint longer than 6 bytes
+                   | (isl & (vl > 5u))                       // LEN size is a varint32
+                   | (npos > end);
+        const uint64_t room = (uint64_t)(end - npos);        // only meaningful when npos <= end
+        bad |= isl & (val > room);
+        bad |= is_addr & (val > 16u);                        // FixedString(16) overflow
+        if (bad) return false;
+        if (COLS & COL_TIME_RECEIVED) r.time_received = tag == 0x10u ? val : r.time_received;
+        if (COLS & COL_SAMPLING_RATE) r.sampling_rate = tag == 0x18u ? val : r.sampling_rate;
+        if (COLS & COL_SEQUENCE_NUM) r.sequence_num = tag == 0x20u ? (uint32_t)val : r.sequence_num;
+        if (COLS & COL_BYTES) r.bytes = tag == 0x48u ? val : r.bytes;
+        if (COLS & COL_PACKETS) r.packets = tag == 0x50u ? val : r.packets;
+        if (COLS & COL_SRC_AS) r.src_as = tag == 0x70u ? (uint32_t)val : r.src_as;
+        if (COLS & COL_DST_AS) r.dst_as = tag == 0x78u ? (uint32_t)val : r.dst_as;
+        if (COLS & COL_PROTO) r.proto = tag == 0xa0u ? (uint32_t)val : r.proto;
+        if (COLS & COL_SRC_PORT) r.src_port = tag == 0xa8u ? (uint32_t)val : r.src_port;
+        if (COLS & COL_DST_PORT) r.dst_port = tag == 0xb0u ? (uint32_t)val : r.dst_port;
+        if (COLS & COL_ETYPE) r.etype = tag == 0xf0u ? (uint32_t)val : r.etype;
+        if (COLS & COL_TIME_FLOW_START) r.time_flow_start = tag == 0x130u ? val : r.time_flow_start;
+        const uint32_t sz = isl ? (uint32_t)val : 0u;
+        if (WANT_ADDR) {
+            if (is_addr) {
+                if (tag == 0x32u) {
+                    if (COLS & COL_SRC_ADDR) load_fixed16(s, npos, sz, r.src);
+                } else if (tag == 0x3au) {
+                    if (COLS & COL_DST_ADDR) load_fixed16(s, npos, sz, r.dst);
                 } else {
-                    if (COLS & COL_SAMPLER_ADDRESS) load_fixed16(s, pos, sz, r.sampler);
+                    if (COLS & COL_SAMPLER_ADDRESS) load_fixed16(s, npos, sz, r.sampler);
                 }
             }
-            pos += sz;
-        } else if (wt == 1) {
-            pos += tl + 8;
-            if (pos > end) return false;
-        } else if (wt == 5) {
-            pos += tl + 4;
-            if (pos > end) return false;
-        } else {
-            return false;  // groups, wire types 6/7
         }
+        pos = npos + sz;
     }
     return true;
 }
