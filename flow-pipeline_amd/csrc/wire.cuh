@@ -114,38 +114,41 @@ __device__ __forceinline__ void load_fixed16(const Src& s, uint32_t pos, uint32_
 
 // Fast parser.  [pos,end) are byte offsets of the bare payload inside src.
 // Returns true iff the record was decoded exactly; false = defer to parse_generic.
-// The loop body is straight-line (selects, no per-field branches): lanes of a wave
-// sit on different fields whenever a zero-valued field was omitted (proto3), so a
-// switch() would diverge on almost every iteration.  The only divergent control
-// flow is the loop trip count and the rare "not sure" exit.
+//
+// The loop body is straight-line: no per-field branches (proto3 zero-omission puts
+// the lanes of a wave on different fields, a switch() would diverge on almost every
+// iteration) and no early exit - every doubt is OR-ed into a sticky `doubt` word and
+// checked once after the loop together with "the cursor landed exactly on the record
+// end" (any truncated tag/varint/fixed/LEN necessarily overshoots `end`).  Wire-type
+// properties come out of tiny in-register lookup tables (shifted constants) instead
+// of compare/select chains.  The source must be readable ~32 bytes past `end`.
 template <uint32_t COLS, class Src>
 __device__ __forceinline__ bool parse_fast(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
     constexpr bool WANT_ADDR = (COLS & (COL_SRC_ADDR | COL_DST_ADDR | COL_SAMPLER_ADDRESS)) != 0;
+    uint32_t doubt = 0;
     while (pos < end) {
         const uint64_t w = window64(s, pos);
         const uint32_t w0 = (uint32_t)w;
-        const bool two = (w0 & 0x80u) != 0;  // 2-byte tag (fields 16..2047)
-        const uint32_t tag = two ? ((w0 & 0x7fu) | ((w0 >> 1) & 0x3f80u)) : (w0 & 0x7fu);
-        const uint32_t tl = two ? 2u : 1u;
+        const uint32_t two = (w0 >> 7) & 1u;  // 1: 2-byte tag (fields 16..2047)
+        const uint32_t tag = (w0 & 0x7fu) | (((w0 >> 1) & 0x3f80u) & (0u - two));
+        doubt |= (w0 >> 15) & two;            // tag of 3+ bytes
         const uint32_t wt = tag & 7u;
-        const uint64_t v = two ? (w >> 16) : (w >> 8);  // >= 6 valid bytes after the tag
+        const uint64_t v = w >> (8u << two);  // >= 6 valid bytes after the tag
         uint32_t vl;
         uint64_t val;
-        const bool vok = varint6(v, vl, val);
-        const bool isv = wt == 0, isl = wt == 2, f64 = wt == 1, f32 = wt == 5;
-        const bool has_varint = isv | isl;
-        const uint32_t npos = pos + tl + (has_varint ? vl : 0u) + (f64 ? 8u : 0u) + (f32 ? 4u : 0u);
-        const bool is_addr = isl & ((tag == 0x32u) | (tag == 0x3au) | (tag == 0x5au));  // fields 6, 7, 11
-        bool bad = (two & ((w0 & 0x8000u) != 0))            // tag of 3+ bytes
-                   | (tag < 8u)                              // field number 0
-                   | !(has_varint | f64 | f32)               // groups, wire types 6/7
-                   | (has_varint & !vok)                     // varint longer than 6 bytes
-                   | (isl & (vl > 5u))                       // LEN size is a varint32
-                   | (npos > end);
-        const uint64_t room = (uint64_t)(end - npos);        // only meaningful when npos <= end
-        bad |= isl & (val > room);
-        bad |= is_addr & (val > 16u);                        // FixedString(16) overflow
-        if (bad) return false;
+        const uint32_t novar = varint6(v, vl, val) ? 0u : 1u;
+        // per-wire-type facts from shifted constants: 0 varint, 1 fixed64, 2 LEN, 5 fixed32
+        const uint32_t hv = (0x05u >> wt) & 1u;              // carries a varint (value or size)
+        const uint32_t isl = (0x04u >> wt) & 1u;             // LEN
+        const uint32_t fixw = (0x400080u >> (wt * 4u)) & 0xfu;  // fixed payload bytes
+        doubt |= ((0x27u >> wt) & 1u) ^ 1u;                  // groups (3,4) and wire types 6,7
+        doubt |= tag < 8u ? 1u : 0u;                         // field number 0
+        doubt |= hv & novar;                                 // varint longer than 6 bytes
+        doubt |= isl & (vl > 5u ? 1u : 0u);                  // LEN size is a varint32
+        // LEN payload size, clamped so the cursor can neither wrap nor loop
+        const uint32_t sz = (uint32_t)(val >> 20) ? (1u << 20) : (uint32_t)val;
+        const uint32_t is_addr = isl & ((((tag | 8u) == 0x3au) | (tag == 0x5au)) ? 1u : 0u);  // fields 6, 7, 11
+        doubt |= is_addr & (sz > 16u ? 1u : 0u);             // FixedString(16) overflow
         if (COLS & COL_TIME_RECEIVED) r.time_received = tag == 0x10u ? val : r.time_received;
         if (COLS & COL_SAMPLING_RATE) r.sampling_rate = tag == 0x18u ? val : r.sampling_rate;
         if (COLS & COL_SEQUENCE_NUM) r.sequence_num = tag == 0x20u ? (uint32_t)val : r.sequence_num;
@@ -158,21 +161,22 @@ __device__ __forceinline__ bool parse_fast(const Src& s, uint32_t pos, uint32_t 
         if (COLS & COL_DST_PORT) r.dst_port = tag == 0xb0u ? (uint32_t)val : r.dst_port;
         if (COLS & COL_ETYPE) r.etype = tag == 0xf0u ? (uint32_t)val : r.etype;
         if (COLS & COL_TIME_FLOW_START) r.time_flow_start = tag == 0x130u ? val : r.time_flow_start;
-        const uint32_t sz = isl ? (uint32_t)val : 0u;
+        const uint32_t npos = pos + 1u + two + (vl & (0u - hv)) + fixw;
         if (WANT_ADDR) {
             if (is_addr) {
-                if (tag == 0x32u) {
-                    if (COLS & COL_SRC_ADDR) load_fixed16(s, npos, sz, r.src);
-                } else if (tag == 0x3au) {
-                    if (COLS & COL_DST_ADDR) load_fixed16(s, npos, sz, r.dst);
-                } else {
-                    if (COLS & COL_SAMPLER_ADDRESS) load_fixed16(s, npos, sz, r.sampler);
+                uint32_t a16[4];
+                load_fixed16(s, npos, sz > 16u ? 16u : sz, a16);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (COLS & COL_SRC_ADDR) r.src[k] = tag == 0x32u ? a16[k] : r.src[k];
+                    if (COLS & COL_DST_ADDR) r.dst[k] = tag == 0x3au ? a16[k] : r.dst[k];
+                    if (COLS & COL_SAMPLER_ADDRESS) r.sampler[k] = tag == 0x5au ? a16[k] : r.sampler[k];
                 }
             }
         }
-        pos = npos + sz;
+        pos = npos + (sz & (0u - isl));
     }
-    return true;
+    return doubt == 0 && pos == end;
 }
 
 // ---- generic parser (complete semantics) -----------------------------------

@@ -1,0 +1,88 @@
+"""N>1 host path on CPU: world_size-2 gloo.  Kafka partitions are sharded over ranks,
+each rank aggregates its shard (here with the oracle standing in for the GPU - the
+product kernels cannot run without a HIP device), and the window-close exchange
+(all-gather of rows + re-aggregation; sketch all-reduce) is the real dist.py code."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import _pkg
+    fa = _pkg.load()
+    po = _pkg.load_oracle()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, nparts = 40000, 8
+    gp = po.gen_params(mode=po.GEN_ASPAIRS, framed=1, seed=10, n_total=n)
+    buf, off = po.gen_records(gp, 0, n)
+    raw = bytes(buf)
+    mine = fa.dist.partitions_of(rank, world, nparts)
+    shard = po.Rollup(300)
+    for p in mine:  # record i lives in partition i mod nparts (mocker sets no key, mocker.go:103-106)
+        recs = [raw[int(off[k]):int(off[k + 1])] for k in range(p, n, nparts)]
+        o = np.zeros(len(recs) + 1, dtype=np.uint64)
+        o[1:] = np.cumsum([len(r) for r in recs])
+        shard.ingest(np.frombuffer(b"".join(recs), dtype=np.uint8), o, 1)
+    parts = fa.dist.allgather_rows(shard.rows().astype(fa.dist.ROW5M_DTYPE), device="cpu")
+    merged = fa.dist.merge_rows_host(parts)
+    whole = po.Rollup(300)
+    whole.ingest(buf, off, 1)
+    ok = merged.tobytes() == whole.rows().tobytes()
+    # dense sketch merge: u64 wrap-around sum == int64 all-reduce bit for bit
+    sk = np.full(1024, np.uint64(2**63 + 12345 + rank), dtype=np.uint64)
+    t = torch.from_numpy(sk.view(np.int64))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    want = (sum(2**63 + 12345 + r for r in range(world))) % 2**64
+    ok = ok and int(sk[0]) == want
+    q.put((rank, ok, len(merged), len(mine)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_window_close_merge():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
+    assert sorted(r[3] for r in res) == [4, 4]
+
+
+def test_merge_rows_host_sums_duplicates():
+    sys.path.insert(0, ROOT)
+    import _pkg
+    fa = _pkg.load()
+    a = np.zeros(2, dtype=fa.dist.ROW5M_DTYPE)
+    a["timeslot"] = [300, 600]
+    a["src_as"] = 1
+    a["bytes"] = [2**64 - 1, 5]
+    a["count"] = 1
+    b = a.copy()
+    b["bytes"] = [2, 7]
+    m = fa.dist.merge_rows_host([a, b])
+    assert len(m) == 2 and list(m["timeslot"]) == [300, 600]
+    assert list(m["bytes"]) == [1, 12] and list(m["count"]) == [2, 2]  # wraps mod 2^64
+    assert fa.dist.partitions_of(1, 4, 8) == [1, 5]
