@@ -27,8 +27,9 @@ struct fa_ctx {
     fa_config cfg{};
     uint32_t gran = 300;
     hipStream_t stream = nullptr;
-    // one (start, stop) event pair per ingest launch, bracketing the tile kernel only
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    // three events per ingest launch: before / after the tile kernel, after the aggregation kernel
+    struct LaunchEvents { hipEvent_t e0, e1, e2; };
+    std::vector<LaunchEvents> ev_pool;
     size_t ev_used = 0;
 
     Slot* tab = nullptr;
@@ -37,8 +38,14 @@ struct fa_ctx {
     uint32_t spill_cap = 1u << 18;
     Counters* d_ctr = nullptr;
     Counters* h_ctr = nullptr;  // pinned
-    uint32_t* d_exotic = nullptr;
+    uint32_t* d_exotic = nullptr;  // deferral lists: [0,cap) exotic, [cap,2cap) retry
     size_t exotic_cap = 0;
+    // scatter sink
+    uint4* seg = nullptr;
+    size_t seg_tuples = 0;
+    uint32_t* seg_counts = nullptr;
+    size_t seg_counts_cap = 0;
+    int sink_mode = 0;  // 0 auto, 1 direct, 2 scatter (env FA_SINK)
 
     // host-fed path: pinned staging (double buffered) + device input
     uint8_t* h_stage[2] = {nullptr, nullptr};
@@ -105,6 +112,8 @@ static KArgs make_args(fa_ctx* c) {
     a.cols = c->cols;
     a.dbg = c->dbg;
     a.tile_recs = BLOCK;
+    a.retry_idx = c->d_exotic ? c->d_exotic + c->exotic_cap : nullptr;
+    a.gran_recip = (1.0 / (double)c->gran) * (1.0 + 1.0 / 1099511627776.0);
     return a;
 }
 
@@ -149,7 +158,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (cfg.cms_depth == 0) cfg.cms_depth = 4;
     if (cfg.cms_width_log2 == 0) cfg.cms_width_log2 = 20;
     if (cfg.key_sets == 0) cfg.key_sets = FA_KEYS_AS_PAIR;
-    if (cfg.max_batch_records == 0) cfg.max_batch_records = 1u << 24;
+    if (cfg.max_batch_records == 0 || cfg.max_batch_records > AGG_MAX_BATCH) cfg.max_batch_records = AGG_MAX_BATCH;
     uint32_t gran = cfg.subwindow_secs ? cfg.subwindow_secs : cfg.window_secs;
     if (cfg.device < 0 || cfg.device >= ndev || gran < 60 || 86400 % gran != 0 ||
         cfg.window_secs % gran != 0 || 86400 % cfg.window_secs != 0 || cfg.table_capacity_log2 < 10 ||
@@ -163,6 +172,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     c->gran = gran;
     c->cap_log2 = cfg.table_capacity_log2;
     if (const char* d = getenv("FA_DEBUG_FLAGS")) c->dbg = (uint32_t)strtoul(d, nullptr, 0);
+    if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
     auto bail = [&](const char* what, hipError_t e) {
         g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
         fa_destroy(c);
@@ -216,6 +226,8 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->d_ctr);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     (void)hipFree(c->d_exotic);
+    (void)hipFree(c->seg);
+    (void)hipFree(c->seg_counts);
     for (int i = 0; i < 2; i++) {
         if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
         (void)hipFree(c->d_in[i]);
@@ -226,8 +238,9 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->cms_src);
     (void)hipFree(c->cms_dst);
     for (auto& p : c->ev_pool) {
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+        (void)hipEventDestroy(p.e2);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -262,17 +275,21 @@ static int settle(fa_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < c->ev_used; i++) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].e0, c->ev_pool[i].e1) == hipSuccess) {
             c->stats.kernel_ns = (uint64_t)((double)ms * 1e6);
             c->stats.kernel_ns_total += c->stats.kernel_ns;
             c->stats.kernel_launches += 1;
         }
+        if (hipEventElapsedTime(&ms, c->ev_pool[i].e0, c->ev_pool[i].e2) == hipSuccess)
+            c->stats.batch_ns_total += (uint64_t)((double)ms * 1e6);
     }
     c->ev_used = 0;
     Counters h = *c->h_ctr;
     c->stats.records_ok = h.ok;
     c->stats.records_bad = h.bad;
     c->stats.records_slow = h.slow;
+    c->stats.records_direct = h.direct;
+    c->stats.records_retried = h.retried;
     c->stats.table_used = c->used_base + h.used;
     if (h.spill_lost) {
         c->sticky = FA_ERR_TABLE_FULL;
@@ -311,16 +328,19 @@ extern "C" int fa_sync(fa_ctx* c) {
 }
 
 // ---- ingest ---------------------------------------------------------------------------
+// Launch order on the ctx stream: [probe] -> tile -> retry -> exotic -> [agg].
 template <int MODE>
-static int launch_tiles(fa_ctx* c, const KArgs& a, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+static int launch_tiles(fa_ctx* c, const KArgs& a, int grid, fa_ctx::LaunchEvents* ev = nullptr) {
     dim3 b(BLOCK);
+    dim3 g(grid);
     dim3 ge(std::min(256u, (a.n + BLOCK - 1) / BLOCK));
+    if (MODE == MODE_INGEST && a.seg) hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, c->stream, a);
+    if (ev) (void)hipEventRecord(ev->e0, c->stream);
 #define FA_LAUNCH(KS)                                                                           \
     case KS: {                                                                                  \
-        dim3 g(grid_for(c, tile_kernel<MODE, KS>, a.n, a.tile_recs));                                        \
-        if (ev_start) (void)hipEventRecord(ev_start, c->stream);                                \
         hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);                     \
-        if (ev_stop) (void)hipEventRecord(ev_stop, c->stream);                                  \
+        if (ev) (void)hipEventRecord(ev->e1, c->stream);                                        \
+        hipLaunchKernelGGL((retry_kernel<MODE, KS>), ge, b, 0, c->stream, a);                   \
         hipLaunchKernelGGL((exotic_kernel<MODE, KS>), ge, b, 0, c->stream, a);                  \
         break;                                                                                  \
     }
@@ -333,19 +353,69 @@ static int launch_tiles(fa_ctx* c, const KArgs& a, hipEvent_t ev_start = nullptr
         }
     }
 #undef FA_LAUNCH
+    if (MODE == MODE_INGEST && a.seg) hipLaunchKernelGGL(agg_kernel, dim3(NPART), dim3(AGG_BLOCK), 0, c->stream, a);
+    if (ev) (void)hipEventRecord(ev->e2, c->stream);
     HIPCHK(c, hipGetLastError());
     return FA_OK;
 }
 
+template <int MODE>
+static int tile_grid(fa_ctx* c, uint32_t n, uint32_t tile_recs) {
+    if constexpr (MODE == MODE_DECODE) return grid_for(c, tile_kernel<MODE_DECODE, 1u>, n, tile_recs);
+    switch (c->cfg.key_sets) {
+    case 1u: return grid_for(c, tile_kernel<MODE_INGEST, 1u>, n, tile_recs);
+    case 2u: return grid_for(c, tile_kernel<MODE_INGEST, 2u>, n, tile_recs);
+    case 3u: return grid_for(c, tile_kernel<MODE_INGEST, 3u>, n, tile_recs);
+    case 4u: return grid_for(c, tile_kernel<MODE_INGEST, 4u>, n, tile_recs);
+    case 5u: return grid_for(c, tile_kernel<MODE_INGEST, 5u>, n, tile_recs);
+    case 6u: return grid_for(c, tile_kernel<MODE_INGEST, 6u>, n, tile_recs);
+    default: return grid_for(c, tile_kernel<MODE_INGEST, 7u>, n, tile_recs);
+    }
+}
+
+// deferral lists for n records: exotic [0,cap) and retry [cap,2cap)
 static int ensure_exotic(fa_ctx* c, size_t n) {
     if (c->exotic_cap >= n) return FA_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_exotic);
     c->d_exotic = nullptr;
     size_t cap = std::max<size_t>(n, 1 << 16);
-    if (hipMalloc(&c->d_exotic, cap * sizeof(uint32_t)) != hipSuccess)
-        return fail(c, FA_ERR_NOMEM, "hipMalloc(deferral list) failed");
+    if (hipMalloc(&c->d_exotic, 2 * cap * sizeof(uint32_t)) != hipSuccess)
+        return fail(c, FA_ERR_NOMEM, "hipMalloc(deferral lists) failed");
     c->exotic_cap = cap;
+    return FA_OK;
+}
+
+// Tuple segments for a batch of n records processed by nwg workgroups: capacity per (partition,
+// workgroup) = 2x the mean + 32 (a Poisson mean of m never reaches 2m+32; skewed batches overflow into
+// the direct path).  The region stride gets a skew so that consecutive partitions do not alias in L2.
+static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
+    const size_t avg = n / ((size_t)nwg * NPART);
+    const uint32_t capq = (uint32_t)((2 * avg + 32 + 3) & ~(size_t)3);
+    const size_t region = (size_t)nwg * capq + 24;
+    const size_t tuples = region * NPART;
+    if (c->seg_tuples < tuples) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->seg);
+        c->seg = nullptr;
+        c->seg_tuples = 0;
+        if (hipMalloc(&c->seg, tuples * sizeof(uint4)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(tuple segments) failed");
+        c->seg_tuples = tuples;
+    }
+    const size_t ncnt = (size_t)nwg * NPART;
+    if (c->seg_counts_cap < ncnt) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->seg_counts);
+        c->seg_counts = nullptr;
+        c->seg_counts_cap = 0;
+        if (hipMalloc(&c->seg_counts, ncnt * sizeof(uint32_t)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(segment counts) failed");
+        c->seg_counts_cap = ncnt;
+    }
+    a.seg = c->seg;
+    a.seg_counts = c->seg_counts;
+    a.capq = capq;
+    a.nwg = nwg;
+    a.region = region;
     return FA_OK;
 }
 
@@ -363,20 +433,29 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     a.off = (const uint32_t*)d_off;
     a.n = (uint32_t)n;
     a.tile_recs = tile_recs_for(len, n);
+    const int grid = tile_grid<MODE_INGEST>(c, a.n, a.tile_recs);
+    // small batches are not worth a second pass: they go straight to the device-wide table
+    const bool scatter = (c->cfg.key_sets & FA_KEYS_AS_PAIR) && (c->sink_mode == 2 || (c->sink_mode == 0 && n >= (1u << 15)));
+    if (scatter) {
+        rc = ensure_segments(c, n, (uint32_t)grid, a);
+        if (rc) return rc;
+    }
     HIPCHK(c, hipMemsetAsync(&c->d_ctr->exotic_count, 0, sizeof(unsigned int), c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr->retry_count, 0, sizeof(unsigned int), c->stream));
     if (c->ev_used == c->ev_pool.size()) {
         if (c->ev_pool.size() >= 4096) {  // bound the pool: fold what is pending
             rc = settle(c);
             if (rc) return rc;
         } else {
-            hipEvent_t e0, e1;
-            HIPCHK(c, hipEventCreate(&e0));
-            HIPCHK(c, hipEventCreate(&e1));
-            c->ev_pool.emplace_back(e0, e1);
+            fa_ctx::LaunchEvents e{};
+            HIPCHK(c, hipEventCreate(&e.e0));
+            HIPCHK(c, hipEventCreate(&e.e1));
+            HIPCHK(c, hipEventCreate(&e.e2));
+            c->ev_pool.push_back(e);
         }
     }
-    auto& evp = c->ev_pool[c->ev_used++];
-    rc = launch_tiles<MODE_INGEST>(c, a, evp.first, evp.second);
+    fa_ctx::LaunchEvents* evp = &c->ev_pool[c->ev_used++];
+    rc = launch_tiles<MODE_INGEST>(c, a, grid, evp);
     if (rc) return rc;
     c->stats.bytes_in += len;
     c->stats.batches += 1;
@@ -552,7 +631,8 @@ extern "C" int fa_decode_device(fa_ctx* c, const void* d_buf, size_t len, const 
         a.n = (uint32_t)n;
         a.tile_recs = tile_recs_for(len, n);
         HIPCHK(c, hipMemsetAsync(&c->d_ctr->exotic_count, 0, sizeof(unsigned int), c->stream));
-        rc = launch_tiles<MODE_DECODE>(c, a);
+        HIPCHK(c, hipMemsetAsync(&c->d_ctr->retry_count, 0, sizeof(unsigned int), c->stream));
+        rc = launch_tiles<MODE_DECODE>(c, a, tile_grid<MODE_DECODE>(c, a.n, a.tile_recs));
         if (rc) return rc;
     }
     out->time_received = c->cols.time_received;

@@ -1,13 +1,19 @@
 // kernels.cuh - the gfx950 kernels of libflowagg.
 //
-// Hot path (one launch per batch):  tile_kernel<MODE_INGEST,...>
+// Hot path (per batch):  probe_kernel -> tile_kernel<MODE_INGEST,...> -> retry/exotic -> agg_kernel
 //   wire bytes in HBM --global_load_lds_dwordx4 (async DMA)--> LDS tile (21.25 KiB)
-//   -> one record per lane parsed out of LDS (wire.cuh, parse_fast)
+//   -> one record per lane parsed out of LDS (wire.cuh, parse_canon)
 //   -> key = (TimeReceived/granule, SrcAS, DstAS, EType)   [create.sh:92-110]
-//   -> wave-level duplicate combining (DPP row shifts + readlane)
-//   -> per-workgroup LDS hash table (hot keys)  -> device-wide table (HBM/L2, 64-bit atomics)
-//   Records the fast parser is not sure about are appended to a deferral list
-//   and handled by exotic_kernel with the complete (generic) parser.
+//   -> per-workgroup LDS hash table absorbs hot keys (mocker.go:61-62 has 9 groups)
+//   -> everything else leaves the workgroup as a 16-byte tuple appended to the workgroup's PRIVATE
+//      segment of the key's hash partition (position from an LDS counter - no global atomics:
+//      MI355X retires only ~23.7 G global-atomic line requests/s, tools/sink_bench.hip);
+//   agg_kernel: one 1024-thread workgroup per key partition streams the partition's segments back,
+//      aggregates them in an LDS hash table (two packed 64-bit LDS atomics per tuple) and adds each
+//      group to the device-wide table once.
+//   Records parse_canon is not sure about go to retry_kernel (parse_fast, any field order) and from
+//   there to exotic_kernel (parse_generic, complete semantics); values that do not fit a tuple take
+//   the direct device-wide-table path (64-bit atomics).
 //
 // Roofline: HBM-bound integer/byte work; algorithmic bytes = wire bytes, read
 // once (DESIGN.md "Roofline").  No MFMA anywhere - nothing here is a contraction.
@@ -25,21 +31,29 @@ constexpr int BLOCK = 256;
 constexpr int TILE_BYTES = 21760;  // one LDS tile buffer: 256 records x 85 B (framed mocker records are <= 85)
 constexpr int TILE_PAD = 112;      // readable slack behind the staged bytes (window / address reads)
 constexpr int TILE_STRIDE = TILE_BYTES + TILE_PAD;
-constexpr int LDS_SLOTS = 128;     // per-workgroup pre-aggregation slots (5 KiB)
+constexpr int LDS_SLOTS = 64;      // per-workgroup hot-key slots (2.5 KiB)
 constexpr int LDS_PROBES = 2;
+constexpr int PART_LOG2 = 8;       // key partitions of the scatter sink (256: see tools/scatter_bench.hip)
+constexpr int NPART = 1 << PART_LOG2;
+constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table
+constexpr int AGG_SLOTS = 4096;    // 128 KiB of LDS: 32 B per slot
+constexpr int AGG_PROBES = 16;
+constexpr uint32_t TUPLE_TB_SPAN = 16;        // time buckets a batch may span on the tuple path
+constexpr uint32_t TUPLE_MAX_BYTES = 1u << 28, TUPLE_MAX_PACKETS = 1u << 15, TUPLE_MAX_ETYPE = 1u << 16;
+constexpr uint32_t AGG_MAX_BATCH = 1u << 24;  // count <= 2^24 per slot keeps the packed LDS sums exact
 static_assert(TILE_STRIDE % 16 == 0, "LDS tile buffers must stay 16-byte aligned");
 
 enum { MODE_INGEST = 0, MODE_DECODE = 1 };
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
-enum { DBG_NO_SINK = 1, DBG_NO_WAVE_COMBINE = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16 };
+enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32 };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
 };
 
 struct Counters {
-    unsigned long long ok, bad, slow, spill_lost, used;
-    unsigned int exotic_count, spill_count, rows_count, pad;
+    unsigned long long ok, bad, slow, spill_lost, used, direct, retried;
+    unsigned int exotic_count, spill_count, rows_count, retry_count, tb_base, pad;
 };
 
 struct ColumnPtrs {
@@ -68,12 +82,20 @@ struct KArgs {
     ColumnPtrs cols;
     uint32_t tile_recs;  // records per tile (<= BLOCK), chosen by the host from the mean record size
     uint32_t dbg;  // FA_DEBUG_FLAGS ablation switches (0 in production)
+    uint32_t* retry_idx;   // records parse_canon deferred
+    double gran_recip;     // (1/gran)(1+2^-40): floor(t * gran_recip) == t / gran for every u32 t
+    // scatter sink (seg == nullptr: every record takes the direct device-wide-table path)
+    uint4* seg;            // [NPART][region] tuples; partition p, workgroup w: seg[p*region + w*capq + q]
+    uint32_t* seg_counts;  // [NPART][nwg]
+    uint32_t capq;         // tuples per (partition, workgroup) segment
+    uint32_t nwg;          // workgroups of the tile kernel that filled the segments
+    unsigned long long region;  // tuples per partition (nwg*capq plus a skew against power-of-two strides)
 };
 
 // ---- sinks ------------------------------------------------------------------
-__device__ __forceinline__ void agg_global(const KArgs& a, uint64_t k0, uint64_t k1, uint64_t h,
+__device__ __forceinline__ void agg_global(const KArgs& a, uint64_t k0, uint64_t k1, uint32_t h,
                                            uint64_t b, uint64_t p, uint64_t c) {
-    uint32_t i = (uint32_t)h & a.mask;
+    uint32_t i = h & a.mask;
     for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i + 1) & a.mask) {
         Slot* s = &a.tab[i];
         unsigned long long c0 = s->k0;
@@ -164,8 +186,8 @@ __device__ __forceinline__ void dma_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F
 
 // ---- device-wide table probe ------------------------------------------------------
 // Finds or claims the slot of (k0,k1); returns nullptr when the probe limit is hit.
-__device__ __forceinline__ Slot* table_find_or_claim(const KArgs& a, uint64_t k0, uint64_t k1, uint64_t h) {
-    uint32_t i = (uint32_t)h & a.mask;
+__device__ __forceinline__ Slot* table_find_or_claim(const KArgs& a, uint64_t k0, uint64_t k1, uint32_t h) {
+    uint32_t i = h & a.mask;
     for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i + 1) & a.mask) {
         Slot* s = &a.tab[i];
         const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(s);  // one 16-byte load: k0,k1
@@ -223,11 +245,25 @@ __device__ __forceinline__ void spill_park(const KArgs& a, uint64_t k0, uint64_t
         atomicAdd(&a.ctr->spill_lost, 1ull);
 }
 
+// t / gran for a runtime granule without an integer division (see KArgs::gran_recip)
+__device__ __forceinline__ uint32_t time_bucket(const KArgs& a, uint32_t t32) {
+    return (uint32_t)((double)t32 * a.gran_recip);
+}
+
+// varint(len) frame prefix of 1 or 2 bytes (records < 16 KiB) straight from the first window
+__device__ __forceinline__ bool frame_short(uint32_t x, uint32_t rec_len, uint32_t& prefix_len) {
+    const uint32_t b0 = x & 0xffu, b1 = (x >> 8) & 0xffu;
+    const bool one = b0 < 0x80u;
+    const uint32_t val = one ? b0 : ((b0 & 0x7fu) | (b1 << 7));
+    prefix_len = one ? 1u : 2u;
+    return (one || b1 < 0x80u) && rec_len >= prefix_len && val == rec_len - prefix_len;
+}
+
 // ---- per-lane work on a staged record (called by every lane of the workgroup) ------
 template <int MODE, uint32_t KEYSETS, uint32_t COLS>
-__device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, const uint32_t* tile,
-                                          bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx,
-                                          uint32_t& n_ok) {
+__device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, uint32_t* part_cnt, const uint32_t* tile,
+                                          bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
+                                          uint32_t& n_ok, uint32_t& n_direct) {
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false;
     Rec r;
@@ -237,16 +273,20 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         sure = true;
         if (a.framed) {
             uint32_t pl = 0;
-            sure = frame_fast(window64(src, pos), end - pos, pl);
+            const uint32_t i = pos >> 2;
+            sure = frame_short(fa_alignbyte(src.dw(i + 1), src.dw(i), pos), end - pos, pl);
             pos += pl;
         }
-        if (sure && !(a.dbg & DBG_NO_PARSE)) sure = parse_fast<COLS>(src, pos, end, r);
+        if (sure && !(a.dbg & DBG_NO_PARSE)) {
+            if (a.dbg & DBG_LOOP_PARSER) sure = parse_fast<COLS>(src, pos, end, r);
+            else sure = parse_canon<COLS>(src, pos, end, r);
+        }
         if (!sure) {
-            unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
-            a.exotic_idx[j] = rec_idx;
+            unsigned int j = atomicAdd(&a.ctr->retry_count, 1u);
+            a.retry_idx[j] = rec_idx;
         }
     }
-    // ---- sink (reconverged: the quad-grouped atomics need the whole wave) ----
+    // ---- sink ----
     if (MODE == MODE_DECODE) {
         if (sure) store_columns(a.cols, rec_idx, r, 0);
         return;
@@ -258,18 +298,38 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     }
     if (KEYSETS & FA_KEYS_AS_PAIR) {
         const uint32_t t32 = (uint32_t)r.time_received;  // UInt64 -> DateTime (create.sh:39)
+        const uint32_t tb = time_bucket(a, t32);
         uint64_t k0, k1;
-        pack_key(t32 / a.gran, r.src_as, r.dst_as, r.etype, k0, k1);
-        const uint64_t h = key_hash(k0, k1);
+        pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
+        const uint32_t h = key_hash(k0, k1);
         const uint64_t b = r.bytes, p = r.packets, c = 1;
         bool pending = sure;
         if (pending && !(a.dbg & DBG_NO_LDS_TABLE)) pending = !lds_table_add<LDS_SLOTS, LDS_PROBES>(lt, k0, k1, h, b, p, c);
-        Slot* sp = nullptr;
-        if (pending && !(a.dbg & DBG_NO_GLOBAL)) {
-            sp = table_find_or_claim(a, k0, k1, h);
-            if (!sp) spill_park(a, k0, k1, b, p, c);
+        // tuple path: 16 bytes to this workgroup's private segment of the key's partition
+        if (pending && a.seg) {
+            const uint32_t tbr = tb - tb_base;
+            const bool fits = tbr < TUPLE_TB_SPAN && b < TUPLE_MAX_BYTES && p < TUPLE_MAX_PACKETS && r.etype < TUPLE_MAX_ETYPE;
+            if (fits) {
+                const uint32_t part = h >> (32 - PART_LOG2);
+                const uint32_t q = atomicAdd(&part_cnt[part], 1u);
+                if (q < a.capq) {
+                    if (!(a.dbg & DBG_NO_TUPLE_STORE))
+                        a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + q] =
+                            make_uint4(r.src_as, r.dst_as, (uint32_t)b | (tbr << 28), (uint32_t)p | (r.etype << 15));
+                    pending = false;
+                }
+            }
         }
-        quad_atomic_update(sp, b, p, c);
+        // direct path (what is left): device-wide table, one atomic line transaction per record
+        if (__builtin_amdgcn_ballot_w64(pending) != 0ull && !(a.dbg & DBG_NO_GLOBAL)) {  // wave-uniform
+            Slot* sp = nullptr;
+            if (pending) {
+                n_direct++;
+                sp = table_find_or_claim(a, k0, k1, h);
+                if (!sp) spill_park(a, k0, k1, b, p, c);
+            }
+            quad_atomic_update(sp, b, p, c);
+        }
     }
     if (sure && (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
         const uint64_t w = r.bytes * r.sampling_rate;  // viz-ch.json:233 sum(Bytes*SamplingRate)
@@ -309,11 +369,16 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     constexpr uint32_t COLS = MODE == MODE_DECODE ? (uint32_t)COL_ALL : cols_for_keysets<KEYSETS>();
     __shared__ __attribute__((aligned(16))) uint32_t tile[TILE_STRIDE / 4];
     __shared__ LdsTable<LDS_SLOTS> lt;
+    __shared__ uint32_t part_cnt[NPART];  // tuples this workgroup appended per key partition
 
     const uint32_t tid = threadIdx.x;
-    if (MODE == MODE_INGEST && (KEYSETS & FA_KEYS_AS_PAIR)) lds_table_clear(lt);
+    if (MODE == MODE_INGEST && (KEYSETS & FA_KEYS_AS_PAIR)) {
+        lds_table_clear(lt);
+        for (int i = tid; i < NPART; i += BLOCK) part_cnt[i] = 0;
+    }
+    const uint32_t tb_base = MODE == MODE_INGEST ? a.ctr->tb_base : 0u;
 
-    uint32_t n_ok = 0;
+    uint32_t n_ok = 0, n_direct = 0;
     const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
     const uint32_t stride = gridDim.x;
     uint32_t t = blockIdx.x;
@@ -346,7 +411,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                 unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
                 a.exotic_idx[j] = cur.r0 + tid;
             }
-            lane_work<MODE, KEYSETS, COLS>(a, lt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, n_ok);
+            lane_work<MODE, KEYSETS, COLS>(a, lt, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, n_ok, n_direct);
         } else {
             // rare: the tile's bytes exceed the LDS buffer (big records): stage it in passes
             uint32_t done = 0;
@@ -374,7 +439,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                     }
                     done += 1;
                 } else {
-                    lane_work<MODE, KEYSETS, COLS>(a, lt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, n_ok);
+                    lane_work<MODE, KEYSETS, COLS>(a, lt, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, n_ok, n_direct);
                     done += nfit;
                 }
                 __syncthreads();  // the buffer is restaged by the next pass
@@ -394,8 +459,171 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                     agg_global(a, k0, k1, key_hash(k0, k1), lt.bytes[i], lt.packets[i], c);
             }
         }
+        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
+            for (int i = tid; i < NPART; i += BLOCK)
+                a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min(part_cnt[i], a.capq);
+        }
         uint64_t tot = wave_sum_u64(n_ok);
         if (__lane_id() == 0 && tot) atomicAdd(&a.ctr->ok, (unsigned long long)tot);
+        tot = wave_sum_u64(n_direct);
+        if (__lane_id() == 0 && tot) atomicAdd(&a.ctr->direct, (unsigned long long)tot);
+    }
+}
+
+// ---- probe: where in time does this batch sit? ---------------------------------------------
+// 64 evenly spaced records are decoded with the complete parser; tb_base = (smallest time bucket
+// seen) - 2, so that the 4-bit relative bucket of the tuple path covers the batch (Kafka partitions
+// are close to time-ordered; records outside [tb_base, tb_base+16) take the direct path).
+__global__ __launch_bounds__(64) void probe_kernel(KArgs a) {
+    __shared__ uint32_t lo;
+    if (threadIdx.x == 0) lo = 0xffffffffu;
+    __syncthreads();
+    const uint32_t idx = a.n <= 64 ? threadIdx.x : (uint32_t)(((uint64_t)threadIdx.x * (a.n - 1)) / 63u);
+    if (idx < a.n) {
+        const uint32_t o0 = a.off[idx], o1 = a.off[idx + 1];
+        if (o1 >= o0) {
+            const uint8_t* p = a.buf + o0;
+            const uint8_t* end = a.buf + o1;
+            bool ok = true;
+            if (a.framed) ok = frame_generic(p, end);
+            Rec r;
+            if (ok) ok = parse_generic(p, end, r);
+            if (ok) atomicMin(&lo, time_bucket(a, (uint32_t)r.time_received));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.ctr->tb_base = lo == 0xffffffffu ? 0u : (lo > 2u ? lo - 2u : 0u);
+}
+
+// ---- second chance: records parse_canon deferred ---------------------------------------------
+// One record per lane straight from HBM/L2 with the order-free fast parser; what it is not sure
+// about moves on to exotic_kernel.  Updates go to the device-wide table after a wave-level combine
+// (this tier is about staying exact and tolerable on producers that do not emit canonical order).
+template <int MODE, uint32_t KEYSETS>
+__global__ __launch_bounds__(BLOCK) void retry_kernel(KArgs a) {
+    constexpr uint32_t COLS = MODE == MODE_DECODE ? (uint32_t)COL_ALL : cols_for_keysets<KEYSETS>();
+    const uint32_t cnt = a.ctr->retry_count;
+    const uint32_t rounds = (cnt + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
+    uint32_t n_ok = 0;
+    for (uint32_t it = 0; it < rounds; it++) {  // whole waves stay together (wave_combine below)
+        const uint32_t j = (it * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
+        bool sure = false;
+        Rec r;
+        rec_clear(r);
+        uint32_t idx = 0;
+        if (j < cnt) {
+            idx = a.retry_idx[j];
+            uint32_t pos = a.off[idx], end = a.off[idx + 1];
+            GlobalSrc src{reinterpret_cast<const uint32_t*>(a.buf)};
+            sure = end >= pos;
+            if (sure && a.framed) {
+                uint32_t pl = 0;
+                sure = frame_fast(window64(src, pos), end - pos, pl);
+                pos += pl;
+            }
+            if (sure) sure = parse_fast<COLS>(src, pos, end, r);
+            if (!sure) {
+                unsigned int e = atomicAdd(&a.ctr->exotic_count, 1u);
+                a.exotic_idx[e] = idx;
+            }
+        }
+        if (MODE == MODE_DECODE) {
+            if (sure) store_columns(a.cols, idx, r, 0);
+            continue;
+        }
+        n_ok += sure ? 1 : 0;
+        if (KEYSETS & FA_KEYS_AS_PAIR) {
+            uint64_t k0, k1;
+            pack_key(time_bucket(a, (uint32_t)r.time_received), r.src_as, r.dst_as, r.etype, k0, k1);
+            uint64_t b = r.bytes, p = r.packets, c = 1;
+            bool valid = sure;
+            wave_combine<16, 2>(valid, k0, k1, b, p, c);
+            if (valid) agg_global(a, k0, k1, key_hash(k0, k1), b, p, c);
+        }
+        if (sure && (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
+            const uint64_t w = r.bytes * r.sampling_rate;
+            if (KEYSETS & FA_KEYS_SRCADDR_CMS) cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
+            if (KEYSETS & FA_KEYS_DSTADDR_CMS) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
+        }
+    }
+    if (MODE == MODE_INGEST) {
+        uint64_t tot = wave_sum_u64(n_ok);
+        if (__lane_id() == 0 && tot) {
+            atomicAdd(&a.ctr->ok, (unsigned long long)tot);
+            atomicAdd(&a.ctr->retried, (unsigned long long)tot);
+        }
+    }
+}
+
+// ---- aggregation of the scattered tuples -----------------------------------------------------
+// One 1024-thread workgroup per key partition.  LDS table slot = key (2 words, same claim protocol
+// as the other tables) + two packed sums:  s1 = sum(bytes) (< 2^28 * 2^24),
+// s2 = sum(packets) << 25 | count  (packets < 2^15, count <= 2^24: no carry between the fields).
+struct AggTable {
+    unsigned long long k0[AGG_SLOTS], k1[AGG_SLOTS], s1[AGG_SLOTS], s2[AGG_SLOTS];
+};
+static_assert(sizeof(AggTable) == 131072, "agg_kernel LDS table");
+
+__global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
+    __shared__ AggTable lt;
+    constexpr int SU = 4;  // segments a wave reads at a time (16-byte loads in flight per lane)
+    const uint32_t part = blockIdx.x;
+    for (int i = threadIdx.x; i < AGG_SLOTS; i += AGG_BLOCK) {
+        lt.k0[i] = 0;
+        lt.k1[i] = 0;
+        lt.s1[i] = 0;
+        lt.s2[i] = 0;
+    }
+    __syncthreads();
+    const uint32_t tb_base = a.ctr->tb_base;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint4* pbase = a.seg + (size_t)part * a.region;
+    const uint32_t* pc = a.seg_counts + (size_t)part * a.nwg;
+    for (uint32_t w0 = wave * SU; w0 < a.nwg; w0 += (AGG_BLOCK / 64) * SU) {
+        uint32_t c[SU], cmax = 0;
+#pragma unroll
+        for (int s = 0; s < SU; s++) {
+            c[s] = w0 + s < a.nwg ? pc[w0 + s] : 0u;
+            cmax = max(cmax, c[s]);
+        }
+        for (uint32_t k = 0; k * 64 < cmax; k++) {
+            const uint32_t q = lane + 64 * k;
+            uint4 t[SU];
+#pragma unroll
+            for (int s = 0; s < SU; s++)
+                if (q < c[s]) t[s] = pbase[(size_t)(w0 + s) * a.capq + q];
+#pragma unroll
+            for (int s = 0; s < SU; s++) {
+                if (q >= c[s]) continue;
+                const uint32_t sa = t[s].x, da = t[s].y, by = t[s].z & 0x0fffffffu, tbr = t[s].z >> 28;
+                const uint32_t pk = t[s].w & 0x7fffu, et = t[s].w >> 15;
+                uint64_t k0, k1;
+                pack_key(tb_base + tbr, sa, da, et, k0, k1);
+                const uint32_t h = key_hash(k0, k1);
+                const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
+                uint32_t i = h & (AGG_SLOTS - 1);
+                bool done = false;
+#pragma unroll 1
+                for (int probe = 0; probe < AGG_PROBES && !done; probe++, i = (i + 1) & (AGG_SLOTS - 1)) {
+                    unsigned long long c0 = lt.k0[i];
+                    if (c0 == 0) c0 = atomicCAS(&lt.k0[i], 0ull, (unsigned long long)k0);
+                    if (c0 != 0 && c0 != k0) continue;
+                    unsigned long long c1 = lt.k1[i];
+                    if (c1 == 0) c1 = atomicCAS(&lt.k1[i], 0ull, (unsigned long long)k1);
+                    if (c1 != 0 && c1 != k1) continue;
+                    if (by) atomicAdd(&lt.s1[i], (unsigned long long)by);
+                    atomicAdd(&lt.s2[i], v2);
+                    done = true;
+                }
+                if (!done) agg_global(a, k0, k1, h, by, pk, 1);  // partition holds more groups than the LDS table
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < AGG_SLOTS; i += AGG_BLOCK) {
+        const unsigned long long k0 = lt.k0[i], k1 = lt.k1[i], s2 = lt.s2[i];
+        if (k0 != 0 && k1 != 0 && s2 != 0)
+            agg_global(a, k0, k1, key_hash(k0, k1), lt.s1[i], s2 >> 25, s2 & 0x1ffffffull);
     }
 }
 

@@ -50,17 +50,29 @@ __host__ __device__ __forceinline__ void unpack_key(uint64_t k0, uint64_t k1, ui
     tb = (uint32_t)((k1 >> 32) & 0x7ffffffu);
     etype = (uint32_t)k1;
 }
-__host__ __device__ __forceinline__ uint64_t key_hash(uint64_t k0, uint64_t k1) {
-    return mix64(k0 ^ mix64(k1));
+// 32-bit key hash: three quarter-rate multiplies and a few full-rate ops (the splitmix64 cascade it
+// replaces cost four 64-bit multiplies, ~100 issue slots per record).  Bit usage: the device-wide
+// table and the aggregation kernel's LDS table index with the LOW bits, the key partition of the
+// scatter sink is the TOP bits, the per-workgroup hot-key table uses bits 8.., so the three are
+// independent enough for linear probing.
+__host__ __device__ __forceinline__ uint32_t key_hash(uint64_t k0, uint64_t k1) {
+    const uint32_t a = (uint32_t)k0, b = (uint32_t)(k0 >> 32), c = (uint32_t)k1, d = (uint32_t)(k1 >> 32);
+    uint32_t h = a * 0x9E3779B1u + b;
+    h ^= h >> 15;
+    h = (h ^ c ^ ((d << 13) | (d >> 19))) * 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
 }
 
 #define FA_MAX_PROBES 128
 
 // Upsert into the device-wide table.  Returns false on overflow (probe limit).
 __device__ __forceinline__ bool table_upsert(Slot* tab, uint32_t mask, uint64_t k0, uint64_t k1,
-                                             uint64_t h, uint64_t bytes, uint64_t packets,
+                                             uint32_t h, uint64_t bytes, uint64_t packets,
                                              uint64_t count) {
-    uint32_t i = (uint32_t)h & mask;
+    uint32_t i = h & mask;
     for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i + 1) & mask) {
         Slot* s = &tab[i];
         unsigned long long c0 = s->k0;  // may be stale-EMPTY; never a wrong non-empty value
@@ -98,9 +110,9 @@ __device__ __forceinline__ void lds_table_clear(LdsTable<SLOTS>& t) {
 
 // Returns true if absorbed; false -> caller goes to the device-wide table.
 template <int SLOTS, int PROBES>
-__device__ __forceinline__ bool lds_table_add(LdsTable<SLOTS>& t, uint64_t k0, uint64_t k1, uint64_t h,
+__device__ __forceinline__ bool lds_table_add(LdsTable<SLOTS>& t, uint64_t k0, uint64_t k1, uint32_t h,
                                               uint64_t bytes, uint64_t packets, uint64_t count) {
-    uint32_t i = (uint32_t)(h >> 32) & (SLOTS - 1);
+    uint32_t i = (h >> 8) & (SLOTS - 1);
 #pragma unroll 1
     for (int probe = 0; probe < PROBES; probe++, i = (i + 1) & (SLOTS - 1)) {
         unsigned long long c0 = t.k0[i];

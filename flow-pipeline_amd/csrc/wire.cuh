@@ -7,7 +7,15 @@
 // listed in SURVEY.md Appendix A.2 (what proto.Unmarshal does at
 // inserter/inserter.go:122-126).
 //
-// Two tiers:
+// Three tiers (each one only ever answers "decoded exactly" or "not sure"; the last is the truth):
+//   parse_canon<>   - speculates that the record is what proto.Marshal (mocker.go:97) / GoFlow emit:
+//                     each pb-ext/flow.proto field at most once, in ascending field-number order,
+//                     minimal tags, small varints.  Straight-line walk over the 27 schema fields
+//                     with wave-uniform skips of the fields no lane of the wave carries
+//                     (~280 VALU instructions for a mocker-shaped record, independent of order
+//                     checks, wire-type dispatch or capture selects).  Anything else - other field
+//                     order, duplicates, unknown fields, long varints, groups - leaves the cursor
+//                     short of the record end and is answered "not sure".
 //   parse_fast<>    - one record per lane, reads the record through 8-byte
 //                     sliding windows built from aligned dword loads (LDS tile
 //                     or global memory).  Handles every field whose tag is <= 2
@@ -24,6 +32,33 @@
 #include <stdint.h>
 
 namespace fa {
+
+// ---- portability shims: the parsers also compile for the host so that tests can fuzz them
+// against the oracle without a GPU (tests/test_host_parsers.py); the product only runs the
+// device instantiations.
+#define FA_HD __host__ __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FA_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)  // wave-uniform: does any lane ...
+#else
+#define FA_ANY(c) (c)
+#endif
+FA_HD uint32_t fa_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);  // uses sh[1:0]
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (sh & 3)));
+#endif
+}
+// find-first-bit-low; 0xffffffff for 0 (v_ffbl_b32's defined result, which __builtin_ctz does not promise)
+FA_HD uint32_t fa_ffbl(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return x ? (uint32_t)__builtin_ctz(x) : 0xffffffffu;
+#endif
+}
 
 // Column selection bitmask (what a kernel variant needs; the rest is dead code).
 enum : uint32_t {
@@ -52,7 +87,7 @@ struct Rec {
     uint32_t sampler[4], src[4], dst[4];  // FixedString(16), little-endian dwords
 };
 
-__device__ __forceinline__ void rec_clear(Rec& r) {
+FA_HD void rec_clear(Rec& r) {
     r.time_received = r.time_flow_start = r.sampling_rate = r.bytes = r.packets = 0;
     r.sequence_num = r.src_as = r.dst_as = r.etype = r.proto = r.src_port = r.dst_port = 0;
 #pragma unroll
@@ -62,26 +97,26 @@ __device__ __forceinline__ void rec_clear(Rec& r) {
 // ---- byte sources ---------------------------------------------------------
 struct LdsSrc {
     const uint32_t* base;  // LDS, dword aligned
-    __device__ __forceinline__ uint32_t dw(uint32_t i) const { return base[i]; }
+    FA_HD uint32_t dw(uint32_t i) const { return base[i]; }
 };
 struct GlobalSrc {
     const uint32_t* base;  // global, dword aligned
-    __device__ __forceinline__ uint32_t dw(uint32_t i) const { return base[i]; }
+    FA_HD uint32_t dw(uint32_t i) const { return base[i]; }
 };
 
 // 8 bytes starting at byte offset pos (little endian), from aligned dwords.
 template <class Src>
-__device__ __forceinline__ uint64_t window64(const Src& s, uint32_t pos) {
+FA_HD uint64_t window64(const Src& s, uint32_t pos) {
     uint32_t i = pos >> 2, sh = pos & 3;
     uint32_t d0 = s.dw(i), d1 = s.dw(i + 1), d2 = s.dw(i + 2);
-    uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    uint32_t lo = fa_alignbyte(d1, d0, sh);
+    uint32_t hi = fa_alignbyte(d2, d1, sh);
     return (uint64_t)hi << 32 | lo;
 }
 
 // Varint of 1..6 bytes sitting in the low bytes of v.  Returns false when the
 // stop byte is not within 6 bytes.  *len = encoded length, *val = value (< 2^42).
-__device__ __forceinline__ bool varint6(uint64_t v, uint32_t& len, uint64_t& val) {
+FA_HD bool varint6(uint64_t v, uint32_t& len, uint64_t& val) {
     const uint64_t m = ~v & 0x0000808080808080ull;
     const uint32_t stop = (uint32_t)__builtin_ctzll(m | (1ull << 63));  // 7,15,...,47 (63: none)
     len = (stop >> 3) + 1;
@@ -96,14 +131,14 @@ __device__ __forceinline__ bool varint6(uint64_t v, uint32_t& len, uint64_t& val
 
 // Up to 16 payload bytes at byte offset pos, zero padded beyond len (<= 16).
 template <class Src>
-__device__ __forceinline__ void load_fixed16(const Src& s, uint32_t pos, uint32_t len, uint32_t out[4]) {
+FA_HD void load_fixed16(const Src& s, uint32_t pos, uint32_t len, uint32_t out[4]) {
     uint32_t i = pos >> 2, sh = pos & 3;
     uint32_t d0 = s.dw(i), d1 = s.dw(i + 1), d2 = s.dw(i + 2), d3 = s.dw(i + 3), d4 = s.dw(i + 4);
     uint32_t w[4];
-    w[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    w[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    w[2] = __builtin_amdgcn_alignbyte(d3, d2, sh);
-    w[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    w[0] = fa_alignbyte(d1, d0, sh);
+    w[1] = fa_alignbyte(d2, d1, sh);
+    w[2] = fa_alignbyte(d3, d2, sh);
+    w[3] = fa_alignbyte(d4, d3, sh);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         int rem = (int)len - 4 * k;  // bytes of this dword that belong to the value
@@ -123,7 +158,7 @@ __device__ __forceinline__ void load_fixed16(const Src& s, uint32_t pos, uint32_
 // properties come out of tiny in-register lookup tables (shifted constants) instead
 // of compare/select chains.  The source must be readable ~32 bytes past `end`.
 template <uint32_t COLS, class Src>
-__device__ __forceinline__ bool parse_fast(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
+FA_HD bool parse_fast(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
     constexpr bool WANT_ADDR = (COLS & (COL_SRC_ADDR | COL_DST_ADDR | COL_SAMPLER_ADDRESS)) != 0;
     uint32_t doubt = 0;
     while (pos < end) {
@@ -179,13 +214,148 @@ __device__ __forceinline__ bool parse_fast(const Src& s, uint32_t pos, uint32_t 
     return doubt == 0 && pos == end;
 }
 
+// ---- canonical-order parser ---------------------------------------------------------
+// Cursor over the record: pos plus the 8 bytes at pos (x = bytes pos..pos+3, y = pos+4..pos+7).
+// The window is re-read only after some lane of the wave has advanced.
+struct Cursor {
+    uint32_t pos, x, y;
+};
+template <class Src>
+FA_HD void cur_load(const Src& s, Cursor& c) {
+    const uint32_t i = c.pos >> 2;
+    const uint32_t d0 = s.dw(i), d1 = s.dw(i + 1), d2 = s.dw(i + 2);
+    c.x = fa_alignbyte(d1, d0, c.pos);
+    c.y = fa_alignbyte(d2, d1, c.pos);
+}
+
+// 4 varint bytes in v (little endian), stop byte's bit 7 at bit index sb (7,15,23,31) -> value (< 2^28)
+FA_HD uint32_t varint28(uint32_t v, uint32_t sb) {
+    const uint32_t m = v & ((2u << (sb & 31u)) - 1u) & 0x7f7f7f7fu;
+    const uint32_t t = m - ((m & 0x7f007f00u) >> 1);  // two 14-bit halves
+    return t - (t >> 16) * 0xC000u;                    // lo14 | hi14 << 14
+}
+
+// Varint field whose value fits 4 bytes (< 2^28).  TAG: the 1- or 2-byte tag as a little-endian
+// integer.  A longer value, a truncated one or one that would cross `end` is "no match": the cursor
+// stays, the final pos == end test fails and the record is deferred to the general parsers.
+template <uint32_t TAG, bool WANT, class Src>
+FA_HD void canon_short(const Src& s, Cursor& c, uint32_t end, uint32_t& out) {
+    constexpr uint32_t TL = TAG > 0xffu ? 2u : 1u;
+    const bool m = (c.x & (TL == 1 ? 0xffu : 0xffffu)) == TAG;
+    if (FA_ANY(m)) {
+        const uint32_t v = fa_alignbyte(c.y, c.x, TL);  // value bytes 0..3
+        const uint32_t sb = fa_ffbl(~v & 0x80808080u);
+        const uint32_t pn = c.pos + (sb >> 3) + (TL + 1u);  // sb = 0xffffffff (no stop) -> far beyond end
+        const bool ok = m && pn <= end;
+        if (WANT) {
+            const uint32_t val = varint28(v, sb);
+            out = ok ? val : out;
+        }
+        c.pos = ok ? pn : c.pos;
+        cur_load(s, c);
+    }
+}
+
+// Varint field read through the whole 8-byte window: value of up to 8-TL bytes (timestamps,
+// sequence numbers).  Produces the full 64-bit value (< 2^49 / 2^42).
+template <uint32_t TAG, bool WANT, class Src>
+FA_HD void canon_long(const Src& s, Cursor& c, uint32_t end, uint64_t& out) {
+    constexpr uint32_t TL = TAG > 0xffu ? 2u : 1u;
+    const bool m = (c.x & (TL == 1 ? 0xffu : 0xffffu)) == TAG;
+    if (FA_ANY(m)) {
+        const uint32_t s0 = fa_ffbl(~c.x & (TL == 1 ? 0x80808000u : 0x80800000u));
+        const uint32_t s1 = fa_ffbl(~c.y & 0x80808080u) | 32u;  // stays 0xffffffff when there is no stop
+        const uint32_t sb = s0 < s1 ? s0 : s1;                  // window bit index of the stop byte's bit 7
+        const uint32_t pn = c.pos + (sb >> 3) + 1u;
+        const bool ok = m && pn <= end;
+        if (WANT) {
+            const uint32_t lo = fa_alignbyte(c.y, c.x, TL);  // value bytes 0..3
+            const uint32_t hi = c.y >> (8u * TL);            // value bytes 4..
+            const uint32_t sv = (sb - 8u * TL) & 63u;        // stop bit relative to the value (7..55)
+            const uint64_t keep = (2ull << sv) - 1ull;
+            const uint32_t a = varint28(lo & (uint32_t)keep, 31u);
+            const uint32_t b = varint28(hi & (uint32_t)(keep >> 32), 31u);
+            const uint64_t val = (uint64_t)a | ((uint64_t)b << 28);
+            out = ok ? val : out;
+        }
+        c.pos = ok ? pn : c.pos;
+        cur_load(s, c);
+    }
+}
+
+// bytes field holding an address: one length byte <= 16 (FixedString(16), create.sh:11-13)
+template <uint32_t TAG, bool WANT, class Src>
+FA_HD void canon_addr(const Src& s, Cursor& c, uint32_t end, uint32_t out[4]) {
+    const bool m = (c.x & 0xffu) == TAG;
+    if (FA_ANY(m)) {
+        const uint32_t len = (c.x >> 8) & 0xffu;
+        const uint32_t pn = c.pos + 2u + len;
+        const bool ok = m && len <= 16u && pn <= end;
+        if (WANT) {
+            uint32_t a16[4];
+            load_fixed16(s, c.pos + 2u, len > 16u ? 16u : len, a16);
+#pragma unroll
+            for (int k = 0; k < 4; k++) out[k] = ok ? a16[k] : out[k];
+        }
+        c.pos = ok ? pn : c.pos;
+        cur_load(s, c);
+    }
+}
+
+// r must be cleared by the caller.  Returns true iff [pos,end) is exactly a canonical encoding.
+// Field list = pb-ext/flow.proto:16-64 in field-number order (what proto.Marshal emits).
+template <uint32_t COLS, class Src>
+FA_HD bool parse_canon(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
+    Cursor c;
+    c.pos = pos;
+    cur_load(s, c);
+    uint32_t d32 = 0;  // discarded captures
+    uint64_t d64 = 0;
+    uint32_t sr32 = 0, by32 = 0, pk32 = 0;
+    canon_short<0x08u, false>(s, c, end, d32);                                              //  1 Type
+    canon_long<0x10u, (COLS & COL_TIME_RECEIVED) != 0>(s, c, end, r.time_received);         //  2 TimeReceived
+    canon_short<0x18u, (COLS & COL_SAMPLING_RATE) != 0>(s, c, end, sr32);                   //  3 SamplingRate
+    {
+        uint64_t seq = 0;
+        canon_long<0x20u, (COLS & COL_SEQUENCE_NUM) != 0>(s, c, end, seq);                  //  4 SequenceNum
+        r.sequence_num = (uint32_t)seq;
+    }
+    canon_long<0x28u, false>(s, c, end, d64);                                               //  5 TimeFlowEnd
+    canon_addr<0x32u, (COLS & COL_SRC_ADDR) != 0>(s, c, end, r.src);                        //  6 SrcAddr
+    canon_addr<0x3au, (COLS & COL_DST_ADDR) != 0>(s, c, end, r.dst);                        //  7 DstAddr
+    canon_short<0x48u, (COLS & COL_BYTES) != 0>(s, c, end, by32);                           //  9 Bytes
+    canon_short<0x50u, (COLS & COL_PACKETS) != 0>(s, c, end, pk32);                         // 10 Packets
+    canon_addr<0x5au, (COLS & COL_SAMPLER_ADDRESS) != 0>(s, c, end, r.sampler);             // 11 SamplerAddress
+    canon_short<0x70u, (COLS & COL_SRC_AS) != 0>(s, c, end, r.src_as);                      // 14 SrcAS
+    canon_short<0x78u, (COLS & COL_DST_AS) != 0>(s, c, end, r.dst_as);                      // 15 DstAS
+    canon_short<0x0190u, false>(s, c, end, d32);                                            // 18 InIf
+    canon_short<0x0198u, false>(s, c, end, d32);                                            // 19 OutIf
+    canon_short<0x01a0u, (COLS & COL_PROTO) != 0>(s, c, end, r.proto);                      // 20 Proto
+    canon_short<0x01a8u, (COLS & COL_SRC_PORT) != 0>(s, c, end, r.src_port);                // 21 SrcPort
+    canon_short<0x01b0u, (COLS & COL_DST_PORT) != 0>(s, c, end, r.dst_port);                // 22 DstPort
+    canon_short<0x01b8u, false>(s, c, end, d32);                                            // 23 IPTos
+    canon_short<0x01c0u, false>(s, c, end, d32);                                            // 24 ForwardingStatus
+    canon_short<0x01c8u, false>(s, c, end, d32);                                            // 25 IPTTL
+    canon_short<0x01d0u, false>(s, c, end, d32);                                            // 26 TCPFlags
+    canon_short<0x01f0u, (COLS & COL_ETYPE) != 0>(s, c, end, r.etype);                      // 30 Etype
+    canon_short<0x01f8u, false>(s, c, end, d32);                                            // 31 IcmpType
+    canon_short<0x0280u, false>(s, c, end, d32);                                            // 32 IcmpCode
+    canon_short<0x02a8u, false>(s, c, end, d32);                                            // 37 IPv6FlowLabel
+    canon_long<0x02b0u, (COLS & COL_TIME_FLOW_START) != 0>(s, c, end, r.time_flow_start);   // 38 TimeFlowStart
+    canon_short<0x02d0u, false>(s, c, end, d32);                                            // 42 FlowDirection
+    r.sampling_rate = sr32;
+    r.bytes = by32;
+    r.packets = pk32;
+    return c.pos == end;
+}
+
 // ---- generic parser (complete semantics) -----------------------------------
 struct ByteRd {
     const uint8_t* p;
     const uint8_t* end;
 };
 
-__device__ inline bool g_varint(ByteRd& r, int max_bytes, uint64_t& out) {
+FA_HD bool g_varint(ByteRd& r, int max_bytes, uint64_t& out) {
     uint64_t v = 0;
     for (int i = 0; i < max_bytes; i++) {
         if (r.p >= r.end) return false;
@@ -205,7 +375,7 @@ __device__ inline bool g_varint(ByteRd& r, int max_bytes, uint64_t& out) {
 #define FA_MAX_GROUP_DEPTH 100
 
 // Returns true = record OK (r filled), false = malformed.
-__device__ __noinline__ bool parse_generic(const uint8_t* p, const uint8_t* end, Rec& r) {
+__host__ __device__ __noinline__ bool parse_generic(const uint8_t* p, const uint8_t* end, Rec& r) {
     uint32_t stack[FA_MAX_GROUP_DEPTH];
     int depth = 0;
     ByteRd rd{p, end};
@@ -278,7 +448,7 @@ __device__ __noinline__ bool parse_generic(const uint8_t* p, const uint8_t* end,
 // Strip the frame prefix of a framed record: varint(len) || payload with
 // len == remaining bytes (mocker.go:98-106: one record per Kafka message).
 // Fast form on a window; returns false when not sure.
-__device__ __forceinline__ bool frame_fast(uint64_t w, uint32_t rec_len, uint32_t& prefix_len) {
+FA_HD bool frame_fast(uint64_t w, uint32_t rec_len, uint32_t& prefix_len) {
     uint32_t vl;
     uint64_t val;
     if (!varint6(w, vl, val)) return false;
@@ -287,7 +457,7 @@ __device__ __forceinline__ bool frame_fast(uint64_t w, uint32_t rec_len, uint32_
     return true;
 }
 
-__device__ inline bool frame_generic(const uint8_t*& p, const uint8_t* end) {
+FA_HD bool frame_generic(const uint8_t*& p, const uint8_t* end) {
     ByteRd rd{p, end};
     uint64_t len;
     if (!g_varint(rd, 10, len)) return false;

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 1
+#define FA_ABI_VERSION 2
 
 typedef struct fa_ctx fa_ctx;
 
@@ -67,7 +67,7 @@ typedef struct {
     uint32_t key_sets;            /* 0 -> FA_KEYS_AS_PAIR */
     int32_t framed;               /* 1: each record is varint(len)||payload (-proto.fixedlen=true,
                                      mocker.go:98-101); 0: bare payload (mocker.go:96-97) */
-    uint32_t max_batch_records;   /* upper bound on n per ingest call; 0 -> 1<<24 */
+    uint32_t max_batch_records;   /* upper bound on n per ingest launch; 0 or > 1<<24 -> 1<<24 */
     uint32_t reserved[5];
 } fa_config;
 
@@ -108,6 +108,9 @@ typedef struct {
     uint64_t kernel_ns;        /* device time of the last ingest kernel launch (hipEvent) */
     uint64_t kernel_ns_total;  /* summed over every ingest kernel launch */
     uint64_t kernel_launches;
+    uint64_t batch_ns_total;   /* tile kernel .. aggregation kernel, summed over every ingest launch */
+    uint64_t records_direct;   /* records that took the direct device-wide-table path */
+    uint64_t records_retried;  /* records decoded by the order-free second-chance parser */
 } fa_stats_t;
 
 typedef struct {

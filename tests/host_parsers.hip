@@ -1,0 +1,215 @@
+// host_parsers.hip - differential fuzz of the device parsers' HOST instantiations (wire.cuh compiles
+// for both sides) against the CPU oracle.  TEST INFRASTRUCTURE: built and run by
+// tests/test_host_parsers.py; links oracle/liboracle.so as the checker.
+//
+// Contract checked for the two speculative tiers (parse_canon, parse_fast):
+//   "sure" => the oracle accepts the record and all 15 columns are identical;
+//   "not sure" is always allowed (the record is deferred to parse_generic), but must not happen
+//   for plain generator output (otherwise the fast path would be useless).
+// parse_generic must agree with the oracle on verdict and columns for every input.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../flow-pipeline_amd/csrc/wire.cuh"
+#include "../oracle/flow_oracle.h"
+
+using namespace fa;
+
+static uint64_t rng_state = 0x1234567;
+static uint64_t rnd() {
+    rng_state += 0x9E3779B97F4A7C15ull;
+    uint64_t z = rng_state;
+    z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ull; z ^= z >> 27; z *= 0x94d049bb133111ebull; z ^= z >> 31;
+    return z;
+}
+
+static bool same(const Rec& r, const fo_row& o, uint32_t cols) {
+    bool ok = true;
+    if (cols & COL_TIME_RECEIVED) ok &= r.time_received == o.time_received;
+    if (cols & COL_TIME_FLOW_START) ok &= r.time_flow_start == o.time_flow_start;
+    if (cols & COL_SAMPLING_RATE) ok &= r.sampling_rate == o.sampling_rate;
+    if (cols & COL_BYTES) ok &= r.bytes == o.bytes;
+    if (cols & COL_PACKETS) ok &= r.packets == o.packets;
+    if (cols & COL_SEQUENCE_NUM) ok &= r.sequence_num == o.sequence_num;
+    if (cols & COL_SRC_AS) ok &= r.src_as == o.src_as;
+    if (cols & COL_DST_AS) ok &= r.dst_as == o.dst_as;
+    if (cols & COL_ETYPE) ok &= r.etype == o.etype;
+    if (cols & COL_PROTO) ok &= r.proto == o.proto;
+    if (cols & COL_SRC_PORT) ok &= r.src_port == o.src_port;
+    if (cols & COL_DST_PORT) ok &= r.dst_port == o.dst_port;
+    if (cols & COL_SAMPLER_ADDRESS) ok &= memcmp(r.sampler, o.sampler_address, 16) == 0;
+    if (cols & COL_SRC_ADDR) ok &= memcmp(r.src, o.src_addr, 16) == 0;
+    if (cols & COL_DST_ADDR) ok &= memcmp(r.dst, o.dst_addr, 16) == 0;
+    return ok;
+}
+
+struct Stats {
+    uint64_t cases = 0, canon_sure = 0, fast_sure = 0, oracle_ok = 0, fail = 0;
+};
+
+static void hexdump(const uint8_t* p, size_t n) {
+    for (size_t i = 0; i < n; i++) printf("%02x", p[i]);
+    printf("\n");
+}
+
+// payload = bare FlowMessage bytes
+static void check(const uint8_t* payload, size_t n, Stats& st, bool must_be_canon) {
+    // aligned, padded copy at a random byte offset (the parsers read ~32 bytes past the end)
+    static std::vector<uint32_t> buf(4096);
+    const uint32_t shift = (uint32_t)(rnd() & 15);
+    if (n + 64 > buf.size() * 4) return;
+    uint8_t* b = reinterpret_cast<uint8_t*>(buf.data());
+    for (size_t i = 0; i < shift; i++) b[i] = (uint8_t)rnd();
+    memcpy(b + shift, payload, n);
+    for (size_t i = shift + n; i < shift + n + 48; i++) b[i] = (uint8_t)rnd();  // garbage behind the record
+    LdsSrc src{buf.data()};
+    fo_row want;
+    const int orc = fo_decode(payload, n, &want);
+    st.cases++;
+    st.oracle_ok += orc == FO_OK;
+    {
+        Rec r;
+        rec_clear(r);
+        const bool sure = parse_canon<COL_ALL>(src, shift, shift + (uint32_t)n, r);
+        st.canon_sure += sure;
+        if ((sure && (orc != FO_OK || !same(r, want, COL_ALL))) || (must_be_canon && !sure)) {
+            if (st.fail++ < 10) { printf("parse_canon mismatch (sure=%d oracle=%d): ", sure, orc); hexdump(payload, n); }
+        }
+        Rec r2;
+        rec_clear(r2);
+        const bool sure2 = parse_canon<COLS_AS_ROLLUP>(src, shift, shift + (uint32_t)n, r2);
+        if (sure2 != sure || (sure2 && !same(r2, want, COLS_AS_ROLLUP))) {
+            if (st.fail++ < 10) { printf("parse_canon<AS_ROLLUP> mismatch: "); hexdump(payload, n); }
+        }
+    }
+    {
+        Rec r;
+        rec_clear(r);
+        const bool sure = parse_fast<COL_ALL>(src, shift, shift + (uint32_t)n, r);
+        st.fast_sure += sure;
+        if (sure && (orc != FO_OK || !same(r, want, COL_ALL))) {
+            if (st.fail++ < 10) { printf("parse_fast mismatch (oracle=%d): ", orc); hexdump(payload, n); }
+        }
+    }
+    {
+        Rec r;
+        const bool ok = parse_generic(b + shift, b + shift + n, r);
+        if (ok != (orc == FO_OK) || (ok && !same(r, want, COL_ALL))) {
+            if (st.fail++ < 10) { printf("parse_generic mismatch (ok=%d oracle=%d): ", ok, orc); hexdump(payload, n); }
+        }
+    }
+}
+
+static size_t put_varint(uint8_t* p, uint64_t v, int pad_to = 0) {
+    size_t k = 0;
+    while (v >= 0x80 || (int)k + 1 < pad_to) {
+        p[k++] = (uint8_t)(v | 0x80);
+        v >>= 7;
+        if (k >= 10) break;
+    }
+    p[k++] = (uint8_t)(v & 0x7f);
+    return k;
+}
+
+// canonical-ish random record over the full flow.proto field set
+static size_t random_schema_record(uint8_t* out, bool canonical, bool small) {
+    static const uint32_t varint_fields[] = {1, 2, 3, 4, 5, 9, 10, 14, 15, 18, 19, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 37, 38, 42};
+    struct F { uint32_t field; uint8_t enc[40]; size_t n; };
+    std::vector<F> fs;
+    for (uint32_t f = 1; f <= 42; f++) {
+        bool is_var = false;
+        for (uint32_t vf : varint_fields) is_var |= vf == f;
+        const bool is_addr = f == 6 || f == 7 || f == 11;
+        if (!is_var && !is_addr) continue;
+        if ((rnd() & 3) == 0) continue;  // absent
+        F x;
+        x.field = f;
+        size_t k = put_varint(x.enc, (uint64_t)f << 3 | (is_addr ? 2 : 0));
+        if (is_addr) {
+            const uint32_t len = (rnd() & 7) == 0 ? (uint32_t)(rnd() % (small ? 17 : 20)) : ((rnd() & 1) ? 16 : 4);
+            k += put_varint(x.enc + k, len);
+            for (uint32_t i = 0; i < len; i++) x.enc[k++] = (uint8_t)rnd();
+        } else {
+            const bool longf = f == 2 || f == 4 || f == 5 || f == 38;
+            const int bits = small ? (int)(rnd() % (longf ? 43 : 29)) : (int)(rnd() % 66);
+            uint64_t v = bits >= 64 ? rnd() : (rnd() & ((1ull << bits) - 1));
+            if ((rnd() & 7) == 0) v = 0;
+            k += put_varint(x.enc + k, v, canonical ? 0 : ((rnd() & 15) == 0 ? (int)(rnd() % 11) : 0));
+        }
+        x.n = k;
+        fs.push_back(x);
+    }
+    if (!canonical && fs.size() > 1) {
+        const uint32_t kind = (uint32_t)(rnd() % 4);
+        if (kind == 0) std::swap(fs[rnd() % fs.size()], fs[rnd() % fs.size()]);
+        if (kind == 1) fs.push_back(fs[rnd() % fs.size()]);  // duplicate (last wins)
+        if (kind == 2) {                                     // unknown field
+            F x;
+            x.field = 1000;
+            size_t k = put_varint(x.enc, (uint64_t)(50 + rnd() % 2000) << 3 | (rnd() & 1 ? 0 : 5));
+            if ((x.enc[0] & 7) == 5) { for (int i = 0; i < 4; i++) x.enc[k++] = (uint8_t)rnd(); }
+            else k += put_varint(x.enc + k, rnd());
+            x.n = k;
+            fs.insert(fs.begin() + rnd() % (fs.size() + 1), x);
+        }
+    }
+    size_t n = 0;
+    for (auto& f : fs) { memcpy(out + n, f.enc, f.n); n += f.n; }
+    return n;
+}
+
+int main(int argc, char** argv) {
+    const uint64_t iters = argc > 1 ? strtoull(argv[1], 0, 0) : 200000;
+    Stats gen, canon, noncanon, mut, small;
+    // 1. generator output, all modes: must be accepted by parse_canon
+    for (uint32_t mode = 0; mode < 3; mode++) {
+        fo_gen_params gp;
+        memset(&gp, 0, sizeof gp);
+        gp.mode = mode; gp.framed = 0; gp.seed = 5 + mode; gp.n_total = iters; gp.t0 = 1600000200; gp.span_secs = 900; gp.per_sec = 4;
+        gp.zipf_log2_universe = 24; gp.zipf_s_x100 = 110;
+        std::vector<uint8_t> buf(iters * 100 + 1024);
+        std::vector<uint64_t> off(iters + 1);
+        const size_t w = fo_gen_records(&gp, 0, iters, buf.data(), buf.size(), off.data());
+        if (w == (size_t)-1) { printf("generator overflow\n"); return 2; }
+        for (uint64_t i = 0; i < iters; i++) check(buf.data() + off[i], off[i + 1] - off[i], gen, true);
+        // 2. byte-level mutations of generator output
+        for (uint64_t i = 0; i < iters; i++) {
+            uint8_t tmp[256];
+            size_t n = off[i + 1] - off[i];
+            memcpy(tmp, buf.data() + off[i], n);
+            const uint32_t kind = (uint32_t)(rnd() % 5);
+            if (kind == 0) tmp[rnd() % n] = (uint8_t)rnd();
+            if (kind == 1) tmp[rnd() % n] ^= (uint8_t)(1u << (rnd() & 7));
+            if (kind == 2) n = rnd() % (n + 1);  // truncate
+            if (kind == 3 && n + 8 < sizeof tmp) { size_t k = rnd() % 8 + 1; for (size_t j = 0; j < k; j++) tmp[n++] = (uint8_t)rnd(); }
+            if (kind == 4) { size_t a = rnd() % n, b = rnd() % n; uint8_t t = tmp[a]; tmp[a] = tmp[b]; tmp[b] = t; }
+            check(tmp, n, mut, false);
+        }
+    }
+    // 3. random records over the whole schema
+    for (uint64_t i = 0; i < iters; i++) {
+        uint8_t tmp[1024];
+        size_t n = random_schema_record(tmp, true, true);
+        check(tmp, n, small, true);
+        n = random_schema_record(tmp, true, false);
+        check(tmp, n, canon, false);
+        n = random_schema_record(tmp, false, (rnd() & 1) != 0);
+        check(tmp, n, noncanon, false);
+    }
+    auto pr = [](const char* name, const Stats& s) {
+        printf("%-28s cases=%llu oracle_ok=%llu canon_sure=%llu fast_sure=%llu FAIL=%llu\n", name, (unsigned long long)s.cases,
+               (unsigned long long)s.oracle_ok, (unsigned long long)s.canon_sure, (unsigned long long)s.fast_sure, (unsigned long long)s.fail);
+    };
+    pr("generator (3 modes)", gen);
+    pr("mutated generator output", mut);
+    pr("random schema, canonical small", small);
+    pr("random schema, canonical", canon);
+    pr("random schema, non-canonical", noncanon);
+    const uint64_t fails = gen.fail + mut.fail + canon.fail + noncanon.fail + small.fail;
+    printf(fails ? "FAILED\n" : "OK\n");
+    return fails ? 1 : 0;
+}

@@ -1,0 +1,51 @@
+"""CPU tests of the device parsers' host instantiations (wire.cuh compiles for host and device)
+and of the host-side arithmetic the kernels rely on.  No GPU needed."""
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parsers_fuzz_against_oracle(po):
+    """parse_canon / parse_fast may only answer "sure" with exactly the oracle's columns;
+    parse_generic must agree with the oracle on every input (tests/host_parsers.hip)."""
+    po.build()
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "host_parsers")
+    src = os.path.join(ROOT, "tests", "host_parsers.hip")
+    deps = [src, os.path.join(ROOT, "flow-pipeline_amd", "csrc", "wire.cuh")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.check_call([
+            "/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-value", "-o", exe, src,
+            "-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    res = subprocess.run([exe, "150000"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = {l.split("cases=")[0].strip(): l for l in res.stdout.splitlines() if "cases=" in l}
+    # the fast tier must accept plain generator output and canonical records with small values
+    for name in ("generator (3 modes)", "random schema, canonical small"):
+        f = dict(kv.split("=") for kv in lines[name].split() if "=" in kv)
+        assert f["canon_sure"] == f["cases"] and f["FAIL"] == "0", lines[name]
+
+
+def test_time_bucket_reciprocal_is_exact():
+    """kernels.cuh time_bucket(): floor(double(t) * (1/g)(1+2^-40)) == t // g for every u32 t.
+    Checked at every multiple of g (+-1) near the ends of the range and on random t."""
+    rng = np.random.default_rng(1)
+    grans = [g for g in range(60, 86401) if 86400 % g == 0]
+    assert 300 in grans and 60 in grans
+    for g in grans:
+        c = (1.0 / g) * (1.0 + 1.0 / 1099511627776.0)
+        q = np.concatenate([np.arange(0, 2000, dtype=np.uint64), (2**32 - 1) // g - np.arange(0, 2000, dtype=np.uint64),
+                            rng.integers(0, (2**32 - 1) // g, 4000, dtype=np.uint64)])
+        for d in (-1, 0, 1, g - 1):
+            t = q * np.uint64(g) + np.uint64(d % g if d >= 0 else 0)
+            if d == -1:
+                t = np.where(q > 0, q * np.uint64(g) - np.uint64(1), np.uint64(0))
+            t = t[t < 2**32]
+            got = np.floor(t.astype(np.float64) * c).astype(np.uint64)
+            assert np.array_equal(got, t // np.uint64(g)), g
+        t = rng.integers(0, 2**32, 20000, dtype=np.uint64)
+        assert np.array_equal(np.floor(t.astype(np.float64) * c).astype(np.uint64), t // np.uint64(g)), g
