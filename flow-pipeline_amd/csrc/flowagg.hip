@@ -46,6 +46,7 @@ struct fa_ctx {
     uint32_t* seg_counts = nullptr;
     size_t seg_counts_cap = 0;
     int sink_mode = 0;  // 0 auto, 1 direct, 2 scatter (env FA_SINK)
+    uint32_t plog2 = PART_LOG2_MAX, wgpc_cap = 0;  // experiment knobs (env FA_PLOG2, FA_WGPC)
 
     // host-fed path: pinned staging (double buffered) + device input
     uint8_t* h_stage[2] = {nullptr, nullptr};
@@ -125,7 +126,8 @@ static int grid_for(fa_ctx* c, K kernel, uint32_t n, uint32_t tile_recs) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess || per_cu < 1)
         per_cu = 2;
-    uint32_t g = (uint32_t)c->num_cus * (uint32_t)per_cu;
+    if (c->wgpc_cap && (int)c->wgpc_cap < per_cu) per_cu = (int)c->wgpc_cap;
+    uint32_t g = std::min<uint32_t>((uint32_t)c->num_cus * (uint32_t)per_cu, AGG_MAX_NWG);
     return (int)std::max(1u, std::min(tiles, g));
 }
 
@@ -172,6 +174,8 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     c->gran = gran;
     c->cap_log2 = cfg.table_capacity_log2;
     if (const char* d = getenv("FA_DEBUG_FLAGS")) c->dbg = (uint32_t)strtoul(d, nullptr, 0);
+    if (const char* d = getenv("FA_PLOG2")) c->plog2 = std::min<uint32_t>(PART_LOG2_MAX, std::max<uint32_t>(4, (uint32_t)atoi(d)));
+    if (const char* d = getenv("FA_WGPC")) c->wgpc_cap = (uint32_t)atoi(d);
     if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
     auto bail = [&](const char* what, hipError_t e) {
         g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
@@ -353,7 +357,7 @@ static int launch_tiles(fa_ctx* c, const KArgs& a, int grid, fa_ctx::LaunchEvent
         }
     }
 #undef FA_LAUNCH
-    if (MODE == MODE_INGEST && a.seg) hipLaunchKernelGGL(agg_kernel, dim3(NPART), dim3(AGG_BLOCK), 0, c->stream, a);
+    if (MODE == MODE_INGEST && a.seg) hipLaunchKernelGGL(agg_kernel, dim3(1u << a.plog2), dim3(AGG_BLOCK), 0, c->stream, a);
     if (ev) (void)hipEventRecord(ev->e2, c->stream);
     HIPCHK(c, hipGetLastError());
     return FA_OK;
@@ -390,6 +394,7 @@ static int ensure_exotic(fa_ctx* c, size_t n) {
 // workgroup) = 2x the mean + 32 (a Poisson mean of m never reaches 2m+32; skewed batches overflow into
 // the direct path).  The region stride gets a skew so that consecutive partitions do not alias in L2.
 static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
+    const size_t NPART = (size_t)1 << c->plog2;
     const size_t avg = n / ((size_t)nwg * NPART);
     const uint32_t capq = (uint32_t)((2 * avg + 32 + 3) & ~(size_t)3);
     const size_t region = (size_t)nwg * capq + 24;
@@ -416,6 +421,7 @@ static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     a.capq = capq;
     a.nwg = nwg;
     a.region = region;
+    a.plog2 = c->plog2;
     return FA_OK;
 }
 

@@ -33,8 +33,8 @@ constexpr int TILE_PAD = 112;      // readable slack behind the staged bytes (wi
 constexpr int TILE_STRIDE = TILE_BYTES + TILE_PAD;
 constexpr int LDS_SLOTS = 64;      // per-workgroup hot-key slots (2.5 KiB)
 constexpr int LDS_PROBES = 2;
-constexpr int PART_LOG2 = 8;       // key partitions of the scatter sink (256: see tools/scatter_bench.hip)
-constexpr int NPART = 1 << PART_LOG2;
+constexpr int PART_LOG2_MAX = 8;   // key partitions of the scatter sink (<= 256: see tools/scatter_bench.hip)
+constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
 constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table
 constexpr int AGG_SLOTS = 4096;    // 128 KiB of LDS: 32 B per slot
 constexpr int AGG_PROBES = 16;
@@ -45,7 +45,8 @@ static_assert(TILE_STRIDE % 16 == 0, "LDS tile buffers must stay 16-byte aligned
 
 enum { MODE_INGEST = 0, MODE_DECODE = 1 };
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
-enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32 };
+enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256 };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -90,6 +91,7 @@ struct KArgs {
     uint32_t capq;         // tuples per (partition, workgroup) segment
     uint32_t nwg;          // workgroups of the tile kernel that filled the segments
     unsigned long long region;  // tuples per partition (nwg*capq plus a skew against power-of-two strides)
+    uint32_t plog2;        // log2(key partitions)
 };
 
 // ---- sinks ------------------------------------------------------------------
@@ -310,7 +312,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             const uint32_t tbr = tb - tb_base;
             const bool fits = tbr < TUPLE_TB_SPAN && b < TUPLE_MAX_BYTES && p < TUPLE_MAX_PACKETS && r.etype < TUPLE_MAX_ETYPE;
             if (fits) {
-                const uint32_t part = h >> (32 - PART_LOG2);
+                const uint32_t part = h >> (32 - a.plog2);
                 const uint32_t q = atomicAdd(&part_cnt[part], 1u);
                 if (q < a.capq) {
                     if (!(a.dbg & DBG_NO_TUPLE_STORE))
@@ -369,12 +371,12 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     constexpr uint32_t COLS = MODE == MODE_DECODE ? (uint32_t)COL_ALL : cols_for_keysets<KEYSETS>();
     __shared__ __attribute__((aligned(16))) uint32_t tile[TILE_STRIDE / 4];
     __shared__ LdsTable<LDS_SLOTS> lt;
-    __shared__ uint32_t part_cnt[NPART];  // tuples this workgroup appended per key partition
+    __shared__ uint32_t part_cnt[NPART_MAX];  // tuples this workgroup appended per key partition
 
     const uint32_t tid = threadIdx.x;
     if (MODE == MODE_INGEST && (KEYSETS & FA_KEYS_AS_PAIR)) {
         lds_table_clear(lt);
-        for (int i = tid; i < NPART; i += BLOCK) part_cnt[i] = 0;
+        for (int i = tid; i < NPART_MAX; i += BLOCK) part_cnt[i] = 0;
     }
     const uint32_t tb_base = MODE == MODE_INGEST ? a.ctr->tb_base : 0u;
 
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
             }
         }
         if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
-            for (int i = tid; i < NPART; i += BLOCK)
+            for (int i = tid; i < (1 << a.plog2); i += BLOCK)
                 a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min(part_cnt[i], a.capq);
         }
         uint64_t tot = wave_sum_u64(n_ok);
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
 }
 
 // ---- probe: where in time does this batch sit? ---------------------------------------------
-// 64 evenly spaced records are decoded with the complete parser; tb_base = (smallest time bucket
+// 64 evenly spaced records are decoded; tb_base = (smallest time bucket
 // seen) - 2, so that the 4-bit relative bucket of the tuple path covers the batch (Kafka partitions
 // are close to time-ordered; records outside [tb_base, tb_base+16) take the direct path).
 __global__ __launch_bounds__(64) void probe_kernel(KArgs a) {
@@ -480,16 +482,20 @@ __global__ __launch_bounds__(64) void probe_kernel(KArgs a) {
     __syncthreads();
     const uint32_t idx = a.n <= 64 ? threadIdx.x : (uint32_t)(((uint64_t)threadIdx.x * (a.n - 1)) / 63u);
     if (idx < a.n) {
-        const uint32_t o0 = a.off[idx], o1 = a.off[idx + 1];
-        if (o1 >= o0) {
-            const uint8_t* p = a.buf + o0;
-            const uint8_t* end = a.buf + o1;
-            bool ok = true;
-            if (a.framed) ok = frame_generic(p, end);
-            Rec r;
-            if (ok) ok = parse_generic(p, end, r);
-            if (ok) atomicMin(&lo, time_bucket(a, (uint32_t)r.time_received));
+        uint32_t pos = a.off[idx], end = a.off[idx + 1];
+        // tb_base is only a hint (it decides which records may use the tuple path, never a result), so
+        // the order-free fast parser is enough: samples it is not sure about are skipped
+        GlobalSrc src{reinterpret_cast<const uint32_t*>(a.buf)};
+        bool ok = end >= pos;
+        if (ok && a.framed) {
+            uint32_t pl = 0;
+            ok = frame_fast(window64(src, pos), end - pos, pl);
+            pos += pl;
         }
+        Rec r;
+        rec_clear(r);
+        if (ok) ok = parse_fast<COL_TIME_RECEIVED>(src, pos, end, r);
+        if (ok) atomicMin(&lo, time_bucket(a, (uint32_t)r.time_received));
     }
     __syncthreads();
     if (threadIdx.x == 0) a.ctr->tb_base = lo == 0xffffffffu ? 0u : (lo > 2u ? lo - 2u : 0u);
@@ -564,9 +570,124 @@ struct AggTable {
 };
 static_assert(sizeof(AggTable) == 131072, "agg_kernel LDS table");
 
+// slow path of the LDS upsert: claim / probe; false = the table is full around this hash
+__device__ __forceinline__ bool agg_lds_upsert(AggTable& lt, uint64_t k0, uint64_t k1, uint32_t h, uint32_t by,
+                                               unsigned long long v2) {
+    uint32_t i = h & (AGG_SLOTS - 1);
+#pragma unroll 1
+    for (int probe = 0; probe < AGG_PROBES; probe++, i = (i + 1) & (AGG_SLOTS - 1)) {
+        unsigned long long c0 = lt.k0[i];
+        if (c0 == 0) c0 = atomicCAS(&lt.k0[i], 0ull, (unsigned long long)k0);
+        if (c0 != 0 && c0 != k0) continue;
+        unsigned long long c1 = lt.k1[i];
+        if (c1 == 0) c1 = atomicCAS(&lt.k1[i], 0ull, (unsigned long long)k1);
+        if (c1 != 0 && c1 != k1) continue;
+        if (by) atomicAdd(&lt.s1[i], (unsigned long long)by);
+        atomicAdd(&lt.s2[i], v2);
+        return true;
+    }
+    return false;
+}
+
+constexpr int AGG_MAX_NWG = 2048;  // tile-kernel workgroups (256 CUs x at most 8 per CU)
+constexpr int AGG_SU = 4;  // segments a wave reads at a time (16-byte loads in flight per lane, x2 buffers)
+
+struct AggBatch {
+    uint4 t[AGG_SU];
+    uint32_t c[AGG_SU];
+};
+
+// issue the loads of lanes [0,64) of AGG_SU consecutive segments starting at w0.  The segment counts
+// come from LDS (pc, zero padded): a count read from global memory would put a full vmcnt drain between
+// consecutive tuple loads.
+__device__ __forceinline__ void agg_fetch(const KArgs& a, const uint4* pbase, const uint32_t* pc, uint32_t w0, uint32_t lane,
+                                          AggBatch& b) {
+#pragma unroll
+    for (int s = 0; s < AGG_SU; s++) b.c[s] = pc[min(w0 + s, (uint32_t)(AGG_MAX_NWG + AGG_SU - 1))];  // 0 past nwg
+    // unconditional loads (lanes past the count re-read slot 0 of a valid segment): with predicated
+    // loads the compiler cannot count what is in flight and drains everything (vmcnt(0)) before the
+    // previous batch is consumed
+#pragma unroll
+    for (int s = 0; s < AGG_SU; s++) {
+        const uint32_t w = min(w0 + s, a.nwg - 1u);
+        b.t[s] = pbase[(size_t)w * a.capq + (lane < b.c[s] ? lane : 0u)];
+    }
+}
+
+__device__ __forceinline__ void agg_tuple(const KArgs& a, AggTable& lt, uint32_t tb_base, const uint4& t) {
+    const uint32_t by = t.z & 0x0fffffffu, tbr = t.z >> 28, pk = t.w & 0x7fffu, et = t.w >> 15;
+    uint64_t k0, k1;
+    pack_key(tb_base + tbr, t.x, t.y, et, k0, k1);
+    const uint32_t h = key_hash(k0, k1);
+    const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
+    if (!agg_lds_upsert(lt, k0, k1, h, by, v2)) agg_global(a, k0, k1, h, by, pk, 1);
+}
+
+// The common case (the key already sits in its home slot) for all AGG_SU tuples at once, so that the LDS
+// round trips of the segments overlap; everything else goes through the probing upsert.
+__device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b) {
+    uint64_t k0[AGG_SU], k1[AGG_SU];
+    uint32_t h[AGG_SU];
+    unsigned long long c0[AGG_SU], c1[AGG_SU];
+    if (a.dbg & DBG_AGG_NO_LDS) {  // ablation: consume the loads only
+        uint32_t x = 0;
+#pragma unroll
+        for (int s = 0; s < AGG_SU; s++) x ^= b.t[s].x ^ b.t[s].y ^ b.t[s].z ^ b.t[s].w;
+        if (x == 0x12345678u) lt.s1[lane] = x;
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < AGG_SU; s++) {
+        const uint32_t tbr = b.t[s].z >> 28, et = b.t[s].w >> 15;
+        pack_key(tb_base + tbr, b.t[s].x, b.t[s].y, et, k0[s], k1[s]);
+        h[s] = key_hash(k0[s], k1[s]);
+        const uint32_t i = h[s] & (AGG_SLOTS - 1);
+        c0[s] = lt.k0[i];
+        c1[s] = lt.k1[i];
+    }
+    uint32_t pending = 0;  // segments whose tuple is not in its home slot (probing / claiming needed)
+#pragma unroll
+    for (int s = 0; s < AGG_SU; s++) {
+        if (lane >= b.c[s]) continue;
+        const uint32_t by = b.t[s].z & 0x0fffffffu, pk = b.t[s].w & 0x7fffu;
+        const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
+        const uint32_t i = h[s] & (AGG_SLOTS - 1);
+        if (c0[s] == k0[s] && c1[s] == k1[s]) {
+            if (by) atomicAdd(&lt.s1[i], (unsigned long long)by);
+            atomicAdd(&lt.s2[i], v2);
+        } else {
+            pending |= 1u << s;
+        }
+    }
+    if (a.dbg & DBG_AGG_NO_SLOW) return;
+    // the leftovers of all AGG_SU segments share one loop: a lane works on its first pending tuple
+    // per round, so the wave pays max-over-lanes(pending tuples) upserts instead of one per segment
+    while (__builtin_amdgcn_ballot_w64(pending != 0) != 0ull) {
+        if (pending != 0) {
+            const uint32_t s = (uint32_t)__builtin_ctz(pending);
+            pending &= pending - 1u;
+            uint64_t sk0 = k0[0], sk1 = k1[0];
+            uint32_t sh = h[0], sz = b.t[0].z, sw = b.t[0].w;
+#pragma unroll
+            for (int j = 1; j < AGG_SU; j++) {
+                const bool pick = s == (uint32_t)j;
+                sk0 = pick ? k0[j] : sk0;
+                sk1 = pick ? k1[j] : sk1;
+                sh = pick ? h[j] : sh;
+                sz = pick ? b.t[j].z : sz;
+                sw = pick ? b.t[j].w : sw;
+            }
+            const uint32_t by = sz & 0x0fffffffu, pk = sw & 0x7fffu;
+            const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
+            if (!agg_lds_upsert(lt, sk0, sk1, sh, by, v2))
+                agg_global(a, sk0, sk1, sh, by, pk, 1);  // partition holds more groups than the LDS table
+        }
+    }
+}
+
 __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     __shared__ AggTable lt;
-    constexpr int SU = 4;  // segments a wave reads at a time (16-byte loads in flight per lane)
+    __shared__ uint32_t pc[AGG_MAX_NWG + AGG_SU];  // this partition's segment counts, zero padded
     const uint32_t part = blockIdx.x;
     for (int i = threadIdx.x; i < AGG_SLOTS; i += AGG_BLOCK) {
         lt.k0[i] = 0;
@@ -574,56 +695,46 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
         lt.s1[i] = 0;
         lt.s2[i] = 0;
     }
-    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_SU; i += AGG_BLOCK)
+        pc[i] = i < a.nwg ? a.seg_counts[(size_t)part * a.nwg + i] : 0u;
     const uint32_t tb_base = a.ctr->tb_base;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint4* pbase = a.seg + (size_t)part * a.region;
-    const uint32_t* pc = a.seg_counts + (size_t)part * a.nwg;
-    for (uint32_t w0 = wave * SU; w0 < a.nwg; w0 += (AGG_BLOCK / 64) * SU) {
-        uint32_t c[SU], cmax = 0;
-#pragma unroll
-        for (int s = 0; s < SU; s++) {
-            c[s] = w0 + s < a.nwg ? pc[w0 + s] : 0u;
-            cmax = max(cmax, c[s]);
-        }
-        for (uint32_t k = 0; k * 64 < cmax; k++) {
-            const uint32_t q = lane + 64 * k;
-            uint4 t[SU];
-#pragma unroll
-            for (int s = 0; s < SU; s++)
-                if (q < c[s]) t[s] = pbase[(size_t)(w0 + s) * a.capq + q];
-#pragma unroll
-            for (int s = 0; s < SU; s++) {
-                if (q >= c[s]) continue;
-                const uint32_t sa = t[s].x, da = t[s].y, by = t[s].z & 0x0fffffffu, tbr = t[s].z >> 28;
-                const uint32_t pk = t[s].w & 0x7fffu, et = t[s].w >> 15;
-                uint64_t k0, k1;
-                pack_key(tb_base + tbr, sa, da, et, k0, k1);
-                const uint32_t h = key_hash(k0, k1);
-                const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
-                uint32_t i = h & (AGG_SLOTS - 1);
-                bool done = false;
-#pragma unroll 1
-                for (int probe = 0; probe < AGG_PROBES && !done; probe++, i = (i + 1) & (AGG_SLOTS - 1)) {
-                    unsigned long long c0 = lt.k0[i];
-                    if (c0 == 0) c0 = atomicCAS(&lt.k0[i], 0ull, (unsigned long long)k0);
-                    if (c0 != 0 && c0 != k0) continue;
-                    unsigned long long c1 = lt.k1[i];
-                    if (c1 == 0) c1 = atomicCAS(&lt.k1[i], 0ull, (unsigned long long)k1);
-                    if (c1 != 0 && c1 != k1) continue;
-                    if (by) atomicAdd(&lt.s1[i], (unsigned long long)by);
-                    atomicAdd(&lt.s2[i], v2);
-                    done = true;
-                }
-                if (!done) agg_global(a, k0, k1, h, by, pk, 1);  // partition holds more groups than the LDS table
-            }
-        }
+    constexpr uint32_t STEP = (AGG_BLOCK / 64) * AGG_SU;
+    __syncthreads();  // table cleared, counts staged
+    // software pipeline over this wave's segment groups: the next group's loads fly during the LDS work
+    // (every fetch is unconditional - clamped addresses, zero counts past the end - so that the compiler
+    // can count the loads in flight and wait for the older batch only)
+    AggBatch b0, b1;
+    uint32_t w0 = wave * AGG_SU;
+    agg_fetch(a, pbase, pc, w0, lane, b0);
+    while (true) {
+        agg_fetch(a, pbase, pc, w0 + STEP, lane, b1);
+        agg_consume(a, lt, tb_base, lane, b0);
+        agg_fetch(a, pbase, pc, w0 + 2 * STEP, lane, b0);
+        agg_consume(a, lt, tb_base, lane, b1);
+        w0 += 2 * STEP;
+        if (w0 >= a.nwg) break;
+    }
+    // segments longer than one wave pass (rare: the mean is <= 43 tuples)
+    for (uint32_t w = wave; w < a.nwg; w += AGG_BLOCK / 64) {
+        const uint32_t c = pc[w];
+        for (uint32_t q = 64 + lane; q < c; q += 64) agg_tuple(a, lt, tb_base, pbase[(size_t)w * a.capq + q]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < AGG_SLOTS; i += AGG_BLOCK) {
+    // every group of this partition goes to the device-wide table once; quad-grouped: one atomic line
+    // transaction per group.  Uniform trip count: the whole wave takes part in the quad rounds.
+    if (a.dbg & DBG_AGG_NO_FLUSH) return;
+    for (int i0 = 0; i0 < AGG_SLOTS; i0 += AGG_BLOCK) {
+        const int i = i0 + threadIdx.x;
         const unsigned long long k0 = lt.k0[i], k1 = lt.k1[i], s2 = lt.s2[i];
-        if (k0 != 0 && k1 != 0 && s2 != 0)
-            agg_global(a, k0, k1, key_hash(k0, k1), lt.s1[i], s2 >> 25, s2 & 0x1ffffffull);
+        Slot* sp = nullptr;
+        const unsigned long long b = lt.s1[i], p = s2 >> 25, c = s2 & 0x1ffffffull;
+        if (k0 != 0 && k1 != 0 && s2 != 0) {
+            sp = table_find_or_claim(a, k0, k1, key_hash(k0, k1));
+            if (!sp) spill_park(a, k0, k1, b, p, c);
+        }
+        quad_atomic_update(sp, b, p, c);
     }
 }
 

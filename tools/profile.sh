@@ -1,7 +1,7 @@
 #!/bin/bash
-# rocprofv3 evidence for bench.py (run on the GPU box via gpurun).  Three separate
-# passes: kernel trace + stats, then one PMC pass per counter group (FETCH_SIZE and
-# WRITE_SIZE do not fit one pass on gfx950).  Output: gpurun_out/prof/<tag>/...
+# rocprofv3 evidence for bench.py (run on the GPU box via gpurun).  Separate passes: kernel trace +
+# stats, then one PMC pass per counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950;
+# PMC passes never carry sys/hip/hsa trace options).  Output: gpurun_out/prof/<tag>/...
 TAG=${1:-r01}
 shift
 ARGS=${@:---steps 3 --warmup 1 --cpu-sample 0}
@@ -13,7 +13,11 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python $ROOT/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python $ROOT/bench.py $ARGS > $OUT/pmc_write.log 2>&1
+if [ -n "$PROF_SQ" ]; then
+  rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq1 -o sq1 -- python $ROOT/bench.py $ARGS > $OUT/pmc_sq1.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -d $OUT/pmc_sq2 -o sq2 -- python $ROOT/bench.py $ARGS > $OUT/pmc_sq2.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM -d $OUT/pmc_sq3 -o sq3 -- python $ROOT/bench.py $ARGS > $OUT/pmc_sq3.log 2>&1
+fi
 cd $ROOT
-find $OUT -name "*.csv" | head -20
 python $ROOT/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
