@@ -22,6 +22,8 @@ from . import dist, schema  # noqa: F401  (re-export)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libflowagg.so")
+if os.environ.get("FA_LIB_VARIANT"):  # A/B experiments only (tools/): libflowagg_<variant>.so built with make OUT=... EXTRA=...
+    LIB_PATH = os.path.join(_HERE, "libflowagg_%s.so" % os.environ["FA_LIB_VARIANT"])
 
 FA_KEYS_AS_PAIR = 1
 FA_KEYS_SRCADDR_CMS = 2
@@ -48,7 +50,8 @@ class Config(C.Structure):
         ("device", C.c_int32), ("window_secs", C.c_uint32), ("subwindow_secs", C.c_uint32),
         ("table_capacity_log2", C.c_uint32), ("cms_depth", C.c_uint32),
         ("cms_width_log2", C.c_uint32), ("cms_seed", C.c_uint64), ("key_sets", C.c_uint32),
-        ("framed", C.c_int32), ("max_batch_records", C.c_uint32), ("reserved", C.c_uint32 * 5),
+        ("framed", C.c_int32), ("max_batch_records", C.c_uint32), ("topk_capacity_log2", C.c_uint32),
+        ("reserved", C.c_uint32 * 4),
     ]
 
 
@@ -99,7 +102,7 @@ assert ROW5M_DTYPE.itemsize == 48 and FLOW_ROW_DTYPE.itemsize == 120
 EXPORTS = [
     "fa_abi_version", "fa_create", "fa_destroy", "fa_last_error", "fa_ingest", "fa_ingest_device",
     "fa_sync", "fa_decode", "fa_decode_device", "fa_open_timeslots", "fa_close_window",
-    "fa_read_window", "fa_topk", "fa_cms_query", "fa_cms_read", "fa_cms_reset",
+    "fa_read_window", "fa_topk", "fa_topk_merge_keys", "fa_cms_query", "fa_cms_read", "fa_cms_reset",
     "fa_device_state_get", "fa_merge_rows", "fa_merge_allreduce", "fa_stats",
     "fa_mock_generate_device", "fa_mock_generate_host",
 ]
@@ -110,7 +113,7 @@ _LIB = None
 def build(force=False):
     """Compile libflowagg.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcdir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(srcdir, f) for f in os.listdir(srcdir)] + [
+    srcs = [os.path.join(srcdir, f) for f in os.listdir(srcdir) if not f.endswith(".so")] + [
         os.path.join(_HERE, "..", "include", "flowagg.h")]
     if (force or not os.path.exists(LIB_PATH)
             or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)):
@@ -144,6 +147,7 @@ def lib():
     L.fa_close_window.argtypes = [vp, u32, vp, sz, szp]
     L.fa_read_window.argtypes = [vp, u32, vp, sz, szp]
     L.fa_topk.argtypes = [vp, u32, sz, vp, sz, szp]
+    L.fa_topk_merge_keys.argtypes = [vp, u32, vp, sz]
     L.fa_cms_query.argtypes = [vp, u32, C.c_char_p, C.POINTER(u64)]
     L.fa_cms_read.argtypes = [vp, u32, vp, sz]
     L.fa_cms_reset.argtypes = [vp, u32]
@@ -180,10 +184,11 @@ class FlowAgg:
 
     def __init__(self, device=0, window_secs=300, subwindow_secs=0, table_capacity_log2=20,
                  key_sets=FA_KEYS_AS_PAIR, framed=True, cms_depth=4, cms_width_log2=20,
-                 cms_seed=0x5EED, max_batch_records=0):
+                 cms_seed=0x5EED, max_batch_records=0, topk_capacity_log2=0):
         self._L = lib()
         self.cfg = Config(device, window_secs, subwindow_secs, table_capacity_log2, cms_depth,
-                          cms_width_log2, cms_seed, key_sets, 1 if framed else 0, max_batch_records)
+                          cms_width_log2, cms_seed, key_sets, 1 if framed else 0, max_batch_records,
+                          topk_capacity_log2)
         h = C.c_void_p()
         rc = self._L.fa_create(C.byref(self.cfg), C.byref(h))
         if rc:
@@ -291,10 +296,17 @@ class FlowAgg:
         self._chk(self._L.fa_cms_reset(self._h, key_set))
 
     def topk(self, key_set, k) -> np.ndarray:
+        """k heaviest addresses by Count-Min estimate of sum(Bytes*SamplingRate): (key, weight) rows."""
+        k = min(int(k), 1 << (self.cfg.topk_capacity_log2 or 20))
         out = np.zeros(k, dtype=TOPK_DTYPE)
         n = C.c_size_t()
         self._chk(self._L.fa_topk(self._h, key_set, k, out.ctypes.data, k, C.byref(n)))
-        return out[:n.value]
+        return out[:n.value].copy()
+
+    def topk_merge_keys(self, key_set, keys: np.ndarray):
+        """Adds candidate keys (uint8[n,16]) found by other contexts / ranks."""
+        kk = np.ascontiguousarray(keys, dtype=np.uint8).reshape(-1, 16)
+        self._chk(self._L.fa_topk_merge_keys(self._h, key_set, kk.ctypes.data, len(kk)))
 
     def device_state(self) -> DeviceState:
         st = DeviceState()

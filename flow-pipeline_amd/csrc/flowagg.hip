@@ -68,6 +68,9 @@ struct fa_ctx {
     unsigned long long* cms_src = nullptr;
     unsigned long long* cms_dst = nullptr;
     size_t cms_words = 0;
+    KeySlot* ks_src = nullptr;  // distinct-address sets (fa_topk)
+    KeySlot* ks_dst = nullptr;
+    uint32_t ks_log2 = 20;
 
     fa_stats_t stats{};
     uint64_t used_base = 0;  // groups created before the current counter epoch
@@ -110,6 +113,9 @@ static KArgs make_args(fa_ctx* c) {
     a.cms_depth = c->cfg.cms_depth;
     a.cms_wl2 = c->cfg.cms_width_log2;
     a.cms_seed = c->cfg.cms_seed;
+    a.ks_src = c->ks_src;
+    a.ks_dst = c->ks_dst;
+    a.ks_mask = (1u << c->ks_log2) - 1;
     a.cols = c->cols;
     a.dbg = c->dbg;
     a.tile_recs = BLOCK;
@@ -160,12 +166,13 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (cfg.cms_depth == 0) cfg.cms_depth = 4;
     if (cfg.cms_width_log2 == 0) cfg.cms_width_log2 = 20;
     if (cfg.key_sets == 0) cfg.key_sets = FA_KEYS_AS_PAIR;
+    if (cfg.topk_capacity_log2 == 0) cfg.topk_capacity_log2 = 20;
     if (cfg.max_batch_records == 0 || cfg.max_batch_records > AGG_MAX_BATCH) cfg.max_batch_records = AGG_MAX_BATCH;
     uint32_t gran = cfg.subwindow_secs ? cfg.subwindow_secs : cfg.window_secs;
     if (cfg.device < 0 || cfg.device >= ndev || gran < 60 || 86400 % gran != 0 ||
         cfg.window_secs % gran != 0 || 86400 % cfg.window_secs != 0 || cfg.table_capacity_log2 < 10 ||
         cfg.table_capacity_log2 > 30 || cfg.cms_depth > 16 || cfg.cms_width_log2 < 4 ||
-        cfg.cms_width_log2 > 28 || (cfg.key_sets & ~7u)) {
+        cfg.cms_width_log2 > 28 || (cfg.key_sets & ~7u) || cfg.topk_capacity_log2 < 8 || cfg.topk_capacity_log2 > 30) {
         g_create_error = "fa_create: invalid configuration";
         return FA_ERR_ARG;
     }
@@ -215,6 +222,16 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
             if ((e = hipMemsetAsync(c->cms_dst, 0, c->cms_words * 8, c->stream)) != hipSuccess)
                 return bail("memset", e);
         }
+        c->ks_log2 = cfg.topk_capacity_log2;
+        const size_t ks_bytes = sizeof(KeySlot) << c->ks_log2;
+        if (cfg.key_sets & FA_KEYS_SRCADDR_CMS) {
+            if ((e = hipMalloc(&c->ks_src, ks_bytes)) != hipSuccess) return bail("hipMalloc(key set)", e);
+            if ((e = hipMemsetAsync(c->ks_src, 0, ks_bytes, c->stream)) != hipSuccess) return bail("memset", e);
+        }
+        if (cfg.key_sets & FA_KEYS_DSTADDR_CMS) {
+            if ((e = hipMalloc(&c->ks_dst, ks_bytes)) != hipSuccess) return bail("hipMalloc(key set)", e);
+            if ((e = hipMemsetAsync(c->ks_dst, 0, ks_bytes, c->stream)) != hipSuccess) return bail("memset", e);
+        }
     }
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("sync", e);
     c->stats.table_capacity = 1ull << c->cap_log2;
@@ -241,6 +258,8 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->d_rows);
     (void)hipFree(c->cms_src);
     (void)hipFree(c->cms_dst);
+    (void)hipFree(c->ks_src);
+    (void)hipFree(c->ks_dst);
     for (auto& p : c->ev_pool) {
         (void)hipEventDestroy(p.e0);
         (void)hipEventDestroy(p.e1);
@@ -332,7 +351,7 @@ extern "C" int fa_sync(fa_ctx* c) {
 }
 
 // ---- ingest ---------------------------------------------------------------------------
-// Launch order on the ctx stream: [probe] -> tile -> retry -> exotic -> [agg].
+// Launch order on the ctx stream: [probe] -> tile -> deferred -> [agg].
 template <int MODE>
 static int launch_tiles(fa_ctx* c, const KArgs& a, int grid, fa_ctx::LaunchEvents* ev = nullptr) {
     dim3 b(BLOCK);
@@ -344,8 +363,7 @@ static int launch_tiles(fa_ctx* c, const KArgs& a, int grid, fa_ctx::LaunchEvent
     case KS: {                                                                                  \
         hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);                     \
         if (ev) (void)hipEventRecord(ev->e1, c->stream);                                        \
-        hipLaunchKernelGGL((retry_kernel<MODE, KS>), ge, b, 0, c->stream, a);                   \
-        hipLaunchKernelGGL((exotic_kernel<MODE, KS>), ge, b, 0, c->stream, a);                  \
+        hipLaunchKernelGGL((deferred_kernel<MODE, KS>), ge, b, 0, c->stream, a);                \
         break;                                                                                  \
     }
     if constexpr (MODE == MODE_DECODE) {
@@ -357,7 +375,7 @@ static int launch_tiles(fa_ctx* c, const KArgs& a, int grid, fa_ctx::LaunchEvent
         }
     }
 #undef FA_LAUNCH
-    if (MODE == MODE_INGEST && a.seg) hipLaunchKernelGGL(agg_kernel, dim3(1u << a.plog2), dim3(AGG_BLOCK), 0, c->stream, a);
+    if (MODE == MODE_INGEST && a.seg) hipLaunchKernelGGL(agg_kernel, dim3((1u << a.plog2) * AGG_SPLIT), dim3(AGG_BLOCK), 0, c->stream, a);
     if (ev) (void)hipEventRecord(ev->e2, c->stream);
     HIPCHK(c, hipGetLastError());
     return FA_OK;
@@ -896,6 +914,8 @@ extern "C" int fa_cms_reset(fa_ctx* c, uint32_t key_set) {
     unsigned long long* p = cms_of(c, key_set);
     if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
     HIPCHK(c, hipMemsetAsync(p, 0, c->cms_words * 8, c->stream));
+    KeySlot* ks = key_set == FA_KEYS_SRCADDR_CMS ? c->ks_src : c->ks_dst;
+    if (ks) HIPCHK(c, hipMemsetAsync(ks, 0, sizeof(KeySlot) << c->ks_log2, c->stream));
     return FA_OK;
 }
 
@@ -924,8 +944,83 @@ extern "C" int fa_cms_query(fa_ctx* c, uint32_t key_set, const uint8_t key[16], 
     return FA_OK;
 }
 
-extern "C" int fa_topk(fa_ctx* c, uint32_t, size_t, fa_topk_row*, size_t, size_t*) {
-    return fail(c, FA_ERR_UNSUPPORTED, "fa_topk: candidate tracking lands with BASELINE config 3 (DESIGN.md, next)");
+extern "C" int fa_topk(fa_ctx* c, uint32_t key_set, size_t k, fa_topk_row* out, size_t cap, size_t* n_out) {
+    if (!c || !n_out || (!out && cap)) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    unsigned long long* cms = cms_of(c, key_set);
+    KeySlot* ks = key_set == FA_KEYS_SRCADDR_CMS ? c->ks_src : key_set == FA_KEYS_DSTADDR_CMS ? c->ks_dst : nullptr;
+    if (!cms || !ks) return fail(c, FA_ERR_ARG, "fa_topk: key set not enabled");
+    int rc = settle(c);
+    if (rc) return rc;
+    if (c->h_ctr->ks_overflow) return fail(c, FA_ERR_TABLE_FULL, "fa_topk: distinct-address set overflowed (raise topk_capacity_log2)");
+    const uint32_t nslots = 1u << c->ks_log2;
+    TopkRow* d_rows = nullptr;
+    if (hipMalloc(&d_rows, (size_t)nslots * sizeof(TopkRow)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "fa_topk: hipMalloc failed");
+    std::vector<TopkRow> rows;
+    hipError_t e = hipMemsetAsync(&c->d_ctr->ks_rows, 0, sizeof(unsigned int), c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(topk_rows_kernel, dim3(1024), dim3(256), 0, c->stream, ks, nslots, cms, c->cfg.cms_depth,
+                           c->cfg.cms_width_log2, c->cfg.cms_seed, d_rows, nslots, c->d_ctr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) {
+        rows.resize(c->h_ctr->ks_rows);
+        if (!rows.empty()) e = hipMemcpy(rows.data(), d_rows, rows.size() * sizeof(TopkRow), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_rows);
+    if (e != hipSuccess) {
+        c->err = std::string("fa_topk: ") + hipGetErrorString(e);
+        return FA_ERR_HIP;
+    }
+    // order: weight descending, then key bytes ascending (memcmp order of the FixedString(16))
+    auto key_less = [](const TopkRow& x, const TopkRow& y) {
+        uint8_t a[16], b[16];
+        memcpy(a, &x.lo, 8); memcpy(a + 8, &x.hi, 8);
+        memcpy(b, &y.lo, 8); memcpy(b + 8, &y.hi, 8);
+        return memcmp(a, b, 16) < 0;
+    };
+    auto row_less = [&](const TopkRow& x, const TopkRow& y) {
+        if (x.weight != y.weight) return x.weight > y.weight;
+        return key_less(x, y);
+    };
+    std::sort(rows.begin(), rows.end(), row_less);
+    // a key stored twice (see keyset_insert) has the same estimate twice: adjacent after the sort
+    rows.erase(std::unique(rows.begin(), rows.end(), [](const TopkRow& x, const TopkRow& y) { return x.lo == y.lo && x.hi == y.hi; }),
+               rows.end());
+    const size_t m = std::min(k, rows.size());
+    *n_out = m;
+    if (m > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
+    for (size_t i = 0; i < m; i++) {
+        memcpy(out[i].key, &rows[i].lo, 8);
+        memcpy(out[i].key + 8, &rows[i].hi, 8);
+        out[i].weight = rows[i].weight;
+    }
+    return FA_OK;
+}
+
+extern "C" int fa_topk_merge_keys(fa_ctx* c, uint32_t key_set, const uint8_t* keys, size_t n) {
+    if (!c || (!keys && n)) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    KeySlot* ks = key_set == FA_KEYS_SRCADDR_CMS ? c->ks_src : key_set == FA_KEYS_DSTADDR_CMS ? c->ks_dst : nullptr;
+    if (!ks) return fail(c, FA_ERR_ARG, "fa_topk_merge_keys: key set not enabled");
+    if (!n) return FA_OK;
+    uint4* d = nullptr;
+    if (hipMalloc(&d, n * 16) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc failed");
+    hipError_t e = hipMemcpyAsync(d, keys, n * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        KArgs a = make_args(c);
+        hipLaunchKernelGGL(keyset_merge_kernel, dim3(256), dim3(256), 0, c->stream, d, (uint32_t)n, ks, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        c->err = std::string("fa_topk_merge_keys: ") + hipGetErrorString(e);
+        return FA_ERR_HIP;
+    }
+    return FA_OK;
 }
 
 extern "C" int fa_device_state_get(fa_ctx* c, fa_device_state* out) {

@@ -11,8 +11,8 @@
 //   agg_kernel: one 1024-thread workgroup per key partition streams the partition's segments back,
 //      aggregates them in an LDS hash table (two packed 64-bit LDS atomics per tuple) and adds each
 //      group to the device-wide table once.
-//   Records parse_canon is not sure about go to retry_kernel (parse_fast, any field order) and from
-//   there to exotic_kernel (parse_generic, complete semantics); values that do not fit a tuple take
+//   Records parse_canon is not sure about go to deferred_kernel (parse_fast, any field order, then
+//   parse_generic, complete semantics); values that do not fit a tuple take
 //   the direct device-wide-table path (64-bit atomics).
 //
 // Roofline: HBM-bound integer/byte work; algorithmic bytes = wire bytes, read
@@ -36,7 +36,14 @@ constexpr int LDS_PROBES = 2;
 constexpr int PART_LOG2_MAX = 8;   // key partitions of the scatter sink (<= 256: see tools/scatter_bench.hip)
 constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
 constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table
-constexpr int AGG_SLOTS = 4096;    // 128 KiB of LDS: 32 B per slot
+#ifndef FA_AGG_SLOTS
+#define FA_AGG_SLOTS 4096
+#endif
+#ifndef FA_AGG_SPLIT
+#define FA_AGG_SPLIT 1
+#endif
+constexpr int AGG_SLOTS = FA_AGG_SLOTS;  // 32 B of LDS per slot (4096: 128 KiB)
+constexpr int AGG_SPLIT = FA_AGG_SPLIT;  // workgroups per key partition (each with its own LDS table)
 constexpr int AGG_PROBES = 16;
 constexpr uint32_t TUPLE_TB_SPAN = 16;        // time buckets a batch may span on the tuple path
 constexpr uint32_t TUPLE_MAX_BYTES = 1u << 28, TUPLE_MAX_PACKETS = 1u << 15, TUPLE_MAX_ETYPE = 1u << 16;
@@ -54,7 +61,18 @@ struct SpillEntry {
 
 struct Counters {
     unsigned long long ok, bad, slow, spill_lost, used, direct, retried;
-    unsigned int exotic_count, spill_count, rows_count, retry_count, tb_base, pad;
+    unsigned int exotic_count, spill_count, rows_count, retry_count, tb_base, ks_overflow, ks_rows, pad;
+};
+
+// Distinct-address set behind fa_topk (the dashboards rank EVERY address,
+// viz-ch.json:233,479).  32-byte slots; tag = 0 (empty) | bit 63 (claimed) | bit 62 (key written) |
+// 62 hash bits of the key.
+struct __attribute__((aligned(32))) KeySlot {
+    unsigned long long tag, lo, hi, pad;
+};
+constexpr unsigned long long KS_CLAIMED = 1ull << 63, KS_READY = 1ull << 62;
+struct TopkRow {
+    unsigned long long lo, hi, weight;
 };
 
 struct ColumnPtrs {
@@ -80,6 +98,9 @@ struct KArgs {
     unsigned long long* cms_dst;
     uint32_t cms_depth, cms_wl2;
     uint64_t cms_seed;
+    KeySlot* ks_src;  // distinct SrcAddr / DstAddr values seen (nullptr when the key set is off)
+    KeySlot* ks_dst;
+    uint32_t ks_mask;
     ColumnPtrs cols;
     uint32_t tile_recs;  // records per tile (<= BLOCK), chosen by the host from the mean record size
     uint32_t dbg;  // FA_DEBUG_FLAGS ablation switches (0 in production)
@@ -135,6 +156,63 @@ __device__ __forceinline__ void cms_add(unsigned long long* cms, uint32_t depth,
         uint64_t h = cms_hash(lo, hi, seed, r);
         atomicAdd(&cms[((size_t)r << wl2) + (size_t)(h >> (64 - wl2))], (unsigned long long)w);
     }
+}
+
+// Inserts a FixedString(16) key into the distinct-key set.  The per-XCD L2s are not coherent, so a plain
+// load may show an OLD version of a slot - harmless for the fast path (a slot never changes once its
+// key is written, so a complete match is always true), but everything else must come from the memory
+// side: the slot is claimed by CAS on its tag (hash of the key), the key words are written with
+// returning atomics, then the READY bit is set; a lane that needs to compare against a slot owned by
+// an equal tag reads the key words with atomics as well.  A lane that meets an equal tag whose key is
+// not written yet cannot compare and moves on, so a key may (rarely) be stored twice - fa_topk removes
+// duplicates.  The set is exact in content: a key is dropped only when the table is full, and that is
+// reported (ks_overflow -> FA_ERR_TABLE_FULL).
+__device__ __forceinline__ void keyset_insert(const KArgs& a, KeySlot* tab, const uint32_t key[4]) {
+    const unsigned long long lo = (unsigned long long)key[1] << 32 | key[0], hi = (unsigned long long)key[3] << 32 | key[2];
+    uint32_t h = key[0] * 0x9E3779B1u + key[1];
+    h ^= h >> 15;
+    h = (h ^ key[2]) * 0x85EBCA6Bu + key[3];
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    uint32_t g = (key[3] ^ 0x27D4EB2Fu) * 0x165667B1u + key[2];
+    g ^= g >> 15;
+    g = (g ^ key[1]) * 0xD3A2646Du + key[0];
+    g ^= g >> 14;
+    const unsigned long long mytag = KS_CLAIMED | (((unsigned long long)g << 32 | h) & (KS_READY - 1));
+    uint32_t i = h & a.ks_mask;
+    for (int probe = 0; probe < 256; probe++, i = (i + 1) & a.ks_mask) {
+        KeySlot* s = &tab[i];
+        // fast path: the key is already there.  System-scope loads are served by the memory side, past the
+        // (incoherent) per-XCD L2s; a slot never changes once READY, so a complete match is always true.
+        unsigned long long t = __hip_atomic_load(&s->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (t == (mytag | KS_READY)) {
+            const unsigned long long l = __hip_atomic_load(&s->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long q = __hip_atomic_load(&s->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (l == lo && q == hi) return;
+            continue;  // equal tag, different key
+        }
+        if (t != 0 && t != mytag) continue;  // somebody else's slot
+        bool done = false;
+        if (t == 0) {
+            t = atomicCAS(&s->tag, 0ull, mytag);
+            if (t == 0) {  // claimed: publish the key, then mark it readable
+                const unsigned long long o1 = atomicExch(&s->lo, lo), o2 = atomicExch(&s->hi, hi);
+                if ((o1 & o2) != ~0ull) atomicOr(&s->tag, KS_READY);  // (always true: orders the OR behind both writes)
+                done = true;
+            }
+        }
+        // (claimers of this wave have published by now; owners in other waves are a few instructions away)
+        if (!done && (t | KS_READY) == (mytag | KS_READY)) {
+            for (int spin = 0; spin < 4096 && !(t & KS_READY); spin++) t = atomicOr(&s->tag, 0ull);
+            if (t & KS_READY) {
+                const unsigned long long l = atomicAdd(&s->lo, 0ull), q = atomicAdd(&s->hi, 0ull);  // memory-side reads
+                done = l == lo && q == hi;
+            }
+        }
+        if (done) return;
+    }
+    atomicAdd(&a.ctr->ks_overflow, 1u);
 }
 
 __device__ __forceinline__ void store_columns(const ColumnPtrs& c, uint32_t idx, const Rec& r,
@@ -335,8 +413,14 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     }
     if (sure && (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
         const uint64_t w = r.bytes * r.sampling_rate;  // viz-ch.json:233 sum(Bytes*SamplingRate)
-        if (KEYSETS & FA_KEYS_SRCADDR_CMS) cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
-        if (KEYSETS & FA_KEYS_DSTADDR_CMS) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
+        if (KEYSETS & FA_KEYS_SRCADDR_CMS) {
+            cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
+            keyset_insert(a, a.ks_src, r.src);
+        }
+        if (KEYSETS & FA_KEYS_DSTADDR_CMS) {
+            cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
+            keyset_insert(a, a.ks_dst, r.dst);
+        }
     }
 }
 
@@ -455,10 +539,23 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     if (MODE == MODE_INGEST) {
         if (KEYSETS & FA_KEYS_AS_PAIR) {
             __syncthreads();
-            for (int i = tid; i < LDS_SLOTS; i += BLOCK) {
-                unsigned long long k0 = lt.k0[i], k1 = lt.k1[i], c = lt.count[i];
-                if (k0 != 0 && k1 != 0 && c != 0)
-                    agg_global(a, k0, k1, key_hash(k0, k1), lt.bytes[i], lt.packets[i], c);
+            // hot-key table -> device-wide table, one atomic line transaction per group (uniform trip count:
+            // the quad rounds need the whole wave)
+            for (int i0 = 0; i0 < LDS_SLOTS; i0 += BLOCK) {
+                const int i = i0 + tid;
+                Slot* sp = nullptr;
+                unsigned long long b = 0, p = 0, c = 0;
+                if (i < LDS_SLOTS) {
+                    const unsigned long long k0 = lt.k0[i], k1 = lt.k1[i];
+                    b = lt.bytes[i];
+                    p = lt.packets[i];
+                    c = lt.count[i];
+                    if (k0 != 0 && k1 != 0 && c != 0) {
+                        sp = table_find_or_claim(a, k0, k1, key_hash(k0, k1));
+                        if (!sp) spill_park(a, k0, k1, b, p, c);
+                    }
+                }
+                quad_atomic_update(sp, b, p, c);
             }
         }
         if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
@@ -501,13 +598,56 @@ __global__ __launch_bounds__(64) void probe_kernel(KArgs a) {
     if (threadIdx.x == 0) a.ctr->tb_base = lo == 0xffffffffu ? 0u : (lo > 2u ? lo - 2u : 0u);
 }
 
+// Records the tile kernel could not stage (broken offsets, tiles larger than the LDS buffer): complete
+// semantics, one record per lane straight from HBM.
+template <int MODE, uint32_t KEYSETS>
+__device__ __forceinline__ void exotic_pass(const KArgs& a) {
+    const uint32_t cnt = a.ctr->exotic_count;
+    for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < cnt; j += gridDim.x * BLOCK) {
+        uint32_t idx = a.exotic_idx[j];
+        const uint8_t* p = a.buf + a.off[idx];
+        const uint8_t* end = a.buf + a.off[idx + 1];
+        bool ok = end >= p;
+        if (ok && a.framed) ok = frame_generic(p, end);
+        Rec r;
+        if (ok)
+            ok = parse_generic(p, end, r);
+        if (!ok) rec_clear(r);
+        atomicAdd(&a.ctr->slow, 1ull);
+        if (MODE == MODE_DECODE) {
+            store_columns(a.cols, idx, r, ok ? 0 : 1);
+            continue;
+        }
+        if (!ok) {
+            atomicAdd(&a.ctr->bad, 1ull);
+            continue;
+        }
+        atomicAdd(&a.ctr->ok, 1ull);
+        if (KEYSETS & FA_KEYS_AS_PAIR) {
+            uint64_t k0, k1;
+            pack_key((uint32_t)r.time_received / a.gran, r.src_as, r.dst_as, r.etype, k0, k1);
+            agg_global(a, k0, k1, key_hash(k0, k1), r.bytes, r.packets, 1);
+        }
+        uint64_t w = r.bytes * r.sampling_rate;
+        if (KEYSETS & FA_KEYS_SRCADDR_CMS) {
+            cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
+            keyset_insert(a, a.ks_src, r.src);
+        }
+        if (KEYSETS & FA_KEYS_DSTADDR_CMS) {
+            cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
+            keyset_insert(a, a.ks_dst, r.dst);
+        }
+    }
+}
+
 // ---- second chance: records parse_canon deferred ---------------------------------------------
 // One record per lane straight from HBM/L2 with the order-free fast parser; what it is not sure
-// about moves on to exotic_kernel.  Updates go to the device-wide table after a wave-level combine
+// about is decided in place by the complete parser.  Updates go to the device-wide table after a wave-level combine
 // (this tier is about staying exact and tolerable on producers that do not emit canonical order).
 template <int MODE, uint32_t KEYSETS>
-__global__ __launch_bounds__(BLOCK) void retry_kernel(KArgs a) {
+__global__ __launch_bounds__(BLOCK) void deferred_kernel(KArgs a) {
     constexpr uint32_t COLS = MODE == MODE_DECODE ? (uint32_t)COL_ALL : cols_for_keysets<KEYSETS>();
+    exotic_pass<MODE, KEYSETS>(a);
     const uint32_t cnt = a.ctr->retry_count;
     const uint32_t rounds = (cnt + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
     uint32_t n_ok = 0;
@@ -528,9 +668,17 @@ __global__ __launch_bounds__(BLOCK) void retry_kernel(KArgs a) {
                 pos += pl;
             }
             if (sure) sure = parse_fast<COLS>(src, pos, end, r);
-            if (!sure) {
-                unsigned int e = atomicAdd(&a.ctr->exotic_count, 1u);
-                a.exotic_idx[e] = idx;
+            if (!sure) {  // third tier, in place: the complete parser decides
+                const uint8_t* p = a.buf + a.off[idx];
+                const uint8_t* pe = a.buf + a.off[idx + 1];
+                bool ok = pe >= p;
+                if (ok && a.framed) ok = frame_generic(p, pe);
+                if (ok) ok = parse_generic(p, pe, r);
+                if (!ok) rec_clear(r);
+                atomicAdd(&a.ctr->slow, 1ull);
+                if (MODE == MODE_DECODE) store_columns(a.cols, idx, r, ok ? 0 : 1);
+                else if (!ok) atomicAdd(&a.ctr->bad, 1ull);
+                sure = ok && MODE != MODE_DECODE;
             }
         }
         if (MODE == MODE_DECODE) {
@@ -548,8 +696,14 @@ __global__ __launch_bounds__(BLOCK) void retry_kernel(KArgs a) {
         }
         if (sure && (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
             const uint64_t w = r.bytes * r.sampling_rate;
-            if (KEYSETS & FA_KEYS_SRCADDR_CMS) cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
-            if (KEYSETS & FA_KEYS_DSTADDR_CMS) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
+            if (KEYSETS & FA_KEYS_SRCADDR_CMS) {
+                cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
+                keyset_insert(a, a.ks_src, r.src);
+            }
+            if (KEYSETS & FA_KEYS_DSTADDR_CMS) {
+                cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
+                keyset_insert(a, a.ks_dst, r.dst);
+            }
         }
     }
     if (MODE == MODE_INGEST) {
@@ -568,7 +722,7 @@ __global__ __launch_bounds__(BLOCK) void retry_kernel(KArgs a) {
 struct AggTable {
     unsigned long long k0[AGG_SLOTS], k1[AGG_SLOTS], s1[AGG_SLOTS], s2[AGG_SLOTS];
 };
-static_assert(sizeof(AggTable) == 131072, "agg_kernel LDS table");
+static_assert(sizeof(AggTable) == 32 * AGG_SLOTS, "agg_kernel LDS table");
 
 // slow path of the LDS upsert: claim / probe; false = the table is full around this hash
 __device__ __forceinline__ bool agg_lds_upsert(AggTable& lt, uint64_t k0, uint64_t k1, uint32_t h, uint32_t by,
@@ -590,7 +744,11 @@ __device__ __forceinline__ bool agg_lds_upsert(AggTable& lt, uint64_t k0, uint64
 }
 
 constexpr int AGG_MAX_NWG = 2048;  // tile-kernel workgroups (256 CUs x at most 8 per CU)
-constexpr int AGG_SU = 4;  // segments a wave reads at a time (16-byte loads in flight per lane, x2 buffers)
+#ifndef FA_AGG_SU
+#define FA_AGG_SU 4
+#endif
+constexpr int AGG_SU = FA_AGG_SU;  // segments a wave reads at a time (16-byte loads in flight per lane, x2 buffers)
+constexpr int AGG_CH = 4;  // tuples of a batch that are hashed / probed together
 
 struct AggBatch {
     uint4 t[AGG_SU];
@@ -625,21 +783,22 @@ __device__ __forceinline__ void agg_tuple(const KArgs& a, AggTable& lt, uint32_t
 
 // The common case (the key already sits in its home slot) for all AGG_SU tuples at once, so that the LDS
 // round trips of the segments overlap; everything else goes through the probing upsert.
-__device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b) {
-    uint64_t k0[AGG_SU], k1[AGG_SU];
-    uint32_t h[AGG_SU];
-    unsigned long long c0[AGG_SU], c1[AGG_SU];
+template <int S0>
+__device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b) {
+    uint64_t k0[AGG_CH], k1[AGG_CH];
+    uint32_t h[AGG_CH];
+    unsigned long long c0[AGG_CH], c1[AGG_CH];
     if (a.dbg & DBG_AGG_NO_LDS) {  // ablation: consume the loads only
         uint32_t x = 0;
 #pragma unroll
-        for (int s = 0; s < AGG_SU; s++) x ^= b.t[s].x ^ b.t[s].y ^ b.t[s].z ^ b.t[s].w;
+        for (int s = 0; s < AGG_CH; s++) x ^= b.t[S0 + s].x ^ b.t[S0 + s].y ^ b.t[S0 + s].z ^ b.t[S0 + s].w;
         if (x == 0x12345678u) lt.s1[lane] = x;
         return;
     }
 #pragma unroll
-    for (int s = 0; s < AGG_SU; s++) {
-        const uint32_t tbr = b.t[s].z >> 28, et = b.t[s].w >> 15;
-        pack_key(tb_base + tbr, b.t[s].x, b.t[s].y, et, k0[s], k1[s]);
+    for (int s = 0; s < AGG_CH; s++) {
+        const uint32_t tbr = b.t[S0 + s].z >> 28, et = b.t[S0 + s].w >> 15;
+        pack_key(tb_base + tbr, b.t[S0 + s].x, b.t[S0 + s].y, et, k0[s], k1[s]);
         h[s] = key_hash(k0[s], k1[s]);
         const uint32_t i = h[s] & (AGG_SLOTS - 1);
         c0[s] = lt.k0[i];
@@ -647,9 +806,9 @@ __device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32
     }
     uint32_t pending = 0;  // segments whose tuple is not in its home slot (probing / claiming needed)
 #pragma unroll
-    for (int s = 0; s < AGG_SU; s++) {
-        if (lane >= b.c[s]) continue;
-        const uint32_t by = b.t[s].z & 0x0fffffffu, pk = b.t[s].w & 0x7fffu;
+    for (int s = 0; s < AGG_CH; s++) {
+        if (lane >= b.c[S0 + s]) continue;
+        const uint32_t by = b.t[S0 + s].z & 0x0fffffffu, pk = b.t[S0 + s].w & 0x7fffu;
         const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
         const uint32_t i = h[s] & (AGG_SLOTS - 1);
         if (c0[s] == k0[s] && c1[s] == k1[s]) {
@@ -660,22 +819,22 @@ __device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32
         }
     }
     if (a.dbg & DBG_AGG_NO_SLOW) return;
-    // the leftovers of all AGG_SU segments share one loop: a lane works on its first pending tuple
+    // the leftovers of the AGG_CH segments share one loop: a lane works on its first pending tuple
     // per round, so the wave pays max-over-lanes(pending tuples) upserts instead of one per segment
     while (__builtin_amdgcn_ballot_w64(pending != 0) != 0ull) {
         if (pending != 0) {
             const uint32_t s = (uint32_t)__builtin_ctz(pending);
             pending &= pending - 1u;
             uint64_t sk0 = k0[0], sk1 = k1[0];
-            uint32_t sh = h[0], sz = b.t[0].z, sw = b.t[0].w;
+            uint32_t sh = h[0], sz = b.t[S0].z, sw = b.t[S0].w;
 #pragma unroll
-            for (int j = 1; j < AGG_SU; j++) {
+            for (int j = 1; j < AGG_CH; j++) {
                 const bool pick = s == (uint32_t)j;
                 sk0 = pick ? k0[j] : sk0;
                 sk1 = pick ? k1[j] : sk1;
                 sh = pick ? h[j] : sh;
-                sz = pick ? b.t[j].z : sz;
-                sw = pick ? b.t[j].w : sw;
+                sz = pick ? b.t[S0 + j].z : sz;
+                sw = pick ? b.t[S0 + j].w : sw;
             }
             const uint32_t by = sz & 0x0fffffffu, pk = sw & 0x7fffu;
             const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
@@ -685,10 +844,15 @@ __device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32
     }
 }
 
+__device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b) {
+    agg_consume_chunk<0>(a, lt, tb_base, lane, b);
+    if (AGG_SU > AGG_CH) agg_consume_chunk<AGG_SU - AGG_CH>(a, lt, tb_base, lane, b);
+}
+
 __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     __shared__ AggTable lt;
     __shared__ uint32_t pc[AGG_MAX_NWG + AGG_SU];  // this partition's segment counts, zero padded
-    const uint32_t part = blockIdx.x;
+    const uint32_t part = blockIdx.x / AGG_SPLIT, sub = blockIdx.x % AGG_SPLIT;
     for (int i = threadIdx.x; i < AGG_SLOTS; i += AGG_BLOCK) {
         lt.k0[i] = 0;
         lt.k1[i] = 0;
@@ -700,13 +864,13 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     const uint32_t tb_base = a.ctr->tb_base;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint4* pbase = a.seg + (size_t)part * a.region;
-    constexpr uint32_t STEP = (AGG_BLOCK / 64) * AGG_SU;
+    constexpr uint32_t STEP = (AGG_BLOCK / 64) * AGG_SU * AGG_SPLIT;
     __syncthreads();  // table cleared, counts staged
     // software pipeline over this wave's segment groups: the next group's loads fly during the LDS work
     // (every fetch is unconditional - clamped addresses, zero counts past the end - so that the compiler
     // can count the loads in flight and wait for the older batch only)
     AggBatch b0, b1;
-    uint32_t w0 = wave * AGG_SU;
+    uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * AGG_SU;
     agg_fetch(a, pbase, pc, w0, lane, b0);
     while (true) {
         agg_fetch(a, pbase, pc, w0 + STEP, lane, b1);
@@ -717,7 +881,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
         if (w0 >= a.nwg) break;
     }
     // segments longer than one wave pass (rare: the mean is <= 43 tuples)
-    for (uint32_t w = wave; w < a.nwg; w += AGG_BLOCK / 64) {
+    for (uint32_t w = sub * (AGG_BLOCK / 64) + wave; w < a.nwg; w += (AGG_BLOCK / 64) * AGG_SPLIT) {
         const uint32_t c = pc[w];
         for (uint32_t q = 64 + lane; q < c; q += 64) agg_tuple(a, lt, tb_base, pbase[(size_t)w * a.capq + q]);
     }
@@ -735,41 +899,6 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
             if (!sp) spill_park(a, k0, k1, b, p, c);
         }
         quad_atomic_update(sp, b, p, c);
-    }
-}
-
-// Deferred records: complete semantics, one record per lane straight from HBM.
-template <int MODE, uint32_t KEYSETS>
-__global__ __launch_bounds__(BLOCK) void exotic_kernel(KArgs a) {
-    const uint32_t cnt = a.ctr->exotic_count;
-    for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < cnt; j += gridDim.x * BLOCK) {
-        uint32_t idx = a.exotic_idx[j];
-        const uint8_t* p = a.buf + a.off[idx];
-        const uint8_t* end = a.buf + a.off[idx + 1];
-        bool ok = end >= p;
-        if (ok && a.framed) ok = frame_generic(p, end);
-        Rec r;
-        if (ok)
-            ok = parse_generic(p, end, r);
-        if (!ok) rec_clear(r);
-        atomicAdd(&a.ctr->slow, 1ull);
-        if (MODE == MODE_DECODE) {
-            store_columns(a.cols, idx, r, ok ? 0 : 1);
-            continue;
-        }
-        if (!ok) {
-            atomicAdd(&a.ctr->bad, 1ull);
-            continue;
-        }
-        atomicAdd(&a.ctr->ok, 1ull);
-        if (KEYSETS & FA_KEYS_AS_PAIR) {
-            uint64_t k0, k1;
-            pack_key((uint32_t)r.time_received / a.gran, r.src_as, r.dst_as, r.etype, k0, k1);
-            agg_global(a, k0, k1, key_hash(k0, k1), r.bytes, r.packets, 1);
-        }
-        uint64_t w = r.bytes * r.sampling_rate;
-        if (KEYSETS & FA_KEYS_SRCADDR_CMS) cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
-        if (KEYSETS & FA_KEYS_DSTADDR_CMS) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
     }
 }
 
@@ -821,6 +950,32 @@ __global__ void merge_rows_kernel(const Row5m* rows, uint32_t n, KArgs a) {
         uint64_t k0, k1;
         pack_key(rows[i].timeslot / a.gran, rows[i].src_as, rows[i].dst_as, rows[i].etype, k0, k1);
         agg_global(a, k0, k1, key_hash(k0, k1), rows[i].bytes, rows[i].packets, rows[i].count);
+    }
+}
+
+// ---- heavy hitters ---------------------------------------------------------------------------
+// One row per stored key: its Count-Min estimate = min over the sketch rows (>= the exact
+// sum(Bytes*SamplingRate), viz-ch.json:233).  The host sorts, removes duplicate keys and cuts at k.
+__global__ void topk_rows_kernel(const KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth,
+                                 uint32_t wl2, uint64_t seed, TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) {
+        if ((ks[i].tag & KS_READY) == 0) continue;
+        const unsigned long long lo = ks[i].lo, hi = ks[i].hi;
+        unsigned long long best = ~0ull;
+        for (uint32_t r = 0; r < depth; r++) {
+            const unsigned long long v = cms[((size_t)r << wl2) + (size_t)(cms_hash(lo, hi, seed, r) >> (64 - wl2))];
+            best = v < best ? v : best;
+        }
+        const unsigned int j = atomicAdd(&ctr->ks_rows, 1u);
+        if (j < rows_cap) rows[j] = TopkRow{lo, hi, best};
+    }
+}
+
+// keys found by other GPUs / Kafka partitions join this context's candidate set (window close)
+__global__ void keyset_merge_kernel(const uint4* keys, uint32_t n, KeySlot* tab, KArgs a) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t k[4] = {keys[i].x, keys[i].y, keys[i].z, keys[i].w};
+        keyset_insert(a, tab, k);
     }
 }
 

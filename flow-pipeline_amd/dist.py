@@ -103,3 +103,44 @@ def allreduce_sketches(agg, group=None):
             t = torch.as_tensor(_DevArray(ptr, st.cms_words), device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     torch.cuda.synchronize()
+
+
+def allgather_bytes(arr: np.ndarray, group=None, device=None):
+    """All ranks receive every rank's uint8 payload (list indexed by rank)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    flat = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1)
+    n = torch.tensor([flat.size], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    mine = torch.zeros(max(max(counts), 1), dtype=torch.uint8)
+    mine[:flat.size] = torch.from_numpy(flat.copy())
+    mine = mine.to(dev)
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine, group=group)
+    return [b.cpu().numpy()[:c].copy() for c, b in zip(counts, bufs)]
+
+
+def merge_topk_candidates(parts, k_keep=None) -> np.ndarray:
+    """Union of per-rank candidate keys (uint8[n,16] each), duplicates removed, sorted."""
+    keys = [np.ascontiguousarray(p, dtype=np.uint8).reshape(-1, 16) for p in parts if len(p)]
+    if not keys:
+        return np.zeros((0, 16), dtype=np.uint8)
+    allk = np.unique(np.concatenate(keys).view([("k", "u1", 16)]).reshape(-1))
+    return allk.view(np.uint8).reshape(-1, 16)
+
+
+def topk_merged(agg, key_set, k, candidates_per_rank=None, group=None, device=None):
+    """Heavy hitters across ranks at window close: all-reduce the sketches (dense, exact), exchange
+    every rank's local candidates (its top `candidates_per_rank` keys; all distinct keys when None),
+    add the union to the local set and rank by the merged estimate.  With candidates_per_rank=None
+    the result equals the single-GPU result bit for bit."""
+    ncand = candidates_per_rank if candidates_per_rank is not None else (1 << 30)
+    local = agg.topk(key_set, ncand)
+    allreduce_sketches(agg, group=group)
+    parts = allgather_bytes(local["key"], group=group, device=device)
+    agg.topk_merge_keys(key_set, merge_topk_candidates(parts))
+    return agg.topk(key_set, k)

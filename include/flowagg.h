@@ -68,7 +68,8 @@ typedef struct {
     int32_t framed;               /* 1: each record is varint(len)||payload (-proto.fixedlen=true,
                                      mocker.go:98-101); 0: bare payload (mocker.go:96-97) */
     uint32_t max_batch_records;   /* upper bound on n per ingest launch; 0 or > 1<<24 -> 1<<24 */
-    uint32_t reserved[5];
+    uint32_t topk_capacity_log2;  /* slots of each distinct-address set behind fa_topk (32 B each); 0 -> 20 */
+    uint32_t reserved[4];
 } fa_config;
 
 /* One flows_5m row, scalar columns (create.sh:70-90). */
@@ -156,13 +157,19 @@ int fa_close_window(fa_ctx*, uint32_t timeslot, fa_row5m* out, size_t cap, size_
 int fa_read_window(fa_ctx*, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out);
 
 /* ---- heavy hitters -------------------------------------------------------- */
-/* key_set: FA_KEYS_SRCADDR_CMS or FA_KEYS_DSTADDR_CMS.  Rows sorted by weight
- * descending, ties by key ascending. */
+/* key_set: FA_KEYS_SRCADDR_CMS or FA_KEYS_DSTADDR_CMS.  The k addresses with the largest Count-Min
+ * estimate of sum(Bytes*SamplingRate) (viz-ch.json:233,479) among ALL distinct addresses ingested
+ * since the last fa_cms_reset; rows sorted by weight descending, ties by key bytes ascending.
+ * Deterministic (independent of ingestion order).  FA_ERR_TABLE_FULL if the distinct-address set
+ * overflowed (cfg.topk_capacity_log2). */
 int fa_topk(fa_ctx*, uint32_t key_set, size_t k, fa_topk_row* out, size_t cap, size_t* n_out);
+/* Adds candidate keys found elsewhere (another GPU / Kafka partition) to this ctx's distinct-address
+ * set, so that fa_topk after fa_merge_allreduce ranks the union.  keys: n * 16 bytes (host). */
+int fa_topk_merge_keys(fa_ctx*, uint32_t key_set, const uint8_t* keys, size_t n);
 int fa_cms_query(fa_ctx*, uint32_t key_set, const uint8_t key[16], uint64_t* weight);
 /* Copies the raw sketch (depth * 2^width_log2 uint64) to host. */
 int fa_cms_read(fa_ctx*, uint32_t key_set, uint64_t* out, size_t cap_words);
-int fa_cms_reset(fa_ctx*, uint32_t key_set);
+int fa_cms_reset(fa_ctx*, uint32_t key_set); /* sketch and distinct-address set */
 
 /* ---- multi-GPU merge at window close (one ctx per GPU / Kafka partition) --- */
 /* Exposes the device-resident mergeable state so the host can run collectives

@@ -369,3 +369,51 @@ def test_scatter_sink_hot_keys_and_many_batches(gpu_lib, fa, po, monkeypatch):
         st = agg.stats()
     assert st["records_ok"] == 250000
     assert got.tobytes() == ref.rows().tobytes()
+
+
+def test_topk_matches_oracle(gpu_lib, fa, po):
+    """fa_topk = every distinct address ranked by its Count-Min estimate of sum(Bytes*SamplingRate)
+    (viz-ch.json:233,479): identical to the CPU sketch + exhaustive ranking, and an over-estimate of
+    the exact GROUP BY the dashboard runs."""
+    n = 60000
+    gp = po.gen_params(mode=2, framed=1, seed=31, n_total=n, zipf_log2_universe=11)
+    buf, off = po.gen_records(gp, 0, n)
+    truth = po.gen_rows(gp, 0, n)
+    depth, wl2, seed = 4, 10, 0xBEEF
+    for col, ks in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+        cms = np.zeros(depth << wl2, dtype=np.uint64)
+        exact = {}
+        for k in range(n):
+            w = (int(truth["bytes"][k]) * int(truth["sampling_rate"][k])) & (2**64 - 1)
+            key = bytes(truth[col][k])
+            po.cms_update(cms, depth, wl2, seed, key, w)
+            exact[key] = (exact.get(key, 0) + w) & (2**64 - 1)
+        want = sorted(((po.cms_query(cms, depth, wl2, seed, key), key) for key in exact), key=lambda t: (-t[0], t[1]))
+        with fa.FlowAgg(framed=True, key_sets=fa.FA_KEYS_AS_PAIR | ks, cms_depth=depth, cms_width_log2=wl2,
+                        cms_seed=seed, topk_capacity_log2=14) as agg:
+            agg.ingest(buf, off)
+            got = agg.topk(ks, 100)
+            everything = agg.topk(ks, 1 << 20)
+            # candidates from "another partition": unseen keys join the set and are ranked by the sketch
+            extra = np.frombuffer(bytes(range(32)), dtype=np.uint8).reshape(2, 16)
+            agg.topk_merge_keys(ks, extra)
+            merged = agg.topk(ks, 1 << 20)
+        assert len(got) == 100 and len(everything) == len(exact)
+        for row, (w, key) in zip(got, want[:100]):
+            assert bytes(row["key"]) == key and int(row["weight"]) == w
+        assert all(int(r["weight"]) >= exact[bytes(r["key"])] for r in everything)  # CMS never under-estimates
+        assert len(merged) == len(exact) + 2
+        for r in merged:
+            if bytes(r["key"]) in (bytes(extra[0]), bytes(extra[1])):
+                assert int(r["weight"]) == po.cms_query(cms, depth, wl2, seed, bytes(r["key"]))
+
+
+def test_topk_reports_overflow(gpu_lib, fa, po):
+    n = 40000
+    gp = po.gen_params(mode=2, framed=1, seed=32, n_total=n, zipf_log2_universe=16)
+    buf, off = po.gen_records(gp, 0, n)
+    with fa.FlowAgg(framed=True, key_sets=fa.FA_KEYS_SRCADDR_CMS, topk_capacity_log2=8) as agg:
+        agg.ingest(buf, off)
+        with pytest.raises(fa.FlowAggError) as ei:
+            agg.topk(fa.FA_KEYS_SRCADDR_CMS, 10)
+        assert ei.value.code == -5
