@@ -28,6 +28,18 @@ sys.path.insert(0, ROOT)
 import _pkg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# HBM bytes per launch from rocprofv3 PMC passes of THIS command line (tools/profile.sh; PMC counters
+# cannot be read from inside the process).  Only quoted when the workload is the default one profiled.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")
+
+
+def pmc_traffic(default_workload):
+    if not default_workload or not os.path.exists(TRAFFIC_FILE):
+        return None, None
+    with open(TRAFFIC_FILE) as f:
+        t = json.load(f)
+    k = t.get("kernels", {})
+    return k.get("tile_kernel", {}).get("traffic_bytes"), k
 
 
 def mix64(z):
@@ -148,6 +160,8 @@ def main():
     assert args.no_assert or ok_total == expect, "merged count() %d != records ingested %d" % (ok_total, expect)
 
     value = n_rec * args.steps * world / elapsed
+    traffic, traffic_all = pmc_traffic(args.records == 100_000_000 and args.chunk == 16_666_667 and args.mode == "aspairs"
+                                       and not os.environ.get("FA_DEBUG_FLAGS"))
     out = {
         "metric": "FlowMessages/sec aggregated into flows_5m",
         "value": value,
@@ -183,7 +197,9 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": "profiles/r01_traffic.json: rocprofv3 --pmc, 2*FETCH_SIZE (gfx950 wide-read "
+                              "correction) + WRITE_SIZE, bytes per launch" if traffic else None,
             "kernel": "fa::tile_kernel<MODE_INGEST, AS_PAIR>",
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": avg_launch_s * 1e3,
@@ -192,6 +208,7 @@ def main():
             "all_kernels_avg_ms": avg_batch_s * 1e3,
             "all_kernels_achieved": achieved_batch,
             "all_kernels_frac": achieved_batch / HBM_PEAK_GBS,
+            "agg_kernel_traffic": (traffic_all or {}).get("agg_kernel", {}).get("traffic_bytes"),
         },
     }
 

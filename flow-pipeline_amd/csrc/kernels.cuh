@@ -53,7 +53,7 @@ static_assert(TILE_STRIDE % 16 == 0, "LDS tile buffers must stay 16-byte aligned
 enum { MODE_INGEST = 0, MODE_DECODE = 1 };
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
-       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256 };
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512 };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -248,6 +248,7 @@ constexpr uint32_t cols_for_keysets() {
 // Copies nbytes (rounded up to 16) from 16-byte-aligned global memory into an LDS
 // buffer with `global_load_lds_dwordx4`: 1 KiB per wave-instruction, no VGPR round
 // trip, asynchronous (tracked by vmcnt).  Lanes past the end are masked off.
+template <int AUX = 0>
 __device__ __forceinline__ void dma_to_lds(const uint8_t* g, uint32_t nbytes, uint32_t* lds) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t npieces = (nbytes + 1023u) >> 10;
@@ -256,7 +257,7 @@ __device__ __forceinline__ void dma_to_lds(const uint8_t* g, uint32_t nbytes, ui
         if (o < nbytes) {
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(g + o),
-                (__attribute__((address_space(3))) void*)(lds + p * 256u), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(lds + p * 256u), 16, 0, AUX);
         }
     }
 }
@@ -478,7 +479,12 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
 
     for (; t < ntiles; t += stride) {
         // (1) stream this tile's wire bytes into LDS (async DMA) ...
-        if (cur.fits) dma_to_lds(a.buf + (cur.lo & ~15u), cur.hi - (cur.lo & ~15u), tile);
+        if (cur.fits) {
+            // nt: the wire bytes are read exactly once; keeping them out of the way of the L2's open tuple lines
+            // is worth 11 % of the launch (MI355X, tools/knobs.sh FA_DEBUG_FLAGS=512)
+            if (a.dbg & DBG_DMA_NO_NT) dma_to_lds<0>(a.buf + (cur.lo & ~15u), cur.hi - (cur.lo & ~15u), tile);
+            else dma_to_lds<2>(a.buf + (cur.lo & ~15u), cur.hi - (cur.lo & ~15u), tile);
+        }
         // ... and meanwhile fetch the next tile's descriptor and offsets
         const TileDesc nxt = tile_desc(a, t + stride, ntiles);
         uint32_t n0 = 0, n1 = 0;

@@ -47,3 +47,31 @@ for sub in sorted(os.listdir(out)):
             if counter == "FETCH_SIZE":
                 extra += "  | x2 gfx950 wide-read correction = %.1f MB" % (avg * 2 * 1024 / 1e6)
             print("%-56s launches=%-4d avg=%14.1f%s  avg_dur=%.1f us" % (name[:56], n, avg, extra, dur / 1e3))
+
+# machine-readable HBM traffic of the two hot-path kernels (bench.py's roofline.traffic reads the copy
+# committed under profiles/): reads = FETCH_SIZE x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md
+# "HBM"), writes = WRITE_SIZE as reported (1:1 on coalesced dword stores: gen_len_kernel writes 4 B per
+# record and reports exactly that).
+import json
+
+traffic = {}
+for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    d = db(sub)
+    if not d:
+        continue
+    q = ("select kernel_name, count(*), avg(value), avg(duration) from counters_collection "
+         "where counter_name=? group by kernel_name")
+    for name, n, avg, dur in d.execute(q, (counter,)):
+        key = "tile_kernel" if "tile_kernel<0" in name else "agg_kernel" if "agg_kernel" in name else None
+        if key:
+            traffic.setdefault(key, {})[counter] = avg * 1024.0
+            traffic[key]["launches"] = n
+            traffic[key]["avg_dur_us_under_pmc"] = dur / 1e3
+for k, v in traffic.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        v["read_bytes_corrected"] = 2.0 * v["FETCH_SIZE"]
+        v["traffic_bytes"] = 2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]
+if traffic:
+    with open(os.path.join(out, "traffic.json"), "w") as f:
+        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/profile.sh",
+                   "bench_args": os.environ.get("PROF_BENCH_ARGS", ""), "kernels": traffic}, f, indent=1)

@@ -19,5 +19,5 @@ if [ -n "$PROF_SQ" ]; then
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM -d $OUT/pmc_sq3 -o sq3 -- python $ROOT/bench.py $ARGS > $OUT/pmc_sq3.log 2>&1
 fi
 cd $ROOT
-python $ROOT/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+PROF_BENCH_ARGS="$ARGS" python $ROOT/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
