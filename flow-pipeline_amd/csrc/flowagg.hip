@@ -242,6 +242,11 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
 extern "C" void fa_destroy(fa_ctx* c) {
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if ((c->dbg & DBG_TIMING) && c->d_ctr && c->h_ctr && hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost) == hipSuccess &&
+        c->h_ctr->t_tiles)
+        fprintf(stderr, "[flowagg timing] per tile (wave 0 of every workgroup, core clocks): wait %.0f  work %.0f  | tiles %llu  total/wg-launch %.0f\n",
+                (double)c->h_ctr->t_wait / (double)c->h_ctr->t_tiles, (double)c->h_ctr->t_work / (double)c->h_ctr->t_tiles,
+                (unsigned long long)c->h_ctr->t_tiles, (double)c->h_ctr->t_total);
     (void)hipFree(c->tab);
     (void)hipFree(c->spill);
     (void)hipFree(c->d_ctr);

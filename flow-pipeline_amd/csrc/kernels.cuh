@@ -53,7 +53,7 @@ static_assert(TILE_STRIDE % 16 == 0, "LDS tile buffers must stay 16-byte aligned
 enum { MODE_INGEST = 0, MODE_DECODE = 1 };
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
-       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512 };
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024 };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -62,6 +62,7 @@ struct SpillEntry {
 struct Counters {
     unsigned long long ok, bad, slow, spill_lost, used, direct, retried;
     unsigned int exotic_count, spill_count, rows_count, retry_count, tb_base, ks_overflow, ks_rows, pad;
+    unsigned long long t_wait, t_work, t_tiles, t_total;  // DBG_TIMING: core-clock cycles of wave 0 of every workgroup
 };
 
 // Distinct-address set behind fa_topk (the dashboards rank EVERY address,
@@ -477,7 +478,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     }
     __syncthreads();  // LDS table cleared
 
+    const bool timing = (a.dbg & DBG_TIMING) != 0 && tid == 0;
+    unsigned long long tm_wait = 0, tm_work = 0, tm_tiles = 0, tm_start = timing ? clock64() : 0ull;
     for (; t < ntiles; t += stride) {
+        const unsigned long long tm0 = timing ? clock64() : 0ull;
         // (1) stream this tile's wire bytes into LDS (async DMA) ...
         if (cur.fits) {
             // nt: the wire bytes are read exactly once; keeping them out of the way of the L2's open tuple lines
@@ -494,6 +498,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
         }
         dma_wait_all();
         __syncthreads();
+        const unsigned long long tm1 = timing ? clock64() : 0ull;
 
         // (2) parse + aggregate out of LDS
         if (cur.fits) {
@@ -538,9 +543,21 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
             }
         }
         __syncthreads();  // everyone is done reading the tile
+        if (timing) {
+            const unsigned long long tm2 = clock64();
+            tm_wait += tm1 - tm0;
+            tm_work += tm2 - tm1;
+            tm_tiles++;
+        }
         cur = nxt;
         o0 = n0;
         o1 = n1;
+    }
+    if (timing) {
+        atomicAdd(&a.ctr->t_wait, tm_wait);
+        atomicAdd(&a.ctr->t_work, tm_work);
+        atomicAdd(&a.ctr->t_tiles, tm_tiles);
+        atomicAdd(&a.ctr->t_total, clock64() - tm_start);
     }
     if (MODE == MODE_INGEST) {
         if (KEYSETS & FA_KEYS_AS_PAIR) {
