@@ -28,6 +28,9 @@ if os.environ.get("FA_LIB_VARIANT"):  # A/B experiments only (tools/): libflowag
 FA_KEYS_AS_PAIR = 1
 FA_KEYS_SRCADDR_CMS = 2
 FA_KEYS_DSTADDR_CMS = 4
+FA_KEYS_ADDR_PORT_PROTO = 8
+FA_KEYS_PORT_HIST = 16
+FA_KEYS_MINUTE_SERIES = 32
 ALL_TIMESLOTS = 0xFFFFFFFF
 
 MOCK_MOCKER, MOCK_ASPAIRS, MOCK_ZIPF = 0, 1, 2
@@ -51,7 +54,7 @@ class Config(C.Structure):
         ("table_capacity_log2", C.c_uint32), ("cms_depth", C.c_uint32),
         ("cms_width_log2", C.c_uint32), ("cms_seed", C.c_uint64), ("key_sets", C.c_uint32),
         ("framed", C.c_int32), ("max_batch_records", C.c_uint32), ("topk_capacity_log2", C.c_uint32),
-        ("reserved", C.c_uint32 * 4),
+        ("wide_capacity_log2", C.c_uint32), ("reserved", C.c_uint32 * 3),
     ]
 
 
@@ -59,7 +62,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "records_ok", "records_bad", "records_slow", "bytes_in", "batches", "table_used",
         "table_capacity", "kernel_ns", "kernel_ns_total", "kernel_launches", "batch_ns_total",
-        "records_direct", "records_retried")]
+        "records_direct", "records_retried", "wide_used", "wide_capacity")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -81,7 +84,8 @@ class Columns(C.Structure):
 
 
 class DeviceState(C.Structure):
-    _fields_ = [("cms_src", C.c_void_p), ("cms_dst", C.c_void_p), ("cms_words", C.c_size_t)]
+    _fields_ = [("cms_src", C.c_void_p), ("cms_dst", C.c_void_p), ("cms_words", C.c_size_t),
+                ("port_hist", C.c_void_p), ("port_hist_words", C.c_size_t)]
 
 
 ROW5M_DTYPE = np.dtype([
@@ -96,7 +100,14 @@ FLOW_ROW_DTYPE = np.dtype([
     ("src_addr", "u1", 16), ("dst_addr", "u1", 16),
 ])
 TOPK_DTYPE = np.dtype([("key", "u1", 16), ("weight", "<u8")])
+ROW_APP_DTYPE = np.dtype([
+    ("date", "<u4"), ("timeslot", "<u4"), ("src_addr", "u1", 16), ("dst_port", "<u4"), ("proto", "<u4"),
+    ("bytes", "<u8"), ("packets", "<u8"), ("count", "<u8"),
+])
+PORT_ROW_DTYPE = np.dtype([("port", "<u4"), ("_pad", "<u4"), ("weight", "<u8"), ("count", "<u8")])
+MINUTE_ROW_DTYPE = np.dtype([("minute", "<u4"), ("_pad", "<u4"), ("weight", "<u8"), ("count", "<u8")])
 assert ROW5M_DTYPE.itemsize == 48 and FLOW_ROW_DTYPE.itemsize == 120
+assert ROW_APP_DTYPE.itemsize == 56 and PORT_ROW_DTYPE.itemsize == 24 and MINUTE_ROW_DTYPE.itemsize == 24
 
 # every symbol include/flowagg.h declares (checked by the CPU test-suite)
 EXPORTS = [
@@ -105,6 +116,8 @@ EXPORTS = [
     "fa_read_window", "fa_topk", "fa_topk_merge_keys", "fa_cms_query", "fa_cms_read", "fa_cms_reset",
     "fa_device_state_get", "fa_merge_rows", "fa_merge_allreduce", "fa_stats",
     "fa_mock_generate_device", "fa_mock_generate_host",
+    "fa_read_window_app", "fa_close_window_app", "fa_merge_rows_app", "fa_top_ports", "fa_merge_ports",
+    "fa_minute_series", "fa_merge_minutes", "fa_dashboard_reset",
 ]
 
 _LIB = None
@@ -157,6 +170,14 @@ def lib():
     L.fa_stats.argtypes = [vp, C.POINTER(Stats)]
     L.fa_mock_generate_device.argtypes = [vp, C.POINTER(MockParams), u64, u64, vp, sz, vp, C.POINTER(u64)]
     L.fa_mock_generate_host.argtypes = [C.POINTER(MockParams), u64, u64, vp, sz, vp, C.POINTER(u64)]
+    L.fa_read_window_app.argtypes = [vp, u32, vp, sz, szp]
+    L.fa_close_window_app.argtypes = [vp, u32, vp, sz, szp]
+    L.fa_merge_rows_app.argtypes = [vp, vp, sz]
+    L.fa_top_ports.argtypes = [vp, C.c_int, sz, vp, sz, szp]
+    L.fa_merge_ports.argtypes = [vp, C.c_int, vp, sz]
+    L.fa_minute_series.argtypes = [vp, vp, sz, szp]
+    L.fa_merge_minutes.argtypes = [vp, vp, sz]
+    L.fa_dashboard_reset.argtypes = [vp]
     _LIB = L
     return L
 
@@ -184,11 +205,11 @@ class FlowAgg:
 
     def __init__(self, device=0, window_secs=300, subwindow_secs=0, table_capacity_log2=20,
                  key_sets=FA_KEYS_AS_PAIR, framed=True, cms_depth=4, cms_width_log2=20,
-                 cms_seed=0x5EED, max_batch_records=0, topk_capacity_log2=0):
+                 cms_seed=0x5EED, max_batch_records=0, topk_capacity_log2=0, wide_capacity_log2=0):
         self._L = lib()
         self.cfg = Config(device, window_secs, subwindow_secs, table_capacity_log2, cms_depth,
                           cms_width_log2, cms_seed, key_sets, 1 if framed else 0, max_batch_records,
-                          topk_capacity_log2)
+                          topk_capacity_log2, wide_capacity_log2)
         h = C.c_void_p()
         rc = self._L.fa_create(C.byref(self.cfg), C.byref(h))
         if rc:
@@ -246,11 +267,11 @@ class FlowAgg:
         return cols
 
     # -- window close ---------------------------------------------------------------
-    def _rows_call(self, fn, timeslot):
+    def _rows_call(self, fn, timeslot, dtype=ROW5M_DTYPE):
         n = C.c_size_t()
         cap = 1 << 12
         while True:
-            out = np.zeros(cap, dtype=ROW5M_DTYPE)
+            out = np.zeros(cap, dtype=dtype)
             rc = fn(self._h, timeslot, out.ctypes.data, cap, C.byref(n))
             if rc == -6:  # FA_ERR_CAPACITY: n holds the required size
                 cap = n.value
@@ -279,6 +300,54 @@ class FlowAgg:
     def merge_rows(self, rows: np.ndarray):
         r = np.ascontiguousarray(rows, dtype=ROW5M_DTYPE)
         self._chk(self._L.fa_merge_rows(self._h, r.ctypes.data, len(r)))
+
+    # -- second exact key set: (SrcAddr, DstPort, Proto) -------------------------------
+    def read_window_app(self, timeslot=ALL_TIMESLOTS) -> np.ndarray:
+        return self._rows_call(self._L.fa_read_window_app, timeslot, ROW_APP_DTYPE)
+
+    def close_window_app(self, timeslot=ALL_TIMESLOTS) -> np.ndarray:
+        return self._rows_call(self._L.fa_close_window_app, timeslot, ROW_APP_DTYPE)
+
+    def merge_rows_app(self, rows: np.ndarray):
+        r = np.ascontiguousarray(rows, dtype=ROW_APP_DTYPE)
+        self._chk(self._L.fa_merge_rows_app(self._h, r.ctypes.data, len(r)))
+
+    # -- dashboard read side -------------------------------------------------------------
+    def top_ports(self, dst: int, k=1 << 32) -> np.ndarray:
+        """GROUP BY SrcPort (dst=0) / DstPort (dst=1) ORDER BY sum(Bytes*SamplingRate) DESC, first k rows."""
+        n = C.c_size_t()
+        cap = 1 << 12
+        while True:
+            out = np.zeros(cap, dtype=PORT_ROW_DTYPE)
+            rc = self._L.fa_top_ports(self._h, dst, min(int(k), 1 << 40), out.ctypes.data, cap, C.byref(n))
+            if rc == -6:
+                cap = n.value
+                continue
+            self._chk(rc)
+            return out[:n.value].copy()
+
+    def merge_ports(self, dst: int, rows: np.ndarray):
+        r = np.ascontiguousarray(rows, dtype=PORT_ROW_DTYPE)
+        self._chk(self._L.fa_merge_ports(self._h, dst, r.ctypes.data, len(r)))
+
+    def minute_series(self) -> np.ndarray:
+        n = C.c_size_t()
+        cap = 1 << 10
+        while True:
+            out = np.zeros(cap, dtype=MINUTE_ROW_DTYPE)
+            rc = self._L.fa_minute_series(self._h, out.ctypes.data, cap, C.byref(n))
+            if rc == -6:
+                cap = n.value
+                continue
+            self._chk(rc)
+            return out[:n.value].copy()
+
+    def merge_minutes(self, rows: np.ndarray):
+        r = np.ascontiguousarray(rows, dtype=MINUTE_ROW_DTYPE)
+        self._chk(self._L.fa_merge_minutes(self._h, r.ctypes.data, len(r)))
+
+    def dashboard_reset(self):
+        self._chk(self._L.fa_dashboard_reset(self._h))
 
     # -- sketches -------------------------------------------------------------------
     def cms_read(self, key_set) -> np.ndarray:

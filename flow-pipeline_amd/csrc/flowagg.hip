@@ -72,6 +72,14 @@ struct fa_ctx {
     KeySlot* ks_dst = nullptr;
     uint32_t ks_log2 = 20;
 
+    // wide key sets (wide.cuh): one table + the dense port histograms
+    WSlot* wtab = nullptr;
+    uint32_t wcap_log2 = 20;
+    WSpillEntry* wspill = nullptr;
+    uint32_t wspill_cap = 1u << 18;
+    uint64_t wused_base = 0;
+    ulonglong2* port_hist = nullptr;  // [2][PORT_DENSE]
+
     fa_stats_t stats{};
     uint64_t used_base = 0;  // groups created before the current counter epoch
     std::string err;
@@ -120,6 +128,12 @@ static KArgs make_args(fa_ctx* c) {
     a.dbg = c->dbg;
     a.tile_recs = BLOCK;
     a.retry_idx = c->d_exotic ? c->d_exotic + c->exotic_cap : nullptr;
+    a.key_sets = c->cfg.key_sets;
+    a.wtab = c->wtab;
+    a.wmask = (1u << c->wcap_log2) - 1;
+    a.wspill = c->wspill;
+    a.wspill_cap = c->wspill_cap;
+    a.port_hist = c->port_hist;
     a.gran_recip = (1.0 / (double)c->gran) * (1.0 + 1.0 / 1099511627776.0);
     return a;
 }
@@ -167,12 +181,14 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (cfg.cms_width_log2 == 0) cfg.cms_width_log2 = 20;
     if (cfg.key_sets == 0) cfg.key_sets = FA_KEYS_AS_PAIR;
     if (cfg.topk_capacity_log2 == 0) cfg.topk_capacity_log2 = 20;
+    if (cfg.wide_capacity_log2 == 0) cfg.wide_capacity_log2 = 20;
     if (cfg.max_batch_records == 0 || cfg.max_batch_records > AGG_MAX_BATCH) cfg.max_batch_records = AGG_MAX_BATCH;
     uint32_t gran = cfg.subwindow_secs ? cfg.subwindow_secs : cfg.window_secs;
     if (cfg.device < 0 || cfg.device >= ndev || gran < 60 || 86400 % gran != 0 ||
         cfg.window_secs % gran != 0 || 86400 % cfg.window_secs != 0 || cfg.table_capacity_log2 < 10 ||
         cfg.table_capacity_log2 > 30 || cfg.cms_depth > 16 || cfg.cms_width_log2 < 4 ||
-        cfg.cms_width_log2 > 28 || (cfg.key_sets & ~7u) || cfg.topk_capacity_log2 < 8 || cfg.topk_capacity_log2 > 30) {
+        cfg.cms_width_log2 > 28 || (cfg.key_sets & ~63u) || cfg.topk_capacity_log2 < 8 || cfg.topk_capacity_log2 > 30 ||
+        cfg.wide_capacity_log2 < 8 || cfg.wide_capacity_log2 > 30) {
         g_create_error = "fa_create: invalid configuration";
         return FA_ERR_ARG;
     }
@@ -233,6 +249,19 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
             if ((e = hipMemsetAsync(c->ks_dst, 0, ks_bytes, c->stream)) != hipSuccess) return bail("memset", e);
         }
     }
+    if (cfg.key_sets & FA_KEYS_WIDE) {
+        c->wcap_log2 = cfg.wide_capacity_log2;
+        const size_t wbytes = sizeof(WSlot) << c->wcap_log2;
+        if ((e = hipMalloc(&c->wtab, wbytes)) != hipSuccess) return bail("hipMalloc(wide table)", e);
+        if ((e = hipMemsetAsync(c->wtab, 0, wbytes, c->stream)) != hipSuccess) return bail("memset", e);
+        if ((e = hipMalloc(&c->wspill, sizeof(WSpillEntry) * c->wspill_cap)) != hipSuccess) return bail("hipMalloc(wide spill)", e);
+        c->stats.wide_capacity = 1ull << c->wcap_log2;
+    }
+    if (cfg.key_sets & FA_KEYS_PORT_HIST) {
+        const size_t hbytes = sizeof(ulonglong2) * 2 * PORT_DENSE;
+        if ((e = hipMalloc(&c->port_hist, hbytes)) != hipSuccess) return bail("hipMalloc(port histograms)", e);
+        if ((e = hipMemsetAsync(c->port_hist, 0, hbytes, c->stream)) != hipSuccess) return bail("memset", e);
+    }
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("sync", e);
     c->stats.table_capacity = 1ull << c->cap_log2;
     *out = c;
@@ -265,6 +294,9 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->cms_dst);
     (void)hipFree(c->ks_src);
     (void)hipFree(c->ks_dst);
+    (void)hipFree(c->wtab);
+    (void)hipFree(c->wspill);
+    (void)hipFree(c->port_hist);
     for (auto& p : c->ev_pool) {
         (void)hipEventDestroy(p.e0);
         (void)hipEventDestroy(p.e1);
@@ -294,6 +326,62 @@ static int rebuild_table(fa_ctx* c, uint32_t new_log2, uint32_t tb_lo, uint32_t 
     HIPCHK(c, hipFree(old));
     c->used_base = 0;
     c->stats.table_capacity = 1ull << c->cap_log2;
+    return FA_OK;
+}
+
+// Wide table: fresh table of 2^new_log2 slots holding every row that is not selected by
+// (kind_mask, [tb_lo,tb_hi)) - see wrow_selected().
+static int rebuild_wide(fa_ctx* c, uint32_t new_log2, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi) {
+    WSlot* nt = nullptr;
+    size_t bytes = sizeof(WSlot) << new_log2;
+    if (hipMalloc(&nt, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "rebuild_wide: hipMalloc failed");
+    HIPCHK(c, hipMemsetAsync(nt, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->d_ctr->wused, 0, sizeof(unsigned long long), c->stream));
+    WSlot* old = c->wtab;
+    uint32_t old_slots = 1u << c->wcap_log2;
+    c->wtab = nt;
+    c->wcap_log2 = new_log2;
+    KArgs a = make_args(c);
+    hipLaunchKernelGGL(wrebuild_kernel, dim3(1024), dim3(256), 0, c->stream, old, old_slots, kind_mask, tb_lo, tb_hi, a);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(old));
+    c->wused_base = 0;
+    c->stats.wide_capacity = 1ull << c->wcap_log2;
+    return FA_OK;
+}
+
+// grows the wide table / replays parked updates until nothing is pending (h = fresh copy of the counters)
+static int settle_wide(fa_ctx* c, Counters& h) {
+    if (!c->wtab) return FA_OK;
+    c->stats.wide_used = c->wused_base + h.wused;
+    if (h.wspill_lost) {
+        c->sticky = FA_ERR_TABLE_FULL;
+        return fail(c, FA_ERR_TABLE_FULL, "wide-key table and its spill buffer overflowed; aggregates were lost");
+    }
+    int guard = 0;
+    while (h.wspill_count || c->stats.wide_used * 2 > (1ull << c->wcap_log2)) {
+        if (c->wcap_log2 >= 30 || ++guard > 8) return fail(c, FA_ERR_TABLE_FULL, "wide-key table cannot grow further");
+        const uint32_t nspill = h.wspill_count;
+        int rc = rebuild_wide(c, c->wcap_log2 + 1, 0, 0, 0 /* nothing selected: keep everything */);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(&c->d_ctr->wspill_count, 0, sizeof(unsigned int), c->stream));
+        if (nspill) {
+            WSpillEntry* tmp = nullptr;
+            HIPCHK(c, hipMalloc(&tmp, sizeof(WSpillEntry) * nspill));
+            HIPCHK(c, hipMemcpyAsync(tmp, c->wspill, sizeof(WSpillEntry) * nspill, hipMemcpyDeviceToDevice, c->stream));
+            KArgs a = make_args(c);
+            static_assert(sizeof(WSpillEntry) == sizeof(WRow), "spill entries replay as rows");
+            hipLaunchKernelGGL(wmerge_kernel, dim3(256), dim3(256), 0, c->stream, (const WRow*)tmp, nspill, a);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipFree(tmp));
+        }
+        HIPCHK(c, hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost));
+        h = *c->h_ctr;
+        c->stats.wide_used = c->wused_base + h.wused;
+        if (h.wspill_lost) return fail(c, FA_ERR_TABLE_FULL, "wide spill buffer overflowed during replay");
+    }
     return FA_OK;
 }
 
@@ -346,7 +434,7 @@ static int settle(fa_ctx* c) {
         c->stats.table_used = c->used_base + h.used;
         if (h.spill_lost) return fail(c, FA_ERR_TABLE_FULL, "spill buffer overflowed during replay");
     }
-    return FA_OK;
+    return settle_wide(c, h);
 }
 
 extern "C" int fa_sync(fa_ctx* c) {
@@ -376,7 +464,11 @@ static int launch_tiles(fa_ctx* c, const KArgs& a, int grid, fa_ctx::LaunchEvent
     } else {
         switch (c->cfg.key_sets) {
             FA_LAUNCH(1u) FA_LAUNCH(2u) FA_LAUNCH(3u) FA_LAUNCH(4u) FA_LAUNCH(5u) FA_LAUNCH(6u) FA_LAUNCH(7u)
-        default: return fail(c, FA_ERR_ARG, "bad key_sets");
+        default:  // any wide key set: the generic variant (runtime mask)
+            hipLaunchKernelGGL((tile_kernel<MODE, KS_ALL>), g, b, 0, c->stream, a);
+            if (ev) (void)hipEventRecord(ev->e1, c->stream);
+            hipLaunchKernelGGL((deferred_kernel<MODE, KS_ALL>), ge, b, 0, c->stream, a);
+            break;
         }
     }
 #undef FA_LAUNCH
@@ -396,7 +488,8 @@ static int tile_grid(fa_ctx* c, uint32_t n, uint32_t tile_recs) {
     case 4u: return grid_for(c, tile_kernel<MODE_INGEST, 4u>, n, tile_recs);
     case 5u: return grid_for(c, tile_kernel<MODE_INGEST, 5u>, n, tile_recs);
     case 6u: return grid_for(c, tile_kernel<MODE_INGEST, 6u>, n, tile_recs);
-    default: return grid_for(c, tile_kernel<MODE_INGEST, 7u>, n, tile_recs);
+    case 7u: return grid_for(c, tile_kernel<MODE_INGEST, 7u>, n, tile_recs);
+    default: return grid_for(c, tile_kernel<MODE_INGEST, KS_ALL>, n, tile_recs);
     }
 }
 
@@ -896,6 +989,274 @@ extern "C" int fa_merge_rows(fa_ctx* c, const fa_row5m* rows, size_t n) {
     return settle(c);
 }
 
+// ---- wide key sets: window close and dashboard reads -----------------------------------------------
+// Collects the selected rows of the wide table into a host vector (unsorted).
+static int collect_wide(fa_ctx* c, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, std::vector<WRow>& rows) {
+    rows.clear();
+    if (!c->wtab) return fail(c, FA_ERR_ARG, "key set not enabled");
+    int rc = settle(c);
+    if (rc) return rc;
+    size_t need = std::max<uint64_t>(c->stats.wide_used, 1024);
+    WRow* d = nullptr;
+    if (hipMalloc(&d, need * sizeof(WRow)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide rows) failed");
+    hipError_t e = hipMemsetAsync(&c->d_ctr->wrows_count, 0, sizeof(unsigned int), c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(wextract_kernel, dim3(1024), dim3(256), 0, c->stream, c->wtab, 1u << c->wcap_log2, kind_mask, tb_lo,
+                           tb_hi, d, (uint32_t)need, c->d_ctr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    size_t n = e == hipSuccess ? c->h_ctr->wrows_count : 0;
+    if (e == hipSuccess && n > need) {
+        (void)hipFree(d);
+        return fail(c, FA_ERR_HIP, "internal: wide row buffer too small");
+    }
+    if (e == hipSuccess && n) {
+        rows.resize(n);
+        e = hipMemcpy(rows.data(), d, n * sizeof(WRow), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        c->err = std::string("collect_wide: ") + hipGetErrorString(e);
+        return FA_ERR_HIP;
+    }
+    return FA_OK;
+}
+
+// rows (already packed keys) -> device -> wmerge_kernel
+static int merge_wide(fa_ctx* c, const std::vector<WRow>& rows) {
+    if (!c->wtab) return fail(c, FA_ERR_ARG, "key set not enabled");
+    if (rows.empty()) return FA_OK;
+    WRow* d = nullptr;
+    if (hipMalloc(&d, rows.size() * sizeof(WRow)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc failed");
+    hipError_t e = hipMemcpyAsync(d, rows.data(), rows.size() * sizeof(WRow), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        KArgs a = make_args(c);
+        hipLaunchKernelGGL(wmerge_kernel, dim3(256), dim3(256), 0, c->stream, d, (uint32_t)rows.size(), a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        c->err = std::string("merge_wide: ") + hipGetErrorString(e);
+        return FA_ERR_HIP;
+    }
+    return settle(c);
+}
+
+static bool app_less(const fa_row_app& x, const fa_row_app& y) {
+    if (x.date != y.date) return x.date < y.date;
+    if (x.timeslot != y.timeslot) return x.timeslot < y.timeslot;
+    int m = memcmp(x.src_addr, y.src_addr, 16);
+    if (m) return m < 0;
+    if (x.dst_port != y.dst_port) return x.dst_port < y.dst_port;
+    return x.proto < y.proto;
+}
+
+static int window_rows_app(fa_ctx* c, uint32_t timeslot, std::vector<fa_row_app>& out, uint32_t& lo, uint32_t& hi) {
+    out.clear();
+    if (!(c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO)) return fail(c, FA_ERR_ARG, "FA_KEYS_ADDR_PORT_PROTO not enabled");
+    if (!bucket_range(c, timeslot, lo, hi)) {
+        lo = hi = 0;
+        return FA_OK;
+    }
+    std::vector<WRow> raw;
+    int rc = collect_wide(c, 1u << WK_APP, lo, hi, raw);
+    if (rc) return rc;
+    out.resize(raw.size());
+    for (size_t i = 0; i < raw.size(); i++) {
+        uint32_t kind, tb, port, proto;
+        uint64_t alo, ahi;
+        wkey_unpack(raw[i].w, kind, tb, alo, ahi, port, proto);
+        fa_row_app& r = out[i];
+        r.timeslot = (timeslot != 0xFFFFFFFFu && c->gran != c->cfg.window_secs) ? timeslot : tb * c->gran;
+        r.date = r.timeslot / 86400u;
+        memcpy(r.src_addr, &alo, 8);
+        memcpy(r.src_addr + 8, &ahi, 8);
+        r.dst_port = port;
+        r.proto = proto;
+        r.bytes = raw[i].v0;
+        r.packets = raw[i].v1;
+        r.count = raw[i].v2;
+    }
+    std::sort(out.begin(), out.end(), app_less);
+    size_t w = 0;  // fold the sub-buckets of a sliding window
+    for (size_t i = 0; i < out.size(); i++) {
+        if (w && !app_less(out[w - 1], out[i]) && !app_less(out[i], out[w - 1])) {
+            out[w - 1].bytes += out[i].bytes;
+            out[w - 1].packets += out[i].packets;
+            out[w - 1].count += out[i].count;
+        } else {
+            out[w++] = out[i];
+        }
+    }
+    out.resize(w);
+    return FA_OK;
+}
+
+extern "C" int fa_read_window_app(fa_ctx* c, uint32_t timeslot, fa_row_app* out, size_t cap, size_t* n_out) {
+    if (!c || !n_out) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    std::vector<fa_row_app> rows;
+    uint32_t lo, hi;
+    int rc = window_rows_app(c, timeslot, rows, lo, hi);
+    if (rc) return rc;
+    *n_out = rows.size();
+    if (rows.size() > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
+    if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(fa_row_app));
+    return FA_OK;
+}
+
+extern "C" int fa_close_window_app(fa_ctx* c, uint32_t timeslot, fa_row_app* out, size_t cap, size_t* n_out) {
+    if (!c || !n_out) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    std::vector<fa_row_app> rows;
+    uint32_t lo, hi;
+    int rc = window_rows_app(c, timeslot, rows, lo, hi);
+    if (rc) return rc;
+    *n_out = rows.size();
+    if (rows.size() > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
+    if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(fa_row_app));
+    if (lo == hi) return FA_OK;
+    uint32_t rm_hi = (timeslot != 0xFFFFFFFFu && c->gran != c->cfg.window_secs) ? lo + 1 : hi;
+    return rebuild_wide(c, c->wcap_log2, 1u << WK_APP, lo, rm_hi);
+}
+
+extern "C" int fa_merge_rows_app(fa_ctx* c, const fa_row_app* rows, size_t n) {
+    if (!c || (!rows && n)) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    if (!(c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO)) return fail(c, FA_ERR_ARG, "FA_KEYS_ADDR_PORT_PROTO not enabled");
+    std::vector<WRow> w(n);
+    for (size_t i = 0; i < n; i++) {
+        if (rows[i].timeslot % c->gran) return fail(c, FA_ERR_ARG, "fa_merge_rows_app: timeslot not on this ctx's bucket grid");
+        uint64_t lo, hi;
+        memcpy(&lo, rows[i].src_addr, 8);
+        memcpy(&hi, rows[i].src_addr + 8, 8);
+        WKey k;
+        wkey_pack(WK_APP, rows[i].timeslot / c->gran, lo, hi, rows[i].dst_port, rows[i].proto, k);
+        w[i] = WRow{{k.w[0], k.w[1], k.w[2], k.w[3]}, rows[i].bytes, rows[i].packets, rows[i].count};
+    }
+    return merge_wide(c, w);
+}
+
+extern "C" int fa_top_ports(fa_ctx* c, int dst, size_t k, fa_port_row* out, size_t cap, size_t* n_out) {
+    if (!c || !n_out || (!out && cap) || (dst != 0 && dst != 1)) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    if (!c->port_hist) return fail(c, FA_ERR_ARG, "FA_KEYS_PORT_HIST not enabled");
+    std::vector<WRow> big;
+    int rc = collect_wide(c, 1u << (dst ? WK_DSTPORT : WK_SRCPORT), 0, 0, big);  // settles the stream
+    if (rc) return rc;
+    std::vector<ulonglong2> dense(PORT_DENSE);
+    HIPCHK(c, hipMemcpy(dense.data(), c->port_hist + (size_t)dst * PORT_DENSE, sizeof(ulonglong2) * PORT_DENSE, hipMemcpyDeviceToHost));
+    std::vector<fa_port_row> rows;
+    for (uint32_t p = 0; p < PORT_DENSE; p++)
+        if (dense[p].y) rows.push_back(fa_port_row{p, 0, dense[p].x, dense[p].y});
+    for (auto& r : big) {
+        uint32_t kind, tb, port, proto;
+        uint64_t lo, hi;
+        wkey_unpack(r.w, kind, tb, lo, hi, port, proto);
+        rows.push_back(fa_port_row{port, 0, r.v0, r.v2});
+    }
+    std::sort(rows.begin(), rows.end(), [](const fa_port_row& x, const fa_port_row& y) {
+        if (x.weight != y.weight) return x.weight > y.weight;
+        return x.port < y.port;
+    });
+    const size_t m = std::min(k, rows.size());
+    *n_out = m;
+    if (m > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
+    if (m) memcpy(out, rows.data(), m * sizeof(fa_port_row));
+    return FA_OK;
+}
+
+__global__ void port_merge_kernel(const fa_port_row* rows, uint32_t n, ulonglong2* hist) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        unsigned long long* e = reinterpret_cast<unsigned long long*>(&hist[rows[i].port]);
+        if (rows[i].weight) atomicAdd(e, (unsigned long long)rows[i].weight);
+        atomicAdd(e + 1, (unsigned long long)rows[i].count);
+    }
+}
+
+extern "C" int fa_merge_ports(fa_ctx* c, int dst, const fa_port_row* rows, size_t n) {
+    if (!c || (!rows && n) || (dst != 0 && dst != 1)) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    if (!c->port_hist) return fail(c, FA_ERR_ARG, "FA_KEYS_PORT_HIST not enabled");
+    std::vector<fa_port_row> small;
+    std::vector<WRow> big;
+    for (size_t i = 0; i < n; i++) {
+        if (rows[i].port < PORT_DENSE) {
+            small.push_back(rows[i]);
+        } else {
+            WKey k;
+            wkey_pack(dst ? WK_DSTPORT : WK_SRCPORT, 0, 0, 0, rows[i].port, 0, k);
+            big.push_back(WRow{{k.w[0], k.w[1], k.w[2], k.w[3]}, rows[i].weight, 0, rows[i].count});
+        }
+    }
+    if (!small.empty()) {
+        fa_port_row* d = nullptr;
+        if (hipMalloc(&d, small.size() * sizeof(fa_port_row)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc failed");
+        hipError_t e = hipMemcpyAsync(d, small.data(), small.size() * sizeof(fa_port_row), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(port_merge_kernel, dim3(64), dim3(256), 0, c->stream, d, (uint32_t)small.size(),
+                               c->port_hist + (size_t)dst * PORT_DENSE);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d);
+        if (e != hipSuccess) {
+            c->err = std::string("fa_merge_ports: ") + hipGetErrorString(e);
+            return FA_ERR_HIP;
+        }
+    }
+    return merge_wide(c, big);
+}
+
+extern "C" int fa_minute_series(fa_ctx* c, fa_minute_row* out, size_t cap, size_t* n_out) {
+    if (!c || !n_out || (!out && cap)) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    if (!(c->cfg.key_sets & FA_KEYS_MINUTE_SERIES)) return fail(c, FA_ERR_ARG, "FA_KEYS_MINUTE_SERIES not enabled");
+    std::vector<WRow> raw;
+    int rc = collect_wide(c, 1u << WK_MINUTE, 0, 0, raw);
+    if (rc) return rc;
+    std::vector<fa_minute_row> rows(raw.size());
+    for (size_t i = 0; i < raw.size(); i++) {
+        uint32_t kind, tb, port, proto;
+        uint64_t lo, hi;
+        wkey_unpack(raw[i].w, kind, tb, lo, hi, port, proto);
+        rows[i] = fa_minute_row{port * 60u, 0, raw[i].v0, raw[i].v2};
+    }
+    std::sort(rows.begin(), rows.end(), [](const fa_minute_row& x, const fa_minute_row& y) { return x.minute < y.minute; });
+    *n_out = rows.size();
+    if (rows.size() > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
+    if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(fa_minute_row));
+    return FA_OK;
+}
+
+extern "C" int fa_merge_minutes(fa_ctx* c, const fa_minute_row* rows, size_t n) {
+    if (!c || (!rows && n)) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    if (!(c->cfg.key_sets & FA_KEYS_MINUTE_SERIES)) return fail(c, FA_ERR_ARG, "FA_KEYS_MINUTE_SERIES not enabled");
+    std::vector<WRow> w(n);
+    for (size_t i = 0; i < n; i++) {
+        if (rows[i].minute % 60u) return fail(c, FA_ERR_ARG, "fa_merge_minutes: not a minute boundary");
+        WKey k;
+        wkey_pack(WK_MINUTE, 0, 0, 0, rows[i].minute / 60u, 0, k);
+        w[i] = WRow{{k.w[0], k.w[1], k.w[2], k.w[3]}, rows[i].weight, 0, rows[i].count};
+    }
+    return merge_wide(c, w);
+}
+
+extern "C" int fa_dashboard_reset(fa_ctx* c) {
+    if (!c) return FA_ERR_ARG;
+    if (c->sticky) return c->sticky;
+    int rc = settle(c);
+    if (rc) return rc;
+    if (c->port_hist) HIPCHK(c, hipMemsetAsync(c->port_hist, 0, sizeof(ulonglong2) * 2 * PORT_DENSE, c->stream));
+    if (c->wtab && (c->cfg.key_sets & (FA_KEYS_PORT_HIST | FA_KEYS_MINUTE_SERIES)))
+        return rebuild_wide(c, c->wcap_log2, (1u << WK_SRCPORT) | (1u << WK_DSTPORT) | (1u << WK_MINUTE), 0, 0);
+    return FA_OK;
+}
+
 // ---- sketches -----------------------------------------------------------------------------------
 static unsigned long long* cms_of(fa_ctx* c, uint32_t key_set) {
     if (key_set == FA_KEYS_SRCADDR_CMS) return c->cms_src;
@@ -1035,6 +1396,8 @@ extern "C" int fa_device_state_get(fa_ctx* c, fa_device_state* out) {
     out->cms_src = c->cms_src;
     out->cms_dst = c->cms_dst;
     out->cms_words = c->cms_words;
+    out->port_hist = c->port_hist;
+    out->port_hist_words = c->port_hist ? (size_t)4 * PORT_DENSE : 0;
     return FA_OK;
 }
 
@@ -1057,6 +1420,8 @@ extern "C" int fa_merge_allreduce(fa_ctx* c, void* comm) {
         return fail(c, FA_ERR_HIP, "ncclAllReduce(cms_src) failed");
     if (c->cms_dst && fn(c->cms_dst, c->cms_dst, c->cms_words, ncclUint64, ncclSum, comm, c->stream) != 0)
         return fail(c, FA_ERR_HIP, "ncclAllReduce(cms_dst) failed");
+    if (c->port_hist && fn(c->port_hist, c->port_hist, (size_t)4 * PORT_DENSE, ncclUint64, ncclSum, comm, c->stream) != 0)
+        return fail(c, FA_ERR_HIP, "ncclAllReduce(port histograms) failed");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FA_OK;
 }
@@ -1081,7 +1446,7 @@ extern "C" int fa_mock_generate_device(fa_ctx* c, const fa_mock_params* g, uint6
     do {
         hipLaunchKernelGGL(gen_len_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, *g, i0, (uint32_t)n, len);
         if (hipMemsetAsync(len + n, 0, 4, c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
-        hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, len, off, (int)(n + 1), c->stream);
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, len, off, (int)(n + 1), c->stream);
         if (hipMalloc(&tmp, tmp_bytes) != hipSuccess) { rc = FA_ERR_NOMEM; break; }
         if (hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, len, off, (int)(n + 1), c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
         uint32_t total = 0;

@@ -23,6 +23,7 @@
 
 #include "gen.cuh"
 #include "table.cuh"
+#include "wide.cuh"
 #include "wire.cuh"
 
 namespace fa {
@@ -51,6 +52,11 @@ constexpr uint32_t AGG_MAX_BATCH = 1u << 24;  // count <= 2^24 per slot keeps th
 static_assert(TILE_STRIDE % 16 == 0, "LDS tile buffers must stay 16-byte aligned");
 
 enum { MODE_INGEST = 0, MODE_DECODE = 1 };
+// Kernel variants are compiled for the key-set masks 1..7 (rollup and/or sketches); every other
+// combination runs the KS_ALL variant, which parses the union of the columns and tests the runtime mask.
+constexpr uint32_t KS_ALL = 0xFFu;
+constexpr uint32_t FA_KEYS_WIDE = FA_KEYS_ADDR_PORT_PROTO | FA_KEYS_PORT_HIST | FA_KEYS_MINUTE_SERIES;
+constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense histograms
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
        DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024 };
@@ -63,6 +69,8 @@ struct Counters {
     unsigned long long ok, bad, slow, spill_lost, used, direct, retried;
     unsigned int exotic_count, spill_count, rows_count, retry_count, tb_base, ks_overflow, ks_rows, pad;
     unsigned long long t_wait, t_work, t_tiles, t_total;  // DBG_TIMING: core-clock cycles of wave 0 of every workgroup
+    unsigned long long wused, wspill_lost;  // wide table (wide.cuh)
+    unsigned int wspill_count, wrows_count;
 };
 
 // Distinct-address set behind fa_topk (the dashboards rank EVERY address,
@@ -114,7 +122,23 @@ struct KArgs {
     uint32_t nwg;          // workgroups of the tile kernel that filled the segments
     unsigned long long region;  // tuples per partition (nwg*capq plus a skew against power-of-two strides)
     uint32_t plog2;        // log2(key partitions)
+    // wide key sets (wide.cuh)
+    uint32_t key_sets;     // runtime mask (the KS_ALL kernel variant tests it)
+    WSlot* wtab;
+    uint32_t wmask;
+    WSpillEntry* wspill;
+    uint32_t wspill_cap;
+    ulonglong2* port_hist;  // [2][PORT_DENSE] {sum(Bytes*SamplingRate), count()}: SrcPort, then DstPort
 };
+
+__device__ __forceinline__ WArgs wargs(const KArgs& a) {
+    return WArgs{a.wtab, a.wmask, a.wspill, a.wspill_cap, &a.ctr->wspill_count, &a.ctr->wspill_lost, &a.ctr->wused};
+}
+// does this kernel variant serve key set X for this launch?
+template <uint32_t KEYSETS>
+__device__ __forceinline__ bool ks_on(const KArgs& a, uint32_t x) {
+    return (KEYSETS & x) != 0 && (KEYSETS != KS_ALL || (a.key_sets & x) != 0);
+}
 
 // ---- sinks ------------------------------------------------------------------
 __device__ __forceinline__ void agg_global(const KArgs& a, uint64_t k0, uint64_t k1, uint32_t h,
@@ -242,6 +266,9 @@ constexpr uint32_t cols_for_keysets() {
     if (KEYSETS & FA_KEYS_AS_PAIR) c |= COLS_AS_ROLLUP;
     if (KEYSETS & FA_KEYS_SRCADDR_CMS) c |= COL_SRC_ADDR | COL_BYTES | COL_SAMPLING_RATE;
     if (KEYSETS & FA_KEYS_DSTADDR_CMS) c |= COL_DST_ADDR | COL_BYTES | COL_SAMPLING_RATE;
+    if (KEYSETS & FA_KEYS_ADDR_PORT_PROTO) c |= COL_TIME_RECEIVED | COL_SRC_ADDR | COL_DST_PORT | COL_PROTO | COL_BYTES | COL_PACKETS;
+    if (KEYSETS & FA_KEYS_PORT_HIST) c |= COL_SRC_PORT | COL_DST_PORT | COL_BYTES | COL_SAMPLING_RATE;
+    if (KEYSETS & FA_KEYS_MINUTE_SERIES) c |= COL_TIME_FLOW_START | COL_BYTES | COL_SAMPLING_RATE;
     return c;
 }
 
@@ -302,21 +329,131 @@ __device__ __forceinline__ uint64_t quad_bcast_u64(uint64_t v) {
 // adjacent lanes of ONE instruction: in round Q every quad works on the record of
 // its lane Q; lane w of the quad adds word w (bytes, packets, count).  One
 // transaction per record instead of three.  Must be called by the full wave.
-template <int Q>
+template <int Q, int VOFF>
 __device__ __forceinline__ void quad_round(uint64_t ptr, uint64_t b, uint64_t p, uint64_t c, uint32_t w) {
     const uint64_t qp = quad_bcast_u64<Q>(ptr);
     const uint64_t qb = quad_bcast_u64<Q>(b), qq = quad_bcast_u64<Q>(p), qc = quad_bcast_u64<Q>(c);
     const uint64_t v = w == 0 ? qb : w == 1 ? qq : qc;
     if (qp != 0 && w < 3 && v != 0)
-        atomicAdd(reinterpret_cast<unsigned long long*>(qp) + 2 + w, (unsigned long long)v);
+        atomicAdd(reinterpret_cast<unsigned long long*>(qp) + VOFF + w, (unsigned long long)v);
+}
+// slot = base pointer of a 64-byte slot whose three sums start at word VOFF (2: Slot, 4: WSlot); 0 = nothing to do
+template <int VOFF>
+__device__ __forceinline__ void quad_atomic_update_at(uint64_t ptr, uint64_t b, uint64_t p, uint64_t c) {
+    const uint32_t w = threadIdx.x & 3;
+    quad_round<0, VOFF>(ptr, b, p, c, w);
+    quad_round<1, VOFF>(ptr, b, p, c, w);
+    quad_round<2, VOFF>(ptr, b, p, c, w);
+    quad_round<3, VOFF>(ptr, b, p, c, w);
 }
 __device__ __forceinline__ void quad_atomic_update(Slot* sp, uint64_t b, uint64_t p, uint64_t c) {
-    const uint64_t ptr = (uint64_t)sp;  // 0 = nothing to do for this lane
+    quad_atomic_update_at<2>((uint64_t)sp, b, p, c);
+}
+
+// Dense port histograms, quad-grouped: in round Q the quad works on its lane Q's record; lanes 0,1 add
+// {weight, 1} to the SrcPort entry and lanes 2,3 to the DstPort entry (two 16-byte entries = two atomic
+// line transactions per record instead of four).  0 = no entry for that direction.  Full wave.
+template <int Q>
+__device__ __forceinline__ void port_round(uint64_t ps, uint64_t pd, uint64_t wgt, uint32_t w) {
+    const uint64_t qs = quad_bcast_u64<Q>(ps), qd = quad_bcast_u64<Q>(pd), qw = quad_bcast_u64<Q>(wgt);
+    const uint64_t base = w < 2 ? qs : qd;
+    const uint64_t v = (w & 1) ? 1ull : qw;
+    if (base != 0 && v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(base) + (w & 1), (unsigned long long)v);
+}
+__device__ __forceinline__ void port_hist_update(uint64_t ps, uint64_t pd, uint64_t wgt) {
     const uint32_t w = threadIdx.x & 3;
-    quad_round<0>(ptr, b, p, c, w);
-    quad_round<1>(ptr, b, p, c, w);
-    quad_round<2>(ptr, b, p, c, w);
-    quad_round<3>(ptr, b, p, c, w);
+    port_round<0>(ps, pd, wgt, w);
+    port_round<1>(ps, pd, wgt, w);
+    port_round<2>(ps, pd, wgt, w);
+    port_round<3>(ps, pd, wgt, w);
+}
+
+// ---- wide key sets ----------------------------------------------------------------------------------
+__device__ __forceinline__ void app_key(const KArgs& a, const Rec& r, uint32_t tb, WKey& k) {
+    wkey_pack(WK_APP, tb, (uint64_t)r.src[1] << 32 | r.src[0], (uint64_t)r.src[3] << 32 | r.src[2], r.dst_port, r.proto, k);
+}
+__device__ __forceinline__ uint32_t minute_of(const Rec& r) {
+    return (uint32_t)r.time_flow_start / 60u;  // UInt64 -> DateTime (create.sh:40), toStartOfMinute (viz-ch.json:74)
+}
+
+// Per-lane form (deferred records, no wave cooperation): every wide key set through plain atomics.
+template <uint32_t KEYSETS>
+__device__ __forceinline__ void wide_sink_slow(const KArgs& a, const Rec& r, uint32_t tb) {
+    const WArgs t = wargs(a);
+    const uint64_t wgt = r.bytes * r.sampling_rate;  // viz-ch.json:74,358,604 sum(Bytes*SamplingRate), UInt64 wrap
+    if (ks_on<KEYSETS>(a, FA_KEYS_ADDR_PORT_PROTO)) {
+        WKey k;
+        app_key(a, r, tb, k);
+        wagg_global(t, k, r.bytes, r.packets, 1);
+    }
+    if (ks_on<KEYSETS>(a, FA_KEYS_PORT_HIST)) {
+        for (int d = 0; d < 2; d++) {
+            const uint32_t port = d ? r.dst_port : r.src_port;
+            if (port < PORT_DENSE) {
+                unsigned long long* e = reinterpret_cast<unsigned long long*>(&a.port_hist[(size_t)d * PORT_DENSE + port]);
+                if (wgt) atomicAdd(e, (unsigned long long)wgt);
+                atomicAdd(e + 1, 1ull);
+            } else {
+                WKey k;
+                wkey_pack(d ? WK_DSTPORT : WK_SRCPORT, 0, 0, 0, port, 0, k);
+                wagg_global(t, k, wgt, 0, 1);
+            }
+        }
+    }
+    if (ks_on<KEYSETS>(a, FA_KEYS_MINUTE_SERIES)) {
+        WKey k;
+        wkey_pack(WK_MINUTE, 0, 0, 0, minute_of(r), 0, k);
+        wagg_global(t, k, wgt, 0, 1);
+    }
+}
+
+// Full-wave form (tile kernel): one atomic line transaction per record and key set.
+template <uint32_t KEYSETS>
+__device__ __forceinline__ void wide_sink_wave(const KArgs& a, LdsMinutes& lm, const Rec& r, bool sure, uint32_t tb) {
+    const WArgs t = wargs(a);
+    const uint64_t wgt = r.bytes * r.sampling_rate;
+    if (ks_on<KEYSETS>(a, FA_KEYS_ADDR_PORT_PROTO)) {
+        WSlot* sp = nullptr;
+        if (sure) {
+            WKey k;
+            app_key(a, r, tb, k);
+            sp = wtable_find_or_claim(t, k, wkey_hash(k));
+            if (!sp) wspill_park(t, k, r.bytes, r.packets, 1);
+        }
+        quad_atomic_update_at<4>((uint64_t)sp, r.bytes, r.packets, 1);
+    }
+    if (ks_on<KEYSETS>(a, FA_KEYS_PORT_HIST)) {
+        uint64_t ps = 0, pd = 0;
+        if (sure) {
+            if (r.src_port < PORT_DENSE) {
+                ps = (uint64_t)&a.port_hist[r.src_port];
+            } else {
+                WKey k;
+                wkey_pack(WK_SRCPORT, 0, 0, 0, r.src_port, 0, k);
+                wagg_global(t, k, wgt, 0, 1);
+            }
+            if (r.dst_port < PORT_DENSE) {
+                pd = (uint64_t)&a.port_hist[(size_t)PORT_DENSE + r.dst_port];
+            } else {
+                WKey k;
+                wkey_pack(WK_DSTPORT, 0, 0, 0, r.dst_port, 0, k);
+                wagg_global(t, k, wgt, 0, 1);
+            }
+        }
+        port_hist_update(ps, pd, wgt);
+    }
+    if (ks_on<KEYSETS>(a, FA_KEYS_MINUTE_SERIES)) {
+        // lanes of a wave almost always share one or two minutes: fold them, then one LDS update per group
+        const uint32_t minute = minute_of(r);
+        uint64_t w0 = wgt, z = 0, c = 1;
+        bool valid = sure;
+        wave_combine<4, 2>(valid, (uint64_t)minute, 1ull, w0, z, c);
+        if (valid && !lds_minutes_add(lm, minute, w0, c)) {
+            WKey k;
+            wkey_pack(WK_MINUTE, 0, 0, 0, minute, 0, k);
+            wagg_global(t, k, w0, 0, c);
+        }
+    }
 }
 
 __device__ __forceinline__ void spill_park(const KArgs& a, uint64_t k0, uint64_t k1, uint64_t b, uint64_t p, uint64_t c) {
@@ -343,7 +480,7 @@ __device__ __forceinline__ bool frame_short(uint32_t x, uint32_t rec_len, uint32
 
 // ---- per-lane work on a staged record (called by every lane of the workgroup) ------
 template <int MODE, uint32_t KEYSETS, uint32_t COLS>
-__device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, uint32_t* part_cnt, const uint32_t* tile,
+__device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, LdsMinutes& lm, uint32_t* part_cnt, const uint32_t* tile,
                                           bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
                                           uint32_t& n_ok, uint32_t& n_direct) {
     // ---- parse (divergent: only lanes that own a staged record) ----
@@ -378,9 +515,9 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         n_ok += (uint32_t)(r.time_received ^ r.bytes ^ r.packets ^ r.src_as ^ r.dst_as ^ r.etype) & 1;
         return;
     }
-    if (KEYSETS & FA_KEYS_AS_PAIR) {
-        const uint32_t t32 = (uint32_t)r.time_received;  // UInt64 -> DateTime (create.sh:39)
-        const uint32_t tb = time_bucket(a, t32);
+    const uint32_t t32 = (uint32_t)r.time_received;  // UInt64 -> DateTime (create.sh:39)
+    const uint32_t tb = time_bucket(a, t32);
+    if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
         uint64_t k0, k1;
         pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
         const uint32_t h = key_hash(k0, k1);
@@ -415,15 +552,16 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     }
     if (sure && (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
         const uint64_t w = r.bytes * r.sampling_rate;  // viz-ch.json:233 sum(Bytes*SamplingRate)
-        if (KEYSETS & FA_KEYS_SRCADDR_CMS) {
+        if (ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS)) {
             cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
             keyset_insert(a, a.ks_src, r.src);
         }
-        if (KEYSETS & FA_KEYS_DSTADDR_CMS) {
+        if (ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS)) {
             cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
             keyset_insert(a, a.ks_dst, r.dst);
         }
     }
+    if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb);
 }
 
 // ---- the tile kernel ----------------------------------------------------------
@@ -458,12 +596,14 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t tile[TILE_STRIDE / 4];
     __shared__ LdsTable<LDS_SLOTS> lt;
     __shared__ uint32_t part_cnt[NPART_MAX];  // tuples this workgroup appended per key partition
+    __shared__ LdsMinutes lm;                 // per-minute series pre-aggregation (KS_ALL variant only)
 
     const uint32_t tid = threadIdx.x;
     if (MODE == MODE_INGEST && (KEYSETS & FA_KEYS_AS_PAIR)) {
         lds_table_clear(lt);
         for (int i = tid; i < NPART_MAX; i += BLOCK) part_cnt[i] = 0;
     }
+    if (MODE == MODE_INGEST && (KEYSETS & FA_KEYS_MINUTE_SERIES)) lds_minutes_clear(lm);
     const uint32_t tb_base = MODE == MODE_INGEST ? a.ctr->tb_base : 0u;
 
     uint32_t n_ok = 0, n_direct = 0;
@@ -479,9 +619,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     __syncthreads();  // LDS table cleared
 
     const bool timing = (a.dbg & DBG_TIMING) != 0 && tid == 0;
-    unsigned long long tm_wait = 0, tm_work = 0, tm_tiles = 0, tm_start = timing ? clock64() : 0ull;
+    uint32_t tm_wait = 0, tm_work = 0, tm_tiles = 0;
+    const uint32_t tm_start = timing ? (uint32_t)clock64() : 0u;
     for (; t < ntiles; t += stride) {
-        const unsigned long long tm0 = timing ? clock64() : 0ull;
+        const uint32_t tm0 = timing ? (uint32_t)clock64() : 0u;
         // (1) stream this tile's wire bytes into LDS (async DMA) ...
         if (cur.fits) {
             // nt: the wire bytes are read exactly once; keeping them out of the way of the L2's open tuple lines
@@ -498,7 +639,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
         }
         dma_wait_all();
         __syncthreads();
-        const unsigned long long tm1 = timing ? clock64() : 0ull;
+        const uint32_t tm1 = timing ? (uint32_t)clock64() : 0u;
 
         // (2) parse + aggregate out of LDS
         if (cur.fits) {
@@ -508,7 +649,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                 unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
                 a.exotic_idx[j] = cur.r0 + tid;
             }
-            lane_work<MODE, KEYSETS, COLS>(a, lt, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, n_ok, n_direct);
+            lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, n_ok, n_direct);
         } else {
             // rare: the tile's bytes exceed the LDS buffer (big records): stage it in passes
             uint32_t done = 0;
@@ -536,7 +677,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                     }
                     done += 1;
                 } else {
-                    lane_work<MODE, KEYSETS, COLS>(a, lt, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, n_ok, n_direct);
+                    lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, n_ok, n_direct);
                     done += nfit;
                 }
                 __syncthreads();  // the buffer is restaged by the next pass
@@ -544,7 +685,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
         }
         __syncthreads();  // everyone is done reading the tile
         if (timing) {
-            const unsigned long long tm2 = clock64();
+            const uint32_t tm2 = (uint32_t)clock64();
             tm_wait += tm1 - tm0;
             tm_work += tm2 - tm1;
             tm_tiles++;
@@ -554,12 +695,20 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
         o1 = n1;
     }
     if (timing) {
-        atomicAdd(&a.ctr->t_wait, tm_wait);
-        atomicAdd(&a.ctr->t_work, tm_work);
-        atomicAdd(&a.ctr->t_tiles, tm_tiles);
-        atomicAdd(&a.ctr->t_total, clock64() - tm_start);
+        atomicAdd(&a.ctr->t_wait, (unsigned long long)tm_wait);
+        atomicAdd(&a.ctr->t_work, (unsigned long long)tm_work);
+        atomicAdd(&a.ctr->t_tiles, (unsigned long long)tm_tiles);
+        atomicAdd(&a.ctr->t_total, (unsigned long long)((uint32_t)clock64() - tm_start));
     }
     if (MODE == MODE_INGEST) {
+        if (KEYSETS & FA_KEYS_MINUTE_SERIES) {
+            __syncthreads();
+            if (tid < LDS_MINUTES && lm.key[tid] != 0 && lm.c[tid] != 0) {
+                WKey k;
+                wkey_pack(WK_MINUTE, 0, 0, 0, lm.key[tid] - 1u, 0, k);
+                wagg_global(wargs(a), k, lm.w[tid], 0, lm.c[tid]);
+            }
+        }
         if (KEYSETS & FA_KEYS_AS_PAIR) {
             __syncthreads();
             // hot-key table -> device-wide table, one atomic line transaction per group (uniform trip count:
@@ -646,20 +795,22 @@ __device__ __forceinline__ void exotic_pass(const KArgs& a) {
             continue;
         }
         atomicAdd(&a.ctr->ok, 1ull);
-        if (KEYSETS & FA_KEYS_AS_PAIR) {
+        const uint32_t tb = (uint32_t)r.time_received / a.gran;
+        if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
             uint64_t k0, k1;
-            pack_key((uint32_t)r.time_received / a.gran, r.src_as, r.dst_as, r.etype, k0, k1);
+            pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
             agg_global(a, k0, k1, key_hash(k0, k1), r.bytes, r.packets, 1);
         }
         uint64_t w = r.bytes * r.sampling_rate;
-        if (KEYSETS & FA_KEYS_SRCADDR_CMS) {
+        if (ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS)) {
             cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
             keyset_insert(a, a.ks_src, r.src);
         }
-        if (KEYSETS & FA_KEYS_DSTADDR_CMS) {
+        if (ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS)) {
             cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
             keyset_insert(a, a.ks_dst, r.dst);
         }
+        if (KEYSETS & FA_KEYS_WIDE) wide_sink_slow<KEYSETS>(a, r, tb);
     }
 }
 
@@ -709,9 +860,10 @@ __global__ __launch_bounds__(BLOCK) void deferred_kernel(KArgs a) {
             continue;
         }
         n_ok += sure ? 1 : 0;
-        if (KEYSETS & FA_KEYS_AS_PAIR) {
+        const uint32_t tb = time_bucket(a, (uint32_t)r.time_received);
+        if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
             uint64_t k0, k1;
-            pack_key(time_bucket(a, (uint32_t)r.time_received), r.src_as, r.dst_as, r.etype, k0, k1);
+            pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
             uint64_t b = r.bytes, p = r.packets, c = 1;
             bool valid = sure;
             wave_combine<16, 2>(valid, k0, k1, b, p, c);
@@ -719,15 +871,16 @@ __global__ __launch_bounds__(BLOCK) void deferred_kernel(KArgs a) {
         }
         if (sure && (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
             const uint64_t w = r.bytes * r.sampling_rate;
-            if (KEYSETS & FA_KEYS_SRCADDR_CMS) {
+            if (ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS)) {
                 cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
                 keyset_insert(a, a.ks_src, r.src);
             }
-            if (KEYSETS & FA_KEYS_DSTADDR_CMS) {
+            if (ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS)) {
                 cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
                 keyset_insert(a, a.ks_dst, r.dst);
             }
         }
+        if (sure && (KEYSETS & FA_KEYS_WIDE)) wide_sink_slow<KEYSETS>(a, r, tb);
     }
     if (MODE == MODE_INGEST) {
         uint64_t tot = wave_sum_u64(n_ok);
@@ -973,6 +1126,48 @@ __global__ void merge_rows_kernel(const Row5m* rows, uint32_t n, KArgs a) {
         uint64_t k0, k1;
         pack_key(rows[i].timeslot / a.gran, rows[i].src_as, rows[i].dst_as, rows[i].etype, k0, k1);
         agg_global(a, k0, k1, key_hash(k0, k1), rows[i].bytes, rows[i].packets, rows[i].count);
+    }
+}
+
+// ---- wide table maintenance ---------------------------------------------------------------------
+struct WRow {
+    unsigned long long w[4], v0, v1, v2;
+};
+// which rows: kind_mask bit k selects kind k; WK_APP rows additionally need tb in [tb_lo, tb_hi)
+__device__ __forceinline__ bool wrow_selected(const unsigned long long w[4], uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi) {
+    uint32_t kind, tb, port, proto;
+    uint64_t lo, hi;
+    wkey_unpack(w, kind, tb, lo, hi, port, proto);
+    if (!((kind_mask >> kind) & 1u)) return false;
+    return kind != WK_APP || (tb >= tb_lo && tb < tb_hi);
+}
+__global__ void wextract_kernel(const WSlot* tab, uint32_t nslots, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, WRow* rows,
+                                uint32_t rows_cap, Counters* ctr) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) {
+        const WSlot& s = tab[i];
+        if (s.w[0] == 0 || s.w[1] == 0 || s.w[2] == 0 || s.w[3] == 0 || s.v2 == 0) continue;
+        if (!wrow_selected(s.w, kind_mask, tb_lo, tb_hi)) continue;
+        const unsigned int j = atomicAdd(&ctr->wrows_count, 1u);
+        if (j < rows_cap) rows[j] = WRow{{s.w[0], s.w[1], s.w[2], s.w[3]}, s.v0, s.v1, s.v2};
+    }
+}
+// Re-inserts every row that is NOT selected into a fresh table (window removal / reset / growth).
+__global__ void wrebuild_kernel(const WSlot* old_tab, uint32_t old_slots, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, KArgs a) {
+    const WArgs t = wargs(a);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < old_slots; i += gridDim.x * blockDim.x) {
+        const WSlot& s = old_tab[i];
+        if (s.w[0] == 0 || s.w[1] == 0 || s.w[2] == 0 || s.w[3] == 0 || s.v2 == 0) continue;
+        if (wrow_selected(s.w, kind_mask, tb_lo, tb_hi)) continue;
+        WKey k{{s.w[0], s.w[1], s.w[2], s.w[3]}};
+        wagg_global(t, k, s.v0, s.v1, s.v2);
+    }
+}
+// parked updates / rows produced elsewhere (another GPU / Kafka partition) folded into this table
+__global__ void wmerge_kernel(const WRow* rows, uint32_t n, KArgs a) {
+    const WArgs t = wargs(a);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        WKey k{{rows[i].w[0], rows[i].w[1], rows[i].w[2], rows[i].w[3]}};
+        wagg_global(t, k, rows[i].v0, rows[i].v1, rows[i].v2);
     }
 }
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 2
+#define FA_ABI_VERSION 3
 
 typedef struct fa_ctx fa_ctx;
 
@@ -52,7 +52,13 @@ typedef enum {
 enum {
     FA_KEYS_AS_PAIR = 1u,     /* flows_5m: (Date,Timeslot,SrcAS,DstAS,EType) - create.sh:92-110 */
     FA_KEYS_SRCADDR_CMS = 2u, /* Count-Min sketch over SrcAddr, weight Bytes*SamplingRate (viz-ch.json:233) */
-    FA_KEYS_DSTADDR_CMS = 4u  /* same over DstAddr (viz-ch.json:479) */
+    FA_KEYS_DSTADDR_CMS = 4u, /* same over DstAddr (viz-ch.json:479) */
+    FA_KEYS_ADDR_PORT_PROTO = 8u, /* exact (Date,Timeslot,SrcAddr,DstPort,Proto) -> sum(Bytes), sum(Packets), count():
+                                     second concurrent key set of BASELINE config 5, same Date/Timeslot rule as
+                                     flows_5m (create.sh:92-110); rows via fa_*_window_app */
+    FA_KEYS_PORT_HIST = 16u,      /* exact sum(Bytes*SamplingRate), count() GROUP BY SrcPort and GROUP BY DstPort
+                                     (viz-ch.json:358,604); dense below 65536, hashed above (UInt32 column) */
+    FA_KEYS_MINUTE_SERIES = 32u   /* sum(Bytes*SamplingRate) GROUP BY toStartOfMinute(TimeFlowStart) (viz-ch.json:74) */
 };
 
 typedef struct {
@@ -69,7 +75,9 @@ typedef struct {
                                      mocker.go:98-101); 0: bare payload (mocker.go:96-97) */
     uint32_t max_batch_records;   /* upper bound on n per ingest launch; 0 or > 1<<24 -> 1<<24 */
     uint32_t topk_capacity_log2;  /* slots of each distinct-address set behind fa_topk (32 B each); 0 -> 20 */
-    uint32_t reserved[4];
+    uint32_t wide_capacity_log2;  /* slots of the wide-key table (64 B each) behind FA_KEYS_ADDR_PORT_PROTO /
+                                     PORT_HIST / MINUTE_SERIES; 0 -> 20; grows by itself like the flows_5m table */
+    uint32_t reserved[3];
 } fa_config;
 
 /* One flows_5m row, scalar columns (create.sh:70-90). */
@@ -79,6 +87,30 @@ typedef struct {
     uint32_t src_as, dst_as, etype, _pad;
     uint64_t bytes, packets, count; /* sum(Bytes), sum(Packets), count() - wrap mod 2^64 */
 } fa_row5m;
+
+/* One row of the (SrcAddr,DstPort,Proto) rollup (FA_KEYS_ADDR_PORT_PROTO). */
+typedef struct {
+    uint32_t date;        /* toDate(TimeReceived) */
+    uint32_t timeslot;    /* start of the (sub)window, seconds */
+    uint8_t src_addr[16]; /* FixedString(16) (create.sh:12) */
+    uint32_t dst_port, proto;
+    uint64_t bytes, packets, count;
+} fa_row_app;
+
+/* GROUP BY SrcPort / DstPort (viz-ch.json:358,604). */
+typedef struct {
+    uint32_t port, _pad;
+    uint64_t weight; /* sum(Bytes*SamplingRate), wraps mod 2^64 */
+    uint64_t count;  /* rows with this port (a port whose rows all have weight 0 is still a group) */
+} fa_port_row;
+
+/* GROUP BY toStartOfMinute(TimeFlowStart) (viz-ch.json:74). */
+typedef struct {
+    uint32_t minute; /* start of the minute, seconds (TimeFlowStart narrowed to DateTime, create.sh:40) */
+    uint32_t _pad;
+    uint64_t weight; /* sum(Bytes*SamplingRate) */
+    uint64_t count;
+} fa_minute_row;
 
 /* One row of the `flows` table (create.sh:7-27): the 15 projected columns. */
 typedef struct {
@@ -112,6 +144,8 @@ typedef struct {
     uint64_t batch_ns_total;   /* tile kernel .. aggregation kernel, summed over every ingest launch */
     uint64_t records_direct;   /* records that took the direct device-wide-table path */
     uint64_t records_retried;  /* records decoded by the order-free second-chance parser */
+    uint64_t wide_used;        /* occupied slots of the wide-key table */
+    uint64_t wide_capacity;
 } fa_stats_t;
 
 typedef struct {
@@ -156,6 +190,25 @@ int fa_close_window(fa_ctx*, uint32_t timeslot, fa_row5m* out, size_t cap, size_
 /* Same, without removing (peek). */
 int fa_read_window(fa_ctx*, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out);
 
+/* ---- second exact key set: (SrcAddr, DstPort, Proto) ----------------------- */
+/* Same contract as fa_read_window / fa_close_window / fa_merge_rows; rows sorted by
+ * (date, timeslot, src_addr bytes, dst_port, proto).  Need FA_KEYS_ADDR_PORT_PROTO. */
+int fa_read_window_app(fa_ctx*, uint32_t timeslot, fa_row_app* out, size_t cap, size_t* n_out);
+int fa_close_window_app(fa_ctx*, uint32_t timeslot, fa_row_app* out, size_t cap, size_t* n_out);
+int fa_merge_rows_app(fa_ctx*, const fa_row_app* rows, size_t n);
+
+/* ---- dashboard read side (not windowed: the dashboard picks $timeFilter) ----- */
+/* dst = 0: GROUP BY SrcPort, 1: GROUP BY DstPort.  Every port that occurred, ORDER BY weight DESC
+ * (ties: port ascending), cut at k.  Needs FA_KEYS_PORT_HIST. */
+int fa_top_ports(fa_ctx*, int dst, size_t k, fa_port_row* out, size_t cap, size_t* n_out);
+/* Adds port rows produced by another ctx / rank. */
+int fa_merge_ports(fa_ctx*, int dst, const fa_port_row* rows, size_t n);
+/* The per-minute series, ORDER BY minute.  Needs FA_KEYS_MINUTE_SERIES. */
+int fa_minute_series(fa_ctx*, fa_minute_row* out, size_t cap, size_t* n_out);
+int fa_merge_minutes(fa_ctx*, const fa_minute_row* rows, size_t n);
+/* Clears the port groups and the minute series (start of a new $timeFilter range). */
+int fa_dashboard_reset(fa_ctx*);
+
 /* ---- heavy hitters -------------------------------------------------------- */
 /* key_set: FA_KEYS_SRCADDR_CMS or FA_KEYS_DSTADDR_CMS.  The k addresses with the largest Count-Min
  * estimate of sum(Bytes*SamplingRate) (viz-ch.json:233,479) among ALL distinct addresses ingested
@@ -178,6 +231,8 @@ typedef struct {
     void* cms_src;      /* depth*2^width_log2 uint64, or NULL */
     void* cms_dst;
     size_t cms_words;
+    void* port_hist;        /* 2*65536 entries of {weight, count} uint64 (SrcPort, then DstPort), or NULL */
+    size_t port_hist_words; /* 4*65536 */
 } fa_device_state;
 int fa_device_state_get(fa_ctx*, fa_device_state* out);
 /* Adds partial rows produced by another ctx/rank (e.g. gathered over RCCL)
@@ -185,7 +240,7 @@ int fa_device_state_get(fa_ctx*, fa_device_state* out);
  * equals the single-shard table bit for bit. */
 int fa_merge_rows(fa_ctx*, const fa_row5m* rows, size_t n);
 /* In-library RCCL path: comm is an `ncclComm_t`; all-reduces (sum, uint64) the
- * sketches in place on the ctx stream. */
+ * sketches and the dense port histograms in place on the ctx stream. */
 int fa_merge_allreduce(fa_ctx*, void* rccl_comm);
 
 int fa_stats(fa_ctx*, fa_stats_t* out);

@@ -198,3 +198,90 @@ def bench_rollup(gp: GenParams, i0: int, n: int, threads: int):
                                C.byref(bad), C.byref(cs))
     return {"seconds": dt, "wire_bytes": wire.value, "groups": groups.value, "bad": bad.value,
             "checksum": cs.value}
+
+
+# ---- wide key sets and dashboard read side (numpy restatements over decoded rows) -----------------
+# Same status as the flows_5m rollup: "parity unpinned" (restated from the SQL; ClickHouse cannot run
+# here).  Input = (rows ROW_DTYPE, status) of decode_batch(); bad records are dropped
+# (inserter/inserter.go:125-126).  All sums are UInt64 and wrap mod 2^64.
+ROW_APP_DTYPE = np.dtype([
+    ("date", "<u4"), ("timeslot", "<u4"), ("src_addr", "u1", 16), ("dst_port", "<u4"), ("proto", "<u4"),
+    ("bytes", "<u8"), ("packets", "<u8"), ("count", "<u8"),
+])
+PORT_ROW_DTYPE = np.dtype([("port", "<u4"), ("_pad", "<u4"), ("weight", "<u8"), ("count", "<u8")])
+MINUTE_ROW_DTYPE = np.dtype([("minute", "<u4"), ("_pad", "<u4"), ("weight", "<u8"), ("count", "<u8")])
+
+
+def _group_sum(keys, values):
+    """keys: list of uint64 arrays, most significant first; values: list of uint64 arrays.
+    -> (index of the first row of every group in sorted order, [summed values])."""
+    order = np.lexsort(tuple(reversed(keys)))
+    ks = [k[order] for k in keys]
+    first = np.ones(len(order), dtype=bool)
+    if len(order) > 1:
+        diff = np.zeros(len(order) - 1, dtype=bool)
+        for k in ks:
+            diff |= k[1:] != k[:-1]
+        first[1:] = diff
+    starts = np.nonzero(first)[0]
+    with np.errstate(over="ignore"):
+        sums = [np.add.reduceat(v[order].astype(np.uint64), starts) if len(order) else v[:0] for v in values]
+    return order[starts] if len(order) else order, sums
+
+
+def rollup_app(rows, status, granule=300, window=None, timeslot=None):
+    """GROUP BY Date, Timeslot, SrcAddr, DstPort, Proto -> sum(Bytes), sum(Packets), count(): the second
+    key set of BASELINE config 5, with the Date/Timeslot rule of flows_5m_view
+    (compose/clickhouse/create.sh:92-110: toDate / toStartOfFiveMinute of the DateTime-narrowed
+    TimeReceived, create.sh:39,66).  window/timeslot: fold the sub-buckets [timeslot, timeslot+window)
+    into one row per key (sliding windows over `granule`-second sub-buckets)."""
+    r = rows[status == 0]
+    t32 = (r["time_received"] & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+    ts = t32 - t32 % np.uint64(granule)
+    if timeslot is not None:
+        keep = (ts >= np.uint64(timeslot)) & (ts < np.uint64(timeslot + (window or granule)))
+        r, ts = r[keep], ts[keep]
+        ts = np.full(len(r), timeslot, dtype=np.uint64)
+    addr = np.ascontiguousarray(r["src_addr"])
+    a_hi = addr[:, :8].copy().view(">u8").reshape(-1).astype(np.uint64)   # byte-lexicographic order
+    a_lo = addr[:, 8:].copy().view(">u8").reshape(-1).astype(np.uint64)
+    keys = [ts, a_hi, a_lo, r["dst_port"].astype(np.uint64), r["proto"].astype(np.uint64)]
+    idx, (b, p, c) = _group_sum(keys, [r["bytes"], r["packets"], np.ones(len(r), dtype=np.uint64)])
+    out = np.zeros(len(idx), dtype=ROW_APP_DTYPE)
+    out["timeslot"] = ts[idx]
+    out["date"] = ts[idx] // np.uint64(86400)
+    out["src_addr"] = addr[idx]
+    out["dst_port"] = r["dst_port"][idx]
+    out["proto"] = r["proto"][idx]
+    out["bytes"], out["packets"], out["count"] = b, p, c
+    return out
+
+
+def top_ports(rows, status, dst=0):
+    """SELECT SrcPort|DstPort AS port, sum(Bytes*SamplingRate) AS sumbytes ... GROUP BY port ORDER BY
+    sumbytes DESC (compose/grafana/dashboards/viz-ch.json:358,604); ties ordered by port."""
+    r = rows[status == 0]
+    port = r["dst_port" if dst else "src_port"].astype(np.uint64)
+    with np.errstate(over="ignore"):
+        w = r["bytes"] * r["sampling_rate"]
+    idx, (ws, cs) = _group_sum([port], [w, np.ones(len(r), dtype=np.uint64)])
+    out = np.zeros(len(idx), dtype=PORT_ROW_DTYPE)
+    out["port"] = port[idx]
+    out["weight"], out["count"] = ws, cs
+    order = np.lexsort((out["port"], np.uint64(0xFFFFFFFFFFFFFFFF) - out["weight"]))
+    return out[order]
+
+
+def minute_series(rows, status):
+    """SELECT toStartOfMinute(TimeFlowStart) AS t, sum(Bytes*SamplingRate) ... GROUP BY t ORDER BY t
+    (viz-ch.json:74); TimeFlowStart narrowed UInt64 -> DateTime as in flows_raw (create.sh:40)."""
+    r = rows[status == 0]
+    t32 = (r["time_flow_start"] & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+    minute = t32 - t32 % np.uint64(60)
+    with np.errstate(over="ignore"):
+        w = r["bytes"] * r["sampling_rate"]
+    idx, (ws, cs) = _group_sum([minute], [w, np.ones(len(r), dtype=np.uint64)])
+    out = np.zeros(len(idx), dtype=MINUTE_ROW_DTYPE)
+    out["minute"] = minute[idx]
+    out["weight"], out["count"] = ws, cs
+    return out

@@ -177,3 +177,46 @@ def test_cms_overestimates_only(po):
         po.cms_update(cms, depth, wl2, seed, key, w)
     for k, v in exact.items():
         assert po.cms_query(cms, depth, wl2, seed, k) >= v
+
+
+def test_wide_keyset_restatements_against_plain_dicts(po):
+    """The numpy restatements of the wide key sets (rollup_app / top_ports / minute_series) against an
+    independent row-at-a-time Python restatement of the same SQL on a small sample."""
+    n = 3000
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=77, n_total=n, span_secs=700, zipf_log2_universe=6)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    M = (1 << 64) - 1
+    app, ports, minutes = {}, ({}, {}), {}
+    for r in rows[status == 0]:
+        t = int(r["time_received"]) & 0xFFFFFFFF
+        ts = t - t % 300
+        k = (ts // 86400, ts, bytes(r["src_addr"]), int(r["dst_port"]), int(r["proto"]))
+        b, p, c = app.get(k, (0, 0, 0))
+        app[k] = ((b + int(r["bytes"])) & M, (p + int(r["packets"])) & M, c + 1)
+        w = (int(r["bytes"]) * int(r["sampling_rate"])) & M
+        for d, col in enumerate(("src_port", "dst_port")):
+            ww, cc = ports[d].get(int(r[col]), (0, 0))
+            ports[d][int(r[col])] = ((ww + w) & M, cc + 1)
+        tf = int(r["time_flow_start"]) & 0xFFFFFFFF
+        ww, cc = minutes.get(tf - tf % 60, (0, 0))
+        minutes[tf - tf % 60] = ((ww + w) & M, cc + 1)
+    got = po.rollup_app(rows, status, 300)
+    want = sorted(app.items())
+    assert len(got) == len(want)
+    for g, (k, v) in zip(got, want):
+        assert (int(g["date"]), int(g["timeslot"]), bytes(g["src_addr"]), int(g["dst_port"]), int(g["proto"])) == k
+        assert (int(g["bytes"]), int(g["packets"]), int(g["count"])) == v
+    for d in (0, 1):
+        got = po.top_ports(rows, status, d)
+        want = sorted(ports[d].items(), key=lambda kv: (-kv[1][0], kv[0]))
+        assert [(int(g["port"]), int(g["weight"]), int(g["count"])) for g in got] == [(k, v[0], v[1]) for k, v in want]
+    got = po.minute_series(rows, status)
+    assert [(int(g["minute"]), int(g["weight"]), int(g["count"])) for g in got] == [(k, v[0], v[1]) for k, v in sorted(minutes.items())]
+    # sliding window fold: 5 one-minute sub-buckets == direct 300 s window starting on a minute
+    start = po.T0 + 120
+    sel = (rows["time_received"] >= start) & (rows["time_received"] < start + 300)
+    a = po.rollup_app(rows, status, 60, window=300, timeslot=start)
+    b = po.rollup_app(rows[sel], status[sel], 86400)
+    for col in ("src_addr", "dst_port", "proto", "bytes", "packets", "count"):
+        assert np.array_equal(a[col], b[col]), col
