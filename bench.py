@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=16_666_667, help="records per ingest launch (<= 2^24)")
     ap.add_argument("--mode", default="aspairs", choices=["mocker", "aspairs", "zipf"])
     ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="records timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--key-sets", type=int, default=1, help="fa key_sets mask (must include 1 = flows_5m rollup); 9 = config 5's "
+                    "two concurrent key sets; side measurements only - the default is the BASELINE metric")
+    ap.add_argument("--zipf-s", type=int, default=110, help="zipf exponent x100 for --mode zipf")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-assert", action="store_true", help="ablation runs (FA_DEBUG_FLAGS): skip result checks")
     args = ap.parse_args()
@@ -96,10 +99,12 @@ def main():
     mode = {"mocker": fa.MOCK_MOCKER, "aspairs": fa.MOCK_ASPAIRS, "zipf": fa.MOCK_ZIPF}[args.mode]
     n_rec = args.records
     # every rank = one Kafka partition with its own stream (seed 2 = config 2, + rank)
-    mp = fa.mock_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000)
+    mp = fa.mock_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000,
+                        zipf_s_x100=args.zipf_s)
+    assert args.key_sets & fa.FA_KEYS_AS_PAIR, "--key-sets must include the flows_5m rollup"
 
-    agg = fa.FlowAgg(device=local_rank, framed=True, table_capacity_log2=20, key_sets=fa.FA_KEYS_AS_PAIR,
-                     max_batch_records=args.chunk)
+    agg = fa.FlowAgg(device=local_rank, framed=True, table_capacity_log2=20, key_sets=args.key_sets,
+                     max_batch_records=args.chunk, wide_capacity_log2=26 if args.key_sets & 8 else 0)
     chunks = []
     wire_bytes = 0
     i0 = 0
@@ -161,7 +166,7 @@ def main():
 
     value = n_rec * args.steps * world / elapsed
     traffic, traffic_all = pmc_traffic(args.records == 100_000_000 and args.chunk == 16_666_667 and args.mode == "aspairs"
-                                       and not os.environ.get("FA_DEBUG_FLAGS"))
+                                       and not os.environ.get("FA_DEBUG_FLAGS") and args.key_sets == 1)
     out = {
         "metric": "FlowMessages/sec aggregated into flows_5m",
         "value": value,
@@ -183,6 +188,7 @@ def main():
             "wire_bytes_per_gpu_per_step": wire_bytes,
             "bytes_per_record": wire_bytes / n_rec,
             "generator": args.mode,
+            "key_sets": args.key_sets,
             "launches_per_step": len(chunks),
             "partitioning": "one Kafka partition per GPU, no data-path collective; rows all-gathered at window close",
             "window_close_merge_ms": merge_ms,
@@ -200,7 +206,7 @@ def main():
             "traffic": traffic,
             "traffic_source": "profiles/r01_traffic.json: rocprofv3 --pmc, 2*FETCH_SIZE (gfx950 wide-read "
                               "correction) + WRITE_SIZE, bytes per launch" if traffic else None,
-            "kernel": "fa::tile_kernel<MODE_INGEST, AS_PAIR>",
+            "kernel": "fa::tile_kernel<MODE_INGEST, AS_PAIR>" if args.key_sets == 1 else "fa::tile_kernel<MODE_INGEST, KS_ALL>",
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": avg_launch_s * 1e3,
             "launches_timed": int(launches),

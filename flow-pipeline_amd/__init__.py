@@ -117,7 +117,7 @@ EXPORTS = [
     "fa_device_state_get", "fa_merge_rows", "fa_merge_allreduce", "fa_stats",
     "fa_mock_generate_device", "fa_mock_generate_host",
     "fa_read_window_app", "fa_close_window_app", "fa_merge_rows_app", "fa_top_ports", "fa_merge_ports",
-    "fa_minute_series", "fa_merge_minutes", "fa_dashboard_reset",
+    "fa_minute_series", "fa_merge_minutes", "fa_dashboard_reset", "fa_rows_to_rowbinary",
 ]
 
 _LIB = None
@@ -178,6 +178,7 @@ def lib():
     L.fa_minute_series.argtypes = [vp, vp, sz, szp]
     L.fa_merge_minutes.argtypes = [vp, vp, sz]
     L.fa_dashboard_reset.argtypes = [vp]
+    L.fa_rows_to_rowbinary.argtypes = [vp, sz, vp, sz, szp]
     _LIB = L
     return L
 
@@ -198,6 +199,39 @@ def mock_generate_host(mp: MockParams, i0: int, n: int):
     if rc:
         raise FlowAggError(rc, "fa_mock_generate_host")
     return buf[:w.value].copy(), off
+
+
+def rows_to_rowbinary(rows: np.ndarray) -> bytes:
+    """flows_5m rows -> `INSERT INTO flows_5m FORMAT RowBinary` payload (create.sh:70-90 column list)."""
+    r = np.ascontiguousarray(rows, dtype=ROW5M_DTYPE)
+    out = np.empty(len(r) * 70, dtype=np.uint8)
+    n = C.c_size_t()
+    rc = lib().fa_rows_to_rowbinary(r.ctypes.data, len(r), out.ctypes.data, out.size, C.byref(n))
+    if rc:
+        raise FlowAggError(rc, "fa_rows_to_rowbinary")
+    return out[:n.value].tobytes()
+
+
+def rowbinary_to_rows(blob: bytes) -> np.ndarray:
+    """Inverse of rows_to_rowbinary (plain Python decoder, for tests and offline checks)."""
+    import struct
+    out = []
+    p = 0
+    while p < len(blob):
+        date, ts, sa, da = struct.unpack_from("<HIII", blob, p)
+        p += 14
+        arr = []
+        for fmt, size in (("<I", 4), ("<Q", 8), ("<Q", 8), ("<Q", 8)):
+            if blob[p] != 1:
+                raise ValueError("ETypeMap arrays hold exactly one element")
+            arr.append(struct.unpack_from(fmt, blob, p + 1)[0])
+            p += 1 + size
+        b, pk, c = struct.unpack_from("<QQQ", blob, p)
+        p += 24
+        if (b, pk, c) != tuple(arr[1:]):
+            raise ValueError("ETypeMap values differ from the scalar columns")
+        out.append((date, ts, sa, da, arr[0], 0, b, pk, c))
+    return np.array(out, dtype=ROW5M_DTYPE)
 
 
 class FlowAgg:

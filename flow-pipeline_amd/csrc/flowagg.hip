@@ -989,6 +989,37 @@ extern "C" int fa_merge_rows(fa_ctx* c, const fa_row5m* rows, size_t n) {
     return settle(c);
 }
 
+// ---- RowBinary sink -------------------------------------------------------------------------------
+// ClickHouse RowBinary: fixed-width little-endian integers, arrays as LEB128 length + elements; Nested
+// columns travel as one array per sub-column (format restated from the ClickHouse documentation; no
+// server in this image to load it into).
+extern "C" int fa_rows_to_rowbinary(const fa_row5m* rows, size_t n, uint8_t* out, size_t cap, size_t* bytes_out) {
+    if ((!rows && n) || !bytes_out) return FA_ERR_ARG;
+    const size_t need = n * (size_t)FA_ROWBINARY_ROW5M_BYTES;
+    *bytes_out = need;
+    if (need > cap || (!out && need)) return FA_ERR_CAPACITY;
+    uint8_t* p = out;
+    auto put = [&](uint64_t v, int bytes) {
+        for (int i = 0; i < bytes; i++) *p++ = (uint8_t)(v >> (8 * i));
+    };
+    for (size_t i = 0; i < n; i++) {
+        const fa_row5m& r = rows[i];
+        if (r.date > 0xFFFFu) return FA_ERR_ARG;
+        put(r.date, 2);
+        put(r.timeslot, 4);
+        put(r.src_as, 4);
+        put(r.dst_as, 4);
+        put(1, 1); put(r.etype, 4);    // ETypeMap.EType   [EType]
+        put(1, 1); put(r.bytes, 8);    // ETypeMap.Bytes   [Bytes]
+        put(1, 1); put(r.packets, 8);  // ETypeMap.Packets [Packets]
+        put(1, 1); put(r.count, 8);    // ETypeMap.Count   [Count]
+        put(r.bytes, 8);
+        put(r.packets, 8);
+        put(r.count, 8);
+    }
+    return FA_OK;
+}
+
 // ---- wide key sets: window close and dashboard reads -----------------------------------------------
 // Collects the selected rows of the wide table into a host vector (unsorted).
 static int collect_wide(fa_ctx* c, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, std::vector<WRow>& rows) {

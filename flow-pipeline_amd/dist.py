@@ -28,6 +28,14 @@ ROW5M_DTYPE = np.dtype([
 ])
 
 
+ROW_APP_DTYPE = np.dtype([
+    ("date", "<u4"), ("timeslot", "<u4"), ("src_addr", "u1", 16), ("dst_port", "<u4"), ("proto", "<u4"),
+    ("bytes", "<u8"), ("packets", "<u8"), ("count", "<u8"),
+])
+PORT_ROW_DTYPE = np.dtype([("port", "<u4"), ("_pad", "<u4"), ("weight", "<u8"), ("count", "<u8")])
+MINUTE_ROW_DTYPE = np.dtype([("minute", "<u4"), ("_pad", "<u4"), ("weight", "<u8"), ("count", "<u8")])
+
+
 def partitions_of(rank: int, world: int, n_partitions: int):
     """Kafka partitions owned by `rank` (round-robin, like a balanced consumer group)."""
     return [p for p in range(n_partitions) if p % world == rank]
@@ -51,6 +59,78 @@ def merge_rows_host(parts) -> np.ndarray:
         for f in ("bytes", "packets", "count"):
             out[f] = np.add.reduceat(rows[f], starts)
     return out
+
+
+def _merge_sorted_groups(rows, key_cols, sum_cols):
+    """rows sorted so that equal keys are adjacent -> one row per key, sum_cols added mod 2^64."""
+    if len(rows) == 0:
+        return rows
+    first = np.ones(len(rows), dtype=bool)
+    diff = np.zeros(len(rows) - 1, dtype=bool)
+    for c in key_cols:
+        a = rows[c]
+        d = a[1:] != a[:-1]
+        diff |= d.reshape(len(d), -1).any(axis=1)
+    first[1:] = diff
+    starts = np.nonzero(first)[0]
+    out = rows[starts].copy()
+    with np.errstate(over="ignore"):
+        for f in sum_cols:
+            out[f] = np.add.reduceat(rows[f], starts)
+    return out
+
+
+def merge_rows_app_host(parts) -> np.ndarray:
+    """Partial (SrcAddr,DstPort,Proto) row sets -> one row per key, sorted like fa_read_window_app."""
+    parts = [np.ascontiguousarray(p, dtype=ROW_APP_DTYPE) for p in parts if len(p)]
+    if not parts:
+        return np.zeros(0, dtype=ROW_APP_DTYPE)
+    rows = np.concatenate(parts)
+    addr = np.ascontiguousarray(rows["src_addr"])
+    hi = addr[:, :8].copy().view(">u8").reshape(-1)
+    lo = addr[:, 8:].copy().view(">u8").reshape(-1)
+    order = np.lexsort((rows["proto"], rows["dst_port"], lo, hi, rows["timeslot"], rows["date"]))
+    return _merge_sorted_groups(rows[order], ("date", "timeslot", "src_addr", "dst_port", "proto"), ("bytes", "packets", "count"))
+
+
+def merge_ports_host(parts) -> np.ndarray:
+    """Partial GROUP BY port row sets -> merged, ORDER BY weight DESC, port (viz-ch.json:358,604)."""
+    parts = [np.ascontiguousarray(p, dtype=PORT_ROW_DTYPE) for p in parts if len(p)]
+    if not parts:
+        return np.zeros(0, dtype=PORT_ROW_DTYPE)
+    rows = np.concatenate(parts)
+    rows = _merge_sorted_groups(rows[np.argsort(rows["port"], kind="stable")], ("port",), ("weight", "count"))
+    return rows[np.lexsort((rows["port"], np.uint64(0xFFFFFFFFFFFFFFFF) - rows["weight"]))]
+
+
+def merge_minutes_host(parts) -> np.ndarray:
+    """Partial per-minute series -> merged, ORDER BY minute (viz-ch.json:74)."""
+    parts = [np.ascontiguousarray(p, dtype=MINUTE_ROW_DTYPE) for p in parts if len(p)]
+    if not parts:
+        return np.zeros(0, dtype=MINUTE_ROW_DTYPE)
+    rows = np.concatenate(parts)
+    return _merge_sorted_groups(rows[np.argsort(rows["minute"], kind="stable")], ("minute",), ("weight", "count"))
+
+
+def allgather_struct(rows: np.ndarray, dtype, group=None, device=None):
+    """All ranks receive every rank's rows of `dtype` (list indexed by rank)."""
+    rows = np.ascontiguousarray(rows, dtype=dtype)
+    return [b.view(dtype).copy() for b in allgather_bytes(rows.view(np.uint8).reshape(-1), group=group, device=device)]
+
+
+def close_window_app_merged(agg, timeslot, group=None, device=None) -> np.ndarray:
+    """Window close of the (SrcAddr,DstPort,Proto) key set across ranks (identical result on every rank)."""
+    local = agg.close_window_app(timeslot)
+    return merge_rows_app_host(allgather_struct(local, ROW_APP_DTYPE, group=group, device=device))
+
+
+def top_ports_merged(agg, dst, k=None, group=None, device=None) -> np.ndarray:
+    rows = merge_ports_host(allgather_struct(agg.top_ports(dst), PORT_ROW_DTYPE, group=group, device=device))
+    return rows if k is None else rows[:k]
+
+
+def minute_series_merged(agg, group=None, device=None) -> np.ndarray:
+    return merge_minutes_host(allgather_struct(agg.minute_series(), MINUTE_ROW_DTYPE, group=group, device=device))
 
 
 def allgather_rows(rows: np.ndarray, group=None, device=None):
@@ -98,9 +178,9 @@ def allreduce_sketches(agg, group=None):
     import torch
     import torch.distributed as dist
     st = agg.device_state()
-    for ptr in (st.cms_src, st.cms_dst):
-        if ptr:
-            t = torch.as_tensor(_DevArray(ptr, st.cms_words), device="cuda")
+    for ptr, words in ((st.cms_src, st.cms_words), (st.cms_dst, st.cms_words), (st.port_hist, st.port_hist_words)):
+        if ptr:  # the dense port histograms merge the same way (ports >= 65536 travel as rows: top_ports_merged)
+            t = torch.as_tensor(_DevArray(ptr, words), device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     torch.cuda.synchronize()
 

@@ -1,0 +1,459 @@
+// inserter_gpu - C++ host side above the C-ABI: the reference's Kafka consumer
+// (inserter/inserter.go) with its per-row Postgres sink replaced by libflowagg on an MI355X.
+//
+// The reference host is Go (sarama consumer group).  There is no Go toolchain in this image, so the
+// host side is written in C++ and mirrors the reference's interface for this path name by name:
+//   flags                 inserter.go:25-42  (same names, defaults and meaning; -postgres.* accepted and unused)
+//   ConsumerGroupHandler  Setup / Cleanup / ConsumeClaim            inserter.go:167-196
+//   buffer -> flush       by -flush.count and by -flush.dur          inserter.go:113-120,189-191
+//   error policy          malformed record: counted + dropped (inside the library, inserter.go:125-126);
+//                         sink error: fatal (log.Fatal, inserter.go:102-105)
+//   insert_count          the Prometheus counter of inserter.go:44-49 (written to -metrics.dump at exit)
+// The cgo twin of this file (what a maintainer of the reference would add) is go/inserter-gpu/main.go.
+//
+// Kafka itself is out of scope (no broker in this image): a claim's message stream is read
+// from a partition log file - the message values back to back, which is self-delimiting when the producer
+// runs with -proto.fixedlen=true (mocker.go:98-101; one framed record per message value), or with a
+// 4-byte little-endian length in front of every value (-input.format=len32) for bare records.
+//
+// Differences from the reference, on purpose (same as the Go shim):
+//   - messages are marked AFTER the sink accepted the batch (the reference marks first, inserter.go:188);
+//   - one aggregation context per claimed partition, no global mutex (inserter.go:84,115);
+//   - insert_count is actually incremented.
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/flowagg.h"
+
+// ---- flags (Go `flag` syntax: -name=value, -name value, --name=value; bools: -name / -name=false) -------
+struct Flags {
+    std::string LogLevel = "info";
+    std::string MetricsAddr = ":8081", MetricsPath = "/metrics";
+    std::string KafkaVersion = "2.1.1", KafkaTopic = "flows-processed", KafkaBrk = "127.0.0.1:9092,[::1]:9092",
+                KafkaGroup = "postgres-inserter";
+    double FlushTime = 5.0;  // -flush.dur (seconds; Go duration syntax accepted)
+    long FlushCount = 100;   // -flush.count
+    std::string PostgresUser = "postgres", PostgresPass, PostgresHost = "127.0.0.1", PostgresDbName = "postgres";
+    long PostgresPort = 5432;
+    // additive
+    long GpuDevices = 1;
+    bool ProtoFixed = true;
+    long WindowSecs = 300, CloseLagSec = 30;
+    long KeySets = FA_KEYS_AS_PAIR;
+    std::string InputFiles, InputFormat = "framed";
+    std::string OutRowBinary, OutTsv, OffsetsOut, MetricsDump;
+    bool DryRun = false;  // test double for the host logic: batches are logged, nothing is computed
+    bool CloseAllAtEnd = true;
+};
+
+static int g_loglevel = 2;  // 0 error, 1 warn, 2 info, 3 debug
+static std::mutex g_logmu;
+static void logf(int lvl, const char* fmt, ...) {
+    if (lvl > g_loglevel) return;
+    std::lock_guard<std::mutex> g(g_logmu);
+    static const char* names[] = {"error", "warning", "info", "debug"};
+    fprintf(stderr, "level=%s msg=\"", names[lvl]);
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "\"\n");
+}
+[[noreturn]] static void fatal(const char* fmt, ...) {  // log.Fatal
+    {
+        std::lock_guard<std::mutex> g(g_logmu);
+        fprintf(stderr, "level=fatal msg=\"");
+        va_list ap;
+        va_start(ap, fmt);
+        vfprintf(stderr, fmt, ap);
+        va_end(ap);
+        fprintf(stderr, "\"\n");
+    }
+    _Exit(1);
+}
+
+static bool parse_duration(const std::string& s, double& secs) {  // "5s", "500ms", "1m30s", "2h", plain number = seconds
+    secs = 0;
+    size_t i = 0;
+    bool any = false;
+    while (i < s.size()) {
+        size_t j = i;
+        while (j < s.size() && (isdigit((unsigned char)s[j]) || s[j] == '.')) j++;
+        if (j == i) return false;
+        double v = atof(s.substr(i, j - i).c_str());
+        size_t k = j;
+        while (k < s.size() && isalpha((unsigned char)s[k])) k++;
+        std::string u = s.substr(j, k - j);
+        if (u == "" && k == s.size()) secs += v;
+        else if (u == "ns") secs += v * 1e-9;
+        else if (u == "us") secs += v * 1e-6;
+        else if (u == "ms") secs += v * 1e-3;
+        else if (u == "s") secs += v;
+        else if (u == "m") secs += v * 60;
+        else if (u == "h") secs += v * 3600;
+        else return false;
+        any = true;
+        i = k;
+    }
+    return any;
+}
+
+static void usage_and_exit(const std::string& bad) {
+    fprintf(stderr, "flag provided but not defined: -%s\n", bad.c_str());
+    exit(2);
+}
+
+static Flags parse_flags(int argc, char** argv) {
+    Flags f;
+    std::map<std::string, std::string*> strs = {
+        {"loglevel", &f.LogLevel}, {"metrics.addr", &f.MetricsAddr}, {"metrics.path", &f.MetricsPath},
+        {"kafka.version", &f.KafkaVersion}, {"kafka.topic", &f.KafkaTopic}, {"kafka.brokers", &f.KafkaBrk},
+        {"kafka.group", &f.KafkaGroup}, {"postgres.user", &f.PostgresUser}, {"postgres.pass", &f.PostgresPass},
+        {"postgres.host", &f.PostgresHost}, {"postgres.dbname", &f.PostgresDbName}, {"input.files", &f.InputFiles},
+        {"input.format", &f.InputFormat}, {"out.rowbinary", &f.OutRowBinary}, {"out.tsv", &f.OutTsv},
+        {"offsets.out", &f.OffsetsOut}, {"metrics.dump", &f.MetricsDump}};
+    std::map<std::string, long*> ints = {
+        {"flush.count", &f.FlushCount}, {"postgres.port", &f.PostgresPort}, {"gpu.devices", &f.GpuDevices},
+        {"window.secs", &f.WindowSecs}, {"window.lag", &f.CloseLagSec},
+        {"key.sets", &f.KeySets}};
+    std::map<std::string, bool*> bools = {{"proto.fixedlen", &f.ProtoFixed}, {"sink.dryrun", &f.DryRun},
+                                          {"window.closeall", &f.CloseAllAtEnd}};
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        if (a.size() < 2 || a[0] != '-') fatal("unexpected argument %s", a.c_str());
+        a = a.substr(a[1] == '-' ? 2 : 1);
+        std::string name = a, val;
+        bool has = false;
+        size_t eq = a.find('=');
+        if (eq != std::string::npos) {
+            name = a.substr(0, eq);
+            val = a.substr(eq + 1);
+            has = true;
+        }
+        if (bools.count(name)) {
+            *bools[name] = !has || val == "true" || val == "1" || val == "t" || val == "T" || val == "TRUE" || val == "True";
+            continue;
+        }
+        if (!has) {
+            if (i + 1 >= argc) fatal("flag needs an argument: -%s", name.c_str());
+            val = argv[++i];
+        }
+        if (strs.count(name)) *strs[name] = val;
+        else if (ints.count(name)) *ints[name] = atol(val.c_str());
+        else if (name == "flush.dur") {
+            if (!parse_duration(val, f.FlushTime)) fatal("invalid value \"%s\" for flag -flush.dur", val.c_str());
+        } else usage_and_exit(name);
+    }
+    return f;
+}
+
+// ---- the consumer-group surface of the reference (sarama), reduced to what inserter.go uses -------------
+struct ConsumerMessage {
+    int32_t Partition;
+    int64_t Offset;
+    const uint8_t* Value;
+    size_t Len;
+};
+
+struct ConsumerGroupSession {
+    std::mutex mu;
+    std::map<int32_t, int64_t> marked;  // partition -> next offset to consume (sarama: offset+1 is committed)
+    void MarkMessage(const ConsumerMessage& m, const char* /*metadata*/) {
+        std::lock_guard<std::mutex> g(mu);
+        int64_t& o = marked[m.Partition];
+        if (m.Offset + 1 > o) o = m.Offset + 1;
+    }
+};
+
+// One claimed partition: a message stream.  next() returns false when the claim is closed.
+class ConsumerGroupClaim {
+public:
+    ConsumerGroupClaim(int32_t part, std::vector<uint8_t> log, bool len32) : part_(part), log_(std::move(log)), len32_(len32) {}
+    int32_t Partition() const { return part_; }
+    bool next(ConsumerMessage& m) {
+        if (pos_ >= log_.size()) return false;
+        size_t start = pos_, len = 0;
+        if (len32_) {
+            if (log_.size() - pos_ < 4) fatal("partition %d: truncated length prefix at byte %zu", part_, pos_);
+            uint32_t l;
+            memcpy(&l, &log_[pos_], 4);
+            start = pos_ + 4;
+            len = l;
+        } else {  // value = varint(len) || payload (mocker.go:98-101): the value includes its prefix
+            uint64_t v = 0;
+            size_t p = pos_;
+            for (int i = 0;; i++) {
+                if (i >= 10 || p >= log_.size()) fatal("partition %d: bad varint frame at byte %zu", part_, pos_);
+                uint8_t b = log_[p++];
+                v |= (uint64_t)(b & 0x7f) << (7 * i);
+                if (!(b & 0x80)) break;
+            }
+            len = (p - pos_) + v;
+        }
+        if (len > log_.size() - start) fatal("partition %d: message at byte %zu runs past the end of the log", part_, pos_);
+        m = ConsumerMessage{part_, off_++, &log_[start], len};
+        pos_ = start + len;
+        return true;
+    }
+
+private:
+    int32_t part_;
+    std::vector<uint8_t> log_;
+    bool len32_;
+    size_t pos_ = 0;
+    int64_t off_ = 0;
+};
+
+struct ConsumerGroupHandler {
+    virtual ~ConsumerGroupHandler() {}
+    virtual int Setup(ConsumerGroupSession&) = 0;
+    virtual int Cleanup(ConsumerGroupSession&) = 0;
+    virtual int ConsumeClaim(ConsumerGroupSession&, ConsumerGroupClaim&) = 0;
+};
+
+// ---- the sink -----------------------------------------------------------------------------------------------
+static std::atomic<uint64_t> Inserts{0};  // insert_count (inserter.go:44-49)
+static std::atomic<uint64_t> RowsOut{0}, Flushes{0};
+
+class RowWriter {  // flows_5m rows of closed windows: RowBinary for clickhouse-client / HTTP, TSV for humans
+public:
+    void open(const Flags& f) {
+        if (!f.OutRowBinary.empty() && !(rb_ = fopen(f.OutRowBinary.c_str(), "wb"))) fatal("cannot open %s", f.OutRowBinary.c_str());
+        if (!f.OutTsv.empty() && !(tsv_ = fopen(f.OutTsv.c_str(), "w"))) fatal("cannot open %s", f.OutTsv.c_str());
+    }
+    void write(const std::vector<fa_row5m>& rows) {
+        if (rows.empty()) return;
+        std::lock_guard<std::mutex> g(mu_);
+        if (rb_) {
+            std::vector<uint8_t> buf(rows.size() * FA_ROWBINARY_ROW5M_BYTES);
+            size_t n = 0;
+            if (fa_rows_to_rowbinary(rows.data(), rows.size(), buf.data(), buf.size(), &n) != 0) fatal("fa_rows_to_rowbinary failed");
+            if (fwrite(buf.data(), 1, n, rb_) != n) fatal("short write on the RowBinary sink");
+        }
+        if (tsv_)
+            for (auto& r : rows)
+                fprintf(tsv_, "%u\t%u\t%u\t%u\t%u\t%llu\t%llu\t%llu\n", r.date, r.timeslot, r.src_as, r.dst_as, r.etype,
+                        (unsigned long long)r.bytes, (unsigned long long)r.packets, (unsigned long long)r.count);
+        RowsOut += rows.size();
+    }
+    void close() {
+        if (rb_) fclose(rb_);
+        if (tsv_) fclose(tsv_);
+        rb_ = tsv_ = nullptr;
+    }
+
+private:
+    std::mutex mu_;
+    FILE* rb_ = nullptr;
+    FILE* tsv_ = nullptr;
+};
+
+// one aggregation context per claimed partition (fa_ctx is not thread-safe; distinct ctxs are independent)
+struct PartitionState {
+    fa_ctx* ctx = nullptr;
+    std::vector<uint8_t> buf;       // message values back to back
+    std::vector<uint64_t> offsets;  // n+1 entries
+    std::vector<ConsumerMessage> pending;
+};
+
+class State : public ConsumerGroupHandler {
+public:
+    State(const Flags& f, RowWriter& w) : f_(f), out_(w) {}
+
+    int Setup(ConsumerGroupSession&) override { return 0; }
+    int Cleanup(ConsumerGroupSession&) override { return 0; }
+
+    // ConsumeClaim: the consumer group runs one of these per claimed partition, concurrently (inserter.go:176)
+    int ConsumeClaim(ConsumerGroupSession& session, ConsumerGroupClaim& claim) override {
+        PartitionState* p = partition(claim.Partition());
+        auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(f_.FlushTime);
+        ConsumerMessage m;
+        while (claim.next(m)) {
+            p->buf.insert(p->buf.end(), m.Value, m.Value + m.Len);
+            p->offsets.push_back(p->buf.size());
+            p->pending.push_back(m);
+            if ((long)p->pending.size() >= f_.FlushCount) flush(*p, session);  // inserter.go:118-120
+            if (std::chrono::steady_clock::now() >= deadline) {                // inserter.go:189-191
+                flush(*p, session);
+                closeWindows(*p, (int64_t)time(nullptr), false);
+                deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(f_.FlushTime);
+            }
+        }
+        flush(*p, session);  // claim closed
+        return 0;
+    }
+
+    // flush = inserter.go:90-111 with the per-row db.Exec loop replaced by one fa_ingest
+    void flush(PartitionState& p, ConsumerGroupSession& session) {
+        const size_t n = p.offsets.size() - 1;
+        if (n == 0) return;
+        logf(3, "Processed %zu records in the last iteration.", n);
+        if (f_.DryRun) {
+            logf(2, "dryrun flush partition=%d records=%zu bytes=%zu", p.pending.front().Partition, n, p.buf.size());
+        } else {
+            // fa_ingest copies into library-owned pinned memory before returning
+            int rc = fa_ingest(p.ctx, p.buf.data(), p.buf.size(), p.offsets.data(), n);
+            if (rc != 0) fatal("fa_ingest: %d %s", rc, fa_last_error(p.ctx));  // sink error is fatal, inserter.go:102-105
+        }
+        Inserts += n;
+        Flushes += 1;
+        for (auto& m : p.pending) session.MarkMessage(m, "");  // after the sink accepted the batch
+        p.buf.clear();
+        p.offsets.assign(1, 0);
+        p.pending.clear();
+    }
+
+    // emits finished flows_5m rows (create.sh:70-90) to the bulk-load sink
+    void closeWindows(PartitionState& p, int64_t now, bool all) {
+        if (f_.DryRun) return;
+        std::vector<uint32_t> slots(64);
+        size_t ns = 0;
+        int rc = fa_open_timeslots(p.ctx, slots.data(), slots.size(), &ns);
+        if (rc == FA_ERR_CAPACITY) {
+            slots.resize(ns);
+            rc = fa_open_timeslots(p.ctx, slots.data(), slots.size(), &ns);
+        }
+        if (rc != 0) fatal("fa_open_timeslots: %d %s", rc, fa_last_error(p.ctx));
+        const uint32_t gran = (uint32_t)f_.WindowSecs;
+        for (size_t i = 0; i < ns; i++) {
+            const uint32_t ts = slots[i];
+            if (!all && (int64_t)ts + gran + f_.CloseLagSec > now) continue;
+            std::vector<fa_row5m> rows(1 << 16);
+            size_t nr = 0;
+            rc = closeOne(p, ts, rows, nr);
+            if (rc != 0) fatal("fa_close_window: %d %s", rc, fa_last_error(p.ctx));
+            rows.resize(nr);
+            logf(2, "flows_5m timeslot %u: %zu rows", ts, nr);
+            out_.write(rows);
+        }
+    }
+
+    void finish(ConsumerGroupSession&) {
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto& kv : parts_) {
+            if (f_.CloseAllAtEnd) closeWindows(*kv.second, 0, true);
+            if (!f_.DryRun) {
+                fa_stats_t st;
+                if (fa_stats(kv.second->ctx, &st) == 0)
+                    logf(2, "partition %d: records_ok=%llu records_bad=%llu", kv.first, (unsigned long long)st.records_ok,
+                         (unsigned long long)st.records_bad);
+                bad_ += st.records_bad;
+                fa_destroy(kv.second->ctx);
+            }
+        }
+    }
+    uint64_t bad() const { return bad_; }
+
+private:
+    int closeOne(PartitionState& p, uint32_t ts, std::vector<fa_row5m>& rows, size_t& nr) {
+        int rc = fa_close_window(p.ctx, ts, rows.data(), rows.size(), &nr);
+        if (rc == FA_ERR_CAPACITY) {
+            rows.resize(nr);
+            rc = fa_close_window(p.ctx, ts, rows.data(), rows.size(), &nr);
+        }
+        return rc;
+    }
+
+    PartitionState* partition(int32_t part) {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = parts_.find(part);
+        if (it != parts_.end()) return it->second.get();
+        auto p = std::make_unique<PartitionState>();
+        p->offsets.assign(1, 0);
+        if (!f_.DryRun) {
+            fa_config cfg;
+            memset(&cfg, 0, sizeof cfg);
+            cfg.device = (int32_t)(part % (f_.GpuDevices > 0 ? f_.GpuDevices : 1));
+            cfg.window_secs = (uint32_t)f_.WindowSecs;
+            cfg.subwindow_secs = 0;  // the sink stores tumbling windows (what flows_5m holds, create.sh:96)
+            cfg.key_sets = (uint32_t)f_.KeySets;
+            cfg.framed = f_.ProtoFixed ? 1 : 0;
+            int rc = fa_create(&cfg, &p->ctx);
+            if (rc != 0) fatal("fa_create: %d %s", rc, fa_last_error(nullptr));
+        }
+        PartitionState* raw = p.get();
+        parts_[part] = std::move(p);
+        return raw;
+    }
+
+    const Flags& f_;
+    RowWriter& out_;
+    std::mutex mu_;
+    std::map<int32_t, std::unique_ptr<PartitionState>> parts_;
+    uint64_t bad_ = 0;
+};
+
+static std::vector<uint8_t> read_file(const std::string& path) {
+    FILE* fp = fopen(path.c_str(), "rb");
+    if (!fp) fatal("cannot open %s", path.c_str());
+    std::vector<uint8_t> v;
+    uint8_t tmp[1 << 16];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof tmp, fp)) > 0) v.insert(v.end(), tmp, tmp + n);
+    fclose(fp);
+    return v;
+}
+
+int main(int argc, char** argv) {
+    Flags f = parse_flags(argc, argv);
+    g_loglevel = f.LogLevel == "debug" ? 3 : f.LogLevel == "info" ? 2 : f.LogLevel == "warning" || f.LogLevel == "warn" ? 1 : 0;
+    if (f.InputFiles.empty())
+        fatal("no Kafka client in this build: pass -input.files=p0.log,p1.log (one partition log per file, topic %s)", f.KafkaTopic.c_str());
+    if (f.InputFormat != "framed" && f.InputFormat != "len32") fatal("-input.format must be framed or len32");
+    if (f.InputFormat == "framed" && !f.ProtoFixed) fatal("-input.format=framed needs -proto.fixedlen=true (bare values are not self-delimiting)");
+    if (f.FlushCount < 1) fatal("-flush.count must be >= 1");
+
+    RowWriter out;
+    out.open(f);
+    State s(f, out);
+    ConsumerGroupSession session;
+
+    std::vector<std::unique_ptr<ConsumerGroupClaim>> claims;
+    int32_t part = 0;
+    size_t i = 0;
+    while (i <= f.InputFiles.size()) {
+        size_t j = f.InputFiles.find(',', i);
+        if (j == std::string::npos) j = f.InputFiles.size();
+        if (j > i) claims.push_back(std::make_unique<ConsumerGroupClaim>(part++, read_file(f.InputFiles.substr(i, j - i)), f.InputFormat == "len32"));
+        i = j + 1;
+    }
+    if (s.Setup(session) != 0) fatal("Setup failed");
+    logf(2, "inserter-gpu up and running: %zu partition(s), flush.count=%ld flush.dur=%gs", claims.size(), f.FlushCount, f.FlushTime);
+    std::vector<std::thread> workers;
+    for (auto& c : claims) workers.emplace_back([&s, &session, &c] { s.ConsumeClaim(session, *c); });
+    for (auto& t : workers) t.join();
+    s.finish(session);
+    if (s.Cleanup(session) != 0) fatal("Cleanup failed");
+    out.close();
+
+    if (!f.OffsetsOut.empty()) {
+        FILE* fp = fopen(f.OffsetsOut.c_str(), "w");
+        if (!fp) fatal("cannot open %s", f.OffsetsOut.c_str());
+        for (auto& kv : session.marked) fprintf(fp, "%d\t%lld\n", kv.first, (long long)kv.second);
+        fclose(fp);
+    }
+    if (!f.MetricsDump.empty()) {
+        FILE* fp = fopen(f.MetricsDump.c_str(), "w");
+        if (!fp) fatal("cannot open %s", f.MetricsDump.c_str());
+        fprintf(fp, "# HELP insert_count Inserts made to Postgres.\n# TYPE insert_count counter\ninsert_count %llu\n",
+                (unsigned long long)Inserts.load());
+        fprintf(fp, "# TYPE flowagg_flushes counter\nflowagg_flushes %llu\n", (unsigned long long)Flushes.load());
+        fprintf(fp, "# TYPE flowagg_rows_out counter\nflowagg_rows_out %llu\n", (unsigned long long)RowsOut.load());
+        fprintf(fp, "# TYPE flowagg_records_bad counter\nflowagg_records_bad %llu\n", (unsigned long long)s.bad());
+        fclose(fp);
+    }
+    logf(2, "done: insert_count=%llu flushes=%llu rows_out=%llu", (unsigned long long)Inserts.load(), (unsigned long long)Flushes.load(),
+         (unsigned long long)RowsOut.load());
+    return 0;
+}

@@ -190,6 +190,17 @@ int fa_close_window(fa_ctx*, uint32_t timeslot, fa_row5m* out, size_t cap, size_
 /* Same, without removing (peek). */
 int fa_read_window(fa_ctx*, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out);
 
+/* ---- bulk-load sink: flows_5m rows as ClickHouse RowBinary ------------------- */
+/* Serialises rows for `INSERT INTO flows_5m FORMAT RowBinary` with the column list of
+ * create.sh:70-90: Date (UInt16 days), Timeslot (DateTime = UInt32), SrcAS, DstAS (UInt32),
+ * ETypeMap.EType Array(UInt32), ETypeMap.Bytes / .Packets / .Count Array(UInt64) - one element each,
+ * what flows_5m_view writes (create.sh:100-103) - then Bytes, Packets, Count (UInt64).  70 bytes per
+ * row; replaces the reference's per-row db.Exec (inserter/inserter.go:100-106).  Pure host code, no ctx.
+ * Returns FA_ERR_CAPACITY (and the size in *bytes_out) when cap is too small; FA_ERR_ARG for a Date
+ * that does not fit UInt16. */
+#define FA_ROWBINARY_ROW5M_BYTES 70
+int fa_rows_to_rowbinary(const fa_row5m* rows, size_t n, uint8_t* out, size_t cap, size_t* bytes_out);
+
 /* ---- second exact key set: (SrcAddr, DstPort, Proto) ----------------------- */
 /* Same contract as fa_read_window / fa_close_window / fa_merge_rows; rows sorted by
  * (date, timeslot, src_addr bytes, dst_port, proto).  Need FA_KEYS_ADDR_PORT_PROTO. */

@@ -66,3 +66,22 @@ def test_host_generator_matches_oracle(fa, po):
             wb, wo = po.gen_records(gp, 100, 5000)
             hb, ho = fa.mock_generate_host(mp, 100, 5000)
             assert np.array_equal(hb, wb) and np.array_equal(ho, wo)
+
+
+def test_rowbinary_sink_known_answer(fa):
+    """flows_5m row of SURVEY Appendix A.1 KAT-1 -> RowBinary bytes (create.sh:70-90 column order), written
+    out by hand from the ClickHouse RowBinary rules: LE fixed-width ints, arrays = LEB128 length + elements."""
+    import numpy as np
+    rows = np.zeros(2, dtype=fa.ROW5M_DTYPE)
+    rows[0] = (19987, 1726899900, 65002, 65001, 34525, 0, 1499, 99, 1)
+    rows[1] = (19987, 1726899900, 1, 2, 0x800, 0, 2**64 - 1, 2**63, 7)
+    blob = fa.rows_to_rowbinary(rows)
+    want0 = ("134e" "bc66ee66" "eafd0000" "e9fd0000"
+             "01" "dd860000" "01" "db05000000000000" "01" "6300000000000000" "01" "0100000000000000"
+             "db05000000000000" "6300000000000000" "0100000000000000")
+    assert len(blob) == 140 and blob[:70].hex() == want0
+    assert fa.rowbinary_to_rows(blob).tobytes() == rows.tobytes()
+    bad = rows[:1].copy()
+    bad["date"] = 70000  # Date is UInt16 days
+    with pytest.raises(fa.FlowAggError):
+        fa.rows_to_rowbinary(bad)

@@ -52,6 +52,19 @@ def _worker(rank, world, port, q):
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     want = (sum(2**63 + 12345 + r for r in range(world))) % 2**64
     ok = ok and int(sk[0]) == want
+    # wide key sets: per-shard partial rows (oracle restatements standing in for the GPU) -> all-gather -> merge
+    rows, status = po.decode_batch(buf, off, 1)
+    sel = np.zeros(n, dtype=bool)
+    for p in mine:
+        sel[p::nparts] = True
+    d = fa.dist
+    app = d.merge_rows_app_host(d.allgather_struct(po.rollup_app(rows[sel], status[sel], 300), d.ROW_APP_DTYPE, device="cpu"))
+    ok = ok and app.tobytes() == po.rollup_app(rows, status, 300).astype(d.ROW_APP_DTYPE).tobytes()
+    for dst in (0, 1):
+        ports = d.merge_ports_host(d.allgather_struct(po.top_ports(rows[sel], status[sel], dst), d.PORT_ROW_DTYPE, device="cpu"))
+        ok = ok and ports.tobytes() == po.top_ports(rows, status, dst).tobytes()
+    mins = d.merge_minutes_host(d.allgather_struct(po.minute_series(rows[sel], status[sel]), d.MINUTE_ROW_DTYPE, device="cpu"))
+    ok = ok and mins.tobytes() == po.minute_series(rows, status).tobytes()
     q.put((rank, ok, len(merged), len(mine)))
     dist.destroy_process_group()
 
