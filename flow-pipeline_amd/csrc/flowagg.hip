@@ -562,8 +562,10 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         rc = ensure_segments(c, n, (uint32_t)grid, a);
         if (rc) return rc;
     }
-    HIPCHK(c, hipMemsetAsync(&c->d_ctr->exotic_count, 0, sizeof(unsigned int), c->stream));
-    HIPCHK(c, hipMemsetAsync(&c->d_ctr->retry_count, 0, sizeof(unsigned int), c->stream));
+    if (!scatter) {  // (the scatter path's probe kernel resets them)
+        HIPCHK(c, hipMemsetAsync(&c->d_ctr->exotic_count, 0, sizeof(unsigned int), c->stream));
+        HIPCHK(c, hipMemsetAsync(&c->d_ctr->retry_count, 0, sizeof(unsigned int), c->stream));
+    }
     if (c->ev_used == c->ev_pool.size()) {
         if (c->ev_pool.size() >= 4096) {  // bound the pool: fold what is pending
             rc = settle(c);

@@ -59,7 +59,7 @@ constexpr uint32_t FA_KEYS_WIDE = FA_KEYS_ADDR_PORT_PROTO | FA_KEYS_PORT_HIST | 
 constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense histograms
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
-       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024 };
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096 };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -482,7 +482,7 @@ __device__ __forceinline__ bool frame_short(uint32_t x, uint32_t rec_len, uint32
 template <int MODE, uint32_t KEYSETS, uint32_t COLS>
 __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, LdsMinutes& lm, uint32_t* part_cnt, const uint32_t* tile,
                                           bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
-                                          uint32_t& n_ok, uint32_t& n_direct) {
+                                          uint32_t& n_ok, uint32_t& n_direct, uint32_t& lt_seen, uint32_t& lt_hits) {
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false;
     Rec r;
@@ -523,7 +523,18 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         const uint32_t h = key_hash(k0, k1);
         const uint64_t b = r.bytes, p = r.packets, c = 1;
         bool pending = sure;
-        if (pending && !(a.dbg & DBG_NO_LDS_TABLE)) pending = !lds_table_add<LDS_SLOTS, LDS_PROBES>(lt, k0, k1, h, b, p, c);
+        // hot-key table: worth its LDS atomics only while it absorbs records.  Every wave keeps score (ballots:
+        // wave-uniform, no LDS traffic) and stops offering records once fewer than 1 in 8 of its first 256 stuck
+        // (64 k uniform AS pairs never do; the mocker's 9 groups always do).  lt_seen == ~0u: switched off.
+        if (lt_seen != 0xffffffffu && !(a.dbg & DBG_NO_LDS_TABLE)) {
+            if (pending) pending = !lds_table_add<LDS_SLOTS, LDS_PROBES>(lt, k0, k1, h, b, p, c);
+            lt_seen += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sure));
+            lt_hits += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sure && !pending));
+            if (lt_seen >= 256u) {
+                if (lt_hits * 8u < lt_seen) lt_seen = 0xffffffffu;
+                else lt_seen = lt_hits = 0;
+            }
+        }
         // tuple path: 16 bytes to this workgroup's private segment of the key's partition
         if (pending && a.seg) {
             const uint32_t tbr = tb - tb_base;
@@ -532,9 +543,15 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 const uint32_t part = h >> (32 - a.plog2);
                 const uint32_t q = atomicAdd(&part_cnt[part], 1u);
                 if (q < a.capq) {
-                    if (!(a.dbg & DBG_NO_TUPLE_STORE))
-                        a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + q] =
-                            make_uint4(r.src_as, r.dst_as, (uint32_t)b | (tbr << 28), (uint32_t)p | (r.etype << 15));
+                    if (!(a.dbg & DBG_NO_TUPLE_STORE)) {
+                        uint4* dstp = &a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + q];
+                        const uint4 tv = make_uint4(r.src_as, r.dst_as, (uint32_t)b | (tbr << 28), (uint32_t)p | (r.etype << 15));
+                        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                        const v4u tvv = {tv.x, tv.y, tv.z, tv.w};
+                        if (a.dbg & DBG_TUPLE_NT) __builtin_nontemporal_store(tvv, reinterpret_cast<v4u*>(dstp));
+                        else if (a.dbg & DBG_TUPLE_SC) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dstp), "v"(tvv) : "memory");
+                        else *dstp = tv;
+                    }
                     pending = false;
                 }
             }
@@ -606,7 +623,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     if (MODE == MODE_INGEST && (KEYSETS & FA_KEYS_MINUTE_SERIES)) lds_minutes_clear(lm);
     const uint32_t tb_base = MODE == MODE_INGEST ? a.ctr->tb_base : 0u;
 
-    uint32_t n_ok = 0, n_direct = 0;
+    uint32_t n_ok = 0, n_direct = 0, lt_seen = 0, lt_hits = 0;
     const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
     const uint32_t stride = gridDim.x;
     uint32_t t = blockIdx.x;
@@ -649,7 +666,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                 unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
                 a.exotic_idx[j] = cur.r0 + tid;
             }
-            lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, n_ok, n_direct);
+            lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, n_ok, n_direct, lt_seen, lt_hits);
         } else {
             // rare: the tile's bytes exceed the LDS buffer (big records): stage it in passes
             uint32_t done = 0;
@@ -677,7 +694,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                     }
                     done += 1;
                 } else {
-                    lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, n_ok, n_direct);
+                    lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, n_ok, n_direct, lt_seen, lt_hits);
                     done += nfit;
                 }
                 __syncthreads();  // the buffer is restaged by the next pass
@@ -761,13 +778,31 @@ __global__ __launch_bounds__(64) void probe_kernel(KArgs a) {
             ok = frame_fast(window64(src, pos), end - pos, pl);
             pos += pl;
         }
-        Rec r;
-        rec_clear(r);
-        if (ok) ok = parse_fast<COL_TIME_RECEIVED>(src, pos, end, r);
-        if (ok) atomicMin(&lo, time_bucket(a, (uint32_t)r.time_received));
+        if (ok) {
+            // what proto.Marshal emits (mocker.go:97): [Type 08 xx] then TimeReceived 10 <varint> - one or two
+            // cache-resident windows instead of a walk over the whole record; anything else: the general parser
+            uint64_t w = window64(src, pos);
+            if ((w & 0x80ffu) == 0x0008u) {
+                pos += 2;
+                w = window64(src, pos);
+            }
+            uint32_t vl;
+            uint64_t val;
+            if ((w & 0xffu) == 0x10u && varint6(w >> 8, vl, val) && pos + 1 + vl <= end) {
+                atomicMin(&lo, time_bucket(a, (uint32_t)val));
+            } else {
+                Rec r;
+                rec_clear(r);
+                if (parse_fast<COL_TIME_RECEIVED>(src, pos, end, r)) atomicMin(&lo, time_bucket(a, (uint32_t)r.time_received));
+            }
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) a.ctr->tb_base = lo == 0xffffffffu ? 0u : (lo > 2u ? lo - 2u : 0u);
+    if (threadIdx.x == 0) {
+        a.ctr->tb_base = lo == 0xffffffffu ? 0u : (lo > 2u ? lo - 2u : 0u);
+        a.ctr->exotic_count = 0;  // the batch's deferral lists start empty (saves two memset dispatches per batch)
+        a.ctr->retry_count = 0;
+    }
 }
 
 // Records the tile kernel could not stage (broken offsets, tiles larger than the LDS buffer): complete
@@ -901,11 +936,12 @@ struct AggTable {
 static_assert(sizeof(AggTable) == 32 * AGG_SLOTS, "agg_kernel LDS table");
 
 // slow path of the LDS upsert: claim / probe; false = the table is full around this hash
+// (skip = leading slots of the probe sequence already known to hold other keys: a key never changes)
 __device__ __forceinline__ bool agg_lds_upsert(AggTable& lt, uint64_t k0, uint64_t k1, uint32_t h, uint32_t by,
-                                               unsigned long long v2) {
-    uint32_t i = h & (AGG_SLOTS - 1);
+                                               unsigned long long v2, uint32_t skip = 0) {
+    uint32_t i = (h + skip) & (AGG_SLOTS - 1);
 #pragma unroll 1
-    for (int probe = 0; probe < AGG_PROBES; probe++, i = (i + 1) & (AGG_SLOTS - 1)) {
+    for (int probe = (int)skip; probe < AGG_PROBES; probe++, i = (i + 1) & (AGG_SLOTS - 1)) {
         unsigned long long c0 = lt.k0[i];
         if (c0 == 0) c0 = atomicCAS(&lt.k0[i], 0ull, (unsigned long long)k0);
         if (c0 != 0 && c0 != k0) continue;
@@ -971,26 +1007,39 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
         if (x == 0x12345678u) lt.s1[lane] = x;
         return;
     }
+    // home slot and its successor are read together: at the table's load (<= 40 %) linear probing leaves ~30 % of
+    // the keys one slot away from home and ~10 % further; only the latter (and first occurrences) take the
+    // probing path below
+    unsigned long long d0[AGG_CH], d1[AGG_CH];
 #pragma unroll
     for (int s = 0; s < AGG_CH; s++) {
         const uint32_t tbr = b.t[S0 + s].z >> 28, et = b.t[S0 + s].w >> 15;
         pack_key(tb_base + tbr, b.t[S0 + s].x, b.t[S0 + s].y, et, k0[s], k1[s]);
         h[s] = key_hash(k0[s], k1[s]);
-        const uint32_t i = h[s] & (AGG_SLOTS - 1);
+        const uint32_t i = h[s] & (AGG_SLOTS - 1), j = (i + 1) & (AGG_SLOTS - 1);
         c0[s] = lt.k0[i];
         c1[s] = lt.k1[i];
+        d0[s] = lt.k0[j];
+        d1[s] = lt.k1[j];
     }
     uint32_t pending = 0;  // segments whose tuple is not in its home slot (probing / claiming needed)
+    uint32_t skipw = 0;    // 2 bits per segment: leading probe slots known to hold other keys
 #pragma unroll
     for (int s = 0; s < AGG_CH; s++) {
         if (lane >= b.c[S0 + s]) continue;
         const uint32_t by = b.t[S0 + s].z & 0x0fffffffu, pk = b.t[S0 + s].w & 0x7fffu;
         const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
         const uint32_t i = h[s] & (AGG_SLOTS - 1);
-        if (c0[s] == k0[s] && c1[s] == k1[s]) {
-            if (by) atomicAdd(&lt.s1[i], (unsigned long long)by);
-            atomicAdd(&lt.s2[i], v2);
+        const bool at0 = c0[s] == k0[s] && c1[s] == k1[s], at1 = d0[s] == k0[s] && d1[s] == k1[s];
+        if (at0 || at1) {
+            const uint32_t t = at0 ? i : (i + 1) & (AGG_SLOTS - 1);
+            if (by) atomicAdd(&lt.s1[t], (unsigned long long)by);
+            atomicAdd(&lt.s2[t], v2);
         } else {
+            // slots that definitely belong to other keys need no second look on the probing path
+            const bool o0 = (c0[s] != 0 && c0[s] != k0[s]) || (c0[s] == k0[s] && c1[s] != 0 && c1[s] != k1[s]);
+            const bool o1 = (d0[s] != 0 && d0[s] != k0[s]) || (d0[s] == k0[s] && d1[s] != 0 && d1[s] != k1[s]);
+            skipw |= (o0 ? (o1 ? 2u : 1u) : 0u) << (2 * s);
             pending |= 1u << s;
         }
     }
@@ -1014,7 +1063,7 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
             }
             const uint32_t by = sz & 0x0fffffffu, pk = sw & 0x7fffu;
             const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
-            if (!agg_lds_upsert(lt, sk0, sk1, sh, by, v2))
+            if (!agg_lds_upsert(lt, sk0, sk1, sh, by, v2, (skipw >> (2 * s)) & 3u))
                 agg_global(a, sk0, sk1, sh, by, pk, 1);  // partition holds more groups than the LDS table
         }
     }
@@ -1065,14 +1114,28 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     // every group of this partition goes to the device-wide table once; quad-grouped: one atomic line
     // transaction per group.  Uniform trip count: the whole wave takes part in the quad rounds.
     if (a.dbg & DBG_AGG_NO_FLUSH) return;
-    for (int i0 = 0; i0 < AGG_SLOTS; i0 += AGG_BLOCK) {
-        const int i = i0 + threadIdx.x;
-        const unsigned long long k0 = lt.k0[i], k1 = lt.k1[i], s2 = lt.s2[i];
+    constexpr int NF = AGG_SLOTS / AGG_BLOCK;  // slots per thread
+    unsigned long long fk0[NF], fk1[NF], fs1[NF], fs2[NF];
+    ulonglong2 home[NF];
+    uint32_t fh[NF];
+#pragma unroll
+    for (int q = 0; q < NF; q++) {  // phase 1: the home-slot probes of all NF groups fly together
+        const int i = q * AGG_BLOCK + threadIdx.x;
+        fk0[q] = lt.k0[i];
+        fk1[q] = lt.k1[i];
+        fs1[q] = lt.s1[i];
+        fs2[q] = lt.s2[i];
+        fh[q] = key_hash(fk0[q], fk1[q]);
+        home[q] = *reinterpret_cast<const ulonglong2*>(&a.tab[fh[q] & a.mask]);
+    }
+#pragma unroll
+    for (int q = 0; q < NF; q++) {
         Slot* sp = nullptr;
-        const unsigned long long b = lt.s1[i], p = s2 >> 25, c = s2 & 0x1ffffffull;
-        if (k0 != 0 && k1 != 0 && s2 != 0) {
-            sp = table_find_or_claim(a, k0, k1, key_hash(k0, k1));
-            if (!sp) spill_park(a, k0, k1, b, p, c);
+        const unsigned long long b = fs1[q], p = fs2[q] >> 25, c = fs2[q] & 0x1ffffffull;
+        if (fk0[q] != 0 && fk1[q] != 0 && fs2[q] != 0) {
+            if (home[q].x == fk0[q] && home[q].y == fk1[q]) sp = &a.tab[fh[q] & a.mask];
+            else sp = table_find_or_claim(a, fk0[q], fk1[q], fh[q]);
+            if (!sp) spill_park(a, fk0[q], fk1[q], b, p, c);
         }
         quad_atomic_update(sp, b, p, c);
     }
