@@ -88,11 +88,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N")
+    # FA_BENCH_BACKEND=gloo + FA_BENCH_SHARE_GPU=1: dry run of the N>1 code path on a 1-GPU box (all ranks on
+    # device 0, exchange over gloo) - for testing the harness only, never a reported configuration
+    backend = os.environ.get("FA_BENCH_BACKEND", "nccl")
+    if os.environ.get("FA_BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if backend == "nccl" else torch.device("cpu")  # where the window-close exchange tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     fa = _pkg.load()
     fa.build()
@@ -139,7 +148,7 @@ def main():
     elapsed = time.perf_counter() - t0
     st1 = agg.stats()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -155,7 +164,7 @@ def main():
     # window close across ranks (the only exchange step): gather + merge flows_5m rows
     t_merge = time.perf_counter()
     if world > 1:
-        merged = fa.dist.close_window_merged(agg, fa.ALL_TIMESLOTS, device=dev)
+        merged = fa.dist.close_window_merged(agg, fa.ALL_TIMESLOTS, device=xdev)
     else:
         merged = agg.close_window(fa.ALL_TIMESLOTS)
     merge_ms = (time.perf_counter() - t_merge) * 1e3
@@ -206,7 +215,8 @@ def main():
             "traffic": traffic,
             "traffic_source": "profiles/r01_traffic.json: rocprofv3 --pmc, 2*FETCH_SIZE (gfx950 wide-read "
                               "correction) + WRITE_SIZE, bytes per launch" if traffic else None,
-            "kernel": "fa::tile_kernel<MODE_INGEST, AS_PAIR>" if args.key_sets == 1 else "fa::tile_kernel<MODE_INGEST, KS_ALL>",
+            "kernel": ("fa::wtile_kernel<%s>" if st1["wave_tile_launches"] > st0["wave_tile_launches"] else "fa::tile_kernel<MODE_INGEST, %s>")
+                      % ("AS_PAIR" if args.key_sets == 1 else "KS_ALL"),
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "avg_launch_ms": avg_launch_s * 1e3,
             "launches_timed": int(launches),

@@ -62,7 +62,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "records_ok", "records_bad", "records_slow", "bytes_in", "batches", "table_used",
         "table_capacity", "kernel_ns", "kernel_ns_total", "kernel_launches", "batch_ns_total",
-        "records_direct", "records_retried", "wide_used", "wide_capacity")]
+        "records_direct", "records_retried", "wide_used", "wide_capacity", "wave_tile_launches")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -46,6 +46,11 @@ struct fa_ctx {
     uint32_t* seg_counts = nullptr;
     size_t seg_counts_cap = 0;
     int sink_mode = 0;  // 0 auto, 1 direct, 2 scatter (env FA_SINK)
+    bool use_wave_tiles = false;  // decision for the batch being launched
+    // tile kernel choice (env FA_TILE=auto|wave|wg): wave-private tiles + LDS tuple bins pay when most records
+    // leave as tuples (many groups); with few groups the hot-key table absorbs them and the 256-thread kernel's
+    // higher occupancy wins.  auto = by the number of groups the table held at the last settle.
+    int tile_mode = 0;  // 0 auto, 1 wave, 2 workgroup
     uint32_t plog2 = PART_LOG2_MAX, wgpc_cap = 0;  // experiment knobs (env FA_PLOG2, FA_WGPC)
 
     // host-fed path: pinned staging (double buffered) + device input
@@ -199,6 +204,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_DEBUG_FLAGS")) c->dbg = (uint32_t)strtoul(d, nullptr, 0);
     if (const char* d = getenv("FA_PLOG2")) c->plog2 = std::min<uint32_t>(PART_LOG2_MAX, std::max<uint32_t>(4, (uint32_t)atoi(d)));
     if (const char* d = getenv("FA_WGPC")) c->wgpc_cap = (uint32_t)atoi(d);
+    if (const char* d = getenv("FA_TILE")) c->tile_mode = !strcmp(d, "wave") ? 1 : !strcmp(d, "wg") ? 2 : 0;
     if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
     auto bail = [&](const char* what, hipError_t e) {
         g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
@@ -452,9 +458,16 @@ static int launch_tiles(fa_ctx* c, const KArgs& a, int grid, fa_ctx::LaunchEvent
     dim3 ge(std::min(256u, (a.n + BLOCK - 1) / BLOCK));
     if (MODE == MODE_INGEST && a.seg) hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, c->stream, a);
     if (ev) (void)hipEventRecord(ev->e0, c->stream);
+    const bool wave_tiles = MODE == MODE_INGEST && a.seg != nullptr && a.tile_recs <= (uint32_t)WT_RECS && c->use_wave_tiles;
+    if (wave_tiles) c->stats.wave_tile_launches += 1;
 #define FA_LAUNCH(KS)                                                                           \
     case KS: {                                                                                  \
-        hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);                     \
+        if constexpr (MODE == MODE_INGEST) {                                                    \
+            if (wave_tiles) hipLaunchKernelGGL((wtile_kernel<KS>), g, dim3(WBLOCK), 0, c->stream, a); \
+            else hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);            \
+        } else {                                                                                \
+            hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);                 \
+        }                                                                                       \
         if (ev) (void)hipEventRecord(ev->e1, c->stream);                                        \
         hipLaunchKernelGGL((deferred_kernel<MODE, KS>), ge, b, 0, c->stream, a);                \
         break;                                                                                  \
@@ -465,7 +478,8 @@ static int launch_tiles(fa_ctx* c, const KArgs& a, int grid, fa_ctx::LaunchEvent
         switch (c->cfg.key_sets) {
             FA_LAUNCH(1u) FA_LAUNCH(2u) FA_LAUNCH(3u) FA_LAUNCH(4u) FA_LAUNCH(5u) FA_LAUNCH(6u) FA_LAUNCH(7u)
         default:  // any wide key set: the generic variant (runtime mask)
-            hipLaunchKernelGGL((tile_kernel<MODE, KS_ALL>), g, b, 0, c->stream, a);
+            if (wave_tiles) hipLaunchKernelGGL((wtile_kernel<KS_ALL>), g, dim3(WBLOCK), 0, c->stream, a);
+            else hipLaunchKernelGGL((tile_kernel<MODE, KS_ALL>), g, b, 0, c->stream, a);
             if (ev) (void)hipEventRecord(ev->e1, c->stream);
             hipLaunchKernelGGL((deferred_kernel<MODE, KS_ALL>), ge, b, 0, c->stream, a);
             break;
@@ -555,9 +569,18 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     a.off = (const uint32_t*)d_off;
     a.n = (uint32_t)n;
     a.tile_recs = tile_recs_for(len, n);
-    const int grid = tile_grid<MODE_INGEST>(c, a.n, a.tile_recs);
+    int grid = tile_grid<MODE_INGEST>(c, a.n, a.tile_recs);
     // small batches are not worth a second pass: they go straight to the device-wide table
     const bool scatter = (c->cfg.key_sets & FA_KEYS_AS_PAIR) && (c->sink_mode == 2 || (c->sink_mode == 0 && n >= (1u << 15)));
+    c->use_wave_tiles = scatter && (c->tile_mode == 1 || (c->tile_mode == 0 && c->stats.table_used >= 8192));
+    if (c->use_wave_tiles) {  // wave-private tiles: <= 64 records per wave, 8 waves per workgroup, 2 workgroups per CU
+        double avg = (double)len / (double)n + 0.5;
+        double r = ((double)WT_STRIDE - 16.0 - 15.0) / avg;
+        a.tile_recs = r >= (double)WT_RECS ? WT_RECS : r < 1.0 ? 1u : (uint32_t)r;
+        const uint32_t wtiles = (a.n + a.tile_recs - 1) / a.tile_recs;
+        const uint32_t wgs = (wtiles + (WBLOCK / 64) - 1) / (WBLOCK / 64);
+        grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * 2u));
+    }
     if (scatter) {
         rc = ensure_segments(c, n, (uint32_t)grid, a);
         if (rc) return rc;

@@ -36,6 +36,17 @@ constexpr int LDS_SLOTS = 64;      // per-workgroup hot-key slots (2.5 KiB)
 constexpr int LDS_PROBES = 2;
 constexpr int PART_LOG2_MAX = 8;   // key partitions of the scatter sink (<= 256: see tools/scatter_bench.hip)
 constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
+#ifndef FA_WBLOCK
+#define FA_WBLOCK 512
+#define FA_WT_STRIDE 5472
+#define FA_BIN_CAP 8
+#define FA_WT_FLUSH_EVERY 2
+#endif
+constexpr int WBLOCK = FA_WBLOCK;   // wave-tile kernel: 8 waves, each with a private LDS tile of <= 64 records
+constexpr int WT_RECS = 64;
+constexpr int WT_STRIDE = FA_WT_STRIDE;  // 64 records x 85 B + alignment slack (16-byte multiple); overreads land in the next tile / the bins
+constexpr uint32_t BIN_CAP = FA_BIN_CAP; // tuples a workgroup holds back per key partition between two flushes (256 x 8 x 16 B = 32 KiB)
+constexpr int WT_FLUSH_EVERY = FA_WT_FLUSH_EVERY;  // wave-tiles between flushes: 2 x 512 records / 256 partitions = 4 tuples per bin on average
 constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table
 #ifndef FA_AGG_SLOTS
 #define FA_AGG_SLOTS 4096
@@ -482,7 +493,8 @@ __device__ __forceinline__ bool frame_short(uint32_t x, uint32_t rec_len, uint32
 template <int MODE, uint32_t KEYSETS, uint32_t COLS>
 __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, LdsMinutes& lm, uint32_t* part_cnt, const uint32_t* tile,
                                           bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
-                                          uint32_t& n_ok, uint32_t& n_direct, uint32_t& lt_seen, uint32_t& lt_hits) {
+                                          uint32_t& n_ok, uint32_t& n_direct, uint32_t& lt_seen, uint32_t& lt_hits,
+                                          uint4* bins = nullptr, uint32_t* bin_cnt = nullptr) {
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false;
     Rec r;
@@ -541,18 +553,27 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             const bool fits = tbr < TUPLE_TB_SPAN && b < TUPLE_MAX_BYTES && p < TUPLE_MAX_PACKETS && r.etype < TUPLE_MAX_ETYPE;
             if (fits) {
                 const uint32_t part = h >> (32 - a.plog2);
-                const uint32_t q = atomicAdd(&part_cnt[part], 1u);
-                if (q < a.capq) {
-                    if (!(a.dbg & DBG_NO_TUPLE_STORE)) {
-                        uint4* dstp = &a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + q];
-                        const uint4 tv = make_uint4(r.src_as, r.dst_as, (uint32_t)b | (tbr << 28), (uint32_t)p | (r.etype << 15));
-                        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                        const v4u tvv = {tv.x, tv.y, tv.z, tv.w};
-                        if (a.dbg & DBG_TUPLE_NT) __builtin_nontemporal_store(tvv, reinterpret_cast<v4u*>(dstp));
-                        else if (a.dbg & DBG_TUPLE_SC) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dstp), "v"(tvv) : "memory");
-                        else *dstp = tv;
-                    }
+                const uint4 tv = make_uint4(r.src_as, r.dst_as, (uint32_t)b | (tbr << 28), (uint32_t)p | (r.etype << 15));
+                // wave-tile kernel: the tuple waits in the workgroup's LDS bin of its partition and leaves in a
+                // contiguous run at the next flush; a full bin falls back to the single 16-byte store
+                uint32_t bslot = BIN_CAP;
+                if (bins) bslot = atomicAdd(&bin_cnt[part], 1u);
+                if (bslot < BIN_CAP) {
+                    bins[part * BIN_CAP + bslot] = tv;
                     pending = false;
+                } else {
+                    const uint32_t q = atomicAdd(&part_cnt[part], 1u);
+                    if (q < a.capq) {
+                        if (!(a.dbg & DBG_NO_TUPLE_STORE)) {
+                            uint4* dstp = &a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + q];
+                            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                            const v4u tvv = {tv.x, tv.y, tv.z, tv.w};
+                            if (a.dbg & DBG_TUPLE_NT) __builtin_nontemporal_store(tvv, reinterpret_cast<v4u*>(dstp));
+                            else if (a.dbg & DBG_TUPLE_SC) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dstp), "v"(tvv) : "memory");
+                            else *dstp = tv;
+                        }
+                        pending = false;
+                    }
                 }
             }
         }
@@ -756,6 +777,171 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
         tot = wave_sum_u64(n_direct);
         if (__lane_id() == 0 && tot) atomicAdd(&a.ctr->direct, (unsigned long long)tot);
     }
+}
+
+// ---- the wave-tile kernel ---------------------------------------------------------------------------
+// Same per-record work as tile_kernel, different residency: 2 workgroups of 8 waves per CU; every WAVE stages
+// its own tile of <= 64 records into a private LDS buffer and parses it without any workgroup barrier, and the
+// LDS this frees (the 256-thread kernel spends all of it on co-resident tiles) holds the tuple bins: a tuple
+// waits in the bin of its key partition and leaves in a contiguous run (4 tuples = 64 bytes on average) every
+// WT_FLUSH_EVERY tiles, instead of as a single 16-byte store whose cache line is evicted from the L2 long
+// before its neighbours arrive (DESIGN.md "Measurements").  The workgroup's segments are 3x longer, which
+// also suits agg_kernel's 64-lane loads.
+struct WTileDesc {
+    uint32_t r0, nrec, lo, hi;
+    bool fits;
+};
+__device__ __forceinline__ WTileDesc wtile_desc(const KArgs& a, uint32_t t, uint32_t ntiles) {
+    WTileDesc d{0, 0, 0, 0, false};
+    if (t < ntiles) {
+        d.r0 = t * a.tile_recs;
+        d.nrec = min(a.tile_recs, a.n - d.r0);
+        d.lo = a.off[d.r0];
+        d.hi = a.off[d.r0 + d.nrec];
+        d.fits = d.hi >= d.lo && (d.hi - (d.lo & ~15u)) <= (uint32_t)(WT_STRIDE - 16);
+    }
+    return d;
+}
+
+template <uint32_t KEYSETS>
+__global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
+    constexpr uint32_t COLS = cols_for_keysets<KEYSETS>();
+    constexpr int WAVES = WBLOCK / 64;
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[WAVES * WT_STRIDE / 4];
+    __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BIN_CAP];
+    __shared__ uint32_t bin_cnt[NPART_MAX];
+    __shared__ uint32_t part_cnt[NPART_MAX];
+    __shared__ LdsTable<LDS_SLOTS> lt;
+    __shared__ LdsMinutes lm;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (KEYSETS & FA_KEYS_AS_PAIR) {
+        lds_table_clear(lt);
+        for (int i = tid; i < NPART_MAX; i += WBLOCK) {
+            part_cnt[i] = 0;
+            bin_cnt[i] = 0;
+        }
+    }
+    if (KEYSETS & FA_KEYS_MINUTE_SERIES) lds_minutes_clear(lm);
+    const uint32_t tb_base = a.ctr->tb_base;
+    uint32_t* tile = tiles + wave * (WT_STRIDE / 4);
+
+    uint32_t n_ok = 0, n_direct = 0, lt_seen = 0, lt_hits = 0;
+    const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
+    const uint32_t stride = gridDim.x * WAVES;
+    const uint32_t rounds = (ntiles + stride - 1) / stride;  // the same for every wave of the grid (flush barriers)
+    uint32_t t = blockIdx.x * WAVES + wave;
+    WTileDesc cur = wtile_desc(a, t, ntiles);
+    uint32_t o0 = 0, o1 = 0;
+    if (lane < cur.nrec) {
+        o0 = a.off[cur.r0 + lane];
+        o1 = a.off[cur.r0 + lane + 1];
+    }
+    __syncthreads();  // LDS state cleared
+
+    auto issue_dma = [&](const WTileDesc& d) {
+        if (d.fits) {
+            const uint32_t cbase = d.lo & ~15u, nbytes = d.hi - cbase;
+            for (uint32_t o = lane * 16u; o < nbytes; o += 1024u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.buf + cbase + o),
+                                                 (__attribute__((address_space(3))) void*)(tile + (o - lane * 16u) / 4u), 16, 0, 2);
+        }
+    };
+    // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous
+    // tile was consumed, BEFORE the flush barriers, so that the memory system stays busy during a flush) and
+    // the descriptor + offsets of the tile after it are in flight
+    issue_dma(cur);
+    WTileDesc nxt = wtile_desc(a, t + stride, ntiles);
+    uint32_t n0 = 0, n1 = 0;
+    if (lane < nxt.nrec) {
+        n0 = a.off[nxt.r0 + lane];
+        n1 = a.off[nxt.r0 + lane + 1];
+    }
+    for (uint32_t round = 0; round < rounds; round++, t += stride) {
+        dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
+        // parse + sink
+        if (cur.nrec != 0) {
+            const uint32_t cbase = cur.lo & ~15u;
+            bool mine = cur.fits && lane < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
+            if (lane < cur.nrec && !mine) {  // tile larger than the buffer / broken offsets: the generic path judges it
+                unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
+                a.exotic_idx[j] = cur.r0 + lane;
+            }
+            lane_work<MODE_INGEST, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, n_ok,
+                                                  n_direct, lt_seen, lt_hits, bins, bin_cnt);
+        }
+        cur = nxt;
+        o0 = n0;
+        o1 = n1;
+        issue_dma(cur);  // next tile (the buffer is free: every read of the old tile has returned)
+        nxt = wtile_desc(a, t + 2 * stride, ntiles);
+        n0 = n1 = 0;
+        if (lane < nxt.nrec) {
+            n0 = a.off[nxt.r0 + lane];
+            n1 = a.off[nxt.r0 + lane + 1];
+        }
+        // (3) every WT_FLUSH_EVERY rounds the bins leave in runs (positions from the partition counters)
+        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg && ((round % WT_FLUSH_EVERY) == WT_FLUSH_EVERY - 1 || round + 1 == rounds)) {
+            __syncthreads();
+            for (uint32_t idx = tid; idx < (uint32_t)NPART_MAX * BIN_CAP; idx += WBLOCK) {
+                const uint32_t p = idx / BIN_CAP, sl = idx % BIN_CAP;
+                const uint32_t cnt = min(bin_cnt[p], BIN_CAP);
+                if (sl < cnt) {
+                    const uint32_t q = part_cnt[p] + sl;
+                    const uint4 tv = bins[idx];
+                    if (q < a.capq) {
+                        if (!(a.dbg & DBG_NO_TUPLE_STORE)) a.seg[(size_t)p * a.region + (size_t)blockIdx.x * a.capq + q] = tv;
+                    } else {  // segment full (skewed batch): straight to the device-wide table
+                        const uint32_t by = tv.z & 0x0fffffffu, tbr = tv.z >> 28, pk = tv.w & 0x7fffu, et = tv.w >> 15;
+                        uint64_t k0, k1;
+                        pack_key(tb_base + tbr, tv.x, tv.y, et, k0, k1);
+                        agg_global(a, k0, k1, key_hash(k0, k1), by, pk, 1);
+                        n_direct++;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < NPART_MAX) {
+                part_cnt[tid] += min(bin_cnt[tid], BIN_CAP);
+                bin_cnt[tid] = 0;
+            }
+            __syncthreads();
+        }
+    }
+    if (KEYSETS & FA_KEYS_MINUTE_SERIES) {
+        __syncthreads();
+        if (tid < LDS_MINUTES && lm.key[tid] != 0 && lm.c[tid] != 0) {
+            WKey k;
+            wkey_pack(WK_MINUTE, 0, 0, 0, lm.key[tid] - 1u, 0, k);
+            wagg_global(wargs(a), k, lm.w[tid], 0, lm.c[tid]);
+        }
+    }
+    if (KEYSETS & FA_KEYS_AS_PAIR) {
+        __syncthreads();
+        for (int i0 = 0; i0 < LDS_SLOTS; i0 += WBLOCK) {  // hot-key table -> device-wide table (full waves: quad rounds)
+            const int i = i0 + tid;
+            Slot* sp = nullptr;
+            unsigned long long b = 0, p = 0, c = 0;
+            if (i < LDS_SLOTS) {
+                const unsigned long long k0 = lt.k0[i], k1 = lt.k1[i];
+                b = lt.bytes[i];
+                p = lt.packets[i];
+                c = lt.count[i];
+                if (k0 != 0 && k1 != 0 && c != 0) {
+                    sp = table_find_or_claim(a, k0, k1, key_hash(k0, k1));
+                    if (!sp) spill_park(a, k0, k1, b, p, c);
+                }
+            }
+            quad_atomic_update(sp, b, p, c);
+        }
+        if (a.seg)
+            for (int i = tid; i < (1 << a.plog2); i += WBLOCK) a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min(part_cnt[i], a.capq);
+    }
+    uint64_t tot = wave_sum_u64(n_ok);
+    if (__lane_id() == 0 && tot) atomicAdd(&a.ctr->ok, (unsigned long long)tot);
+    tot = wave_sum_u64(n_direct);
+    if (__lane_id() == 0 && tot) atomicAdd(&a.ctr->direct, (unsigned long long)tot);
 }
 
 // ---- probe: where in time does this batch sit? ---------------------------------------------
@@ -970,17 +1156,21 @@ struct AggBatch {
 // issue the loads of lanes [0,64) of AGG_SU consecutive segments starting at w0.  The segment counts
 // come from LDS (pc, zero padded): a count read from global memory would put a full vmcnt drain between
 // consecutive tuple loads.
+// (j = chunk level: lanes [0,64) cover tuples [64j, 64j+64) of every segment)
 __device__ __forceinline__ void agg_fetch(const KArgs& a, const uint4* pbase, const uint32_t* pc, uint32_t w0, uint32_t lane,
-                                          AggBatch& b) {
+                                          uint32_t j, AggBatch& b) {
 #pragma unroll
-    for (int s = 0; s < AGG_SU; s++) b.c[s] = pc[min(w0 + s, (uint32_t)(AGG_MAX_NWG + AGG_SU - 1))];  // 0 past nwg
+    for (int s = 0; s < AGG_SU; s++) {
+        const uint32_t c = pc[min(w0 + s, (uint32_t)(AGG_MAX_NWG + AGG_SU - 1))];  // 0 past nwg
+        b.c[s] = c > 64u * j ? min(c - 64u * j, 64u) : 0u;
+    }
     // unconditional loads (lanes past the count re-read slot 0 of a valid segment): with predicated
     // loads the compiler cannot count what is in flight and drains everything (vmcnt(0)) before the
     // previous batch is consumed
 #pragma unroll
     for (int s = 0; s < AGG_SU; s++) {
         const uint32_t w = min(w0 + s, a.nwg - 1u);
-        b.t[s] = pbase[(size_t)w * a.capq + (lane < b.c[s] ? lane : 0u)];
+        b.t[s] = pbase[(size_t)w * a.capq + (lane < b.c[s] ? 64u * j + lane : 0u)];
     }
 }
 
@@ -1084,31 +1274,41 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
         lt.s1[i] = 0;
         lt.s2[i] = 0;
     }
-    for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_SU; i += AGG_BLOCK)
-        pc[i] = i < a.nwg ? a.seg_counts[(size_t)part * a.nwg + i] : 0u;
+    __shared__ uint32_t maxc_s;
+    if (threadIdx.x == 0) maxc_s = 0;
+    __syncthreads();
+    uint32_t mymax = 0;
+    for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_SU; i += AGG_BLOCK) {
+        const uint32_t c = i < a.nwg ? a.seg_counts[(size_t)part * a.nwg + i] : 0u;
+        pc[i] = c;
+        mymax = max(mymax, c);
+    }
+    for (int o = 32; o > 0; o >>= 1) mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&maxc_s, mymax);
     const uint32_t tb_base = a.ctr->tb_base;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint4* pbase = a.seg + (size_t)part * a.region;
     constexpr uint32_t STEP = (AGG_BLOCK / 64) * AGG_SU * AGG_SPLIT;
     __syncthreads();  // table cleared, counts staged
+    const uint32_t maxc = maxc_s;
     // software pipeline over this wave's segment groups: the next group's loads fly during the LDS work
     // (every fetch is unconditional - clamped addresses, zero counts past the end - so that the compiler
     // can count the loads in flight and wait for the older batch only)
-    AggBatch b0, b1;
-    uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * AGG_SU;
-    agg_fetch(a, pbase, pc, w0, lane, b0);
-    while (true) {
-        agg_fetch(a, pbase, pc, w0 + STEP, lane, b1);
-        agg_consume(a, lt, tb_base, lane, b0);
-        agg_fetch(a, pbase, pc, w0 + 2 * STEP, lane, b0);
-        agg_consume(a, lt, tb_base, lane, b1);
-        w0 += 2 * STEP;
-        if (w0 >= a.nwg) break;
-    }
-    // segments longer than one wave pass (rare: the mean is <= 43 tuples)
-    for (uint32_t w = sub * (AGG_BLOCK / 64) + wave; w < a.nwg; w += (AGG_BLOCK / 64) * AGG_SPLIT) {
-        const uint32_t c = pc[w];
-        for (uint32_t q = 64 + lane; q < c; q += 64) agg_tuple(a, lt, tb_base, pbase[(size_t)w * a.capq + q]);
+    // chunk levels: level j covers tuples [64j, 64j+64) of every segment (segments of the 512-thread tile kernel
+    // hold ~127 tuples, those of the 256-thread one ~42)
+    const uint32_t levels = (__builtin_amdgcn_readfirstlane(maxc) + 63u) >> 6;
+    for (uint32_t j = 0; j < levels; j++) {
+        AggBatch b0, b1;
+        uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * AGG_SU;
+        agg_fetch(a, pbase, pc, w0, lane, j, b0);
+        while (true) {
+            agg_fetch(a, pbase, pc, w0 + STEP, lane, j, b1);
+            agg_consume(a, lt, tb_base, lane, b0);
+            agg_fetch(a, pbase, pc, w0 + 2 * STEP, lane, j, b0);
+            agg_consume(a, lt, tb_base, lane, b1);
+            w0 += 2 * STEP;
+            if (w0 >= a.nwg) break;
+        }
     }
     __syncthreads();
     // every group of this partition goes to the device-wide table once; quad-grouped: one atomic line

@@ -146,6 +146,7 @@ typedef struct {
     uint64_t records_retried;  /* records decoded by the order-free second-chance parser */
     uint64_t wide_used;        /* occupied slots of the wide-key table */
     uint64_t wide_capacity;
+    uint64_t wave_tile_launches; /* ingest launches that ran the wave-tile kernel (the rest: workgroup-tile kernel) */
 } fa_stats_t;
 
 typedef struct {

@@ -354,6 +354,41 @@ def test_decode_noncanonical_records(gpu_lib, fa, po):
     assert_decode_equal(got, want, wstatus)
 
 
+@pytest.mark.parametrize("tile", ["wave", "wg", "auto"])
+def test_tile_kernel_variants_agree_with_oracle(gpu_lib, fa, po, monkeypatch, tile):
+    """Both ingest kernels (wave-private tiles + LDS tuple bins / 256-thread workgroup tiles) and the automatic
+    choice between them, over several batches incl. escapes, hot keys and a record size that shrinks the tiles."""
+    monkeypatch.setenv("FA_TILE", tile)
+    n = 400000
+    gp = po.gen_params(mode=1, framed=1, seed=31, n_total=n, span_secs=1500)
+    buf, off = po.gen_records(gp, 0, n)
+    recs = _custom_records(fa, po, 40000, 32)
+    big = [_enc_record(fa, [(2, po.T0 + 5), (14, 70000 + (i % 50)), (15, 9), (9, 10), (1000, b"z" * 300)]) for i in range(40000)]
+    ref = po.Rollup(300)
+    with fa.FlowAgg(framed=True) as agg:
+        for lo, hi in ((0, n // 2), (n // 2, n)):
+            b, o = buf[int(off[lo]):int(off[hi])], off[lo:hi + 1] - off[lo]
+            agg.ingest(b, o)
+            ref.ingest(b, o, 1)
+            agg.sync()  # the automatic choice looks at the table size of the last settle
+        st = agg.stats()
+        if tile == "wave":
+            assert st["wave_tile_launches"] == 2
+        elif tile == "wg":
+            assert st["wave_tile_launches"] == 0
+        else:
+            assert st["wave_tile_launches"] == 1  # first batch: empty table -> workgroup kernel; then many groups -> wave kernel
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+    ref = po.Rollup(300)
+    with fa.FlowAgg(framed=False) as agg:
+        for rr in (recs, big, recs):
+            b, o = concat(rr)
+            agg.ingest(b, o)
+            ref.ingest(b, o, 0)
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+        assert agg.stats()["records_ok"] == 120000
+
+
 def test_scatter_sink_hot_keys_and_many_batches(gpu_lib, fa, po, monkeypatch):
     """Same context, several batches, skewed keys (mocker: 9 groups) and uniform keys mixed:
     segment overflow, the hot-key table and repeated aggregation passes all stay exact."""
