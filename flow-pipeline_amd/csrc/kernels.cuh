@@ -70,7 +70,7 @@ constexpr uint32_t FA_KEYS_WIDE = FA_KEYS_ADDR_PORT_PROTO | FA_KEYS_PORT_HIST | 
 constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense histograms
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
-       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096 };
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_FLUSH = 65536, DBG_NO_FRAME = 131072 };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -502,7 +502,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     if (mine) {
         LdsSrc src{tile};
         sure = true;
-        if (a.framed) {
+        if (a.framed && !(a.dbg & DBG_NO_FRAME)) {
             uint32_t pl = 0;
             const uint32_t i = pos >> 2;
             sure = frame_short(fa_alignbyte(src.dw(i + 1), src.dw(i), pos), end - pos, pl);
@@ -602,24 +602,57 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb);
 }
 
+// End-of-kernel counters: one global atomic per WORKGROUP.  All waves of the grid finish at about the same
+// time, and same-address atomics serialize at the memory side: one atomic per wave (8192 of them) was a
+// ~30 us tail on a 0.4 ms launch.
+__device__ __forceinline__ void block_counters_add(uint32_t* lds2, Counters* ctr, uint32_t n_ok, uint32_t n_direct) {
+    if (threadIdx.x < 2) lds2[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t ok = (uint32_t)wave_sum_u64(n_ok), direct = (uint32_t)wave_sum_u64(n_direct);
+    if (__lane_id() == 0) {
+        if (ok) atomicAdd(&lds2[0], ok);
+        if (direct) atomicAdd(&lds2[1], direct);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (lds2[0]) atomicAdd(&ctr->ok, (unsigned long long)lds2[0]);
+        if (lds2[1]) atomicAdd(&ctr->direct, (unsigned long long)lds2[1]);
+    }
+}
+
 // ---- the tile kernel ----------------------------------------------------------
 // Persistent workgroups; tile = 256 consecutive records (one per lane).  The wire
 // bytes of tile t+1 stream into the second LDS buffer (async DMA) while tile t is
 // parsed and aggregated, so the HBM latency hides behind the integer work.
+// The descriptor is two loads (lo, hi) whose values must NOT be looked at before the tile's turn comes: any
+// arithmetic on them right after the loads makes the compiler wait for them - and, vmcnt being in-order, for
+// the DMA issued just before - and only then issue the per-lane offset loads: two serialized memory round
+// trips per tile (this cost 25 % of the staging bandwidth, tools/read_bench2.hip).  fits() is evaluated
+// when the tile is current.
 struct TileDesc {
     uint32_t r0, nrec, lo, hi;  // records [r0,r0+nrec), wire bytes [lo,hi)
-    bool fits;                  // whole tile fits one LDS buffer (the normal case)
 };
 __device__ __forceinline__ TileDesc tile_desc(const KArgs& a, uint32_t t, uint32_t ntiles) {
-    TileDesc d{0, 0, 0, 0, false};
+    TileDesc d{0, 0, 0, 0};
     if (t < ntiles) {
         d.r0 = t * a.tile_recs;
         d.nrec = min(a.tile_recs, a.n - d.r0);
-        d.lo = a.off[d.r0];
-        d.hi = a.off[d.r0 + d.nrec];
-        d.fits = d.hi >= d.lo && (d.hi - (d.lo & ~15u)) <= (uint32_t)TILE_BYTES;
+        // the indices are laundered through VGPRs: for provably uniform addresses the compiler moves the loaded
+        // values to SGPRs at once (v_readfirstlane right behind the loads = the same premature wait)
+        uint32_t i0 = d.r0, i1 = d.r0 + d.nrec;
+        asm volatile("" : "+v"(i0), "+v"(i1));
+        d.lo = a.off[i0];
+        d.hi = a.off[i1];
     }
     return d;
+}
+// the bounds of the tile whose turn has come, as wave-uniform scalars
+__device__ __forceinline__ TileDesc tile_current(const TileDesc& d) {
+    return TileDesc{d.r0, d.nrec, (uint32_t)__builtin_amdgcn_readfirstlane((int)d.lo), (uint32_t)__builtin_amdgcn_readfirstlane((int)d.hi)};
+}
+template <int BYTES>
+__device__ __forceinline__ bool tile_fits(const TileDesc& d) {  // whole tile fits one LDS buffer (the normal case)
+    return d.nrec != 0 && d.hi >= d.lo && (d.hi - (d.lo & ~15u)) <= (uint32_t)BYTES;
 }
 
 // Persistent workgroups; tile = up to 256 consecutive records (one per lane) staged
@@ -648,7 +681,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
     const uint32_t stride = gridDim.x;
     uint32_t t = blockIdx.x;
-    TileDesc cur = tile_desc(a, t, ntiles);
+    TileDesc cur = tile_current(tile_desc(a, t, ntiles));
     uint32_t o0 = 0, o1 = 0;  // this lane's record of the current tile
     if (t < ntiles && tid < cur.nrec) {
         o0 = a.off[cur.r0 + tid];
@@ -660,9 +693,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     uint32_t tm_wait = 0, tm_work = 0, tm_tiles = 0;
     const uint32_t tm_start = timing ? (uint32_t)clock64() : 0u;
     for (; t < ntiles; t += stride) {
+        const bool cur_fits = tile_fits<TILE_BYTES>(cur);
         const uint32_t tm0 = timing ? (uint32_t)clock64() : 0u;
         // (1) stream this tile's wire bytes into LDS (async DMA) ...
-        if (cur.fits) {
+        if (cur_fits) {
             // nt: the wire bytes are read exactly once; keeping them out of the way of the L2's open tuple lines
             // is worth 11 % of the launch (MI355X, tools/knobs.sh FA_DEBUG_FLAGS=512)
             if (a.dbg & DBG_DMA_NO_NT) dma_to_lds<0>(a.buf + (cur.lo & ~15u), cur.hi - (cur.lo & ~15u), tile);
@@ -680,7 +714,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
         const uint32_t tm1 = timing ? (uint32_t)clock64() : 0u;
 
         // (2) parse + aggregate out of LDS
-        if (cur.fits) {
+        if (cur_fits) {
             const uint32_t cbase = cur.lo & ~15u;
             const bool mine = tid < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
             if (tid < cur.nrec && !mine) {  // broken offsets: let the generic path judge it
@@ -728,7 +762,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
             tm_work += tm2 - tm1;
             tm_tiles++;
         }
-        cur = nxt;
+        cur = tile_current(nxt);
         o0 = n0;
         o1 = n1;
     }
@@ -772,10 +806,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
             for (int i = tid; i < (1 << a.plog2); i += BLOCK)
                 a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min(part_cnt[i], a.capq);
         }
-        uint64_t tot = wave_sum_u64(n_ok);
-        if (__lane_id() == 0 && tot) atomicAdd(&a.ctr->ok, (unsigned long long)tot);
-        tot = wave_sum_u64(n_direct);
-        if (__lane_id() == 0 && tot) atomicAdd(&a.ctr->direct, (unsigned long long)tot);
+        block_counters_add(part_cnt, a.ctr, n_ok, n_direct);  // (part_cnt has been written out: reused as scratch)
     }
 }
 
@@ -787,18 +818,21 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
 // WT_FLUSH_EVERY tiles, instead of as a single 16-byte store whose cache line is evicted from the L2 long
 // before its neighbours arrive (DESIGN.md "Measurements").  The workgroup's segments are 3x longer, which
 // also suits agg_kernel's 64-lane loads.
-struct WTileDesc {
-    uint32_t r0, nrec, lo, hi;
-    bool fits;
-};
+typedef TileDesc WTileDesc;  // (same rule: the loaded bounds are not looked at before the tile's turn)
 __device__ __forceinline__ WTileDesc wtile_desc(const KArgs& a, uint32_t t, uint32_t ntiles) {
-    WTileDesc d{0, 0, 0, 0, false};
+    WTileDesc d{0, 0, 0, 0};
     if (t < ntiles) {
         d.r0 = t * a.tile_recs;
         d.nrec = min(a.tile_recs, a.n - d.r0);
-        d.lo = a.off[d.r0];
-        d.hi = a.off[d.r0 + d.nrec];
-        d.fits = d.hi >= d.lo && (d.hi - (d.lo & ~15u)) <= (uint32_t)(WT_STRIDE - 16);
+        if (a.dbg & DBG_SYNTH_TILES) {  // measurement only: fixed-size aligned tiles, no descriptor loads
+            d.lo = t * 4608u;
+            d.hi = d.lo + 4608u;
+            return d;
+        }
+        uint32_t i0 = d.r0, i1 = d.r0 + d.nrec;
+        asm volatile("" : "+v"(i0), "+v"(i1));  // (see tile_desc)
+        d.lo = a.off[i0];
+        d.hi = a.off[i1];
     }
     return d;
 }
@@ -832,16 +866,17 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     const uint32_t stride = gridDim.x * WAVES;
     const uint32_t rounds = (ntiles + stride - 1) / stride;  // the same for every wave of the grid (flush barriers)
     uint32_t t = blockIdx.x * WAVES + wave;
-    WTileDesc cur = wtile_desc(a, t, ntiles);
+    WTileDesc cur = tile_current(wtile_desc(a, t, ntiles));
     uint32_t o0 = 0, o1 = 0;
-    if (lane < cur.nrec) {
-        o0 = a.off[cur.r0 + lane];
-        o1 = a.off[cur.r0 + lane + 1];
-    }
+    const bool lane_off = !(a.dbg & DBG_NO_LANE_OFF);
+    // one offset load per lane: a record's end is its neighbour's start (lane nrec-1: the tile's end, already known)
+    if (lane_off && lane < cur.nrec) o0 = a.off[cur.r0 + lane];
+    o1 = (uint32_t)__shfl_down((int)o0, 1);
+    if (lane + 1 >= cur.nrec) o1 = cur.hi;
     __syncthreads();  // LDS state cleared
 
     auto issue_dma = [&](const WTileDesc& d) {
-        if (d.fits) {
+        if (tile_fits<WT_STRIDE - 16>(d)) {
             const uint32_t cbase = d.lo & ~15u, nbytes = d.hi - cbase;
             for (uint32_t o = lane * 16u; o < nbytes; o += 1024u)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.buf + cbase + o),
@@ -853,36 +888,32 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     // the descriptor + offsets of the tile after it are in flight
     issue_dma(cur);
     WTileDesc nxt = wtile_desc(a, t + stride, ntiles);
-    uint32_t n0 = 0, n1 = 0;
-    if (lane < nxt.nrec) {
-        n0 = a.off[nxt.r0 + lane];
-        n1 = a.off[nxt.r0 + lane + 1];
-    }
+    uint32_t n0 = 0;
+    if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
     for (uint32_t round = 0; round < rounds; round++, t += stride) {
         dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
         // parse + sink
         if (cur.nrec != 0) {
             const uint32_t cbase = cur.lo & ~15u;
-            bool mine = cur.fits && lane < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
-            if (lane < cur.nrec && !mine) {  // tile larger than the buffer / broken offsets: the generic path judges it
+            bool mine = tile_fits<WT_STRIDE - 16>(cur) && lane < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
+            if (a.dbg & DBG_NOT_MINE) mine = mine && o0 == 0x7fffffffu;
+            if (lane < cur.nrec && !mine && !(a.dbg & (DBG_NO_LANE_OFF | DBG_SYNTH_TILES | DBG_NOT_MINE))) {  // tile larger than the buffer / broken offsets
                 unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
                 a.exotic_idx[j] = cur.r0 + lane;
             }
             lane_work<MODE_INGEST, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, n_ok,
                                                   n_direct, lt_seen, lt_hits, bins, bin_cnt);
         }
-        cur = nxt;
+        cur = tile_current(nxt);
         o0 = n0;
-        o1 = n1;
+        o1 = (uint32_t)__shfl_down((int)o0, 1);
+        if (lane + 1 >= cur.nrec) o1 = cur.hi;
         issue_dma(cur);  // next tile (the buffer is free: every read of the old tile has returned)
         nxt = wtile_desc(a, t + 2 * stride, ntiles);
-        n0 = n1 = 0;
-        if (lane < nxt.nrec) {
-            n0 = a.off[nxt.r0 + lane];
-            n1 = a.off[nxt.r0 + lane + 1];
-        }
+        n0 = 0;
+        if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
         // (3) every WT_FLUSH_EVERY rounds the bins leave in runs (positions from the partition counters)
-        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg && ((round % WT_FLUSH_EVERY) == WT_FLUSH_EVERY - 1 || round + 1 == rounds)) {
+        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg && !(a.dbg & DBG_NO_FLUSH) && ((round % WT_FLUSH_EVERY) == WT_FLUSH_EVERY - 1 || round + 1 == rounds)) {
             __syncthreads();
             for (uint32_t idx = tid; idx < (uint32_t)NPART_MAX * BIN_CAP; idx += WBLOCK) {
                 const uint32_t p = idx / BIN_CAP, sl = idx % BIN_CAP;
@@ -938,10 +969,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
         if (a.seg)
             for (int i = tid; i < (1 << a.plog2); i += WBLOCK) a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min(part_cnt[i], a.capq);
     }
-    uint64_t tot = wave_sum_u64(n_ok);
-    if (__lane_id() == 0 && tot) atomicAdd(&a.ctr->ok, (unsigned long long)tot);
-    tot = wave_sum_u64(n_direct);
-    if (__lane_id() == 0 && tot) atomicAdd(&a.ctr->direct, (unsigned long long)tot);
+    block_counters_add(bin_cnt, a.ctr, n_ok, n_direct);  // (the bins are empty by now: reused as scratch)
 }
 
 // ---- probe: where in time does this batch sit? ---------------------------------------------
