@@ -575,7 +575,9 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     c->use_wave_tiles = scatter && (c->tile_mode == 1 || (c->tile_mode == 0 && c->stats.table_used >= 8192));
     if (c->use_wave_tiles) {  // wave-private tiles: <= 64 records per wave, 8 waves per workgroup, 2 workgroups per CU
         double avg = (double)len / (double)n + 0.5;
-        double r = ((double)WT_STRIDE - 16.0 - 15.0) / avg;
+        // (a tile that does not fit its buffer goes to the deferred parsers as a whole, so leave ~4 sigma of
+        // headroom for a mix of 60- and 84-byte records when the buffer is tight)
+        double r = ((double)WT_STRIDE - 16.0 - 15.0 - 12.0 * 8.0 * 4.0) / avg;
         a.tile_recs = r >= (double)WT_RECS ? WT_RECS : r < 1.0 ? 1u : (uint32_t)r;
         const uint32_t wtiles = (a.n + a.tile_recs - 1) / a.tile_recs;
         const uint32_t wgs = (wtiles + (WBLOCK / 64) - 1) / (WBLOCK / 64);
