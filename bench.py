@@ -33,13 +33,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")
 
 
-def pmc_traffic(default_workload):
+def pmc_traffic(default_workload, kernel_key="tile_kernel"):
     if not default_workload or not os.path.exists(TRAFFIC_FILE):
         return None, None
     with open(TRAFFIC_FILE) as f:
         t = json.load(f)
     k = t.get("kernels", {})
-    return k.get("tile_kernel", {}).get("traffic_bytes"), k
+    return k.get(kernel_key, {}).get("traffic_bytes"), k
 
 
 def mix64(z):
@@ -175,7 +175,8 @@ def main():
 
     value = n_rec * args.steps * world / elapsed
     traffic, traffic_all = pmc_traffic(args.records == 100_000_000 and args.chunk == 16_666_667 and args.mode == "aspairs"
-                                       and not os.environ.get("FA_DEBUG_FLAGS") and args.key_sets == 1)
+                                       and not os.environ.get("FA_DEBUG_FLAGS") and args.key_sets == 1,
+                                       "wtile_kernel" if st1["wave_tile_launches"] > st0["wave_tile_launches"] else "tile_kernel")
     out = {
         "metric": "FlowMessages/sec aggregated into flows_5m",
         "value": value,

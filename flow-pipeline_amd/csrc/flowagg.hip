@@ -526,7 +526,7 @@ static int ensure_exotic(fa_ctx* c, size_t n) {
 static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     const size_t NPART = (size_t)1 << c->plog2;
     const size_t avg = n / ((size_t)nwg * NPART);
-    const uint32_t capq = (uint32_t)((2 * avg + 32 + 3) & ~(size_t)3);
+    const uint32_t capq = (uint32_t)((2 * avg + 32 + 7) & ~(size_t)7);  // whole 128-byte lines
     const size_t region = (size_t)nwg * capq + 24;
     const size_t tuples = region * NPART;
     if (c->seg_tuples < tuples) {
@@ -537,7 +537,7 @@ static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
         if (hipMalloc(&c->seg, tuples * sizeof(uint4)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(tuple segments) failed");
         c->seg_tuples = tuples;
     }
-    const size_t ncnt = (size_t)nwg * NPART;
+    const size_t ncnt = (size_t)nwg * NPART_MAX * 2;  // front and back counts
     if (c->seg_counts_cap < ncnt) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->seg_counts);
@@ -549,6 +549,8 @@ static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     a.seg = c->seg;
     a.seg_counts = c->seg_counts;
     a.capq = capq;
+    a.capb = std::min<uint32_t>(std::max<uint32_t>(32u, (capq / 4) & ~7u), 0xfff8u);  // back part: single tuples, bin leftovers
+    a.capf = std::min<uint32_t>(capq - a.capb, 0xffffu * 8u);                           // front part: full lines
     a.nwg = nwg;
     a.region = region;
     a.plog2 = c->plog2;

@@ -128,8 +128,9 @@ struct KArgs {
     double gran_recip;     // (1/gran)(1+2^-40): floor(t * gran_recip) == t / gran for every u32 t
     // scatter sink (seg == nullptr: every record takes the direct device-wide-table path)
     uint4* seg;            // [NPART][region] tuples; partition p, workgroup w: seg[p*region + w*capq + q]
-    uint32_t* seg_counts;  // [NPART][nwg]
-    uint32_t capq;         // tuples per (partition, workgroup) segment
+    uint32_t* seg_counts;  // [2][NPART][nwg]: tuples at the front of a segment, tuples at its back (wave-tile kernel only)
+    uint32_t capq;         // tuples per (partition, workgroup) segment (multiple of 8 = 128-byte lines)
+    uint32_t capf, capb;   // wave-tile kernel: front part (full lines, grows up from 0) and back part (single tuples, grows down from capq-1)
     uint32_t nwg;          // workgroups of the tile kernel that filled the segments
     unsigned long long region;  // tuples per partition (nwg*capq plus a skew against power-of-two strides)
     uint32_t plog2;        // log2(key partitions)
@@ -548,19 +549,30 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             }
         }
         // tuple path: 16 bytes to this workgroup's private segment of the key's partition
+        uint32_t fill_part = 0xffffffffu;  // wave-tile kernel: the bin this lane has just filled
         if (pending && a.seg) {
             const uint32_t tbr = tb - tb_base;
             const bool fits = tbr < TUPLE_TB_SPAN && b < TUPLE_MAX_BYTES && p < TUPLE_MAX_PACKETS && r.etype < TUPLE_MAX_ETYPE;
             if (fits) {
                 const uint32_t part = h >> (32 - a.plog2);
                 const uint4 tv = make_uint4(r.src_as, r.dst_as, (uint32_t)b | (tbr << 28), (uint32_t)p | (r.etype << 15));
-                // wave-tile kernel: the tuple waits in the workgroup's LDS bin of its partition and leaves in a
-                // contiguous run at the next flush; a full bin falls back to the single 16-byte store
-                uint32_t bslot = BIN_CAP;
-                if (bins) bslot = atomicAdd(&bin_cnt[part], 1u);
-                if (bslot < BIN_CAP) {
-                    bins[part * BIN_CAP + bslot] = tv;
-                    pending = false;
+                if (bins) {
+                    // wave-tile kernel: the tuple waits in the workgroup's LDS bin of its partition; the lane that takes
+                    // the last slot of a bin sends the 8 tuples off as one full, aligned 128-byte line (below)
+                    const uint32_t slot = atomicAdd(&bin_cnt[part], 1u) & 0xffffu;  // low half: slots taken, high half: slots written
+                    if (slot < BIN_CAP) {
+                        bins[part * BIN_CAP + slot] = tv;
+                        atomicAdd(&bin_cnt[part], 0x10000u);
+                        fill_part = slot == BIN_CAP - 1 ? part : fill_part;
+                        pending = false;
+                    } else {  // the bin is on its way out: single 16-byte store to the back part of the segment
+                        const uint32_t ob = atomicAdd(&part_cnt[part], 0x10000u) >> 16;
+                        if (ob < a.capb) {
+                            if (!(a.dbg & DBG_NO_TUPLE_STORE))
+                                a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob)] = tv;
+                            pending = false;
+                        }
+                    }
                 } else {
                     const uint32_t q = atomicAdd(&part_cnt[part], 1u);
                     if (q < a.capq) {
@@ -573,6 +585,45 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                             else *dstp = tv;
                         }
                         pending = false;
+                    }
+                }
+            }
+        }
+        // Full bins leave as whole, aligned 128-byte lines, up to 8 bins per pass: lane group g (8 lanes) takes the
+        // g-th filled bin, each lane copies one tuple - one store instruction writes 8 complete lines, no partial
+        // lines and no workgroup barrier.  The producers of a bin's other slots may sit in other waves: the high
+        // half of the bin word counts the slots WRITTEN, and nobody can take a slot of a full bin, so the spin
+        // below only ever waits for straight-line code of waves that never wait for us (producers of this wave
+        // finished in lockstep above).  Scratch = the head of the wave's tile buffer (its bytes are parsed).
+        if (bins) {
+            const unsigned long long fm = __builtin_amdgcn_ballot_w64(fill_part != 0xffffffffu);
+            if (fm != 0ull) {
+                uint32_t* scratch = const_cast<uint32_t*>(tile);
+                const uint32_t ln = __lane_id(), g = ln >> 3, sub = ln & 7u;
+                const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << ln) - 1ull));
+                const uint32_t todo = (uint32_t)__builtin_popcountll(fm);
+                for (uint32_t base = 0; base < todo; base += 8u) {
+                    if (fill_part != 0xffffffffu && rank - base < 8u) scratch[rank - base] = fill_part;
+                    const bool act = g < min(8u, todo - base);
+                    const uint32_t fp = act ? scratch[g] : 0u;
+                    while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&bin_cnt[fp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < BIN_CAP) != 0ull) {}
+                    uint32_t line = 0;
+                    if (act && sub == 0) line = atomicAdd(&part_cnt[fp], 1u) & 0xffffu;  // low half: lines at the front
+                    line = (uint32_t)__shfl((int)line, (int)(ln & ~7u));
+                    if (act) {
+                        const uint4 tq = bins[fp * BIN_CAP + sub];
+                        if ((line + 1u) * BIN_CAP <= a.capf) {
+                            if (!(a.dbg & DBG_NO_TUPLE_STORE))
+                                a.seg[(size_t)fp * a.region + (size_t)blockIdx.x * a.capq + line * BIN_CAP + sub] = tq;
+                        } else {  // front part full (skewed batch): straight to the device-wide table
+                            const uint32_t qby = tq.z & 0x0fffffffu, qtbr = tq.z >> 28, qpk = tq.w & 0x7fffu, qet = tq.w >> 15;
+                            uint64_t q0, q1;
+                            pack_key(tb_base + qtbr, tq.x, tq.y, qet, q0, q1);
+                            agg_global(a, q0, q1, key_hash(q0, q1), qby, qpk, 1);
+                            n_direct++;
+                        }
+                        // (behind the reads: LDS operations of a wave complete in order)
+                        if (sub == 0) __hip_atomic_store(&bin_cnt[fp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
@@ -804,7 +855,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
         }
         if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
             for (int i = tid; i < (1 << a.plog2); i += BLOCK)
+{
                 a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min(part_cnt[i], a.capq);
+                a.seg_counts[((size_t)NPART_MAX + i) * a.nwg + blockIdx.x] = 0;
+            }
         }
         block_counters_add(part_cnt, a.ctr, n_ok, n_direct);  // (part_cnt has been written out: reused as scratch)
     }
@@ -912,33 +966,33 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
         nxt = wtile_desc(a, t + 2 * stride, ntiles);
         n0 = 0;
         if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
-        // (3) every WT_FLUSH_EVERY rounds the bins leave in runs (positions from the partition counters)
-        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg && !(a.dbg & DBG_NO_FLUSH) && ((round % WT_FLUSH_EVERY) == WT_FLUSH_EVERY - 1 || round + 1 == rounds)) {
-            __syncthreads();
-            for (uint32_t idx = tid; idx < (uint32_t)NPART_MAX * BIN_CAP; idx += WBLOCK) {
-                const uint32_t p = idx / BIN_CAP, sl = idx % BIN_CAP;
-                const uint32_t cnt = min(bin_cnt[p], BIN_CAP);
-                if (sl < cnt) {
-                    const uint32_t q = part_cnt[p] + sl;
-                    const uint4 tv = bins[idx];
-                    if (q < a.capq) {
-                        if (!(a.dbg & DBG_NO_TUPLE_STORE)) a.seg[(size_t)p * a.region + (size_t)blockIdx.x * a.capq + q] = tv;
-                    } else {  // segment full (skewed batch): straight to the device-wide table
-                        const uint32_t by = tv.z & 0x0fffffffu, tbr = tv.z >> 28, pk = tv.w & 0x7fffu, et = tv.w >> 15;
-                        uint64_t k0, k1;
-                        pack_key(tb_base + tbr, tv.x, tv.y, et, k0, k1);
-                        agg_global(a, k0, k1, key_hash(k0, k1), by, pk, 1);
-                        n_direct++;
-                    }
+    }
+    // what is left in the bins (fewer than BIN_CAP tuples each) goes to the back part of the segments
+    if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
+        __syncthreads();
+        for (uint32_t idx = tid; idx < (uint32_t)NPART_MAX * BIN_CAP; idx += WBLOCK) {
+            const uint32_t p = idx / BIN_CAP, sl = idx % BIN_CAP;
+            const uint32_t cnt = min(bin_cnt[p] & 0xffffu, BIN_CAP);
+            if (sl < cnt) {
+                const uint32_t ob = (part_cnt[p] >> 16) + sl;
+                const uint4 tv = bins[idx];
+                if (ob < a.capb) {
+                    if (!(a.dbg & DBG_NO_TUPLE_STORE)) a.seg[(size_t)p * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob)] = tv;
+                } else {  // back part full (skewed batch): straight to the device-wide table
+                    const uint32_t by = tv.z & 0x0fffffffu, tbr = tv.z >> 28, pk = tv.w & 0x7fffu, et = tv.w >> 15;
+                    uint64_t k0, k1;
+                    pack_key(tb_base + tbr, tv.x, tv.y, et, k0, k1);
+                    agg_global(a, k0, k1, key_hash(k0, k1), by, pk, 1);
+                    n_direct++;
                 }
             }
-            __syncthreads();
-            if (tid < NPART_MAX) {
-                part_cnt[tid] += min(bin_cnt[tid], BIN_CAP);
-                bin_cnt[tid] = 0;
-            }
-            __syncthreads();
         }
+        __syncthreads();
+        if (tid < NPART_MAX) {
+            part_cnt[tid] += min(bin_cnt[tid] & 0xffffu, BIN_CAP) << 16;
+            bin_cnt[tid] = 0;
+        }
+        __syncthreads();
     }
     if (KEYSETS & FA_KEYS_MINUTE_SERIES) {
         __syncthreads();
@@ -967,7 +1021,11 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
             quad_atomic_update(sp, b, p, c);
         }
         if (a.seg)
-            for (int i = tid; i < (1 << a.plog2); i += WBLOCK) a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min(part_cnt[i], a.capq);
+            for (int i = tid; i < (1 << a.plog2); i += WBLOCK) {
+                const uint32_t w = part_cnt[i];
+                a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min((w & 0xffffu) * BIN_CAP, a.capf);
+                a.seg_counts[((size_t)NPART_MAX + i) * a.nwg + blockIdx.x] = min(w >> 16, a.capb);
+            }
     }
     block_counters_add(bin_cnt, a.ctr, n_ok, n_direct);  // (the bins are empty by now: reused as scratch)
 }
@@ -1184,13 +1242,17 @@ struct AggBatch {
 // issue the loads of lanes [0,64) of AGG_SU consecutive segments starting at w0.  The segment counts
 // come from LDS (pc, zero padded): a count read from global memory would put a full vmcnt drain between
 // consecutive tuple loads.
-// (j = chunk level: lanes [0,64) cover tuples [64j, 64j+64) of every segment)
+// (j = chunk level: lanes [0,64) cover tuples [64j, 64j+64) of every segment's front part - or, BACK, of the
+// c tuples that end at the segment's last slot)
+template <bool BACK>
 __device__ __forceinline__ void agg_fetch(const KArgs& a, const uint4* pbase, const uint32_t* pc, uint32_t w0, uint32_t lane,
                                           uint32_t j, AggBatch& b) {
+    uint32_t first[AGG_SU];
 #pragma unroll
     for (int s = 0; s < AGG_SU; s++) {
         const uint32_t c = pc[min(w0 + s, (uint32_t)(AGG_MAX_NWG + AGG_SU - 1))];  // 0 past nwg
         b.c[s] = c > 64u * j ? min(c - 64u * j, 64u) : 0u;
+        first[s] = (BACK ? a.capq - c : 0u) + 64u * j;
     }
     // unconditional loads (lanes past the count re-read slot 0 of a valid segment): with predicated
     // loads the compiler cannot count what is in flight and drains everything (vmcnt(0)) before the
@@ -1198,7 +1260,7 @@ __device__ __forceinline__ void agg_fetch(const KArgs& a, const uint4* pbase, co
 #pragma unroll
     for (int s = 0; s < AGG_SU; s++) {
         const uint32_t w = min(w0 + s, a.nwg - 1u);
-        b.t[s] = pbase[(size_t)w * a.capq + (lane < b.c[s] ? 64u * j + lane : 0u)];
+        b.t[s] = pbase[(size_t)w * a.capq + (lane < b.c[s] ? first[s] + lane : 0u)];
     }
 }
 
@@ -1302,23 +1364,33 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
         lt.s1[i] = 0;
         lt.s2[i] = 0;
     }
-    __shared__ uint32_t maxc_s;
-    if (threadIdx.x == 0) maxc_s = 0;
+    __shared__ uint32_t pcb[AGG_MAX_NWG + AGG_SU];  // ... and the counts of the segments' back parts
+    __shared__ uint32_t maxc_s[2];
+    if (threadIdx.x < 2) maxc_s[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t mymax = 0;
+    uint32_t mymax = 0, mymaxb = 0;
     for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_SU; i += AGG_BLOCK) {
         const uint32_t c = i < a.nwg ? a.seg_counts[(size_t)part * a.nwg + i] : 0u;
+        const uint32_t cb = i < a.nwg ? a.seg_counts[((size_t)NPART_MAX + part) * a.nwg + i] : 0u;
         pc[i] = c;
+        pcb[i] = cb;
         mymax = max(mymax, c);
+        mymaxb = max(mymaxb, cb);
     }
-    for (int o = 32; o > 0; o >>= 1) mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(&maxc_s, mymax);
+    for (int o = 32; o > 0; o >>= 1) {
+        mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, o));
+        mymaxb = max(mymaxb, (uint32_t)__shfl_xor((int)mymaxb, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&maxc_s[0], mymax);
+        atomicMax(&maxc_s[1], mymaxb);
+    }
     const uint32_t tb_base = a.ctr->tb_base;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint4* pbase = a.seg + (size_t)part * a.region;
     constexpr uint32_t STEP = (AGG_BLOCK / 64) * AGG_SU * AGG_SPLIT;
     __syncthreads();  // table cleared, counts staged
-    const uint32_t maxc = maxc_s;
+    const uint32_t maxc = maxc_s[0], maxcb = maxc_s[1];
     // software pipeline over this wave's segment groups: the next group's loads fly during the LDS work
     // (every fetch is unconditional - clamped addresses, zero counts past the end - so that the compiler
     // can count the loads in flight and wait for the older batch only)
@@ -1328,11 +1400,25 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     for (uint32_t j = 0; j < levels; j++) {
         AggBatch b0, b1;
         uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * AGG_SU;
-        agg_fetch(a, pbase, pc, w0, lane, j, b0);
+        agg_fetch<false>(a, pbase, pc, w0, lane, j, b0);
         while (true) {
-            agg_fetch(a, pbase, pc, w0 + STEP, lane, j, b1);
+            agg_fetch<false>(a, pbase, pc, w0 + STEP, lane, j, b1);
             agg_consume(a, lt, tb_base, lane, b0);
-            agg_fetch(a, pbase, pc, w0 + 2 * STEP, lane, j, b0);
+            agg_fetch<false>(a, pbase, pc, w0 + 2 * STEP, lane, j, b0);
+            agg_consume(a, lt, tb_base, lane, b1);
+            w0 += 2 * STEP;
+            if (w0 >= a.nwg) break;
+        }
+    }
+    const uint32_t levels_b = (__builtin_amdgcn_readfirstlane(maxcb) + 63u) >> 6;
+    for (uint32_t j = 0; j < levels_b; j++) {  // the back parts (single tuples and bin leftovers of the wave-tile kernel)
+        AggBatch b0, b1;
+        uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * AGG_SU;
+        agg_fetch<true>(a, pbase, pcb, w0, lane, j, b0);
+        while (true) {
+            agg_fetch<true>(a, pbase, pcb, w0 + STEP, lane, j, b1);
+            agg_consume(a, lt, tb_base, lane, b0);
+            agg_fetch<true>(a, pbase, pcb, w0 + 2 * STEP, lane, j, b0);
             agg_consume(a, lt, tb_base, lane, b1);
             w0 += 2 * STEP;
             if (w0 >= a.nwg) break;

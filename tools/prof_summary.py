@@ -62,7 +62,8 @@ for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     q = ("select kernel_name, count(*), avg(value), avg(duration) from counters_collection "
          "where counter_name=? group by kernel_name")
     for name, n, avg, dur in d.execute(q, (counter,)):
-        key = "tile_kernel" if ("tile_kernel<0" in name or "wtile_kernel" in name) else "agg_kernel" if "agg_kernel" in name else None
+        key = ("wtile_kernel" if "wtile_kernel" in name else "tile_kernel" if "tile_kernel<0" in name
+               else "agg_kernel" if "agg_kernel" in name else None)
         if key:
             traffic.setdefault(key, {})[counter] = avg * 1024.0
             traffic[key]["launches"] = n
