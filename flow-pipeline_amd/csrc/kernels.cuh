@@ -1232,36 +1232,39 @@ constexpr int AGG_MAX_NWG = 2048;  // tile-kernel workgroups (256 CUs x at most 
 #define FA_AGG_SU 4
 #endif
 constexpr int AGG_SU = FA_AGG_SU;  // segments a wave reads at a time (16-byte loads in flight per lane, x2 buffers)
+constexpr int AGG_PAD = AGG_SU * 8;  // zero counts behind the last segment (the back pass reads 8 segments per load)
 constexpr int AGG_CH = 4;  // tuples of a batch that are hashed / probed together
 
 struct AggBatch {
     uint4 t[AGG_SU];
-    uint32_t c[AGG_SU];
+    uint32_t v;  // bit s: t[s] is a tuple of this lane (not a dummy load)
 };
 
 // issue the loads of lanes [0,64) of AGG_SU consecutive segments starting at w0.  The segment counts
 // come from LDS (pc, zero padded): a count read from global memory would put a full vmcnt drain between
 // consecutive tuple loads.
-// (j = chunk level: lanes [0,64) cover tuples [64j, 64j+64) of every segment's front part - or, BACK, of the
-// c tuples that end at the segment's last slot)
+// Front parts: chunk level j = tuples [64j, 64j+64) of a segment, one segment per 64 lanes.
+// Back parts (a handful of tuples each): level j = tuples [8j, 8j+8) of the c tuples that end at the segment's
+// last slot, EIGHT segments per 64 lanes.  Loads are unconditional (lanes without a tuple re-read slot 0 of a
+// valid segment): with predicated loads the compiler cannot count what is in flight and drains everything
+// (vmcnt(0)) before the previous batch is consumed.
 template <bool BACK>
 __device__ __forceinline__ void agg_fetch(const KArgs& a, const uint4* pbase, const uint32_t* pc, uint32_t w0, uint32_t lane,
                                           uint32_t j, AggBatch& b) {
-    uint32_t first[AGG_SU];
+    constexpr uint32_t SEGS = BACK ? 8u : 1u, PER = 64u / SEGS;  // segments per load, lanes per segment
+    uint32_t idx[AGG_SU], seg[AGG_SU];
+    b.v = 0;
 #pragma unroll
     for (int s = 0; s < AGG_SU; s++) {
-        const uint32_t c = pc[min(w0 + s, (uint32_t)(AGG_MAX_NWG + AGG_SU - 1))];  // 0 past nwg
-        b.c[s] = c > 64u * j ? min(c - 64u * j, 64u) : 0u;
-        first[s] = (BACK ? a.capq - c : 0u) + 64u * j;
+        seg[s] = w0 + (uint32_t)s * SEGS + (BACK ? lane / PER : 0u);
+        const uint32_t c = pc[min(seg[s], (uint32_t)(AGG_MAX_NWG + AGG_PAD - 1))];  // 0 past nwg
+        const uint32_t q = PER * j + (BACK ? lane % PER : lane);
+        const bool valid = q < c;
+        b.v |= valid ? 1u << s : 0u;
+        idx[s] = valid ? (BACK ? a.capq - c : 0u) + q : 0u;
     }
-    // unconditional loads (lanes past the count re-read slot 0 of a valid segment): with predicated
-    // loads the compiler cannot count what is in flight and drains everything (vmcnt(0)) before the
-    // previous batch is consumed
 #pragma unroll
-    for (int s = 0; s < AGG_SU; s++) {
-        const uint32_t w = min(w0 + s, a.nwg - 1u);
-        b.t[s] = pbase[(size_t)w * a.capq + (lane < b.c[s] ? first[s] + lane : 0u)];
-    }
+    for (int s = 0; s < AGG_SU; s++) b.t[s] = pbase[(size_t)min(seg[s], a.nwg - 1u) * a.capq + idx[s]];
 }
 
 __device__ __forceinline__ void agg_tuple(const KArgs& a, AggTable& lt, uint32_t tb_base, const uint4& t) {
@@ -1306,7 +1309,7 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
     uint32_t skipw = 0;    // 2 bits per segment: leading probe slots known to hold other keys
 #pragma unroll
     for (int s = 0; s < AGG_CH; s++) {
-        if (lane >= b.c[S0 + s]) continue;
+        if (!((b.v >> (S0 + s)) & 1u)) continue;
         const uint32_t by = b.t[S0 + s].z & 0x0fffffffu, pk = b.t[S0 + s].w & 0x7fffu;
         const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
         const uint32_t i = h[s] & (AGG_SLOTS - 1);
@@ -1356,7 +1359,7 @@ __device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32
 
 __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     __shared__ AggTable lt;
-    __shared__ uint32_t pc[AGG_MAX_NWG + AGG_SU];  // this partition's segment counts, zero padded
+    __shared__ uint32_t pc[AGG_MAX_NWG + AGG_PAD];  // this partition's segment counts, zero padded
     const uint32_t part = blockIdx.x / AGG_SPLIT, sub = blockIdx.x % AGG_SPLIT;
     for (int i = threadIdx.x; i < AGG_SLOTS; i += AGG_BLOCK) {
         lt.k0[i] = 0;
@@ -1364,12 +1367,12 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
         lt.s1[i] = 0;
         lt.s2[i] = 0;
     }
-    __shared__ uint32_t pcb[AGG_MAX_NWG + AGG_SU];  // ... and the counts of the segments' back parts
+    __shared__ uint32_t pcb[AGG_MAX_NWG + AGG_PAD];  // ... and the counts of the segments' back parts
     __shared__ uint32_t maxc_s[2];
     if (threadIdx.x < 2) maxc_s[threadIdx.x] = 0;
     __syncthreads();
     uint32_t mymax = 0, mymaxb = 0;
-    for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_SU; i += AGG_BLOCK) {
+    for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_PAD; i += AGG_BLOCK) {
         const uint32_t c = i < a.nwg ? a.seg_counts[(size_t)part * a.nwg + i] : 0u;
         const uint32_t cb = i < a.nwg ? a.seg_counts[((size_t)NPART_MAX + part) * a.nwg + i] : 0u;
         pc[i] = c;
@@ -1410,17 +1413,18 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
             if (w0 >= a.nwg) break;
         }
     }
-    const uint32_t levels_b = (__builtin_amdgcn_readfirstlane(maxcb) + 63u) >> 6;
+    const uint32_t levels_b = (__builtin_amdgcn_readfirstlane(maxcb) + 7u) >> 3;
+    constexpr uint32_t STEP_B = STEP * 8u;
     for (uint32_t j = 0; j < levels_b; j++) {  // the back parts (single tuples and bin leftovers of the wave-tile kernel)
         AggBatch b0, b1;
-        uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * AGG_SU;
+        uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * AGG_SU * 8u;
         agg_fetch<true>(a, pbase, pcb, w0, lane, j, b0);
         while (true) {
-            agg_fetch<true>(a, pbase, pcb, w0 + STEP, lane, j, b1);
+            agg_fetch<true>(a, pbase, pcb, w0 + STEP_B, lane, j, b1);
             agg_consume(a, lt, tb_base, lane, b0);
-            agg_fetch<true>(a, pbase, pcb, w0 + 2 * STEP, lane, j, b0);
+            agg_fetch<true>(a, pbase, pcb, w0 + 2 * STEP_B, lane, j, b0);
             agg_consume(a, lt, tb_base, lane, b1);
-            w0 += 2 * STEP;
+            w0 += 2 * STEP_B;
             if (w0 >= a.nwg) break;
         }
     }

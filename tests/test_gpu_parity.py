@@ -354,11 +354,14 @@ def test_decode_noncanonical_records(gpu_lib, fa, po):
     assert_decode_equal(got, want, wstatus)
 
 
-@pytest.mark.parametrize("tile", ["wave", "wg", "auto"])
+@pytest.mark.parametrize("tile", ["wave", "wg", ""])
 def test_tile_kernel_variants_agree_with_oracle(gpu_lib, fa, po, monkeypatch, tile):
-    """Both ingest kernels (wave-private tiles + LDS tuple bins / 256-thread workgroup tiles) and the automatic
-    choice between them, over several batches incl. escapes, hot keys and a record size that shrinks the tiles."""
-    monkeypatch.setenv("FA_TILE", tile)
+    """Both ingest kernels (wave-private tiles + LDS tuple bins: the default / 256-thread workgroup tiles) over
+    several batches incl. escapes, hot keys and a record size that shrinks the tiles."""
+    if tile:
+        monkeypatch.setenv("FA_TILE", tile)
+    else:
+        monkeypatch.delenv("FA_TILE", raising=False)
     n = 400000
     gp = po.gen_params(mode=1, framed=1, seed=31, n_total=n, span_secs=1500)
     buf, off = po.gen_records(gp, 0, n)
@@ -370,14 +373,9 @@ def test_tile_kernel_variants_agree_with_oracle(gpu_lib, fa, po, monkeypatch, ti
             b, o = buf[int(off[lo]):int(off[hi])], off[lo:hi + 1] - off[lo]
             agg.ingest(b, o)
             ref.ingest(b, o, 1)
-            agg.sync()  # the automatic choice looks at the table size of the last settle
+            agg.sync()
         st = agg.stats()
-        if tile == "wave":
-            assert st["wave_tile_launches"] == 2
-        elif tile == "wg":
-            assert st["wave_tile_launches"] == 0
-        else:
-            assert st["wave_tile_launches"] == 1  # first batch: empty table -> workgroup kernel; then many groups -> wave kernel
+        assert st["wave_tile_launches"] == (0 if tile == "wg" else 2)
         assert agg.read_window().tobytes() == ref.rows().tobytes()
     ref = po.Rollup(300)
     with fa.FlowAgg(framed=False) as agg:
