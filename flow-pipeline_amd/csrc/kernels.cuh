@@ -1,13 +1,15 @@
 // kernels.cuh - the gfx950 kernels of libflowagg.
 //
-// Hot path (per batch):  probe_kernel -> tile_kernel<MODE_INGEST,...> -> retry/exotic -> agg_kernel
-//   wire bytes in HBM --global_load_lds_dwordx4 (async DMA)--> LDS tile (21.25 KiB)
+// Hot path (per batch):  probe_kernel -> wtile_kernel<KEYSETS> -> deferred_kernel -> agg_kernel
+//   wire bytes in HBM --global_load_lds_dwordx4 nt (async DMA)--> the wave's LDS tile (<= 64 records)
 //   -> one record per lane parsed out of LDS (wire.cuh, parse_canon)
 //   -> key = (TimeReceived/granule, SrcAS, DstAS, EType)   [create.sh:92-110]
 //   -> per-workgroup LDS hash table absorbs hot keys (mocker.go:61-62 has 9 groups)
-//   -> everything else leaves the workgroup as a 16-byte tuple appended to the workgroup's PRIVATE
-//      segment of the key's hash partition (position from an LDS counter - no global atomics:
-//      MI355X retires only ~23.7 G global-atomic line requests/s, tools/sink_bench.hip);
+//   -> everything else leaves the workgroup as a 16-byte tuple in the workgroup's PRIVATE segment of the
+//      key's hash partition, 8 tuples = one aligned 128-byte line at a time (LDS bins; positions from LDS
+//      counters - no global atomics: MI355X retires only ~23.7 G global-atomic line requests/s,
+//      tools/sink_bench.hip);
+//   (tile_kernel = the 256-thread workgroup-tile form: decode path, direct sink, FA_TILE=wg)
 //   agg_kernel: one 1024-thread workgroup per key partition streams the partition's segments back,
 //      aggregates them in an LDS hash table (two packed 64-bit LDS atomics per tuple) and adds each
 //      group to the device-wide table once.
@@ -36,17 +38,10 @@ constexpr int LDS_SLOTS = 64;      // per-workgroup hot-key slots (2.5 KiB)
 constexpr int LDS_PROBES = 2;
 constexpr int PART_LOG2_MAX = 8;   // key partitions of the scatter sink (<= 256: see tools/scatter_bench.hip)
 constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
-#ifndef FA_WBLOCK
-#define FA_WBLOCK 512
-#define FA_WT_STRIDE 5472
-#define FA_BIN_CAP 8
-#define FA_WT_FLUSH_EVERY 2
-#endif
-constexpr int WBLOCK = FA_WBLOCK;   // wave-tile kernel: 8 waves, each with a private LDS tile of <= 64 records
+constexpr int WBLOCK = 512;         // wave-tile kernel: 8 waves, each with a private LDS tile of <= 64 records
 constexpr int WT_RECS = 64;
-constexpr int WT_STRIDE = FA_WT_STRIDE;  // 64 records x 85 B + alignment slack (16-byte multiple); overreads land in the next tile / the bins
-constexpr uint32_t BIN_CAP = FA_BIN_CAP; // tuples a workgroup holds back per key partition between two flushes (256 x 8 x 16 B = 32 KiB)
-constexpr int WT_FLUSH_EVERY = FA_WT_FLUSH_EVERY;  // wave-tiles between flushes: 2 x 512 records / 256 partitions = 4 tuples per bin on average
+constexpr int WT_STRIDE = 5472;     // 64 records x 85 B + alignment slack (16-byte multiple); overreads land in the next tile / the bins
+constexpr uint32_t BIN_CAP = 8;     // a bin = one 128-byte line of tuples per key partition (256 x 8 x 16 B = 32 KiB per workgroup)
 constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table
 #ifndef FA_AGG_SLOTS
 #define FA_AGG_SLOTS 4096
@@ -70,7 +65,7 @@ constexpr uint32_t FA_KEYS_WIDE = FA_KEYS_ADDR_PORT_PROTO | FA_KEYS_PORT_HIST | 
 constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense histograms
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
-       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_FLUSH = 65536, DBG_NO_FRAME = 131072 };
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_FRAME = 131072 };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -865,13 +860,16 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
 }
 
 // ---- the wave-tile kernel ---------------------------------------------------------------------------
-// Same per-record work as tile_kernel, different residency: 2 workgroups of 8 waves per CU; every WAVE stages
-// its own tile of <= 64 records into a private LDS buffer and parses it without any workgroup barrier, and the
-// LDS this frees (the 256-thread kernel spends all of it on co-resident tiles) holds the tuple bins: a tuple
-// waits in the bin of its key partition and leaves in a contiguous run (4 tuples = 64 bytes on average) every
-// WT_FLUSH_EVERY tiles, instead of as a single 16-byte store whose cache line is evicted from the L2 long
-// before its neighbours arrive (DESIGN.md "Measurements").  The workgroup's segments are 3x longer, which
-// also suits agg_kernel's 64-lane loads.
+// The production ingest kernel of the scatter sink.  Same per-record work as tile_kernel, different
+// residency: 2 workgroups of 8 waves per CU; every WAVE stages its own tile of <= 64 records into a private
+// LDS buffer (its next DMA is issued the moment the tile is consumed) and parses it - there is no workgroup
+// barrier anywhere in the steady state.  The LDS this frees (the 256-thread kernel spends all of it on
+// co-resident tiles) holds the tuple bins: a tuple waits in the 8-slot bin of its key partition, and a full bin
+// leaves as ONE aligned 128-byte line (lane_work), instead of as eight 16-byte stores whose cache line is
+// evicted from the L2 long before its neighbours arrive (DESIGN.md "Measurements").  A segment therefore has a
+// front part of whole lines and a back part for the odd tuples (bin leftovers at the end of the launch, tuples
+// that met a bin on its way out).  The workgroup's segments are 3x longer than tile_kernel's, which also
+// suits agg_kernel's 64-lane loads.
 typedef TileDesc WTileDesc;  // (same rule: the loaded bounds are not looked at before the tile's turn)
 __device__ __forceinline__ WTileDesc wtile_desc(const KArgs& a, uint32_t t, uint32_t ntiles) {
     WTileDesc d{0, 0, 0, 0};
