@@ -113,7 +113,8 @@ def main():
     assert args.key_sets & fa.FA_KEYS_AS_PAIR, "--key-sets must include the flows_5m rollup"
 
     agg = fa.FlowAgg(device=local_rank, framed=True, table_capacity_log2=20, key_sets=args.key_sets,
-                     max_batch_records=args.chunk, wide_capacity_log2=26 if args.key_sets & 8 else 0)
+                     max_batch_records=args.chunk, wide_capacity_log2=26 if args.key_sets & 8 else 0,
+                     topk_capacity_log2=25 if args.key_sets & 6 else 0)  # distinct addresses: 2^24 in the zipf / aspairs generators
     chunks = []
     wire_bytes = 0
     i0 = 0

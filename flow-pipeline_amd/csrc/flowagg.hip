@@ -73,7 +73,8 @@ struct fa_ctx {
 
     unsigned long long* cms_src = nullptr;
     unsigned long long* cms_dst = nullptr;
-    size_t cms_words = 0;
+    size_t cms_words = 0;   // words of ONE copy; the buffers hold CMS_REPLICAS copies
+    bool cms_dirty = false;  // copies > 0 may hold counts (cms_fold)
     KeySlot* ks_src = nullptr;  // distinct-address sets (fa_topk)
     KeySlot* ks_dst = nullptr;
     uint32_t ks_log2 = 20;
@@ -236,13 +237,13 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
         c->cms_words = (size_t)cfg.cms_depth << cfg.cms_width_log2;
         if (cfg.key_sets & FA_KEYS_SRCADDR_CMS) {
-            if ((e = hipMalloc(&c->cms_src, c->cms_words * 8)) != hipSuccess) return bail("hipMalloc(cms)", e);
-            if ((e = hipMemsetAsync(c->cms_src, 0, c->cms_words * 8, c->stream)) != hipSuccess)
+            if ((e = hipMalloc(&c->cms_src, c->cms_words * 8 * CMS_REPLICAS)) != hipSuccess) return bail("hipMalloc(cms)", e);
+            if ((e = hipMemsetAsync(c->cms_src, 0, c->cms_words * 8 * CMS_REPLICAS, c->stream)) != hipSuccess)
                 return bail("memset", e);
         }
         if (cfg.key_sets & FA_KEYS_DSTADDR_CMS) {
-            if ((e = hipMalloc(&c->cms_dst, c->cms_words * 8)) != hipSuccess) return bail("hipMalloc(cms)", e);
-            if ((e = hipMemsetAsync(c->cms_dst, 0, c->cms_words * 8, c->stream)) != hipSuccess)
+            if ((e = hipMalloc(&c->cms_dst, c->cms_words * 8 * CMS_REPLICAS)) != hipSuccess) return bail("hipMalloc(cms)", e);
+            if ((e = hipMemsetAsync(c->cms_dst, 0, c->cms_words * 8 * CMS_REPLICAS, c->stream)) != hipSuccess)
                 return bail("memset", e);
         }
         c->ks_log2 = cfg.topk_capacity_log2;
@@ -392,8 +393,14 @@ static int settle_wide(fa_ctx* c, Counters& h) {
     return FA_OK;
 }
 
+static int cms_fold(fa_ctx* c);
+
 // Waits for the stream, folds device counters into stats, replays spills after growing.
 static int settle(fa_ctx* c) {
+    if (c->cms_dirty) {
+        int frc = cms_fold(c);
+        if (frc) return frc;
+    }
     HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < c->ev_used; i++) {
@@ -611,6 +618,7 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     if (rc) return rc;
     c->stats.bytes_in += len;
     c->stats.batches += 1;
+    if (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) c->cms_dirty = true;
     return FA_OK;
 }
 
@@ -1319,6 +1327,16 @@ extern "C" int fa_dashboard_reset(fa_ctx* c) {
 }
 
 // ---- sketches -----------------------------------------------------------------------------------
+// Sums the sketch copies into copy 0 (kernels.cuh, cms_add).  Every reader of a sketch calls this first.
+static int cms_fold(fa_ctx* c) {
+    if (!c->cms_dirty) return FA_OK;
+    for (unsigned long long* p : {c->cms_src, c->cms_dst})
+        if (p) hipLaunchKernelGGL(cms_fold_kernel, dim3(2048), dim3(256), 0, c->stream, p, c->cms_words);
+    HIPCHK(c, hipGetLastError());
+    c->cms_dirty = false;
+    return FA_OK;
+}
+
 static unsigned long long* cms_of(fa_ctx* c, uint32_t key_set) {
     if (key_set == FA_KEYS_SRCADDR_CMS) return c->cms_src;
     if (key_set == FA_KEYS_DSTADDR_CMS) return c->cms_dst;
@@ -1340,7 +1358,7 @@ extern "C" int fa_cms_reset(fa_ctx* c, uint32_t key_set) {
     if (!c) return FA_ERR_ARG;
     unsigned long long* p = cms_of(c, key_set);
     if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
-    HIPCHK(c, hipMemsetAsync(p, 0, c->cms_words * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(p, 0, c->cms_words * 8 * CMS_REPLICAS, c->stream));
     KeySlot* ks = key_set == FA_KEYS_SRCADDR_CMS ? c->ks_src : c->ks_dst;
     if (ks) HIPCHK(c, hipMemsetAsync(ks, 0, sizeof(KeySlot) << c->ks_log2, c->stream));
     return FA_OK;

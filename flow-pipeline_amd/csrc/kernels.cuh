@@ -180,14 +180,62 @@ __device__ __forceinline__ uint64_t cms_hash(uint64_t lo, uint64_t hi, uint64_t 
     uint64_t h = mix64(lo ^ mix64(seed + 0x9E3779B97F4A7C15ull * (row + 1)));
     return mix64(h ^ hi);
 }
+// The sketch is kept in CMS_REPLICAS copies; a workgroup adds to copy blockIdx % CMS_REPLICAS and the copies
+// are summed into copy 0 before anything reads the sketch (cms_fold_kernel).  Counters of heavy hitters are
+// hit by every wave of the chip, and same-address atomics serialize at the memory side (~10 ns each:
+// 1.9 M updates of the top Zipf-1.1 key per launch cost ~19 ms on one copy); u64 sums commute, so the folded
+// sketch is bit-identical to a single-copy one.
+constexpr uint32_t CMS_REPLICAS = 8;
 __device__ __forceinline__ void cms_add(unsigned long long* cms, uint32_t depth, uint32_t wl2,
                                         uint64_t seed, const uint32_t key[4], uint64_t w) {
     if (w == 0) return;
     uint64_t lo = (uint64_t)key[1] << 32 | key[0], hi = (uint64_t)key[3] << 32 | key[2];
+    unsigned long long* copy = cms + (size_t)(blockIdx.x % CMS_REPLICAS) * ((size_t)depth << wl2);
     for (uint32_t r = 0; r < depth; r++) {
         uint64_t h = cms_hash(lo, hi, seed, r);
-        atomicAdd(&cms[((size_t)r << wl2) + (size_t)(h >> (64 - wl2))], (unsigned long long)w);
+        atomicAdd(&copy[((size_t)r << wl2) + (size_t)(h >> (64 - wl2))], (unsigned long long)w);
     }
+}
+__global__ void cms_fold_kernel(unsigned long long* cms, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long sum = 0;
+        for (uint32_t r = 1; r < CMS_REPLICAS; r++) {
+            const unsigned long long v = cms[r * words + i];
+            if (v) {
+                sum += v;
+                cms[r * words + i] = 0;
+            }
+        }
+        if (sum) cms[i] += sum;
+    }
+}
+
+// Folds the lanes of a wave that carry the same 16-byte key: the first lane to claim the key's slot in a
+// 64-entry LDS table keeps the key and receives the weights of the others (valid = false for those).  One
+// round whatever the key distribution (wave_combine gives up on skewed mixes of hot and cold keys); lanes that
+// lose the slot to a DIFFERENT key just stay on their own.  scratch: 768 bytes of wave-private LDS.
+__device__ __forceinline__ void wave_fold_lds(uint32_t* scratch, bool& valid, uint64_t lo, uint64_t hi, uint64_t& w) {
+    uint32_t* owner = scratch;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(scratch + 64);
+    const uint32_t ln = __lane_id();
+    owner[ln] = 0xffffffffu;
+    acc[ln] = 0;
+    uint32_t h = (uint32_t)lo * 0x9E3779B1u ^ (uint32_t)(lo >> 32) * 0x85EBCA6Bu ^ (uint32_t)hi * 0xC2B2AE35u ^ (uint32_t)(hi >> 32) * 0x27D4EB2Fu;
+    h ^= h >> 15;
+    const uint32_t slot = (h * 0x2545F491u) >> 26;
+    uint32_t win = ln;
+    if (valid) {
+        const uint32_t prev = atomicCAS(&owner[slot], 0xffffffffu, ln);
+        win = prev == 0xffffffffu ? ln : prev;
+    }
+    const uint64_t wlo = (uint64_t)(uint32_t)__shfl((int)(uint32_t)(lo >> 32), (int)win) << 32 | (uint32_t)__shfl((int)(uint32_t)lo, (int)win);
+    const uint64_t whi = (uint64_t)(uint32_t)__shfl((int)(uint32_t)(hi >> 32), (int)win) << 32 | (uint32_t)__shfl((int)(uint32_t)hi, (int)win);
+    const bool same = valid && win != ln && wlo == lo && whi == hi;
+    if (same) {
+        if (w) atomicAdd(&acc[slot], (unsigned long long)w);
+        valid = false;
+    }
+    if (valid && win == ln) w += acc[slot];  // (behind the adds: LDS operations of a wave complete in order)
 }
 
 // Inserts a FixedString(16) key into the distinct-key set.  The per-XCD L2s are not coherent, so a plain
@@ -215,8 +263,15 @@ __device__ __forceinline__ void keyset_insert(const KArgs& a, KeySlot* tab, cons
     uint32_t i = h & a.ks_mask;
     for (int probe = 0; probe < 256; probe++, i = (i + 1) & a.ks_mask) {
         KeySlot* s = &tab[i];
-        // fast path: the key is already there.  System-scope loads are served by the memory side, past the
-        // (incoherent) per-XCD L2s; a slot never changes once READY, so a complete match is always true.
+        // fastest path: the key is already there and this XCD's L2 knows it.  Plain (cached) loads may be stale,
+        // but a slot never changes once READY, so a complete match is always true; anything else is looked at
+        // again through the memory side below.
+        {
+            const ulonglong2 c01 = *reinterpret_cast<const ulonglong2*>(&s->tag);  // tag, lo
+            if (c01.x == (mytag | KS_READY) && c01.y == lo && s->hi == hi) return;
+        }
+        // the key may be there: system-scope loads are served by the memory side, past the (incoherent) per-XCD
+        // L2s
         unsigned long long t = __hip_atomic_load(&s->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (t == (mytag | KS_READY)) {
             const unsigned long long l = __hip_atomic_load(&s->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -634,15 +689,27 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             quad_atomic_update(sp, b, p, c);
         }
     }
-    if (sure && (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
-        const uint64_t w = r.bytes * r.sampling_rate;  // viz-ch.json:233 sum(Bytes*SamplingRate)
+    if (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
+        // lanes of a wave that carry the same address (heavy hitters) are folded first: one sketch update and
+        // one distinct-set probe per address and wave (wave-tile kernel: its parsed tile buffer is the scratch)
+        const uint64_t w = r.bytes * r.sampling_rate;  // viz-ch.json:233 sum(Bytes*SamplingRate), UInt64 wrap
         if (ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS)) {
-            cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
-            keyset_insert(a, a.ks_src, r.src);
+            uint64_t ws = w;
+            bool valid = sure;
+            if (bins) wave_fold_lds(const_cast<uint32_t*>(tile), valid, (uint64_t)r.src[1] << 32 | r.src[0], (uint64_t)r.src[3] << 32 | r.src[2], ws);
+            if (valid) {
+                cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, ws);
+                keyset_insert(a, a.ks_src, r.src);
+            }
         }
         if (ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS)) {
-            cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
-            keyset_insert(a, a.ks_dst, r.dst);
+            uint64_t ws = w;
+            bool valid = sure;
+            if (bins) wave_fold_lds(const_cast<uint32_t*>(tile), valid, (uint64_t)r.dst[1] << 32 | r.dst[0], (uint64_t)r.dst[3] << 32 | r.dst[2], ws);
+            if (valid) {
+                cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, ws);
+                keyset_insert(a, a.ks_dst, r.dst);
+            }
         }
     }
     if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb);
