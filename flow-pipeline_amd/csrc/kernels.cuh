@@ -540,12 +540,61 @@ __device__ __forceinline__ bool frame_short(uint32_t x, uint32_t rec_len, uint32
     return (one || b1 < 0x80u) && rec_len >= prefix_len && val == rec_len - prefix_len;
 }
 
+// Full bins leave as whole, aligned 128-byte lines, up to 8 bins per pass: lane group g (8 lanes) takes the
+// g-th filled bin, each lane copies one tuple - one store instruction writes 8 complete lines, no partial
+// lines and no workgroup barrier.  The producers of a bin's other slots may sit in other waves: the high
+// half of the bin word counts the slots WRITTEN, and nobody can take a slot of a full bin, so the spin
+// below only ever waits for straight-line code of waves that never wait for us (producers of this wave
+// finished in lockstep inside lane_work).  fill_part: the bin this lane filled (or ~0); scratch: 32 bytes of
+// wave-private LDS.  Must be called by the full wave.
+__device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t* bin_cnt, uint32_t* part_cnt, uint32_t* scratch,
+                                           uint32_t fill_part, uint32_t tb_base, uint32_t& n_direct) {
+    const unsigned long long fm = __builtin_amdgcn_ballot_w64(fill_part != 0xffffffffu);
+    if (fm == 0ull) return;
+    const uint32_t ln = __lane_id(), g = ln >> 3, sub = ln & 7u;
+    const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << ln) - 1ull));
+    const uint32_t todo = (uint32_t)__builtin_popcountll(fm);
+    for (uint32_t base = 0; base < todo; base += 8u) {
+        if (fill_part != 0xffffffffu && rank - base < 8u) scratch[rank - base] = fill_part;
+        const bool act = g < min(8u, todo - base);
+        const uint32_t fp = act ? scratch[g] : 0u;
+        // the written-slot check, the tuple read and the line allocation are issued back to back (LDS operations
+        // of a wave complete in order, so the read sees what the check saw); only a bin that is still being
+        // written costs further round trips
+        const uint32_t c0 = __hip_atomic_load(&bin_cnt[fp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint4 tq = bins[fp * BIN_CAP + sub];
+        uint32_t line = 0;
+        if (act && sub == 0) line = atomicAdd(&part_cnt[fp], 1u) & 0xffffu;  // low half: lines at the front
+        bool late = false;
+        if (__builtin_amdgcn_ballot_w64(act && (c0 >> 16) < BIN_CAP) != 0ull) {
+            late = true;
+            while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&bin_cnt[fp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < BIN_CAP) != 0ull) {}
+        }
+        line = (uint32_t)__shfl((int)line, (int)(ln & ~7u));
+        if (act) {
+            const uint4 tv = late ? bins[fp * BIN_CAP + sub] : tq;
+            if ((line + 1u) * BIN_CAP <= a.capf) {
+                if (!(a.dbg & DBG_NO_TUPLE_STORE))
+                    a.seg[(size_t)fp * a.region + (size_t)blockIdx.x * a.capq + line * BIN_CAP + sub] = tv;
+            } else {  // front part full (skewed batch): straight to the device-wide table
+                const uint32_t qby = tv.z & 0x0fffffffu, qtbr = tv.z >> 28, qpk = tv.w & 0x7fffu, qet = tv.w >> 15;
+                uint64_t q0, q1;
+                pack_key(tb_base + qtbr, tv.x, tv.y, qet, q0, q1);
+                agg_global(a, q0, q1, key_hash(q0, q1), qby, qpk, 1);
+                n_direct++;
+            }
+            // (behind the reads: LDS operations of a wave complete in order)
+            if (sub == 0) __hip_atomic_store(&bin_cnt[fp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
 // ---- per-lane work on a staged record (called by every lane of the workgroup) ------
 template <int MODE, uint32_t KEYSETS, uint32_t COLS>
 __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, LdsMinutes& lm, uint32_t* part_cnt, const uint32_t* tile,
                                           bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
                                           uint32_t& n_ok, uint32_t& n_direct, uint32_t& lt_seen, uint32_t& lt_hits,
-                                          uint4* bins = nullptr, uint32_t* bin_cnt = nullptr) {
+                                          uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out) {
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false;
     Rec r;
@@ -639,45 +688,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 }
             }
         }
-        // Full bins leave as whole, aligned 128-byte lines, up to 8 bins per pass: lane group g (8 lanes) takes the
-        // g-th filled bin, each lane copies one tuple - one store instruction writes 8 complete lines, no partial
-        // lines and no workgroup barrier.  The producers of a bin's other slots may sit in other waves: the high
-        // half of the bin word counts the slots WRITTEN, and nobody can take a slot of a full bin, so the spin
-        // below only ever waits for straight-line code of waves that never wait for us (producers of this wave
-        // finished in lockstep above).  Scratch = the head of the wave's tile buffer (its bytes are parsed).
-        if (bins) {
-            const unsigned long long fm = __builtin_amdgcn_ballot_w64(fill_part != 0xffffffffu);
-            if (fm != 0ull) {
-                uint32_t* scratch = const_cast<uint32_t*>(tile);
-                const uint32_t ln = __lane_id(), g = ln >> 3, sub = ln & 7u;
-                const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << ln) - 1ull));
-                const uint32_t todo = (uint32_t)__builtin_popcountll(fm);
-                for (uint32_t base = 0; base < todo; base += 8u) {
-                    if (fill_part != 0xffffffffu && rank - base < 8u) scratch[rank - base] = fill_part;
-                    const bool act = g < min(8u, todo - base);
-                    const uint32_t fp = act ? scratch[g] : 0u;
-                    while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&bin_cnt[fp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < BIN_CAP) != 0ull) {}
-                    uint32_t line = 0;
-                    if (act && sub == 0) line = atomicAdd(&part_cnt[fp], 1u) & 0xffffu;  // low half: lines at the front
-                    line = (uint32_t)__shfl((int)line, (int)(ln & ~7u));
-                    if (act) {
-                        const uint4 tq = bins[fp * BIN_CAP + sub];
-                        if ((line + 1u) * BIN_CAP <= a.capf) {
-                            if (!(a.dbg & DBG_NO_TUPLE_STORE))
-                                a.seg[(size_t)fp * a.region + (size_t)blockIdx.x * a.capq + line * BIN_CAP + sub] = tq;
-                        } else {  // front part full (skewed batch): straight to the device-wide table
-                            const uint32_t qby = tq.z & 0x0fffffffu, qtbr = tq.z >> 28, qpk = tq.w & 0x7fffu, qet = tq.w >> 15;
-                            uint64_t q0, q1;
-                            pack_key(tb_base + qtbr, tq.x, tq.y, qet, q0, q1);
-                            agg_global(a, q0, q1, key_hash(q0, q1), qby, qpk, 1);
-                            n_direct++;
-                        }
-                        // (behind the reads: LDS operations of a wave complete in order)
-                        if (sub == 0) __hip_atomic_store(&bin_cnt[fp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-            }
-        }
+        fill_out = fill_part;  // full bins leave in bins_flush(), which the wave-tile kernel runs in the shadow of its next DMA
         // direct path (what is left): device-wide table, one atomic line transaction per record
         if (__builtin_amdgcn_ballot_w64(pending) != 0ull && !(a.dbg & DBG_NO_GLOBAL)) {  // wave-uniform
             Slot* sp = nullptr;
@@ -790,7 +801,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     if (MODE == MODE_INGEST && (KEYSETS & FA_KEYS_MINUTE_SERIES)) lds_minutes_clear(lm);
     const uint32_t tb_base = MODE == MODE_INGEST ? a.ctr->tb_base : 0u;
 
-    uint32_t n_ok = 0, n_direct = 0, lt_seen = 0, lt_hits = 0;
+    uint32_t n_ok = 0, n_direct = 0, lt_seen = 0, lt_hits = 0, no_fill = 0;
     const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
     const uint32_t stride = gridDim.x;
     uint32_t t = blockIdx.x;
@@ -834,7 +845,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                 unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
                 a.exotic_idx[j] = cur.r0 + tid;
             }
-            lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, n_ok, n_direct, lt_seen, lt_hits);
+            lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, n_ok, n_direct, lt_seen, lt_hits, nullptr, nullptr, no_fill);
         } else {
             // rare: the tile's bytes exceed the LDS buffer (big records): stage it in passes
             uint32_t done = 0;
@@ -862,7 +873,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                     }
                     done += 1;
                 } else {
-                    lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, n_ok, n_direct, lt_seen, lt_hits);
+                    lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, n_ok, n_direct, lt_seen, lt_hits, nullptr, nullptr, no_fill);
                     done += nfit;
                 }
                 __syncthreads();  // the buffer is restaged by the next pass
@@ -964,6 +975,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BIN_CAP];
     __shared__ uint32_t bin_cnt[NPART_MAX];
     __shared__ uint32_t part_cnt[NPART_MAX];
+    __shared__ uint32_t flush_scratch[WAVES * 8];
     __shared__ LdsTable<LDS_SLOTS> lt;
     __shared__ LdsMinutes lm;
 
@@ -1011,6 +1023,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
     for (uint32_t round = 0; round < rounds; round++, t += stride) {
         dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
+        uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
         // parse + sink
         if (cur.nrec != 0) {
             const uint32_t cbase = cur.lo & ~15u;
@@ -1021,8 +1034,11 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
                 a.exotic_idx[j] = cur.r0 + lane;
             }
             lane_work<MODE_INGEST, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, n_ok,
-                                                  n_direct, lt_seen, lt_hits, bins, bin_cnt);
+                                                  n_direct, lt_seen, lt_hits, bins, bin_cnt, fill);
         }
+        // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
+        // queue and the wave would wait for the write acknowledgements on top of its tile (measured: +15 %)
+        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
         cur = tile_current(nxt);
         o0 = n0;
         o1 = (uint32_t)__shfl_down((int)o0, 1);
