@@ -561,14 +561,16 @@ __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t
         // the written-slot check, the tuple read and the line allocation are issued back to back (LDS operations
         // of a wave complete in order, so the read sees what the check saw); only a bin that is still being
         // written costs further round trips
-        const uint32_t c0 = __hip_atomic_load(&bin_cnt[fp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (acquire / release pair with the producers' written-slot count: without it the COMPILER may move the
+        // tuple read above the check - it did, and rows differed from the oracle at 16 M records)
+        const uint32_t c0 = __hip_atomic_load(&bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint4 tq = bins[fp * BIN_CAP + sub];
         uint32_t line = 0;
         if (act && sub == 0) line = atomicAdd(&part_cnt[fp], 1u) & 0xffffu;  // low half: lines at the front
         bool late = false;
         if (__builtin_amdgcn_ballot_w64(act && (c0 >> 16) < BIN_CAP) != 0ull) {
             late = true;
-            while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&bin_cnt[fp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < BIN_CAP) != 0ull) {}
+            while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < BIN_CAP) != 0ull) {}
         }
         line = (uint32_t)__shfl((int)line, (int)(ln & ~7u));
         if (act) {
@@ -583,8 +585,8 @@ __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t
                 agg_global(a, q0, q1, key_hash(q0, q1), qby, qpk, 1);
                 n_direct++;
             }
-            // (behind the reads: LDS operations of a wave complete in order)
-            if (sub == 0) __hip_atomic_store(&bin_cnt[fp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (release: behind the tuple reads above)
+            if (sub == 0) __hip_atomic_store(&bin_cnt[fp], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
@@ -658,10 +660,12 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 if (bins) {
                     // wave-tile kernel: the tuple waits in the workgroup's LDS bin of its partition; the lane that takes
                     // the last slot of a bin sends the 8 tuples off as one full, aligned 128-byte line (below)
-                    const uint32_t slot = atomicAdd(&bin_cnt[part], 1u) & 0xffffu;  // low half: slots taken, high half: slots written
+                    // (acquire: the tuple write below must not move above the claim - the previous occupants of the bin
+                    // are read by the flusher until it resets the word; release: the tuple is written before it counts)
+                    const uint32_t slot = __hip_atomic_fetch_add(&bin_cnt[part], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;  // low half: slots taken, high half: slots written
                     if (slot < BIN_CAP) {
                         bins[part * BIN_CAP + slot] = tv;
-                        atomicAdd(&bin_cnt[part], 0x10000u);
+                        __hip_atomic_fetch_add(&bin_cnt[part], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         fill_part = slot == BIN_CAP - 1 ? part : fill_part;
                         pending = false;
                     } else {  // the bin is on its way out: single 16-byte store to the back part of the segment

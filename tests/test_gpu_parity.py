@@ -450,3 +450,53 @@ def test_topk_reports_overflow(gpu_lib, fa, po):
         with pytest.raises(fa.FlowAggError) as ei:
             agg.topk(fa.FA_KEYS_SRCADDR_CMS, 10)
         assert ei.value.code == -5
+
+
+@pytest.mark.parametrize("mode,tile", [(1, ""), (2, ""), (0, ""), (1, "wg")])
+def test_large_device_batches_checksum_equals_oracle(gpu_lib, fa, po, monkeypatch, mode, tile):
+    """Bench-scale batches (4 M records generated in HBM, full grids, every LDS bin cycling hundreds of times):
+    the order-independent checksum of the flows_5m rows equals the multi-threaded oracle's.  Small batches do
+    not exercise the cross-wave bin hand-over enough to catch ordering mistakes there."""
+    import torch
+    if tile:
+        monkeypatch.setenv("FA_TILE", tile)
+    n = 4_000_000
+
+    def mix64(z):
+        z = z.astype(np.uint64)
+        with np.errstate(over="ignore"):
+            z ^= z >> np.uint64(30)
+            z *= np.uint64(0xbf58476d1ce4e5b9)
+            z ^= z >> np.uint64(27)
+            z *= np.uint64(0x94d049bb133111eb)
+            z ^= z >> np.uint64(31)
+        return z
+
+    def checksum(rows):
+        with np.errstate(over="ignore"):
+            a = (rows["timeslot"].astype(np.uint64) << np.uint64(32)) | rows["etype"].astype(np.uint64)
+            b = (rows["src_as"].astype(np.uint64) << np.uint64(32)) | rows["dst_as"].astype(np.uint64)
+            h = mix64(a ^ mix64(b))
+            v = rows["bytes"] * np.uint64(3) + rows["packets"] * np.uint64(5) + rows["count"] * np.uint64(7) + np.uint64(1)
+            return int((h * v).sum(dtype=np.uint64))
+
+    gp = po.gen_params(mode=mode, framed=1, seed=40 + mode, n_total=n, span_secs=900, per_sec=50_000)
+    want = po.bench_rollup(gp, 0, n, 8)
+    assert want["bad"] == 0
+    mp = fa.mock_params(mode=mode, framed=1, seed=40 + mode, n_total=n, span_secs=900, per_sec=50_000)
+    dev = torch.device("cuda", 0)
+    with fa.FlowAgg(framed=True, max_batch_records=n) as agg:
+        cap = n * 96 + 4096
+        d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        w = agg.mock_generate_device(mp, 0, n, d_buf.data_ptr(), cap, d_off.data_ptr())
+        assert w == want["wire_bytes"]
+        for _ in range(3):  # the same batch three times: sums triple, groups stay
+            agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), n)
+        rows = agg.read_window()
+        assert len(rows) == want["groups"]
+        for col in ("bytes", "packets", "count"):
+            assert (rows[col] % np.uint64(3) == 0).all()
+            rows[col] //= np.uint64(3)
+        assert checksum(rows) == want["checksum"]
+        assert int(rows["count"].sum()) == n
