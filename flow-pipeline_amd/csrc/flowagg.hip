@@ -35,7 +35,7 @@ struct fa_ctx {
     Slot* tab = nullptr;
     uint32_t cap_log2 = 20;
     SpillEntry* spill = nullptr;
-    uint32_t spill_cap = 1u << 18;
+    uint32_t spill_cap = 1u << 22;  // parked updates of ONE batch that met a full table (168 MB): the aggregation kernel parks at most 2^20 groups per batch, the rest is headroom for the per-record paths
     Counters* d_ctr = nullptr;
     Counters* h_ctr = nullptr;  // pinned
     uint32_t* d_exotic = nullptr;  // deferral lists: [0,cap) exotic, [cap,2cap) retry
@@ -83,7 +83,7 @@ struct fa_ctx {
     WSlot* wtab = nullptr;
     uint32_t wcap_log2 = 20;
     WSpillEntry* wspill = nullptr;
-    uint32_t wspill_cap = 1u << 18;
+    uint32_t wspill_cap = 1u << 22;
     uint64_t wused_base = 0;
     ulonglong2* port_hist = nullptr;  // [2][PORT_DENSE]
 

@@ -41,8 +41,10 @@ typedef enum {
     FA_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime error at create */
     FA_ERR_HIP = -3,        /* HIP runtime error (text in fa_last_error) */
     FA_ERR_NOMEM = -4,
-    FA_ERR_TABLE_FULL = -5, /* group-by table overflow: rows were NOT lost, the
-                               call failed as a whole; recreate with a larger table */
+    FA_ERR_TABLE_FULL = -5, /* a single batch created more new groups than the table's free slots plus the
+                               spill buffer (4 M parked updates) hold - the tables grow BETWEEN batches;
+                               aggregates of that batch were lost and the ctx refuses further work (sticky).
+                               Recreate with a larger table_capacity_log2 / wide_capacity_log2. */
     FA_ERR_CAPACITY = -6,   /* caller's output buffer too small; *n_out = required */
     FA_ERR_FRAMING = -7,    /* offsets==NULL and the stream is not a chain of framed records */
     FA_ERR_UNSUPPORTED = -8

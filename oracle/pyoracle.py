@@ -285,3 +285,30 @@ def minute_series(rows, status):
     out["minute"] = minute[idx]
     out["weight"], out["count"] = ws, cs
     return out
+
+
+def cms_sketch_numpy(keys16: np.ndarray, weights: np.ndarray, depth: int, width_log2: int, seed: int) -> np.ndarray:
+    """Vectorised Count-Min sketch over uint8[n,16] keys (the same hash as fo_hash_key16 / fo_cms_update in
+    flow_oracle.c, restated in numpy so that bench-scale inputs can be checked; pinned against the C functions by
+    tests/test_oracle_golden.py).  -> uint64[depth << width_log2]."""
+    def mix64(z):
+        z = z.astype(np.uint64)
+        with np.errstate(over="ignore"):
+            z ^= z >> np.uint64(30)
+            z *= np.uint64(0xbf58476d1ce4e5b9)
+            z ^= z >> np.uint64(27)
+            z *= np.uint64(0x94d049bb133111eb)
+            z ^= z >> np.uint64(31)
+        return z
+    k = np.ascontiguousarray(keys16, dtype=np.uint8).reshape(-1, 16)
+    lo = k[:, :8].copy().view("<u8").reshape(-1)
+    hi = k[:, 8:].copy().view("<u8").reshape(-1)
+    w = np.ascontiguousarray(weights, dtype=np.uint64)
+    out = np.zeros(depth << width_log2, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for r in range(depth):
+            s = mix64(np.array([(seed + 0x9E3779B97F4A7C15 * (r + 1)) & (2**64 - 1)], dtype=np.uint64))[0]
+            h = mix64(mix64(lo ^ s) ^ hi)
+            idx = (h >> np.uint64(64 - width_log2)).astype(np.int64) + (r << width_log2)
+            np.add.at(out, idx, w)
+    return out

@@ -500,3 +500,50 @@ def test_large_device_batches_checksum_equals_oracle(gpu_lib, fa, po, monkeypatc
             rows[col] //= np.uint64(3)
         assert checksum(rows) == want["checksum"]
         assert int(rows["count"].sum()) == n
+
+
+def test_config3_shape_sketches_and_topk_at_scale(gpu_lib, fa, po):
+    """BASELINE config 3 shape at 3 M records (Zipf 1.1 addresses, 2^20 universe, weight Bytes*SamplingRate):
+    both sketches bit-exact against the CPU sketch (wave-level folding of equal addresses, replicated
+    counters folded before the read), top-100 identical to ranking every distinct address by its estimate,
+    estimates never below the exact GROUP BY."""
+    import torch
+    n = 3_000_000
+    gp = po.gen_params(mode=2, framed=1, seed=3, n_total=n, zipf_log2_universe=20, zipf_s_x100=110)
+    mp = fa.mock_params(mode=2, framed=1, seed=3, n_total=n, zipf_log2_universe=20, zipf_s_x100=110)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    assert status.sum() == 0
+    with np.errstate(over="ignore"):
+        w = rows["bytes"] * rows["sampling_rate"]
+    depth, wl2, seed = 4, 16, 0x5EED
+    ks = fa.FA_KEYS_AS_PAIR | fa.FA_KEYS_SRCADDR_CMS | fa.FA_KEYS_DSTADDR_CMS
+    dev = torch.device("cuda", 0)
+    with fa.FlowAgg(framed=True, key_sets=ks, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=21,
+                    max_batch_records=n) as agg:
+        d_buf = torch.empty(n * 96 + 4096, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        wbytes = agg.mock_generate_device(mp, 0, n, d_buf.data_ptr(), d_buf.numel(), d_off.data_ptr())
+        assert wbytes == len(buf)
+        agg.ingest_device(d_buf.data_ptr(), wbytes, d_off.data_ptr(), n)
+        for col, key_set in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+            want = po.cms_sketch_numpy(rows[col], w, depth, wl2, seed)
+            got = agg.cms_read(key_set).reshape(-1)
+            assert np.array_equal(got, want), col
+            # exact GROUP BY address (viz-ch.json:233,479) and the ranking by estimate
+            keys = np.ascontiguousarray(rows[col]).view([("k", "u1", 16)]).reshape(-1)
+            uniq, inv = np.unique(keys, return_inverse=True)
+            exact = np.zeros(len(uniq), dtype=np.uint64)
+            with np.errstate(over="ignore"):
+                np.add.at(exact, inv, w)
+            ukeys = uniq.view(np.uint8).reshape(-1, 16)
+            top = agg.topk(key_set, 100)
+            everything = agg.topk(key_set, 1 << 21)
+            assert len(everything) == len(uniq)
+            got_w = {bytes(r["key"]): int(r["weight"]) for r in everything}
+            for k, e in zip(ukeys, exact):
+                assert got_w[bytes(k)] >= int(e)  # never an under-estimate
+            order = sorted(got_w.items(), key=lambda kv: (-kv[1], kv[0]))[:100]
+            assert [(bytes(r["key"]), int(r["weight"])) for r in top] == order
+            for r in top[:10]:
+                assert int(r["weight"]) == po.cms_query(want, depth, wl2, seed, bytes(r["key"]))

@@ -220,3 +220,15 @@ def test_wide_keyset_restatements_against_plain_dicts(po):
     b = po.rollup_app(rows[sel], status[sel], 86400)
     for col in ("src_addr", "dst_port", "proto", "bytes", "packets", "count"):
         assert np.array_equal(a[col], b[col]), col
+
+
+def test_numpy_sketch_restatement_matches_c_oracle(po):
+    rng = np.random.default_rng(3)
+    keys = rng.integers(0, 256, size=(3000, 16), dtype=np.uint8)
+    keys[:500] = keys[0]  # a heavy hitter
+    w = rng.integers(0, 2**63, size=3000, dtype=np.uint64) * np.uint64(3)  # wraps
+    depth, wl2, seed = 4, 9, 0xABCDEF
+    want = np.zeros(depth << wl2, dtype=np.uint64)
+    for k in range(len(keys)):
+        po.cms_update(want, depth, wl2, seed, bytes(keys[k]), int(w[k]))
+    assert np.array_equal(po.cms_sketch_numpy(keys, w, depth, wl2, seed), want)

@@ -179,3 +179,35 @@ def test_wide_shard_merge_equals_single_shard(gpu_lib, fa, po):
     _same(a.minute_series(), po.minute_series(rows, status), ("minute", "weight", "count"))
     a.close()
     b.close()
+
+
+def test_config5_shape_at_scale(gpu_lib, fa, po):
+    """BASELINE config 5 shape at 3 M records generated in HBM (Zipf 0.8, every key set at once, 60 s sub-buckets):
+    full grids, table growth from 2^20 slots, both exact rollups, ports and minutes against the oracle."""
+    import torch
+    n = 3_000_000
+    kw = dict(mode=2, framed=1, seed=5, n_total=n, span_secs=900, zipf_log2_universe=22, zipf_s_x100=80)
+    gp = po.gen_params(**kw)
+    mp = fa.mock_params(**kw)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    ks = fa.FA_KEYS_AS_PAIR | fa.FA_KEYS_ADDR_PORT_PROTO | fa.FA_KEYS_PORT_HIST | fa.FA_KEYS_MINUTE_SERIES
+    dev = torch.device("cuda", 0)
+    with fa.FlowAgg(framed=True, key_sets=ks, window_secs=300, subwindow_secs=60, max_batch_records=n) as agg:
+        d_buf = torch.empty(n * 96 + 4096, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        wbytes = agg.mock_generate_device(mp, 0, n, d_buf.data_ptr(), d_buf.numel(), d_off.data_ptr())
+        assert wbytes == len(buf)
+        agg.ingest_device(d_buf.data_ptr(), wbytes, d_off.data_ptr(), n)
+        want = po.rollup_app(rows, status, 60)
+        got = agg.read_window_app()
+        _same(got, want, APP_COLS)
+        assert agg.stats()["wide_capacity"] >= 2 * len(want)
+        start = po.T0 + 120  # a sliding 5-minute window
+        _same(agg.read_window_app(start), po.rollup_app(rows, status, 60, window=300, timeslot=start), APP_COLS)
+        ref = po.Rollup(60)
+        ref.ingest(buf, off, 1)
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+        for d in (0, 1):
+            _same(agg.top_ports(d), po.top_ports(rows, status, d), ("port", "weight", "count"))
+        _same(agg.minute_series(), po.minute_series(rows, status), ("minute", "weight", "count"))
