@@ -18,7 +18,7 @@ import subprocess
 
 import numpy as np
 
-from . import dist, schema  # noqa: F401  (re-export)
+from . import dist, schema, spill  # noqa: F401  (re-export)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libflowagg.so")

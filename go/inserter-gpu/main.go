@@ -68,6 +68,8 @@ var (
 	ProtoFixed  = flag.Bool("proto.fixedlen", true, "Messages carry the varint length prefix (mocker -proto.fixedlen)")
 	WindowSecs  = flag.Int("window.secs", 300, "Rollup window (toStartOfFiveMinute)")
 	CloseLagSec = flag.Int("window.lag", 30, "Close a window this many seconds after it ended")
+	KeySets     = flag.Int("key.sets", 1, "fa key_sets mask (1 = flows_5m rollup; see include/flowagg.h)")
+	OutRowBin   = flag.String("out.rowbinary", "", "Append closed flows_5m rows to this file as ClickHouse RowBinary")
 
 	Inserts = prometheus.NewCounter(prometheus.CounterOpts{Name: "insert_count", Help: "Flow messages aggregated on the GPU."})
 )
@@ -96,7 +98,7 @@ func newPartition(partition int32) *partitionState {
 	cfg := C.fa_config{}
 	cfg.device = C.int32_t(int(partition) % *GpuDevices)
 	cfg.window_secs = C.uint32_t(*WindowSecs)
-	cfg.key_sets = C.FA_KEYS_AS_PAIR
+	cfg.key_sets = C.uint32_t(*KeySets)
 	if *ProtoFixed {
 		cfg.framed = 1
 	}
@@ -127,8 +129,9 @@ func (p *partitionState) flush(session sarama.ConsumerGroupSession) {
 	p.buf, p.offsets, p.pending = p.buf[:0], p.offsets[:1], p.pending[:0]
 }
 
-// closeWindows emits finished flows_5m rows (create.sh:70-90).  A production build hands
-// them to ClickHouse/Postgres bulk loaders; here they are logged.
+// closeWindows emits finished flows_5m rows (create.sh:70-90) as one RowBinary payload per window
+// (`INSERT INTO flows_5m FORMAT RowBinary`) instead of the reference's per-row db.Exec
+// (inserter.go:100-106).  Same logic as flow-pipeline_amd/host/inserter_gpu.cpp, which is built and tested.
 func (p *partitionState) closeWindows(now time.Time) {
 	var slots [64]C.uint32_t
 	var ns C.size_t
@@ -151,6 +154,21 @@ func (p *partitionState) closeWindows(now time.Time) {
 			log.Fatalf("fa_close_window: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
 		}
 		log.Infof("flows_5m timeslot %d: %d rows", ts, int(nr))
+		if *OutRowBin != "" && nr > 0 {
+			buf := make([]byte, int(nr)*C.FA_ROWBINARY_ROW5M_BYTES)
+			var nb C.size_t
+			if rc := C.fa_rows_to_rowbinary(&rows[0], nr, (*C.uint8_t)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)), &nb); rc != 0 {
+				log.Fatalf("fa_rows_to_rowbinary: %d", int(rc))
+			}
+			f, err := os.OpenFile(*OutRowBin, os.O_APPEND|os.O_CREATE|os.O_WRONLY, 0644)
+			if err != nil {
+				log.Fatal(err)
+			}
+			if _, err = f.Write(buf[:int(nb)]); err != nil {
+				log.Fatal(err)
+			}
+			f.Close()
+		}
 	}
 }
 
