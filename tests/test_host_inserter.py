@@ -110,14 +110,17 @@ def test_sink_error_is_fatal_without_a_gpu(exe, po, tmp_path):
 
 
 @pytest.mark.gpu
-def test_partition_logs_to_rowbinary_equal_oracle(gpu_lib, exe, fa, po, tmp_path):
-    n, nparts = 60000, 3
+@pytest.mark.parametrize("n,flush", [(60000, 7000), (450000, 65536)])
+def test_partition_logs_to_rowbinary_equal_oracle(gpu_lib, exe, fa, po, tmp_path, n, flush):
+    """(7000-record flushes take the direct sink, 65536-record ones the scatter sink - three contexts on three
+    streams of one GPU at the same time)"""
+    nparts = 3
     buf, off, paths = _partition_logs(po, tmp_path, n, nparts)
     # one malformed message in partition 1: counted and dropped, never fatal (inserter.go:125-126)
     with open(paths[1], "ab") as f:
         f.write(bytes.fromhex("05" + "70ffffffff"))
     rb, m = tmp_path / "flows_5m.rowbinary", tmp_path / "metrics.txt"
-    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-flush.count=7000", "-out.rowbinary=%s" % rb,
+    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-flush.count=%d" % flush, "-out.rowbinary=%s" % rb,
                         "-metrics.dump=%s" % m, "-gpu.devices=1"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     met = _metrics(m)
