@@ -1312,7 +1312,7 @@ __device__ __forceinline__ bool agg_lds_upsert(AggTable& lt, uint64_t k0, uint64
     return false;
 }
 
-constexpr int AGG_MAX_NWG = 2048;  // tile-kernel workgroups (256 CUs x at most 8 per CU)
+constexpr int AGG_MAX_NWG = 1536;  // ingest-kernel workgroups: 256 CUs x 6 (workgroup-tile kernel) or x 2 (wave-tile kernel)
 #ifndef FA_AGG_SU
 #define FA_AGG_SU 4
 #endif
@@ -1363,8 +1363,14 @@ __device__ __forceinline__ void agg_tuple(const KArgs& a, AggTable& lt, uint32_t
 
 // The common case (the key already sits in its home slot) for all AGG_SU tuples at once, so that the LDS
 // round trips of the segments overlap; everything else goes through the probing upsert.
+// the queued leftovers of a wave, one per lane (LDS operations of a wave complete in order: the queue needs no fence)
+__device__ __forceinline__ void agg_drain(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const uint4* queue, uint32_t qn) {
+    if (lane < qn) agg_tuple(a, lt, tb_base, queue[lane]);
+}
+
 template <int S0>
-__device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b) {
+__device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b,
+                                                  uint4* queue, uint32_t& qn) {
     uint64_t k0[AGG_CH], k1[AGG_CH];
     uint32_t h[AGG_CH];
     unsigned long long c0[AGG_CH], c1[AGG_CH];
@@ -1412,34 +1418,29 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
         }
     }
     if (a.dbg & DBG_AGG_NO_SLOW) return;
-    // the leftovers of the AGG_CH segments share one loop: a lane works on its first pending tuple
-    // per round, so the wave pays max-over-lanes(pending tuples) upserts instead of one per segment
-    while (__builtin_amdgcn_ballot_w64(pending != 0) != 0ull) {
-        if (pending != 0) {
-            const uint32_t s = (uint32_t)__builtin_ctz(pending);
-            pending &= pending - 1u;
-            uint64_t sk0 = k0[0], sk1 = k1[0];
-            uint32_t sh = h[0], sz = b.t[S0].z, sw = b.t[S0].w;
+    // The leftovers (first occurrences of a group, keys two or more slots from home: ~5 % of the tuples) wait in
+    // the wave's queue and take the probing path 64 at a time: handled on the spot, each round of the probing
+    // loop would run with one or two active lanes.
 #pragma unroll
-            for (int j = 1; j < AGG_CH; j++) {
-                const bool pick = s == (uint32_t)j;
-                sk0 = pick ? k0[j] : sk0;
-                sk1 = pick ? k1[j] : sk1;
-                sh = pick ? h[j] : sh;
-                sz = pick ? b.t[S0 + j].z : sz;
-                sw = pick ? b.t[S0 + j].w : sw;
+    for (int s = 0; s < AGG_CH; s++) {
+        const bool pnd = (pending >> s) & 1u;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pnd);
+        if (m != 0ull) {
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+            if (qn + cnt > 64u) {
+                agg_drain(a, lt, tb_base, lane, queue, qn);
+                qn = 0;
             }
-            const uint32_t by = sz & 0x0fffffffu, pk = sw & 0x7fffu;
-            const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
-            if (!agg_lds_upsert(lt, sk0, sk1, sh, by, v2, (skipw >> (2 * s)) & 3u))
-                agg_global(a, sk0, sk1, sh, by, pk, 1);  // partition holds more groups than the LDS table
+            if (pnd) queue[qn + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = b.t[S0 + s];
+            qn += cnt;
         }
     }
 }
 
-__device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b) {
-    agg_consume_chunk<0>(a, lt, tb_base, lane, b);
-    if (AGG_SU > AGG_CH) agg_consume_chunk<AGG_SU - AGG_CH>(a, lt, tb_base, lane, b);
+__device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b,
+                                            uint4* queue, uint32_t& qn) {
+    agg_consume_chunk<0>(a, lt, tb_base, lane, b, queue, qn);
+    if (AGG_SU > AGG_CH) agg_consume_chunk<AGG_SU - AGG_CH>(a, lt, tb_base, lane, b, queue, qn);
 }
 
 __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
@@ -1453,6 +1454,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
         lt.s2[i] = 0;
     }
     __shared__ uint32_t pcb[AGG_MAX_NWG + AGG_PAD];  // ... and the counts of the segments' back parts
+    __shared__ uint4 queues[(AGG_BLOCK / 64) * 64];  // per wave: tuples that need the probing path
     __shared__ uint32_t maxc_s[2];
     if (threadIdx.x < 2) maxc_s[threadIdx.x] = 0;
     __syncthreads();
@@ -1479,6 +1481,8 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     constexpr uint32_t STEP = (AGG_BLOCK / 64) * AGG_SU * AGG_SPLIT;
     __syncthreads();  // table cleared, counts staged
     const uint32_t maxc = maxc_s[0], maxcb = maxc_s[1];
+    uint4* queue = queues + wave * 64;
+    uint32_t qn = 0;  // wave-uniform
     // software pipeline over this wave's segment groups: the next group's loads fly during the LDS work
     // (every fetch is unconditional - clamped addresses, zero counts past the end - so that the compiler
     // can count the loads in flight and wait for the older batch only)
@@ -1491,9 +1495,9 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
         agg_fetch<false>(a, pbase, pc, w0, lane, j, b0);
         while (true) {
             agg_fetch<false>(a, pbase, pc, w0 + STEP, lane, j, b1);
-            agg_consume(a, lt, tb_base, lane, b0);
+            agg_consume(a, lt, tb_base, lane, b0, queue, qn);
             agg_fetch<false>(a, pbase, pc, w0 + 2 * STEP, lane, j, b0);
-            agg_consume(a, lt, tb_base, lane, b1);
+            agg_consume(a, lt, tb_base, lane, b1, queue, qn);
             w0 += 2 * STEP;
             if (w0 >= a.nwg) break;
         }
@@ -1506,13 +1510,14 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
         agg_fetch<true>(a, pbase, pcb, w0, lane, j, b0);
         while (true) {
             agg_fetch<true>(a, pbase, pcb, w0 + STEP_B, lane, j, b1);
-            agg_consume(a, lt, tb_base, lane, b0);
+            agg_consume(a, lt, tb_base, lane, b0, queue, qn);
             agg_fetch<true>(a, pbase, pcb, w0 + 2 * STEP_B, lane, j, b0);
-            agg_consume(a, lt, tb_base, lane, b1);
+            agg_consume(a, lt, tb_base, lane, b1, queue, qn);
             w0 += 2 * STEP_B;
             if (w0 >= a.nwg) break;
         }
     }
+    agg_drain(a, lt, tb_base, lane, queue, qn);
     __syncthreads();
     // every group of this partition goes to the device-wide table once; quad-grouped: one atomic line
     // transaction per group.  Uniform trip count: the whole wave takes part in the quad rounds.
