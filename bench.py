@@ -168,6 +168,14 @@ def main():
         merged = fa.dist.close_window_merged(agg, fa.ALL_TIMESLOTS, device=xdev)
     else:
         merged = agg.close_window(fa.ALL_TIMESLOTS)
+    topk_rows = None
+    if args.key_sets & fa.FA_KEYS_SRCADDR_CMS:
+        # BASELINE configs[3] shape: per-GPU sketches, RCCL all-reduce at window close, top-k over the union of the
+        # ranks' candidates (dist.topk_merged); single rank: the local ranking
+        if world > 1 and backend == "nccl":
+            topk_rows = fa.dist.topk_merged(agg, fa.FA_KEYS_SRCADDR_CMS, 100, candidates_per_rank=1000, device=xdev)
+        else:
+            topk_rows = agg.topk(fa.FA_KEYS_SRCADDR_CMS, 100)
     merge_ms = (time.perf_counter() - t_merge) * 1e3
     total_steps = args.warmup + args.steps
     ok_total = int(merged["count"].sum())
@@ -204,6 +212,7 @@ def main():
             "partitioning": "one Kafka partition per GPU, no data-path collective; rows all-gathered at window close",
             "window_close_merge_ms": merge_ms,
             "groups": int(len(merged)),
+            "topk_src_addr_rows": None if topk_rows is None else int(len(topk_rows)),
             "records_direct_path": int(st1["records_direct"] - st0["records_direct"]),
             "records_second_chance_parser": int(st1["records_retried"] - st0["records_retried"]),
             "wire_GBps_whole_job": wire_bytes * args.steps * world / elapsed / 1e9,
