@@ -1,0 +1,277 @@
+// agg.cuh - aggregation of the scattered tuples: one workgroup per key partition, LDS hash table, one device-table
+// update per group.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sinks.cuh"
+
+namespace fa {
+
+// ---- aggregation of the scattered tuples -----------------------------------------------------
+// One 1024-thread workgroup per key partition.  LDS table slot = key (2 words, same claim protocol
+// as the other tables) + two packed sums:  s1 = sum(bytes) (< 2^28 * 2^24),
+// s2 = sum(packets) << 25 | count  (packets < 2^15, count <= 2^24: no carry between the fields).
+struct AggTable {
+    unsigned long long k0[AGG_SLOTS], k1[AGG_SLOTS], s1[AGG_SLOTS], s2[AGG_SLOTS];
+};
+static_assert(sizeof(AggTable) == 32 * AGG_SLOTS, "agg_kernel LDS table");
+
+// slow path of the LDS upsert: claim / probe; false = the table is full around this hash
+// (skip = leading slots of the probe sequence already known to hold other keys: a key never changes)
+__device__ __forceinline__ bool agg_lds_upsert(AggTable& lt, uint64_t k0, uint64_t k1, uint32_t h, uint32_t by,
+                                               unsigned long long v2, uint32_t skip = 0) {
+    uint32_t i = (h + skip) & (AGG_SLOTS - 1);
+#pragma unroll 1
+    for (int probe = (int)skip; probe < AGG_PROBES; probe++, i = (i + 1) & (AGG_SLOTS - 1)) {
+        unsigned long long c0 = lt.k0[i];
+        if (c0 == 0) c0 = atomicCAS(&lt.k0[i], 0ull, (unsigned long long)k0);
+        if (c0 != 0 && c0 != k0) continue;
+        unsigned long long c1 = lt.k1[i];
+        if (c1 == 0) c1 = atomicCAS(&lt.k1[i], 0ull, (unsigned long long)k1);
+        if (c1 != 0 && c1 != k1) continue;
+        if (by) atomicAdd(&lt.s1[i], (unsigned long long)by);
+        atomicAdd(&lt.s2[i], v2);
+        return true;
+    }
+    return false;
+}
+
+constexpr int AGG_MAX_NWG = 1536;  // ingest-kernel workgroups: 256 CUs x 6 (workgroup-tile kernel) or x 2 (wave-tile kernel)
+#ifndef FA_AGG_SU
+#define FA_AGG_SU 4
+#endif
+constexpr int AGG_SU = FA_AGG_SU;  // segments a wave reads at a time (16-byte loads in flight per lane, x2 buffers)
+constexpr int AGG_PAD = AGG_SU * 8;  // zero counts behind the last segment (the back pass reads 8 segments per load)
+constexpr int AGG_CH = 4;  // tuples of a batch that are hashed / probed together
+
+struct AggBatch {
+    uint4 t[AGG_SU];
+    uint32_t v;  // bit s: t[s] is a tuple of this lane (not a dummy load)
+};
+
+// issue the loads of lanes [0,64) of AGG_SU consecutive segments starting at w0.  The segment counts
+// come from LDS (pc, zero padded): a count read from global memory would put a full vmcnt drain between
+// consecutive tuple loads.
+// Front parts: chunk level j = tuples [64j, 64j+64) of a segment, one segment per 64 lanes.
+// Back parts (a handful of tuples each): level j = tuples [8j, 8j+8) of the c tuples that end at the segment's
+// last slot, EIGHT segments per 64 lanes.  Loads are unconditional (lanes without a tuple re-read slot 0 of a
+// valid segment): with predicated loads the compiler cannot count what is in flight and drains everything
+// (vmcnt(0)) before the previous batch is consumed.
+template <bool BACK>
+__device__ __forceinline__ void agg_fetch(const KArgs& a, const uint4* pbase, const uint32_t* pc, uint32_t w0, uint32_t lane,
+                                          uint32_t j, AggBatch& b) {
+    constexpr uint32_t SEGS = BACK ? 8u : 1u, PER = 64u / SEGS;  // segments per load, lanes per segment
+    uint32_t idx[AGG_SU], seg[AGG_SU];
+    b.v = 0;
+#pragma unroll
+    for (int s = 0; s < AGG_SU; s++) {
+        seg[s] = w0 + (uint32_t)s * SEGS + (BACK ? lane / PER : 0u);
+        const uint32_t c = pc[min(seg[s], (uint32_t)(AGG_MAX_NWG + AGG_PAD - 1))];  // 0 past nwg
+        const uint32_t q = PER * j + (BACK ? lane % PER : lane);
+        const bool valid = q < c;
+        b.v |= valid ? 1u << s : 0u;
+        idx[s] = valid ? (BACK ? a.capq - c : 0u) + q : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < AGG_SU; s++) b.t[s] = pbase[(size_t)min(seg[s], a.nwg - 1u) * a.capq + idx[s]];
+}
+
+__device__ __forceinline__ void agg_tuple(const KArgs& a, AggTable& lt, uint32_t tb_base, const uint4& t) {
+    const uint32_t by = t.z & 0x0fffffffu, tbr = t.z >> 28, pk = t.w & 0x7fffu, et = t.w >> 15;
+    uint64_t k0, k1;
+    pack_key(tb_base + tbr, t.x, t.y, et, k0, k1);
+    const uint32_t h = key_hash(k0, k1);
+    const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
+    if (!agg_lds_upsert(lt, k0, k1, h, by, v2)) agg_global(a, k0, k1, h, by, pk, 1);
+}
+
+// The common case (the key already sits in its home slot) for all AGG_SU tuples at once, so that the LDS
+// round trips of the segments overlap; everything else goes through the probing upsert.
+// the queued leftovers of a wave, one per lane (LDS operations of a wave complete in order: the queue needs no fence)
+__device__ __forceinline__ void agg_drain(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const uint4* queue, uint32_t qn) {
+    if (lane < qn) agg_tuple(a, lt, tb_base, queue[lane]);
+}
+
+template <int S0>
+__device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b,
+                                                  uint4* queue, uint32_t& qn) {
+    uint64_t k0[AGG_CH], k1[AGG_CH];
+    uint32_t h[AGG_CH];
+    unsigned long long c0[AGG_CH], c1[AGG_CH];
+    if (a.dbg & DBG_AGG_NO_LDS) {  // ablation: consume the loads only
+        uint32_t x = 0;
+#pragma unroll
+        for (int s = 0; s < AGG_CH; s++) x ^= b.t[S0 + s].x ^ b.t[S0 + s].y ^ b.t[S0 + s].z ^ b.t[S0 + s].w;
+        if (x == 0x12345678u) lt.s1[lane] = x;
+        return;
+    }
+    // home slot and its successor are read together: at the table's load (<= 40 %) linear probing leaves ~30 % of
+    // the keys one slot away from home and ~10 % further; only the latter (and first occurrences) take the
+    // probing path below
+    unsigned long long d0[AGG_CH], d1[AGG_CH];
+#pragma unroll
+    for (int s = 0; s < AGG_CH; s++) {
+        const uint32_t tbr = b.t[S0 + s].z >> 28, et = b.t[S0 + s].w >> 15;
+        pack_key(tb_base + tbr, b.t[S0 + s].x, b.t[S0 + s].y, et, k0[s], k1[s]);
+        h[s] = key_hash(k0[s], k1[s]);
+        const uint32_t i = h[s] & (AGG_SLOTS - 1), j = (i + 1) & (AGG_SLOTS - 1);
+        c0[s] = lt.k0[i];
+        c1[s] = lt.k1[i];
+        d0[s] = lt.k0[j];
+        d1[s] = lt.k1[j];
+    }
+    uint32_t pending = 0;  // segments whose tuple is not in its home slot (probing / claiming needed)
+    uint32_t skipw = 0;    // 2 bits per segment: leading probe slots known to hold other keys
+#pragma unroll
+    for (int s = 0; s < AGG_CH; s++) {
+        if (!((b.v >> (S0 + s)) & 1u)) continue;
+        const uint32_t by = b.t[S0 + s].z & 0x0fffffffu, pk = b.t[S0 + s].w & 0x7fffu;
+        const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
+        const uint32_t i = h[s] & (AGG_SLOTS - 1);
+        const bool at0 = c0[s] == k0[s] && c1[s] == k1[s], at1 = d0[s] == k0[s] && d1[s] == k1[s];
+        if (at0 || at1) {
+            const uint32_t t = at0 ? i : (i + 1) & (AGG_SLOTS - 1);
+            if (by) atomicAdd(&lt.s1[t], (unsigned long long)by);
+            atomicAdd(&lt.s2[t], v2);
+        } else {
+            // slots that definitely belong to other keys need no second look on the probing path
+            const bool o0 = (c0[s] != 0 && c0[s] != k0[s]) || (c0[s] == k0[s] && c1[s] != 0 && c1[s] != k1[s]);
+            const bool o1 = (d0[s] != 0 && d0[s] != k0[s]) || (d0[s] == k0[s] && d1[s] != 0 && d1[s] != k1[s]);
+            skipw |= (o0 ? (o1 ? 2u : 1u) : 0u) << (2 * s);
+            pending |= 1u << s;
+        }
+    }
+    if (a.dbg & DBG_AGG_NO_SLOW) return;
+    // The leftovers (first occurrences of a group, keys two or more slots from home: ~5 % of the tuples) wait in
+    // the wave's queue and take the probing path 64 at a time: handled on the spot, each round of the probing
+    // loop would run with one or two active lanes.
+#pragma unroll
+    for (int s = 0; s < AGG_CH; s++) {
+        const bool pnd = (pending >> s) & 1u;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pnd);
+        if (m != 0ull) {
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+            if (qn + cnt > 64u) {
+                agg_drain(a, lt, tb_base, lane, queue, qn);
+                qn = 0;
+            }
+            if (pnd) queue[qn + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = b.t[S0 + s];
+            qn += cnt;
+        }
+    }
+}
+
+__device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b,
+                                            uint4* queue, uint32_t& qn) {
+    agg_consume_chunk<0>(a, lt, tb_base, lane, b, queue, qn);
+    if (AGG_SU > AGG_CH) agg_consume_chunk<AGG_SU - AGG_CH>(a, lt, tb_base, lane, b, queue, qn);
+}
+
+__global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
+    __shared__ AggTable lt;
+    __shared__ uint32_t pc[AGG_MAX_NWG + AGG_PAD];  // this partition's segment counts, zero padded
+    const uint32_t part = blockIdx.x / AGG_SPLIT, sub = blockIdx.x % AGG_SPLIT;
+    for (int i = threadIdx.x; i < AGG_SLOTS; i += AGG_BLOCK) {
+        lt.k0[i] = 0;
+        lt.k1[i] = 0;
+        lt.s1[i] = 0;
+        lt.s2[i] = 0;
+    }
+    __shared__ uint32_t pcb[AGG_MAX_NWG + AGG_PAD];  // ... and the counts of the segments' back parts
+    __shared__ uint4 queues[(AGG_BLOCK / 64) * 64];  // per wave: tuples that need the probing path
+    __shared__ uint32_t maxc_s[2];
+    if (threadIdx.x < 2) maxc_s[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mymax = 0, mymaxb = 0;
+    for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_PAD; i += AGG_BLOCK) {
+        const uint32_t c = i < a.nwg ? a.seg_counts[(size_t)part * a.nwg + i] : 0u;
+        const uint32_t cb = i < a.nwg ? a.seg_counts[((size_t)NPART_MAX + part) * a.nwg + i] : 0u;
+        pc[i] = c;
+        pcb[i] = cb;
+        mymax = max(mymax, c);
+        mymaxb = max(mymaxb, cb);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, o));
+        mymaxb = max(mymaxb, (uint32_t)__shfl_xor((int)mymaxb, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&maxc_s[0], mymax);
+        atomicMax(&maxc_s[1], mymaxb);
+    }
+    const uint32_t tb_base = a.ctr->tb_base;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint4* pbase = a.seg + (size_t)part * a.region;
+    constexpr uint32_t STEP = (AGG_BLOCK / 64) * AGG_SU * AGG_SPLIT;
+    __syncthreads();  // table cleared, counts staged
+    const uint32_t maxc = maxc_s[0], maxcb = maxc_s[1];
+    uint4* queue = queues + wave * 64;
+    uint32_t qn = 0;  // wave-uniform
+    // software pipeline over this wave's segment groups: the next group's loads fly during the LDS work
+    // (every fetch is unconditional - clamped addresses, zero counts past the end - so that the compiler
+    // can count the loads in flight and wait for the older batch only)
+    // chunk levels: level j covers tuples [64j, 64j+64) of every segment (segments of the 512-thread tile kernel
+    // hold ~127 tuples, those of the 256-thread one ~42)
+    const uint32_t levels = (__builtin_amdgcn_readfirstlane(maxc) + 63u) >> 6;
+    for (uint32_t j = 0; j < levels; j++) {
+        AggBatch b0, b1;
+        uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * AGG_SU;
+        agg_fetch<false>(a, pbase, pc, w0, lane, j, b0);
+        while (true) {
+            agg_fetch<false>(a, pbase, pc, w0 + STEP, lane, j, b1);
+            agg_consume(a, lt, tb_base, lane, b0, queue, qn);
+            agg_fetch<false>(a, pbase, pc, w0 + 2 * STEP, lane, j, b0);
+            agg_consume(a, lt, tb_base, lane, b1, queue, qn);
+            w0 += 2 * STEP;
+            if (w0 >= a.nwg) break;
+        }
+    }
+    const uint32_t levels_b = (__builtin_amdgcn_readfirstlane(maxcb) + 7u) >> 3;
+    constexpr uint32_t STEP_B = STEP * 8u;
+    for (uint32_t j = 0; j < levels_b; j++) {  // the back parts (single tuples and bin leftovers of the wave-tile kernel)
+        AggBatch b0, b1;
+        uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * AGG_SU * 8u;
+        agg_fetch<true>(a, pbase, pcb, w0, lane, j, b0);
+        while (true) {
+            agg_fetch<true>(a, pbase, pcb, w0 + STEP_B, lane, j, b1);
+            agg_consume(a, lt, tb_base, lane, b0, queue, qn);
+            agg_fetch<true>(a, pbase, pcb, w0 + 2 * STEP_B, lane, j, b0);
+            agg_consume(a, lt, tb_base, lane, b1, queue, qn);
+            w0 += 2 * STEP_B;
+            if (w0 >= a.nwg) break;
+        }
+    }
+    agg_drain(a, lt, tb_base, lane, queue, qn);
+    __syncthreads();
+    // every group of this partition goes to the device-wide table once; quad-grouped: one atomic line
+    // transaction per group.  Uniform trip count: the whole wave takes part in the quad rounds.
+    if (a.dbg & DBG_AGG_NO_FLUSH) return;
+    constexpr int NF = AGG_SLOTS / AGG_BLOCK;  // slots per thread
+    unsigned long long fk0[NF], fk1[NF], fs1[NF], fs2[NF];
+    ulonglong2 home[NF];
+    uint32_t fh[NF];
+#pragma unroll
+    for (int q = 0; q < NF; q++) {  // phase 1: the home-slot probes of all NF groups fly together
+        const int i = q * AGG_BLOCK + threadIdx.x;
+        fk0[q] = lt.k0[i];
+        fk1[q] = lt.k1[i];
+        fs1[q] = lt.s1[i];
+        fs2[q] = lt.s2[i];
+        fh[q] = key_hash(fk0[q], fk1[q]);
+        home[q] = *reinterpret_cast<const ulonglong2*>(&a.tab[fh[q] & a.mask]);
+    }
+#pragma unroll
+    for (int q = 0; q < NF; q++) {
+        Slot* sp = nullptr;
+        const unsigned long long b = fs1[q], p = fs2[q] >> 25, c = fs2[q] & 0x1ffffffull;
+        if (fk0[q] != 0 && fk1[q] != 0 && fs2[q] != 0) {
+            if (home[q].x == fk0[q] && home[q].y == fk1[q]) sp = &a.tab[fh[q] & a.mask];
+            else sp = table_find_or_claim(a, fk0[q], fk1[q], fh[q]);
+            if (!sp) spill_park(a, fk0[q], fk1[q], b, p, c);
+        }
+        quad_atomic_update(sp, b, p, c);
+    }
+}
+
+}  // namespace fa

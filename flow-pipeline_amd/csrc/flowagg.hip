@@ -1327,7 +1327,7 @@ extern "C" int fa_dashboard_reset(fa_ctx* c) {
 }
 
 // ---- sketches -----------------------------------------------------------------------------------
-// Sums the sketch copies into copy 0 (kernels.cuh, cms_add).  Every reader of a sketch calls this first.
+// Sums the sketch copies into copy 0 (sinks.cuh, cms_add).  Every reader of a sketch calls this first.
 static int cms_fold(fa_ctx* c) {
     if (!c->cms_dirty) return FA_OK;
     for (unsigned long long* p : {c->cms_src, c->cms_dst})

@@ -1,0 +1,703 @@
+// ingest.cuh - the ingest kernels: per-record work (parse -> key -> sink), the LDS tuple bins, the wave-tile
+// kernel (production), the workgroup-tile kernel (decode path / direct sink), probe and deferred kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sinks.cuh"
+
+namespace fa {
+
+// ---- per-lane work on a staged record (called by every lane of the workgroup) ------
+template <int MODE, uint32_t KEYSETS, uint32_t COLS>
+__device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, LdsMinutes& lm, uint32_t* part_cnt, const uint32_t* tile,
+                                          bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
+                                          uint32_t& n_ok, uint32_t& n_direct, uint32_t& lt_seen, uint32_t& lt_hits,
+                                          uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out) {
+    // ---- parse (divergent: only lanes that own a staged record) ----
+    bool sure = false;
+    Rec r;
+    rec_clear(r);
+    if (mine) {
+        LdsSrc src{tile};
+        sure = true;
+        if (a.framed && !(a.dbg & DBG_NO_FRAME)) {
+            uint32_t pl = 0;
+            const uint32_t i = pos >> 2;
+            sure = frame_short(fa_alignbyte(src.dw(i + 1), src.dw(i), pos), end - pos, pl);
+            pos += pl;
+        }
+        if (sure && !(a.dbg & DBG_NO_PARSE)) {
+            if (a.dbg & DBG_LOOP_PARSER) sure = parse_fast<COLS>(src, pos, end, r);
+            else sure = parse_canon<COLS>(src, pos, end, r);
+        }
+        if (!sure) {
+            unsigned int j = atomicAdd(&a.ctr->retry_count, 1u);
+            a.retry_idx[j] = rec_idx;
+        }
+    }
+    // ---- sink ----
+    if (MODE == MODE_DECODE) {
+        if (sure) store_columns(a.cols, rec_idx, r, 0);
+        return;
+    }
+    n_ok += sure ? 1 : 0;
+    if (a.dbg & DBG_NO_SINK) {
+        n_ok += (uint32_t)(r.time_received ^ r.bytes ^ r.packets ^ r.src_as ^ r.dst_as ^ r.etype) & 1;
+        return;
+    }
+    const uint32_t t32 = (uint32_t)r.time_received;  // UInt64 -> DateTime (create.sh:39)
+    const uint32_t tb = time_bucket(a, t32);
+    if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
+        uint64_t k0, k1;
+        pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
+        const uint32_t h = key_hash(k0, k1);
+        const uint64_t b = r.bytes, p = r.packets, c = 1;
+        bool pending = sure;
+        // hot-key table: worth its LDS atomics only while it absorbs records.  Every wave keeps score (ballots:
+        // wave-uniform, no LDS traffic) and stops offering records once fewer than 1 in 8 of its first 256 stuck
+        // (64 k uniform AS pairs never do; the mocker's 9 groups always do).  lt_seen == ~0u: switched off.
+        if (lt_seen != 0xffffffffu && !(a.dbg & DBG_NO_LDS_TABLE)) {
+            if (pending) pending = !lds_table_add<LDS_SLOTS, LDS_PROBES>(lt, k0, k1, h, b, p, c);
+            lt_seen += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sure));
+            lt_hits += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sure && !pending));
+            if (lt_seen >= 256u) {
+                if (lt_hits * 8u < lt_seen) lt_seen = 0xffffffffu;
+                else lt_seen = lt_hits = 0;
+            }
+        }
+        // tuple path: 16 bytes to this workgroup's private segment of the key's partition
+        uint32_t fill_part = 0xffffffffu;  // wave-tile kernel: the bin this lane has just filled
+        if (pending && a.seg) {
+            const uint32_t tbr = tb - tb_base;
+            const bool fits = tbr < TUPLE_TB_SPAN && b < TUPLE_MAX_BYTES && p < TUPLE_MAX_PACKETS && r.etype < TUPLE_MAX_ETYPE;
+            if (fits) {
+                const uint32_t part = h >> (32 - a.plog2);
+                const uint4 tv = make_uint4(r.src_as, r.dst_as, (uint32_t)b | (tbr << 28), (uint32_t)p | (r.etype << 15));
+                if (bins) {
+                    // wave-tile kernel: the tuple waits in the workgroup's LDS bin of its partition; the lane that takes
+                    // the last slot of a bin sends the 8 tuples off as one full, aligned 128-byte line (below)
+                    // (acquire: the tuple write below must not move above the claim - the previous occupants of the bin
+                    // are read by the flusher until it resets the word; release: the tuple is written before it counts)
+                    const uint32_t slot = __hip_atomic_fetch_add(&bin_cnt[part], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;  // low half: slots taken, high half: slots written
+                    if (slot < BIN_CAP) {
+                        bins[part * BIN_CAP + slot] = tv;
+                        __hip_atomic_fetch_add(&bin_cnt[part], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        fill_part = slot == BIN_CAP - 1 ? part : fill_part;
+                        pending = false;
+                    } else {  // the bin is on its way out: single 16-byte store to the back part of the segment
+                        const uint32_t ob = atomicAdd(&part_cnt[part], 0x10000u) >> 16;
+                        if (ob < a.capb) {
+                            if (!(a.dbg & DBG_NO_TUPLE_STORE))
+                                a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob)] = tv;
+                            pending = false;
+                        }
+                    }
+                } else {
+                    const uint32_t q = atomicAdd(&part_cnt[part], 1u);
+                    if (q < a.capq) {
+                        if (!(a.dbg & DBG_NO_TUPLE_STORE)) {
+                            uint4* dstp = &a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + q];
+                            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                            const v4u tvv = {tv.x, tv.y, tv.z, tv.w};
+                            if (a.dbg & DBG_TUPLE_NT) __builtin_nontemporal_store(tvv, reinterpret_cast<v4u*>(dstp));
+                            else if (a.dbg & DBG_TUPLE_SC) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dstp), "v"(tvv) : "memory");
+                            else *dstp = tv;
+                        }
+                        pending = false;
+                    }
+                }
+            }
+        }
+        fill_out = fill_part;  // full bins leave in bins_flush(), which the wave-tile kernel runs right after this call
+        // direct path (what is left): device-wide table, one atomic line transaction per record
+        if (__builtin_amdgcn_ballot_w64(pending) != 0ull && !(a.dbg & DBG_NO_GLOBAL)) {  // wave-uniform
+            Slot* sp = nullptr;
+            if (pending) {
+                n_direct++;
+                sp = table_find_or_claim(a, k0, k1, h);
+                if (!sp) spill_park(a, k0, k1, b, p, c);
+            }
+            quad_atomic_update(sp, b, p, c);
+        }
+    }
+    if (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
+        // lanes of a wave that carry the same address (heavy hitters) are folded first: one sketch update and
+        // one distinct-set probe per address and wave (wave-tile kernel: its parsed tile buffer is the scratch)
+        const uint64_t w = r.bytes * r.sampling_rate;  // viz-ch.json:233 sum(Bytes*SamplingRate), UInt64 wrap
+        if (ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS)) {
+            uint64_t ws = w;
+            bool valid = sure;
+            if (bins) wave_fold_lds(const_cast<uint32_t*>(tile), valid, (uint64_t)r.src[1] << 32 | r.src[0], (uint64_t)r.src[3] << 32 | r.src[2], ws);
+            if (valid) {
+                cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, ws);
+                keyset_insert(a, a.ks_src, r.src);
+            }
+        }
+        if (ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS)) {
+            uint64_t ws = w;
+            bool valid = sure;
+            if (bins) wave_fold_lds(const_cast<uint32_t*>(tile), valid, (uint64_t)r.dst[1] << 32 | r.dst[0], (uint64_t)r.dst[3] << 32 | r.dst[2], ws);
+            if (valid) {
+                cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, ws);
+                keyset_insert(a, a.ks_dst, r.dst);
+            }
+        }
+    }
+    if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb);
+}
+
+// End-of-kernel counters: one global atomic per WORKGROUP.  All waves of the grid finish at about the same
+// time, and same-address atomics serialize at the memory side: one atomic per wave (8192 of them) was a
+// ~30 us tail on a 0.4 ms launch.
+__device__ __forceinline__ void block_counters_add(uint32_t* lds2, Counters* ctr, uint32_t n_ok, uint32_t n_direct) {
+    if (threadIdx.x < 2) lds2[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t ok = (uint32_t)wave_sum_u64(n_ok), direct = (uint32_t)wave_sum_u64(n_direct);
+    if (__lane_id() == 0) {
+        if (ok) atomicAdd(&lds2[0], ok);
+        if (direct) atomicAdd(&lds2[1], direct);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (lds2[0]) atomicAdd(&ctr->ok, (unsigned long long)lds2[0]);
+        if (lds2[1]) atomicAdd(&ctr->direct, (unsigned long long)lds2[1]);
+    }
+}
+
+// ---- the tile kernel ----------------------------------------------------------
+// Persistent workgroups; tile = 256 consecutive records (one per lane).  The wire
+// bytes of tile t+1 stream into the second LDS buffer (async DMA) while tile t is
+// parsed and aggregated, so the HBM latency hides behind the integer work.
+// The descriptor is two loads (lo, hi) whose values must NOT be looked at before the tile's turn comes: any
+// arithmetic on them right after the loads makes the compiler wait for them - and, vmcnt being in-order, for
+// the DMA issued just before - and only then issue the per-lane offset loads: two serialized memory round
+// trips per tile (this cost 25 % of the staging bandwidth, tools/read_bench2.hip).  fits() is evaluated
+// when the tile is current.
+struct TileDesc {
+    uint32_t r0, nrec, lo, hi;  // records [r0,r0+nrec), wire bytes [lo,hi)
+};
+__device__ __forceinline__ TileDesc tile_desc(const KArgs& a, uint32_t t, uint32_t ntiles) {
+    TileDesc d{0, 0, 0, 0};
+    if (t < ntiles) {
+        d.r0 = t * a.tile_recs;
+        d.nrec = min(a.tile_recs, a.n - d.r0);
+        // the indices are laundered through VGPRs: for provably uniform addresses the compiler moves the loaded
+        // values to SGPRs at once (v_readfirstlane right behind the loads = the same premature wait)
+        uint32_t i0 = d.r0, i1 = d.r0 + d.nrec;
+        asm volatile("" : "+v"(i0), "+v"(i1));
+        d.lo = a.off[i0];
+        d.hi = a.off[i1];
+    }
+    return d;
+}
+// the bounds of the tile whose turn has come, as wave-uniform scalars
+__device__ __forceinline__ TileDesc tile_current(const TileDesc& d) {
+    return TileDesc{d.r0, d.nrec, (uint32_t)__builtin_amdgcn_readfirstlane((int)d.lo), (uint32_t)__builtin_amdgcn_readfirstlane((int)d.hi)};
+}
+template <int BYTES>
+__device__ __forceinline__ bool tile_fits(const TileDesc& d) {  // whole tile fits one LDS buffer (the normal case)
+    return d.nrec != 0 && d.hi >= d.lo && (d.hi - (d.lo & ~15u)) <= (uint32_t)BYTES;
+}
+
+// Persistent workgroups; tile = up to 256 consecutive records (one per lane) staged
+// in ONE LDS buffer.  LDS bounds the number of records a CU can hold, and the parse
+// is a long dependent chain per record, so the LDS goes to as many co-resident
+// workgroups as possible (6 per CU = 6 waves/SIMD): while one workgroup waits for
+// its DMA, the others parse.  (A double-buffered variant with 3 workgroups/CU
+// staged at 4.0 TB/s but left the parse latency-bound at 3 waves/SIMD.)
+template <int MODE, uint32_t KEYSETS>
+__global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
+    constexpr uint32_t COLS = MODE == MODE_DECODE ? (uint32_t)COL_ALL : cols_for_keysets<KEYSETS>();
+    __shared__ __attribute__((aligned(16))) uint32_t tile[TILE_STRIDE / 4];
+    __shared__ LdsTable<LDS_SLOTS> lt;
+    __shared__ uint32_t part_cnt[NPART_MAX];  // tuples this workgroup appended per key partition
+    __shared__ LdsMinutes lm;                 // per-minute series pre-aggregation (KS_ALL variant only)
+
+    const uint32_t tid = threadIdx.x;
+    if (MODE == MODE_INGEST && (KEYSETS & FA_KEYS_AS_PAIR)) {
+        lds_table_clear(lt);
+        for (int i = tid; i < NPART_MAX; i += BLOCK) part_cnt[i] = 0;
+    }
+    if (MODE == MODE_INGEST && (KEYSETS & FA_KEYS_MINUTE_SERIES)) lds_minutes_clear(lm);
+    const uint32_t tb_base = MODE == MODE_INGEST ? a.ctr->tb_base : 0u;
+
+    uint32_t n_ok = 0, n_direct = 0, lt_seen = 0, lt_hits = 0, no_fill = 0;
+    const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
+    const uint32_t stride = gridDim.x;
+    uint32_t t = blockIdx.x;
+    TileDesc cur = tile_current(tile_desc(a, t, ntiles));
+    uint32_t o0 = 0, o1 = 0;  // this lane's record of the current tile
+    if (t < ntiles && tid < cur.nrec) {
+        o0 = a.off[cur.r0 + tid];
+        o1 = a.off[cur.r0 + tid + 1];
+    }
+    __syncthreads();  // LDS table cleared
+
+    const bool timing = (a.dbg & DBG_TIMING) != 0 && tid == 0;
+    uint32_t tm_wait = 0, tm_work = 0, tm_tiles = 0;
+    const uint32_t tm_start = timing ? (uint32_t)clock64() : 0u;
+    for (; t < ntiles; t += stride) {
+        const bool cur_fits = tile_fits<TILE_BYTES>(cur);
+        const uint32_t tm0 = timing ? (uint32_t)clock64() : 0u;
+        // (1) stream this tile's wire bytes into LDS (async DMA) ...
+        if (cur_fits) {
+            // nt: the wire bytes are read exactly once; keeping them out of the way of the L2's open tuple lines
+            // is worth 11 % of the launch (MI355X, tools/knobs.sh FA_DEBUG_FLAGS=512)
+            if (a.dbg & DBG_DMA_NO_NT) dma_to_lds<0>(a.buf + (cur.lo & ~15u), cur.hi - (cur.lo & ~15u), tile);
+            else dma_to_lds<2>(a.buf + (cur.lo & ~15u), cur.hi - (cur.lo & ~15u), tile);
+        }
+        // ... and meanwhile fetch the next tile's descriptor and offsets
+        const TileDesc nxt = tile_desc(a, t + stride, ntiles);
+        uint32_t n0 = 0, n1 = 0;
+        if (tid < nxt.nrec) {
+            n0 = a.off[nxt.r0 + tid];
+            n1 = a.off[nxt.r0 + tid + 1];
+        }
+        dma_wait_all();
+        __syncthreads();
+        const uint32_t tm1 = timing ? (uint32_t)clock64() : 0u;
+
+        // (2) parse + aggregate out of LDS
+        if (cur_fits) {
+            const uint32_t cbase = cur.lo & ~15u;
+            const bool mine = tid < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
+            if (tid < cur.nrec && !mine) {  // broken offsets: let the generic path judge it
+                unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
+                a.exotic_idx[j] = cur.r0 + tid;
+            }
+            lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, n_ok, n_direct, lt_seen, lt_hits, nullptr, nullptr, no_fill);
+        } else {
+            // rare: the tile's bytes exceed the LDS buffer (big records): stage it in passes
+            uint32_t done = 0;
+            while (done < cur.nrec) {
+                const uint32_t first = a.off[cur.r0 + done];
+                const uint32_t cbase = first & ~15u;
+                const uint32_t climit = cbase + TILE_BYTES;
+                const uint32_t stage_end = min(cur.hi, climit);
+                if (stage_end > cbase) dma_to_lds(a.buf + cbase, stage_end - cbase, tile);
+                const uint32_t k = done + tid;
+                uint32_t p0 = 0, p1 = 0;
+                bool mine = false;
+                if (k < cur.nrec) {
+                    p0 = a.off[cur.r0 + k];
+                    p1 = a.off[cur.r0 + k + 1];
+                    mine = p1 <= climit && p1 >= p0 && p0 >= cbase && p1 <= cur.hi;
+                }
+                dma_wait_all();
+                const int nfit = __syncthreads_count(mine);  // offsets are monotone: a prefix fits
+                if (nfit == 0) {
+                    // one record larger than the LDS buffer (or broken offsets): generic path
+                    if (tid == 0) {
+                        unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
+                        a.exotic_idx[j] = cur.r0 + done;
+                    }
+                    done += 1;
+                } else {
+                    lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, n_ok, n_direct, lt_seen, lt_hits, nullptr, nullptr, no_fill);
+                    done += nfit;
+                }
+                __syncthreads();  // the buffer is restaged by the next pass
+            }
+        }
+        __syncthreads();  // everyone is done reading the tile
+        if (timing) {
+            const uint32_t tm2 = (uint32_t)clock64();
+            tm_wait += tm1 - tm0;
+            tm_work += tm2 - tm1;
+            tm_tiles++;
+        }
+        cur = tile_current(nxt);
+        o0 = n0;
+        o1 = n1;
+    }
+    if (timing) {
+        atomicAdd(&a.ctr->t_wait, (unsigned long long)tm_wait);
+        atomicAdd(&a.ctr->t_work, (unsigned long long)tm_work);
+        atomicAdd(&a.ctr->t_tiles, (unsigned long long)tm_tiles);
+        atomicAdd(&a.ctr->t_total, (unsigned long long)((uint32_t)clock64() - tm_start));
+    }
+    if (MODE == MODE_INGEST) {
+        if (KEYSETS & FA_KEYS_MINUTE_SERIES) {
+            __syncthreads();
+            if (tid < LDS_MINUTES && lm.key[tid] != 0 && lm.c[tid] != 0) {
+                WKey k;
+                wkey_pack(WK_MINUTE, 0, 0, 0, lm.key[tid] - 1u, 0, k);
+                wagg_global(wargs(a), k, lm.w[tid], 0, lm.c[tid]);
+            }
+        }
+        if (KEYSETS & FA_KEYS_AS_PAIR) {
+            __syncthreads();
+            // hot-key table -> device-wide table, one atomic line transaction per group (uniform trip count:
+            // the quad rounds need the whole wave)
+            for (int i0 = 0; i0 < LDS_SLOTS; i0 += BLOCK) {
+                const int i = i0 + tid;
+                Slot* sp = nullptr;
+                unsigned long long b = 0, p = 0, c = 0;
+                if (i < LDS_SLOTS) {
+                    const unsigned long long k0 = lt.k0[i], k1 = lt.k1[i];
+                    b = lt.bytes[i];
+                    p = lt.packets[i];
+                    c = lt.count[i];
+                    if (k0 != 0 && k1 != 0 && c != 0) {
+                        sp = table_find_or_claim(a, k0, k1, key_hash(k0, k1));
+                        if (!sp) spill_park(a, k0, k1, b, p, c);
+                    }
+                }
+                quad_atomic_update(sp, b, p, c);
+            }
+        }
+        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
+            for (int i = tid; i < (1 << a.plog2); i += BLOCK)
+{
+                a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min(part_cnt[i], a.capq);
+                a.seg_counts[((size_t)NPART_MAX + i) * a.nwg + blockIdx.x] = 0;
+            }
+        }
+        block_counters_add(part_cnt, a.ctr, n_ok, n_direct);  // (part_cnt has been written out: reused as scratch)
+    }
+}
+
+// ---- the wave-tile kernel ---------------------------------------------------------------------------
+// The production ingest kernel of the scatter sink.  Same per-record work as tile_kernel, different
+// residency: 2 workgroups of 8 waves per CU; every WAVE stages its own tile of <= 64 records into a private
+// LDS buffer (its next DMA is issued the moment the tile is consumed) and parses it - there is no workgroup
+// barrier anywhere in the steady state.  The LDS this frees (the 256-thread kernel spends all of it on
+// co-resident tiles) holds the tuple bins: a tuple waits in the 8-slot bin of its key partition, and a full bin
+// leaves as ONE aligned 128-byte line (lane_work), instead of as eight 16-byte stores whose cache line is
+// evicted from the L2 long before its neighbours arrive (DESIGN.md "Measurements").  A segment therefore has a
+// front part of whole lines and a back part for the odd tuples (bin leftovers at the end of the launch, tuples
+// that met a bin on its way out).  The workgroup's segments are 3x longer than tile_kernel's, which also
+// suits agg_kernel's 64-lane loads.
+typedef TileDesc WTileDesc;  // (same rule: the loaded bounds are not looked at before the tile's turn)
+__device__ __forceinline__ WTileDesc wtile_desc(const KArgs& a, uint32_t t, uint32_t ntiles) {
+    WTileDesc d{0, 0, 0, 0};
+    if (t < ntiles) {
+        d.r0 = t * a.tile_recs;
+        d.nrec = min(a.tile_recs, a.n - d.r0);
+        if (a.dbg & DBG_SYNTH_TILES) {  // measurement only: fixed-size aligned tiles, no descriptor loads
+            d.lo = t * 4608u;
+            d.hi = d.lo + 4608u;
+            return d;
+        }
+        uint32_t i0 = d.r0, i1 = d.r0 + d.nrec;
+        asm volatile("" : "+v"(i0), "+v"(i1));  // (see tile_desc)
+        d.lo = a.off[i0];
+        d.hi = a.off[i1];
+    }
+    return d;
+}
+
+template <uint32_t KEYSETS>
+__global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
+    constexpr uint32_t COLS = cols_for_keysets<KEYSETS>();
+    constexpr int WAVES = WBLOCK / 64;
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[WAVES * WT_STRIDE / 4];
+    __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BIN_CAP];
+    __shared__ uint32_t bin_cnt[NPART_MAX];
+    __shared__ uint32_t part_cnt[NPART_MAX];
+    __shared__ uint32_t flush_scratch[WAVES * 8];
+    __shared__ LdsTable<LDS_SLOTS> lt;
+    __shared__ LdsMinutes lm;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (KEYSETS & FA_KEYS_AS_PAIR) {
+        lds_table_clear(lt);
+        for (int i = tid; i < NPART_MAX; i += WBLOCK) {
+            part_cnt[i] = 0;
+            bin_cnt[i] = 0;
+        }
+    }
+    if (KEYSETS & FA_KEYS_MINUTE_SERIES) lds_minutes_clear(lm);
+    const uint32_t tb_base = a.ctr->tb_base;
+    uint32_t* tile = tiles + wave * (WT_STRIDE / 4);
+
+    uint32_t n_ok = 0, n_direct = 0, lt_seen = 0, lt_hits = 0;
+    const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
+    const uint32_t stride = gridDim.x * WAVES;
+    const uint32_t rounds = (ntiles + stride - 1) / stride;  // the same for every wave of the grid (flush barriers)
+    uint32_t t = blockIdx.x * WAVES + wave;
+    WTileDesc cur = tile_current(wtile_desc(a, t, ntiles));
+    uint32_t o0 = 0, o1 = 0;
+    const bool lane_off = !(a.dbg & DBG_NO_LANE_OFF);
+    // one offset load per lane: a record's end is its neighbour's start (lane nrec-1: the tile's end, already known)
+    if (lane_off && lane < cur.nrec) o0 = a.off[cur.r0 + lane];
+    o1 = (uint32_t)__shfl_down((int)o0, 1);
+    if (lane + 1 >= cur.nrec) o1 = cur.hi;
+    __syncthreads();  // LDS state cleared
+
+    auto issue_dma = [&](const WTileDesc& d) {
+        if (tile_fits<WT_STRIDE - 16>(d)) {
+            const uint32_t cbase = d.lo & ~15u, nbytes = d.hi - cbase;
+            for (uint32_t o = lane * 16u; o < nbytes; o += 1024u)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.buf + cbase + o),
+                                                 (__attribute__((address_space(3))) void*)(tile + (o - lane * 16u) / 4u), 16, 0, 2);
+        }
+    };
+    // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous
+    // tile was consumed, BEFORE the flush barriers, so that the memory system stays busy during a flush) and
+    // the descriptor + offsets of the tile after it are in flight
+    issue_dma(cur);
+    WTileDesc nxt = wtile_desc(a, t + stride, ntiles);
+    uint32_t n0 = 0;
+    if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
+    for (uint32_t round = 0; round < rounds; round++, t += stride) {
+        dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
+        uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
+        // parse + sink
+        if (cur.nrec != 0) {
+            const uint32_t cbase = cur.lo & ~15u;
+            bool mine = tile_fits<WT_STRIDE - 16>(cur) && lane < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
+            if (a.dbg & DBG_NOT_MINE) mine = mine && o0 == 0x7fffffffu;
+            if (lane < cur.nrec && !mine && !(a.dbg & (DBG_NO_LANE_OFF | DBG_SYNTH_TILES | DBG_NOT_MINE))) {  // tile larger than the buffer / broken offsets
+                unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
+                a.exotic_idx[j] = cur.r0 + lane;
+            }
+            lane_work<MODE_INGEST, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, n_ok,
+                                                  n_direct, lt_seen, lt_hits, bins, bin_cnt, fill);
+        }
+        // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
+        // queue and the wave would wait for the write acknowledgements on top of its tile (measured: +15 %)
+        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
+        cur = tile_current(nxt);
+        o0 = n0;
+        o1 = (uint32_t)__shfl_down((int)o0, 1);
+        if (lane + 1 >= cur.nrec) o1 = cur.hi;
+        issue_dma(cur);  // next tile (the buffer is free: every read of the old tile has returned)
+        nxt = wtile_desc(a, t + 2 * stride, ntiles);
+        n0 = 0;
+        if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
+    }
+    // what is left in the bins (fewer than BIN_CAP tuples each) goes to the back part of the segments
+    if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
+        __syncthreads();
+        for (uint32_t idx = tid; idx < (uint32_t)NPART_MAX * BIN_CAP; idx += WBLOCK) {
+            const uint32_t p = idx / BIN_CAP, sl = idx % BIN_CAP;
+            const uint32_t cnt = min(bin_cnt[p] & 0xffffu, BIN_CAP);
+            if (sl < cnt) {
+                const uint32_t ob = (part_cnt[p] >> 16) + sl;
+                const uint4 tv = bins[idx];
+                if (ob < a.capb) {
+                    if (!(a.dbg & DBG_NO_TUPLE_STORE)) a.seg[(size_t)p * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob)] = tv;
+                } else {  // back part full (skewed batch): straight to the device-wide table
+                    const uint32_t by = tv.z & 0x0fffffffu, tbr = tv.z >> 28, pk = tv.w & 0x7fffu, et = tv.w >> 15;
+                    uint64_t k0, k1;
+                    pack_key(tb_base + tbr, tv.x, tv.y, et, k0, k1);
+                    agg_global(a, k0, k1, key_hash(k0, k1), by, pk, 1);
+                    n_direct++;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < NPART_MAX) {
+            part_cnt[tid] += min(bin_cnt[tid] & 0xffffu, BIN_CAP) << 16;
+            bin_cnt[tid] = 0;
+        }
+        __syncthreads();
+    }
+    if (KEYSETS & FA_KEYS_MINUTE_SERIES) {
+        __syncthreads();
+        if (tid < LDS_MINUTES && lm.key[tid] != 0 && lm.c[tid] != 0) {
+            WKey k;
+            wkey_pack(WK_MINUTE, 0, 0, 0, lm.key[tid] - 1u, 0, k);
+            wagg_global(wargs(a), k, lm.w[tid], 0, lm.c[tid]);
+        }
+    }
+    if (KEYSETS & FA_KEYS_AS_PAIR) {
+        __syncthreads();
+        for (int i0 = 0; i0 < LDS_SLOTS; i0 += WBLOCK) {  // hot-key table -> device-wide table (full waves: quad rounds)
+            const int i = i0 + tid;
+            Slot* sp = nullptr;
+            unsigned long long b = 0, p = 0, c = 0;
+            if (i < LDS_SLOTS) {
+                const unsigned long long k0 = lt.k0[i], k1 = lt.k1[i];
+                b = lt.bytes[i];
+                p = lt.packets[i];
+                c = lt.count[i];
+                if (k0 != 0 && k1 != 0 && c != 0) {
+                    sp = table_find_or_claim(a, k0, k1, key_hash(k0, k1));
+                    if (!sp) spill_park(a, k0, k1, b, p, c);
+                }
+            }
+            quad_atomic_update(sp, b, p, c);
+        }
+        if (a.seg)
+            for (int i = tid; i < (1 << a.plog2); i += WBLOCK) {
+                const uint32_t w = part_cnt[i];
+                a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min((w & 0xffffu) * BIN_CAP, a.capf);
+                a.seg_counts[((size_t)NPART_MAX + i) * a.nwg + blockIdx.x] = min(w >> 16, a.capb);
+            }
+    }
+    block_counters_add(bin_cnt, a.ctr, n_ok, n_direct);  // (the bins are empty by now: reused as scratch)
+}
+
+// ---- probe: where in time does this batch sit? ---------------------------------------------
+// 64 evenly spaced records are decoded; tb_base = (smallest time bucket
+// seen) - 2, so that the 4-bit relative bucket of the tuple path covers the batch (Kafka partitions
+// are close to time-ordered; records outside [tb_base, tb_base+16) take the direct path).
+__global__ __launch_bounds__(64) void probe_kernel(KArgs a) {
+    __shared__ uint32_t lo;
+    if (threadIdx.x == 0) lo = 0xffffffffu;
+    __syncthreads();
+    const uint32_t idx = a.n <= 64 ? threadIdx.x : (uint32_t)(((uint64_t)threadIdx.x * (a.n - 1)) / 63u);
+    if (idx < a.n) {
+        uint32_t pos = a.off[idx], end = a.off[idx + 1];
+        // tb_base is only a hint (it decides which records may use the tuple path, never a result), so
+        // the order-free fast parser is enough: samples it is not sure about are skipped
+        GlobalSrc src{reinterpret_cast<const uint32_t*>(a.buf)};
+        bool ok = end >= pos;
+        if (ok && a.framed) {
+            uint32_t pl = 0;
+            ok = frame_fast(window64(src, pos), end - pos, pl);
+            pos += pl;
+        }
+        if (ok) {
+            // what proto.Marshal emits (mocker.go:97): [Type 08 xx] then TimeReceived 10 <varint> - one or two
+            // cache-resident windows instead of a walk over the whole record; anything else: the general parser
+            uint64_t w = window64(src, pos);
+            if ((w & 0x80ffu) == 0x0008u) {
+                pos += 2;
+                w = window64(src, pos);
+            }
+            uint32_t vl;
+            uint64_t val;
+            if ((w & 0xffu) == 0x10u && varint6(w >> 8, vl, val) && pos + 1 + vl <= end) {
+                atomicMin(&lo, time_bucket(a, (uint32_t)val));
+            } else {
+                Rec r;
+                rec_clear(r);
+                if (parse_fast<COL_TIME_RECEIVED>(src, pos, end, r)) atomicMin(&lo, time_bucket(a, (uint32_t)r.time_received));
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.ctr->tb_base = lo == 0xffffffffu ? 0u : (lo > 2u ? lo - 2u : 0u);
+        a.ctr->exotic_count = 0;  // the batch's deferral lists start empty (saves two memset dispatches per batch)
+        a.ctr->retry_count = 0;
+    }
+}
+
+// Records the tile kernel could not stage (broken offsets, tiles larger than the LDS buffer): complete
+// semantics, one record per lane straight from HBM.
+template <int MODE, uint32_t KEYSETS>
+__device__ __forceinline__ void exotic_pass(const KArgs& a) {
+    const uint32_t cnt = a.ctr->exotic_count;
+    for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < cnt; j += gridDim.x * BLOCK) {
+        uint32_t idx = a.exotic_idx[j];
+        const uint8_t* p = a.buf + a.off[idx];
+        const uint8_t* end = a.buf + a.off[idx + 1];
+        bool ok = end >= p;
+        if (ok && a.framed) ok = frame_generic(p, end);
+        Rec r;
+        if (ok)
+            ok = parse_generic(p, end, r);
+        if (!ok) rec_clear(r);
+        atomicAdd(&a.ctr->slow, 1ull);
+        if (MODE == MODE_DECODE) {
+            store_columns(a.cols, idx, r, ok ? 0 : 1);
+            continue;
+        }
+        if (!ok) {
+            atomicAdd(&a.ctr->bad, 1ull);
+            continue;
+        }
+        atomicAdd(&a.ctr->ok, 1ull);
+        const uint32_t tb = (uint32_t)r.time_received / a.gran;
+        if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
+            uint64_t k0, k1;
+            pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
+            agg_global(a, k0, k1, key_hash(k0, k1), r.bytes, r.packets, 1);
+        }
+        uint64_t w = r.bytes * r.sampling_rate;
+        if (ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS)) {
+            cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
+            keyset_insert(a, a.ks_src, r.src);
+        }
+        if (ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS)) {
+            cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
+            keyset_insert(a, a.ks_dst, r.dst);
+        }
+        if (KEYSETS & FA_KEYS_WIDE) wide_sink_slow<KEYSETS>(a, r, tb);
+    }
+}
+
+// ---- second chance: records parse_canon deferred ---------------------------------------------
+// One record per lane straight from HBM/L2 with the order-free fast parser; what it is not sure
+// about is decided in place by the complete parser.  Updates go to the device-wide table after a wave-level combine
+// (this tier is about staying exact and tolerable on producers that do not emit canonical order).
+template <int MODE, uint32_t KEYSETS>
+__global__ __launch_bounds__(BLOCK) void deferred_kernel(KArgs a) {
+    constexpr uint32_t COLS = MODE == MODE_DECODE ? (uint32_t)COL_ALL : cols_for_keysets<KEYSETS>();
+    exotic_pass<MODE, KEYSETS>(a);
+    const uint32_t cnt = a.ctr->retry_count;
+    const uint32_t rounds = (cnt + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
+    uint32_t n_ok = 0;
+    for (uint32_t it = 0; it < rounds; it++) {  // whole waves stay together (wave_combine below)
+        const uint32_t j = (it * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x;
+        bool sure = false;
+        Rec r;
+        rec_clear(r);
+        uint32_t idx = 0;
+        if (j < cnt) {
+            idx = a.retry_idx[j];
+            uint32_t pos = a.off[idx], end = a.off[idx + 1];
+            GlobalSrc src{reinterpret_cast<const uint32_t*>(a.buf)};
+            sure = end >= pos;
+            if (sure && a.framed) {
+                uint32_t pl = 0;
+                sure = frame_fast(window64(src, pos), end - pos, pl);
+                pos += pl;
+            }
+            if (sure) sure = parse_fast<COLS>(src, pos, end, r);
+            if (!sure) {  // third tier, in place: the complete parser decides
+                const uint8_t* p = a.buf + a.off[idx];
+                const uint8_t* pe = a.buf + a.off[idx + 1];
+                bool ok = pe >= p;
+                if (ok && a.framed) ok = frame_generic(p, pe);
+                if (ok) ok = parse_generic(p, pe, r);
+                if (!ok) rec_clear(r);
+                atomicAdd(&a.ctr->slow, 1ull);
+                if (MODE == MODE_DECODE) store_columns(a.cols, idx, r, ok ? 0 : 1);
+                else if (!ok) atomicAdd(&a.ctr->bad, 1ull);
+                sure = ok && MODE != MODE_DECODE;
+            }
+        }
+        if (MODE == MODE_DECODE) {
+            if (sure) store_columns(a.cols, idx, r, 0);
+            continue;
+        }
+        n_ok += sure ? 1 : 0;
+        const uint32_t tb = time_bucket(a, (uint32_t)r.time_received);
+        if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
+            uint64_t k0, k1;
+            pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
+            uint64_t b = r.bytes, p = r.packets, c = 1;
+            bool valid = sure;
+            wave_combine<16, 2>(valid, k0, k1, b, p, c);
+            if (valid) agg_global(a, k0, k1, key_hash(k0, k1), b, p, c);
+        }
+        if (sure && (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
+            const uint64_t w = r.bytes * r.sampling_rate;
+            if (ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS)) {
+                cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
+                keyset_insert(a, a.ks_src, r.src);
+            }
+            if (ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS)) {
+                cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
+                keyset_insert(a, a.ks_dst, r.dst);
+            }
+        }
+        if (sure && (KEYSETS & FA_KEYS_WIDE)) wide_sink_slow<KEYSETS>(a, r, tb);
+    }
+    if (MODE == MODE_INGEST) {
+        uint64_t tot = wave_sum_u64(n_ok);
+        if (__lane_id() == 0 && tot) {
+            atomicAdd(&a.ctr->ok, (unsigned long long)tot);
+            atomicAdd(&a.ctr->retried, (unsigned long long)tot);
+        }
+    }
+}
+
+}  // namespace fa

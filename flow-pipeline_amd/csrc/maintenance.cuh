@@ -1,0 +1,147 @@
+// maintenance.cuh - kernels off the hot path: window close (extract / rebuild), spill replay, row merges, wide-table
+// maintenance, top-k rows, synthetic producer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sinks.cuh"
+
+namespace fa {
+
+// ---- window close ---------------------------------------------------------------
+struct Row5m {
+    uint32_t date, timeslot, src_as, dst_as, etype, pad;
+    unsigned long long bytes, packets, count;
+};
+
+// Appends rows whose time bucket lies in [tb_lo, tb_hi) to `rows`.
+__global__ void extract_kernel(const Slot* tab, uint32_t nslots, uint32_t gran, uint32_t tb_lo,
+                               uint32_t tb_hi, Row5m* rows, uint32_t rows_cap, Counters* ctr) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) {
+        const Slot& s = tab[i];
+        if (s.k0 == 0 || s.k1 == 0 || s.count == 0) continue;
+        uint32_t tb, sa, da, et;
+        unpack_key(s.k0, s.k1, tb, sa, da, et);
+        if (tb < tb_lo || tb >= tb_hi) continue;
+        unsigned int j = atomicAdd(&ctr->rows_count, 1u);
+        if (j < rows_cap) {
+            uint32_t ts = tb * gran;
+            rows[j] = Row5m{ts / 86400u, ts, sa, da, et, 0, s.bytes, s.packets, s.count};
+        }
+    }
+}
+
+// Re-inserts every row outside [tb_lo, tb_hi) into a fresh table (window removal / growth).
+__global__ void rebuild_kernel(const Slot* old_tab, uint32_t old_slots, uint32_t tb_lo, uint32_t tb_hi,
+                               KArgs a) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < old_slots; i += gridDim.x * blockDim.x) {
+        const Slot& s = old_tab[i];
+        if (s.k0 == 0 || s.k1 == 0 || s.count == 0) continue;
+        uint32_t tb, sa, da, et;
+        unpack_key(s.k0, s.k1, tb, sa, da, et);
+        if (tb >= tb_lo && tb < tb_hi) continue;
+        agg_global(a, s.k0, s.k1, key_hash(s.k0, s.k1), s.bytes, s.packets, s.count);
+    }
+}
+
+__global__ void replay_spill_kernel(const SpillEntry* sp, uint32_t n, KArgs a) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        agg_global(a, sp[i].k0, sp[i].k1, key_hash(sp[i].k0, sp[i].k1), sp[i].bytes, sp[i].packets,
+                   sp[i].count);
+}
+
+// rows produced elsewhere (another GPU / Kafka partition) folded into this table
+__global__ void merge_rows_kernel(const Row5m* rows, uint32_t n, KArgs a) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint64_t k0, k1;
+        pack_key(rows[i].timeslot / a.gran, rows[i].src_as, rows[i].dst_as, rows[i].etype, k0, k1);
+        agg_global(a, k0, k1, key_hash(k0, k1), rows[i].bytes, rows[i].packets, rows[i].count);
+    }
+}
+
+// ---- wide table maintenance ---------------------------------------------------------------------
+struct WRow {
+    unsigned long long w[4], v0, v1, v2;
+};
+// which rows: kind_mask bit k selects kind k; WK_APP rows additionally need tb in [tb_lo, tb_hi)
+__device__ __forceinline__ bool wrow_selected(const unsigned long long w[4], uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi) {
+    uint32_t kind, tb, port, proto;
+    uint64_t lo, hi;
+    wkey_unpack(w, kind, tb, lo, hi, port, proto);
+    if (!((kind_mask >> kind) & 1u)) return false;
+    return kind != WK_APP || (tb >= tb_lo && tb < tb_hi);
+}
+__global__ void wextract_kernel(const WSlot* tab, uint32_t nslots, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, WRow* rows,
+                                uint32_t rows_cap, Counters* ctr) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) {
+        const WSlot& s = tab[i];
+        if (s.w[0] == 0 || s.w[1] == 0 || s.w[2] == 0 || s.w[3] == 0 || s.v2 == 0) continue;
+        if (!wrow_selected(s.w, kind_mask, tb_lo, tb_hi)) continue;
+        const unsigned int j = atomicAdd(&ctr->wrows_count, 1u);
+        if (j < rows_cap) rows[j] = WRow{{s.w[0], s.w[1], s.w[2], s.w[3]}, s.v0, s.v1, s.v2};
+    }
+}
+// Re-inserts every row that is NOT selected into a fresh table (window removal / reset / growth).
+__global__ void wrebuild_kernel(const WSlot* old_tab, uint32_t old_slots, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, KArgs a) {
+    const WArgs t = wargs(a);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < old_slots; i += gridDim.x * blockDim.x) {
+        const WSlot& s = old_tab[i];
+        if (s.w[0] == 0 || s.w[1] == 0 || s.w[2] == 0 || s.w[3] == 0 || s.v2 == 0) continue;
+        if (wrow_selected(s.w, kind_mask, tb_lo, tb_hi)) continue;
+        WKey k{{s.w[0], s.w[1], s.w[2], s.w[3]}};
+        wagg_global(t, k, s.v0, s.v1, s.v2);
+    }
+}
+// parked updates / rows produced elsewhere (another GPU / Kafka partition) folded into this table
+__global__ void wmerge_kernel(const WRow* rows, uint32_t n, KArgs a) {
+    const WArgs t = wargs(a);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        WKey k{{rows[i].w[0], rows[i].w[1], rows[i].w[2], rows[i].w[3]}};
+        wagg_global(t, k, rows[i].v0, rows[i].v1, rows[i].v2);
+    }
+}
+
+// ---- heavy hitters ---------------------------------------------------------------------------
+// One row per stored key: its Count-Min estimate = min over the sketch rows (>= the exact
+// sum(Bytes*SamplingRate), viz-ch.json:233).  The host sorts, removes duplicate keys and cuts at k.
+__global__ void topk_rows_kernel(const KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth,
+                                 uint32_t wl2, uint64_t seed, TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) {
+        if ((ks[i].tag & KS_READY) == 0) continue;
+        const unsigned long long lo = ks[i].lo, hi = ks[i].hi;
+        unsigned long long best = ~0ull;
+        for (uint32_t r = 0; r < depth; r++) {
+            const unsigned long long v = cms[((size_t)r << wl2) + (size_t)(cms_hash(lo, hi, seed, r) >> (64 - wl2))];
+            best = v < best ? v : best;
+        }
+        const unsigned int j = atomicAdd(&ctr->ks_rows, 1u);
+        if (j < rows_cap) rows[j] = TopkRow{lo, hi, best};
+    }
+}
+
+// keys found by other GPUs / Kafka partitions join this context's candidate set (window close)
+__global__ void keyset_merge_kernel(const uint4* keys, uint32_t n, KeySlot* tab, KArgs a) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t k[4] = {keys[i].x, keys[i].y, keys[i].z, keys[i].w};
+        keyset_insert(a, tab, k);
+    }
+}
+
+// ---- synthetic producer ------------------------------------------------------------
+__global__ void gen_len_kernel(fa_mock_params g, uint64_t i0, uint32_t n, uint32_t* len) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t tmp[208];
+    len[i] = gen_encode(g, i0 + i, tmp);
+}
+__global__ void gen_write_kernel(fa_mock_params g, uint64_t i0, uint32_t n, const uint32_t* off,
+                                 uint8_t* out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t tmp[208];
+    uint32_t l = gen_encode(g, i0 + i, tmp);
+    uint8_t* p = out + off[i];
+    for (uint32_t k = 0; k < l; k++) p[k] = tmp[k];
+}
+
+}  // namespace fa

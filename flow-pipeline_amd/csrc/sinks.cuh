@@ -1,0 +1,576 @@
+// sinks.cuh - shared state of the gfx950 kernels (constants, counters, kernel arguments) and the sinks a decoded
+// record can go to: device-wide group-by table (quad-grouped atomics), Count-Min sketch copies, distinct-address
+// set, SoA columns, wide-key table, port histograms.  See kernels.cuh for the map of the hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gen.cuh"
+#include "table.cuh"
+#include "wide.cuh"
+#include "wire.cuh"
+
+namespace fa {
+
+constexpr int BLOCK = 256;
+constexpr int TILE_BYTES = 21760;  // one LDS tile buffer: 256 records x 85 B (framed mocker records are <= 85)
+constexpr int TILE_PAD = 112;      // readable slack behind the staged bytes (window / address reads)
+constexpr int TILE_STRIDE = TILE_BYTES + TILE_PAD;
+constexpr int LDS_SLOTS = 64;      // per-workgroup hot-key slots (2.5 KiB)
+constexpr int LDS_PROBES = 2;
+constexpr int PART_LOG2_MAX = 8;   // key partitions of the scatter sink (<= 256: see tools/scatter_bench.hip)
+constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
+constexpr int WBLOCK = 512;         // wave-tile kernel: 8 waves, each with a private LDS tile of <= 64 records
+constexpr int WT_RECS = 64;
+constexpr int WT_STRIDE = 5472;     // 64 records x 85 B + alignment slack (16-byte multiple); overreads land in the next tile / the bins
+constexpr uint32_t BIN_CAP = 8;     // a bin = one 128-byte line of tuples per key partition (256 x 8 x 16 B = 32 KiB per workgroup)
+constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table
+#ifndef FA_AGG_SLOTS
+#define FA_AGG_SLOTS 4096
+#endif
+#ifndef FA_AGG_SPLIT
+#define FA_AGG_SPLIT 1
+#endif
+constexpr int AGG_SLOTS = FA_AGG_SLOTS;  // 32 B of LDS per slot (4096: 128 KiB)
+constexpr int AGG_SPLIT = FA_AGG_SPLIT;  // workgroups per key partition (each with its own LDS table)
+constexpr int AGG_PROBES = 16;
+constexpr uint32_t TUPLE_TB_SPAN = 16;        // time buckets a batch may span on the tuple path
+constexpr uint32_t TUPLE_MAX_BYTES = 1u << 28, TUPLE_MAX_PACKETS = 1u << 15, TUPLE_MAX_ETYPE = 1u << 16;
+constexpr uint32_t AGG_MAX_BATCH = 1u << 24;  // count <= 2^24 per slot keeps the packed LDS sums exact
+static_assert(TILE_STRIDE % 16 == 0, "LDS tile buffers must stay 16-byte aligned");
+
+enum { MODE_INGEST = 0, MODE_DECODE = 1 };
+// Kernel variants are compiled for the key-set masks 1..7 (rollup and/or sketches); every other
+// combination runs the KS_ALL variant, which parses the union of the columns and tests the runtime mask.
+constexpr uint32_t KS_ALL = 0xFFu;
+constexpr uint32_t FA_KEYS_WIDE = FA_KEYS_ADDR_PORT_PROTO | FA_KEYS_PORT_HIST | FA_KEYS_MINUTE_SERIES;
+constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense histograms
+// ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
+enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_FRAME = 131072 };
+
+struct SpillEntry {
+    unsigned long long k0, k1, bytes, packets, count;
+};
+
+struct Counters {
+    unsigned long long ok, bad, slow, spill_lost, used, direct, retried;
+    unsigned int exotic_count, spill_count, rows_count, retry_count, tb_base, ks_overflow, ks_rows, pad;
+    unsigned long long t_wait, t_work, t_tiles, t_total;  // DBG_TIMING: core-clock cycles of wave 0 of every workgroup
+    unsigned long long wused, wspill_lost;  // wide table (wide.cuh)
+    unsigned int wspill_count, wrows_count;
+};
+
+// Distinct-address set behind fa_topk (the dashboards rank EVERY address,
+// viz-ch.json:233,479).  32-byte slots; tag = 0 (empty) | bit 63 (claimed) | bit 62 (key written) |
+// 62 hash bits of the key.
+struct __attribute__((aligned(32))) KeySlot {
+    unsigned long long tag, lo, hi, pad;
+};
+constexpr unsigned long long KS_CLAIMED = 1ull << 63, KS_READY = 1ull << 62;
+struct TopkRow {
+    unsigned long long lo, hi, weight;
+};
+
+struct ColumnPtrs {
+    uint64_t *time_received, *time_flow_start, *sampling_rate, *bytes, *packets;
+    uint32_t *sequence_num, *src_as, *dst_as, *etype, *proto, *src_port, *dst_port;
+    uint4 *sampler_address, *src_addr, *dst_addr;
+    uint8_t* status;
+};
+
+struct KArgs {
+    const uint8_t* buf;   // 16-byte aligned device pointer
+    const uint32_t* off;  // n+1 offsets
+    uint32_t n;
+    uint32_t framed;
+    uint32_t gran;
+    Slot* tab;
+    uint32_t mask;
+    SpillEntry* spill;
+    uint32_t spill_cap;
+    Counters* ctr;
+    uint32_t* exotic_idx;
+    unsigned long long* cms_src;
+    unsigned long long* cms_dst;
+    uint32_t cms_depth, cms_wl2;
+    uint64_t cms_seed;
+    KeySlot* ks_src;  // distinct SrcAddr / DstAddr values seen (nullptr when the key set is off)
+    KeySlot* ks_dst;
+    uint32_t ks_mask;
+    ColumnPtrs cols;
+    uint32_t tile_recs;  // records per tile (<= BLOCK), chosen by the host from the mean record size
+    uint32_t dbg;  // FA_DEBUG_FLAGS ablation switches (0 in production)
+    uint32_t* retry_idx;   // records parse_canon deferred
+    double gran_recip;     // (1/gran)(1+2^-40): floor(t * gran_recip) == t / gran for every u32 t
+    // scatter sink (seg == nullptr: every record takes the direct device-wide-table path)
+    uint4* seg;            // [NPART][region] tuples; partition p, workgroup w: seg[p*region + w*capq + q]
+    uint32_t* seg_counts;  // [2][NPART][nwg]: tuples at the front of a segment, tuples at its back (wave-tile kernel only)
+    uint32_t capq;         // tuples per (partition, workgroup) segment (multiple of 8 = 128-byte lines)
+    uint32_t capf, capb;   // wave-tile kernel: front part (full lines, grows up from 0) and back part (single tuples, grows down from capq-1)
+    uint32_t nwg;          // workgroups of the tile kernel that filled the segments
+    unsigned long long region;  // tuples per partition (nwg*capq plus a skew against power-of-two strides)
+    uint32_t plog2;        // log2(key partitions)
+    // wide key sets (wide.cuh)
+    uint32_t key_sets;     // runtime mask (the KS_ALL kernel variant tests it)
+    WSlot* wtab;
+    uint32_t wmask;
+    WSpillEntry* wspill;
+    uint32_t wspill_cap;
+    ulonglong2* port_hist;  // [2][PORT_DENSE] {sum(Bytes*SamplingRate), count()}: SrcPort, then DstPort
+};
+
+__device__ __forceinline__ WArgs wargs(const KArgs& a) {
+    return WArgs{a.wtab, a.wmask, a.wspill, a.wspill_cap, &a.ctr->wspill_count, &a.ctr->wspill_lost, &a.ctr->wused};
+}
+// does this kernel variant serve key set X for this launch?
+template <uint32_t KEYSETS>
+__device__ __forceinline__ bool ks_on(const KArgs& a, uint32_t x) {
+    return (KEYSETS & x) != 0 && (KEYSETS != KS_ALL || (a.key_sets & x) != 0);
+}
+
+// ---- sinks ------------------------------------------------------------------
+__device__ __forceinline__ void agg_global(const KArgs& a, uint64_t k0, uint64_t k1, uint32_t h,
+                                           uint64_t b, uint64_t p, uint64_t c) {
+    uint32_t i = h & a.mask;
+    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i + 1) & a.mask) {
+        Slot* s = &a.tab[i];
+        unsigned long long c0 = s->k0;
+        if (c0 == 0) c0 = atomicCAS(&s->k0, 0ull, (unsigned long long)k0);
+        if (c0 != 0 && c0 != k0) continue;
+        unsigned long long c1 = s->k1;
+        if (c1 == 0) {
+            c1 = atomicCAS(&s->k1, 0ull, (unsigned long long)k1);
+            if (c1 == 0) atomicAdd(&a.ctr->used, 1ull);  // this lane created the group
+        }
+        if (c1 != 0 && c1 != k1) continue;
+        if (b) atomicAdd(&s->bytes, (unsigned long long)b);
+        if (p) atomicAdd(&s->packets, (unsigned long long)p);
+        atomicAdd(&s->count, (unsigned long long)c);
+        return;
+    }
+    // probe limit: park the partial aggregate; the host grows the table and replays it
+    unsigned int j = atomicAdd(&a.ctr->spill_count, 1u);
+    if (j < a.spill_cap) {
+        a.spill[j] = SpillEntry{k0, k1, b, p, c};
+    } else {
+        atomicAdd(&a.ctr->spill_lost, 1ull);
+    }
+}
+
+__device__ __forceinline__ uint64_t cms_hash(uint64_t lo, uint64_t hi, uint64_t seed, uint32_t row) {
+    uint64_t h = mix64(lo ^ mix64(seed + 0x9E3779B97F4A7C15ull * (row + 1)));
+    return mix64(h ^ hi);
+}
+// The sketch is kept in CMS_REPLICAS copies; a workgroup adds to copy blockIdx % CMS_REPLICAS and the copies
+// are summed into copy 0 before anything reads the sketch (cms_fold_kernel).  Counters of heavy hitters are
+// hit by every wave of the chip, and same-address atomics serialize at the memory side (~10 ns each:
+// 1.9 M updates of the top Zipf-1.1 key per launch cost ~19 ms on one copy); u64 sums commute, so the folded
+// sketch is bit-identical to a single-copy one.
+constexpr uint32_t CMS_REPLICAS = 8;
+__device__ __forceinline__ void cms_add(unsigned long long* cms, uint32_t depth, uint32_t wl2,
+                                        uint64_t seed, const uint32_t key[4], uint64_t w) {
+    if (w == 0) return;
+    uint64_t lo = (uint64_t)key[1] << 32 | key[0], hi = (uint64_t)key[3] << 32 | key[2];
+    unsigned long long* copy = cms + (size_t)(blockIdx.x % CMS_REPLICAS) * ((size_t)depth << wl2);
+    for (uint32_t r = 0; r < depth; r++) {
+        uint64_t h = cms_hash(lo, hi, seed, r);
+        atomicAdd(&copy[((size_t)r << wl2) + (size_t)(h >> (64 - wl2))], (unsigned long long)w);
+    }
+}
+__global__ void cms_fold_kernel(unsigned long long* cms, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long sum = 0;
+        for (uint32_t r = 1; r < CMS_REPLICAS; r++) {
+            const unsigned long long v = cms[r * words + i];
+            if (v) {
+                sum += v;
+                cms[r * words + i] = 0;
+            }
+        }
+        if (sum) cms[i] += sum;
+    }
+}
+
+// Folds the lanes of a wave that carry the same 16-byte key: the first lane to claim the key's slot in a
+// 64-entry LDS table keeps the key and receives the weights of the others (valid = false for those).  One
+// round whatever the key distribution (wave_combine gives up on skewed mixes of hot and cold keys); lanes that
+// lose the slot to a DIFFERENT key just stay on their own.  scratch: 768 bytes of wave-private LDS.
+__device__ __forceinline__ void wave_fold_lds(uint32_t* scratch, bool& valid, uint64_t lo, uint64_t hi, uint64_t& w) {
+    uint32_t* owner = scratch;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(scratch + 64);
+    const uint32_t ln = __lane_id();
+    owner[ln] = 0xffffffffu;
+    acc[ln] = 0;
+    uint32_t h = (uint32_t)lo * 0x9E3779B1u ^ (uint32_t)(lo >> 32) * 0x85EBCA6Bu ^ (uint32_t)hi * 0xC2B2AE35u ^ (uint32_t)(hi >> 32) * 0x27D4EB2Fu;
+    h ^= h >> 15;
+    const uint32_t slot = (h * 0x2545F491u) >> 26;
+    uint32_t win = ln;
+    if (valid) {
+        const uint32_t prev = atomicCAS(&owner[slot], 0xffffffffu, ln);
+        win = prev == 0xffffffffu ? ln : prev;
+    }
+    const uint64_t wlo = (uint64_t)(uint32_t)__shfl((int)(uint32_t)(lo >> 32), (int)win) << 32 | (uint32_t)__shfl((int)(uint32_t)lo, (int)win);
+    const uint64_t whi = (uint64_t)(uint32_t)__shfl((int)(uint32_t)(hi >> 32), (int)win) << 32 | (uint32_t)__shfl((int)(uint32_t)hi, (int)win);
+    const bool same = valid && win != ln && wlo == lo && whi == hi;
+    if (same) {
+        if (w) atomicAdd(&acc[slot], (unsigned long long)w);
+        valid = false;
+    }
+    if (valid && win == ln) w += acc[slot];  // (behind the adds: LDS operations of a wave complete in order)
+}
+
+// Inserts a FixedString(16) key into the distinct-key set.  The per-XCD L2s are not coherent, so a plain
+// load may show an OLD version of a slot - harmless for the fast path (a slot never changes once its
+// key is written, so a complete match is always true), but everything else must come from the memory
+// side: the slot is claimed by CAS on its tag (hash of the key), the key words are written with
+// returning atomics, then the READY bit is set; a lane that needs to compare against a slot owned by
+// an equal tag reads the key words with atomics as well.  A lane that meets an equal tag whose key is
+// not written yet cannot compare and moves on, so a key may (rarely) be stored twice - fa_topk removes
+// duplicates.  The set is exact in content: a key is dropped only when the table is full, and that is
+// reported (ks_overflow -> FA_ERR_TABLE_FULL).
+__device__ __forceinline__ void keyset_insert(const KArgs& a, KeySlot* tab, const uint32_t key[4]) {
+    const unsigned long long lo = (unsigned long long)key[1] << 32 | key[0], hi = (unsigned long long)key[3] << 32 | key[2];
+    uint32_t h = key[0] * 0x9E3779B1u + key[1];
+    h ^= h >> 15;
+    h = (h ^ key[2]) * 0x85EBCA6Bu + key[3];
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    uint32_t g = (key[3] ^ 0x27D4EB2Fu) * 0x165667B1u + key[2];
+    g ^= g >> 15;
+    g = (g ^ key[1]) * 0xD3A2646Du + key[0];
+    g ^= g >> 14;
+    const unsigned long long mytag = KS_CLAIMED | (((unsigned long long)g << 32 | h) & (KS_READY - 1));
+    uint32_t i = h & a.ks_mask;
+    for (int probe = 0; probe < 256; probe++, i = (i + 1) & a.ks_mask) {
+        KeySlot* s = &tab[i];
+        // fastest path: the key is already there and this XCD's L2 knows it.  Plain (cached) loads may be stale,
+        // but a slot never changes once READY, so a complete match is always true; anything else is looked at
+        // again through the memory side below.
+        {
+            const ulonglong2 c01 = *reinterpret_cast<const ulonglong2*>(&s->tag);  // tag, lo
+            if (c01.x == (mytag | KS_READY) && c01.y == lo && s->hi == hi) return;
+        }
+        // the key may be there: system-scope loads are served by the memory side, past the (incoherent) per-XCD
+        // L2s
+        unsigned long long t = __hip_atomic_load(&s->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (t == (mytag | KS_READY)) {
+            const unsigned long long l = __hip_atomic_load(&s->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long q = __hip_atomic_load(&s->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (l == lo && q == hi) return;
+            continue;  // equal tag, different key
+        }
+        if (t != 0 && t != mytag) continue;  // somebody else's slot
+        bool done = false;
+        if (t == 0) {
+            t = atomicCAS(&s->tag, 0ull, mytag);
+            if (t == 0) {  // claimed: publish the key, then mark it readable
+                const unsigned long long o1 = atomicExch(&s->lo, lo), o2 = atomicExch(&s->hi, hi);
+                if ((o1 & o2) != ~0ull) atomicOr(&s->tag, KS_READY);  // (always true: orders the OR behind both writes)
+                done = true;
+            }
+        }
+        // (claimers of this wave have published by now; owners in other waves are a few instructions away)
+        if (!done && (t | KS_READY) == (mytag | KS_READY)) {
+            for (int spin = 0; spin < 4096 && !(t & KS_READY); spin++) t = atomicOr(&s->tag, 0ull);
+            if (t & KS_READY) {
+                const unsigned long long l = atomicAdd(&s->lo, 0ull), q = atomicAdd(&s->hi, 0ull);  // memory-side reads
+                done = l == lo && q == hi;
+            }
+        }
+        if (done) return;
+    }
+    atomicAdd(&a.ctr->ks_overflow, 1u);
+}
+
+__device__ __forceinline__ void store_columns(const ColumnPtrs& c, uint32_t idx, const Rec& r,
+                                              uint8_t status) {
+    c.time_received[idx] = r.time_received;
+    c.time_flow_start[idx] = r.time_flow_start;
+    c.sampling_rate[idx] = r.sampling_rate;
+    c.bytes[idx] = r.bytes;
+    c.packets[idx] = r.packets;
+    c.sequence_num[idx] = r.sequence_num;
+    c.src_as[idx] = r.src_as;
+    c.dst_as[idx] = r.dst_as;
+    c.etype[idx] = r.etype;
+    c.proto[idx] = r.proto;
+    c.src_port[idx] = r.src_port;
+    c.dst_port[idx] = r.dst_port;
+    c.sampler_address[idx] = make_uint4(r.sampler[0], r.sampler[1], r.sampler[2], r.sampler[3]);
+    c.src_addr[idx] = make_uint4(r.src[0], r.src[1], r.src[2], r.src[3]);
+    c.dst_addr[idx] = make_uint4(r.dst[0], r.dst[1], r.dst[2], r.dst[3]);
+    c.status[idx] = status;
+}
+
+template <uint32_t KEYSETS>
+constexpr uint32_t cols_for_keysets() {
+    uint32_t c = 0;
+    if (KEYSETS & FA_KEYS_AS_PAIR) c |= COLS_AS_ROLLUP;
+    if (KEYSETS & FA_KEYS_SRCADDR_CMS) c |= COL_SRC_ADDR | COL_BYTES | COL_SAMPLING_RATE;
+    if (KEYSETS & FA_KEYS_DSTADDR_CMS) c |= COL_DST_ADDR | COL_BYTES | COL_SAMPLING_RATE;
+    if (KEYSETS & FA_KEYS_ADDR_PORT_PROTO) c |= COL_TIME_RECEIVED | COL_SRC_ADDR | COL_DST_PORT | COL_PROTO | COL_BYTES | COL_PACKETS;
+    if (KEYSETS & FA_KEYS_PORT_HIST) c |= COL_SRC_PORT | COL_DST_PORT | COL_BYTES | COL_SAMPLING_RATE;
+    if (KEYSETS & FA_KEYS_MINUTE_SERIES) c |= COL_TIME_FLOW_START | COL_BYTES | COL_SAMPLING_RATE;
+    return c;
+}
+
+// ---- LDS DMA staging ------------------------------------------------------------
+// Copies nbytes (rounded up to 16) from 16-byte-aligned global memory into an LDS
+// buffer with `global_load_lds_dwordx4`: 1 KiB per wave-instruction, no VGPR round
+// trip, asynchronous (tracked by vmcnt).  Lanes past the end are masked off.
+template <int AUX = 0>
+__device__ __forceinline__ void dma_to_lds(const uint8_t* g, uint32_t nbytes, uint32_t* lds) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t npieces = (nbytes + 1023u) >> 10;
+    for (uint32_t p = wave; p < npieces; p += BLOCK / 64) {
+        const uint32_t o = p * 1024u + lane * 16u;
+        if (o < nbytes) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(g + o),
+                (__attribute__((address_space(3))) void*)(lds + p * 256u), 16, 0, AUX);
+        }
+    }
+}
+// vmcnt(0) through the builtin (not inline asm) so that the compiler's own waitcnt
+// scoreboard learns the DMA has landed and does not re-drain before LDS reads.
+__device__ __forceinline__ void dma_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+// ---- device-wide table probe ------------------------------------------------------
+// Finds or claims the slot of (k0,k1); returns nullptr when the probe limit is hit.
+__device__ __forceinline__ Slot* table_find_or_claim(const KArgs& a, uint64_t k0, uint64_t k1, uint32_t h) {
+    uint32_t i = h & a.mask;
+    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i + 1) & a.mask) {
+        Slot* s = &a.tab[i];
+        const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(s);  // one 16-byte load: k0,k1
+        unsigned long long c0 = kk.x, c1 = kk.y;
+        if (c0 == k0 && c1 == k1) return s;  // common case: no atomics on the key words
+        if (c0 == 0) c0 = atomicCAS(&s->k0, 0ull, (unsigned long long)k0);
+        if (c0 != 0 && c0 != k0) continue;
+        if (c1 == 0) {
+            c1 = atomicCAS(&s->k1, 0ull, (unsigned long long)k1);
+            if (c1 == 0) atomicAdd(&a.ctr->used, 1ull);  // this lane created the group
+        }
+        if (c1 != 0 && c1 != k1) continue;
+        return s;
+    }
+    return nullptr;
+}
+
+// Broadcast lane Q of every quad to the 4 lanes of that quad (DPP quad_perm, VALU only).
+template <int Q>
+__device__ __forceinline__ uint64_t quad_bcast_u64(uint64_t v) {
+    constexpr int CTRL = Q | (Q << 2) | (Q << 4) | (Q << 6);
+    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+    return (uint64_t)hi << 32 | lo;
+}
+
+// Quad-grouped atomics.  The memory side retires ~23.7 G atomic cache-line
+// transactions/s no matter how many lanes of one instruction hit the line
+// (tools/atomics_bench.hip), so the three sums of a slot are issued by three
+// adjacent lanes of ONE instruction: in round Q every quad works on the record of
+// its lane Q; lane w of the quad adds word w (bytes, packets, count).  One
+// transaction per record instead of three.  Must be called by the full wave.
+template <int Q, int VOFF>
+__device__ __forceinline__ void quad_round(uint64_t ptr, uint64_t b, uint64_t p, uint64_t c, uint32_t w) {
+    const uint64_t qp = quad_bcast_u64<Q>(ptr);
+    const uint64_t qb = quad_bcast_u64<Q>(b), qq = quad_bcast_u64<Q>(p), qc = quad_bcast_u64<Q>(c);
+    const uint64_t v = w == 0 ? qb : w == 1 ? qq : qc;
+    if (qp != 0 && w < 3 && v != 0)
+        atomicAdd(reinterpret_cast<unsigned long long*>(qp) + VOFF + w, (unsigned long long)v);
+}
+// slot = base pointer of a 64-byte slot whose three sums start at word VOFF (2: Slot, 4: WSlot); 0 = nothing to do
+template <int VOFF>
+__device__ __forceinline__ void quad_atomic_update_at(uint64_t ptr, uint64_t b, uint64_t p, uint64_t c) {
+    const uint32_t w = threadIdx.x & 3;
+    quad_round<0, VOFF>(ptr, b, p, c, w);
+    quad_round<1, VOFF>(ptr, b, p, c, w);
+    quad_round<2, VOFF>(ptr, b, p, c, w);
+    quad_round<3, VOFF>(ptr, b, p, c, w);
+}
+__device__ __forceinline__ void quad_atomic_update(Slot* sp, uint64_t b, uint64_t p, uint64_t c) {
+    quad_atomic_update_at<2>((uint64_t)sp, b, p, c);
+}
+
+// Dense port histograms, quad-grouped: in round Q the quad works on its lane Q's record; lanes 0,1 add
+// {weight, 1} to the SrcPort entry and lanes 2,3 to the DstPort entry (two 16-byte entries = two atomic
+// line transactions per record instead of four).  0 = no entry for that direction.  Full wave.
+template <int Q>
+__device__ __forceinline__ void port_round(uint64_t ps, uint64_t pd, uint64_t wgt, uint32_t w) {
+    const uint64_t qs = quad_bcast_u64<Q>(ps), qd = quad_bcast_u64<Q>(pd), qw = quad_bcast_u64<Q>(wgt);
+    const uint64_t base = w < 2 ? qs : qd;
+    const uint64_t v = (w & 1) ? 1ull : qw;
+    if (base != 0 && v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(base) + (w & 1), (unsigned long long)v);
+}
+__device__ __forceinline__ void port_hist_update(uint64_t ps, uint64_t pd, uint64_t wgt) {
+    const uint32_t w = threadIdx.x & 3;
+    port_round<0>(ps, pd, wgt, w);
+    port_round<1>(ps, pd, wgt, w);
+    port_round<2>(ps, pd, wgt, w);
+    port_round<3>(ps, pd, wgt, w);
+}
+
+// ---- wide key sets ----------------------------------------------------------------------------------
+__device__ __forceinline__ void app_key(const KArgs& a, const Rec& r, uint32_t tb, WKey& k) {
+    wkey_pack(WK_APP, tb, (uint64_t)r.src[1] << 32 | r.src[0], (uint64_t)r.src[3] << 32 | r.src[2], r.dst_port, r.proto, k);
+}
+__device__ __forceinline__ uint32_t minute_of(const Rec& r) {
+    return (uint32_t)r.time_flow_start / 60u;  // UInt64 -> DateTime (create.sh:40), toStartOfMinute (viz-ch.json:74)
+}
+
+// Per-lane form (deferred records, no wave cooperation): every wide key set through plain atomics.
+template <uint32_t KEYSETS>
+__device__ __forceinline__ void wide_sink_slow(const KArgs& a, const Rec& r, uint32_t tb) {
+    const WArgs t = wargs(a);
+    const uint64_t wgt = r.bytes * r.sampling_rate;  // viz-ch.json:74,358,604 sum(Bytes*SamplingRate), UInt64 wrap
+    if (ks_on<KEYSETS>(a, FA_KEYS_ADDR_PORT_PROTO)) {
+        WKey k;
+        app_key(a, r, tb, k);
+        wagg_global(t, k, r.bytes, r.packets, 1);
+    }
+    if (ks_on<KEYSETS>(a, FA_KEYS_PORT_HIST)) {
+        for (int d = 0; d < 2; d++) {
+            const uint32_t port = d ? r.dst_port : r.src_port;
+            if (port < PORT_DENSE) {
+                unsigned long long* e = reinterpret_cast<unsigned long long*>(&a.port_hist[(size_t)d * PORT_DENSE + port]);
+                if (wgt) atomicAdd(e, (unsigned long long)wgt);
+                atomicAdd(e + 1, 1ull);
+            } else {
+                WKey k;
+                wkey_pack(d ? WK_DSTPORT : WK_SRCPORT, 0, 0, 0, port, 0, k);
+                wagg_global(t, k, wgt, 0, 1);
+            }
+        }
+    }
+    if (ks_on<KEYSETS>(a, FA_KEYS_MINUTE_SERIES)) {
+        WKey k;
+        wkey_pack(WK_MINUTE, 0, 0, 0, minute_of(r), 0, k);
+        wagg_global(t, k, wgt, 0, 1);
+    }
+}
+
+// Full-wave form (tile kernel): one atomic line transaction per record and key set.
+template <uint32_t KEYSETS>
+__device__ __forceinline__ void wide_sink_wave(const KArgs& a, LdsMinutes& lm, const Rec& r, bool sure, uint32_t tb) {
+    const WArgs t = wargs(a);
+    const uint64_t wgt = r.bytes * r.sampling_rate;
+    if (ks_on<KEYSETS>(a, FA_KEYS_ADDR_PORT_PROTO)) {
+        WSlot* sp = nullptr;
+        if (sure) {
+            WKey k;
+            app_key(a, r, tb, k);
+            sp = wtable_find_or_claim(t, k, wkey_hash(k));
+            if (!sp) wspill_park(t, k, r.bytes, r.packets, 1);
+        }
+        quad_atomic_update_at<4>((uint64_t)sp, r.bytes, r.packets, 1);
+    }
+    if (ks_on<KEYSETS>(a, FA_KEYS_PORT_HIST)) {
+        uint64_t ps = 0, pd = 0;
+        if (sure) {
+            if (r.src_port < PORT_DENSE) {
+                ps = (uint64_t)&a.port_hist[r.src_port];
+            } else {
+                WKey k;
+                wkey_pack(WK_SRCPORT, 0, 0, 0, r.src_port, 0, k);
+                wagg_global(t, k, wgt, 0, 1);
+            }
+            if (r.dst_port < PORT_DENSE) {
+                pd = (uint64_t)&a.port_hist[(size_t)PORT_DENSE + r.dst_port];
+            } else {
+                WKey k;
+                wkey_pack(WK_DSTPORT, 0, 0, 0, r.dst_port, 0, k);
+                wagg_global(t, k, wgt, 0, 1);
+            }
+        }
+        port_hist_update(ps, pd, wgt);
+    }
+    if (ks_on<KEYSETS>(a, FA_KEYS_MINUTE_SERIES)) {
+        // lanes of a wave almost always share one or two minutes: fold them, then one LDS update per group
+        const uint32_t minute = minute_of(r);
+        uint64_t w0 = wgt, z = 0, c = 1;
+        bool valid = sure;
+        wave_combine<4, 2>(valid, (uint64_t)minute, 1ull, w0, z, c);
+        if (valid && !lds_minutes_add(lm, minute, w0, c)) {
+            WKey k;
+            wkey_pack(WK_MINUTE, 0, 0, 0, minute, 0, k);
+            wagg_global(t, k, w0, 0, c);
+        }
+    }
+}
+
+__device__ __forceinline__ void spill_park(const KArgs& a, uint64_t k0, uint64_t k1, uint64_t b, uint64_t p, uint64_t c) {
+    unsigned int j = atomicAdd(&a.ctr->spill_count, 1u);
+    if (j < a.spill_cap)
+        a.spill[j] = SpillEntry{k0, k1, b, p, c};
+    else
+        atomicAdd(&a.ctr->spill_lost, 1ull);
+}
+
+// t / gran for a runtime granule without an integer division (see KArgs::gran_recip)
+__device__ __forceinline__ uint32_t time_bucket(const KArgs& a, uint32_t t32) {
+    return (uint32_t)((double)t32 * a.gran_recip);
+}
+
+// varint(len) frame prefix of 1 or 2 bytes (records < 16 KiB) straight from the first window
+__device__ __forceinline__ bool frame_short(uint32_t x, uint32_t rec_len, uint32_t& prefix_len) {
+    const uint32_t b0 = x & 0xffu, b1 = (x >> 8) & 0xffu;
+    const bool one = b0 < 0x80u;
+    const uint32_t val = one ? b0 : ((b0 & 0x7fu) | (b1 << 7));
+    prefix_len = one ? 1u : 2u;
+    return (one || b1 < 0x80u) && rec_len >= prefix_len && val == rec_len - prefix_len;
+}
+
+// Full bins leave as whole, aligned 128-byte lines, up to 8 bins per pass: lane group g (8 lanes) takes the
+// g-th filled bin, each lane copies one tuple - one store instruction writes 8 complete lines, no partial
+// lines and no workgroup barrier.  The producers of a bin's other slots may sit in other waves: the high
+// half of the bin word counts the slots WRITTEN, and nobody can take a slot of a full bin, so the spin
+// below only ever waits for straight-line code of waves that never wait for us (producers of this wave
+// finished in lockstep inside lane_work).  fill_part: the bin this lane filled (or ~0); scratch: 32 bytes of
+// wave-private LDS.  Must be called by the full wave.
+__device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t* bin_cnt, uint32_t* part_cnt, uint32_t* scratch,
+                                           uint32_t fill_part, uint32_t tb_base, uint32_t& n_direct) {
+    const unsigned long long fm = __builtin_amdgcn_ballot_w64(fill_part != 0xffffffffu);
+    if (fm == 0ull) return;
+    const uint32_t ln = __lane_id(), g = ln >> 3, sub = ln & 7u;
+    const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << ln) - 1ull));
+    const uint32_t todo = (uint32_t)__builtin_popcountll(fm);
+    for (uint32_t base = 0; base < todo; base += 8u) {
+        if (fill_part != 0xffffffffu && rank - base < 8u) scratch[rank - base] = fill_part;
+        const bool act = g < min(8u, todo - base);
+        const uint32_t fp = act ? scratch[g] : 0u;
+        // the written-slot check, the tuple read and the line allocation are issued back to back (LDS operations
+        // of a wave complete in order, so the read sees what the check saw); only a bin that is still being
+        // written costs further round trips
+        // (acquire / release pair with the producers' written-slot count: without it the COMPILER may move the
+        // tuple read above the check - it did, and rows differed from the oracle at 16 M records)
+        const uint32_t c0 = __hip_atomic_load(&bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint4 tq = bins[fp * BIN_CAP + sub];
+        uint32_t line = 0;
+        if (act && sub == 0) line = atomicAdd(&part_cnt[fp], 1u) & 0xffffu;  // low half: lines at the front
+        bool late = false;
+        if (__builtin_amdgcn_ballot_w64(act && (c0 >> 16) < BIN_CAP) != 0ull) {
+            late = true;
+            while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < BIN_CAP) != 0ull) {}
+        }
+        line = (uint32_t)__shfl((int)line, (int)(ln & ~7u));
+        if (act) {
+            const uint4 tv = late ? bins[fp * BIN_CAP + sub] : tq;
+            if ((line + 1u) * BIN_CAP <= a.capf) {
+                if (!(a.dbg & DBG_NO_TUPLE_STORE))
+                    a.seg[(size_t)fp * a.region + (size_t)blockIdx.x * a.capq + line * BIN_CAP + sub] = tv;
+            } else {  // front part full (skewed batch): straight to the device-wide table
+                const uint32_t qby = tv.z & 0x0fffffffu, qtbr = tv.z >> 28, qpk = tv.w & 0x7fffu, qet = tv.w >> 15;
+                uint64_t q0, q1;
+                pack_key(tb_base + qtbr, tv.x, tv.y, qet, q0, q1);
+                agg_global(a, q0, q1, key_hash(q0, q1), qby, qpk, 1);
+                n_direct++;
+            }
+            // (release: behind the tuple reads above)
+            if (sub == 0) __hip_atomic_store(&bin_cnt[fp], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+}  // namespace fa

@@ -31,7 +31,7 @@ def test_parsers_fuzz_against_oracle(po):
 
 
 def test_time_bucket_reciprocal_is_exact():
-    """kernels.cuh time_bucket(): floor(double(t) * (1/g)(1+2^-40)) == t // g for every u32 t.
+    """sinks.cuh time_bucket(): floor(double(t) * (1/g)(1+2^-40)) == t // g for every u32 t.
     Checked at every multiple of g (+-1) near the ends of the range and on random t."""
     rng = np.random.default_rng(1)
     grans = [g for g in range(60, 86401) if 86400 % g == 0]

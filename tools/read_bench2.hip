@@ -1,5 +1,5 @@
 // read_bench2.hip - which ingredient of the ingest kernel's staging loop costs read bandwidth?
-// Emulates the wave-tile loop (flow-pipeline_amd/csrc/kernels.cuh, wtile_kernel) piece by piece:
+// Emulates the wave-tile loop (flow-pipeline_amd/csrc/ingest.cuh, wtile_kernel) piece by piece:
 //   F_DESC   tile bounds from an offsets array (2 uniform loads per tile, prefetched one tile ahead)
 //   F_LANE   one offset load per lane per tile (prefetched one tile ahead)
 //   F_UNAL   tiles start at the record's 16-byte-aligned address (not 1 KiB aligned), 72-byte records

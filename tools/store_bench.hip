@@ -1,7 +1,7 @@
 // store_bench.hip - what does the tuple scatter of the tile kernel cost, by write granularity?
 //
 // The tile kernel appends one 16-byte tuple per record to the (key partition, workgroup) segment
-// (kernels.cuh, lane_work).  Ablation on MI355X: those stores are 0.145 ms of a 0.475 ms launch
+// (ingest.cuh, lane_work).  Ablation on MI355X: those stores are 0.145 ms of a 0.475 ms launch
 // (16.67 M records).  This microbenchmark replays only the store pattern: G adjacent lanes append
 // G*16 contiguous bytes to the same segment (G = 1 is today's pattern; G = 4 / 8 is what LDS-binned
 // flushing of full 64 / 128-byte lines would emit), P partitions, persistent 256-thread workgroups.
