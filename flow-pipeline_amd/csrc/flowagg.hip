@@ -47,6 +47,7 @@ struct fa_ctx {
     size_t seg_counts_cap = 0;
     int sink_mode = 0;  // 0 auto, 1 direct, 2 scatter (env FA_SINK)
     bool use_wave_tiles = false;  // decision for the batch being launched
+    uint32_t seg_cap_limit = 0;   // env FA_SEG_CAP (tests only): upper bound on tuples per segment
     // ingest kernel (env FA_TILE=wave|wg, measurement / tests): wave-private tiles + LDS tuple bins is the
     // production kernel of the scatter sink (never slower than the 256-thread workgroup-tile kernel on the
     // workloads measured, 15-20 % faster when most records leave as tuples); the workgroup kernel serves the
@@ -206,6 +207,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_DEBUG_FLAGS")) c->dbg = (uint32_t)strtoul(d, nullptr, 0);
     if (const char* d = getenv("FA_PLOG2")) c->plog2 = std::min<uint32_t>(PART_LOG2_MAX, std::max<uint32_t>(4, (uint32_t)atoi(d)));
     if (const char* d = getenv("FA_WGPC")) c->wgpc_cap = (uint32_t)atoi(d);
+    if (const char* d = getenv("FA_SEG_CAP")) c->seg_cap_limit = std::max<uint32_t>(40u, (uint32_t)atoi(d) & ~7u);
     if (const char* d = getenv("FA_TILE")) c->tile_mode = !strcmp(d, "wave") ? 1 : !strcmp(d, "wg") ? 2 : 0;
     if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
     auto bail = [&](const char* what, hipError_t e) {
@@ -534,7 +536,8 @@ static int ensure_exotic(fa_ctx* c, size_t n) {
 static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     const size_t NPART = (size_t)1 << c->plog2;
     const size_t avg = n / ((size_t)nwg * NPART);
-    const uint32_t capq = (uint32_t)((2 * avg + 32 + 7) & ~(size_t)7);  // whole 128-byte lines
+    uint32_t capq = (uint32_t)((2 * avg + 32 + 7) & ~(size_t)7);  // whole 128-byte lines
+    if (c->seg_cap_limit) capq = std::min(capq, c->seg_cap_limit);  // (tests: force the segment-overflow fallbacks)
     const size_t region = (size_t)nwg * capq + 24;
     const size_t tuples = region * NPART;
     if (c->seg_tuples < tuples) {

@@ -452,15 +452,10 @@ def test_topk_reports_overflow(gpu_lib, fa, po):
         assert ei.value.code == -5
 
 
-@pytest.mark.parametrize("mode,tile", [(1, ""), (2, ""), (0, ""), (1, "wg")])
-def test_large_device_batches_checksum_equals_oracle(gpu_lib, fa, po, monkeypatch, mode, tile):
-    """Bench-scale batches (4 M records generated in HBM, full grids, every LDS bin cycling hundreds of times):
-    the order-independent checksum of the flows_5m rows equals the multi-threaded oracle's.  Small batches do
-    not exercise the cross-wave bin hand-over enough to catch ordering mistakes there."""
+def _large_batch_checksum_run(fa, po, mode, n=4_000_000):
+    """4 M records generated in HBM, ingested three times; rows checked against the multi-threaded oracle's
+    order-independent checksum.  Returns the ctx statistics."""
     import torch
-    if tile:
-        monkeypatch.setenv("FA_TILE", tile)
-    n = 4_000_000
 
     def mix64(z):
         z = z.astype(np.uint64)
@@ -500,6 +495,30 @@ def test_large_device_batches_checksum_equals_oracle(gpu_lib, fa, po, monkeypatc
             rows[col] //= np.uint64(3)
         assert checksum(rows) == want["checksum"]
         assert int(rows["count"].sum()) == n
+        return agg.stats()
+
+
+@pytest.mark.parametrize("mode,tile", [(1, ""), (2, ""), (0, ""), (1, "wg")])
+def test_large_device_batches_checksum_equals_oracle(gpu_lib, fa, po, monkeypatch, mode, tile):
+    """Bench-scale batches (full grids, every LDS bin cycling hundreds of times).  Small batches do not exercise
+    the cross-wave bin hand-over enough to catch ordering mistakes there."""
+    if tile:
+        monkeypatch.setenv("FA_TILE", tile)
+    st = _large_batch_checksum_run(fa, po, mode)
+    assert st["wave_tile_launches"] == (0 if tile == "wg" else 3)
+
+
+@pytest.mark.parametrize("tile,cap", [("", 40), ("", 64), ("wg", 40)])
+def test_segment_overflow_fallbacks_stay_exact(gpu_lib, fa, po, monkeypatch, tile, cap):
+    """Segments far too small for the batch (FA_SEG_CAP, a test knob): full bins that find the front part full,
+    single tuples that find the back part full and the workgroup kernel's plain overflow all fall back to the
+    device-wide table - slower, but the rows must not change."""
+    monkeypatch.setenv("FA_SEG_CAP", str(cap))
+    if tile:
+        monkeypatch.setenv("FA_TILE", tile)
+    st = _large_batch_checksum_run(fa, po, 1)
+    if not tile:  # (the workgroup kernel's 1536 segments per partition hold ~10 tuples each here: rarely above 40)
+        assert st["records_direct"] > (3_000_000 if cap == 40 else 10_000), st  # the fallbacks really ran (of 12 M records)
 
 
 def test_config3_shape_sketches_and_topk_at_scale(gpu_lib, fa, po):
@@ -547,3 +566,5 @@ def test_config3_shape_sketches_and_topk_at_scale(gpu_lib, fa, po):
             assert [(bytes(r["key"]), int(r["weight"])) for r in top] == order
             for r in top[:10]:
                 assert int(r["weight"]) == po.cms_query(want, depth, wl2, seed, bytes(r["key"]))
+
+
