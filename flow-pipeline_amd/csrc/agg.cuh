@@ -18,12 +18,11 @@ struct AggTable {
 static_assert(sizeof(AggTable) == 32 * AGG_SLOTS, "agg_kernel LDS table");
 
 // slow path of the LDS upsert: claim / probe; false = the table is full around this hash
-// (skip = leading slots of the probe sequence already known to hold other keys: a key never changes)
 __device__ __forceinline__ bool agg_lds_upsert(AggTable& lt, uint64_t k0, uint64_t k1, uint32_t h, uint32_t by,
-                                               unsigned long long v2, uint32_t skip = 0) {
-    uint32_t i = (h + skip) & (AGG_SLOTS - 1);
+                                               unsigned long long v2) {
+    uint32_t i = h & (AGG_SLOTS - 1);
 #pragma unroll 1
-    for (int probe = (int)skip; probe < AGG_PROBES; probe++, i = (i + 1) & (AGG_SLOTS - 1)) {
+    for (int probe = 0; probe < AGG_PROBES; probe++, i = (i + 1) & (AGG_SLOTS - 1)) {
         unsigned long long c0 = lt.k0[i];
         if (c0 == 0) c0 = atomicCAS(&lt.k0[i], 0ull, (unsigned long long)k0);
         if (c0 != 0 && c0 != k0) continue;
@@ -122,7 +121,6 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
         d1[s] = lt.k1[j];
     }
     uint32_t pending = 0;  // segments whose tuple is not in its home slot (probing / claiming needed)
-    uint32_t skipw = 0;    // 2 bits per segment: leading probe slots known to hold other keys
 #pragma unroll
     for (int s = 0; s < AGG_CH; s++) {
         if (!((b.v >> (S0 + s)) & 1u)) continue;
@@ -135,10 +133,6 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
             if (by) atomicAdd(&lt.s1[t], (unsigned long long)by);
             atomicAdd(&lt.s2[t], v2);
         } else {
-            // slots that definitely belong to other keys need no second look on the probing path
-            const bool o0 = (c0[s] != 0 && c0[s] != k0[s]) || (c0[s] == k0[s] && c1[s] != 0 && c1[s] != k1[s]);
-            const bool o1 = (d0[s] != 0 && d0[s] != k0[s]) || (d0[s] == k0[s] && d1[s] != 0 && d1[s] != k1[s]);
-            skipw |= (o0 ? (o1 ? 2u : 1u) : 0u) << (2 * s);
             pending |= 1u << s;
         }
     }
