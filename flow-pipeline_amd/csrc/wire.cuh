@@ -328,19 +328,28 @@ FA_HD bool parse_canon(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
     canon_addr<0x5au, (COLS & COL_SAMPLER_ADDRESS) != 0>(s, c, end, r.sampler);             // 11 SamplerAddress
     canon_short<0x70u, (COLS & COL_SRC_AS) != 0>(s, c, end, r.src_as);                      // 14 SrcAS
     canon_short<0x78u, (COLS & COL_DST_AS) != 0>(s, c, end, r.dst_as);                      // 15 DstAS
-    canon_short<0x0190u, false>(s, c, end, d32);                                            // 18 InIf
-    canon_short<0x0198u, false>(s, c, end, d32);                                            // 19 OutIf
-    canon_short<0x01a0u, (COLS & COL_PROTO) != 0>(s, c, end, r.proto);                      // 20 Proto
+    // Runs of fields that flow exporters rarely fill are guarded by ONE tag-range test per run (wave-uniform)
+    // instead of one test per field: 18..20, 23..26, 31..37.  (A lane can only be inside a run if its tag was
+    // in the run's range when the run started - fields come in ascending order.)
+    if (FA_ANY(((c.x & 0xffffu) - 0x0190u) <= 0x0010u)) {
+        canon_short<0x0190u, false>(s, c, end, d32);                                        // 18 InIf
+        canon_short<0x0198u, false>(s, c, end, d32);                                        // 19 OutIf
+        canon_short<0x01a0u, (COLS & COL_PROTO) != 0>(s, c, end, r.proto);                  // 20 Proto
+    }
     canon_short<0x01a8u, (COLS & COL_SRC_PORT) != 0>(s, c, end, r.src_port);                // 21 SrcPort
     canon_short<0x01b0u, (COLS & COL_DST_PORT) != 0>(s, c, end, r.dst_port);                // 22 DstPort
-    canon_short<0x01b8u, false>(s, c, end, d32);                                            // 23 IPTos
-    canon_short<0x01c0u, false>(s, c, end, d32);                                            // 24 ForwardingStatus
-    canon_short<0x01c8u, false>(s, c, end, d32);                                            // 25 IPTTL
-    canon_short<0x01d0u, false>(s, c, end, d32);                                            // 26 TCPFlags
+    if (FA_ANY(((c.x & 0xffffu) - 0x01b8u) <= 0x0018u)) {
+        canon_short<0x01b8u, false>(s, c, end, d32);                                        // 23 IPTos
+        canon_short<0x01c0u, false>(s, c, end, d32);                                        // 24 ForwardingStatus
+        canon_short<0x01c8u, false>(s, c, end, d32);                                        // 25 IPTTL
+        canon_short<0x01d0u, false>(s, c, end, d32);                                        // 26 TCPFlags
+    }
     canon_short<0x01f0u, (COLS & COL_ETYPE) != 0>(s, c, end, r.etype);                      // 30 Etype
-    canon_short<0x01f8u, false>(s, c, end, d32);                                            // 31 IcmpType
-    canon_short<0x0280u, false>(s, c, end, d32);                                            // 32 IcmpCode
-    canon_short<0x02a8u, false>(s, c, end, d32);                                            // 37 IPv6FlowLabel
+    if (FA_ANY(((c.x & 0xffffu) - 0x01f8u) <= 0x00b0u)) {
+        canon_short<0x01f8u, false>(s, c, end, d32);                                        // 31 IcmpType
+        canon_short<0x0280u, false>(s, c, end, d32);                                        // 32 IcmpCode
+        canon_short<0x02a8u, false>(s, c, end, d32);                                        // 37 IPv6FlowLabel
+    }
     canon_long<0x02b0u, (COLS & COL_TIME_FLOW_START) != 0>(s, c, end, r.time_flow_start);   // 38 TimeFlowStart
     canon_short<0x02d0u, false>(s, c, end, d32);                                            // 42 FlowDirection
     r.sampling_rate = sr32;
