@@ -568,3 +568,27 @@ def test_config3_shape_sketches_and_topk_at_scale(gpu_lib, fa, po):
                 assert int(r["weight"]) == po.cms_query(want, depth, wl2, seed, bytes(r["key"]))
 
 
+
+
+def test_empty_and_tiny_batches(gpu_lib, fa, po):
+    """n = 0 (no records, empty buffer), n = 1, an empty record (valid protobuf: every column 0), and a batch
+    made of malformed records only."""
+    with fa.FlowAgg(framed=False) as agg:
+        agg.ingest(b"", np.zeros(1, dtype=np.uint64))  # n = 0
+        assert len(agg.read_window()) == 0 and agg.stats()["records_ok"] == 0
+        one = bytes.fromhex("10a0ceb9b706" "70eafb03" "78e9fb03" "48db0b" "5063")  # not canonical order: Bytes after the ASNs
+        agg.ingest(one, np.array([0, len(one)], dtype=np.uint64))
+        rows = agg.read_window()
+        assert len(rows) == 1 and int(rows["bytes"][0]) == 1499 and int(rows["packets"][0]) == 99 and int(rows["count"][0]) == 1
+        agg.ingest(b"", np.array([0, 0], dtype=np.uint64))  # one empty record: TimeReceived = 0 -> timeslot 0
+        rows = agg.read_window()
+        assert len(rows) == 2 and int(rows["timeslot"][0]) == 0 and int(rows["count"][0]) == 1
+        bad = [bytes.fromhex("70ffffffff"), bytes.fromhex("00"), bytes.fromhex("3210" + "11" * 8)]
+        blob = b"".join(bad)
+        offs = np.array([0, 5, 6, 6 + 10], dtype=np.uint64)
+        agg.ingest(blob, offs)
+        st = agg.stats()
+        assert st["records_bad"] == 3 and st["records_ok"] == 2
+        assert len(agg.read_window()) == 2
+    ref = po.Rollup(300)
+    assert ref.ingest(np.frombuffer(blob, dtype=np.uint8), offs, 0) == 3
