@@ -124,13 +124,35 @@ _LIB = None
 
 
 def build(force=False):
-    """Compile libflowagg.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    """Compile libflowagg.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    Safe under `torch.distributed.run` (every rank calls it): the staleness check and the compile run under an
+    exclusive file lock, the compiler writes to a private name and the result is renamed into place, so a rank
+    never loads a half-written library and at most one rank compiles."""
+    import fcntl
     srcdir = os.path.join(_HERE, "csrc")
     srcs = [os.path.join(srcdir, f) for f in os.listdir(srcdir) if not f.endswith(".so")] + [
         os.path.join(_HERE, "..", "include", "flowagg.h")]
-    if (force or not os.path.exists(LIB_PATH)
-            or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)):
-        subprocess.check_call(["make", "-C", srcdir, "-B"], stdout=subprocess.DEVNULL)
+
+    def stale():
+        return (not os.path.exists(LIB_PATH)
+                or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
+
+    if not (force or stale()):
+        return LIB_PATH
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or stale():
+                tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+                try:
+                    subprocess.check_call(["make", "-C", srcdir, "-B", "OUT=" + tmp], stdout=subprocess.DEVNULL)
+                    os.replace(tmp, LIB_PATH)
+                finally:
+                    if os.path.exists(tmp):
+                        os.unlink(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
