@@ -117,7 +117,7 @@ EXPORTS = [
     "fa_device_state_get", "fa_merge_rows", "fa_merge_allreduce", "fa_stats",
     "fa_mock_generate_device", "fa_mock_generate_host",
     "fa_read_window_app", "fa_close_window_app", "fa_merge_rows_app", "fa_top_ports", "fa_merge_ports",
-    "fa_minute_series", "fa_merge_minutes", "fa_dashboard_reset", "fa_rows_to_rowbinary",
+    "fa_minute_series", "fa_merge_minutes", "fa_dashboard_reset", "fa_rows_to_rowbinary", "fa_format_addr",
 ]
 
 _LIB = None
@@ -201,6 +201,7 @@ def lib():
     L.fa_merge_minutes.argtypes = [vp, vp, sz]
     L.fa_dashboard_reset.argtypes = [vp]
     L.fa_rows_to_rowbinary.argtypes = [vp, sz, vp, sz, szp]
+    L.fa_format_addr.argtypes = [C.c_char_p, u32, C.c_char_p, sz]
     _LIB = L
     return L
 
@@ -232,6 +233,19 @@ def rows_to_rowbinary(rows: np.ndarray) -> bytes:
     if rc:
         raise FlowAggError(rc, "fa_rows_to_rowbinary")
     return out[:n.value].tobytes()
+
+
+def format_addr(addr, etype: int) -> str:
+    """The dashboards' address string (viz-ch.json:233,479): dotted IPv4 of the first four bytes when
+    EType = 0x800, ClickHouse IPv6NumToString of the FixedString(16) otherwise."""
+    a = bytes(addr)
+    if len(a) != 16:
+        raise ValueError("FixedString(16) expected")
+    out = C.create_string_buffer(46)
+    rc = lib().fa_format_addr(a, etype, out, 46)
+    if rc:
+        raise FlowAggError(rc, "fa_format_addr")
+    return out.value.decode("ascii")
 
 
 def rowbinary_to_rows(blob: bytes) -> np.ndarray:

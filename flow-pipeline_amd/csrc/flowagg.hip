@@ -1061,6 +1061,69 @@ extern "C" int fa_rows_to_rowbinary(const fa_row5m* rows, size_t n, uint8_t* out
     return FA_OK;
 }
 
+// ---- dashboard address rendering (viz-ch.json:233,479) ---------------------------------------------
+// IPv6NumToString is restated from BIND's inet_ntop6 (the algorithm ClickHouse's formatIPv6 follows and glibc
+// ships; the CPU test-suite checks this function against glibc on random and structured addresses).
+extern "C" int fa_format_addr(const uint8_t addr[16], uint32_t etype, char* out, size_t cap) {
+    if (!addr || !out) return FA_ERR_ARG;
+    char tmp[FA_ADDR_STRLEN + 2];
+    char* p = tmp;
+    auto dec = [&](unsigned v) {
+        if (v >= 100) *p++ = (char)('0' + v / 100);
+        if (v >= 10) *p++ = (char)('0' + v / 10 % 10);
+        *p++ = (char)('0' + v % 10);
+    };
+    auto dotted = [&](const uint8_t* b) {
+        for (int i = 0; i < 4; i++) {
+            if (i) *p++ = '.';
+            dec(b[i]);
+        }
+    };
+    if (etype == 0x800) {
+        dotted(addr);
+    } else {
+        unsigned w[8];
+        for (int i = 0; i < 8; i++) w[i] = ((unsigned)addr[2 * i] << 8) | addr[2 * i + 1];
+        int best = -1, best_len = 0, cur = -1, cur_len = 0;
+        for (int i = 0; i < 8; i++) {
+            if (w[i] == 0) {
+                if (cur < 0) cur = i, cur_len = 1;
+                else cur_len++;
+            } else if (cur >= 0) {
+                if (best < 0 || cur_len > best_len) best = cur, best_len = cur_len;
+                cur = -1;
+            }
+        }
+        if (cur >= 0 && (best < 0 || cur_len > best_len)) best = cur, best_len = cur_len;
+        if (best >= 0 && best_len < 2) best = -1;
+        bool done = false;
+        for (int i = 0; i < 8 && !done; i++) {
+            if (best >= 0 && i >= best && i < best + best_len) {
+                if (i == best) *p++ = ':';
+                continue;
+            }
+            if (i) *p++ = ':';
+            if (i == 6 && best == 0 && (best_len == 6 || (best_len == 5 && w[5] == 0xffffu))) {
+                dotted(addr + 12);  // encapsulated IPv4
+                done = true;
+                break;
+            }
+            static const char hex[] = "0123456789abcdef";
+            bool lead = true;
+            for (int s = 12; s >= 0; s -= 4) {
+                unsigned d = (w[i] >> s) & 15u;
+                if (d || !lead || s == 0) *p++ = hex[d], lead = false;
+            }
+        }
+        if (!done && best >= 0 && best + best_len == 8) *p++ = ':';
+    }
+    *p++ = 0;
+    const size_t need = (size_t)(p - tmp);
+    if (need > cap) return FA_ERR_CAPACITY;
+    memcpy(out, tmp, need);
+    return FA_OK;
+}
+
 // ---- wide key sets: window close and dashboard reads -----------------------------------------------
 // Collects the selected rows of the wide table into a host vector (unsorted).
 static int collect_wide(fa_ctx* c, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, std::vector<WRow>& rows) {

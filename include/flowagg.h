@@ -223,6 +223,18 @@ int fa_merge_minutes(fa_ctx*, const fa_minute_row* rows, size_t n);
 /* Clears the port groups and the minute series (start of a new $timeFilter range). */
 int fa_dashboard_reset(fa_ctx*);
 
+/* ---- address rendering of the dashboards (host code, no ctx) ------------------ */
+/* The string the top-talker panels group by and display (viz-ch.json:233,479; README.md:186-221):
+ *   if(EType = 0x800, IPv4NumToString(reinterpretAsUInt32(substring(reverse(Addr), 13, 4))), IPv6NumToString(Addr))
+ * EType 0x0800: the first four bytes of the FixedString(16) in network order, dotted ("192.168.1.1"); any
+ * other EType: ClickHouse's IPv6NumToString = the BIND inet_ntop6 rules (longest run of >= 2 zero groups
+ * becomes "::", lower-case hex without leading zeros, "::a.b.c.d" / "::ffff:a.b.c.d" for the encapsulated
+ * IPv4 forms) - README.md:191 renders the FixedString of 192.168.1.1's little-endian UInt32 as "101:a8c0::".
+ * out receives a NUL-terminated string (FA_ADDR_STRLEN bytes always suffice); FA_ERR_CAPACITY if cap is
+ * too small. */
+#define FA_ADDR_STRLEN 46
+int fa_format_addr(const uint8_t addr[16], uint32_t etype, char* out, size_t cap);
+
 /* ---- heavy hitters -------------------------------------------------------- */
 /* key_set: FA_KEYS_SRCADDR_CMS or FA_KEYS_DSTADDR_CMS.  The k addresses with the largest Count-Min
  * estimate of sum(Bytes*SamplingRate) (viz-ch.json:233,479) among ALL distinct addresses ingested

@@ -85,3 +85,35 @@ def test_rowbinary_sink_known_answer(fa):
     bad["date"] = 70000  # Date is UInt16 days
     with pytest.raises(fa.FlowAggError):
         fa.rows_to_rowbinary(bad)
+
+
+def test_format_addr_matches_glibc_and_readme(fa):
+    """fa_format_addr = the dashboards' address expression (viz-ch.json:233,479).  IPv6NumToString follows BIND's
+    inet_ntop6, so glibc's inet_ntop is the second opinion; README.md:155-161,186-221 hold the known answers."""
+    import random
+    import socket
+    import struct
+    if not os.path.exists(fa.LIB_PATH):
+        fa.build()
+    v6 = lambda s: socket.inet_pton(socket.AF_INET6, s)
+    # README.md:155-161 (mocker addresses as ClickHouse prints them) and README.md:191 (192.168.1.1 stored as the
+    # FixedString of its little-endian UInt32 renders as "101:a8c0::")
+    assert fa.format_addr(v6("2001:db8:0:1::80"), 0x86dd) == "2001:db8:0:1::80"
+    assert fa.format_addr(v6("2001:db8:0:1::"), 0x86dd) == "2001:db8:0:1::"
+    assert fa.format_addr(struct.pack("<I", 3232235777) + bytes(12), 0x86dd) == "101:a8c0::"
+    # what GoFlow stores for IPv4 (4 bytes in network order + 12 NULs, SURVEY 8(a)-4) under the EType = 0x800 branch
+    assert fa.format_addr(bytes([192, 168, 1, 1]) + bytes(12), 0x800) == "192.168.1.1"
+    assert fa.format_addr(bytes([0, 0, 0, 0]) + bytes(12), 0x800) == "0.0.0.0"
+    assert fa.format_addr(bytes([255, 255, 255, 255]) + b"\x01" * 12, 0x800) == "255.255.255.255"  # bytes 5..16 ignored
+    assert fa.format_addr(bytes(16), 0) == "::"
+    rng = random.Random(7)
+    cases = [bytes(16), bytes(15) + b"\x01", bytes(10) + b"\xff\xff" + bytes([1, 2, 3, 4]), bytes(12) + bytes([1, 2, 3, 4]),
+             bytes(10) + b"\xff\xfe" + bytes([1, 2, 3, 4]), b"\x00\x01" + bytes(14), b"\xff" * 16]
+    for _ in range(20000):
+        words = [rng.choice((0, 0, 0, 1, 0xff, 0x100, 0xffff, rng.getrandbits(16))) for _ in range(8)]
+        cases.append(struct.pack(">8H", *words))
+    for a in cases:
+        assert fa.format_addr(a, 0x86dd) == socket.inet_ntop(socket.AF_INET6, a), a.hex()
+    out = C.create_string_buffer(4)
+    assert fa.lib().fa_format_addr(bytes(15) + b"\x01", 0x86dd, out, 3) == -6  # "::1" needs 4 bytes
+    assert fa.lib().fa_format_addr(bytes(15) + b"\x01", 0x86dd, out, 4) == 0 and out.value == b"::1"
