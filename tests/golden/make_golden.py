@@ -261,6 +261,53 @@ def make_rollup_fixture():
               open(os.path.join(HERE, "rollup_2000.json"), "w"))
 
 
+def make_readme_fixture():
+    """The only result-bearing text of the reference: the sample outputs of README.md:155-161 (flows_raw) and
+    README.md:180-183 (flows_5m after OPTIMIZE).  The table rows are copied VERBATIM from the README at
+    generation time; the records are upb-encoded mocker-shaped FlowMessages (mocker.go:57-91) chosen so that the five
+    printed flows_raw rows are among them and every (SrcAS,DstAS) group adds up to the printed flows_5m row.  (The
+    README samples come from two different runs of an unseeded mocker, so the mapping of the five raw rows to groups
+    is ours; what the fixture pins is the rendering: Date, Timeslot = toStartOfFiveMinute, DateTime narrowing,
+    IPv6NumToString, the [EType] key, sums and counts.)"""
+    import calendar
+    lines = open(os.path.join(REF, "README.md")).read().split("\n")
+    raw_rows = [l for l in lines[154:161] if l.startswith("\u2502")]
+    agg_rows = [l for l in lines[179:183] if l.startswith("\u2502")]
+    assert len(raw_rows) == 5 and len(agg_rows) == 3, (raw_rows, agg_rows)
+    cell = lambda l: [c.strip() for c in l.strip("\u2502").split("\u2502")]
+    F = schema.message_class("light")
+    t38 = calendar.timegm((2020, 3, 22, 21, 26, 38))
+    ip = lambda s: __import__("socket").inet_pton(__import__("socket").AF_INET6, s)
+    raws = [cell(l) for l in raw_rows]  # Date, TimeReceived, Src, Dst, Bytes, Packets
+    def rec(t, src, dst, b, pk, sa, da, seq):
+        m = F()
+        m.TimeReceived = t; m.TimeFlowStart = t; m.SamplingRate = 1; m.SequenceNum = seq
+        m.SrcAddr = ip(src); m.DstAddr = ip(dst); m.Bytes = b; m.Packets = pk
+        m.SrcAS = sa; m.DstAS = da; m.Etype = 0x86dd; m.SrcPort = 1000 + seq; m.DstPort = 2000 + seq
+        return m.SerializeToString()
+    R = {i: (t38 + (r[1].endswith(":39")), r[2], r[3], int(r[4]), int(r[5])) for i, r in enumerate(raws)}
+    plan = [  # (group DstAS, [(raw row index | None, bytes, packets)])
+        (65000, [(3, 0, 0), (2, 0, 0), (0, 0, 0), (None, 757, 6)]),
+        (65001, [(1, 0, 0), (None, 800, 75), (None, 749, 72)]),
+        (65002, [(4, 0, 0), (None, 1000, 50), (None, 1000, 50), (None, 1000, 55), (None, 1000, 60), (None, 697, 50)]),
+    ]
+    recs, seq, where = [], 0, {}
+    for da, items in plan:
+        for ri, b, pk in items:
+            if ri is None:
+                recs.append(rec(t38 + seq % 2, "2001:db8:0:1::%x" % (seq + 1), "2001:db8:0:1::%x" % (seq + 7), b, pk, 65001, da, seq))
+            else:
+                t, s_, d_, b_, p_ = R[ri]
+                where[ri] = seq
+                recs.append(rec(t, s_, d_, b_, p_, 65001, da, seq))
+            seq += 1
+    json.dump({"source": "README.md:155-161 and README.md:180-183 of the reference, table rows verbatim",
+               "raw_row_record_index": [where[i] for i in range(5)],  # README raw rows 0..4 -> position in records_hex
+               "readme_flows_raw": raw_rows, "readme_flows_5m": agg_rows,
+               "records_hex": [r.hex() for r in recs]},
+              open(os.path.join(HERE, "readme_samples.json"), "w"), ensure_ascii=False, indent=1)
+
+
 SNIPS = [bytes.fromhex(x) for x in [
     "c33e", "c43e", "cb3e", "cc3e", "73", "74", "7001", "7205", "71", "75", "c03e05",
     "ffffffffffffffffff01", "8080808000", "f0ffffff0f", "3200", "3214" + "11" * 20, "a206", "00", "80",
@@ -317,4 +364,5 @@ if __name__ == "__main__":
     cases = make_edge_cases()
     print("edge cases:", len(cases), "bad:", sum(1 for c in cases if c["expect"] is None))
     make_rollup_fixture()
+    make_readme_fixture()
     make_fuzz_fixture()

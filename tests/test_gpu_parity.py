@@ -592,3 +592,18 @@ def test_empty_and_tiny_batches(gpu_lib, fa, po):
         assert len(agg.read_window()) == 2
     ref = po.Rollup(300)
     assert ref.ingest(np.frombuffer(blob, dtype=np.uint8), offs, 0) == 3
+
+
+def test_readme_samples_on_device(gpu_lib, fa, po):
+    """README.md:155-161,180-183 of the reference through the C-ABI: fa_decode gives the printed flows_raw rows,
+    fa_ingest + fa_close_window the printed flows_5m rows (tests/golden/readme_samples.json)."""
+    import json
+    from test_oracle_golden import GOLDEN, readme_batch, readme_render
+    fx = json.load(open(os.path.join(GOLDEN, "readme_samples.json")))
+    buf, off = readme_batch(fa, fx)
+    with fa.FlowAgg(framed=True) as agg:
+        decoded = agg.decode(buf, off)
+        assert not decoded["status"].any()
+        agg.ingest(buf, off)
+        rows = agg.close_window()
+    readme_render(fa, fx, decoded, rows)

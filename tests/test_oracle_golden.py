@@ -232,3 +232,44 @@ def test_numpy_sketch_restatement_matches_c_oracle(po):
     for k in range(len(keys)):
         po.cms_update(want, depth, wl2, seed, bytes(keys[k]), int(w[k]))
     assert np.array_equal(po.cms_sketch_numpy(keys, w, depth, wl2, seed), want)
+
+
+def readme_render(fa, fx, decoded_rows, rows5m):
+    """Renders decoded rows / flows_5m rows the way clickhouse-client printed them in the reference's README and
+    compares cell by cell with the README's own table rows (tests/golden/readme_samples.json)."""
+    import datetime
+    utc = lambda t: datetime.datetime.fromtimestamp(int(t), datetime.timezone.utc)
+    cell = lambda l: [c.strip() for c in l.strip("│").split("│")]
+    for line, idx in zip(fx["readme_flows_raw"], fx["raw_row_record_index"]):
+        d = decoded_rows[idx]
+        t32 = int(d["time_received"]) & 0xFFFFFFFF  # flows_raw: TimeReceived UInt64 -> DateTime (create.sh:41,64-68)
+        got = [utc(t32).strftime("%Y-%m-%d"), utc(t32).strftime("%Y-%m-%d %H:%M:%S"),
+               fa.format_addr(bytes(d["src_addr"]), int(d["etype"])), fa.format_addr(bytes(d["dst_addr"]), int(d["etype"])),
+               str(int(d["bytes"])), str(int(d["packets"]))]
+        assert got == cell(line), (got, line)
+    got5 = []
+    for r in rows5m:
+        e, b, p, c = int(r["etype"]), int(r["bytes"]), int(r["packets"]), int(r["count"])
+        got5.append([(datetime.date(1970, 1, 1) + datetime.timedelta(days=int(r["date"]))).isoformat(),
+                     utc(r["timeslot"]).strftime("%Y-%m-%d %H:%M:%S"), str(int(r["src_as"])), str(int(r["dst_as"])),
+                     "[%d]" % e, "[%d]" % b, "[%d]" % p, "[%d]" % c, str(b), str(p), str(c)])
+    assert got5 == [cell(l) for l in fx["readme_flows_5m"]], got5
+
+
+def readme_batch(fa, fx):
+    recs = [fa.schema.frame(bytes.fromhex(h)) for h in fx["records_hex"]]  # ClickHouse path: -proto.fixedlen=true
+    off = np.zeros(len(recs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in recs])
+    return np.frombuffer(b"".join(recs), dtype=np.uint8), off
+
+
+def test_readme_samples_oracle(po, fa):
+    """The reference's only result-bearing text (README.md:155-161,180-183): the oracle reproduces the printed
+    flows_raw and flows_5m rows (Date, toStartOfFiveMinute, IPv6NumToString, [EType] key, sums, counts)."""
+    fx = json.load(open(os.path.join(GOLDEN, "readme_samples.json")))
+    buf, off = readme_batch(fa, fx)
+    rows, status = po.decode_batch(buf, off, framed=1)
+    assert not status.any()
+    r = po.Rollup(300)
+    assert r.ingest(buf, off, 1) == 0
+    readme_render(fa, fx, rows, r.rows())
