@@ -138,6 +138,10 @@ def build(force=False):
         return (not os.path.exists(LIB_PATH)
                 or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
 
+    if os.environ.get("FA_LIB_VARIANT"):  # A/B libraries are built by hand with their own EXTRA flags: never rebuilt here
+        if not os.path.exists(LIB_PATH):
+            raise FlowAggError(-2, "%s is not built" % LIB_PATH)
+        return LIB_PATH
     if not (force or stale()):
         return LIB_PATH
     with open(os.path.join(_HERE, ".build.lock"), "w") as lock:

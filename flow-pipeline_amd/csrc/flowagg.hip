@@ -586,7 +586,7 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     // small batches are not worth a second pass: they go straight to the device-wide table
     const bool scatter = (c->cfg.key_sets & FA_KEYS_AS_PAIR) && (c->sink_mode == 2 || (c->sink_mode == 0 && n >= (1u << 15)));
     c->use_wave_tiles = scatter && c->tile_mode != 2;
-    if (c->use_wave_tiles) {  // wave-private tiles: <= 64 records per wave, 8 waves per workgroup, 2 workgroups per CU
+    if (c->use_wave_tiles) {  // wave-private tiles: <= 64 records per wave, WBLOCK / 64 waves per workgroup, WT_WG_PER_CU workgroups per CU
         double avg = (double)len / (double)n + 0.5;
         // (a tile that does not fit its buffer goes to the deferred parsers as a whole, so leave ~4 sigma of
         // headroom for a mix of 60- and 84-byte records when the buffer is tight)
@@ -594,7 +594,7 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         a.tile_recs = r >= (double)WT_RECS ? WT_RECS : r < 1.0 ? 1u : (uint32_t)r;
         const uint32_t wtiles = (a.n + a.tile_recs - 1) / a.tile_recs;
         const uint32_t wgs = (wtiles + (WBLOCK / 64) - 1) / (WBLOCK / 64);
-        grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * 2u));
+        grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * (uint32_t)WT_WG_PER_CU));
     }
     if (scatter) {
         rc = ensure_segments(c, n, (uint32_t)grid, a);

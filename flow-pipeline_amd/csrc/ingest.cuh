@@ -392,7 +392,10 @@ template <uint32_t KEYSETS>
 __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     constexpr uint32_t COLS = cols_for_keysets<KEYSETS>();
     constexpr int WAVES = WBLOCK / 64;
+    // (two buffers per wave live in two arrays: the compiler keys its "LDS-DMA still in flight" waits on the
+    // __shared__ variable, so reads of one array do not wait for the DMA into the other)
     __shared__ __attribute__((aligned(16))) uint32_t tiles[WAVES * WT_STRIDE / 4];
+    __shared__ __attribute__((aligned(16))) uint32_t tiles2[WT_NBUF == 2 ? WAVES * WT_STRIDE / 4 : 4];
     __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BIN_CAP];
     __shared__ uint32_t bin_cnt[NPART_MAX];
     __shared__ uint32_t part_cnt[NPART_MAX];
@@ -427,25 +430,16 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     if (lane + 1 >= cur.nrec) o1 = cur.hi;
     __syncthreads();  // LDS state cleared
 
-    auto issue_dma = [&](const WTileDesc& d) {
+    auto issue_dma = [&](const WTileDesc& d, uint32_t* dst) {
         if (tile_fits<WT_STRIDE - 16>(d)) {
             const uint32_t cbase = d.lo & ~15u, nbytes = d.hi - cbase;
             for (uint32_t o = lane * 16u; o < nbytes; o += 1024u)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.buf + cbase + o),
-                                                 (__attribute__((address_space(3))) void*)(tile + (o - lane * 16u) / 4u), 16, 0, 2);
+                                                 (__attribute__((address_space(3))) void*)(dst + (o - lane * 16u) / 4u), 16, 0, 2);
         }
     };
-    // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous
-    // tile was consumed, BEFORE the flush barriers, so that the memory system stays busy during a flush) and
-    // the descriptor + offsets of the tile after it are in flight
-    issue_dma(cur);
-    WTileDesc nxt = wtile_desc(a, t + stride, ntiles);
-    uint32_t n0 = 0;
-    if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
-    for (uint32_t round = 0; round < rounds; round++, t += stride) {
-        dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
-        uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
-        // parse + sink
+    // parse + sink of the wave's current tile (staged in buffer tb)
+    auto consume = [&](uint32_t* tb, uint32_t& fill) {
         if (cur.nrec != 0) {
             const uint32_t cbase = cur.lo & ~15u;
             bool mine = tile_fits<WT_STRIDE - 16>(cur) && lane < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
@@ -454,20 +448,67 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
                 unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
                 a.exotic_idx[j] = cur.r0 + lane;
             }
-            lane_work<MODE_INGEST, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, n_ok,
+            lane_work<MODE_INGEST, KEYSETS, COLS>(a, lt, lm, part_cnt, tb, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, n_ok,
                                                   n_direct, lt_seen, lt_hits, bins, bin_cnt, fill);
         }
-        // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
-        // queue and the wave would wait for the write acknowledgements on top of its tile (measured: +15 %)
+    };
+    // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous
+    // tile was consumed, BEFORE the flush barriers, so that the memory system stays busy during a flush) and
+    // the descriptor + offsets of the tile after it are in flight
+    issue_dma(cur, tile);
+    WTileDesc nxt = wtile_desc(a, t + stride, ntiles);
+    uint32_t n0 = 0;
+    if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
+    if constexpr (WT_NBUF == 1) {
+        for (uint32_t round = 0; round < rounds; round++, t += stride) {
+            dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
+            uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
+            consume(tile, fill);
+            // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
+            // queue and the wave would wait for the write acknowledgements on top of its tile (measured: +15 %)
+            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
+            cur = tile_current(nxt);
+            o0 = n0;
+            o1 = (uint32_t)__shfl_down((int)o0, 1);
+            if (lane + 1 >= cur.nrec) o1 = cur.hi;
+            issue_dma(cur, tile);  // next tile (the buffer is free: every read of the old tile has returned)
+            nxt = wtile_desc(a, t + 2 * stride, ntiles);
+            n0 = 0;
+            if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
+        }
+    } else {
+        // Two buffers per wave: round r parses buffer r & 1 while tile r + 1 flies into the other one.  Order inside a
+        // round: wait (tile r, the bounds of tile r + 1 and last round's line stores are all OLD by now) -> full bins of
+        // the previous round leave (their stores are issued before the DMA, so the next wait does not sit behind fresh
+        // write acknowledgements) -> DMA of tile r + 1 -> bounds of tile r + 2 -> parse + sink.  The body is
+        // instantiated once per buffer so that every LDS access names its array statically (see above).
+        uint32_t* tile2 = tiles2 + wave * (WT_STRIDE / 4);
+        uint32_t fill = 0xffffffffu;
+        auto body = [&](uint32_t* tb_cur, uint32_t* tb_next) {
+            dma_wait_all();
+            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
+            fill = 0xffffffffu;
+            const WTileDesc d1 = tile_current(nxt);
+            const uint32_t p0 = n0;
+            uint32_t p1 = (uint32_t)__shfl_down((int)p0, 1);
+            if (lane + 1 >= d1.nrec) p1 = d1.hi;
+            issue_dma(d1, tb_next);
+            nxt = wtile_desc(a, t + 2 * stride, ntiles);
+            n0 = 0;
+            if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
+            consume(tb_cur, fill);
+            cur = d1;
+            o0 = p0;
+            o1 = p1;
+            t += stride;
+        };
+        for (uint32_t round = 0; round < rounds; round += 2) {
+            body(tile, tile2);
+            if (round + 1 >= rounds) break;
+            body(tile2, tile);
+        }
+        dma_wait_all();  // (nothing useful in flight: the tile past the end is empty)
         if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
-        cur = tile_current(nxt);
-        o0 = n0;
-        o1 = (uint32_t)__shfl_down((int)o0, 1);
-        if (lane + 1 >= cur.nrec) o1 = cur.hi;
-        issue_dma(cur);  // next tile (the buffer is free: every read of the old tile has returned)
-        nxt = wtile_desc(a, t + 2 * stride, ntiles);
-        n0 = 0;
-        if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
     }
     // what is left in the bins (fewer than BIN_CAP tuples each) goes to the back part of the segments
     if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
