@@ -9,11 +9,16 @@
 namespace fa {
 
 // ---- per-lane work on a staged record (called by every lane of the workgroup) ------
-template <int MODE, uint32_t KEYSETS, uint32_t COLS>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// after_parse: called by the whole wave between the parse and the sink (the tile buffer is dead from there on,
+// unless the sketches use it as scratch) - the wave-tile kernel's early DMA issue (FA_WT_EARLY)
+template <int MODE, uint32_t KEYSETS, uint32_t COLS, class Hook = NoHook>
 __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, LdsMinutes& lm, uint32_t* part_cnt, const uint32_t* tile,
                                           bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
                                           uint32_t& n_ok, uint32_t& n_direct, uint32_t& lt_seen, uint32_t& lt_hits,
-                                          uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out) {
+                                          uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook()) {
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false;
     Rec r;
@@ -36,6 +41,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             a.retry_idx[j] = rec_idx;
         }
     }
+    after_parse();
     // ---- sink ----
     if (MODE == MODE_DECODE) {
         if (sure) store_columns(a.cols, rec_idx, r, 0);
@@ -79,14 +85,22 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                     // the last slot of a bin sends the 8 tuples off as one full, aligned 128-byte line (below)
                     // (acquire: the tuple write below must not move above the claim - the previous occupants of the bin
                     // are read by the flusher until it resets the word; release: the tuple is written before it counts)
+#if FA_WT_NBUF == 2 || FA_WT_EARLY
+                    const uint32_t slot = lds_add_rtn_u32(&bin_cnt[part], 1u) & 0xffffu;  // (asm: see table.cuh; in-order LDS + compiler barrier = the same acquire / release)
+#else
                     const uint32_t slot = __hip_atomic_fetch_add(&bin_cnt[part], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;  // low half: slots taken, high half: slots written
+#endif
                     if (slot < BIN_CAP) {
                         bins[part * BIN_CAP + slot] = tv;
+#if FA_WT_NBUF == 2 || FA_WT_EARLY
+                        lds_add_u32(&bin_cnt[part], 0x10000u);
+#else
                         __hip_atomic_fetch_add(&bin_cnt[part], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                         fill_part = slot == BIN_CAP - 1 ? part : fill_part;
                         pending = false;
                     } else {  // the bin is on its way out: single 16-byte store to the back part of the segment
-                        const uint32_t ob = atomicAdd(&part_cnt[part], 0x10000u) >> 16;
+                        const uint32_t ob = lds_add_rtn_u32(&part_cnt[part], 0x10000u) >> 16;
                         if (ob < a.capb) {
                             if (!(a.dbg & DBG_NO_TUPLE_STORE))
                                 a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob)] = tv;
@@ -438,8 +452,16 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
                                                  (__attribute__((address_space(3))) void*)(dst + (o - lane * 16u) / 4u), 16, 0, 2);
         }
     };
+#ifdef FA_WT_TIMING  // measurement builds only (tools/ab_db.sh): core clocks of wave 0 of every workgroup per round
+    uint32_t tm_wait = 0, tm_work = 0, tm_rest = 0, tm_tiles = 0;
+#define FA_WT_CLK(x) const uint32_t x = (uint32_t)clock64()
+#define FA_WT_ACC(w, k, r) (tm_wait += (w), tm_work += (k), tm_rest += (r), tm_tiles++)
+#else
+#define FA_WT_CLK(x)
+#define FA_WT_ACC(w, k, r)
+#endif
     // parse + sink of the wave's current tile (staged in buffer tb)
-    auto consume = [&](uint32_t* tb, uint32_t& fill) {
+    auto consume = [&](uint32_t* tb, uint32_t& fill, auto&& after_parse) {
         if (cur.nrec != 0) {
             const uint32_t cbase = cur.lo & ~15u;
             bool mine = tile_fits<WT_STRIDE - 16>(cur) && lane < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
@@ -449,7 +471,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
                 a.exotic_idx[j] = cur.r0 + lane;
             }
             lane_work<MODE_INGEST, KEYSETS, COLS>(a, lt, lm, part_cnt, tb, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, n_ok,
-                                                  n_direct, lt_seen, lt_hits, bins, bin_cnt, fill);
+                                                  n_direct, lt_seen, lt_hits, bins, bin_cnt, fill, after_parse);
         }
     };
     // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous
@@ -459,11 +481,48 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     WTileDesc nxt = wtile_desc(a, t + stride, ntiles);
     uint32_t n0 = 0;
     if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
-    if constexpr (WT_NBUF == 1) {
+    if constexpr (WT_NBUF == 1 && WT_EARLY && !(KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
+        // One buffer, early issue: the tile buffer is dead once the wave has parsed it, so the next DMA is issued
+        // between the parse and the sink and flies while the tuples are sunk.  The full bins of a round leave at the
+        // top of the NEXT round, behind the wait and before the parse: their line stores are then older than the
+        // DMA (the in-order vmcnt wait never sits behind fresh write acknowledgements).  The sink's LDS atomics are
+        // issued from inline asm (table.cuh) - the compiler would drain vmcnt before each of them.
+        uint32_t fill = 0xffffffffu;
         for (uint32_t round = 0; round < rounds; round++, t += stride) {
+            FA_WT_CLK(c0);
+            dma_wait_all();
+            FA_WT_CLK(c1);
+            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
+            fill = 0xffffffffu;
+            FA_WT_CLK(c2);
+            WTileDesc d1{0, 0, 0, 0};
+            uint32_t p0 = 0, p1 = 0;
+            consume(tile, fill, [&]() {
+                d1 = tile_current(nxt);
+                p0 = n0;
+                p1 = (uint32_t)__shfl_down((int)p0, 1);
+                if (lane + 1 >= d1.nrec) p1 = d1.hi;
+                issue_dma(d1, tile);
+                nxt = wtile_desc(a, t + 2 * stride, ntiles);
+                n0 = 0;
+                if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
+            });
+            FA_WT_CLK(c3);
+            FA_WT_ACC(c1 - c0, c3 - c2, c2 - c1);
+            cur = d1;
+            o0 = p0;
+            o1 = p1;
+        }
+        dma_wait_all();
+        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
+    } else if constexpr (WT_NBUF == 1) {
+        for (uint32_t round = 0; round < rounds; round++, t += stride) {
+            FA_WT_CLK(c0);
             dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
+            FA_WT_CLK(c1);
             uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
-            consume(tile, fill);
+            consume(tile, fill, NoHook());
+            FA_WT_CLK(c2);
             // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
             // queue and the wave would wait for the write acknowledgements on top of its tile (measured: +15 %)
             if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
@@ -475,6 +534,8 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
             nxt = wtile_desc(a, t + 2 * stride, ntiles);
             n0 = 0;
             if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
+            FA_WT_CLK(c3);
+            FA_WT_ACC(c1 - c0, c2 - c1, c3 - c2);
         }
     } else {
         // Two buffers per wave: round r parses buffer r & 1 while tile r + 1 flies into the other one.  Order inside a
@@ -485,7 +546,9 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
         uint32_t* tile2 = tiles2 + wave * (WT_STRIDE / 4);
         uint32_t fill = 0xffffffffu;
         auto body = [&](uint32_t* tb_cur, uint32_t* tb_next) {
+            FA_WT_CLK(c0);
             dma_wait_all();
+            FA_WT_CLK(c1);
             if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
             fill = 0xffffffffu;
             const WTileDesc d1 = tile_current(nxt);
@@ -496,7 +559,10 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
             nxt = wtile_desc(a, t + 2 * stride, ntiles);
             n0 = 0;
             if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
-            consume(tb_cur, fill);
+            FA_WT_CLK(c2);
+            consume(tb_cur, fill, NoHook());
+            FA_WT_CLK(c3);
+            FA_WT_ACC(c1 - c0, c3 - c2, c2 - c1);
             cur = d1;
             o0 = p0;
             o1 = p1;
@@ -510,6 +576,16 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
         dma_wait_all();  // (nothing useful in flight: the tile past the end is empty)
         if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
     }
+#ifdef FA_WT_TIMING
+    if (tid == 0) {  // wait: DMA wait at the top of a round; work: parse + sink; rest (reported as "total"): flush + DMA issue + bounds
+        atomicAdd(&a.ctr->t_wait, (unsigned long long)tm_wait);
+        atomicAdd(&a.ctr->t_work, (unsigned long long)tm_work);
+        atomicAdd(&a.ctr->t_total, (unsigned long long)tm_rest);
+        atomicAdd(&a.ctr->t_tiles, (unsigned long long)tm_tiles);
+    }
+#endif
+#undef FA_WT_CLK
+#undef FA_WT_ACC
     // what is left in the bins (fewer than BIN_CAP tuples each) goes to the back part of the segments
     if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
         __syncthreads();

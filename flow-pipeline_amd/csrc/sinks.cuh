@@ -32,6 +32,10 @@ constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
 #ifndef FA_WT_STRIDE
 #define FA_WT_STRIDE (FA_WT_NBUF == 2 ? 4864 : 5472)
 #endif
+#ifndef FA_WT_EARLY
+#define FA_WT_EARLY 0
+#endif
+constexpr bool WT_EARLY = FA_WT_EARLY != 0;  // one buffer, next DMA issued between the parse and the sink (experiment)
 constexpr int WT_NBUF = FA_WT_NBUF;
 constexpr int WBLOCK = FA_WBLOCK;   // 8 (12) waves, each with private LDS tile(s) of <= 64 records
 constexpr int WT_RECS = 64;

@@ -19,7 +19,49 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// FA_WT_NBUF (sinks.cuh: tile buffers per wave of the wave-tile kernel) also selects how the per-record LDS
+// atomics are issued: with two buffers a tile DMA is in flight while records are sunk, and the compiler
+// drains vmcnt before EVERY LDS atomic it emits while an LDS-DMA is outstanding (atomics carry no alias scope,
+// so it cannot tell the tile buffers from the tables).  Issued from inline asm they do not wait.
+#ifndef FA_WT_NBUF
+#define FA_WT_NBUF 1
+#endif
+
 namespace fa {
+
+#ifndef FA_WT_EARLY
+#define FA_WT_EARLY 0
+#endif
+#if (FA_WT_NBUF == 2 || FA_WT_EARLY) && defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+// (LDS operations of a wave execute in order; the "memory" clobber keeps the compiler's own LDS accesses on
+// their side of the atomic; an lgkmcnt(0) more than the compiler expects only makes its later waits stricter)
+__device__ __forceinline__ uint32_t lds_add_rtn_u32(uint32_t* p, uint32_t v) {
+    uint32_t r;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(lds_addr(p)), "v"(v) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_add_u32(uint32_t* p, uint32_t v) {
+    asm volatile("ds_add_u32 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_add_u64(unsigned long long* p, unsigned long long v) {
+    asm volatile("ds_add_u64 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned long long lds_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long val) {
+    unsigned long long r;
+    asm volatile("ds_cmpst_rtn_b64 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(lds_addr(p)), "v"(cmp), "v"(val) : "memory");
+    return r;
+}
+#else
+__device__ __forceinline__ uint32_t lds_add_rtn_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+__device__ __forceinline__ void lds_add_u32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
+__device__ __forceinline__ void lds_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
+__device__ __forceinline__ unsigned long long lds_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long val) {
+    return atomicCAS(p, cmp, val);
+}
+#endif
 
 struct __attribute__((aligned(64))) Slot {
     unsigned long long k0, k1;
@@ -116,14 +158,14 @@ __device__ __forceinline__ bool lds_table_add(LdsTable<SLOTS>& t, uint64_t k0, u
 #pragma unroll 1
     for (int probe = 0; probe < PROBES; probe++, i = (i + 1) & (SLOTS - 1)) {
         unsigned long long c0 = t.k0[i];
-        if (c0 == 0) c0 = atomicCAS(&t.k0[i], 0ull, (unsigned long long)k0);
+        if (c0 == 0) c0 = lds_cas_u64(&t.k0[i], 0ull, (unsigned long long)k0);
         if (c0 != 0 && c0 != k0) continue;
         unsigned long long c1 = t.k1[i];
-        if (c1 == 0) c1 = atomicCAS(&t.k1[i], 0ull, (unsigned long long)k1);
+        if (c1 == 0) c1 = lds_cas_u64(&t.k1[i], 0ull, (unsigned long long)k1);
         if (c1 != 0 && c1 != k1) continue;
-        if (bytes) atomicAdd(&t.bytes[i], (unsigned long long)bytes);
-        if (packets) atomicAdd(&t.packets[i], (unsigned long long)packets);
-        atomicAdd(&t.count[i], (unsigned long long)count);
+        if (bytes) lds_add_u64(&t.bytes[i], (unsigned long long)bytes);
+        if (packets) lds_add_u64(&t.packets[i], (unsigned long long)packets);
+        lds_add_u64(&t.count[i], (unsigned long long)count);
         return true;
     }
     return false;
