@@ -434,7 +434,28 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
     const uint32_t stride = gridDim.x * WAVES;
     const uint32_t rounds = (ntiles + stride - 1) / stride;  // the same for every wave of the grid (flush barriers)
+#if FA_WT_DYN
+    // Dynamic tile assignment inside the workgroup (default; -DFA_WT_DYN=0 restores the static split): workgroup b
+    // owns the tiles k * gridDim.x + b and its waves draw k from an LDS counter two rounds ahead (the bounds of a
+    // tile are prefetched a round before its DMA), so a wave that runs slower (crowded SIMD, younger wave slot)
+    // simply takes fewer tiles - with the static split every wave runs the same number of rounds and the launch
+    // lasts as long as its slowest wave.
+    __shared__ uint32_t next_k;
+    if (tid == 0) next_k = 2u * WAVES;
+    uint32_t t = wave * gridDim.x + blockIdx.x;
+    const uint32_t t_second = (wave + WAVES) * gridDim.x + blockIdx.x;
+    auto tile_after_next = [&]() {
+        uint32_t k = 0;
+        if (lane == 0) k = lds_add_rtn_u32(&next_k, 1u);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)k) * gridDim.x + blockIdx.x;
+    };
+#define FA_WT_MORE(round) ((void)(round), (void)rounds, cur.nrec != 0)
+#else
     uint32_t t = blockIdx.x * WAVES + wave;
+    const uint32_t t_second = t + stride;
+    auto tile_after_next = [&]() { return t + 2 * stride; };  // (t advances by stride per round)
+#define FA_WT_MORE(round) ((round) < rounds)
+#endif
     WTileDesc cur = tile_current(wtile_desc(a, t, ntiles));
     uint32_t o0 = 0, o1 = 0;
     const bool lane_off = !(a.dbg & DBG_NO_LANE_OFF);
@@ -478,7 +499,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     // tile was consumed, BEFORE the flush barriers, so that the memory system stays busy during a flush) and
     // the descriptor + offsets of the tile after it are in flight
     issue_dma(cur, tile);
-    WTileDesc nxt = wtile_desc(a, t + stride, ntiles);
+    WTileDesc nxt = wtile_desc(a, t_second, ntiles);
     uint32_t n0 = 0;
     if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
     if constexpr (WT_NBUF == 1 && WT_EARLY && !(KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
@@ -488,7 +509,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
         // DMA (the in-order vmcnt wait never sits behind fresh write acknowledgements).  The sink's LDS atomics are
         // issued from inline asm (table.cuh) - the compiler would drain vmcnt before each of them.
         uint32_t fill = 0xffffffffu;
-        for (uint32_t round = 0; round < rounds; round++, t += stride) {
+        for (uint32_t round = 0; FA_WT_MORE(round); round++, t += stride) {
             FA_WT_CLK(c0);
             dma_wait_all();
             FA_WT_CLK(c1);
@@ -503,7 +524,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
                 p1 = (uint32_t)__shfl_down((int)p0, 1);
                 if (lane + 1 >= d1.nrec) p1 = d1.hi;
                 issue_dma(d1, tile);
-                nxt = wtile_desc(a, t + 2 * stride, ntiles);
+                nxt = wtile_desc(a, tile_after_next(), ntiles);
                 n0 = 0;
                 if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
             });
@@ -516,7 +537,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
         dma_wait_all();
         if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
     } else if constexpr (WT_NBUF == 1) {
-        for (uint32_t round = 0; round < rounds; round++, t += stride) {
+        for (uint32_t round = 0; FA_WT_MORE(round); round++, t += stride) {
             FA_WT_CLK(c0);
             dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
             FA_WT_CLK(c1);
@@ -526,12 +547,13 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
             // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
             // queue and the wave would wait for the write acknowledgements on top of its tile (measured: +15 %)
             if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
+            const uint32_t t2 = tile_after_next();  // (dynamic: an LDS atomic - before the DMA, or the compiler drains vmcnt for it)
             cur = tile_current(nxt);
             o0 = n0;
             o1 = (uint32_t)__shfl_down((int)o0, 1);
             if (lane + 1 >= cur.nrec) o1 = cur.hi;
             issue_dma(cur, tile);  // next tile (the buffer is free: every read of the old tile has returned)
-            nxt = wtile_desc(a, t + 2 * stride, ntiles);
+            nxt = wtile_desc(a, t2, ntiles);
             n0 = 0;
             if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
             FA_WT_CLK(c3);
@@ -586,6 +608,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
 #endif
 #undef FA_WT_CLK
 #undef FA_WT_ACC
+#undef FA_WT_MORE
     // what is left in the bins (fewer than BIN_CAP tuples each) goes to the back part of the segments
     if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
         __syncthreads();

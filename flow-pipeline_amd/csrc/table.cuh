@@ -32,6 +32,9 @@ namespace fa {
 #ifndef FA_WT_EARLY
 #define FA_WT_EARLY 0
 #endif
+#ifndef FA_WT_DYN
+#define FA_WT_DYN 1  // dynamic tile assignment inside a workgroup (ingest.cuh): -2..3 % launch time, see DESIGN.md
+#endif
 #if (FA_WT_NBUF == 2 || FA_WT_EARLY) && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
