@@ -442,12 +442,19 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     // lasts as long as its slowest wave.
     __shared__ uint32_t next_k;
     if (tid == 0) next_k = 2u * WAVES;
-    uint32_t t = wave * gridDim.x + blockIdx.x;
-    const uint32_t t_second = (wave + WAVES) * gridDim.x + blockIdx.x;
+#if FA_WT_XCD
+    // neighbouring tiles share a 128-byte line: keep them on one XCD (workgroups go to the XCDs round-robin), so
+    // that the line is fetched into one L2
+    const uint32_t wg_pos = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+#else
+    const uint32_t wg_pos = blockIdx.x;
+#endif
+    uint32_t t = wave * gridDim.x + wg_pos;
+    const uint32_t t_second = (wave + WAVES) * gridDim.x + wg_pos;
     auto tile_after_next = [&]() {
         uint32_t k = 0;
         if (lane == 0) k = lds_add_rtn_u32(&next_k, 1u);
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)k) * gridDim.x + blockIdx.x;
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)k) * gridDim.x + wg_pos;
     };
 #define FA_WT_MORE(round) ((void)(round), (void)rounds, cur.nrec != 0)
 #else

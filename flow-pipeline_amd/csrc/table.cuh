@@ -32,6 +32,9 @@ namespace fa {
 #ifndef FA_WT_EARLY
 #define FA_WT_EARLY 0
 #endif
+#ifndef FA_WT_XCD
+#define FA_WT_XCD 1  // XCD-aware tile numbering of the dynamic draw (ingest.cuh): -2 % on config 2
+#endif
 #ifndef FA_WT_DYN
 #define FA_WT_DYN 1  // dynamic tile assignment inside a workgroup (ingest.cuh): -2..3 % launch time, see DESIGN.md
 #endif
