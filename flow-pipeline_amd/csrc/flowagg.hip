@@ -288,9 +288,9 @@ extern "C" void fa_destroy(fa_ctx* c) {
                 (unsigned long long)c->h_ctr->t_tiles, (double)c->h_ctr->t_total);
 #ifdef FA_WT_TIMING
     if ((c->dbg & DBG_TIMING) && c->h_ctr && c->h_ctr->t_tiles)
-        fprintf(stderr, "[flowagg wave-tile timing] per round: wait %.0f  parse+sink %.0f  flush+issue %.0f  (NBUF %d, %d waves/wg)\n",
+        fprintf(stderr, "[flowagg wave-tile timing] per round: wait %.0f  parse+sink %.0f  flush+issue %.0f  (%d waves/wg)\n",
                 (double)c->h_ctr->t_wait / (double)c->h_ctr->t_tiles, (double)c->h_ctr->t_work / (double)c->h_ctr->t_tiles,
-                (double)c->h_ctr->t_total / (double)c->h_ctr->t_tiles, WT_NBUF, WBLOCK / 64);
+                (double)c->h_ctr->t_total / (double)c->h_ctr->t_tiles, WBLOCK / 64);
 #endif
     (void)hipFree(c->tab);
     (void)hipFree(c->spill);

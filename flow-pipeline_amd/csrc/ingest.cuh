@@ -85,14 +85,14 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                     // the last slot of a bin sends the 8 tuples off as one full, aligned 128-byte line (below)
                     // (acquire: the tuple write below must not move above the claim - the previous occupants of the bin
                     // are read by the flusher until it resets the word; release: the tuple is written before it counts)
-#if FA_WT_NBUF == 2 || FA_WT_EARLY
+#if FA_WT_EARLY
                     const uint32_t slot = lds_add_rtn_u32(&bin_cnt[part], 1u) & 0xffffu;  // (asm: see table.cuh; in-order LDS + compiler barrier = the same acquire / release)
 #else
                     const uint32_t slot = __hip_atomic_fetch_add(&bin_cnt[part], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;  // low half: slots taken, high half: slots written
 #endif
                     if (slot < BIN_CAP) {
                         bins[part * BIN_CAP + slot] = tv;
-#if FA_WT_NBUF == 2 || FA_WT_EARLY
+#if FA_WT_EARLY
                         lds_add_u32(&bin_cnt[part], 0x10000u);
 #else
                         __hip_atomic_fetch_add(&bin_cnt[part], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -406,10 +406,7 @@ template <uint32_t KEYSETS>
 __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     constexpr uint32_t COLS = cols_for_keysets<KEYSETS>();
     constexpr int WAVES = WBLOCK / 64;
-    // (two buffers per wave live in two arrays: the compiler keys its "LDS-DMA still in flight" waits on the
-    // __shared__ variable, so reads of one array do not wait for the DMA into the other)
     __shared__ __attribute__((aligned(16))) uint32_t tiles[WAVES * WT_STRIDE / 4];
-    __shared__ __attribute__((aligned(16))) uint32_t tiles2[WT_NBUF == 2 ? WAVES * WT_STRIDE / 4 : 4];
     __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BIN_CAP];
     __shared__ uint32_t bin_cnt[NPART_MAX];
     __shared__ uint32_t part_cnt[NPART_MAX];
@@ -509,7 +506,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     WTileDesc nxt = wtile_desc(a, t_second, ntiles);
     uint32_t n0 = 0;
     if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
-    if constexpr (WT_NBUF == 1 && WT_EARLY && !(KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
+    if constexpr (WT_EARLY && !(KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
         // One buffer, early issue: the tile buffer is dead once the wave has parsed it, so the next DMA is issued
         // between the parse and the sink and flies while the tuples are sunk.  The full bins of a round leave at the
         // top of the NEXT round, behind the wait and before the parse: their line stores are then older than the
@@ -543,7 +540,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
         }
         dma_wait_all();
         if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
-    } else if constexpr (WT_NBUF == 1) {
+    } else {
         for (uint32_t round = 0; FA_WT_MORE(round); round++, t += stride) {
             FA_WT_CLK(c0);
             dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
@@ -566,44 +563,6 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
             FA_WT_CLK(c3);
             FA_WT_ACC(c1 - c0, c2 - c1, c3 - c2);
         }
-    } else {
-        // Two buffers per wave: round r parses buffer r & 1 while tile r + 1 flies into the other one.  Order inside a
-        // round: wait (tile r, the bounds of tile r + 1 and last round's line stores are all OLD by now) -> full bins of
-        // the previous round leave (their stores are issued before the DMA, so the next wait does not sit behind fresh
-        // write acknowledgements) -> DMA of tile r + 1 -> bounds of tile r + 2 -> parse + sink.  The body is
-        // instantiated once per buffer so that every LDS access names its array statically (see above).
-        uint32_t* tile2 = tiles2 + wave * (WT_STRIDE / 4);
-        uint32_t fill = 0xffffffffu;
-        auto body = [&](uint32_t* tb_cur, uint32_t* tb_next) {
-            FA_WT_CLK(c0);
-            dma_wait_all();
-            FA_WT_CLK(c1);
-            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
-            fill = 0xffffffffu;
-            const WTileDesc d1 = tile_current(nxt);
-            const uint32_t p0 = n0;
-            uint32_t p1 = (uint32_t)__shfl_down((int)p0, 1);
-            if (lane + 1 >= d1.nrec) p1 = d1.hi;
-            issue_dma(d1, tb_next);
-            nxt = wtile_desc(a, t + 2 * stride, ntiles);
-            n0 = 0;
-            if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
-            FA_WT_CLK(c2);
-            consume(tb_cur, fill, NoHook());
-            FA_WT_CLK(c3);
-            FA_WT_ACC(c1 - c0, c3 - c2, c2 - c1);
-            cur = d1;
-            o0 = p0;
-            o1 = p1;
-            t += stride;
-        };
-        for (uint32_t round = 0; round < rounds; round += 2) {
-            body(tile, tile2);
-            if (round + 1 >= rounds) break;
-            body(tile2, tile);
-        }
-        dma_wait_all();  // (nothing useful in flight: the tile past the end is empty)
-        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
     }
 #ifdef FA_WT_TIMING
     if (tid == 0) {  // wait: DMA wait at the top of a round; work: parse + sink; rest (reported as "total"): flush + DMA issue + bounds

@@ -20,28 +20,22 @@ constexpr int LDS_SLOTS = 64;      // per-workgroup hot-key slots (2.5 KiB)
 constexpr int LDS_PROBES = 2;
 constexpr int PART_LOG2_MAX = 8;   // key partitions of the scatter sink (<= 256: see tools/scatter_bench.hip)
 constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
-// wave-tile kernel residency.  FA_WT_NBUF=1 (default): 2 workgroups x 8 waves per CU, one LDS tile per wave.
-// FA_WT_NBUF=2 (experiment, `make EXTRA=-DFA_WT_NBUF=2`): 1 workgroup x 12 waves per CU, TWO tiles per wave - the
-// next tile is in flight while the current one is parsed (see wtile_kernel).
-#ifndef FA_WT_NBUF
-#define FA_WT_NBUF 1
-#endif
+// wave-tile kernel residency: 2 workgroups x 8 waves per CU, one LDS tile per wave (what the 160 KiB of LDS admit
+// next to the tuple bins).  FA_WBLOCK / FA_WT_STRIDE: geometry experiments (tools/wave_scaling.sh).
 #ifndef FA_WBLOCK
-#define FA_WBLOCK (FA_WT_NBUF == 2 ? 768 : 512)
+#define FA_WBLOCK 512
 #endif
 #ifndef FA_WT_STRIDE
-#define FA_WT_STRIDE (FA_WT_NBUF == 2 ? 4864 : 5472)
+#define FA_WT_STRIDE 5472
 #endif
 #ifndef FA_WT_EARLY
 #define FA_WT_EARLY 0
 #endif
-constexpr bool WT_EARLY = FA_WT_EARLY != 0;  // one buffer, next DMA issued between the parse and the sink (experiment)
-constexpr int WT_NBUF = FA_WT_NBUF;
-constexpr int WBLOCK = FA_WBLOCK;   // 8 (12) waves, each with private LDS tile(s) of <= 64 records
+constexpr bool WT_EARLY = FA_WT_EARLY != 0;  // next DMA issued between the parse and the sink (experiment)
+constexpr int WBLOCK = FA_WBLOCK;   // 8 waves, each with a private LDS tile of <= 64 records
 constexpr int WT_RECS = 64;
 constexpr int WT_STRIDE = FA_WT_STRIDE;  // 5472 = 64 records x 85 B + alignment slack (16-byte multiple); overreads land in the next tile / the bins
-constexpr int WT_WG_PER_CU = WT_NBUF == 2 ? 1 : 2;  // what the 160 KiB of LDS admit
-static_assert(WT_NBUF == 1 || WT_NBUF == 2, "one or two tile buffers per wave");
+constexpr int WT_WG_PER_CU = 2;
 static_assert(WBLOCK % 64 == 0 && WBLOCK >= 256 && WBLOCK <= 1024 && WT_STRIDE % 16 == 0, "wave-tile geometry");
 constexpr uint32_t BIN_CAP = 8;     // a bin = one 128-byte line of tuples per key partition (256 x 8 x 16 B = 32 KiB per workgroup)
 constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table

@@ -19,16 +19,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// FA_WT_NBUF (sinks.cuh: tile buffers per wave of the wave-tile kernel) also selects how the per-record LDS
-// atomics are issued: with two buffers a tile DMA is in flight while records are sunk, and the compiler
-// drains vmcnt before EVERY LDS atomic it emits while an LDS-DMA is outstanding (atomics carry no alias scope,
-// so it cannot tell the tile buffers from the tables).  Issued from inline asm they do not wait.
-#ifndef FA_WT_NBUF
-#define FA_WT_NBUF 1
-#endif
-
-namespace fa {
-
+// FA_WT_EARLY (early DMA issue in the wave-tile kernel, ingest.cuh) also selects how the per-record LDS atomics are
+// issued: a tile DMA is then in flight while records are sunk, and the compiler drains vmcnt before EVERY LDS atomic
+// it emits while an LDS-DMA is outstanding (atomics carry no alias scope, so it cannot tell the tile buffers from
+// the tables).  Issued from inline asm they do not wait.
 #ifndef FA_WT_EARLY
 #define FA_WT_EARLY 0
 #endif
@@ -38,7 +32,10 @@ namespace fa {
 #ifndef FA_WT_DYN
 #define FA_WT_DYN 1  // dynamic tile assignment inside a workgroup (ingest.cuh): -2..3 % launch time, see DESIGN.md
 #endif
-#if (FA_WT_NBUF == 2 || FA_WT_EARLY) && defined(__HIP_DEVICE_COMPILE__)
+
+namespace fa {
+
+#if FA_WT_EARLY && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
 }

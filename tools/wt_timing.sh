@@ -1,11 +1,12 @@
 #!/bin/bash
 # Per-round phase timing of the wave-tile kernel (measurement builds: make OUT=../libflowagg_t1.so EXTRA=-DFA_WT_TIMING,
-# ..._t2.so EXTRA="-DFA_WT_NBUF=2 -DFA_WT_TIMING", ..._t2w8.so the same with -DFA_WBLOCK=512 -DFA_WT_STRIDE=5472).
+# ..._te.so EXTRA="-DFA_WT_EARLY=1 -DFA_WT_TIMING"; the t2 / t2w8 libraries of profiles/r01_wtile_phase_timing_s5.txt were the
+# double-buffered kernel of commit f4ed14a).
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 O=gpurun_out/wt_timing.txt
 : > $O
-for v in t1 t2 t2w8; do
+for v in t1 te; do
   for fl in 1024 1025 1041; do
     for mode in aspairs mocker; do
       echo "== lib $v FA_DEBUG_FLAGS=$fl mode $mode" >> $O
