@@ -329,8 +329,12 @@ static int rebuild_table(fa_ctx* c, uint32_t new_log2, uint32_t tb_lo, uint32_t 
     size_t bytes = sizeof(Slot) << new_log2;
     hipError_t e = hipMalloc(&nt, bytes);
     if (e != hipSuccess) return fail(c, FA_ERR_NOMEM, "rebuild_table: hipMalloc failed");
-    HIPCHK(c, hipMemsetAsync(nt, 0, bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(&c->d_ctr->used, 0, sizeof(unsigned long long), c->stream));
+    if ((e = hipMemsetAsync(nt, 0, bytes, c->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(&c->d_ctr->used, 0, sizeof(unsigned long long), c->stream)) != hipSuccess) {
+        (void)hipFree(nt);  // the old table stays in place
+        c->err = std::string("rebuild_table: ") + hipGetErrorString(e);
+        return FA_ERR_HIP;
+    }
     Slot* old = c->tab;
     uint32_t old_slots = 1u << c->cap_log2;
     c->tab = nt;
@@ -351,8 +355,13 @@ static int rebuild_wide(fa_ctx* c, uint32_t new_log2, uint32_t kind_mask, uint32
     WSlot* nt = nullptr;
     size_t bytes = sizeof(WSlot) << new_log2;
     if (hipMalloc(&nt, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "rebuild_wide: hipMalloc failed");
-    HIPCHK(c, hipMemsetAsync(nt, 0, bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(&c->d_ctr->wused, 0, sizeof(unsigned long long), c->stream));
+    hipError_t e;
+    if ((e = hipMemsetAsync(nt, 0, bytes, c->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(&c->d_ctr->wused, 0, sizeof(unsigned long long), c->stream)) != hipSuccess) {
+        (void)hipFree(nt);  // the old table stays in place
+        c->err = std::string("rebuild_wide: ") + hipGetErrorString(e);
+        return FA_ERR_HIP;
+    }
     WSlot* old = c->wtab;
     uint32_t old_slots = 1u << c->wcap_log2;
     c->wtab = nt;
