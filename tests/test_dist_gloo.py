@@ -65,6 +65,19 @@ def _worker(rank, world, port, q):
         ok = ok and ports.tobytes() == po.top_ports(rows, status, dst).tobytes()
     mins = d.merge_minutes_host(d.allgather_struct(po.minute_series(rows[sel], status[sel]), d.MINUTE_ROW_DTYPE, device="cpu"))
     ok = ok and mins.tobytes() == po.minute_series(rows, status).tobytes()
+    # BASELINE config 4 shape on the CPU: per-shard Count-Min sketch -> all-reduce == the sketch of the whole stream bit
+    # for bit; the ranks' candidate keys -> all-gather -> union == every distinct key (dist.topk_merged's exchange)
+    good = status == 0
+    with np.errstate(over="ignore"):
+        w = rows["bytes"] * rows["sampling_rate"]
+    mysk = po.cms_sketch_numpy(rows["src_addr"][sel & good], w[sel & good], 4, 12, 7)
+    ts = torch.from_numpy(mysk.view(np.int64))
+    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    ok = ok and mysk.tobytes() == po.cms_sketch_numpy(rows["src_addr"][good], w[good], 4, 12, 7).tobytes()
+    mykeys = np.unique(np.ascontiguousarray(rows["src_addr"][sel & good]).view([("k", "u1", 16)]).reshape(-1)).view(np.uint8).reshape(-1, 16)
+    union = d.merge_topk_candidates(d.allgather_bytes(mykeys, device="cpu"))
+    allkeys = np.unique(np.ascontiguousarray(rows["src_addr"][good]).view([("k", "u1", 16)]).reshape(-1)).view(np.uint8).reshape(-1, 16)
+    ok = ok and union.tobytes() == allkeys.tobytes() and len(union) > len(mykeys)
     q.put((rank, ok, len(merged), len(mine)))
     dist.destroy_process_group()
 
