@@ -522,7 +522,8 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
             FA_WT_CLK(c2);
             WTileDesc d1{0, 0, 0, 0};
             uint32_t p0 = 0, p1 = 0;
-            consume(tile, fill, [&]() {
+            bool issued = false;
+            auto issue_next = [&]() {
                 d1 = tile_current(nxt);
                 p0 = n0;
                 p1 = (uint32_t)__shfl_down((int)p0, 1);
@@ -531,7 +532,15 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
                 nxt = wtile_desc(a, tile_after_next(), ntiles);
                 n0 = 0;
                 if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
+                issued = true;
+            };
+            // FA_WT_EARLY=1: always early.  =2: early only while this wave's hot-key table absorbs its records (then the
+            // sink is a handful of LDS atomics and the DMA gains a head start); once the wave has given the table up
+            // (lt_seen == ~0: the tuples go through the bins) the DMA is issued after the sink as in the default kernel.
+            consume(tile, fill, [&]() {
+                if (FA_WT_EARLY == 1 || lt_seen != 0xffffffffu) issue_next();
             });
+            if (!issued) issue_next();
             FA_WT_CLK(c3);
             FA_WT_ACC(c1 - c0, c3 - c2, c2 - c1);
             cur = d1;

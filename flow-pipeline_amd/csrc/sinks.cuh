@@ -31,7 +31,7 @@ constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
 #ifndef FA_WT_EARLY
 #define FA_WT_EARLY 0
 #endif
-constexpr bool WT_EARLY = FA_WT_EARLY != 0;  // next DMA issued between the parse and the sink (experiment)
+constexpr bool WT_EARLY = FA_WT_EARLY != 0;  // next DMA issued between the parse and the sink (experiment): 1 always, 2 while the hot-key table is on
 constexpr int WBLOCK = FA_WBLOCK;   // 8 waves, each with a private LDS tile of <= 64 records
 constexpr int WT_RECS = 64;
 constexpr int WT_STRIDE = FA_WT_STRIDE;  // 5472 = 64 records x 85 B + alignment slack (16-byte multiple); overreads land in the next tile / the bins
