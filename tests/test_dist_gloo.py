@@ -112,3 +112,72 @@ def test_merge_rows_host_sums_duplicates():
     assert len(m) == 2 and list(m["timeslot"]) == [300, 600]
     assert list(m["bytes"]) == [1, 12] and list(m["count"]) == [2, 2]  # wraps mod 2^64
     assert fa.dist.partitions_of(1, 4, 8) == [1, 5]
+
+
+def test_host_merges_match_plain_dict_groupby():
+    """merge_rows_host / merge_rows_app_host / merge_ports_host / merge_minutes_host against a row-at-a-time dict
+    group-by on random partial row sets (duplicate keys inside and across parts, u64 wrap-around, empty parts)."""
+    sys.path.insert(0, ROOT)
+    import _pkg
+    d = _pkg.load().dist
+    rng = np.random.default_rng(5)
+    M = 2**64
+
+    def u64(n, big):
+        return rng.integers(0, 2**64 if big else 1000, n, dtype=np.uint64)
+
+    for trial in range(20):
+        nparts = int(rng.integers(1, 5))
+        big = trial % 2 == 0
+        # flows_5m rows
+        parts, ref = [], {}
+        for _ in range(nparts):
+            n = int(rng.integers(0, 60))
+            r = np.zeros(n, dtype=d.ROW5M_DTYPE)
+            r["timeslot"] = rng.integers(0, 3, n) * 300 + 86400 * rng.integers(0, 2, n)
+            r["date"] = r["timeslot"] // 86400
+            r["src_as"], r["dst_as"] = rng.integers(0, 3, n), rng.integers(0, 3, n)
+            r["etype"] = rng.choice([0x800, 0x86dd], n)
+            r["bytes"], r["packets"], r["count"] = u64(n, big), u64(n, big), u64(n, False)
+            parts.append(r)
+            for x in r:
+                k = (int(x["date"]), int(x["timeslot"]), int(x["src_as"]), int(x["dst_as"]), int(x["etype"]))
+                b, p, c = ref.get(k, (0, 0, 0))
+                ref[k] = ((b + int(x["bytes"])) % M, (p + int(x["packets"])) % M, (c + int(x["count"])) % M)
+        got = d.merge_rows_host(parts)
+        assert [(int(x["date"]), int(x["timeslot"]), int(x["src_as"]), int(x["dst_as"]), int(x["etype"])) for x in got] == sorted(ref)
+        assert [(int(x["bytes"]), int(x["packets"]), int(x["count"])) for x in got] == [ref[k] for k in sorted(ref)]
+        # (SrcAddr, DstPort, Proto) rows: sorted by the address BYTES
+        parts, ref = [], {}
+        for _ in range(nparts):
+            n = int(rng.integers(0, 60))
+            r = np.zeros(n, dtype=d.ROW_APP_DTYPE)
+            r["timeslot"] = rng.integers(0, 2, n) * 300
+            r["src_addr"] = rng.integers(0, 2, (n, 16)) * rng.integers(1, 256, (n, 16))
+            r["src_addr"][:, 2:15] = 0
+            r["dst_port"], r["proto"] = rng.integers(0, 3, n), rng.integers(0, 2, n)
+            r["bytes"], r["packets"], r["count"] = u64(n, big), u64(n, big), u64(n, False)
+            parts.append(r)
+            for x in r:
+                k = (int(x["date"]), int(x["timeslot"]), bytes(x["src_addr"]), int(x["dst_port"]), int(x["proto"]))
+                b, p, c = ref.get(k, (0, 0, 0))
+                ref[k] = ((b + int(x["bytes"])) % M, (p + int(x["packets"])) % M, (c + int(x["count"])) % M)
+        got = d.merge_rows_app_host(parts)
+        assert [(int(x["date"]), int(x["timeslot"]), bytes(x["src_addr"]), int(x["dst_port"]), int(x["proto"])) for x in got] == sorted(ref)
+        assert [(int(x["bytes"]), int(x["packets"]), int(x["count"])) for x in got] == [ref[k] for k in sorted(ref)]
+        # port group-by: ORDER BY weight DESC, port; minute series: ORDER BY minute
+        for dtype, key, merge in ((d.PORT_ROW_DTYPE, "port", d.merge_ports_host), (d.MINUTE_ROW_DTYPE, "minute", d.merge_minutes_host)):
+            parts, ref = [], {}
+            for _ in range(nparts):
+                n = int(rng.integers(0, 40))
+                r = np.zeros(n, dtype=dtype)
+                r[key] = rng.integers(0, 12, n)
+                r["weight"], r["count"] = u64(n, big), u64(n, False)
+                parts.append(r)
+                for x in r:
+                    w, c = ref.get(int(x[key]), (0, 0))
+                    ref[int(x[key])] = ((w + int(x["weight"])) % M, (c + int(x["count"])) % M)
+            got = merge(parts)
+            order = sorted(ref, key=(lambda k: (-ref[k][0], k)) if key == "port" else (lambda k: k))
+            assert [int(x[key]) for x in got] == order
+            assert [(int(x["weight"]), int(x["count"])) for x in got] == [ref[k] for k in order]
