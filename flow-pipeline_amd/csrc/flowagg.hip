@@ -291,6 +291,14 @@ extern "C" void fa_destroy(fa_ctx* c) {
         fprintf(stderr, "[flowagg wave-tile timing] per round: wait %.0f  parse+sink %.0f  flush+issue %.0f  (%d waves/wg)\n",
                 (double)c->h_ctr->t_wait / (double)c->h_ctr->t_tiles, (double)c->h_ctr->t_work / (double)c->h_ctr->t_tiles,
                 (double)c->h_ctr->t_total / (double)c->h_ctr->t_tiles, WBLOCK / 64);
+    if ((c->dbg & DBG_TIMING) && c->h_ctr && c->h_ctr->t_tiles)
+        for (int w = 0; w < WBLOCK / 64 && w < 16; w++) {
+            const unsigned long long* t = c->h_ctr->t_slot[w];
+            if (t[3])
+                fprintf(stderr, "[flowagg wave-tile timing] wave slot %2d: %9llu tiles  per tile: wait %.0f  parse+sink %.0f  flush+issue %.0f  | loop clocks (sum over workgroups) per launch %.0f\n",
+                        w, t[3], (double)t[0] / (double)t[3], (double)t[1] / (double)t[3], (double)t[2] / (double)t[3],
+                        (double)t[4] / (double)std::max<uint64_t>(c->stats.wave_tile_launches, 1));
+        }
 #endif
     (void)hipFree(c->tab);
     (void)hipFree(c->spill);

@@ -479,6 +479,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     };
 #ifdef FA_WT_TIMING  // measurement builds only (tools/ab_db.sh): core clocks of wave 0 of every workgroup per round
     uint32_t tm_wait = 0, tm_work = 0, tm_rest = 0, tm_tiles = 0;
+    const uint32_t tm_start = (uint32_t)clock64();
 #define FA_WT_CLK(x) const uint32_t x = (uint32_t)clock64()
 #define FA_WT_ACC(w, k, r) (tm_wait += (w), tm_work += (k), tm_rest += (r), tm_tiles++)
 #else
@@ -579,6 +580,13 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
         atomicAdd(&a.ctr->t_work, (unsigned long long)tm_work);
         atomicAdd(&a.ctr->t_total, (unsigned long long)tm_rest);
         atomicAdd(&a.ctr->t_tiles, (unsigned long long)tm_tiles);
+    }
+    if (lane == 0 && wave < 16u) {  // every wave slot: how even is the work, when does each slot leave the loop
+        atomicAdd(&a.ctr->t_slot[wave][0], (unsigned long long)tm_wait);
+        atomicAdd(&a.ctr->t_slot[wave][1], (unsigned long long)tm_work);
+        atomicAdd(&a.ctr->t_slot[wave][2], (unsigned long long)tm_rest);
+        atomicAdd(&a.ctr->t_slot[wave][3], (unsigned long long)tm_tiles);
+        atomicAdd(&a.ctr->t_slot[wave][4], (unsigned long long)((uint32_t)clock64() - tm_start));
     }
 #endif
 #undef FA_WT_CLK

@@ -73,6 +73,9 @@ struct Counters {
     unsigned long long t_wait, t_work, t_tiles, t_total;  // DBG_TIMING: core-clock cycles of wave 0 of every workgroup
     unsigned long long wused, wspill_lost;  // wide table (wide.cuh)
     unsigned int wspill_count, wrows_count;
+#ifdef FA_WT_TIMING  // measurement builds: per wave slot of the wave-tile kernel {wait, parse+sink, flush+issue, tiles, loop clocks}
+    unsigned long long t_slot[16][5];
+#endif
 };
 
 // Distinct-address set behind fa_topk (the dashboards rank EVERY address,
