@@ -44,64 +44,89 @@ constexpr int AGG_SU = FA_AGG_SU;  // segments a wave reads at a time (16-byte l
 constexpr int AGG_PAD = AGG_SU * 8;  // zero counts behind the last segment (the back pass reads 8 segments per load)
 constexpr int AGG_CH = 4;  // tuples of a batch that are hashed / probed together
 
+// 16-byte loads a lane has in flight per batch: AGG_SU wide tuples, or half as many pieces of compact tuples (the
+// same number of tuples per batch - and of registers per chunk: 1024 threads leave 128 VGPRs per lane)
+template <bool T8>
+constexpr int agg_su() { return T8 ? (AGG_SU + 1) / 2 : AGG_SU; }
 struct AggBatch {
-    uint4 t[AGG_SU];
-    uint32_t v;  // bit s: t[s] is a tuple of this lane (not a dummy load)
+    uint4 t[AGG_SU];  // 16 bytes per load: one wide tuple or two compact ones
+    uint32_t v;       // wide: bit s = t[s] is a tuple of this lane (not a dummy load); compact: bits 2s, 2s+1 = its two halves
 };
 
 // issue the loads of lanes [0,64) of AGG_SU consecutive segments starting at w0.  The segment counts
 // come from LDS (pc, zero padded): a count read from global memory would put a full vmcnt drain between
 // consecutive tuple loads.
-// Front parts: chunk level j = tuples [64j, 64j+64) of a segment, one segment per 64 lanes.
-// Back parts (a handful of tuples each): level j = tuples [8j, 8j+8) of the c tuples that end at the segment's
-// last slot, EIGHT segments per 64 lanes.  Loads are unconditional (lanes without a tuple re-read slot 0 of a
+// Front parts: chunk level j = 16-byte pieces [64j, 64j+64) of a segment, one segment per 64 lanes.
+// Back parts (a handful of tuples each): level j = pieces [8j, 8j+8) of the c tuples that end at the segment's
+// last slot, EIGHT segments per 64 lanes.  Loads are unconditional (lanes without a tuple re-read piece 0 of a
 // valid segment): with predicated loads the compiler cannot count what is in flight and drains everything
 // (vmcnt(0)) before the previous batch is consumed.
-template <bool BACK>
+template <bool BACK, bool T8>
 __device__ __forceinline__ void agg_fetch(const KArgs& a, const uint4* pbase, const uint32_t* pc, uint32_t w0, uint32_t lane,
                                           uint32_t j, AggBatch& b) {
     constexpr uint32_t SEGS = BACK ? 8u : 1u, PER = 64u / SEGS;  // segments per load, lanes per segment
+    constexpr uint32_t TPP = T8 ? 2u : 1u;                         // tuples per 16-byte piece
     uint32_t idx[AGG_SU], seg[AGG_SU];
     b.v = 0;
 #pragma unroll
-    for (int s = 0; s < AGG_SU; s++) {
+    for (int s = 0; s < agg_su<T8>(); s++) {
         seg[s] = w0 + (uint32_t)s * SEGS + (BACK ? lane / PER : 0u);
         const uint32_t c = pc[min(seg[s], (uint32_t)(AGG_MAX_NWG + AGG_PAD - 1))];  // 0 past nwg
-        const uint32_t q = PER * j + (BACK ? lane % PER : lane);
-        const bool valid = q < c;
-        b.v |= valid ? 1u << s : 0u;
-        idx[s] = valid ? (BACK ? a.capq - c : 0u) + q : 0u;
+        const uint32_t first = BACK ? a.capq - c : 0u;                     // first tuple of the part (capq - c may be odd)
+        const uint32_t piece = first / TPP + PER * j + (BACK ? lane % PER : lane);  // 16-byte piece of the segment
+        uint32_t valid = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < TPP; e++) {
+            const uint32_t q = piece * TPP + e;  // tuple index inside the segment
+            valid |= (q >= first && q < first + c) ? 1u << e : 0u;
+        }
+        b.v |= valid << (TPP * s);
+        idx[s] = valid ? piece : 0u;
     }
 #pragma unroll
-    for (int s = 0; s < AGG_SU; s++) b.t[s] = pbase[(size_t)min(seg[s], a.nwg - 1u) * a.capq + idx[s]];
+    for (int s = 0; s < agg_su<T8>(); s++) b.t[s] = pbase[(size_t)min(seg[s], a.nwg - 1u) * (a.capq / TPP) + idx[s]];
 }
 
+// tuple e of a batch, as values (wide: e = piece; compact: e >> 1 = piece, e & 1 = half)
+template <bool T8>
+__device__ __forceinline__ void agg_vals(const AggBatch& b, int e, uint32_t part, TupleVals& v) {
+    if (T8) {
+        const uint4& q = b.t[e >> 1];
+        t8_unpack((e & 1) ? make_uint2(q.z, q.w) : make_uint2(q.x, q.y), part, v);
+    } else {
+        tup16_unpack(b.t[e], v);
+    }
+}
+
+// slow path for one tuple (wide form): probing LDS upsert, then the device-wide table
 __device__ __forceinline__ void agg_tuple(const KArgs& a, AggTable& lt, uint32_t tb_base, const uint4& t) {
-    const uint32_t by = t.z & 0x0fffffffu, tbr = t.z >> 28, pk = t.w & 0x7fffu, et = t.w >> 15;
+    TupleVals v;
+    tup16_unpack(t, v);
     uint64_t k0, k1;
-    pack_key(tb_base + tbr, t.x, t.y, et, k0, k1);
+    pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);
     const uint32_t h = key_hash(k0, k1);
-    const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
-    if (!agg_lds_upsert(lt, k0, k1, h, by, v2)) agg_global(a, k0, k1, h, by, pk, 1);
+    const unsigned long long v2 = ((unsigned long long)v.packets << 25) | 1ull;
+    if (!agg_lds_upsert(lt, k0, k1, h, v.bytes, v2)) agg_global(a, k0, k1, h, v.bytes, v.packets, 1);
 }
 
-// The common case (the key already sits in its home slot) for all AGG_SU tuples at once, so that the LDS
-// round trips of the segments overlap; everything else goes through the probing upsert.
 // the queued leftovers of a wave, one per lane (LDS operations of a wave complete in order: the queue needs no fence)
 __device__ __forceinline__ void agg_drain(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const uint4* queue, uint32_t qn) {
     if (lane < qn) agg_tuple(a, lt, tb_base, queue[lane]);
 }
 
-template <int S0>
-__device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b,
+// The common case (the key already sits in its home slot) for AGG_CH tuples at once, so that the LDS
+// round trips of the segments overlap; everything else goes through the probing upsert.
+template <int E0, bool T8>
+__device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t part, uint32_t lane, const AggBatch& b,
                                                   uint4* queue, uint32_t& qn) {
     uint64_t k0[AGG_CH], k1[AGG_CH];
     uint32_t h[AGG_CH];
+    TupleVals tv[AGG_CH];
     unsigned long long c0[AGG_CH], c1[AGG_CH];
     if (a.dbg & DBG_AGG_NO_LDS) {  // ablation: consume the loads only
         uint32_t x = 0;
 #pragma unroll
-        for (int s = 0; s < AGG_CH; s++) x ^= b.t[S0 + s].x ^ b.t[S0 + s].y ^ b.t[S0 + s].z ^ b.t[S0 + s].w;
+        for (int s = 0; s < agg_su<T8>(); s++) x ^= b.t[s].x ^ b.t[s].y ^ b.t[s].z ^ b.t[s].w;
         if (x == 0x12345678u) lt.s1[lane] = x;
         return;
     }
@@ -111,8 +136,8 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
     unsigned long long d0[AGG_CH], d1[AGG_CH];
 #pragma unroll
     for (int s = 0; s < AGG_CH; s++) {
-        const uint32_t tbr = b.t[S0 + s].z >> 28, et = b.t[S0 + s].w >> 15;
-        pack_key(tb_base + tbr, b.t[S0 + s].x, b.t[S0 + s].y, et, k0[s], k1[s]);
+        agg_vals<T8>(b, E0 + s, part, tv[s]);
+        pack_key(tb_base + tv[s].tbr, tv[s].src_as, tv[s].dst_as, tv[s].etype, k0[s], k1[s]);
         h[s] = key_hash(k0[s], k1[s]);
         const uint32_t i = h[s] & (AGG_SLOTS - 1), j = (i + 1) & (AGG_SLOTS - 1);
         c0[s] = lt.k0[i];
@@ -120,17 +145,16 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
         d0[s] = lt.k0[j];
         d1[s] = lt.k1[j];
     }
-    uint32_t pending = 0;  // segments whose tuple is not in its home slot (probing / claiming needed)
+    uint32_t pending = 0;  // tuples that are not in their home slot (probing / claiming needed)
 #pragma unroll
     for (int s = 0; s < AGG_CH; s++) {
-        if (!((b.v >> (S0 + s)) & 1u)) continue;
-        const uint32_t by = b.t[S0 + s].z & 0x0fffffffu, pk = b.t[S0 + s].w & 0x7fffu;
-        const unsigned long long v2 = ((unsigned long long)pk << 25) | 1ull;
+        if (!((b.v >> (E0 + s)) & 1u)) continue;
+        const unsigned long long v2 = ((unsigned long long)tv[s].packets << 25) | 1ull;
         const uint32_t i = h[s] & (AGG_SLOTS - 1);
         const bool at0 = c0[s] == k0[s] && c1[s] == k1[s], at1 = d0[s] == k0[s] && d1[s] == k1[s];
         if (at0 || at1) {
             const uint32_t t = at0 ? i : (i + 1) & (AGG_SLOTS - 1);
-            if (by) atomicAdd(&lt.s1[t], (unsigned long long)by);
+            if (tv[s].bytes) atomicAdd(&lt.s1[t], (unsigned long long)tv[s].bytes);
             atomicAdd(&lt.s2[t], v2);
         } else {
             pending |= 1u << s;
@@ -138,8 +162,8 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
     }
     if (a.dbg & DBG_AGG_NO_SLOW) return;
     // The leftovers (first occurrences of a group, keys two or more slots from home: ~5 % of the tuples) wait in
-    // the wave's queue and take the probing path 64 at a time: handled on the spot, each round of the probing
-    // loop would run with one or two active lanes.
+    // the wave's queue (as wide tuples) and take the probing path 64 at a time: handled on the spot, each round of
+    // the probing loop would run with one or two active lanes.
 #pragma unroll
     for (int s = 0; s < AGG_CH; s++) {
         const bool pnd = (pending >> s) & 1u;
@@ -150,19 +174,29 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
                 agg_drain(a, lt, tb_base, lane, queue, qn);
                 qn = 0;
             }
-            if (pnd) queue[qn + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = b.t[S0 + s];
+            if (pnd)
+                queue[qn + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] =
+                    tup16_pack(tv[s].src_as, tv[s].dst_as, tv[s].bytes, tv[s].packets, tv[s].tbr, tv[s].etype);
             qn += cnt;
         }
     }
 }
 
-__device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t lane, const AggBatch& b,
+template <bool T8>
+__device__ __forceinline__ void agg_consume(const KArgs& a, AggTable& lt, uint32_t tb_base, uint32_t part, uint32_t lane, const AggBatch& b,
                                             uint4* queue, uint32_t& qn) {
-    agg_consume_chunk<0>(a, lt, tb_base, lane, b, queue, qn);
-    if (AGG_SU > AGG_CH) agg_consume_chunk<AGG_SU - AGG_CH>(a, lt, tb_base, lane, b, queue, qn);
+    constexpr int NT = agg_su<T8>() * (T8 ? 2 : 1);  // tuples per lane and batch
+    static_assert(NT % AGG_CH == 0, "batch = whole chunks");
+    agg_consume_chunk<0, T8>(a, lt, tb_base, part, lane, b, queue, qn);
+    if constexpr (NT > AGG_CH) agg_consume_chunk<AGG_CH, T8>(a, lt, tb_base, part, lane, b, queue, qn);
+    if constexpr (NT > 2 * AGG_CH) agg_consume_chunk<2 * AGG_CH, T8>(a, lt, tb_base, part, lane, b, queue, qn);
+    if constexpr (NT > 3 * AGG_CH) agg_consume_chunk<3 * AGG_CH, T8>(a, lt, tb_base, part, lane, b, queue, qn);
+    static_assert(NT <= 4 * AGG_CH, "agg_consume: add chunks");
 }
 
+template <bool T8>
 __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
+    constexpr uint32_t TPP = T8 ? 2u : 1u;
     __shared__ AggTable lt;
     __shared__ uint32_t pc[AGG_MAX_NWG + AGG_PAD];  // this partition's segment counts, zero padded
     const uint32_t part = blockIdx.x / AGG_SPLIT, sub = blockIdx.x % AGG_SPLIT;
@@ -196,8 +230,10 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     }
     const uint32_t tb_base = a.ctr->tb_base;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint4* pbase = a.seg + (size_t)part * a.region;
-    constexpr uint32_t STEP = (AGG_BLOCK / 64) * AGG_SU * AGG_SPLIT;
+    // (compact tuples: region and capq are even, so every segment starts on a 16-byte boundary)
+    const uint4* pbase = a.seg + (((size_t)part * a.region) >> (T8 ? 1 : 0));
+    constexpr uint32_t SU = agg_su<T8>();
+    constexpr uint32_t STEP = (AGG_BLOCK / 64) * SU * AGG_SPLIT;
     __syncthreads();  // table cleared, counts staged
     const uint32_t maxc = maxc_s[0], maxcb = maxc_s[1];
     uint4* queue = queues + wave * 64;
@@ -205,33 +241,33 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     // software pipeline over this wave's segment groups: the next group's loads fly during the LDS work
     // (every fetch is unconditional - clamped addresses, zero counts past the end - so that the compiler
     // can count the loads in flight and wait for the older batch only)
-    // chunk levels: level j covers tuples [64j, 64j+64) of every segment (segments of the 512-thread tile kernel
-    // hold ~127 tuples, those of the 256-thread one ~42)
-    const uint32_t levels = (__builtin_amdgcn_readfirstlane(maxc) + 63u) >> 6;
+    // chunk levels: level j covers the 16-byte pieces [64j, 64j+64) of every segment
+    const uint32_t levels = (__builtin_amdgcn_readfirstlane(maxc) + 64u * TPP - 1u) / (64u * TPP);
     for (uint32_t j = 0; j < levels; j++) {
         AggBatch b0, b1;
-        uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * AGG_SU;
-        agg_fetch<false>(a, pbase, pc, w0, lane, j, b0);
+        uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * SU;
+        agg_fetch<false, T8>(a, pbase, pc, w0, lane, j, b0);
         while (true) {
-            agg_fetch<false>(a, pbase, pc, w0 + STEP, lane, j, b1);
-            agg_consume(a, lt, tb_base, lane, b0, queue, qn);
-            agg_fetch<false>(a, pbase, pc, w0 + 2 * STEP, lane, j, b0);
-            agg_consume(a, lt, tb_base, lane, b1, queue, qn);
+            agg_fetch<false, T8>(a, pbase, pc, w0 + STEP, lane, j, b1);
+            agg_consume<T8>(a, lt, tb_base, part, lane, b0, queue, qn);
+            agg_fetch<false, T8>(a, pbase, pc, w0 + 2 * STEP, lane, j, b0);
+            agg_consume<T8>(a, lt, tb_base, part, lane, b1, queue, qn);
             w0 += 2 * STEP;
             if (w0 >= a.nwg) break;
         }
     }
-    const uint32_t levels_b = (__builtin_amdgcn_readfirstlane(maxcb) + 7u) >> 3;
+    // back parts: 8 pieces per segment and level; a compact back part of c tuples spans up to c / 2 + 1 pieces
+    const uint32_t levels_b = (__builtin_amdgcn_readfirstlane(maxcb) / TPP + (T8 ? 1u : 0u) + 7u) >> 3;
     constexpr uint32_t STEP_B = STEP * 8u;
-    for (uint32_t j = 0; j < levels_b; j++) {  // the back parts (single tuples and bin leftovers of the wave-tile kernel)
+    for (uint32_t j = 0; j < (maxcb ? levels_b : 0u); j++) {  // the back parts (single tuples and bin leftovers of the wave-tile kernel)
         AggBatch b0, b1;
-        uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * AGG_SU * 8u;
-        agg_fetch<true>(a, pbase, pcb, w0, lane, j, b0);
+        uint32_t w0 = (sub * (AGG_BLOCK / 64) + wave) * SU * 8u;
+        agg_fetch<true, T8>(a, pbase, pcb, w0, lane, j, b0);
         while (true) {
-            agg_fetch<true>(a, pbase, pcb, w0 + STEP_B, lane, j, b1);
-            agg_consume(a, lt, tb_base, lane, b0, queue, qn);
-            agg_fetch<true>(a, pbase, pcb, w0 + 2 * STEP_B, lane, j, b0);
-            agg_consume(a, lt, tb_base, lane, b1, queue, qn);
+            agg_fetch<true, T8>(a, pbase, pcb, w0 + STEP_B, lane, j, b1);
+            agg_consume<T8>(a, lt, tb_base, part, lane, b0, queue, qn);
+            agg_fetch<true, T8>(a, pbase, pcb, w0 + 2 * STEP_B, lane, j, b0);
+            agg_consume<T8>(a, lt, tb_base, part, lane, b1, queue, qn);
             w0 += 2 * STEP_B;
             if (w0 >= a.nwg) break;
         }

@@ -35,18 +35,38 @@ struct fa_ctx {
     Slot* tab = nullptr;
     uint32_t cap_log2 = 20;
     SpillEntry* spill = nullptr;
-    uint32_t spill_cap = 1u << 22;  // parked updates of ONE batch that met a full table (168 MB): the aggregation kernel parks at most 2^20 groups per batch, the rest is headroom for the per-record paths
+    // Parked updates that met a full table.  A record parks at most one update, so 2 x max_batch_records (+ slack for
+    // the per-workgroup flushes) covers everything the host may have in flight before it looks at the counters again
+    // (pre_launch_guard): aggregates are never dropped, the table grows and the parked updates are replayed.
+    uint32_t spill_cap = 0;
     Counters* d_ctr = nullptr;
     Counters* h_ctr = nullptr;  // pinned
+    // counter snapshots, one per ingest launch (ring): what the device had counted when that launch finished
+    static constexpr int NSNAP = 8;
+    Counters* h_snap = nullptr;  // pinned, NSNAP entries
+    hipEvent_t snap_ev[NSNAP] = {};
+    uint64_t snap_records[NSNAP] = {};  // records launched up to and including the snapshot's batch
+    uint64_t snap_seq[NSNAP] = {};      // launch sequence number (0 = unused)
+    uint64_t launch_seq = 0, known_seq = 0;
+    uint64_t launched_records = 0, known_records = 0;
+    Counters known{};                   // newest snapshot (or settle) the host has seen
     uint32_t* d_exotic = nullptr;  // deferral lists: [0,cap) exotic, [cap,2cap) retry
     size_t exotic_cap = 0;
     // scatter sink
     uint4* seg = nullptr;
-    size_t seg_tuples = 0;
+    size_t seg_bytes = 0;
     uint32_t* seg_counts = nullptr;
     size_t seg_counts_cap = 0;
     int sink_mode = 0;  // 0 auto, 1 direct, 2 scatter (env FA_SINK)
     bool use_wave_tiles = false;  // decision for the batch being launched
+    bool use_t8 = false;          // ... compact 8-byte tuples (table.cuh) for it
+    // tuple format feedback: compact tuples while (almost) every record fits them.  A launch whose misfits (records
+    // that only a wide tuple holds - they took the direct path) exceed 1/16 of its records switches the ctx to wide
+    // tuples for the next 64 launches, then compact is tried again.  Only speed depends on this, never results.
+    int t8_mode = 0;              // env FA_TUPLE: 0 adaptive, 1 always compact ("8"), 2 always wide ("16")
+    uint64_t t8_wide_until = 0;   // batches counter value up to which wide tuples are used
+    uint64_t seen_misfit8 = 0, seen_ok = 0;  // counter values at the last look
+    uint32_t par = 0;             // parity of the next launch (Counters::exotic_count / retry_count copies)
     uint32_t seg_cap_limit = 0;   // env FA_SEG_CAP (tests only): upper bound on tuples per segment
     // ingest kernel (env FA_TILE=wave|wg, measurement / tests): wave-private tiles + LDS tuple bins is the
     // production kernel of the scatter sink (never slower than the 256-thread workgroup-tile kernel on the
@@ -84,7 +104,8 @@ struct fa_ctx {
     WSlot* wtab = nullptr;
     uint32_t wcap_log2 = 20;
     WSpillEntry* wspill = nullptr;
-    uint32_t wspill_cap = 1u << 22;
+    uint32_t wspill_cap = 0;      // (updates a record can park in the wide table) x 2 x max_batch_records + slack
+    uint32_t wide_per_record = 0;  // wide-table updates one record can cause (enabled wide key sets)
     uint64_t wused_base = 0;
     ulonglong2* port_hist = nullptr;  // [2][PORT_DENSE]
 
@@ -103,6 +124,14 @@ struct fa_ctx {
             (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                    \
             return FA_ERR_HIP;                                                                  \
         }                                                                                       \
+    } while (0)
+
+// Every entry point runs on the ctx's device whatever device the calling thread had current (several ctxs on
+// different GPUs in one process; Go moves goroutines between OS threads): allocations and launches must not land on
+// the caller's device.
+#define FA_ON_DEVICE(c)                                \
+    do {                                               \
+        if (c) (void)hipSetDevice((c)->cfg.device);    \
     } while (0)
 
 static int fail(fa_ctx* c, int code, const char* msg) {
@@ -143,6 +172,7 @@ static KArgs make_args(fa_ctx* c) {
     a.wspill_cap = c->wspill_cap;
     a.port_hist = c->port_hist;
     a.gran_recip = (1.0 / (double)c->gran) * (1.0 + 1.0 / 1099511627776.0);
+    a.par = c->par;
     return a;
 }
 
@@ -210,6 +240,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_SEG_CAP")) c->seg_cap_limit = std::max<uint32_t>(40u, (uint32_t)atoi(d) & ~7u);
     if (const char* d = getenv("FA_TILE")) c->tile_mode = !strcmp(d, "wave") ? 1 : !strcmp(d, "wg") ? 2 : 0;
     if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
+    if (const char* d = getenv("FA_TUPLE")) c->t8_mode = !strcmp(d, "8") ? 1 : !strcmp(d, "16") ? 2 : 0;
     auto bail = [&](const char* what, hipError_t e) {
         g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
         fa_destroy(c);
@@ -227,6 +258,13 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     for (int i = 0; i < 2; i++)
         if ((e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming)) != hipSuccess)
             return bail("hipEventCreate", e);
+    for (int i = 0; i < fa_ctx::NSNAP; i++)
+        if ((e = hipEventCreateWithFlags(&c->snap_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipHostMalloc(&c->h_snap, sizeof(Counters) * fa_ctx::NSNAP)) != hipSuccess) return bail("hipHostMalloc", e);
+    c->spill_cap = 2u * cfg.max_batch_records + (1u << 21);
+    c->wide_per_record = ((cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO) ? 1u : 0u) + ((cfg.key_sets & FA_KEYS_PORT_HIST) ? 2u : 0u) +
+                         ((cfg.key_sets & FA_KEYS_MINUTE_SERIES) ? 1u : 0u);
+    c->wspill_cap = c->wide_per_record * 2u * cfg.max_batch_records + (1u << 21);
     size_t tab_bytes = sizeof(Slot) << c->cap_log2;
     if ((e = hipMalloc(&c->tab, tab_bytes)) != hipSuccess) return bail("hipMalloc(table)", e);
     if ((e = hipMemsetAsync(c->tab, 0, tab_bytes, c->stream)) != hipSuccess) return bail("memset", e);
@@ -279,6 +317,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
 }
 
 extern "C" void fa_destroy(fa_ctx* c) {
+    FA_ON_DEVICE(c);
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if ((c->dbg & DBG_TIMING) && c->d_ctr && c->h_ctr && hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost) == hipSuccess &&
@@ -304,6 +343,9 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->spill);
     (void)hipFree(c->d_ctr);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    if (c->h_snap) (void)hipHostFree(c->h_snap);
+    for (int i = 0; i < fa_ctx::NSNAP; i++)
+        if (c->snap_ev[i]) (void)hipEventDestroy(c->snap_ev[i]);
     (void)hipFree(c->d_exotic);
     (void)hipFree(c->seg);
     (void)hipFree(c->seg_counts);
@@ -384,6 +426,12 @@ static int rebuild_wide(fa_ctx* c, uint32_t new_log2, uint32_t kind_mask, uint32
     return FA_OK;
 }
 
+static uint32_t log2_ceil(uint64_t v) {
+    uint32_t l = 0;
+    while ((1ull << l) < v) l++;
+    return l;
+}
+
 // grows the wide table / replays parked updates until nothing is pending (h = fresh copy of the counters)
 static int settle_wide(fa_ctx* c, Counters& h) {
     if (!c->wtab) return FA_OK;
@@ -394,22 +442,28 @@ static int settle_wide(fa_ctx* c, Counters& h) {
     }
     int guard = 0;
     while (h.wspill_count || c->stats.wide_used * 2 > (1ull << c->wcap_log2)) {
-        if (c->wcap_log2 >= 30 || ++guard > 8) return fail(c, FA_ERR_TABLE_FULL, "wide-key table cannot grow further");
+        // room for every group that exists plus every parked update, at <= 50 % load, in ONE step
+        const uint32_t want = std::max(c->wcap_log2 + 1, log2_ceil(2 * (c->stats.wide_used + h.wspill_count)));
+        if (want > 30 || ++guard > 8) return fail(c, FA_ERR_TABLE_FULL, "wide-key table cannot grow further");
         const uint32_t nspill = h.wspill_count;
-        int rc = rebuild_wide(c, c->wcap_log2 + 1, 0, 0, 0 /* nothing selected: keep everything */);
-        if (rc) return rc;
-        HIPCHK(c, hipMemsetAsync(&c->d_ctr->wspill_count, 0, sizeof(unsigned int), c->stream));
+        // the parked updates move to a private copy and the buffer is emptied BEFORE the rebuild, so that anything the
+        // rebuild or the replay parks again is kept for the next round of this loop
+        WSpillEntry* tmp = nullptr;
         if (nspill) {
-            WSpillEntry* tmp = nullptr;
-            HIPCHK(c, hipMalloc(&tmp, sizeof(WSpillEntry) * nspill));
-            HIPCHK(c, hipMemcpyAsync(tmp, c->wspill, sizeof(WSpillEntry) * nspill, hipMemcpyDeviceToDevice, c->stream));
+            if (hipMalloc(&tmp, sizeof(WSpillEntry) * nspill) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide spill copy) failed");
+            hipError_t e = hipMemcpyAsync(tmp, c->wspill, sizeof(WSpillEntry) * nspill, hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) { (void)hipFree(tmp); c->err = "settle_wide: copy failed"; return FA_ERR_HIP; }
+        }
+        hipError_t e0 = hipMemsetAsync(&c->d_ctr->wspill_count, 0, sizeof(unsigned int), c->stream);
+        int rc = e0 == hipSuccess ? rebuild_wide(c, want, 0, 0, 0 /* nothing selected: keep everything */) : FA_ERR_HIP;
+        if (rc == FA_OK && nspill) {
             KArgs a = make_args(c);
             static_assert(sizeof(WSpillEntry) == sizeof(WRow), "spill entries replay as rows");
             hipLaunchKernelGGL(wmerge_kernel, dim3(256), dim3(256), 0, c->stream, (const WRow*)tmp, nspill, a);
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            HIPCHK(c, hipFree(tmp));
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = FA_ERR_HIP;
         }
+        if (tmp) (void)hipFree(tmp);
+        if (rc) return rc == FA_ERR_HIP ? fail(c, FA_ERR_HIP, "settle_wide: replay failed") : rc;
         HIPCHK(c, hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost));
         h = *c->h_ctr;
         c->stats.wide_used = c->wused_base + h.wused;
@@ -419,6 +473,14 @@ static int settle_wide(fa_ctx* c, Counters& h) {
 }
 
 static int cms_fold(fa_ctx* c);
+
+// tuple-format feedback (fa_ctx::use_t8): h = counters at least as new as the last look
+static void format_feedback(fa_ctx* c, const Counters& h) {
+    const uint64_t d_mis = h.misfit8 - c->seen_misfit8, d_ok = h.ok - c->seen_ok;
+    if (d_ok && d_mis * 16 > d_ok) c->t8_wide_until = c->stats.batches + 64;
+    c->seen_misfit8 = h.misfit8;
+    c->seen_ok = h.ok;
+}
 
 // Waits for the stream, folds device counters into stats, replays spills after growing.
 static int settle(fa_ctx* c) {
@@ -446,57 +508,129 @@ static int settle(fa_ctx* c) {
     c->stats.records_direct = h.direct;
     c->stats.records_retried = h.retried;
     c->stats.table_used = c->used_base + h.used;
+    format_feedback(c, h);
     if (h.spill_lost) {
         c->sticky = FA_ERR_TABLE_FULL;
         return fail(c, FA_ERR_TABLE_FULL, "group-by table and spill buffer overflowed; aggregates were lost");
     }
     int guard = 0;
     while (h.spill_count || c->stats.table_used * 2 > (1ull << c->cap_log2)) {
-        if (c->cap_log2 >= 30 || ++guard > 8) return fail(c, FA_ERR_TABLE_FULL, "group-by table cannot grow further");
-        uint32_t nspill = h.spill_count;
-        int rc = rebuild_table(c, c->cap_log2 + 1, 1, 0 /* empty range: keep everything */);
-        if (rc) return rc;
-        HIPCHK(c, hipMemsetAsync(&c->d_ctr->spill_count, 0, sizeof(unsigned int), c->stream));
+        // room for every group that exists plus every parked update, at <= 50 % load, in ONE step
+        const uint32_t want = std::max(c->cap_log2 + 1, log2_ceil(2 * (c->stats.table_used + h.spill_count)));
+        if (want > 30 || ++guard > 8) return fail(c, FA_ERR_TABLE_FULL, "group-by table cannot grow further");
+        const uint32_t nspill = h.spill_count;
+        // the parked aggregates move to a private copy and the buffer is emptied BEFORE the rebuild, so that anything
+        // the rebuild or the replay parks again is kept for the next round of this loop
+        SpillEntry* tmp = nullptr;
         if (nspill) {
-            // replay parked aggregates from a private copy (the spill buffer may be re-filled)
-            SpillEntry* tmp = nullptr;
-            HIPCHK(c, hipMalloc(&tmp, sizeof(SpillEntry) * nspill));
-            HIPCHK(c, hipMemcpyAsync(tmp, c->spill, sizeof(SpillEntry) * nspill, hipMemcpyDeviceToDevice, c->stream));
-            KArgs a = make_args(c);
-            hipLaunchKernelGGL(replay_spill_kernel, dim3(256), dim3(256), 0, c->stream, tmp, nspill, a);
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            HIPCHK(c, hipFree(tmp));
+            if (hipMalloc(&tmp, sizeof(SpillEntry) * nspill) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(spill copy) failed");
+            hipError_t e = hipMemcpyAsync(tmp, c->spill, sizeof(SpillEntry) * nspill, hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) { (void)hipFree(tmp); c->err = "settle: copy failed"; return FA_ERR_HIP; }
         }
+        hipError_t e0 = hipMemsetAsync(&c->d_ctr->spill_count, 0, sizeof(unsigned int), c->stream);
+        int rc = e0 == hipSuccess ? rebuild_table(c, want, 1, 0 /* empty range: keep everything */) : FA_ERR_HIP;
+        if (rc == FA_OK && nspill) {
+            KArgs a = make_args(c);
+            hipLaunchKernelGGL(replay_spill_kernel, dim3(1024), dim3(256), 0, c->stream, tmp, nspill, a);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = FA_ERR_HIP;
+        }
+        if (tmp) (void)hipFree(tmp);
+        if (rc) return rc == FA_ERR_HIP ? fail(c, FA_ERR_HIP, "settle: replay failed") : rc;
         HIPCHK(c, hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost));
         h = *c->h_ctr;
         c->stats.table_used = c->used_base + h.used;
         if (h.spill_lost) return fail(c, FA_ERR_TABLE_FULL, "spill buffer overflowed during replay");
     }
-    return settle_wide(c, h);
+    int rc = settle_wide(c, h);
+    // everything launched so far is accounted for
+    c->known = h;
+    c->known_records = c->launched_records;
+    c->known_seq = c->launch_seq;
+    return rc;
+}
+
+// ---- counter snapshots: never lose aggregates ------------------------------------------------------------
+// Every ingest launch is followed by an asynchronous copy of the device counters into a pinned ring slot.  Before
+// the next launch the host looks at the newest snapshot that has landed (no waiting): a table above 50 % load or
+// parked updates are settled (grow + replay) right away, and a launch is only queued while the updates that could
+// be parked by everything in flight still fit the spill buffers - otherwise the host first waits for the newest
+// snapshot.  Steady state costs one 300-byte copy per launch and no synchronisation.
+static void poll_snapshots(fa_ctx* c, bool wait_newest) {
+    if (c->launch_seq == c->known_seq) return;
+    if (wait_newest) (void)hipEventSynchronize(c->snap_ev[(c->launch_seq - 1) % fa_ctx::NSNAP]);
+    for (uint64_t q = c->launch_seq; q > c->known_seq; q--) {  // newest first
+        const int k = (int)((q - 1) % fa_ctx::NSNAP);
+        if (c->snap_seq[k] != q) break;  // overwritten: older ones are gone too
+        if (hipEventQuery(c->snap_ev[k]) == hipSuccess) {
+            c->known = c->h_snap[k];
+            c->known_records = c->snap_records[k];
+            c->known_seq = q;
+            format_feedback(c, c->known);
+            return;
+        }
+    }
+}
+static int pre_launch_guard(fa_ctx* c, size_t n) {
+    auto verdict = [&]() -> int {  // 0 go, 1 look again after waiting, 2 settle
+        const Counters& h = c->known;
+        if (h.spill_count || h.wspill_count || (c->used_base + h.used) * 2 > (1ull << c->cap_log2) ||
+            (c->wtab && (c->wused_base + h.wused) * 2 > (1ull << c->wcap_log2)))
+            return 2;
+        const uint64_t pot = (c->launched_records - c->known_records) + n;  // records whose updates the host has not seen settle
+        if (pot + (1u << 20) > c->spill_cap || (c->wtab && pot * c->wide_per_record + (1u << 20) > c->wspill_cap)) return 1;
+        return 0;
+    };
+    poll_snapshots(c, false);
+    int v = verdict();
+    if (v == 1) {
+        poll_snapshots(c, true);
+        v = verdict() ? 2 : 0;
+    }
+    return v == 2 ? settle(c) : FA_OK;
+}
+static int post_launch_snapshot(fa_ctx* c, size_t n) {
+    c->launched_records += n;
+    c->launch_seq += 1;
+    const int k = (int)((c->launch_seq - 1) % fa_ctx::NSNAP);
+    HIPCHK(c, hipEventSynchronize(c->snap_ev[k]));  // (the slot's previous copy, NSNAP launches ago)
+    HIPCHK(c, hipMemcpyAsync(&c->h_snap[k], c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->snap_ev[k], c->stream));
+    c->snap_records[k] = c->launched_records;
+    c->snap_seq[k] = c->launch_seq;
+    return FA_OK;
 }
 
 extern "C" int fa_sync(fa_ctx* c) {
+    FA_ON_DEVICE(c);
     if (!c) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     return settle(c);
 }
 
 // ---- ingest ---------------------------------------------------------------------------
-// Launch order on the ctx stream: [probe] -> tile -> deferred -> [agg].
+// Launch order on the ctx stream: tile -> deferred -> [agg]   (wave-tile kernel: it finds the batch's time base
+// itself; the workgroup-tile kernel with the scatter sink still takes it from probe_kernel).
 template <int MODE>
-static int launch_tiles(fa_ctx* c, const KArgs& a, int grid, fa_ctx::LaunchEvents* ev = nullptr) {
+static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev = nullptr) {
     dim3 b(BLOCK);
     dim3 g(grid);
     dim3 ge(std::min(256u, (a.n + BLOCK - 1) / BLOCK));
-    if (MODE == MODE_INGEST && a.seg) hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, c->stream, a);
-    if (ev) (void)hipEventRecord(ev->e0, c->stream);
+    a.par = c->par;
+    c->par ^= 1u;
     const bool wave_tiles = MODE == MODE_INGEST && a.seg != nullptr && a.tile_recs <= (uint32_t)WT_RECS && c->use_wave_tiles;
+    const bool t8 = wave_tiles && c->use_t8;
+    if (ev) (void)hipEventRecord(ev->e0, c->stream);
+    if (MODE == MODE_INGEST && a.seg && !wave_tiles) hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, c->stream, a);
     if (wave_tiles) c->stats.wave_tile_launches += 1;
+#define FA_LAUNCH_W(KS)                                                                         \
+    do {                                                                                        \
+        if (t8) hipLaunchKernelGGL((wtile_kernel<KS, true>), g, dim3(WBLOCK), 0, c->stream, a); \
+        else hipLaunchKernelGGL((wtile_kernel<KS, false>), g, dim3(WBLOCK), 0, c->stream, a);   \
+    } while (0)
 #define FA_LAUNCH(KS)                                                                           \
     case KS: {                                                                                  \
         if constexpr (MODE == MODE_INGEST) {                                                    \
-            if (wave_tiles) hipLaunchKernelGGL((wtile_kernel<KS>), g, dim3(WBLOCK), 0, c->stream, a); \
+            if (wave_tiles) FA_LAUNCH_W(KS);                                                    \
             else hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);            \
         } else {                                                                                \
             hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);                 \
@@ -511,7 +645,7 @@ static int launch_tiles(fa_ctx* c, const KArgs& a, int grid, fa_ctx::LaunchEvent
         switch (c->cfg.key_sets) {
             FA_LAUNCH(1u) FA_LAUNCH(2u) FA_LAUNCH(3u) FA_LAUNCH(4u) FA_LAUNCH(5u) FA_LAUNCH(6u) FA_LAUNCH(7u)
         default:  // any wide key set: the generic variant (runtime mask)
-            if (wave_tiles) hipLaunchKernelGGL((wtile_kernel<KS_ALL>), g, dim3(WBLOCK), 0, c->stream, a);
+            if (wave_tiles) FA_LAUNCH_W(KS_ALL);
             else hipLaunchKernelGGL((tile_kernel<MODE, KS_ALL>), g, b, 0, c->stream, a);
             if (ev) (void)hipEventRecord(ev->e1, c->stream);
             hipLaunchKernelGGL((deferred_kernel<MODE, KS_ALL>), ge, b, 0, c->stream, a);
@@ -519,7 +653,12 @@ static int launch_tiles(fa_ctx* c, const KArgs& a, int grid, fa_ctx::LaunchEvent
         }
     }
 #undef FA_LAUNCH
-    if (MODE == MODE_INGEST && a.seg) hipLaunchKernelGGL(agg_kernel, dim3((1u << a.plog2) * AGG_SPLIT), dim3(AGG_BLOCK), 0, c->stream, a);
+#undef FA_LAUNCH_W
+    if (MODE == MODE_INGEST && a.seg) {
+        const dim3 ga((1u << a.plog2) * AGG_SPLIT);
+        if (t8) hipLaunchKernelGGL(agg_kernel<true>, ga, dim3(AGG_BLOCK), 0, c->stream, a);
+        else hipLaunchKernelGGL(agg_kernel<false>, ga, dim3(AGG_BLOCK), 0, c->stream, a);
+    }
     if (ev) (void)hipEventRecord(ev->e2, c->stream);
     HIPCHK(c, hipGetLastError());
     return FA_OK;
@@ -555,21 +694,23 @@ static int ensure_exotic(fa_ctx* c, size_t n) {
 
 // Tuple segments for a batch of n records processed by nwg workgroups: capacity per (partition,
 // workgroup) = 2x the mean + 32 (a Poisson mean of m never reaches 2m+32; skewed batches overflow into
-// the direct path).  The region stride gets a skew so that consecutive partitions do not alias in L2.
-static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
+// the direct path), in whole 128-byte lines (8 wide / 16 compact tuples).  The region stride gets a skew of
+// three lines so that consecutive partitions do not alias in L2.
+static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, bool t8, KArgs& a) {
     const size_t NPART = (size_t)1 << c->plog2;
     const size_t avg = n / ((size_t)nwg * NPART);
-    uint32_t capq = (uint32_t)((2 * avg + 32 + 7) & ~(size_t)7);  // whole 128-byte lines
-    if (c->seg_cap_limit) capq = std::min(capq, c->seg_cap_limit);  // (tests: force the segment-overflow fallbacks)
-    const size_t region = (size_t)nwg * capq + 24;
-    const size_t tuples = region * NPART;
-    if (c->seg_tuples < tuples) {
+    const uint32_t tpl = t8 ? 16u : 8u;  // tuples per line
+    uint32_t capq = (uint32_t)((2 * avg + 32 + tpl - 1) & ~(size_t)(tpl - 1));
+    if (c->seg_cap_limit) capq = std::max<uint32_t>(std::min(capq, c->seg_cap_limit) & ~(tpl - 1), 2 * tpl);  // (tests: force the segment-overflow fallbacks)
+    const size_t region = (size_t)nwg * capq + 3 * tpl;
+    const size_t bytes = region * NPART * (t8 ? 8 : 16);
+    if (c->seg_bytes < bytes) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->seg);
         c->seg = nullptr;
-        c->seg_tuples = 0;
-        if (hipMalloc(&c->seg, tuples * sizeof(uint4)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(tuple segments) failed");
-        c->seg_tuples = tuples;
+        c->seg_bytes = 0;
+        if (hipMalloc(&c->seg, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(tuple segments) failed");
+        c->seg_bytes = bytes;
     }
     const size_t ncnt = (size_t)nwg * NPART_MAX * 2;  // front and back counts
     if (c->seg_counts_cap < ncnt) {
@@ -583,8 +724,9 @@ static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     a.seg = c->seg;
     a.seg_counts = c->seg_counts;
     a.capq = capq;
-    a.capb = std::min<uint32_t>(std::max<uint32_t>(32u, (capq / 4) & ~7u), 0xfff8u);  // back part: single tuples, bin leftovers
-    a.capf = std::min<uint32_t>(capq - a.capb, 0xffffu * 8u);                           // front part: full lines
+    a.capb = std::min<uint32_t>(std::max<uint32_t>(2 * tpl, (capq / 4) & ~(tpl - 1)), 0x10000u - tpl);  // back part: single tuples, bin leftovers
+    a.capb = std::min(a.capb, capq - tpl);
+    a.capf = std::min<uint32_t>(capq - a.capb, 0xffffu * tpl);                                           // front part: full lines
     a.nwg = nwg;
     a.region = region;
     a.plog2 = c->plog2;
@@ -592,13 +734,16 @@ static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
 }
 
 extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const void* d_off, size_t n) {
+    FA_ON_DEVICE(c);
     if (!c) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     if (n == 0) return FA_OK;
     if (!d_buf || !d_off || len >= (1ull << 32) || n > c->cfg.max_batch_records ||
         ((uintptr_t)d_buf & 15) || ((uintptr_t)d_off & 3))
         return fail(c, FA_ERR_ARG, "fa_ingest_device: bad buffer (16-byte aligned, < 4 GiB, n <= max_batch_records)");
-    int rc = ensure_exotic(c, n);
+    int rc = pre_launch_guard(c, n);
+    if (rc) return rc;
+    rc = ensure_exotic(c, n);
     if (rc) return rc;
     KArgs a = make_args(c);
     a.buf = (const uint8_t*)d_buf;
@@ -619,13 +764,12 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         const uint32_t wgs = (wtiles + (WBLOCK / 64) - 1) / (WBLOCK / 64);
         grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * (uint32_t)WT_WG_PER_CU));
     }
+    // tuple format of this launch (table.cuh): compact 8-byte tuples on the wave-tile kernel with 256 partitions,
+    // unless recent launches showed that this stream's records do not fit them
+    c->use_t8 = c->use_wave_tiles && c->plog2 == 8 && c->t8_mode != 2 && (c->t8_mode == 1 || c->stats.batches >= c->t8_wide_until);
     if (scatter) {
-        rc = ensure_segments(c, n, (uint32_t)grid, a);
+        rc = ensure_segments(c, n, (uint32_t)grid, c->use_t8, a);
         if (rc) return rc;
-    }
-    if (!scatter) {  // (the scatter path's probe kernel resets them)
-        HIPCHK(c, hipMemsetAsync(&c->d_ctr->exotic_count, 0, sizeof(unsigned int), c->stream));
-        HIPCHK(c, hipMemsetAsync(&c->d_ctr->retry_count, 0, sizeof(unsigned int), c->stream));
     }
     if (c->ev_used == c->ev_pool.size()) {
         if (c->ev_pool.size() >= 4096) {  // bound the pool: fold what is pending
@@ -641,6 +785,8 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     }
     fa_ctx::LaunchEvents* evp = &c->ev_pool[c->ev_used++];
     rc = launch_tiles<MODE_INGEST>(c, a, grid, evp);
+    if (rc) return rc;
+    rc = post_launch_snapshot(c, n);
     if (rc) return rc;
     c->stats.bytes_in += len;
     c->stats.batches += 1;
@@ -722,6 +868,7 @@ static int stage_and_upload(fa_ctx* c, const uint8_t* buf, size_t len, const uin
 }
 
 extern "C" int fa_ingest(fa_ctx* c, const uint8_t* buf, size_t len, const uint64_t* offsets, size_t n) {
+    FA_ON_DEVICE(c);
     if (!c) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     if (!buf && len) return fail(c, FA_ERR_ARG, "fa_ingest: null buffer");
@@ -802,6 +949,8 @@ static int ensure_columns(fa_ctx* c, size_t n) {
 
 extern "C" int fa_decode_device(fa_ctx* c, const void* d_buf, size_t len, const void* d_off, size_t n,
                                 fa_columns* out) {
+    FA_ON_DEVICE(c);
+    FA_ON_DEVICE(c);
     if (!c || !out) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     if (!d_buf || !d_off || len >= (1ull << 32) || n > c->cfg.max_batch_records || ((uintptr_t)d_buf & 15))
@@ -816,8 +965,6 @@ extern "C" int fa_decode_device(fa_ctx* c, const void* d_buf, size_t len, const 
         a.off = (const uint32_t*)d_off;
         a.n = (uint32_t)n;
         a.tile_recs = tile_recs_for(len, n);
-        HIPCHK(c, hipMemsetAsync(&c->d_ctr->exotic_count, 0, sizeof(unsigned int), c->stream));
-        HIPCHK(c, hipMemsetAsync(&c->d_ctr->retry_count, 0, sizeof(unsigned int), c->stream));
         rc = launch_tiles<MODE_DECODE>(c, a, tile_grid<MODE_DECODE>(c, a.n, a.tile_recs));
         if (rc) return rc;
     }
@@ -842,6 +989,8 @@ extern "C" int fa_decode_device(fa_ctx* c, const void* d_buf, size_t len, const 
 
 extern "C" int fa_decode(fa_ctx* c, const uint8_t* buf, size_t len, const uint64_t* offsets, size_t n,
                          fa_flow_row* out) {
+    FA_ON_DEVICE(c);
+    FA_ON_DEVICE(c);
     if (!c || (!out && n)) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     if (!offsets) return fail(c, FA_ERR_ARG, "fa_decode: offsets required");
@@ -984,6 +1133,7 @@ static int window_rows(fa_ctx* c, uint32_t timeslot, std::vector<fa_row5m>& rows
 }
 
 extern "C" int fa_read_window(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out) {
+    FA_ON_DEVICE(c);
     if (!c || !n_out) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     std::vector<fa_row5m> rows;
@@ -997,6 +1147,7 @@ extern "C" int fa_read_window(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size_
 }
 
 extern "C" int fa_close_window(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out) {
+    FA_ON_DEVICE(c);
     if (!c || !n_out) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     std::vector<fa_row5m> rows;
@@ -1014,6 +1165,7 @@ extern "C" int fa_close_window(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size
 }
 
 extern "C" int fa_open_timeslots(fa_ctx* c, uint32_t* out, size_t cap, size_t* n_out) {
+    FA_ON_DEVICE(c);
     if (!c || !n_out) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     std::vector<fa_row5m> rows;
@@ -1031,6 +1183,7 @@ extern "C" int fa_open_timeslots(fa_ctx* c, uint32_t* out, size_t cap, size_t* n
 }
 
 extern "C" int fa_merge_rows(fa_ctx* c, const fa_row5m* rows, size_t n) {
+    FA_ON_DEVICE(c);
     if (!c || (!rows && n)) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     if (!n) return FA_OK;
@@ -1254,6 +1407,7 @@ static int window_rows_app(fa_ctx* c, uint32_t timeslot, std::vector<fa_row_app>
 }
 
 extern "C" int fa_read_window_app(fa_ctx* c, uint32_t timeslot, fa_row_app* out, size_t cap, size_t* n_out) {
+    FA_ON_DEVICE(c);
     if (!c || !n_out) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     std::vector<fa_row_app> rows;
@@ -1267,6 +1421,7 @@ extern "C" int fa_read_window_app(fa_ctx* c, uint32_t timeslot, fa_row_app* out,
 }
 
 extern "C" int fa_close_window_app(fa_ctx* c, uint32_t timeslot, fa_row_app* out, size_t cap, size_t* n_out) {
+    FA_ON_DEVICE(c);
     if (!c || !n_out) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     std::vector<fa_row_app> rows;
@@ -1282,6 +1437,7 @@ extern "C" int fa_close_window_app(fa_ctx* c, uint32_t timeslot, fa_row_app* out
 }
 
 extern "C" int fa_merge_rows_app(fa_ctx* c, const fa_row_app* rows, size_t n) {
+    FA_ON_DEVICE(c);
     if (!c || (!rows && n)) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     if (!(c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO)) return fail(c, FA_ERR_ARG, "FA_KEYS_ADDR_PORT_PROTO not enabled");
@@ -1299,6 +1455,7 @@ extern "C" int fa_merge_rows_app(fa_ctx* c, const fa_row_app* rows, size_t n) {
 }
 
 extern "C" int fa_top_ports(fa_ctx* c, int dst, size_t k, fa_port_row* out, size_t cap, size_t* n_out) {
+    FA_ON_DEVICE(c);
     if (!c || !n_out || (!out && cap) || (dst != 0 && dst != 1)) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     if (!c->port_hist) return fail(c, FA_ERR_ARG, "FA_KEYS_PORT_HIST not enabled");
@@ -1336,6 +1493,7 @@ __global__ void port_merge_kernel(const fa_port_row* rows, uint32_t n, ulonglong
 }
 
 extern "C" int fa_merge_ports(fa_ctx* c, int dst, const fa_port_row* rows, size_t n) {
+    FA_ON_DEVICE(c);
     if (!c || (!rows && n) || (dst != 0 && dst != 1)) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     if (!c->port_hist) return fail(c, FA_ERR_ARG, "FA_KEYS_PORT_HIST not enabled");
@@ -1370,6 +1528,7 @@ extern "C" int fa_merge_ports(fa_ctx* c, int dst, const fa_port_row* rows, size_
 }
 
 extern "C" int fa_minute_series(fa_ctx* c, fa_minute_row* out, size_t cap, size_t* n_out) {
+    FA_ON_DEVICE(c);
     if (!c || !n_out || (!out && cap)) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     if (!(c->cfg.key_sets & FA_KEYS_MINUTE_SERIES)) return fail(c, FA_ERR_ARG, "FA_KEYS_MINUTE_SERIES not enabled");
@@ -1391,6 +1550,7 @@ extern "C" int fa_minute_series(fa_ctx* c, fa_minute_row* out, size_t cap, size_
 }
 
 extern "C" int fa_merge_minutes(fa_ctx* c, const fa_minute_row* rows, size_t n) {
+    FA_ON_DEVICE(c);
     if (!c || (!rows && n)) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     if (!(c->cfg.key_sets & FA_KEYS_MINUTE_SERIES)) return fail(c, FA_ERR_ARG, "FA_KEYS_MINUTE_SERIES not enabled");
@@ -1405,6 +1565,7 @@ extern "C" int fa_merge_minutes(fa_ctx* c, const fa_minute_row* rows, size_t n) 
 }
 
 extern "C" int fa_dashboard_reset(fa_ctx* c) {
+    FA_ON_DEVICE(c);
     if (!c) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     int rc = settle(c);
@@ -1433,6 +1594,7 @@ static unsigned long long* cms_of(fa_ctx* c, uint32_t key_set) {
 }
 
 extern "C" int fa_cms_read(fa_ctx* c, uint32_t key_set, uint64_t* out, size_t cap_words) {
+    FA_ON_DEVICE(c);
     if (!c || !out) return FA_ERR_ARG;
     unsigned long long* p = cms_of(c, key_set);
     if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
@@ -1444,6 +1606,7 @@ extern "C" int fa_cms_read(fa_ctx* c, uint32_t key_set, uint64_t* out, size_t ca
 }
 
 extern "C" int fa_cms_reset(fa_ctx* c, uint32_t key_set) {
+    FA_ON_DEVICE(c);
     if (!c) return FA_ERR_ARG;
     unsigned long long* p = cms_of(c, key_set);
     if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
@@ -1462,6 +1625,7 @@ static uint64_t cms_hash_host(const uint8_t key[16], uint64_t seed, uint32_t row
 }
 
 extern "C" int fa_cms_query(fa_ctx* c, uint32_t key_set, const uint8_t key[16], uint64_t* weight) {
+    FA_ON_DEVICE(c);
     if (!c || !key || !weight) return FA_ERR_ARG;
     unsigned long long* p = cms_of(c, key_set);
     if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
@@ -1479,6 +1643,7 @@ extern "C" int fa_cms_query(fa_ctx* c, uint32_t key_set, const uint8_t key[16], 
 }
 
 extern "C" int fa_topk(fa_ctx* c, uint32_t key_set, size_t k, fa_topk_row* out, size_t cap, size_t* n_out) {
+    FA_ON_DEVICE(c);
     if (!c || !n_out || (!out && cap)) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     unsigned long long* cms = cms_of(c, key_set);
@@ -1535,6 +1700,7 @@ extern "C" int fa_topk(fa_ctx* c, uint32_t key_set, size_t k, fa_topk_row* out, 
 }
 
 extern "C" int fa_topk_merge_keys(fa_ctx* c, uint32_t key_set, const uint8_t* keys, size_t n) {
+    FA_ON_DEVICE(c);
     if (!c || (!keys && n)) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
     KeySlot* ks = key_set == FA_KEYS_SRCADDR_CMS ? c->ks_src : key_set == FA_KEYS_DSTADDR_CMS ? c->ks_dst : nullptr;
@@ -1558,6 +1724,7 @@ extern "C" int fa_topk_merge_keys(fa_ctx* c, uint32_t key_set, const uint8_t* ke
 }
 
 extern "C" int fa_device_state_get(fa_ctx* c, fa_device_state* out) {
+    FA_ON_DEVICE(c);
     if (!c || !out) return FA_ERR_ARG;
     int rc = settle(c);
     if (rc) return rc;
@@ -1572,6 +1739,7 @@ extern "C" int fa_device_state_get(fa_ctx* c, fa_device_state* out) {
 // RCCL is bound lazily so that libflowagg.so loads on hosts without librccl.
 #include <dlfcn.h>
 extern "C" int fa_merge_allreduce(fa_ctx* c, void* comm) {
+    FA_ON_DEVICE(c);
     if (!c || !comm) return FA_ERR_ARG;
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
     static allreduce_fn fn = nullptr;
@@ -1595,6 +1763,7 @@ extern "C" int fa_merge_allreduce(fa_ctx* c, void* comm) {
 }
 
 extern "C" int fa_stats(fa_ctx* c, fa_stats_t* out) {
+    FA_ON_DEVICE(c);
     if (!c || !out) return FA_ERR_ARG;
     int rc = settle(c);
     *out = c->stats;
@@ -1604,6 +1773,8 @@ extern "C" int fa_stats(fa_ctx* c, fa_stats_t* out) {
 // ---- synthetic producer ------------------------------------------------------------------------
 extern "C" int fa_mock_generate_device(fa_ctx* c, const fa_mock_params* g, uint64_t i0, uint64_t n, void* d_buf,
                                        size_t cap, void* d_off, uint64_t* bytes_out) {
+    FA_ON_DEVICE(c);
+    FA_ON_DEVICE(c);
     if (!c || !g || !d_buf || !d_off || n == 0 || n >= (1ull << 31)) return FA_ERR_ARG;
     uint32_t* off = (uint32_t*)d_off;
     uint32_t* len = nullptr;

@@ -14,13 +14,19 @@ struct NoHook {
 };
 // after_parse: called by the whole wave between the parse and the sink (the tile buffer is dead from there on,
 // unless the sketches use it as scratch) - the wave-tile kernel's early DMA issue (FA_WT_EARLY)
-template <int MODE, uint32_t KEYSETS, uint32_t COLS, class Hook = NoHook>
+// Per-wave tallies that reach the device counters once per workgroup (block_counters_add).
+struct LaneTally {
+    uint32_t ok = 0, direct = 0, second = 0, misfit8 = 0;
+};
+// T8: this launch writes compact 8-byte tuples (wave-tile kernel only; table.cuh)
+template <int MODE, uint32_t KEYSETS, uint32_t COLS, bool T8 = false, class Hook = NoHook>
 __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, LdsMinutes& lm, uint32_t* part_cnt, const uint32_t* tile,
                                           bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
-                                          uint32_t& n_ok, uint32_t& n_direct, uint32_t& lt_seen, uint32_t& lt_hits,
+                                          LaneTally& tally, uint32_t& lt_seen, uint32_t& lt_hits,
                                           uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook()) {
+    constexpr uint32_t TB = bin_cap<T8>();
     // ---- parse (divergent: only lanes that own a staged record) ----
-    bool sure = false;
+    bool sure = false, framed_ok = false;
     Rec r;
     rec_clear(r);
     if (mine) {
@@ -32,14 +38,29 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             sure = frame_short(fa_alignbyte(src.dw(i + 1), src.dw(i), pos), end - pos, pl);
             pos += pl;
         }
+        framed_ok = sure;
         if (sure && !(a.dbg & DBG_NO_PARSE)) {
             if (a.dbg & DBG_LOOP_PARSER) sure = parse_fast<COLS>(src, pos, end, r);
             else sure = parse_canon<COLS>(src, pos, end, r);
         }
-        if (!sure) {
-            unsigned int j = atomicAdd(&a.ctr->retry_count, 1u);
-            a.retry_idx[j] = rec_idx;
+    }
+    // second chance IN PLACE: a record the canonical-order walk is not sure about (other field order, duplicates,
+    // unknown fields) is parsed again by the order-free parser while its bytes still sit in the wave's LDS tile -
+    // only what that one cannot decide either (long varints, groups, 3-byte tags; broken frames) is deferred to
+    // deferred_kernel, which reads it back from HBM one record per lane.  Wave-uniform branch: canonical streams
+    // pay one ballot per tile.
+    if (FA_ANY(framed_ok && !sure) && !(a.dbg & (DBG_LOOP_PARSER | DBG_NO_PARSE | DBG_NO_SECOND))) {
+        if (framed_ok && !sure) {
+            LdsSrc src{tile};
+            rec_clear(r);
+            sure = parse_fast<COLS>(src, pos, end, r);
+            tally.second += sure ? 1u : 0u;
+            if (!sure) rec_clear(r);
         }
+    }
+    if (mine && !sure) {  // (one counter atomic per wave: the compiler folds the lanes' adds - s_bcnt1 + mbcnt)
+        unsigned int j = atomicAdd(&a.ctr->retry_count[a.par], 1u);
+        a.retry_idx[j] = rec_idx;
     }
     after_parse();
     // ---- sink ----
@@ -47,9 +68,9 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         if (sure) store_columns(a.cols, rec_idx, r, 0);
         return;
     }
-    n_ok += sure ? 1 : 0;
+    tally.ok += sure ? 1 : 0;
     if (a.dbg & DBG_NO_SINK) {
-        n_ok += (uint32_t)(r.time_received ^ r.bytes ^ r.packets ^ r.src_as ^ r.dst_as ^ r.etype) & 1;
+        tally.ok += (uint32_t)(r.time_received ^ r.bytes ^ r.packets ^ r.src_as ^ r.dst_as ^ r.etype) & 1;
         return;
     }
     const uint32_t t32 = (uint32_t)r.time_received;  // UInt64 -> DateTime (create.sh:39)
@@ -72,17 +93,27 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 else lt_seen = lt_hits = 0;
             }
         }
-        // tuple path: 16 bytes to this workgroup's private segment of the key's partition
+        // tuple path: one tuple to this workgroup's private segment of the key's partition
         uint32_t fill_part = 0xffffffffu;  // wave-tile kernel: the bin this lane has just filled
         if (pending && a.seg) {
             const uint32_t tbr = tb - tb_base;
-            const bool fits = tbr < TUPLE_TB_SPAN && b < TUPLE_MAX_BYTES && p < TUPLE_MAX_PACKETS && r.etype < TUPLE_MAX_ETYPE;
+            bool fits;
+            uint32_t part;
+            uint4 tv = make_uint4(0, 0, 0, 0);
+            uint2 tc = make_uint2(0, 0);
+            if (T8) {
+                fits = t8_fits(r.src_as, r.dst_as, tbr, b, p, r.etype);
+                tc = t8_pack(r.src_as, r.dst_as, (uint32_t)b, (uint32_t)p, tbr, r.etype, part);
+                tally.misfit8 += (!fits && tup16_fits(tbr, b, p, r.etype)) ? 1u : 0u;
+            } else {
+                fits = tup16_fits(tbr, b, p, r.etype);
+                part = h >> (32 - a.plog2);
+                tv = tup16_pack(r.src_as, r.dst_as, (uint32_t)b, (uint32_t)p, tbr, r.etype);
+            }
             if (fits) {
-                const uint32_t part = h >> (32 - a.plog2);
-                const uint4 tv = make_uint4(r.src_as, r.dst_as, (uint32_t)b | (tbr << 28), (uint32_t)p | (r.etype << 15));
                 if (bins) {
                     // wave-tile kernel: the tuple waits in the workgroup's LDS bin of its partition; the lane that takes
-                    // the last slot of a bin sends the 8 tuples off as one full, aligned 128-byte line (below)
+                    // the last slot of a bin sends the whole bin off as one full, aligned 128-byte line (bins_flush)
                     // (acquire: the tuple write below must not move above the claim - the previous occupants of the bin
                     // are read by the flusher until it resets the word; release: the tuple is written before it counts)
 #if FA_WT_EARLY
@@ -90,24 +121,28 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
 #else
                     const uint32_t slot = __hip_atomic_fetch_add(&bin_cnt[part], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;  // low half: slots taken, high half: slots written
 #endif
-                    if (slot < BIN_CAP) {
-                        bins[part * BIN_CAP + slot] = tv;
+                    if (slot < TB) {
+                        if (T8) reinterpret_cast<uint2*>(bins)[part * TB + slot] = tc;
+                        else bins[part * TB + slot] = tv;
 #if FA_WT_EARLY
                         lds_add_u32(&bin_cnt[part], 0x10000u);
 #else
                         __hip_atomic_fetch_add(&bin_cnt[part], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-                        fill_part = slot == BIN_CAP - 1 ? part : fill_part;
+                        fill_part = slot == TB - 1 ? part : fill_part;
                         pending = false;
-                    } else {  // the bin is on its way out: single 16-byte store to the back part of the segment
+                    } else {  // the bin is on its way out: single store to the back part of the segment
                         const uint32_t ob = lds_add_rtn_u32(&part_cnt[part], 0x10000u) >> 16;
                         if (ob < a.capb) {
-                            if (!(a.dbg & DBG_NO_TUPLE_STORE))
-                                a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob)] = tv;
+                            const size_t at = (size_t)part * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob);
+                            if (!(a.dbg & DBG_NO_TUPLE_STORE)) {
+                                if (T8) reinterpret_cast<uint2*>(a.seg)[at] = tc;
+                                else a.seg[at] = tv;
+                            }
                             pending = false;
                         }
                     }
-                } else {
+                } else if (!T8) {
                     const uint32_t q = atomicAdd(&part_cnt[part], 1u);
                     if (q < a.capq) {
                         if (!(a.dbg & DBG_NO_TUPLE_STORE)) {
@@ -128,7 +163,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         if (__builtin_amdgcn_ballot_w64(pending) != 0ull && !(a.dbg & DBG_NO_GLOBAL)) {  // wave-uniform
             Slot* sp = nullptr;
             if (pending) {
-                n_direct++;
+                tally.direct++;
                 sp = table_find_or_claim(a, k0, k1, h);
                 if (!sp) spill_park(a, k0, k1, b, p, c);
             }
@@ -164,19 +199,73 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
 // End-of-kernel counters: one global atomic per WORKGROUP.  All waves of the grid finish at about the same
 // time, and same-address atomics serialize at the memory side: one atomic per wave (8192 of them) was a
 // ~30 us tail on a 0.4 ms launch.
-__device__ __forceinline__ void block_counters_add(uint32_t* lds2, Counters* ctr, uint32_t n_ok, uint32_t n_direct) {
-    if (threadIdx.x < 2) lds2[threadIdx.x] = 0;
+__device__ __forceinline__ void block_counters_add(uint32_t* lds4, Counters* ctr, const LaneTally& t) {
+    if (threadIdx.x < 4) lds4[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t ok = (uint32_t)wave_sum_u64(n_ok), direct = (uint32_t)wave_sum_u64(n_direct);
+    const uint32_t ok = (uint32_t)wave_sum_u64(t.ok), direct = (uint32_t)wave_sum_u64(t.direct);
+    const uint32_t second = (uint32_t)wave_sum_u64(t.second), mis = (uint32_t)wave_sum_u64(t.misfit8);
     if (__lane_id() == 0) {
-        if (ok) atomicAdd(&lds2[0], ok);
-        if (direct) atomicAdd(&lds2[1], direct);
+        if (ok) atomicAdd(&lds4[0], ok);
+        if (direct) atomicAdd(&lds4[1], direct);
+        if (second) atomicAdd(&lds4[2], second);
+        if (mis) atomicAdd(&lds4[3], mis);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (lds2[0]) atomicAdd(&ctr->ok, (unsigned long long)lds2[0]);
-        if (lds2[1]) atomicAdd(&ctr->direct, (unsigned long long)lds2[1]);
+        if (lds4[0]) atomicAdd(&ctr->ok, (unsigned long long)lds4[0]);
+        if (lds4[1]) atomicAdd(&ctr->direct, (unsigned long long)lds4[1]);
+        if (lds4[2]) atomicAdd(&ctr->retried, (unsigned long long)lds4[2]);
+        if (lds4[3]) atomicAdd(&ctr->misfit8, (unsigned long long)lds4[3]);
     }
+}
+
+// ---- probe: where in time does this batch sit? ---------------------------------------------
+// 64 evenly spaced records are decoded by the 64 lanes of a wave; tb_base = (smallest time bucket seen) - 2, so
+// that the 4-bit relative bucket of the tuple path covers the batch (Kafka partitions are close to time-ordered;
+// records outside [tb_base, tb_base+16) take the direct path).  Wave-uniform result, the same for every wave that
+// asks: the wave-tile kernel evaluates it in its prologue; the workgroup-tile kernel gets it from probe_kernel.
+__device__ __forceinline__ uint32_t probe_tb_base(const KArgs& a) {
+    const uint32_t ln = __lane_id();
+    const uint32_t idx = a.n <= 64 ? ln : (uint32_t)(((uint64_t)ln * (a.n - 1)) / 63u);
+    uint32_t lo = 0xffffffffu;
+    if (idx < a.n) {
+        uint32_t pos = a.off[idx], end = a.off[idx + 1];
+        // tb_base is only a hint (it decides which records may use the tuple path, never a result), so
+        // the order-free fast parser is enough: samples it is not sure about are skipped
+        GlobalSrc src{reinterpret_cast<const uint32_t*>(a.buf)};
+        bool ok = end >= pos;
+        if (ok && a.framed) {
+            uint32_t pl = 0;
+            ok = frame_fast(window64(src, pos), end - pos, pl);
+            pos += pl;
+        }
+        if (ok) {
+            // what proto.Marshal emits (mocker.go:97): [Type 08 xx] then TimeReceived 10 <varint> - one or two
+            // cache-resident windows instead of a walk over the whole record; anything else: the general parser
+            uint64_t w = window64(src, pos);
+            if ((w & 0x80ffu) == 0x0008u) {
+                pos += 2;
+                w = window64(src, pos);
+            }
+            uint32_t vl;
+            uint64_t val;
+            if ((w & 0xffu) == 0x10u && varint6(w >> 8, vl, val) && pos + 1 + vl <= end) {
+                lo = time_bucket(a, (uint32_t)val);
+            } else {
+                Rec r;
+                rec_clear(r);
+                if (parse_fast<COL_TIME_RECEIVED>(src, pos, end, r)) lo = time_bucket(a, (uint32_t)r.time_received);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+    lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+    return lo == 0xffffffffu ? 0u : (lo > 2u ? lo - 2u : 0u);
+}
+__global__ __launch_bounds__(64) void probe_kernel(KArgs a) {
+    const uint32_t tb = probe_tb_base(a);
+    if (threadIdx.x == 0) a.ctr->tb_base = tb;
 }
 
 // ---- the tile kernel ----------------------------------------------------------
@@ -236,7 +325,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     if (MODE == MODE_INGEST && (KEYSETS & FA_KEYS_MINUTE_SERIES)) lds_minutes_clear(lm);
     const uint32_t tb_base = MODE == MODE_INGEST ? a.ctr->tb_base : 0u;
 
-    uint32_t n_ok = 0, n_direct = 0, lt_seen = 0, lt_hits = 0, no_fill = 0;
+    LaneTally tally;
+    uint32_t lt_seen = 0, lt_hits = 0, no_fill = 0;
     const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
     const uint32_t stride = gridDim.x;
     uint32_t t = blockIdx.x;
@@ -277,10 +367,10 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
             const uint32_t cbase = cur.lo & ~15u;
             const bool mine = tid < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
             if (tid < cur.nrec && !mine) {  // broken offsets: let the generic path judge it
-                unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
+                unsigned int j = atomicAdd(&a.ctr->exotic_count[a.par], 1u);
                 a.exotic_idx[j] = cur.r0 + tid;
             }
-            lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, n_ok, n_direct, lt_seen, lt_hits, nullptr, nullptr, no_fill);
+            lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, tally, lt_seen, lt_hits, nullptr, nullptr, no_fill);
         } else {
             // rare: the tile's bytes exceed the LDS buffer (big records): stage it in passes
             uint32_t done = 0;
@@ -303,12 +393,12 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                 if (nfit == 0) {
                     // one record larger than the LDS buffer (or broken offsets): generic path
                     if (tid == 0) {
-                        unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
+                        unsigned int j = atomicAdd(&a.ctr->exotic_count[a.par], 1u);
                         a.exotic_idx[j] = cur.r0 + done;
                     }
                     done += 1;
                 } else {
-                    lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, n_ok, n_direct, lt_seen, lt_hits, nullptr, nullptr, no_fill);
+                    lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, tally, lt_seen, lt_hits, nullptr, nullptr, no_fill);
                     done += nfit;
                 }
                 __syncthreads();  // the buffer is restaged by the next pass
@@ -368,7 +458,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                 a.seg_counts[((size_t)NPART_MAX + i) * a.nwg + blockIdx.x] = 0;
             }
         }
-        block_counters_add(part_cnt, a.ctr, n_ok, n_direct);  // (part_cnt has been written out: reused as scratch)
+        block_counters_add(part_cnt, a.ctr, tally);  // (part_cnt has been written out: reused as scratch)
     }
 }
 
@@ -402,12 +492,13 @@ __device__ __forceinline__ WTileDesc wtile_desc(const KArgs& a, uint32_t t, uint
     return d;
 }
 
-template <uint32_t KEYSETS>
+template <uint32_t KEYSETS, bool T8>
 __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
+    constexpr uint32_t TB = bin_cap<T8>();
     constexpr uint32_t COLS = cols_for_keysets<KEYSETS>();
     constexpr int WAVES = WBLOCK / 64;
     __shared__ __attribute__((aligned(16))) uint32_t tiles[WAVES * WT_STRIDE / 4];
-    __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BIN_CAP];
+    __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BIN_LINE];  // 256 x one 128-byte line (8 wide / 16 compact tuples)
     __shared__ uint32_t bin_cnt[NPART_MAX];
     __shared__ uint32_t part_cnt[NPART_MAX];
     __shared__ uint32_t flush_scratch[WAVES * 8];
@@ -424,10 +515,11 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
         }
     }
     if (KEYSETS & FA_KEYS_MINUTE_SERIES) lds_minutes_clear(lm);
-    const uint32_t tb_base = a.ctr->tb_base;
     uint32_t* tile = tiles + wave * (WT_STRIDE / 4);
 
-    uint32_t n_ok = 0, n_direct = 0, lt_seen = 0, lt_hits = 0;
+    LaneTally tally;
+    uint32_t lt_seen = 0, lt_hits = 0;
+    uint32_t tb_base = 0;  // (set in the prologue below, wave-uniform)
     const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
     const uint32_t stride = gridDim.x * WAVES;
     const uint32_t rounds = (ntiles + stride - 1) / stride;  // the same for every wave of the grid (flush barriers)
@@ -493,11 +585,11 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
             bool mine = tile_fits<WT_STRIDE - 16>(cur) && lane < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
             if (a.dbg & DBG_NOT_MINE) mine = mine && o0 == 0x7fffffffu;
             if (lane < cur.nrec && !mine && !(a.dbg & (DBG_NO_LANE_OFF | DBG_SYNTH_TILES | DBG_NOT_MINE))) {  // tile larger than the buffer / broken offsets
-                unsigned int j = atomicAdd(&a.ctr->exotic_count, 1u);
+                unsigned int j = atomicAdd(&a.ctr->exotic_count[a.par], 1u);
                 a.exotic_idx[j] = cur.r0 + lane;
             }
-            lane_work<MODE_INGEST, KEYSETS, COLS>(a, lt, lm, part_cnt, tb, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, n_ok,
-                                                  n_direct, lt_seen, lt_hits, bins, bin_cnt, fill, after_parse);
+            lane_work<MODE_INGEST, KEYSETS, COLS, T8>(a, lt, lm, part_cnt, tb, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, tally,
+                                                      lt_seen, lt_hits, bins, bin_cnt, fill, after_parse);
         }
     };
     // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous
@@ -507,6 +599,10 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     WTileDesc nxt = wtile_desc(a, t_second, ntiles);
     uint32_t n0 = 0;
     if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
+    // where in time does this batch sit?  Every wave decodes the same 64 samples while its first tile is in flight
+    // (no probe dispatch, no cross-workgroup hand-over: the answer is identical all over the grid)
+    tb_base = probe_tb_base(a);
+    if (blockIdx.x == 0 && tid == 0) a.ctr->tb_base = tb_base;  // (for agg_kernel)
     if constexpr (WT_EARLY && !(KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
         // One buffer, early issue: the tile buffer is dead once the wave has parsed it, so the next DMA is issued
         // between the parse and the sink and flies while the tuples are sunk.  The full bins of a round leave at the
@@ -518,7 +614,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
             FA_WT_CLK(c0);
             dma_wait_all();
             FA_WT_CLK(c1);
-            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
+            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, tally.direct);
             fill = 0xffffffffu;
             FA_WT_CLK(c2);
             WTileDesc d1{0, 0, 0, 0};
@@ -549,7 +645,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
             o1 = p1;
         }
         dma_wait_all();
-        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
+        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, tally.direct);
     } else {
         for (uint32_t round = 0; FA_WT_MORE(round); round++, t += stride) {
             FA_WT_CLK(c0);
@@ -560,7 +656,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
             FA_WT_CLK(c2);
             // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
             // queue and the wave would wait for the write acknowledgements on top of its tile (measured: +15 %)
-            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, n_direct);
+            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, tally.direct);
             const uint32_t t2 = tile_after_next();  // (dynamic: an LDS atomic - before the DMA, or the compiler drains vmcnt for it)
             cur = tile_current(nxt);
             o0 = n0;
@@ -592,29 +688,38 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
 #undef FA_WT_CLK
 #undef FA_WT_ACC
 #undef FA_WT_MORE
-    // what is left in the bins (fewer than BIN_CAP tuples each) goes to the back part of the segments
+    // what is left in the bins (fewer than a line each) goes to the back part of the segments
     if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
         __syncthreads();
-        for (uint32_t idx = tid; idx < (uint32_t)NPART_MAX * BIN_CAP; idx += WBLOCK) {
-            const uint32_t p = idx / BIN_CAP, sl = idx % BIN_CAP;
-            const uint32_t cnt = min(bin_cnt[p] & 0xffffu, BIN_CAP);
+        for (uint32_t idx = tid; idx < (uint32_t)NPART_MAX * TB; idx += WBLOCK) {
+            const uint32_t p = idx / TB, sl = idx % TB;
+            const uint32_t cnt = min(bin_cnt[p] & 0xffffu, TB);
             if (sl < cnt) {
                 const uint32_t ob = (part_cnt[p] >> 16) + sl;
-                const uint4 tv = bins[idx];
+                uint4 tv = make_uint4(0, 0, 0, 0);
+                uint2 tc = make_uint2(0, 0);
+                if (T8) tc = reinterpret_cast<const uint2*>(bins)[idx];
+                else tv = bins[idx];
                 if (ob < a.capb) {
-                    if (!(a.dbg & DBG_NO_TUPLE_STORE)) a.seg[(size_t)p * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob)] = tv;
+                    const size_t at = (size_t)p * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob);
+                    if (!(a.dbg & DBG_NO_TUPLE_STORE)) {
+                        if (T8) reinterpret_cast<uint2*>(a.seg)[at] = tc;
+                        else a.seg[at] = tv;
+                    }
                 } else {  // back part full (skewed batch): straight to the device-wide table
-                    const uint32_t by = tv.z & 0x0fffffffu, tbr = tv.z >> 28, pk = tv.w & 0x7fffu, et = tv.w >> 15;
+                    TupleVals v;
+                    if (T8) t8_unpack(tc, p, v);
+                    else tup16_unpack(tv, v);
                     uint64_t k0, k1;
-                    pack_key(tb_base + tbr, tv.x, tv.y, et, k0, k1);
-                    agg_global(a, k0, k1, key_hash(k0, k1), by, pk, 1);
-                    n_direct++;
+                    pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);
+                    agg_global(a, k0, k1, key_hash(k0, k1), v.bytes, v.packets, 1);
+                    tally.direct++;
                 }
             }
         }
         __syncthreads();
         if (tid < NPART_MAX) {
-            part_cnt[tid] += min(bin_cnt[tid] & 0xffffu, BIN_CAP) << 16;
+            part_cnt[tid] += min(bin_cnt[tid] & 0xffffu, TB) << 16;
             bin_cnt[tid] = 0;
         }
         __syncthreads();
@@ -648,65 +753,18 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
         if (a.seg)
             for (int i = tid; i < (1 << a.plog2); i += WBLOCK) {
                 const uint32_t w = part_cnt[i];
-                a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min((w & 0xffffu) * BIN_CAP, a.capf);
+                a.seg_counts[(size_t)i * a.nwg + blockIdx.x] = min((w & 0xffffu) * TB, a.capf);
                 a.seg_counts[((size_t)NPART_MAX + i) * a.nwg + blockIdx.x] = min(w >> 16, a.capb);
             }
     }
-    block_counters_add(bin_cnt, a.ctr, n_ok, n_direct);  // (the bins are empty by now: reused as scratch)
-}
-
-// ---- probe: where in time does this batch sit? ---------------------------------------------
-// 64 evenly spaced records are decoded; tb_base = (smallest time bucket
-// seen) - 2, so that the 4-bit relative bucket of the tuple path covers the batch (Kafka partitions
-// are close to time-ordered; records outside [tb_base, tb_base+16) take the direct path).
-__global__ __launch_bounds__(64) void probe_kernel(KArgs a) {
-    __shared__ uint32_t lo;
-    if (threadIdx.x == 0) lo = 0xffffffffu;
-    __syncthreads();
-    const uint32_t idx = a.n <= 64 ? threadIdx.x : (uint32_t)(((uint64_t)threadIdx.x * (a.n - 1)) / 63u);
-    if (idx < a.n) {
-        uint32_t pos = a.off[idx], end = a.off[idx + 1];
-        // tb_base is only a hint (it decides which records may use the tuple path, never a result), so
-        // the order-free fast parser is enough: samples it is not sure about are skipped
-        GlobalSrc src{reinterpret_cast<const uint32_t*>(a.buf)};
-        bool ok = end >= pos;
-        if (ok && a.framed) {
-            uint32_t pl = 0;
-            ok = frame_fast(window64(src, pos), end - pos, pl);
-            pos += pl;
-        }
-        if (ok) {
-            // what proto.Marshal emits (mocker.go:97): [Type 08 xx] then TimeReceived 10 <varint> - one or two
-            // cache-resident windows instead of a walk over the whole record; anything else: the general parser
-            uint64_t w = window64(src, pos);
-            if ((w & 0x80ffu) == 0x0008u) {
-                pos += 2;
-                w = window64(src, pos);
-            }
-            uint32_t vl;
-            uint64_t val;
-            if ((w & 0xffu) == 0x10u && varint6(w >> 8, vl, val) && pos + 1 + vl <= end) {
-                atomicMin(&lo, time_bucket(a, (uint32_t)val));
-            } else {
-                Rec r;
-                rec_clear(r);
-                if (parse_fast<COL_TIME_RECEIVED>(src, pos, end, r)) atomicMin(&lo, time_bucket(a, (uint32_t)r.time_received));
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a.ctr->tb_base = lo == 0xffffffffu ? 0u : (lo > 2u ? lo - 2u : 0u);
-        a.ctr->exotic_count = 0;  // the batch's deferral lists start empty (saves two memset dispatches per batch)
-        a.ctr->retry_count = 0;
-    }
+    block_counters_add(bin_cnt, a.ctr, tally);  // (the bins are empty by now: reused as scratch)
 }
 
 // Records the tile kernel could not stage (broken offsets, tiles larger than the LDS buffer): complete
 // semantics, one record per lane straight from HBM.
 template <int MODE, uint32_t KEYSETS>
 __device__ __forceinline__ void exotic_pass(const KArgs& a) {
-    const uint32_t cnt = a.ctr->exotic_count;
+    const uint32_t cnt = a.ctr->exotic_count[a.par];
     for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < cnt; j += gridDim.x * BLOCK) {
         uint32_t idx = a.exotic_idx[j];
         const uint8_t* p = a.buf + a.off[idx];
@@ -754,7 +812,7 @@ template <int MODE, uint32_t KEYSETS>
 __global__ __launch_bounds__(BLOCK) void deferred_kernel(KArgs a) {
     constexpr uint32_t COLS = MODE == MODE_DECODE ? (uint32_t)COL_ALL : cols_for_keysets<KEYSETS>();
     exotic_pass<MODE, KEYSETS>(a);
-    const uint32_t cnt = a.ctr->retry_count;
+    const uint32_t cnt = a.ctr->retry_count[a.par];
     const uint32_t rounds = (cnt + gridDim.x * BLOCK - 1) / (gridDim.x * BLOCK);
     uint32_t n_ok = 0;
     for (uint32_t it = 0; it < rounds; it++) {  // whole waves stay together (wave_combine below)
@@ -813,6 +871,10 @@ __global__ __launch_bounds__(BLOCK) void deferred_kernel(KArgs a) {
             }
         }
         if (sure && (KEYSETS & FA_KEYS_WIDE)) wide_sink_slow<KEYSETS>(a, r, tb);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the next batch's deferral lists start empty (see Counters)
+        a.ctr->exotic_count[a.par ^ 1u] = 0;
+        a.ctr->retry_count[a.par ^ 1u] = 0;
     }
     if (MODE == MODE_INGEST) {
         uint64_t tot = wave_sum_u64(n_ok);

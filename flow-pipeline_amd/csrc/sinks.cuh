@@ -37,7 +37,10 @@ constexpr int WT_RECS = 64;
 constexpr int WT_STRIDE = FA_WT_STRIDE;  // 5472 = 64 records x 85 B + alignment slack (16-byte multiple); overreads land in the next tile / the bins
 constexpr int WT_WG_PER_CU = 2;
 static_assert(WBLOCK % 64 == 0 && WBLOCK >= 256 && WBLOCK <= 1024 && WT_STRIDE % 16 == 0, "wave-tile geometry");
-constexpr uint32_t BIN_CAP = 8;     // a bin = one 128-byte line of tuples per key partition (256 x 8 x 16 B = 32 KiB per workgroup)
+constexpr uint32_t BIN_LINE = 8;    // a bin = one 128-byte line of tuples per key partition = 8 uint4 (256 x 128 B = 32 KiB per workgroup)
+// tuples per bin / per 128-byte line of a segment: 8 wide (16 B) or 16 compact (8 B) ones (table.cuh)
+template <bool T8>
+constexpr uint32_t bin_cap() { return T8 ? 16u : 8u; }
 constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table
 #ifndef FA_AGG_SLOTS
 #define FA_AGG_SLOTS 4096
@@ -48,8 +51,6 @@ constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table
 constexpr int AGG_SLOTS = FA_AGG_SLOTS;  // 32 B of LDS per slot (4096: 128 KiB)
 constexpr int AGG_SPLIT = FA_AGG_SPLIT;  // workgroups per key partition (each with its own LDS table)
 constexpr int AGG_PROBES = 16;
-constexpr uint32_t TUPLE_TB_SPAN = 16;        // time buckets a batch may span on the tuple path
-constexpr uint32_t TUPLE_MAX_BYTES = 1u << 28, TUPLE_MAX_PACKETS = 1u << 15, TUPLE_MAX_ETYPE = 1u << 16;
 constexpr uint32_t AGG_MAX_BATCH = 1u << 24;  // count <= 2^24 per slot keeps the packed LDS sums exact
 static_assert(TILE_STRIDE % 16 == 0, "LDS tile buffers must stay 16-byte aligned");
 
@@ -61,7 +62,7 @@ constexpr uint32_t FA_KEYS_WIDE = FA_KEYS_ADDR_PORT_PROTO | FA_KEYS_PORT_HIST | 
 constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense histograms
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
-       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_FRAME = 131072 };
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072 };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -69,7 +70,11 @@ struct SpillEntry {
 
 struct Counters {
     unsigned long long ok, bad, slow, spill_lost, used, direct, retried;
-    unsigned int exotic_count, spill_count, rows_count, retry_count, tb_base, ks_overflow, ks_rows, pad;
+    unsigned long long misfit8;  // records of compact-tuple launches that would have fitted a wide tuple only (format feedback)
+    // the deferral lists' fill levels come in two copies: batch B appends under copy B & 1 and its deferred kernel
+    // clears the OTHER copy for batch B + 1 (no memset dispatches, no reset race inside one kernel)
+    unsigned int exotic_count[2], retry_count[2];
+    unsigned int spill_count, rows_count, tb_base, ks_overflow, ks_rows, pad;
     unsigned long long t_wait, t_work, t_tiles, t_total;  // DBG_TIMING: core-clock cycles of wave 0 of every workgroup
     unsigned long long wused, wspill_lost;  // wide table (wide.cuh)
     unsigned int wspill_count, wrows_count;
@@ -128,6 +133,7 @@ struct KArgs {
     uint32_t nwg;          // workgroups of the tile kernel that filled the segments
     unsigned long long region;  // tuples per partition (nwg*capq plus a skew against power-of-two strides)
     uint32_t plog2;        // log2(key partitions)
+    uint32_t par;          // batch parity: which copy of the deferral counters this batch uses
     // wide key sets (wide.cuh)
     uint32_t key_sets;     // runtime mask (the KS_ALL kernel variant tests it)
     WSlot* wtab;
@@ -234,7 +240,11 @@ __device__ __forceinline__ void wave_fold_lds(uint32_t* scratch, bool& valid, ui
         if (w) atomicAdd(&acc[slot], (unsigned long long)w);
         valid = false;
     }
-    if (valid && win == ln) w += acc[slot];  // (behind the adds: LDS operations of a wave complete in order)
+    // (behind the adds: LDS operations of a wave complete in order.  The adds and this read sit in different
+    // branches of ONE thread's program, so nothing in the language orders them: the barrier pins the emitted order -
+    // the same class of compiler reordering bins_flush once hit)
+    asm volatile("" ::: "memory");
+    if (valid && win == ln) w += acc[slot];
 }
 
 // Inserts a FixedString(16) key into the distinct-key set.  The per-XCD L2s are not coherent, so a plain
@@ -540,14 +550,16 @@ __device__ __forceinline__ bool frame_short(uint32_t x, uint32_t rec_len, uint32
 }
 
 // Full bins leave as whole, aligned 128-byte lines, up to 8 bins per pass: lane group g (8 lanes) takes the
-// g-th filled bin, each lane copies one tuple - one store instruction writes 8 complete lines, no partial
-// lines and no workgroup barrier.  The producers of a bin's other slots may sit in other waves: the high
-// half of the bin word counts the slots WRITTEN, and nobody can take a slot of a full bin, so the spin
-// below only ever waits for straight-line code of waves that never wait for us (producers of this wave
+// g-th filled bin, each lane copies 16 bytes (one wide tuple or two compact ones) - one store instruction writes 8
+// complete lines, no partial lines and no workgroup barrier.  The producers of a bin's other slots may sit in other
+// waves: the high half of the bin word counts the slots WRITTEN, and nobody can take a slot of a full bin, so the
+// spin below only ever waits for straight-line code of waves that never wait for us (producers of this wave
 // finished in lockstep inside lane_work).  fill_part: the bin this lane filled (or ~0); scratch: 32 bytes of
 // wave-private LDS.  Must be called by the full wave.
+template <bool T8>
 __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t* bin_cnt, uint32_t* part_cnt, uint32_t* scratch,
                                            uint32_t fill_part, uint32_t tb_base, uint32_t& n_direct) {
+    constexpr uint32_t TB = bin_cap<T8>();
     const unsigned long long fm = __builtin_amdgcn_ballot_w64(fill_part != 0xffffffffu);
     if (fm == 0ull) return;
     const uint32_t ln = __lane_id(), g = ln >> 3, sub = ln & 7u;
@@ -563,26 +575,36 @@ __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t
         // (acquire / release pair with the producers' written-slot count: without it the COMPILER may move the
         // tuple read above the check - it did, and rows differed from the oracle at 16 M records)
         const uint32_t c0 = __hip_atomic_load(&bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint4 tq = bins[fp * BIN_CAP + sub];
+        const uint4 tq = bins[fp * BIN_LINE + sub];
         uint32_t line = 0;
         if (act && sub == 0) line = atomicAdd(&part_cnt[fp], 1u) & 0xffffu;  // low half: lines at the front
         bool late = false;
-        if (__builtin_amdgcn_ballot_w64(act && (c0 >> 16) < BIN_CAP) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(act && (c0 >> 16) < TB) != 0ull) {
             late = true;
-            while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < BIN_CAP) != 0ull) {}
+            while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < TB) != 0ull) {}
         }
         line = (uint32_t)__shfl((int)line, (int)(ln & ~7u));
         if (act) {
-            const uint4 tv = late ? bins[fp * BIN_CAP + sub] : tq;
-            if ((line + 1u) * BIN_CAP <= a.capf) {
-                if (!(a.dbg & DBG_NO_TUPLE_STORE))
-                    a.seg[(size_t)fp * a.region + (size_t)blockIdx.x * a.capq + line * BIN_CAP + sub] = tv;
+            const uint4 tv = late ? bins[fp * BIN_LINE + sub] : tq;
+            if ((line + 1u) * TB <= a.capf) {
+                // (compact tuples: region and capq are even, so the segment starts on a uint4 boundary)
+                const size_t seg0 = ((size_t)fp * a.region + (size_t)blockIdx.x * a.capq) >> (T8 ? 1 : 0);
+                if (!(a.dbg & DBG_NO_TUPLE_STORE)) a.seg[seg0 + line * BIN_LINE + sub] = tv;
             } else {  // front part full (skewed batch): straight to the device-wide table
-                const uint32_t qby = tv.z & 0x0fffffffu, qtbr = tv.z >> 28, qpk = tv.w & 0x7fffu, qet = tv.w >> 15;
-                uint64_t q0, q1;
-                pack_key(tb_base + qtbr, tv.x, tv.y, qet, q0, q1);
-                agg_global(a, q0, q1, key_hash(q0, q1), qby, qpk, 1);
-                n_direct++;
+                TupleVals v[2];
+                if (T8) {
+                    t8_unpack(make_uint2(tv.x, tv.y), fp, v[0]);
+                    t8_unpack(make_uint2(tv.z, tv.w), fp, v[1]);
+                } else {
+                    tup16_unpack(tv, v[0]);
+                }
+#pragma unroll
+                for (int e = 0; e < (T8 ? 2 : 1); e++) {
+                    uint64_t q0, q1;
+                    pack_key(tb_base + v[e].tbr, v[e].src_as, v[e].dst_as, v[e].etype, q0, q1);
+                    agg_global(a, q0, q1, key_hash(q0, q1), v[e].bytes, v[e].packets, 1);
+                    n_direct++;
+                }
             }
             // (release: behind the tuple reads above)
             if (sub == 0) __hip_atomic_store(&bin_cnt[fp], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -111,6 +111,74 @@ __host__ __device__ __forceinline__ uint32_t key_hash(uint64_t k0, uint64_t k1) 
     return h;
 }
 
+// ---- scatter-sink tuples (ingest.cuh -> agg.cuh) -----------------------------------------------------
+// A record that is not absorbed by the workgroup's hot-key table leaves the ingest kernel as a tuple in the
+// workgroup's private segment of its key partition.  Two formats; the host picks one per launch (flowagg.hip,
+// adaptive: compact while (almost) every record fits it).  A record that does not fit the launch's format takes
+// the direct device-wide-table path - formats only ever decide speed, never results.
+//   wide    (16 B): {SrcAS, DstAS, Bytes[27:0] | tbr << 28, Packets[14:0] | EType << 15}; partition = key_hash >> 24
+//   compact ( 8 B): SrcAS, DstAS < 2^20 (every publicly routed ASN), Bytes < 2^17, Packets < 2^9, EType one of
+//                   {0, 0x0800, 0x86dd, 0x0806}.  The low 8 bits of SrcAS are NOT stored: the partition is
+//                   part = SrcAS[7:0] ^ mix8(everything else of the key), a bijection for fixed "everything else",
+//                   so the aggregation workgroup of partition `part` recovers them - 72 bits of record in 64.
+//                   (Balanced whenever either SrcAS[7:0] or the rest of the key varies.)
+//                   lo = DstAS | SrcAS[19:8] << 20;  hi = Bytes | Packets << 17 | tbr << 26 | etcode << 30
+// tbr = time bucket relative to the launch's tb_base (< 16).
+constexpr uint32_t TUPLE_TB_SPAN = 16;
+constexpr uint32_t TUPLE_MAX_BYTES = 1u << 28, TUPLE_MAX_PACKETS = 1u << 15, TUPLE_MAX_ETYPE = 1u << 16;
+constexpr uint32_t T8_MAX_AS = 1u << 20, T8_MAX_BYTES = 1u << 17, T8_MAX_PACKETS = 1u << 9;
+struct TupleVals {
+    uint32_t src_as, dst_as, bytes, packets, tbr, etype;
+};
+__host__ __device__ __forceinline__ bool tup16_fits(uint32_t tbr, uint64_t b, uint64_t p, uint32_t etype) {
+    return tbr < TUPLE_TB_SPAN && b < TUPLE_MAX_BYTES && p < TUPLE_MAX_PACKETS && etype < TUPLE_MAX_ETYPE;
+}
+__host__ __device__ __forceinline__ uint4 tup16_pack(uint32_t src_as, uint32_t dst_as, uint32_t b, uint32_t p, uint32_t tbr, uint32_t etype) {
+    return make_uint4(src_as, dst_as, b | (tbr << 28), p | (etype << 15));
+}
+__host__ __device__ __forceinline__ void tup16_unpack(const uint4& t, TupleVals& v) {
+    v.src_as = t.x;
+    v.dst_as = t.y;
+    v.bytes = t.z & 0x0fffffffu;
+    v.tbr = t.z >> 28;
+    v.packets = t.w & 0x7fffu;
+    v.etype = t.w >> 15;
+}
+// 2-bit EType dictionary of the compact format: 0 -> 0 (absent), 1 -> 0x0800, 2 -> 0x86dd, 3 -> 0x0806
+__host__ __device__ __forceinline__ uint32_t t8_etcode(uint32_t etype) {
+    return etype == 0x0800u ? 1u : etype == 0x86ddu ? 2u : etype == 0x0806u ? 3u : 0u;
+}
+__host__ __device__ __forceinline__ uint32_t t8_etype(uint32_t code) {
+    return (code & 2u) ? ((code & 1u) ? 0x0806u : 0x86ddu) : ((code & 1u) ? 0x0800u : 0u);
+}
+// 8 well-mixed bits of the stored part of the key (lo = DstAS | SrcAS[19:8] << 20, kh = tbr | etcode << 4)
+__host__ __device__ __forceinline__ uint32_t t8_mix8(uint32_t lo, uint32_t kh) {
+    uint32_t x = lo * 0x9E3779B1u + kh * 0x85EBCA6Bu;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    return x >> 24;
+}
+__host__ __device__ __forceinline__ bool t8_fits(uint32_t src_as, uint32_t dst_as, uint32_t tbr, uint64_t b, uint64_t p, uint32_t etype) {
+    return tbr < TUPLE_TB_SPAN && (src_as | dst_as) < T8_MAX_AS && b < T8_MAX_BYTES && p < T8_MAX_PACKETS &&
+           (etype == 0u || t8_etcode(etype) != 0u);
+}
+__host__ __device__ __forceinline__ uint2 t8_pack(uint32_t src_as, uint32_t dst_as, uint32_t b, uint32_t p, uint32_t tbr, uint32_t etype,
+                                                  uint32_t& part) {
+    const uint32_t lo = dst_as | ((src_as >> 8) << 20);
+    const uint32_t kh = tbr | (t8_etcode(etype) << 4);
+    part = (src_as & 0xffu) ^ t8_mix8(lo, kh);
+    return make_uint2(lo, b | (p << 17) | (kh << 26));
+}
+__host__ __device__ __forceinline__ void t8_unpack(const uint2& t, uint32_t part, TupleVals& v) {
+    const uint32_t kh = t.y >> 26;
+    v.dst_as = t.x & 0xfffffu;
+    v.src_as = ((t.x >> 20) << 8) | ((part ^ t8_mix8(t.x, kh)) & 0xffu);
+    v.bytes = t.y & 0x1ffffu;
+    v.packets = (t.y >> 17) & 0x1ffu;
+    v.tbr = kh & 15u;
+    v.etype = t8_etype(kh >> 4);
+}
+
 #define FA_MAX_PROBES 128
 
 // Upsert into the device-wide table.  Returns false on overflow (probe limit).
