@@ -10,10 +10,17 @@ Kafka partition with its own 100 M records).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see the contract in the task description) with
-`roofline` (wire bytes / tile-kernel time vs 8 TB/s HBM peak, hipEvent-timed on
-the library's own stream) and `cpu_baseline` (the C oracle on this box's cores
-on a bounded sample of the same workload; N=1 only).
+Rank 0 prints ONE JSON line (see the contract in the task description):
+  roofline      wire bytes / hipEvent time of the WHOLE decode+aggregate path of a launch (ingest kernel +
+                second-chance parsers + tuple aggregation; SURVEY.md 8(d): t_kernel = decode + aggregate) vs the
+                8 TB/s HBM peak; the ingest kernel alone is reported beside it as `dominant_kernel`;
+  cpu_baseline  the C oracle on this box's cores (affinity mask), thread sweep, best run; N=1 only;
+  parity        every record of the step verified against the oracle (per-chunk row checksums), outside the
+                timed region; N=1 only;
+  host_fed      the PCIe-inclusive rate through fa_ingest (host buffers) - a secondary figure, never `value`.
+Other workloads (side measurements, their JSON goes to profiles/): --mode zipf --key-sets 7 (config 3 shape),
+--key-sets 9 (config 5 shape), --mode goflow / reversed (67-field producer / order-free parser), --stage decode
+(projection only).
 """
 import argparse
 import json
@@ -28,18 +35,26 @@ sys.path.insert(0, ROOT)
 import _pkg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# HBM bytes per launch from rocprofv3 PMC passes of THIS command line (tools/profile.sh; PMC counters
-# cannot be read from inside the process).  Only quoted when the workload is the default one profiled.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")
+# HBM bytes per launch from rocprofv3 PMC passes of THIS command line (tools/profile.sh; PMC counters cannot be
+# read from inside the process).  Quoted only for the default workload AND when the file was produced by the very
+# sources this process runs (source_hash stamp).
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+SOA_BYTES_PER_RECORD = 5 * 8 + 7 * 4 + 3 * 16 + 1  # fa_columns: 15 columns + status byte
 
 
-def pmc_traffic(default_workload, kernel_key="tile_kernel"):
-    if not default_workload or not os.path.exists(TRAFFIC_FILE):
-        return None, None
+def pmc_traffic(fa, default_workload):
+    """-> (path traffic bytes per launch, per-kernel dict, note)"""
+    if not default_workload:
+        return None, None, "not the profiled workload"
+    if not os.path.exists(TRAFFIC_FILE):
+        return None, None, "no PMC profile committed"
     with open(TRAFFIC_FILE) as f:
         t = json.load(f)
+    if t.get("source_hash") != fa.source_hash():
+        return None, None, "profiles/r02_traffic.json was measured on other sources (%s != %s)" % (t.get("source_hash"), fa.source_hash())
     k = t.get("kernels", {})
-    return k.get(kernel_key, {}).get("traffic_bytes"), k
+    total = sum(v.get("traffic_bytes", 0.0) for v in k.values())
+    return total or None, k, None
 
 
 def mix64(z):
@@ -63,6 +78,45 @@ def rows_checksum(rows):
         return int((h * v).sum(dtype=np.uint64))
 
 
+def cpu_baseline(po, gp, sample, n_rec):
+    """The C oracle (decode + 15-column projection + hash rollup, one shard per thread, merge by key partition) on
+    the cores this process may use.  Thread sweep, best run reported; the per-core figure stays beside it."""
+    cores = len(os.sched_getaffinity(0))
+    sweep = {}
+    one_n = min(sample, 4_000_000)
+    res = None
+    for th in sorted({1, 8, 32, cores} & set(range(1, cores + 1)) | {1}):
+        n = one_n if th == 1 else sample
+        r = po.bench_rollup(gp, 0, n, th)
+        assert r["bad"] == 0
+        sweep[th] = n / r["seconds"]
+        if th != 1 and (res is None or sweep[th] > res[1]):
+            res = (th, sweep[th], r)
+    if res is None or sweep[1] >= res[1]:  # (a 1-core box, or threads that do not pay off)
+        r1 = po.bench_rollup(gp, 0, one_n, 1)
+        res = (1, max(sweep[1], one_n / r1["seconds"]), r1)
+        sample_used = one_n
+    else:
+        sample_used = sample
+    th, best, r = res
+    out = {
+        "value": best,
+        "unit": "FlowMessages/s",
+        "cores": th,
+        "cores_available": cores,
+        "kind": "port",
+        "sample": "first %d records of the same workload (%.2f GB wire), C oracle restatement (generic protobuf walk + "
+                  "15-column projection + open-addressing rollup), one shard per thread, shard tables merged by key "
+                  "partition; best of a thread sweep; the Go inserter + ClickHouse cannot run in this image"
+                  % (sample_used, r["wire_bytes"] / 1e9),
+        "seconds": r["seconds"],
+        "thread_sweep_records_per_s": {str(k): v for k, v in sorted(sweep.items())},
+        "single_core_value": sweep[1],
+    }
+    assert out["value"] >= out["single_core_value"] * 0.999, out
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,12 +124,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--records", type=int, default=100_000_000, help="records per GPU per step")
     ap.add_argument("--chunk", type=int, default=16_666_667, help="records per ingest launch (<= 2^24)")
-    ap.add_argument("--mode", default="aspairs", choices=["mocker", "aspairs", "zipf"])
+    ap.add_argument("--mode", default="aspairs", choices=["mocker", "aspairs", "zipf", "goflow", "reversed", "distinct"])
+    ap.add_argument("--stage", default="ingest", choices=["ingest", "decode"],
+                    help="decode: the projection stage alone (wire bytes -> 15 SoA columns in HBM, fa_decode_device)")
     ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="records timed on the CPU oracle (0 = skip)")
     ap.add_argument("--key-sets", type=int, default=1, help="fa key_sets mask (must include 1 = flows_5m rollup); 9 = config 5's "
                     "two concurrent key sets; side measurements only - the default is the BASELINE metric")
     ap.add_argument("--zipf-s", type=int, default=110, help="zipf exponent x100 for --mode zipf")
-    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the full-step parity check against the oracle")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive fa_ingest measurement")
     ap.add_argument("--no-assert", action="store_true", help="ablation runs (FA_DEBUG_FLAGS): skip result checks")
     args = ap.parse_args()
 
@@ -105,32 +162,42 @@ def main():
 
     fa = _pkg.load()
     fa.build()
-    mode = {"mocker": fa.MOCK_MOCKER, "aspairs": fa.MOCK_ASPAIRS, "zipf": fa.MOCK_ZIPF}[args.mode]
+    mode = {"mocker": fa.MOCK_MOCKER, "aspairs": fa.MOCK_ASPAIRS, "zipf": fa.MOCK_ZIPF, "goflow": fa.MOCK_GOFLOW,
+            "reversed": fa.MOCK_REVERSED, "distinct": fa.MOCK_DISTINCT}[args.mode]
     n_rec = args.records
     # every rank = one Kafka partition with its own stream (seed 2 = config 2, + rank)
     mp = fa.mock_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000,
                         zipf_s_x100=args.zipf_s)
     assert args.key_sets & fa.FA_KEYS_AS_PAIR, "--key-sets must include the flows_5m rollup"
 
-    agg = fa.FlowAgg(device=local_rank, framed=True, table_capacity_log2=20, key_sets=args.key_sets,
-                     max_batch_records=args.chunk, wide_capacity_log2=26 if args.key_sets & 8 else 0,
-                     topk_capacity_log2=25 if args.key_sets & 6 else 0)  # distinct addresses: 2^24 in the zipf / aspairs generators
+    def new_ctx():
+        return fa.FlowAgg(device=local_rank, framed=True, table_capacity_log2=20, key_sets=args.key_sets,
+                          max_batch_records=args.chunk, wide_capacity_log2=26 if args.key_sets & 8 else 0,
+                          topk_capacity_log2=25 if args.key_sets & 6 else 0)  # distinct addresses: 2^24 in the zipf / aspairs generators
+
+    agg = new_ctx()
     chunks = []
     wire_bytes = 0
     i0 = 0
+    rec_cap = fa.mock_record_cap(mode)
     while i0 < n_rec:
         m = min(args.chunk, n_rec - i0)
-        cap = m * 96 + 4096
+        cap = m * rec_cap + 4096
         d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
         d_off = torch.empty(m + 1, dtype=torch.int32, device=dev)
         w = agg.mock_generate_device(mp, i0, m, d_buf.data_ptr(), cap, d_off.data_ptr())
-        chunks.append((d_buf, d_off, w, m))
+        chunks.append((d_buf, d_off, w, m, i0))
         wire_bytes += w
         i0 += m
 
+    decode_stage = args.stage == "decode"
+
     def step():
-        for d_buf, d_off, w, m in chunks:
-            agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
+        for d_buf, d_off, w, m, _ in chunks:
+            if decode_stage:
+                agg.decode_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
+            else:
+                agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
 
     def fence():
         agg.sync()
@@ -153,41 +220,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    launches = st1["kernel_launches"] - st0["kernel_launches"]
-    kern_s = (st1["kernel_ns_total"] - st0["kernel_ns_total"]) * 1e-9
-    batch_s = (st1["batch_ns_total"] - st0["batch_ns_total"]) * 1e-9  # tile + retry + exotic + agg kernels
     bytes_per_launch = wire_bytes / len(chunks)
-    avg_launch_s = kern_s / max(launches, 1)
-    avg_batch_s = batch_s / max(launches, 1)
-    achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-    achieved_batch = bytes_per_launch / avg_batch_s / 1e9 if avg_batch_s > 0 else 0.0
-
-    # window close across ranks (the only exchange step): gather + merge flows_5m rows
-    t_merge = time.perf_counter()
-    if world > 1:
-        merged = fa.dist.close_window_merged(agg, fa.ALL_TIMESLOTS, device=xdev)
-    else:
-        merged = agg.close_window(fa.ALL_TIMESLOTS)
-    topk_rows = None
-    if args.key_sets & fa.FA_KEYS_SRCADDR_CMS:
-        # BASELINE configs[3] shape: per-GPU sketches, RCCL all-reduce at window close, top-k over the union of the
-        # ranks' candidates (dist.topk_merged); single rank: the local ranking
-        if world > 1 and backend == "nccl":
-            topk_rows = fa.dist.topk_merged(agg, fa.FA_KEYS_SRCADDR_CMS, 100, candidates_per_rank=1000, device=xdev)
-        else:
-            topk_rows = agg.topk(fa.FA_KEYS_SRCADDR_CMS, 100)
-    merge_ms = (time.perf_counter() - t_merge) * 1e3
-    total_steps = args.warmup + args.steps
-    ok_total = int(merged["count"].sum())
-    expect = n_rec * total_steps * world
-    assert args.no_assert or ok_total == expect, "merged count() %d != records ingested %d" % (ok_total, expect)
-
     value = n_rec * args.steps * world / elapsed
-    traffic, traffic_all = pmc_traffic(args.records == 100_000_000 and args.chunk == 16_666_667 and args.mode == "aspairs"
-                                       and not os.environ.get("FA_DEBUG_FLAGS") and args.key_sets == 1,
-                                       "wtile_kernel" if st1["wave_tile_launches"] > st0["wave_tile_launches"] else "tile_kernel")
-    out = {
-        "metric": "FlowMessages/sec aggregated into flows_5m",
+    common = {
+        "metric": "FlowMessages/sec aggregated into flows_5m" if not decode_stage else "FlowMessages/sec decoded and projected into SoA columns",
         "value": value,
         "unit": "FlowMessages/s",
         "n_gpus": world,
@@ -199,76 +235,166 @@ def main():
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
-        "config": {
-            "workload": "BASELINE configs[1]: 1xMI355X per rank, %d mocker-shaped framed FlowMessages, "
-                        "64k SrcAS/DstAS pairs x 2 ETypes x 3 five-minute windows, sum(Bytes,Packets)+count() group-by"
-                        % n_rec,
-            "records_per_gpu_per_step": n_rec,
-            "wire_bytes_per_gpu_per_step": wire_bytes,
-            "bytes_per_record": wire_bytes / n_rec,
-            "generator": args.mode,
-            "key_sets": args.key_sets,
-            "launches_per_step": len(chunks),
-            "partitioning": "one Kafka partition per GPU, no data-path collective; rows all-gathered at window close",
-            "window_close_merge_ms": merge_ms,
-            "groups": int(len(merged)),
-            "topk_src_addr_rows": None if topk_rows is None else int(len(topk_rows)),
-            "records_direct_path": int(st1["records_direct"] - st0["records_direct"]),
-            "records_second_chance_parser": int(st1["records_retried"] - st0["records_retried"]),
-            "wire_GBps_whole_job": wire_bytes * args.steps * world / elapsed / 1e9,
-        },
-        "roofline": {
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "traffic_source": "profiles/r01_traffic.json: rocprofv3 --pmc, 2*FETCH_SIZE (gfx950 wide-read "
-                              "correction) + WRITE_SIZE, bytes per launch" if traffic else None,
-            "kernel": ("fa::wtile_kernel<%s>" if st1["wave_tile_launches"] > st0["wave_tile_launches"] else "fa::tile_kernel<MODE_INGEST, %s>")
-                      % ("AS_PAIR" if args.key_sets == 1 else "KS_ALL"),
-            "algorithmic_bytes_per_launch": bytes_per_launch,
-            "avg_launch_ms": avg_launch_s * 1e3,
-            "launches_timed": int(launches),
-            # every kernel of a batch (tile + second-chance parsers + tuple aggregation), same bytes
-            "all_kernels_avg_ms": avg_batch_s * 1e3,
-            "all_kernels_achieved": achieved_batch,
-            "all_kernels_frac": achieved_batch / HBM_PEAK_GBS,
-            "agg_kernel_traffic": (traffic_all or {}).get("agg_kernel", {}).get("traffic_bytes"),
-        },
     }
+
+    if decode_stage:
+        launches = st1["decode_launches"] - st0["decode_launches"]
+        dec_s = (st1["decode_ns_total"] - st0["decode_ns_total"]) * 1e-9 / max(launches, 1)
+        alg = bytes_per_launch + SOA_BYTES_PER_RECORD * (n_rec / len(chunks))
+        out = dict(common)
+        out["config"] = {
+            "workload": "projection stage of BASELINE configs[1]: %d framed FlowMessages -> 15 SoA columns + status in HBM "
+                        "(fa_decode_device; tile_kernel<MODE_DECODE>), generator %s" % (n_rec, args.mode),
+            "records_per_gpu_per_step": n_rec, "wire_bytes_per_gpu_per_step": wire_bytes, "launches_per_step": len(chunks),
+            "soa_bytes_per_record": SOA_BYTES_PER_RECORD,
+        }
+        out["roofline"] = {
+            "bound": "hbm", "achieved": alg / dec_s / 1e9 if dec_s else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg / dec_s / 1e9 / HBM_PEAK_GBS if dec_s else 0.0, "traffic": None,
+            "kernel": "fa::tile_kernel<MODE_DECODE, 1> + fa::deferred_kernel<MODE_DECODE, 1>",
+            "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_model": "wire bytes read once + %d B of columns written per record (SURVEY.md 8(d))" % SOA_BYTES_PER_RECORD,
+            "avg_launch_ms": dec_s * 1e3, "launches_timed": int(launches),
+        }
+        if rank == 0:
+            print(json.dumps(out))
+        agg.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    launches = st1["kernel_launches"] - st0["kernel_launches"]
+    kern_s = (st1["kernel_ns_total"] - st0["kernel_ns_total"]) * 1e-9
+    batch_s = (st1["batch_ns_total"] - st0["batch_ns_total"]) * 1e-9  # ingest kernel + second-chance parsers + tuple aggregation
+    avg_launch_s = kern_s / max(launches, 1)
+    avg_batch_s = batch_s / max(launches, 1)
+    achieved_kernel = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    achieved_path = bytes_per_launch / avg_batch_s / 1e9 if avg_batch_s > 0 else 0.0
+    wave = st1["wave_tile_launches"] > st0["wave_tile_launches"]
+    compact = st1["compact_tuple_launches"] - st0["compact_tuple_launches"]
+
+    # window close across ranks (the only exchange step): gather + merge flows_5m rows
+    t_merge = time.perf_counter()
+    if world > 1:
+        merged = fa.dist.close_window_merged(agg, fa.ALL_TIMESLOTS, device=xdev)
+    else:
+        merged = agg.close_window(fa.ALL_TIMESLOTS)
+    merge_ms = (time.perf_counter() - t_merge) * 1e3
+    topk_rows = None
+    topk_note = None
+    if args.key_sets & fa.FA_KEYS_SRCADDR_CMS:
+        # BASELINE configs[3] shape: per-GPU sketches, RCCL all-reduce at window close, top-k over the union of EVERY
+        # rank's distinct addresses (exact w.r.t. the merged sketch); single rank: the local ranking
+        if world > 1:
+            topk_rows = fa.dist.topk_merged(agg, fa.FA_KEYS_SRCADDR_CMS, 100, candidates_per_rank=None, device=xdev)
+            topk_note = "exact ranking of the merged sketch: every rank's distinct addresses are candidates"
+        else:
+            topk_rows = agg.topk(fa.FA_KEYS_SRCADDR_CMS, 100)
+            topk_note = "exact ranking of this rank's sketch over its distinct-address set"
+    total_steps = args.warmup + args.steps
+    ok_total = int(merged["count"].sum())
+    expect = n_rec * total_steps * world
+    assert args.no_assert or ok_total == expect, "merged count() %d != records ingested %d" % (ok_total, expect)
+
+    default_workload = (args.records == 100_000_000 and args.chunk == 16_666_667 and args.mode == "aspairs"
+                        and not os.environ.get("FA_DEBUG_FLAGS") and args.key_sets == 1 and wave)
+    traffic, traffic_all, traffic_note = pmc_traffic(fa, default_workload)
+    fmt = "compact8" if compact == launches else "wide16" if compact == 0 else "mixed (%d of %d launches compact)" % (compact, launches)
+    ks_name = "AS_PAIR" if args.key_sets == 1 else "KS_ALL" if args.key_sets > 7 else str(args.key_sets)
+    out = dict(common)
+    out["config"] = {
+        "workload": ("BASELINE configs[1]: 1xMI355X per rank, %d mocker-shaped framed FlowMessages, "
+                     "64k SrcAS/DstAS pairs x 2 ETypes x 3 five-minute windows, sum(Bytes,Packets)+count() group-by" % n_rec)
+                    if args.mode == "aspairs" and args.key_sets == 1 else
+                    "side measurement: generator %s, key_sets %d, %d framed FlowMessages per rank" % (args.mode, args.key_sets, n_rec),
+        "records_per_gpu_per_step": n_rec,
+        "wire_bytes_per_gpu_per_step": wire_bytes,
+        "bytes_per_record": wire_bytes / n_rec,
+        "generator": args.mode,
+        "key_sets": args.key_sets,
+        "launches_per_step": len(chunks),
+        "tuple_format": fmt,
+        "partitioning": "one Kafka partition per GPU, no data-path collective; rows all-gathered at window close",
+        "window_close_merge_ms": merge_ms,
+        "groups": int(len(merged)),
+        "topk_src_addr_rows": None if topk_rows is None else int(len(topk_rows)),
+        "topk": topk_note,
+        "records_direct_path": int(st1["records_direct"] - st0["records_direct"]),
+        "records_second_chance_parser": int(st1["records_retried"] - st0["records_retried"]),
+        "records_generic_parser": int(st1["records_slow"] - st0["records_slow"]),
+        "wire_GBps_whole_job": wire_bytes * args.steps * world / elapsed / 1e9,
+    }
+    t8 = "true" if compact else "false"
+    out["roofline"] = {
+        "bound": "hbm",
+        # t_kernel = decode + aggregate -> every kernel of a launch, first event to last
+        "achieved": achieved_path,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved_path / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_source": ("profiles/r02_traffic.json (sources %s): rocprofv3 --pmc, 2*FETCH_SIZE (gfx950 wide-read correction) + "
+                           "WRITE_SIZE, bytes per launch, summed over the path's kernels" % fa.source_hash()) if traffic else traffic_note,
+        "kernel": ("decode+aggregate path of one launch: fa::wtile_kernel<%s, %s> + fa::deferred_kernel + fa::agg_kernel<%s>" % (ks_name, t8, t8)) if wave
+                  else "decode+aggregate path of one launch: fa::tile_kernel<MODE_INGEST, %s> + fa::deferred_kernel" % ks_name,
+        "algorithmic_bytes_per_launch": bytes_per_launch,
+        "avg_launch_ms": avg_batch_s * 1e3,
+        "launches_timed": int(launches),
+        "dominant_kernel": {
+            "name": ("fa::wtile_kernel<%s, %s>" % (ks_name, t8)) if wave else "fa::tile_kernel<MODE_INGEST, %s>" % ks_name,
+            "avg_launch_ms": avg_launch_s * 1e3,
+            "achieved": achieved_kernel,
+            "frac": achieved_kernel / HBM_PEAK_GBS,
+            "traffic": ((traffic_all or {}).get("wtile_kernel") or {}).get("traffic_bytes"),
+        },
+        "traffic_by_kernel": {k: v.get("traffic_bytes") for k, v in (traffic_all or {}).items()} or None,
+    }
+
+    if rank == 0 and world == 1 and not args.no_verify and not args.no_assert:
+        # parity on the WHOLE step: every chunk again through a fresh ctx, its rows against the oracle's rows for the
+        # same records (order-independent checksum of (key, sums); u64 sums commute, so equal chunk results = equal step)
+        po = _pkg.load_oracle()
+        gp = po.gen_params(mode=mode, framed=1, seed=2, n_total=n_rec, span_secs=900, per_sec=400_000, zipf_s_x100=args.zipf_s)
+        cores = len(os.sched_getaffinity(0))
+        ok = True
+        verified = 0
+        t_v = time.perf_counter()
+        for d_buf, d_off, w, m, first in chunks:
+            check = fa.FlowAgg(device=local_rank, framed=True, table_capacity_log2=20, max_batch_records=args.chunk)
+            check.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
+            rows = check.read_window()
+            cst = check.stats()
+            check.close()
+            ref = po.bench_rollup(gp, first, m, max(1, min(cores, 64)))
+            ok = ok and rows_checksum(rows) == ref["checksum"] and ref["bad"] == 0 and cst["records_bad"] == 0 \
+                and ref["wire_bytes"] == w and ref["groups"] == len(rows)
+            verified += m
+        out["parity"] = {"ok": bool(ok), "records_verified": int(verified), "of_records_per_step": n_rec,
+                         "how": "per launch: GPU flows_5m rows vs C-oracle rows of the same records (row count, wire bytes, "
+                                "order-independent checksum over keys and sums)", "seconds": time.perf_counter() - t_v}
+        assert ok, "GPU rows differ from the oracle"
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         po = _pkg.load_oracle()
-        sample = min(args.cpu_sample, n_rec)
-        gp = po.gen_params(mode=mode, framed=1, seed=2, n_total=n_rec, span_secs=900, per_sec=400_000)
-        cores = os.cpu_count() or 1
-        res = po.bench_rollup(gp, 0, sample, cores)
-        one = po.bench_rollup(gp, 0, min(sample, 2_000_000), 1)  # the same code on ONE core (scalar port), for scale
-        out["cpu_baseline"] = {
-            "value": sample / res["seconds"],
-            "unit": "FlowMessages/s",
-            "cores": cores,
-            "kind": "port",
-            "sample": "first %d records of the same workload (%.2f GB wire), C oracle restatement "
-                      "(decode+project+hash rollup), one shard per thread + pairwise tree merge of the shard tables; "
-                      "the Go inserter + ClickHouse cannot run in this image" % (sample, res["wire_bytes"] / 1e9),
-            "seconds": res["seconds"],
-            "single_core_value": min(sample, 2_000_000) / one["seconds"],
-        }
-        if not args.no_verify:
-            # parity on the same sample: GPU rows checksum == oracle rows checksum
-            d_buf, d_off, w, m = chunks[0]
-            s = min(sample, m)
-            check = fa.FlowAgg(device=local_rank, framed=True, table_capacity_log2=20, max_batch_records=args.chunk)
-            nbytes = int(d_off[s].item())
-            check.ingest_device(d_buf.data_ptr(), nbytes, d_off.data_ptr(), s)
-            rows = check.read_window()
-            check.close()
-            if s == sample:
-                out["parity_sample_ok"] = bool(rows_checksum(rows) == res["checksum"] and res["bad"] == 0)
-                assert out["parity_sample_ok"], "GPU rows differ from the oracle on the CPU sample"
+        gp = po.gen_params(mode=mode, framed=1, seed=2, n_total=n_rec, span_secs=900, per_sec=400_000, zipf_s_x100=args.zipf_s)
+        out["cpu_baseline"] = cpu_baseline(po, gp, min(args.cpu_sample, n_rec), n_rec)
+
+    if rank == 0 and world == 1 and not args.no_host_fed and not args.no_assert:
+        # the path a Kafka consumer uses: host buffers -> pinned staging -> H2D -> the same kernels (never `value`)
+        nh = min(8_000_000, n_rec)
+        hb, ho = fa.mock_generate_host(mp, 0, nh)
+        with fa.FlowAgg(device=local_rank, framed=True, max_batch_records=1 << 22) as hagg:
+            hagg.ingest(hb, ho)
+            hagg.sync()
+            th = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                hagg.ingest(hb, ho)
+            hagg.sync()
+            dt = (time.perf_counter() - th) / reps
+            assert int(hagg.read_window()["count"].sum()) == nh * (reps + 1)
+        out["host_fed"] = {"value": nh / dt, "unit": "FlowMessages/s", "wire_GBps": hb.nbytes / dt / 1e9,
+                           "what": "fa_ingest from pageable host memory (%d records per call): multi-threaded copy into pinned "
+                                   "staging + H2D over PCIe + kernels; link ceiling ~63 GB/s" % nh}
     if rank == 0:
         print(json.dumps(out))
     agg.close()

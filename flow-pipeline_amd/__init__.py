@@ -33,7 +33,7 @@ FA_KEYS_PORT_HIST = 16
 FA_KEYS_MINUTE_SERIES = 32
 ALL_TIMESLOTS = 0xFFFFFFFF
 
-MOCK_MOCKER, MOCK_ASPAIRS, MOCK_ZIPF = 0, 1, 2
+MOCK_MOCKER, MOCK_ASPAIRS, MOCK_ZIPF, MOCK_GOFLOW, MOCK_DISTINCT, MOCK_REVERSED = 0, 1, 2, 3, 4, 5
 T0 = 1_600_000_200  # multiple of 300
 
 ERRORS = {
@@ -62,7 +62,8 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "records_ok", "records_bad", "records_slow", "bytes_in", "batches", "table_used",
         "table_capacity", "kernel_ns", "kernel_ns_total", "kernel_launches", "batch_ns_total",
-        "records_direct", "records_retried", "wide_used", "wide_capacity", "wave_tile_launches")]
+        "records_direct", "records_retried", "wide_used", "wide_capacity", "wave_tile_launches",
+        "compact_tuple_launches", "records_misfit_compact", "decode_ns_total", "decode_launches")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -85,7 +86,8 @@ class Columns(C.Structure):
 
 class DeviceState(C.Structure):
     _fields_ = [("cms_src", C.c_void_p), ("cms_dst", C.c_void_p), ("cms_words", C.c_size_t),
-                ("port_hist", C.c_void_p), ("port_hist_words", C.c_size_t)]
+                ("port_hist", C.c_void_p), ("port_hist_words", C.c_size_t),
+                ("cms_src_merged", C.c_void_p), ("cms_dst_merged", C.c_void_p)]
 
 
 ROW5M_DTYPE = np.dtype([
@@ -114,7 +116,7 @@ EXPORTS = [
     "fa_abi_version", "fa_create", "fa_destroy", "fa_last_error", "fa_ingest", "fa_ingest_device",
     "fa_sync", "fa_decode", "fa_decode_device", "fa_open_timeslots", "fa_close_window",
     "fa_read_window", "fa_topk", "fa_topk_merge_keys", "fa_cms_query", "fa_cms_read", "fa_cms_reset",
-    "fa_device_state_get", "fa_merge_rows", "fa_merge_allreduce", "fa_stats",
+    "fa_device_state_get", "fa_merged_view_set", "fa_merge_rows", "fa_merge_allreduce", "fa_stats",
     "fa_mock_generate_device", "fa_mock_generate_host",
     "fa_read_window_app", "fa_close_window_app", "fa_merge_rows_app", "fa_top_ports", "fa_merge_ports",
     "fa_minute_series", "fa_merge_minutes", "fa_dashboard_reset", "fa_rows_to_rowbinary", "fa_format_addr",
@@ -160,6 +162,19 @@ def build(force=False):
     return LIB_PATH
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the library's sources: stamps profiles (tools/prof_summary.py) so that
+    bench.py only quotes PMC traffic measured on the code it is running."""
+    import hashlib
+    srcdir = os.path.join(_HERE, "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(srcdir)) + [os.path.join("..", "..", "include", "flowagg.h")]:
+        if f.endswith((".cuh", ".hip", ".h", "Makefile")):
+            with open(os.path.join(srcdir, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def lib():
     """Load libflowagg.so.  Raises (never falls back) when it is not built."""
     global _LIB
@@ -191,6 +206,7 @@ def lib():
     L.fa_cms_read.argtypes = [vp, u32, vp, sz]
     L.fa_cms_reset.argtypes = [vp, u32]
     L.fa_device_state_get.argtypes = [vp, C.POINTER(DeviceState)]
+    L.fa_merged_view_set.argtypes = [vp, C.c_int]
     L.fa_merge_rows.argtypes = [vp, vp, sz]
     L.fa_merge_allreduce.argtypes = [vp, vp]
     L.fa_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -216,9 +232,14 @@ def mock_params(mode=MOCK_MOCKER, framed=1, seed=1, n_total=0, t0=T0, span_secs=
                       zipf_s_x100)
 
 
+def mock_record_cap(mode: int) -> int:
+    """Upper bound of the mean framed record size of a generator mode (buffer sizing)."""
+    return 200 if mode == MOCK_GOFLOW else 96
+
+
 def mock_generate_host(mp: MockParams, i0: int, n: int):
     """Host twin of the device producer -> (bytes uint8[], offsets uint64[n+1])."""
-    buf = np.empty(n * 96 + 256, dtype=np.uint8)
+    buf = np.empty(n * mock_record_cap(mp.mode) + 256, dtype=np.uint8)
     off = np.empty(n + 1, dtype=np.uint64)
     w = C.c_uint64()
     rc = lib().fa_mock_generate_host(C.byref(mp), i0, n, buf.ctypes.data, buf.size,
@@ -456,7 +477,12 @@ class FlowAgg:
         self._chk(self._L.fa_device_state_get(self._h, C.byref(st)))
         return st
 
+    def merged_view_set(self, valid: bool):
+        """Declare the merged sketch view (device_state().cms_*_merged) valid / stale."""
+        self._chk(self._L.fa_merged_view_set(self._h, 1 if valid else 0))
+
     def merge_allreduce(self, rccl_comm_ptr: int):
+        """In-library RCCL path: ncclAllReduce of the sketches into the merged view (out of place, idempotent)."""
         self._chk(self._L.fa_merge_allreduce(self._h, rccl_comm_ptr))
 
     def stats(self) -> dict:

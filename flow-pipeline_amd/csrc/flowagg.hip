@@ -10,6 +10,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,6 +33,8 @@ struct fa_ctx {
     struct LaunchEvents { hipEvent_t e0, e1, e2; };
     std::vector<LaunchEvents> ev_pool;
     size_t ev_used = 0;
+    std::vector<LaunchEvents> dev_pool;  // ... of fa_decode_device launches
+    size_t dev_used = 0;
 
     Slot* tab = nullptr;
     uint32_t cap_log2 = 20;
@@ -66,6 +70,7 @@ struct fa_ctx {
     int t8_mode = 0;              // env FA_TUPLE: 0 adaptive, 1 always compact ("8"), 2 always wide ("16")
     uint64_t t8_wide_until = 0;   // batches counter value up to which wide tuples are used
     uint64_t seen_misfit8 = 0, seen_ok = 0;  // counter values at the last look
+    unsigned stage_threads = 8;   // host threads of the staging copy (fa_ingest)
     uint32_t par = 0;             // parity of the next launch (Counters::exotic_count / retry_count copies)
     uint32_t seg_cap_limit = 0;   // env FA_SEG_CAP (tests only): upper bound on tuples per segment
     // ingest kernel (env FA_TILE=wave|wg, measurement / tests): wave-private tiles + LDS tuple bins is the
@@ -96,6 +101,11 @@ struct fa_ctx {
     unsigned long long* cms_dst = nullptr;
     size_t cms_words = 0;   // words of ONE copy; the buffers hold CMS_REPLICAS copies
     bool cms_dirty = false;  // copies > 0 may hold counts (cms_fold)
+    // merged view (window close across GPUs): all-rank sums of the sketches, filled by fa_merge_allreduce or by the
+    // caller's collective (fa_device_state_get + fa_merged_view_set); stale as soon as this ctx ingests again
+    unsigned long long* cms_src_m = nullptr;
+    unsigned long long* cms_dst_m = nullptr;
+    bool merged_valid = false;
     KeySlot* ks_src = nullptr;  // distinct-address sets (fa_topk)
     KeySlot* ks_dst = nullptr;
     uint32_t ks_log2 = 20;
@@ -240,6 +250,8 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_SEG_CAP")) c->seg_cap_limit = std::max<uint32_t>(40u, (uint32_t)atoi(d) & ~7u);
     if (const char* d = getenv("FA_TILE")) c->tile_mode = !strcmp(d, "wave") ? 1 : !strcmp(d, "wg") ? 2 : 0;
     if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
+    if (const char* d = getenv("FA_STAGE_THREADS")) c->stage_threads = (unsigned)std::min(64, std::max(1, atoi(d)));
+    c->stage_threads = std::min(c->stage_threads, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* d = getenv("FA_TUPLE")) c->t8_mode = !strcmp(d, "8") ? 1 : !strcmp(d, "16") ? 2 : 0;
     auto bail = [&](const char* what, hipError_t e) {
         g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
@@ -358,16 +370,19 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->d_rows);
     (void)hipFree(c->cms_src);
     (void)hipFree(c->cms_dst);
+    (void)hipFree(c->cms_src_m);
+    (void)hipFree(c->cms_dst_m);
     (void)hipFree(c->ks_src);
     (void)hipFree(c->ks_dst);
     (void)hipFree(c->wtab);
     (void)hipFree(c->wspill);
     (void)hipFree(c->port_hist);
-    for (auto& p : c->ev_pool) {
-        (void)hipEventDestroy(p.e0);
-        (void)hipEventDestroy(p.e1);
-        (void)hipEventDestroy(p.e2);
-    }
+    for (auto* pool : {&c->ev_pool, &c->dev_pool})
+        for (auto& p : *pool) {
+            (void)hipEventDestroy(p.e0);
+            (void)hipEventDestroy(p.e1);
+            (void)hipEventDestroy(p.e2);
+        }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -501,12 +516,21 @@ static int settle(fa_ctx* c) {
             c->stats.batch_ns_total += (uint64_t)((double)ms * 1e6);
     }
     c->ev_used = 0;
+    for (size_t i = 0; i < c->dev_used; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->dev_pool[i].e0, c->dev_pool[i].e2) == hipSuccess) {
+            c->stats.decode_ns_total += (uint64_t)((double)ms * 1e6);
+            c->stats.decode_launches += 1;
+        }
+    }
+    c->dev_used = 0;
     Counters h = *c->h_ctr;
     c->stats.records_ok = h.ok;
     c->stats.records_bad = h.bad;
     c->stats.records_slow = h.slow;
     c->stats.records_direct = h.direct;
     c->stats.records_retried = h.retried;
+    c->stats.records_misfit_compact = h.misfit8;
     c->stats.table_used = c->used_base + h.used;
     format_feedback(c, h);
     if (h.spill_lost) {
@@ -622,6 +646,7 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
     if (ev) (void)hipEventRecord(ev->e0, c->stream);
     if (MODE == MODE_INGEST && a.seg && !wave_tiles) hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, c->stream, a);
     if (wave_tiles) c->stats.wave_tile_launches += 1;
+    if (t8) c->stats.compact_tuple_launches += 1;
 #define FA_LAUNCH_W(KS)                                                                         \
     do {                                                                                        \
         if (t8) hipLaunchKernelGGL((wtile_kernel<KS, true>), g, dim3(WBLOCK), 0, c->stream, a); \
@@ -790,7 +815,10 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     if (rc) return rc;
     c->stats.bytes_in += len;
     c->stats.batches += 1;
-    if (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) c->cms_dirty = true;
+    if (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
+        c->cms_dirty = true;
+        c->merged_valid = false;
+    }
     return FA_OK;
 }
 
@@ -850,16 +878,38 @@ static int stage_and_upload(fa_ctx* c, const uint8_t* buf, size_t len, const uin
     int rc = ensure_stage(c, s, total);
     if (rc) return rc;
     uint8_t* hs = c->h_stage[s];
-    memcpy(hs, buf, len);
-    memset(hs + len, 0, off_pos - len);
     uint32_t* ho = reinterpret_cast<uint32_t*>(hs + off_pos);
-    uint64_t prev = 0;
-    for (size_t i = 0; i <= n; i++) {
-        uint64_t o = off[i];
-        if (o < prev || o > len) return fail(c, FA_ERR_ARG, "offsets must be non-decreasing and <= len");
-        prev = o;
-        ho[i] = (uint32_t)o;
+    // the copy into pinned memory and the u64 -> u32 narrowing of the offsets run on a few host threads: one thread
+    // moves ~10 GB/s, the PCIe Gen5 link behind it 63 GB/s (env FA_STAGE_THREADS, default 8; small batches: inline)
+    unsigned nthr = c->stage_threads;
+    if (len + n * 12 < (8u << 20)) nthr = 1;
+    std::atomic<int> bad{0};
+    auto work = [&](unsigned t) {
+        const size_t b0 = len * t / nthr, b1 = len * (t + 1) / nthr;
+        if (b1 > b0) memcpy(hs + b0, buf + b0, b1 - b0);
+        const size_t i0 = (n + 1) * t / nthr, i1 = (n + 1) * (t + 1) / nthr;
+        uint64_t prev = i0 ? off[i0 - 1] : 0;
+        for (size_t i = i0; i < i1; i++) {
+            const uint64_t o = off[i];
+            if (o < prev || o > len) {
+                bad.store(1);
+                return;
+            }
+            prev = o;
+            ho[i] = (uint32_t)o;
+        }
+    };
+    if (nthr <= 1) {
+        nthr = 1;
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; t++) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
     }
+    if (bad.load()) return fail(c, FA_ERR_ARG, "offsets must be non-decreasing and <= len");
+    memset(hs + len, 0, off_pos - len);
     HIPCHK(c, hipMemcpyAsync(c->d_in[s], hs, total, hipMemcpyHostToDevice, c->stream));
     *slot = s;  // caller records stage_ev[s] once the kernels reading d_in[s] are enqueued
     *d_buf = c->d_in[s];
@@ -965,7 +1015,19 @@ extern "C" int fa_decode_device(fa_ctx* c, const void* d_buf, size_t len, const 
         a.off = (const uint32_t*)d_off;
         a.n = (uint32_t)n;
         a.tile_recs = tile_recs_for(len, n);
-        rc = launch_tiles<MODE_DECODE>(c, a, tile_grid<MODE_DECODE>(c, a.n, a.tile_recs));
+        if (c->dev_used == c->dev_pool.size()) {
+            if (c->dev_pool.size() >= 1024) {  // bound the pool: fold what is pending
+                rc = settle(c);
+                if (rc) return rc;
+            } else {
+                fa_ctx::LaunchEvents e{};
+                HIPCHK(c, hipEventCreate(&e.e0));
+                HIPCHK(c, hipEventCreate(&e.e1));
+                HIPCHK(c, hipEventCreate(&e.e2));
+                c->dev_pool.push_back(e);
+            }
+        }
+        rc = launch_tiles<MODE_DECODE>(c, a, tile_grid<MODE_DECODE>(c, a.n, a.tile_recs), &c->dev_pool[c->dev_used++]);
         if (rc) return rc;
     }
     out->time_received = c->cols.time_received;
@@ -1587,10 +1649,19 @@ static int cms_fold(fa_ctx* c) {
     return FA_OK;
 }
 
+// the sketch readers answer from: the merged (all-rank) view while it is valid, the ctx's own sketch otherwise
 static unsigned long long* cms_of(fa_ctx* c, uint32_t key_set) {
-    if (key_set == FA_KEYS_SRCADDR_CMS) return c->cms_src;
-    if (key_set == FA_KEYS_DSTADDR_CMS) return c->cms_dst;
+    if (key_set == FA_KEYS_SRCADDR_CMS) return c->merged_valid && c->cms_src_m ? c->cms_src_m : c->cms_src;
+    if (key_set == FA_KEYS_DSTADDR_CMS) return c->merged_valid && c->cms_dst_m ? c->cms_dst_m : c->cms_dst;
     return nullptr;
+}
+static int ensure_merged_view(fa_ctx* c) {
+    for (int d = 0; d < 2; d++) {
+        unsigned long long* own = d ? c->cms_dst : c->cms_src;
+        unsigned long long** m = d ? &c->cms_dst_m : &c->cms_src_m;
+        if (own && !*m && hipMalloc(m, c->cms_words * 8) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(merged sketch view) failed");
+    }
+    return FA_OK;
 }
 
 extern "C" int fa_cms_read(fa_ctx* c, uint32_t key_set, uint64_t* out, size_t cap_words) {
@@ -1608,8 +1679,9 @@ extern "C" int fa_cms_read(fa_ctx* c, uint32_t key_set, uint64_t* out, size_t ca
 extern "C" int fa_cms_reset(fa_ctx* c, uint32_t key_set) {
     FA_ON_DEVICE(c);
     if (!c) return FA_ERR_ARG;
-    unsigned long long* p = cms_of(c, key_set);
+    unsigned long long* p = key_set == FA_KEYS_SRCADDR_CMS ? c->cms_src : key_set == FA_KEYS_DSTADDR_CMS ? c->cms_dst : nullptr;
     if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
+    c->merged_valid = false;
     HIPCHK(c, hipMemsetAsync(p, 0, c->cms_words * 8 * CMS_REPLICAS, c->stream));
     KeySlot* ks = key_set == FA_KEYS_SRCADDR_CMS ? c->ks_src : c->ks_dst;
     if (ks) HIPCHK(c, hipMemsetAsync(ks, 0, sizeof(KeySlot) << c->ks_log2, c->stream));
@@ -1733,6 +1805,18 @@ extern "C" int fa_device_state_get(fa_ctx* c, fa_device_state* out) {
     out->cms_words = c->cms_words;
     out->port_hist = c->port_hist;
     out->port_hist_words = c->port_hist ? (size_t)4 * PORT_DENSE : 0;
+    rc = ensure_merged_view(c);
+    if (rc) return rc;
+    out->cms_src_merged = c->cms_src_m;
+    out->cms_dst_merged = c->cms_dst_m;
+    return FA_OK;
+}
+
+extern "C" int fa_merged_view_set(fa_ctx* c, int valid) {
+    FA_ON_DEVICE(c);
+    if (!c) return FA_ERR_ARG;
+    if (valid && ((c->cms_src && !c->cms_src_m) || (c->cms_dst && !c->cms_dst_m))) return fail(c, FA_ERR_ARG, "fa_merged_view_set: no merged view (call fa_device_state_get first)");
+    c->merged_valid = valid != 0;
     return FA_OK;
 }
 
@@ -1749,16 +1833,18 @@ extern "C" int fa_merge_allreduce(fa_ctx* c, void* comm) {
         if (h) fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
         if (!fn) return fail(c, FA_ERR_UNSUPPORTED, "librccl.so / ncclAllReduce not found");
     }
-    int rc = settle(c);
+    int rc = settle(c);  // (folds the sketch copies into copy 0)
+    if (rc) return rc;
+    rc = ensure_merged_view(c);
     if (rc) return rc;
     const int ncclUint64 = 5, ncclSum = 0;  // rccl.h: ncclDataType_t / ncclRedOp_t
-    if (c->cms_src && fn(c->cms_src, c->cms_src, c->cms_words, ncclUint64, ncclSum, comm, c->stream) != 0)
+    c->merged_valid = false;
+    if (c->cms_src && fn(c->cms_src, c->cms_src_m, c->cms_words, ncclUint64, ncclSum, comm, c->stream) != 0)
         return fail(c, FA_ERR_HIP, "ncclAllReduce(cms_src) failed");
-    if (c->cms_dst && fn(c->cms_dst, c->cms_dst, c->cms_words, ncclUint64, ncclSum, comm, c->stream) != 0)
+    if (c->cms_dst && fn(c->cms_dst, c->cms_dst_m, c->cms_words, ncclUint64, ncclSum, comm, c->stream) != 0)
         return fail(c, FA_ERR_HIP, "ncclAllReduce(cms_dst) failed");
-    if (c->port_hist && fn(c->port_hist, c->port_hist, (size_t)4 * PORT_DENSE, ncclUint64, ncclSum, comm, c->stream) != 0)
-        return fail(c, FA_ERR_HIP, "ncclAllReduce(port histograms) failed");
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->merged_valid = true;
     return FA_OK;
 }
 
@@ -1808,7 +1894,7 @@ extern "C" int fa_mock_generate_host(const fa_mock_params* g, uint64_t i0, uint6
                                      uint64_t* offsets, uint64_t* bytes_out) {
     if (!g || !buf) return FA_ERR_ARG;
     size_t pos = 0;
-    uint8_t tmp[208];
+    uint8_t tmp[FA_MOCK_MAX_RECORD];
     for (uint64_t k = 0; k < n; k++) {
         uint32_t l = gen_encode(*g, i0 + k, tmp);
         if (pos + l > cap) return FA_ERR_CAPACITY;

@@ -25,6 +25,10 @@ struct GenRow {
     uint64_t time_received, sampling_rate, bytes, packets;
     uint32_t sequence_num, src_as, dst_as, etype, proto, src_port, dst_port, addr_len;
     uint8_t src[16], dst[16];
+    // FA_MOCK_GOFLOW only: the fields outside the projection (SamplerAddress is projected: create.sh:11)
+    uint8_t sampler[4], next_hop[16];
+    uint64_t src_mac, dst_mac;
+    uint32_t next_hop_as, src_net, dst_net, in_if, out_if, ip_tos, ip_ttl, tcp_flags, vlan_id, dst_vlan, fragment_id, flow_label;
 };
 
 __host__ __device__ inline uint64_t gen_rnd(const fa_mock_params& g, uint64_t i, uint32_t j) {
@@ -109,9 +113,13 @@ __host__ __device__ inline void gen_row(const fa_mock_params& g, uint64_t i, Gen
         bool v6 = (r2 >> 16) & 1;
         o.etype = v6 ? 0x86dd : 0x0800;
         o.addr_len = v6 ? 16 : 4;
-        if (g.mode == FA_MOCK_ASPAIRS) {
+        if (g.mode == FA_MOCK_ASPAIRS || g.mode == FA_MOCK_GOFLOW || g.mode == FA_MOCK_DISTINCT || g.mode == FA_MOCK_REVERSED) {
             o.src_as = 64512 + (uint32_t)(r2 & 255);
             o.dst_as = 64512 + (uint32_t)((r2 >> 8) & 255);
+            if (g.mode == FA_MOCK_DISTINCT) {  // record i is the only member of its group (i < 2^40)
+                o.src_as = 1 + (uint32_t)(i & 0xfffff);
+                o.dst_as = 1 + (uint32_t)((i >> 20) & 0xfffff);
+            }
             if (v6) {
                 for (int k = 0; k < 15; k++) o.src[k] = o.dst[k] = pfx[k];
                 o.src[15] = (uint8_t)(r4 & 0xff);
@@ -121,6 +129,34 @@ __host__ __device__ inline void gen_row(const fa_mock_params& g, uint64_t i, Gen
                 o.src[3] = (uint8_t)(r4 & 0xff);
                 o.dst[0] = 10; o.dst[1] = (uint8_t)(r4 >> 32); o.dst[2] = (uint8_t)(r4 >> 40);
                 o.dst[3] = (uint8_t)((r4 >> 8) & 0xff);
+            }
+            if (g.mode == FA_MOCK_GOFLOW) {
+                // what GoFlow fills in for an sFlow sample besides the mocker's fields (pb-ext/flow.pb.go:57-147)
+                const uint64_t r6 = gen_rnd(g, i, 6), r7 = gen_rnd(g, i, 7), r8 = gen_rnd(g, i, 8);
+                o.sampling_rate = ((r2 >> 17) & 1) ? 2048 : 1024;
+                o.proto = ((r2 >> 18) & 1) ? 6 : 17;
+                o.sampler[0] = 10; o.sampler[1] = 255; o.sampler[2] = 0; o.sampler[3] = (uint8_t)(r6 & 7);
+                for (int k = 0; k < 16; k++) o.next_hop[k] = 0;
+                if (v6) {
+                    for (int k = 0; k < 15; k++) o.next_hop[k] = pfx[k];
+                    o.next_hop[15] = (uint8_t)(r6 >> 8);
+                } else {
+                    o.next_hop[0] = 10; o.next_hop[1] = (uint8_t)(r6 >> 8); o.next_hop[2] = (uint8_t)(r6 >> 16); o.next_hop[3] = 1;
+                }
+                o.next_hop_as = 64512 + (uint32_t)((r6 >> 24) & 255);
+                o.src_net = v6 ? 48 : 24;
+                o.dst_net = v6 ? 32 + (uint32_t)((r6 >> 32) & 31) : 8 + (uint32_t)((r6 >> 32) & 15);
+                o.in_if = 1 + (uint32_t)((r6 >> 40) & 63);
+                o.out_if = 1 + (uint32_t)((r6 >> 46) & 63);
+                o.ip_tos = (r7 & 3) ? 0 : 0xb8;
+                o.ip_ttl = 32 + (uint32_t)((r7 >> 2) & 127);
+                o.tcp_flags = o.proto == 6 ? (uint32_t)((r7 >> 9) & 0x3f) : 0;
+                o.src_mac = 0x3cfdfe000000ull | ((r7 >> 16) & 0xffffff);  // 48 bits: 7-byte varints
+                o.dst_mac = 0xa0369f000000ull | ((r7 >> 40) & 0xffffff);
+                o.vlan_id = 100 + (uint32_t)(r8 & 15);
+                o.dst_vlan = 200 + (uint32_t)((r8 >> 4) & 15);
+                o.fragment_id = v6 ? 0 : (uint32_t)((r8 >> 8) & 0xffff);
+                o.flow_label = v6 ? (uint32_t)((r8 >> 24) & 0xfffff) : 0;
             }
         } else {
             uint64_t rs = gen_zipf_rank(g, r3), rdst = gen_zipf_rank(g, r4);
@@ -156,12 +192,71 @@ __host__ __device__ inline uint32_t enc_bfield(uint8_t* p, uint32_t field, const
     return n + len;
 }
 
-// Encodes record i into out (>= 208 bytes); returns the record's length.
+// Encodes record i into out (>= FA_MOCK_MAX_RECORD bytes); returns the record's length.
 __host__ __device__ inline uint32_t gen_encode(const fa_mock_params& g, uint64_t i, uint8_t* out) {
     GenRow r;
     gen_row(g, i, r);
-    uint8_t tmp[192];
+    uint8_t tmp[FA_MOCK_MAX_RECORD];
     uint32_t n = 0;
+    if (g.mode == FA_MOCK_GOFLOW) {  // field-number order, proto3 zero omission (golang/protobuf, like mocker.go:97)
+        n += enc_vfield(tmp + n, 1, 1);  // Type = SFLOW_5
+        n += enc_vfield(tmp + n, 2, r.time_received);
+        n += enc_vfield(tmp + n, 3, r.sampling_rate);
+        n += enc_vfield(tmp + n, 4, r.sequence_num);
+        n += enc_vfield(tmp + n, 5, r.time_received);  // TimeFlowEnd
+        n += enc_bfield(tmp + n, 6, r.src, r.addr_len);
+        n += enc_bfield(tmp + n, 7, r.dst, r.addr_len);
+        n += enc_vfield(tmp + n, 9, r.bytes);
+        n += enc_vfield(tmp + n, 10, r.packets);
+        n += enc_bfield(tmp + n, 11, r.sampler, 4);
+        n += enc_bfield(tmp + n, 12, r.next_hop, r.addr_len);
+        n += enc_vfield(tmp + n, 13, r.next_hop_as);
+        n += enc_vfield(tmp + n, 14, r.src_as);
+        n += enc_vfield(tmp + n, 15, r.dst_as);
+        n += enc_vfield(tmp + n, 16, r.src_net);
+        n += enc_vfield(tmp + n, 17, r.dst_net);
+        n += enc_vfield(tmp + n, 18, r.in_if);
+        n += enc_vfield(tmp + n, 19, r.out_if);
+        n += enc_vfield(tmp + n, 20, r.proto);
+        n += enc_vfield(tmp + n, 21, r.src_port);
+        n += enc_vfield(tmp + n, 22, r.dst_port);
+        n += enc_vfield(tmp + n, 23, r.ip_tos);
+        n += enc_vfield(tmp + n, 25, r.ip_ttl);
+        n += enc_vfield(tmp + n, 26, r.tcp_flags);
+        n += enc_vfield(tmp + n, 27, r.src_mac);
+        n += enc_vfield(tmp + n, 28, r.dst_mac);
+        n += enc_vfield(tmp + n, 29, r.vlan_id);
+        n += enc_vfield(tmp + n, 30, r.etype);
+        n += enc_vfield(tmp + n, 33, r.vlan_id);  // SrcVlan
+        n += enc_vfield(tmp + n, 34, r.dst_vlan);
+        n += enc_vfield(tmp + n, 35, r.fragment_id);
+        n += enc_vfield(tmp + n, 37, r.flow_label);
+        n += enc_vfield(tmp + n, 38, r.time_received);  // TimeFlowStart
+        uint32_t k = 0;
+        if (g.framed) k = enc_varint(out, n);
+        for (uint32_t j = 0; j < n; j++) out[k + j] = tmp[j];
+        return k + n;
+    }
+    if (g.mode == FA_MOCK_REVERSED) {
+        n += enc_vfield(tmp + n, 38, r.time_received);
+        n += enc_vfield(tmp + n, 30, r.etype);
+        n += enc_vfield(tmp + n, 22, r.dst_port);
+        n += enc_vfield(tmp + n, 21, r.src_port);
+        n += enc_vfield(tmp + n, 20, r.proto);
+        n += enc_vfield(tmp + n, 15, r.dst_as);
+        n += enc_vfield(tmp + n, 14, r.src_as);
+        n += enc_vfield(tmp + n, 10, r.packets);
+        n += enc_vfield(tmp + n, 9, r.bytes);
+        n += enc_bfield(tmp + n, 7, r.dst, r.addr_len);
+        n += enc_bfield(tmp + n, 6, r.src, r.addr_len);
+        n += enc_vfield(tmp + n, 4, r.sequence_num);
+        n += enc_vfield(tmp + n, 3, r.sampling_rate);
+        n += enc_vfield(tmp + n, 2, r.time_received);
+        uint32_t k = 0;
+        if (g.framed) k = enc_varint(out, n);
+        for (uint32_t j = 0; j < n; j++) out[k + j] = tmp[j];
+        return k + n;
+    }
     n += enc_vfield(tmp + n, 2, r.time_received);
     n += enc_vfield(tmp + n, 3, r.sampling_rate);
     n += enc_vfield(tmp + n, 4, r.sequence_num);

@@ -22,7 +22,7 @@ struct LaneTally {
 template <int MODE, uint32_t KEYSETS, uint32_t COLS, bool T8 = false, class Hook = NoHook>
 __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, LdsMinutes& lm, uint32_t* part_cnt, const uint32_t* tile,
                                           bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
-                                          LaneTally& tally, uint32_t& lt_seen, uint32_t& lt_hits,
+                                          LaneTally& tally, uint32_t& pmode, uint32_t& lt_seen, uint32_t& lt_hits,
                                           uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook()) {
     constexpr uint32_t TB = bin_cap<T8>();
     // ---- parse (divergent: only lanes that own a staged record) ----
@@ -31,31 +31,48 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     rec_clear(r);
     if (mine) {
         LdsSrc src{tile};
-        sure = true;
+        framed_ok = true;
         if (a.framed && !(a.dbg & DBG_NO_FRAME)) {
             uint32_t pl = 0;
             const uint32_t i = pos >> 2;
-            sure = frame_short(fa_alignbyte(src.dw(i + 1), src.dw(i), pos), end - pos, pl);
+            framed_ok = frame_short(fa_alignbyte(src.dw(i + 1), src.dw(i), pos), end - pos, pl);
             pos += pl;
         }
-        framed_ok = sure;
-        if (sure && !(a.dbg & DBG_NO_PARSE)) {
-            if (a.dbg & DBG_LOOP_PARSER) sure = parse_fast<COLS>(src, pos, end, r);
-            else sure = parse_canon<COLS>(src, pos, end, r);
-        }
+        sure = framed_ok && (a.dbg & DBG_NO_PARSE) != 0;
     }
-    // second chance IN PLACE: a record the canonical-order walk is not sure about (other field order, duplicates,
-    // unknown fields) is parsed again by the order-free parser while its bytes still sit in the wave's LDS tile -
-    // only what that one cannot decide either (long varints, groups, 3-byte tags; broken frames) is deferred to
-    // deferred_kernel, which reads it back from HBM one record per lane.  Wave-uniform branch: canonical streams
-    // pay one ballot per tile.
-    if (FA_ANY(framed_ok && !sure) && !(a.dbg & (DBG_LOOP_PARSER | DBG_NO_PARSE | DBG_NO_SECOND))) {
-        if (framed_ok && !sure) {
-            LdsSrc src{tile};
-            rec_clear(r);
-            sure = parse_fast<COLS>(src, pos, end, r);
-            tally.second += sure ? 1u : 0u;
-            if (!sure) rec_clear(r);
+    // Three parsers, each "exact or not sure", tried in the order the wave has learnt from its previous tiles
+    // (pmode, wave-uniform: 0 lean canonical walk first, 1 full canonical walk first, 2 order-free parser first):
+    //  * parse_canon<lean>: the 27 fields of pb-ext/flow.proto in ascending order - what the mocker emits;
+    //  * parse_canon<FULL>: + every other field up to number 2047 as generic runs - what GoFlow emits
+    //    (pb-ext/flow.pb.go:57-147); a wave that needed it once starts with it from then on;
+    //  * parse_fast: any field order, duplicates, unknown fields - IN PLACE, while the bytes still sit in the wave's
+    //    LDS tile.  Only what that one cannot decide either (varints above 2^42 in projected fields, groups, 3-byte
+    //    tags; broken frames) is deferred to deferred_kernel, which reads it back from HBM one record per lane.
+    // Every step is a wave-uniform branch: a stream of one kind pays one ballot per tile for the tiers it never needs.
+    if (!(a.dbg & DBG_NO_PARSE)) {
+        LdsSrc src{tile};
+        if (pmode == 0u && !(a.dbg & DBG_LOOP_PARSER)) {
+            if (framed_ok) sure = parse_canon<COLS, false>(src, pos, end, r);
+        }
+        const bool need_full = framed_ok && !sure;
+        if (pmode <= 1u && FA_ANY(need_full) && !(a.dbg & (DBG_LOOP_PARSER | DBG_NO_SECOND))) {
+            if (need_full) {
+                rec_clear(r);
+                sure = parse_canon<COLS, true>(src, pos, end, r);
+            }
+            if (FA_ANY(need_full && sure)) pmode = 1u;
+        }
+        const bool need_fast = framed_ok && !sure;
+        const unsigned long long fm = __builtin_amdgcn_ballot_w64(need_fast);
+        if (fm != 0ull && !(a.dbg & DBG_NO_SECOND)) {
+            if (need_fast) {
+                rec_clear(r);
+                sure = parse_fast<COLS>(src, pos, end, r);
+                if (!(a.dbg & DBG_LOOP_PARSER)) tally.second += sure ? 1u : 0u;
+                if (!sure) rec_clear(r);
+            }
+            // most of a tile needed the order-free parser and it worked: start with it from now on
+            if (pmode != 2u && __builtin_popcountll(__builtin_amdgcn_ballot_w64(need_fast && sure)) > 32) pmode = 2u;
         }
     }
     if (mine && !sure) {  // (one counter atomic per wave: the compiler folds the lanes' adds - s_bcnt1 + mbcnt)
@@ -326,7 +343,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     const uint32_t tb_base = MODE == MODE_INGEST ? a.ctr->tb_base : 0u;
 
     LaneTally tally;
-    uint32_t lt_seen = 0, lt_hits = 0, no_fill = 0;
+    uint32_t lt_seen = 0, lt_hits = 0, no_fill = 0, pmode = 0;
     const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
     const uint32_t stride = gridDim.x;
     uint32_t t = blockIdx.x;
@@ -370,7 +387,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                 unsigned int j = atomicAdd(&a.ctr->exotic_count[a.par], 1u);
                 a.exotic_idx[j] = cur.r0 + tid;
             }
-            lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, tally, lt_seen, lt_hits, nullptr, nullptr, no_fill);
+            lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, tally, pmode, lt_seen, lt_hits, nullptr, nullptr, no_fill);
         } else {
             // rare: the tile's bytes exceed the LDS buffer (big records): stage it in passes
             uint32_t done = 0;
@@ -398,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                     }
                     done += 1;
                 } else {
-                    lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, tally, lt_seen, lt_hits, nullptr, nullptr, no_fill);
+                    lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, p0 - cbase, p1 - cbase, cur.r0 + k, tb_base, tally, pmode, lt_seen, lt_hits, nullptr, nullptr, no_fill);
                     done += nfit;
                 }
                 __syncthreads();  // the buffer is restaged by the next pass
@@ -518,7 +535,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
     uint32_t* tile = tiles + wave * (WT_STRIDE / 4);
 
     LaneTally tally;
-    uint32_t lt_seen = 0, lt_hits = 0;
+    uint32_t lt_seen = 0, lt_hits = 0, pmode = 0;
     uint32_t tb_base = 0;  // (set in the prologue below, wave-uniform)
     const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
     const uint32_t stride = gridDim.x * WAVES;
@@ -589,7 +606,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
                 a.exotic_idx[j] = cur.r0 + lane;
             }
             lane_work<MODE_INGEST, KEYSETS, COLS, T8>(a, lt, lm, part_cnt, tb, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, tally,
-                                                      lt_seen, lt_hits, bins, bin_cnt, fill, after_parse);
+                                                      pmode, lt_seen, lt_hits, bins, bin_cnt, fill, after_parse);
         }
     };
     // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous

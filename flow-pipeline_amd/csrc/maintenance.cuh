@@ -131,14 +131,14 @@ __global__ void keyset_merge_kernel(const uint4* keys, uint32_t n, KeySlot* tab,
 __global__ void gen_len_kernel(fa_mock_params g, uint64_t i0, uint32_t n, uint32_t* len) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint8_t tmp[208];
+    uint8_t tmp[FA_MOCK_MAX_RECORD];
     len[i] = gen_encode(g, i0 + i, tmp);
 }
 __global__ void gen_write_kernel(fa_mock_params g, uint64_t i0, uint32_t n, const uint32_t* off,
                                  uint8_t* out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint8_t tmp[208];
+    uint8_t tmp[FA_MOCK_MAX_RECORD];
     uint32_t l = gen_encode(g, i0 + i, tmp);
     uint8_t* p = out + off[i];
     for (uint32_t k = 0; k < l; k++) p[k] = tmp[k];

@@ -180,6 +180,7 @@ FA_HD bool parse_fast(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
         doubt |= tag < 8u ? 1u : 0u;                         // field number 0
         doubt |= hv & novar;                                 // varint longer than 6 bytes
         doubt |= isl & (vl > 5u ? 1u : 0u);                  // LEN size is a varint32
+        doubt |= isl & ((uint32_t)(val >> 20) ? 1u : 0u);    // a LEN field of 1 MiB or more: the clamp below would let the cursor land inside the payload
         // LEN payload size, clamped so the cursor can neither wrap nor loop
         const uint32_t sz = (uint32_t)(val >> 20) ? (1u << 20) : (uint32_t)val;
         const uint32_t is_addr = isl & ((((tag | 8u) == 0x3au) | (tag == 0x5au)) ? 1u : 0u);  // fields 6, 7, 11
@@ -302,9 +303,66 @@ FA_HD void canon_addr(const Src& s, Cursor& c, uint32_t end, uint32_t out[4]) {
     }
 }
 
+// ---- fields outside the projection, generically (FULL walk) ------------------------------------------
+// One field of any skippable shape at the cursor of the lanes with `go`: a varint of up to 10 bytes (MAC addresses
+// are 7), fixed32 / fixed64, or a bytes field with a one-byte length.  Anything else (groups, longer lengths, a
+// field that would cross `end`) leaves the cursor where it is - the record then fails the final pos == end test.
+template <bool TWO, class Src>
+FA_HD void canon_skip(const Src& s, Cursor& c, uint32_t end, bool go) {
+    constexpr uint32_t TL = TWO ? 2u : 1u;
+    constexpr uint32_t NONE = 0x20000000u;  // "no such length": pushes the cursor far beyond any record end
+    const uint32_t wt = c.x & 7u;
+    const uint32_t v0 = fa_alignbyte(c.y, c.x, TL);  // value bytes 0..3
+    const uint32_t v1 = c.y >> (8u * TL);            // value bytes 4..(7-TL); zero above
+    const uint32_t s0 = fa_ffbl(~v0 & 0x80808080u);
+    const uint32_t s1 = fa_ffbl(~v1 & (0x80808080u >> (8u * TL))) | 32u;  // (stays 0xffffffff when there is no stop)
+    const uint32_t sb = s0 < s1 ? s0 : s1;
+    uint32_t vlen = sb == 0xffffffffu ? NONE : (sb >> 3) + 1u;
+    if (FA_ANY(go && wt == 0u && sb == 0xffffffffu)) {  // a varint longer than the window: its tail is in the next one
+        Cursor c2;
+        c2.pos = c.pos + 8u;
+        cur_load(s, c2);
+        const uint32_t s2 = fa_ffbl(~c2.x & 0x80808080u);
+        const uint32_t l2 = (s2 >> 3) + 1u;  // bytes of the varint in the second window
+        const bool ok2 = s2 != 0xffffffffu && l2 <= 2u + TL;  // 10 bytes at most in all
+        vlen = sb == 0xffffffffu ? (ok2 ? (8u - TL) + l2 : NONE) : vlen;
+    }
+    const uint32_t lb = v0 & 0xffu;  // bytes field: one length byte
+    const uint32_t body = wt == 0u ? vlen : wt == 1u ? 8u : wt == 5u ? 4u : (wt == 2u && lb < 0x80u) ? 1u + lb : NONE;
+    const uint32_t pn = c.pos + TL + body;
+    const bool ok = go && pn <= end;
+    c.pos = ok ? pn : c.pos;
+    cur_load(s, c);
+}
+
+// A run of fields outside the projection: every field whose tag lies in [LO, HI] is skipped, in any order and any
+// number (they carry no projected column, so their order and multiplicity cannot change the result; a projected
+// field's tag is never inside a run, so a duplicate or out-of-place projected field still fails the record).
+// 1-byte tags: LO, HI < 0x80.  2-byte tags: key = b0 | b1 << 8 with b0 >= 0x80, monotonic in the field number;
+// HI <= 0x7fff excludes tags of 3 and more bytes, LO >= 0x0180 excludes non-minimal ones (b1 = 0).
+template <uint32_t LO, uint32_t HI, class Src>
+FA_HD void canon_run(const Src& s, Cursor& c, uint32_t end) {
+    constexpr bool TWO = LO >= 0x80u;
+    static_assert(TWO ? (LO >= 0x0180u && HI <= 0x7fffu) : HI < 0x80u, "canon_run: tag range");
+    for (int it = 0; it < 96; it++) {  // (bounded: a record of <= 16 KiB cannot hold more fields per run that matter)
+        const uint32_t key = TWO ? (c.x & 0xffffu) : (c.x & 0xffu);
+        bool go = (key - LO) <= (HI - LO) && c.pos < end;
+        if (TWO) go = go && (c.x & 0x80u) != 0u;
+        if (!FA_ANY(go)) break;
+        const uint32_t before = c.pos;
+        canon_skip<TWO>(s, c, end, go);
+        if (!FA_ANY(go && c.pos != before)) break;  // only lanes that cannot move are left
+    }
+}
+
 // r must be cleared by the caller.  Returns true iff [pos,end) is exactly a canonical encoding.
 // Field list = pb-ext/flow.proto:16-64 in field-number order (what proto.Marshal emits).
-template <uint32_t COLS, class Src>
+// FULL: the walk also crosses every field of the 67-field message GoFlow marshals (pb-ext/flow.pb.go:57-147:
+// NextHop 12, NextHopAS 13, SrcNet / DstNet 16-17, SrcMac / DstMac / VlanId 27-29, SrcVlan .. FragmentOffset 33-36,
+// VRF ids, encapsulation, MPLS, PPP 39-64, country / ASDB 100-103) and any other field up to number 2047 - as
+// generic runs between the projected fields.  The lean walk costs nothing extra on flow.proto-shaped records; a
+// wave switches to the full one when its records need it (lane_work).
+template <uint32_t COLS, bool FULL = false, class Src>
 FA_HD bool parse_canon(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
     Cursor c;
     c.pos = pos;
@@ -323,11 +381,14 @@ FA_HD bool parse_canon(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
     canon_long<0x28u, false>(s, c, end, d64);                                               //  5 TimeFlowEnd
     canon_addr<0x32u, (COLS & COL_SRC_ADDR) != 0>(s, c, end, r.src);                        //  6 SrcAddr
     canon_addr<0x3au, (COLS & COL_DST_ADDR) != 0>(s, c, end, r.dst);                        //  7 DstAddr
+    if (FULL) canon_run<0x40u, 0x47u>(s, c, end);                                           //  8 (unassigned)
     canon_short<0x48u, (COLS & COL_BYTES) != 0>(s, c, end, by32);                           //  9 Bytes
     canon_short<0x50u, (COLS & COL_PACKETS) != 0>(s, c, end, pk32);                         // 10 Packets
     canon_addr<0x5au, (COLS & COL_SAMPLER_ADDRESS) != 0>(s, c, end, r.sampler);             // 11 SamplerAddress
+    if (FULL) canon_run<0x60u, 0x6fu>(s, c, end);                                           // 12 NextHop, 13 NextHopAS
     canon_short<0x70u, (COLS & COL_SRC_AS) != 0>(s, c, end, r.src_as);                      // 14 SrcAS
     canon_short<0x78u, (COLS & COL_DST_AS) != 0>(s, c, end, r.dst_as);                      // 15 DstAS
+    if (FULL) canon_run<0x0180u, 0x018fu>(s, c, end);                                       // 16 SrcNet, 17 DstNet
     // Runs of fields that flow exporters rarely fill are guarded by ONE tag-range test per run (wave-uniform)
     // instead of one test per field: 18..20, 23..26, 31..37.  (A lane can only be inside a run if its tag was
     // in the run's range when the run started - fields come in ascending order.)
@@ -344,14 +405,18 @@ FA_HD bool parse_canon(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
         canon_short<0x01c8u, false>(s, c, end, d32);                                        // 25 IPTTL
         canon_short<0x01d0u, false>(s, c, end, d32);                                        // 26 TCPFlags
     }
+    if (FULL) canon_run<0x01d8u, 0x01efu>(s, c, end);                                       // 27 SrcMac, 28 DstMac, 29 VlanId
     canon_short<0x01f0u, (COLS & COL_ETYPE) != 0>(s, c, end, r.etype);                      // 30 Etype
-    if (FA_ANY(((c.x & 0xffffu) - 0x01f8u) <= 0x00b0u)) {
+    if (FULL) {
+        canon_run<0x01f8u, 0x02afu>(s, c, end);                                             // 31 IcmpType .. 37 IPv6FlowLabel
+    } else if (FA_ANY(((c.x & 0xffffu) - 0x01f8u) <= 0x00b0u)) {
         canon_short<0x01f8u, false>(s, c, end, d32);                                        // 31 IcmpType
         canon_short<0x0280u, false>(s, c, end, d32);                                        // 32 IcmpCode
         canon_short<0x02a8u, false>(s, c, end, d32);                                        // 37 IPv6FlowLabel
     }
     canon_long<0x02b0u, (COLS & COL_TIME_FLOW_START) != 0>(s, c, end, r.time_flow_start);   // 38 TimeFlowStart
-    canon_short<0x02d0u, false>(s, c, end, d32);                                            // 42 FlowDirection
+    if (FULL) canon_run<0x02b8u, 0x7fffu>(s, c, end);                                       // 39 .. 2047 (VRF, 42 FlowDirection, encap, MPLS, PPP, country, ASDB)
+    else canon_short<0x02d0u, false>(s, c, end, d32);                                       // 42 FlowDirection
     r.sampling_rate = sr32;
     r.bytes = by32;
     r.packets = pk32;

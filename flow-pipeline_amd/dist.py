@@ -7,9 +7,9 @@ Here partition p is owned by rank ``p % world``; each rank keeps private group-b
 state in HBM for the whole window (no data-path collective), and the only
 exchange is at window close:
 
-* dense Count-Min sketches -> ``all_reduce(SUM)`` in place on the device buffers
-  (RCCL over xGMI when the backend is ``nccl``; u64 wrap-around sum == int64 sum
-  bit for bit);
+* dense Count-Min sketches -> ``all_reduce(SUM)`` of the library's device buffers into
+  the ctx's merged view (out of place, idempotent; RCCL over xGMI when the backend is
+  ``nccl``; u64 wrap-around sum == int64 sum bit for bit);
 * sparse flows_5m rows -> ``all_gather`` of each rank's compacted rows, then a
   local re-aggregation (sum is a commutative monoid, so the merged table equals
   the single-shard table exactly).  Row sets are tens of MB at most (393 k rows x
@@ -174,15 +174,28 @@ class _DevArray:
 
 
 def allreduce_sketches(agg, group=None):
-    """In-place RCCL all-reduce of the ctx's Count-Min sketches (dense, mergeable by +)."""
+    """Window-close merge of the dense state across ranks: RCCL all-reduce (sum, u64 == i64 bit for bit) of every
+    rank's Count-Min sketches INTO the ctx's merged view - out of place: the rank's own sketches stay as they are,
+    so the call is idempotent (calling it twice, or again after more ingest, recomputes the view; nothing is ever
+    counted twice) and fa_topk / fa_cms_read answer from the merged view until the ctx ingests again.  The dense
+    port histograms are NOT reduced here: ports travel as rows (top_ports_merged), like every other sparse result."""
     import torch
     import torch.distributed as dist
-    st = agg.device_state()
-    for ptr, words in ((st.cms_src, st.cms_words), (st.cms_dst, st.cms_words), (st.port_hist, st.port_hist_words)):
-        if ptr:  # the dense port histograms merge the same way (ports >= 65536 travel as rows: top_ports_merged)
-            t = torch.as_tensor(_DevArray(ptr, words), device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    st = agg.device_state()  # (settles the stream: the sketch copies are folded)
+    on_device = dist.get_backend(group) == "nccl"  # gloo (harness tests on a 1-GPU box): staged through host memory
+    for own, merged in ((st.cms_src, st.cms_src_merged), (st.cms_dst, st.cms_dst_merged)):
+        if own:
+            t = torch.as_tensor(_DevArray(merged, st.cms_words), device="cuda")
+            mine = torch.as_tensor(_DevArray(own, st.cms_words), device="cuda")
+            if on_device:
+                t.copy_(mine)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            else:
+                h = mine.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(h)
     torch.cuda.synchronize()
+    agg.merged_view_set(True)
 
 
 def allgather_bytes(arr: np.ndarray, group=None, device=None):

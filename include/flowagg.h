@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 3
+#define FA_ABI_VERSION 4
 
 typedef struct fa_ctx fa_ctx;
 
@@ -41,10 +41,11 @@ typedef enum {
     FA_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime error at create */
     FA_ERR_HIP = -3,        /* HIP runtime error (text in fa_last_error) */
     FA_ERR_NOMEM = -4,
-    FA_ERR_TABLE_FULL = -5, /* a single batch created more new groups than the table's free slots plus the
-                               spill buffer (4 M parked updates) hold - the tables grow BETWEEN batches;
-                               aggregates of that batch were lost and the ctx refuses further work (sticky).
-                               Recreate with a larger table_capacity_log2 / wide_capacity_log2. */
+    FA_ERR_TABLE_FULL = -5, /* a table cannot grow further (2^30 slots) or the distinct-address set behind fa_topk is
+                               full.  Aggregates are never dropped on the way there: updates that meet a full table
+                               are parked (the spill buffers hold everything the host may have in flight: 2 x
+                               max_batch_records per table) and replayed after the table has grown - the host looks
+                               at the device counters before every launch. */
     FA_ERR_CAPACITY = -6,   /* caller's output buffer too small; *n_out = required */
     FA_ERR_FRAMING = -7,    /* offsets==NULL and the stream is not a chain of framed records */
     FA_ERR_UNSUPPORTED = -8
@@ -149,6 +150,11 @@ typedef struct {
     uint64_t wide_used;        /* occupied slots of the wide-key table */
     uint64_t wide_capacity;
     uint64_t wave_tile_launches; /* ingest launches that ran the wave-tile kernel (the rest: workgroup-tile kernel) */
+    /* ABI 4 */
+    uint64_t compact_tuple_launches; /* ... of those, launches that wrote compact 8-byte tuples (the rest: 16-byte ones) */
+    uint64_t records_misfit_compact; /* records of compact-tuple launches whose values only a wide tuple holds */
+    uint64_t decode_ns_total;        /* fa_decode_device: device time, summed over its launches (hipEvent) */
+    uint64_t decode_launches;
 } fa_stats_t;
 
 typedef struct {
@@ -259,20 +265,41 @@ typedef struct {
     size_t cms_words;
     void* port_hist;        /* 2*65536 entries of {weight, count} uint64 (SrcPort, then DstPort), or NULL */
     size_t port_hist_words; /* 4*65536 */
+    /* ABI 4: the MERGED view of the sketches (window close across GPUs): separate buffers of cms_words uint64 that
+     * a collective fills with the sum over all ranks - the ctx's own sketches stay untouched, so the merge can be
+     * repeated (idempotent) and ingest can go on.  NULL when the key set is off. */
+    void* cms_src_merged;
+    void* cms_dst_merged;
 } fa_device_state;
 int fa_device_state_get(fa_ctx*, fa_device_state* out);
+/* Declares the merged view valid (1: the caller's collective has filled cms_*_merged with all-rank sums; fa_topk /
+ * fa_cms_read / fa_cms_query then answer from it) or stale (0).  Any later ingest or fa_cms_reset makes it stale. */
+int fa_merged_view_set(fa_ctx*, int valid);
 /* Adds partial rows produced by another ctx/rank (e.g. gathered over RCCL)
  * into this ctx's table: sum is a commutative monoid, so the merged table
  * equals the single-shard table bit for bit. */
 int fa_merge_rows(fa_ctx*, const fa_row5m* rows, size_t n);
-/* In-library RCCL path: comm is an `ncclComm_t`; all-reduces (sum, uint64) the
- * sketches and the dense port histograms in place on the ctx stream. */
+/* In-library RCCL path: comm is an `ncclComm_t` (librccl.so is bound lazily).  ncclAllReduce(sum, uint64) of the
+ * ctx's sketches INTO the merged view (out of place, on the ctx stream) and marks it valid: calling it again - or
+ * after more ingest - simply recomputes the view, nothing is ever counted twice.  Sparse state (flows_5m rows, wide
+ * rows, port / minute rows) travels as rows: fa_close_window + fa_merge_rows etc. */
 int fa_merge_allreduce(fa_ctx*, void* rccl_comm);
 
 int fa_stats(fa_ctx*, fa_stats_t* out);
 
 /* ---- synthetic producer (mocker/mocker.go:57-106 distribution) ------------ */
-enum { FA_MOCK_MOCKER = 0, FA_MOCK_ASPAIRS = 1, FA_MOCK_ZIPF = 2 };
+enum {
+    FA_MOCK_MOCKER = 0,   /* mocker.go:57-91 literally: 9 (SrcAS,DstAS) groups */
+    FA_MOCK_ASPAIRS = 1,  /* BASELINE config 2: 65 536 AS pairs x 2 ETypes */
+    FA_MOCK_ZIPF = 2,     /* BASELINE configs 3-5: Zipf-distributed addresses */
+    FA_MOCK_GOFLOW = 3,   /* ASPAIRS keys in the shape GoFlow marshals an sFlow sample: 33 of the 67 fields of
+                             pb-ext/flow.pb.go:57-147 (Type, TimeFlowEnd, SamplerAddress, NextHop, NextHopAS, SrcNet,
+                             DstNet, InIf, OutIf, Proto, IP/TCP details, MACs, VLANs, fragment id, flow label), ~165 B */
+    FA_MOCK_DISTINCT = 4, /* ASPAIRS shape, every record its own (SrcAS,DstAS) group: table-growth / spill tests */
+    FA_MOCK_REVERSED = 5  /* ASPAIRS values, fields marshalled in DESCENDING field-number order: valid proto3 that no
+                             canonical-order walk accepts - every record takes the order-free second-chance parser */
+};
+#define FA_MOCK_MAX_RECORD 256 /* upper bound of one generated record (any mode), framed */
 typedef struct {
     uint32_t mode;
     uint32_t framed;    /* -proto.fixedlen */

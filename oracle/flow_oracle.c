@@ -476,9 +476,20 @@ void fo_gen_row(const fo_gen_params* g, uint64_t i, fo_row* o) {
         o->time_received = g->t0 + (uint64_t)g->span_secs * i / nt;
         int v6 = (int)((r2 >> 16) & 1);
         o->etype = v6 ? 0x86dd : 0x0800;
-        if (g->mode == FO_GEN_ASPAIRS) {
+        if (g->mode == FO_GEN_ASPAIRS || g->mode == FO_GEN_GOFLOW || g->mode == FO_GEN_DISTINCT || g->mode == FO_GEN_REVERSED) {
             o->src_as = 64512 + (uint32_t)(r2 & 255);
             o->dst_as = 64512 + (uint32_t)((r2 >> 8) & 255);
+            if (g->mode == FO_GEN_DISTINCT) {
+                o->src_as = 1 + (uint32_t)(i & 0xfffff);
+                o->dst_as = 1 + (uint32_t)((i >> 20) & 0xfffff);
+            }
+            if (g->mode == FO_GEN_GOFLOW) { /* the projected columns GoFlow fills besides the mocker's */
+                o->sampling_rate = (r2 >> 17) & 1 ? 2048 : 1024;
+                o->proto = (r2 >> 18) & 1 ? 6 : 17;
+                o->sampler_address[0] = 10;
+                o->sampler_address[1] = 255;
+                o->sampler_address[3] = (uint8_t)(gen_rnd(g, i, 6) & 7);
+            }
             if (v6) {
                 memcpy(o->src_addr, pfx, 15);
                 memcpy(o->dst_addr, pfx, 15);
@@ -550,11 +561,90 @@ static size_t encode_row(const fo_row* r, uint8_t* p) {
     return n;
 }
 
+/* FO_GEN_GOFLOW: the record as GoFlow marshals an sFlow sample - every field it fills, in field-number order
+ * (pb-ext/flow.pb.go:57-147; golang/protobuf emits known fields ascending and omits zeros).  The fields outside the
+ * ClickHouse projection are derived here from rnd(i,6..8); values: DESIGN.md "Synthetic generator". */
+static size_t encode_goflow(const fo_gen_params* g, uint64_t i, const fo_row* r, uint8_t* p) {
+    static const uint8_t pfx[15] = {0x20, 0x01, 0x0d, 0xb8, 0, 0, 0, 0x01, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t r6 = gen_rnd(g, i, 6), r7 = gen_rnd(g, i, 7), r8 = gen_rnd(g, i, 8);
+    const int v6 = r->etype == 0x86dd;
+    const size_t alen = v6 ? 16 : 4;
+    uint8_t nh[16];
+    memset(nh, 0, 16);
+    if (v6) {
+        memcpy(nh, pfx, 15);
+        nh[15] = (uint8_t)(r6 >> 8);
+    } else {
+        nh[0] = 10; nh[1] = (uint8_t)(r6 >> 8); nh[2] = (uint8_t)(r6 >> 16); nh[3] = 1;
+    }
+    const uint32_t vlan = 100 + (uint32_t)(r8 & 15);
+    size_t n = 0;
+    n += put_vfield(p + n, 1, 1);                                   /* Type = SFLOW_5 */
+    n += put_vfield(p + n, 2, r->time_received);
+    n += put_vfield(p + n, 3, r->sampling_rate);
+    n += put_vfield(p + n, 4, r->sequence_num);
+    n += put_vfield(p + n, 5, r->time_received);                    /* TimeFlowEnd */
+    n += put_bfield(p + n, 6, r->src_addr, alen);
+    n += put_bfield(p + n, 7, r->dst_addr, alen);
+    n += put_vfield(p + n, 9, r->bytes);
+    n += put_vfield(p + n, 10, r->packets);
+    n += put_bfield(p + n, 11, r->sampler_address, 4);
+    n += put_bfield(p + n, 12, nh, alen);                           /* NextHop */
+    n += put_vfield(p + n, 13, 64512 + ((r6 >> 24) & 255));         /* NextHopAS */
+    n += put_vfield(p + n, 14, r->src_as);
+    n += put_vfield(p + n, 15, r->dst_as);
+    n += put_vfield(p + n, 16, v6 ? 48 : 24);                       /* SrcNet */
+    n += put_vfield(p + n, 17, v6 ? 32 + ((r6 >> 32) & 31) : 8 + ((r6 >> 32) & 15)); /* DstNet */
+    n += put_vfield(p + n, 18, 1 + ((r6 >> 40) & 63));              /* InIf */
+    n += put_vfield(p + n, 19, 1 + ((r6 >> 46) & 63));              /* OutIf */
+    n += put_vfield(p + n, 20, r->proto);
+    n += put_vfield(p + n, 21, r->src_port);
+    n += put_vfield(p + n, 22, r->dst_port);
+    n += put_vfield(p + n, 23, (r7 & 3) ? 0 : 0xb8);                /* IPTos */
+    n += put_vfield(p + n, 25, 32 + ((r7 >> 2) & 127));             /* IPTTL */
+    n += put_vfield(p + n, 26, r->proto == 6 ? ((r7 >> 9) & 0x3f) : 0); /* TCPFlags */
+    n += put_vfield(p + n, 27, 0x3cfdfe000000ull | ((r7 >> 16) & 0xffffff)); /* SrcMac */
+    n += put_vfield(p + n, 28, 0xa0369f000000ull | ((r7 >> 40) & 0xffffff)); /* DstMac */
+    n += put_vfield(p + n, 29, vlan);                               /* VlanId */
+    n += put_vfield(p + n, 30, r->etype);
+    n += put_vfield(p + n, 33, vlan);                               /* SrcVlan */
+    n += put_vfield(p + n, 34, 200 + ((r8 >> 4) & 15));             /* DstVlan */
+    n += put_vfield(p + n, 35, v6 ? 0 : ((r8 >> 8) & 0xffff));      /* FragmentId */
+    n += put_vfield(p + n, 37, v6 ? ((r8 >> 24) & 0xfffff) : 0);    /* IPv6FlowLabel */
+    n += put_vfield(p + n, 38, r->time_flow_start);
+    return n;
+}
+
+/* FO_GEN_REVERSED: the same fields, last first (a producer is free to emit fields in any order) */
+static size_t encode_row_reversed(const fo_row* r, uint8_t* p) {
+    static const uint32_t order[14] = {38, 30, 22, 21, 20, 15, 14, 10, 9, 7, 6, 4, 3, 2};
+    size_t n = 0;
+    for (int k = 0; k < 14; k++) {
+        switch (order[k]) {
+        case 38: n += put_vfield(p + n, 38, r->time_flow_start); break;
+        case 30: n += put_vfield(p + n, 30, r->etype); break;
+        case 22: n += put_vfield(p + n, 22, r->dst_port); break;
+        case 21: n += put_vfield(p + n, 21, r->src_port); break;
+        case 20: n += put_vfield(p + n, 20, r->proto); break;
+        case 15: n += put_vfield(p + n, 15, r->dst_as); break;
+        case 14: n += put_vfield(p + n, 14, r->src_as); break;
+        case 10: n += put_vfield(p + n, 10, r->packets); break;
+        case 9: n += put_vfield(p + n, 9, r->bytes); break;
+        case 7: n += put_bfield(p + n, 7, r->dst_addr, addr_len(r, r->dst_addr)); break;
+        case 6: n += put_bfield(p + n, 6, r->src_addr, addr_len(r, r->src_addr)); break;
+        case 4: n += put_vfield(p + n, 4, r->sequence_num); break;
+        case 3: n += put_vfield(p + n, 3, r->sampling_rate); break;
+        default: n += put_vfield(p + n, 2, r->time_received); break;
+        }
+    }
+    return n;
+}
+
 static size_t gen_one(const fo_gen_params* g, uint64_t i, uint8_t* out) {
     fo_row r;
-    uint8_t tmp[192];
+    uint8_t tmp[FO_GEN_MAX_RECORD];
     fo_gen_row(g, i, &r);
-    size_t n = encode_row(&r, tmp);
+    size_t n = g->mode == FO_GEN_GOFLOW ? encode_goflow(g, i, &r, tmp) : g->mode == FO_GEN_REVERSED ? encode_row_reversed(&r, tmp) : encode_row(&r, tmp);
     size_t k = 0;
     if (g->framed) k = put_varint(out, n); /* proto.Buffer.EncodeMessage, mocker.go:99-101 */
     memcpy(out + k, tmp, n);
@@ -562,14 +652,14 @@ static size_t gen_one(const fo_gen_params* g, uint64_t i, uint8_t* out) {
 }
 
 uint32_t fo_gen_record_len(const fo_gen_params* g, uint64_t i) {
-    uint8_t tmp[208];
+    uint8_t tmp[FO_GEN_MAX_RECORD + 16];
     return (uint32_t)gen_one(g, i, tmp);
 }
 
 size_t fo_gen_records(const fo_gen_params* g, uint64_t i0, uint64_t n, uint8_t* out, size_t cap,
                       uint64_t* offsets) {
     size_t pos = 0;
-    uint8_t tmp[208];
+    uint8_t tmp[FO_GEN_MAX_RECORD + 16];
     for (uint64_t k = 0; k < n; k++) {
         size_t l = gen_one(g, i0 + k, tmp);
         if (pos + l > cap) return (size_t)-1;
@@ -582,101 +672,167 @@ size_t fo_gen_records(const fo_gen_params* g, uint64_t i0, uint64_t n, uint8_t* 
 }
 
 /* ------------------------------------------------------------- cpu bench */
+/* One shard of the record range per thread.  Untimed: every thread generates its own shard (so that the sample is
+ * ready in seconds on a many-core host).  Timed, between two barriers: (1) decode + roll up the shard into a
+ * private table sized for it up front, (2) merge by key partition: every thread sorts its groups by
+ * hash % threads, then thread t folds partition t of every shard into the final table part t - one barrier, all
+ * threads busy in both phases (the earlier tree merge left most threads idle and ran SLOWER than one core on a
+ * 256-thread host).  The result is the set of `threads` disjoint table parts. */
+typedef struct {
+    uint32_t timeslot, src_as, dst_as, etype;
+    uint64_t bytes, packets, count;
+} bentry;
 typedef struct job {
     const fo_gen_params* g;
-    const uint8_t* buf;
-    const uint64_t* off;
-    size_t n;
-    fo_rollup* r;
+    uint64_t i0;
+    size_t n;         /* records of this shard */
+    uint8_t* buf;     /* the shard's wire bytes (owned) */
+    uint64_t* off;
+    size_t wire;
+    fo_rollup* r;     /* shard table */
+    fo_rollup* part;  /* final table part t */
+    bentry* ent;      /* this shard's groups, sorted by destination part */
+    size_t* ent_off;  /* threads + 1 */
     uint64_t bad;
-    /* tree merge of the per-thread tables (one level per barrier round) */
-    int t, threads;
-    double t_ingest;
+    int t, threads, failed;
+    double t_start, t_end, t_ingest;
     struct job* all;
     pthread_barrier_t* bar;
 } job;
-
-static double now_s(void);
-static void* job_run(void* a) {
-    job* j = (job*)a;
-    const double t0 = now_s();
-    j->bad = fo_rollup_ingest(j->r, j->buf, j->off, j->n, (int)j->g->framed);
-    j->t_ingest = now_s() - t0;
-    /* shard tables are merged pairwise, level by level, by the threads that built them: log2(threads)
-       parallel rounds instead of threads-1 serial merges (which dominated the run on many-core hosts) */
-    for (int step = 1; step < j->threads; step <<= 1) {
-        pthread_barrier_wait(j->bar);
-        if (j->t % (2 * step) == 0 && j->t + step < j->threads) fo_rollup_merge(j->r, j->all[j->t + step].r);
-    }
-    return NULL;
-}
 
 static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
 }
+static size_t pow2_at_least(size_t v) {
+    size_t c = 1024;
+    while (c < v) c <<= 1;
+    return c;
+}
+static fo_rollup* rollup_new_sized(uint32_t gran, size_t groups) {
+    fo_rollup* r = (fo_rollup*)calloc(1, sizeof *r);
+    r->gran = gran ? gran : 300;
+    r->cap = pow2_at_least(groups * 2 + 2);
+    r->t = (slot*)calloc(r->cap, sizeof(slot));
+    return r;
+}
+static uint64_t slot_hash(const slot* s) {
+    return mix64(((uint64_t)s->src_as << 32 | s->dst_as) ^ mix64((uint64_t)s->timeslot << 32 | s->etype));
+}
+
+static void* job_run(void* a) {
+    job* j = (job*)a;
+    const int T = j->threads;
+    /* untimed: this shard's records */
+    const size_t cap = j->n * (j->g->mode == FO_GEN_GOFLOW ? 200 : 96) + 256;
+    j->buf = (uint8_t*)malloc(cap);
+    j->off = (uint64_t*)malloc((j->n + 1) * sizeof(uint64_t));
+    j->wire = j->buf && j->off ? fo_gen_records(j->g, j->i0, j->n, j->buf, cap, j->off) : (size_t)-1;
+    j->failed = j->wire == (size_t)-1;
+    pthread_barrier_wait(j->bar);
+    j->t_start = now_s();
+    /* (1) decode + roll up */
+    j->r = rollup_new_sized(300, j->n < (1u << 20) ? j->n : (1u << 20));
+    if (!j->failed) j->bad = fo_rollup_ingest(j->r, j->buf, j->off, j->n, (int)j->g->framed);
+    j->t_ingest = now_s() - j->t_start;
+    /* (2a) this shard's groups, ordered by destination part */
+    j->ent_off = (size_t*)calloc((size_t)T + 1, sizeof(size_t));
+    j->ent = (bentry*)malloc((j->r->n + 1) * sizeof(bentry));
+    for (size_t i = 0; i < j->r->cap; i++)
+        if (j->r->t[i].used) j->ent_off[(slot_hash(&j->r->t[i]) >> 40) % (uint64_t)T + 1]++;
+    for (int p = 0; p < T; p++) j->ent_off[p + 1] += j->ent_off[p];
+    {
+        size_t* cur = (size_t*)malloc((size_t)T * sizeof(size_t));
+        memcpy(cur, j->ent_off, (size_t)T * sizeof(size_t));
+        for (size_t i = 0; i < j->r->cap; i++) {
+            const slot* s = &j->r->t[i];
+            if (!s->used) continue;
+            bentry* e = &j->ent[cur[(slot_hash(s) >> 40) % (uint64_t)T]++];
+            e->timeslot = s->timeslot; e->src_as = s->src_as; e->dst_as = s->dst_as; e->etype = s->etype;
+            e->bytes = s->bytes; e->packets = s->packets; e->count = s->count;
+        }
+        free(cur);
+    }
+    pthread_barrier_wait(j->bar);
+    /* (2b) fold partition t of every shard */
+    size_t mine = 0;
+    for (int u = 0; u < T; u++) mine += j->all[u].ent_off[j->t + 1] - j->all[u].ent_off[j->t];
+    j->part = rollup_new_sized(300, mine);
+    for (int u = 0; u < T; u++) {
+        const job* o = &j->all[u];
+        for (size_t k = o->ent_off[j->t]; k < o->ent_off[j->t + 1]; k++) {
+            const bentry* e = &o->ent[k];
+            rollup_put(j->part, e->timeslot, e->src_as, e->dst_as, e->etype, e->bytes, e->packets, e->count);
+        }
+    }
+    pthread_barrier_wait(j->bar);
+    j->t_end = now_s();
+    return NULL;
+}
 
 double fo_bench_rollup(const fo_gen_params* g, uint64_t i0, uint64_t n, int threads,
                        uint64_t* wire_out, uint64_t* groups_out, uint64_t* bad_out,
                        uint64_t* checksum_out) {
     if (threads < 1) threads = 1;
-    size_t cap = (size_t)n * 96 + 256;
-    uint8_t* buf = (uint8_t*)malloc(cap);
-    uint64_t* off = (uint64_t*)malloc((n + 1) * sizeof(uint64_t));
-    size_t wire = fo_gen_records(g, i0, n, buf, cap, off);
+    if ((uint64_t)threads > n && n) threads = (int)n;
     job* jobs = (job*)calloc(threads, sizeof(job));
     pthread_t* th = (pthread_t*)calloc(threads, sizeof(pthread_t));
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, NULL, (unsigned)threads);
-    double t0 = now_s();
     for (int t = 0; t < threads; t++) {
         size_t a = (size_t)(n * t / threads), b = (size_t)(n * (t + 1) / threads);
         jobs[t].g = g;
-        jobs[t].buf = buf;
-        jobs[t].off = off + a;
+        jobs[t].i0 = i0 + a;
         jobs[t].n = b - a;
-        jobs[t].r = fo_rollup_new(300);
         jobs[t].t = t;
         jobs[t].threads = threads;
         jobs[t].all = jobs;
         jobs[t].bar = &bar;
     }
     for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, job_run, &jobs[t]);
-    uint64_t bad = 0;
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    double t0 = jobs[0].t_start, t1 = jobs[0].t_end;
+    uint64_t bad = 0, wire = 0, groups = 0, cs = 0;
+    int failed = 0;
     for (int t = 0; t < threads; t++) {
-        pthread_join(th[t], NULL);
+        if (jobs[t].t_start < t0) t0 = jobs[t].t_start;
+        if (jobs[t].t_end > t1) t1 = jobs[t].t_end;
         bad += jobs[t].bad;
+        wire += jobs[t].failed ? 0 : jobs[t].wire;
+        failed |= jobs[t].failed;
+        groups += jobs[t].part->n;
+        for (size_t i = 0; i < jobs[t].part->cap; i++) {
+            const slot* s = &jobs[t].part->t[i];
+            if (s->used)
+                cs += mix64(((uint64_t)s->timeslot << 32 | s->etype) ^
+                            mix64((uint64_t)s->src_as << 32 | s->dst_as)) *
+                      (s->bytes * 3 + s->packets * 5 + s->count * 7 + 1);
+        }
     }
-    double dt = now_s() - t0; /* jobs[0].r holds the merged table */
+    const double dt = t1 - t0;
     if (getenv("FO_BENCH_VERBOSE")) {
         double lo = 1e9, hi = 0;
         for (int t = 0; t < threads; t++) {
             if (jobs[t].t_ingest < lo) lo = jobs[t].t_ingest;
             if (jobs[t].t_ingest > hi) hi = jobs[t].t_ingest;
         }
-        fprintf(stderr, "[oracle bench] %d threads: shard ingest %.3f..%.3f s, whole run %.3f s (rest: thread start + tree merge)\n",
-                threads, lo, hi, dt);
+        fprintf(stderr, "[oracle bench] %d threads: shard decode+rollup %.3f..%.3f s, whole timed region %.3f s\n", threads, lo, hi, dt);
     }
     pthread_barrier_destroy(&bar);
     if (wire_out) *wire_out = wire;
-    if (groups_out) *groups_out = fo_rollup_size(jobs[0].r);
-    if (bad_out) *bad_out = bad;
-    if (checksum_out) {
-        uint64_t cs = 0;
-        for (size_t i = 0; i < jobs[0].r->cap; i++) {
-            const slot* s = &jobs[0].r->t[i];
-            if (s->used)
-                cs += mix64(((uint64_t)s->timeslot << 32 | s->etype) ^
-                            mix64((uint64_t)s->src_as << 32 | s->dst_as)) *
-                      (s->bytes * 3 + s->packets * 5 + s->count * 7 + 1);
-        }
-        *checksum_out = cs;
+    if (groups_out) *groups_out = groups;
+    if (bad_out) *bad_out = failed ? ~0ull : bad;
+    if (checksum_out) *checksum_out = cs;
+    for (int t = 0; t < threads; t++) {
+        fo_rollup_free(jobs[t].r);
+        fo_rollup_free(jobs[t].part);
+        free(jobs[t].ent);
+        free(jobs[t].ent_off);
+        free(jobs[t].buf);
+        free(jobs[t].off);
     }
-    for (int t = 0; t < threads; t++) fo_rollup_free(jobs[t].r);
     free(jobs);
     free(th);
-    free(buf);
-    free(off);
     return dt;
 }

@@ -106,7 +106,13 @@ uint64_t fo_cms_query(const uint64_t* cms, uint32_t depth, uint32_t width_log2, 
                       const uint8_t key[16]);
 
 /* ---- synthetic generator (mocker.go:57-91 distribution and BASELINE configs) */
-enum { FO_GEN_MOCKER = 0, FO_GEN_ASPAIRS = 1, FO_GEN_ZIPF = 2 };
+enum { FO_GEN_MOCKER = 0, FO_GEN_ASPAIRS = 1, FO_GEN_ZIPF = 2,
+       FO_GEN_GOFLOW = 3,   /* ASPAIRS keys, marshalled with the fields GoFlow fills for an sFlow sample (33 of the 67
+                               fields of pb-ext/flow.pb.go:57-147) - spec: DESIGN.md "Synthetic generator" */
+       FO_GEN_DISTINCT = 4, /* ASPAIRS shape, SrcAS = 1 + (i & 0xfffff), DstAS = 1 + (i >> 20 & 0xfffff): one group per record */
+       FO_GEN_REVERSED = 5  /* ASPAIRS values, fields in descending field-number order (valid proto3, not canonical) */
+};
+#define FO_GEN_MAX_RECORD 256
 typedef struct {
     uint32_t mode;
     uint32_t framed;      /* 1: varint(len) prefix (ClickHouse stacks), 0: bare (Postgres stacks) */

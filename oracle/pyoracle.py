@@ -62,7 +62,8 @@ class GenParams(C.Structure):
     ]
 
 
-GEN_MOCKER, GEN_ASPAIRS, GEN_ZIPF = 0, 1, 2
+GEN_MOCKER, GEN_ASPAIRS, GEN_ZIPF, GEN_GOFLOW, GEN_DISTINCT, GEN_REVERSED = 0, 1, 2, 3, 4, 5
+GEN_MAX_RECORD = 256
 T0 = 1_600_000_200  # multiple of 300
 
 
@@ -144,7 +145,7 @@ def gen_params(mode=GEN_MOCKER, framed=1, seed=1, n_total=0, t0=T0, span_secs=90
 
 def gen_records(gp: GenParams, i0: int, n: int):
     """-> (buf uint8[nbytes], offsets uint64[n+1])"""
-    buf = np.empty(n * 96 + 256, dtype=np.uint8)
+    buf = np.empty(n * (200 if gp.mode == GEN_GOFLOW else 96) + 256, dtype=np.uint8)
     off = np.empty(n + 1, dtype=np.uint64)
     w = lib().fo_gen_records(C.byref(gp), i0, n, buf.ctypes.data, buf.size, off.ctypes.data)
     assert w != 2**64 - 1

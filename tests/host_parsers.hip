@@ -48,7 +48,7 @@ static bool same(const Rec& r, const fo_row& o, uint32_t cols) {
 }
 
 struct Stats {
-    uint64_t cases = 0, canon_sure = 0, fast_sure = 0, oracle_ok = 0, fail = 0;
+    uint64_t cases = 0, canon_sure = 0, full_sure = 0, fast_sure = 0, oracle_ok = 0, fail = 0;
 };
 
 static void hexdump(const uint8_t* p, size_t n) {
@@ -57,7 +57,7 @@ static void hexdump(const uint8_t* p, size_t n) {
 }
 
 // payload = bare FlowMessage bytes
-static void check(const uint8_t* payload, size_t n, Stats& st, bool must_be_canon) {
+static void check(const uint8_t* payload, size_t n, Stats& st, bool must_be_canon, bool must_be_full = false) {
     // aligned, padded copy at a random byte offset (the parsers read ~32 bytes past the end)
     static std::vector<uint32_t> buf(4096);
     const uint32_t shift = (uint32_t)(rnd() & 15);
@@ -78,6 +78,20 @@ static void check(const uint8_t* payload, size_t n, Stats& st, bool must_be_cano
         st.canon_sure += sure;
         if ((sure && (orc != FO_OK || !same(r, want, COL_ALL))) || (must_be_canon && !sure)) {
             if (st.fail++ < 10) { printf("parse_canon mismatch (sure=%d oracle=%d): ", sure, orc); hexdump(payload, n); }
+        }
+        // the FULL walk (67-field producer, generic runs): a superset of the lean one
+        Rec rf;
+        rec_clear(rf);
+        const bool suref = parse_canon<COL_ALL, true>(src, shift, shift + (uint32_t)n, rf);
+        st.full_sure += suref;
+        if ((suref && (orc != FO_OK || !same(rf, want, COL_ALL))) || ((must_be_full || sure) && !suref)) {
+            if (st.fail++ < 10) { printf("parse_canon<FULL> mismatch (sure=%d lean=%d oracle=%d): ", suref, sure, orc); hexdump(payload, n); }
+        }
+        Rec rf2;
+        rec_clear(rf2);
+        const bool suref2 = parse_canon<COLS_AS_ROLLUP, true>(src, shift, shift + (uint32_t)n, rf2);
+        if (suref2 != suref || (suref2 && !same(rf2, want, COLS_AS_ROLLUP))) {
+            if (st.fail++ < 10) { printf("parse_canon<AS_ROLLUP, FULL> mismatch: "); hexdump(payload, n); }
         }
         Rec r2;
         rec_clear(r2);
@@ -116,14 +130,41 @@ static size_t put_varint(uint8_t* p, uint64_t v, int pad_to = 0) {
 }
 
 // canonical-ish random record over the full flow.proto field set
-static size_t random_schema_record(uint8_t* out, bool canonical, bool small) {
+static size_t random_schema_record(uint8_t* out, bool canonical, bool small, bool wide = false) {
     static const uint32_t varint_fields[] = {1, 2, 3, 4, 5, 9, 10, 14, 15, 18, 19, 20, 21, 22, 23, 24, 25, 26, 30, 31, 32, 37, 38, 42};
     struct F { uint32_t field; uint8_t enc[40]; size_t n; };
     std::vector<F> fs;
-    for (uint32_t f = 1; f <= 42; f++) {
+    // wide: the 67-field message of pb-ext/flow.pb.go:57-147 (what GoFlow marshals) - every number up to 64 plus
+    // 100..103; bytes fields 12, 44, 45, 100, 101; MACs (27, 28) are 48-bit values; a sprinkle of unknown fields
+    // (8, 65..99, 200, 2047) of every wire type
+    for (uint32_t f = 1; f <= (wide ? 2047u : 42u); f++) {
         bool is_var = false;
         for (uint32_t vf : varint_fields) is_var |= vf == f;
-        const bool is_addr = f == 6 || f == 7 || f == 11;
+        bool is_addr = f == 6 || f == 7 || f == 11;
+        bool unknown = false;
+        if (wide) {
+            if (f > 103 && f != 200 && f != 2047) continue;
+            const bool in_msg = f <= 64 || (f >= 100 && f <= 103);
+            unknown = !in_msg || f == 8;
+            if (unknown && (rnd() & 15) != 0) continue;
+            if (in_msg && f != 8) {
+                if (f == 12 || f == 44 || f == 45 || f == 100 || f == 101) is_addr = true;
+                else if (!is_addr) is_var = true;
+            }
+        }
+        if (unknown) {  // any skippable wire type
+            F x;
+            x.field = f;
+            const uint32_t wt = (uint32_t[]){0, 1, 2, 5}[rnd() & 3];
+            size_t k = put_varint(x.enc, (uint64_t)f << 3 | wt);
+            if (wt == 0) k += put_varint(x.enc + k, (rnd() & 1) ? rnd() : (rnd() & 0xffff));
+            else if (wt == 1) { for (int i = 0; i < 8; i++) x.enc[k++] = (uint8_t)rnd(); }
+            else if (wt == 5) { for (int i = 0; i < 4; i++) x.enc[k++] = (uint8_t)rnd(); }
+            else { const uint32_t len = (uint32_t)(rnd() % 20); k += put_varint(x.enc + k, len); for (uint32_t i = 0; i < len; i++) x.enc[k++] = (uint8_t)rnd(); }
+            x.n = k;
+            fs.push_back(x);
+            continue;
+        }
         if (!is_var && !is_addr) continue;
         if ((rnd() & 3) == 0) continue;  // absent
         F x;
@@ -135,7 +176,10 @@ static size_t random_schema_record(uint8_t* out, bool canonical, bool small) {
             for (uint32_t i = 0; i < len; i++) x.enc[k++] = (uint8_t)rnd();
         } else {
             const bool longf = f == 2 || f == 4 || f == 5 || f == 38;
-            const int bits = small ? (int)(rnd() % (longf ? 43 : 29)) : (int)(rnd() % 66);
+            const bool projected = f == 2 || f == 3 || f == 4 || f == 9 || f == 10 || f == 14 || f == 15 || f == 20 || f == 21 || f == 22 ||
+                                   f == 30 || f == 38 || f == 1 || f == 5 || f == 18 || f == 19 || (f >= 23 && f <= 26);  // (+ the lean walk's specialised skips)
+            int bits = small ? (int)(rnd() % (longf ? 43 : 29)) : (int)(rnd() % 66);
+            if (wide && small && !projected) bits = (f == 27 || f == 28) ? 48 : (int)(rnd() % 65);  // generic runs take any varint
             uint64_t v = bits >= 64 ? rnd() : (rnd() & ((1ull << bits) - 1));
             if ((rnd() & 7) == 0) v = 0;
             k += put_varint(x.enc + k, v, canonical ? 0 : ((rnd() & 15) == 0 ? (int)(rnd() % 11) : 0));
@@ -164,18 +208,18 @@ static size_t random_schema_record(uint8_t* out, bool canonical, bool small) {
 
 int main(int argc, char** argv) {
     const uint64_t iters = argc > 1 ? strtoull(argv[1], 0, 0) : 200000;
-    Stats gen, canon, noncanon, mut, small;
+    Stats gen, goflow, canon, noncanon, mut, small, wide67, wide67nc;
     // 1. generator output, all modes: must be accepted by parse_canon
-    for (uint32_t mode = 0; mode < 3; mode++) {
+    for (uint32_t mode = 0; mode < 5; mode++) {  // MOCKER, ASPAIRS, ZIPF, GOFLOW (full walk only), DISTINCT
         fo_gen_params gp;
         memset(&gp, 0, sizeof gp);
         gp.mode = mode; gp.framed = 0; gp.seed = 5 + mode; gp.n_total = iters; gp.t0 = 1600000200; gp.span_secs = 900; gp.per_sec = 4;
         gp.zipf_log2_universe = 24; gp.zipf_s_x100 = 110;
-        std::vector<uint8_t> buf(iters * 100 + 1024);
+        std::vector<uint8_t> buf(iters * 200 + 1024);
         std::vector<uint64_t> off(iters + 1);
         const size_t w = fo_gen_records(&gp, 0, iters, buf.data(), buf.size(), off.data());
         if (w == (size_t)-1) { printf("generator overflow\n"); return 2; }
-        for (uint64_t i = 0; i < iters; i++) check(buf.data() + off[i], off[i + 1] - off[i], gen, true);
+        for (uint64_t i = 0; i < iters; i++) check(buf.data() + off[i], off[i + 1] - off[i], mode == 3 ? goflow : gen, mode != 3, true);
         // 2. byte-level mutations of generator output
         for (uint64_t i = 0; i < iters; i++) {
             uint8_t tmp[256];
@@ -199,17 +243,25 @@ int main(int argc, char** argv) {
         check(tmp, n, canon, false);
         n = random_schema_record(tmp, false, (rnd() & 1) != 0);
         check(tmp, n, noncanon, false);
+        // 4. the 67-field producer: canonical order, small projected values -> the FULL walk must take it
+        n = random_schema_record(tmp, true, true, true);
+        if (n < 900) check(tmp, n, wide67, false, true);
+        n = random_schema_record(tmp, (rnd() & 3) != 0, (rnd() & 1) != 0, true);
+        if (n < 900) check(tmp, n, wide67nc, false);
     }
     auto pr = [](const char* name, const Stats& s) {
-        printf("%-28s cases=%llu oracle_ok=%llu canon_sure=%llu fast_sure=%llu FAIL=%llu\n", name, (unsigned long long)s.cases,
-               (unsigned long long)s.oracle_ok, (unsigned long long)s.canon_sure, (unsigned long long)s.fast_sure, (unsigned long long)s.fail);
+        printf("%-28s cases=%llu oracle_ok=%llu canon_sure=%llu full_sure=%llu fast_sure=%llu FAIL=%llu\n", name, (unsigned long long)s.cases,
+               (unsigned long long)s.oracle_ok, (unsigned long long)s.canon_sure, (unsigned long long)s.full_sure, (unsigned long long)s.fast_sure, (unsigned long long)s.fail);
     };
-    pr("generator (3 modes)", gen);
+    pr("generator (4 modes)", gen);
+    pr("generator (goflow)", goflow);
     pr("mutated generator output", mut);
     pr("random schema, canonical small", small);
     pr("random schema, canonical", canon);
     pr("random schema, non-canonical", noncanon);
-    const uint64_t fails = gen.fail + mut.fail + canon.fail + noncanon.fail + small.fail;
+    pr("67-field, canonical small", wide67);
+    pr("67-field, mixed", wide67nc);
+    const uint64_t fails = goflow.fail + gen.fail + mut.fail + canon.fail + noncanon.fail + small.fail + wide67.fail + wide67nc.fail;
     printf(fails ? "FAILED\n" : "OK\n");
     return fails ? 1 : 0;
 }

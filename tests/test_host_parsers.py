@@ -21,13 +21,31 @@ def test_parsers_fuzz_against_oracle(po):
         subprocess.check_call([
             "/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-value", "-o", exe, src,
             "-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
-    res = subprocess.run([exe, "150000"], capture_output=True, text=True, timeout=600)
+    res = subprocess.run([exe, "100000"], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     lines = {l.split("cases=")[0].strip(): l for l in res.stdout.splitlines() if "cases=" in l}
     # the fast tier must accept plain generator output and canonical records with small values
-    for name in ("generator (3 modes)", "random schema, canonical small"):
+    for name in ("generator (4 modes)", "random schema, canonical small"):
         f = dict(kv.split("=") for kv in lines[name].split() if "=" in kv)
-        assert f["canon_sure"] == f["cases"] and f["FAIL"] == "0", lines[name]
+        assert f["canon_sure"] == f["cases"] and f["full_sure"] == f["cases"] and f["FAIL"] == "0", lines[name]
+    # the 67-field producer (pb-ext/flow.pb.go:57-147): the FULL canonical walk must take every record
+    for name in ("generator (goflow)", "67-field, canonical small"):
+        f = dict(kv.split("=") for kv in lines[name].split() if "=" in kv)
+        assert f["full_sure"] == f["cases"] and f["canon_sure"] == "0" and f["FAIL"] == "0", lines[name]
+
+
+def test_tuple_formats_round_trip_and_balance():
+    """table.cuh scatter-sink tuples compiled for the host: wide / compact round trips, fits() is exactly the
+    documented value range, the compact format's partition bijection recovers SrcAS[7:0], partitions stay balanced."""
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "host_tuples")
+    src = os.path.join(ROOT, "tests", "host_tuples.hip")
+    deps = [src, os.path.join(ROOT, "flow-pipeline_amd", "csrc", "table.cuh")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-o", exe, src])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
 
 
 def test_time_bucket_reciprocal_is_exact():

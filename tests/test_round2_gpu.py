@@ -1,0 +1,357 @@
+"""Round-2 GPU parity tests (all through the C-ABI, bit-exact against the oracle): compact / wide scatter tuples
+and the adaptive switch between them, the 67-field producer on the canonical fast path, the order-free parser in
+place, lossless table growth from a tiny table, the in-library RCCL merge (world 1), a 2-rank window close on
+one GPU over gloo (idempotent merges), and the bench harness's N>1 path."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _mix64(z):
+    z = z.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xbf58476d1ce4e5b9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94d049bb133111eb)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+def _checksum(rows):
+    with np.errstate(over="ignore"):
+        a = (rows["timeslot"].astype(np.uint64) << np.uint64(32)) | rows["etype"].astype(np.uint64)
+        b = (rows["src_as"].astype(np.uint64) << np.uint64(32)) | rows["dst_as"].astype(np.uint64)
+        h = _mix64(a ^ _mix64(b))
+        v = rows["bytes"] * np.uint64(3) + rows["packets"] * np.uint64(5) + rows["count"] * np.uint64(7) + np.uint64(1)
+        return int((h * v).sum(dtype=np.uint64))
+
+
+def _device_batch(fa, agg, mode, seed, n, i0=0, n_total=None, **kw):
+    import torch
+    dev = torch.device("cuda", 0)
+    mp = fa.mock_params(mode=mode, framed=1, seed=seed, n_total=n_total or n, span_secs=900, per_sec=50_000, **kw)
+    cap = n * fa.mock_record_cap(mode) + 4096
+    d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    w = agg.mock_generate_device(mp, i0, n, d_buf.data_ptr(), cap, d_off.data_ptr())
+    return d_buf, d_off, w
+
+
+@pytest.mark.parametrize("fmt", ["8", "16", ""])
+@pytest.mark.parametrize("mode", [1, 0, 2])
+def test_tuple_formats_agree_with_oracle(gpu_lib, fa, po, monkeypatch, fmt, mode):
+    """The same 3 M-record batch through compact 8-byte tuples, wide 16-byte tuples and the adaptive default."""
+    if fmt:
+        monkeypatch.setenv("FA_TUPLE", fmt)
+    else:
+        monkeypatch.delenv("FA_TUPLE", raising=False)
+    n = 3_000_000
+    gp = po.gen_params(mode=mode, framed=1, seed=91 + mode, n_total=n, span_secs=900, per_sec=50_000)
+    want = po.bench_rollup(gp, 0, n, 8)
+    with fa.FlowAgg(framed=True, max_batch_records=n) as agg:
+        d_buf, d_off, w = _device_batch(fa, agg, mode, 91 + mode, n)
+        assert w == want["wire_bytes"]
+        agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), n)
+        agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), n)
+        rows = agg.read_window()
+        st = agg.stats()
+    assert len(rows) == want["groups"] and st["records_ok"] == 2 * n and st["records_bad"] == 0
+    for col in ("bytes", "packets", "count"):
+        assert (rows[col] % np.uint64(2) == 0).all()
+        rows[col] //= np.uint64(2)
+    assert _checksum(rows) == want["checksum"]
+    assert st["wave_tile_launches"] == 2
+    assert st["compact_tuple_launches"] == (0 if fmt == "16" else 2)  # generator values fit the compact format
+    assert st["records_misfit_compact"] == 0
+
+
+def _enc(fa, fields):
+    out = bytearray()
+    for f, v in fields:
+        if isinstance(v, (bytes, bytearray)):
+            out += fa.schema.encode_varint((f << 3) | 2) + fa.schema.encode_varint(len(v)) + bytes(v)
+        else:
+            out += fa.schema.encode_varint(f << 3) + fa.schema.encode_varint(int(v))
+    return bytes(out)
+
+
+def _records_with_wide_values(fa, po, n, seed, frac_big):
+    """Generator truth rows re-encoded; a fraction carries values only a WIDE tuple holds (32-bit ASNs, Bytes >= 2^17,
+    Packets >= 2^9, unusual ETypes) and a few values no tuple holds."""
+    gp = po.gen_params(mode=1, framed=0, seed=seed, n_total=n)
+    rows = po.gen_rows(gp, 0, n)
+    rng = np.random.default_rng(seed)
+    big = rng.random(n) < frac_big
+    kind = rng.integers(0, 6, n)
+    recs = []
+    for i in range(n):
+        r = rows[i]
+        sa, da, by, pk, et = int(r["src_as"]), int(r["dst_as"]), int(r["bytes"]), int(r["packets"]), int(r["etype"])
+        if big[i]:
+            k = int(kind[i])
+            if k == 0:
+                sa = 4_200_000_000 + (i % 1000)          # private 32-bit ASN
+            elif k == 1:
+                da = (1 << 20) + (i % 77)
+            elif k == 2:
+                by = (1 << 17) + i
+            elif k == 3:
+                pk = 512 + (i % 3000)
+            elif k == 4:
+                et = 0x8847                               # MPLS: not in the compact dictionary
+            else:
+                by = (1 << 28) + i                        # no tuple at all: direct path in either format
+        alen = 16 if int(r["etype"]) == 0x86dd else 4
+        fields = [(2, int(r["time_received"])), (3, 1), (4, int(r["sequence_num"])), (6, bytes(r["src_addr"][:alen])),
+                  (7, bytes(r["dst_addr"][:alen])), (9, by), (10, pk), (14, sa), (15, da), (21, int(r["src_port"])),
+                  (22, int(r["dst_port"])), (30, et), (38, int(r["time_flow_start"]))]
+        recs.append(fa.schema.frame(_enc(fa, [(f, v) for f, v in fields if isinstance(v, bytes) or v != 0])))
+    lens = np.fromiter((len(r) for r in recs), dtype=np.uint64, count=n)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    return np.frombuffer(b"".join(recs), dtype=np.uint8), off
+
+
+@pytest.mark.parametrize("fmt", ["8", "16"])
+def test_values_outside_the_compact_format_stay_exact(gpu_lib, fa, po, monkeypatch, fmt):
+    monkeypatch.setenv("FA_TUPLE", fmt)
+    monkeypatch.setenv("FA_SINK", "scatter")
+    n = 60000
+    buf, off = _records_with_wide_values(fa, po, n, 5, 0.3)
+    ref = po.Rollup(300)
+    assert ref.ingest(buf, off, 1) == 0
+    with fa.FlowAgg(framed=True) as agg:
+        agg.ingest(buf, off)
+        got = agg.read_window()
+        st = agg.stats()
+    assert got.tobytes() == ref.rows().tobytes()
+    assert st["records_ok"] == n and st["wave_tile_launches"] == 1
+    if fmt == "8":
+        assert 0.15 * n < st["records_misfit_compact"] < 0.35 * n and st["records_direct"] >= st["records_misfit_compact"]
+    else:
+        assert st["records_misfit_compact"] == 0 and 0 < st["records_direct"] < 0.1 * n
+
+
+def test_tuple_format_adapts_to_the_stream(gpu_lib, fa, po, monkeypatch):
+    """A stream whose values do not fit compact tuples: the first launch pays (misfits take the direct path), the
+    counter snapshot switches the ctx to wide tuples; results are exact throughout."""
+    monkeypatch.delenv("FA_TUPLE", raising=False)
+    monkeypatch.setenv("FA_SINK", "scatter")
+    n = 40000
+    buf, off = _records_with_wide_values(fa, po, n, 6, 0.5)
+    ref = po.Rollup(300)
+    with fa.FlowAgg(framed=True) as agg:
+        for _ in range(6):
+            agg.ingest(buf, off)
+            agg.sync()
+            assert ref.ingest(buf, off, 1) == 0
+        got = agg.read_window()
+        st = agg.stats()
+    assert got.tobytes() == ref.rows().tobytes()
+    assert st["wave_tile_launches"] == 6 and 1 <= st["compact_tuple_launches"] <= 2, st
+
+
+@pytest.mark.parametrize("mode,name", [(3, "goflow"), (5, "reversed")])
+def test_producer_shapes_rollup_and_decode(gpu_lib, fa, po, mode, name):
+    """GOFLOW: the 67-field producer (MACs, VLANs, nets, NextHop ...) stays on the canonical fast path - no record
+    reaches the second-chance or generic parsers.  REVERSED: every record takes the order-free parser, in place."""
+    n = 400_000
+    gp = po.gen_params(mode=mode, framed=1, seed=17, n_total=n, span_secs=900)
+    buf, off = po.gen_records(gp, 0, n)
+    ref = po.Rollup(300)
+    assert ref.ingest(buf, off, 1) == 0
+    with fa.FlowAgg(framed=True) as agg:
+        agg.ingest(buf, off)
+        got = agg.read_window()
+        st = agg.stats()
+    assert got.tobytes() == ref.rows().tobytes()
+    assert st["records_ok"] == n and st["records_slow"] == 0 and st["wave_tile_launches"] == 1
+    assert st["records_retried"] == (0 if mode == 3 else n), st
+    m = 50_000
+    want, wstatus = po.decode_batch(buf[:int(off[m])], off[:m + 1], 1)
+    with fa.FlowAgg(framed=True) as agg:
+        dec = agg.decode(buf[:int(off[m])], off[:m + 1])
+    assert not wstatus.any() and not dec["status"].any()
+    for col in want.dtype.names:
+        if col != "_pad":
+            assert np.array_equal(dec[col], want[col]), col
+
+
+def test_goflow_device_generator_matches_oracle(gpu_lib, fa, po):
+    import torch
+    n = 100_000
+    for mode in (3, 4, 5):
+        gp = po.gen_params(mode=mode, framed=1, seed=23, n_total=n, span_secs=900)
+        buf, off = po.gen_records(gp, 0, n)
+        with fa.FlowAgg(framed=True) as agg:
+            d_buf, d_off, w = _device_batch(fa, agg, mode, 23, n)
+            assert w == len(buf)
+            assert bytes(d_buf[:w].cpu().numpy()) == bytes(buf)
+            assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), off)
+        torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("sync_between", [True, False])
+def test_all_distinct_groups_into_a_tiny_table_lose_nothing(gpu_lib, fa, po, sync_between):
+    """8 M records, every one its own (SrcAS,DstAS) group, into a 2^16-slot table: the aggregation kernel's LDS
+    tables overflow, the device table fills up, updates are parked and replayed after the table has grown - no
+    aggregate is dropped, with or without a sync between the launches."""
+    n, parts = 8_000_000, 4
+    m = n // parts
+    gp = po.gen_params(mode=4, framed=1, seed=3, n_total=n, span_secs=600)
+    want = po.bench_rollup(gp, 0, n, 8)
+    assert want["groups"] >= n  # (>= : a group may straddle two 5-minute windows - it does not here)
+    with fa.FlowAgg(framed=True, table_capacity_log2=16, max_batch_records=m) as agg:
+        bufs = [_device_batch(fa, agg, 4, 3, m, i0=k * m, n_total=n) for k in range(parts)]
+        for d_buf, d_off, w in bufs:
+            agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
+            if sync_between:
+                agg.sync()
+        st = agg.stats()
+        assert st["records_ok"] == n and st["table_used"] == want["groups"] and st["table_capacity"] >= 2 * n
+        rows = agg.close_window()
+    assert len(rows) == want["groups"] and int(rows["count"].sum()) == n
+    assert _checksum(rows) == want["checksum"]
+
+
+RCCL_WORKER = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+import _pkg
+fa = _pkg.load(); po = _pkg.load_oracle()
+torch.cuda.set_device(0)
+rccl = None
+for name in ("librccl.so", "librccl.so.1", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so"):
+    try:
+        rccl = C.CDLL(name, mode=C.RTLD_GLOBAL); break
+    except OSError:
+        pass
+assert rccl is not None, "librccl.so not found"
+class UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+uid = UniqueId()
+assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+comm = C.c_void_p()
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+n = 60000
+gp = po.gen_params(mode=2, framed=1, seed=71, n_total=n, zipf_log2_universe=12)
+buf, off = po.gen_records(gp, 0, n)
+KS = (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS)
+with fa.FlowAgg(framed=True, key_sets=7, cms_width_log2=12, topk_capacity_log2=14) as agg:
+    agg.ingest(buf, off)
+    before = [agg.cms_read(k).copy() for k in KS]
+    top = agg.topk(KS[0], 40)
+    agg.merge_allreduce(comm.value)            # ncclAllReduce(sum, u64) inside libflowagg, world 1: identity
+    agg.merge_allreduce(comm.value)            # ... and idempotent: the ctx's own sketches are never reduced in place
+    assert all(np.array_equal(agg.cms_read(k), b) for k, b in zip(KS, before))
+    assert agg.topk(KS[0], 40).tobytes() == top.tobytes()
+    agg.ingest(buf, off)                       # more ingest: the merged view is stale, readers see the local sketch
+    assert all(np.array_equal(agg.cms_read(k), b * np.uint64(2)) for k, b in zip(KS, before))
+    agg.merge_allreduce(comm.value)
+    assert all(np.array_equal(agg.cms_read(k), b * np.uint64(2)) for k, b in zip(KS, before))
+rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+rccl.ncclCommDestroy(comm)
+print("RCCL_OK")
+'''
+
+
+def test_in_library_rccl_allreduce_world1(gpu_lib):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", RCCL_WORKER % {"root": ROOT}], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+TWO_RANK_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import _pkg
+fa = _pkg.load(); po = _pkg.load_oracle()
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)   # both ranks share the box's only GPU; the exchange goes over gloo
+dist.init_process_group("gloo")
+n, nparts = 200000, 8
+gp = po.gen_params(mode=2, framed=1, seed=81, n_total=n, zipf_log2_universe=14)
+buf, off = po.gen_records(gp, 0, n)
+raw = bytes(buf)
+def shard(parts):
+    idx = np.concatenate([np.arange(p, n, nparts) for p in parts]); idx.sort()
+    recs = [raw[int(off[k]):int(off[k + 1])] for k in idx]
+    o = np.zeros(len(recs) + 1, dtype=np.uint64); o[1:] = np.cumsum([len(r) for r in recs])
+    return np.frombuffer(b"".join(recs), dtype=np.uint8), o
+ks = 63
+kw = dict(framed=True, key_sets=ks, cms_width_log2=14, topk_capacity_log2=16)
+with fa.FlowAgg(**kw) as agg, fa.FlowAgg(**kw) as whole:
+    b, o = shard(fa.dist.partitions_of(rank, world, nparts))
+    agg.ingest(b, o)
+    whole.ingest(buf, off)                               # the single-GPU answer
+    dev = "cpu"
+    # the order the advisor flagged: top-k of one sketch, then the other, then ports - nothing may be counted twice
+    for key_set in (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS, fa.FA_KEYS_SRCADDR_CMS):
+        got = fa.dist.topk_merged(agg, key_set, 100, candidates_per_rank=None, device=dev)
+        assert got.tobytes() == whole.topk(key_set, 100).tobytes(), key_set
+        assert np.array_equal(agg.cms_read(key_set), whole.cms_read(key_set))
+    for d in (0, 1):
+        assert fa.dist.top_ports_merged(agg, d, device=dev).tobytes() == whole.top_ports(d).tobytes()
+    assert fa.dist.minute_series_merged(agg, device=dev).tobytes() == whole.minute_series().tobytes()
+    assert fa.dist.close_window_app_merged(agg, fa.ALL_TIMESLOTS, device=dev).tobytes() == whole.close_window_app().tobytes()
+    assert fa.dist.close_window_merged(agg, fa.ALL_TIMESLOTS, device=dev).tobytes() == whole.close_window().tobytes()
+dist.destroy_process_group()
+print("TWO_RANK_OK", rank)
+'''
+
+
+def _torchrun(nproc, args, env_extra, timeout=900):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_two_ranks_one_gpu_window_close_equals_single_rank(gpu_lib, tmp_path):
+    script = tmp_path / "two_rank_worker.py"
+    script.write_text(TWO_RANK_WORKER % {"root": ROOT})
+    r = _torchrun(2, [str(script)], {})
+    assert r.returncode == 0 and r.stdout.count("TWO_RANK_OK") == 2, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_bench_harness_two_ranks_dry_run(gpu_lib):
+    """bench.py's N>1 path (per-rank partitions, barrier + max-over-ranks timing, window close merged across ranks,
+    merged top-k) on the 1-GPU box: both ranks on device 0, exchange over gloo.  Never a reported configuration."""
+    r = _torchrun(2, ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--records", "2000000", "--chunk", "1000000",
+                      "--mode", "zipf", "--key-sets", "3", "--cpu-sample", "0"],
+                  {"FA_BENCH_BACKEND": "gloo", "FA_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["topk_src_addr_rows"] == 100
+    assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
+
+
+def test_bench_side_measurements_run(gpu_lib):
+    """The side-measurement modes of bench.py produce a line (small sizes; numbers are not judged here)."""
+    for extra in (["--stage", "decode"], ["--mode", "goflow"], ["--mode", "reversed"]):
+        r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--records", "2000000", "--chunk", "1000000",
+                            "--cpu-sample", "0", "--no-host-fed"] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, (extra, r.stdout[-1000:], r.stderr[-3000:])
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["roofline"]["frac"] > 0, extra
+        if extra == ["--mode", "goflow"]:
+            assert out["config"]["records_second_chance_parser"] == 0 and out["parity"]["ok"]
+        if extra == ["--mode", "reversed"]:
+            assert out["config"]["records_second_chance_parser"] == 2_000_000 and out["parity"]["ok"]

@@ -63,7 +63,8 @@ for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
          "where counter_name=? group by kernel_name")
     for name, n, avg, dur in d.execute(q, (counter,)):
         key = ("wtile_kernel" if "wtile_kernel" in name else "tile_kernel" if "tile_kernel<0" in name
-               else "agg_kernel" if "agg_kernel" in name else None)
+               else "agg_kernel" if "agg_kernel" in name else "deferred_kernel" if "deferred_kernel<0" in name
+               else "probe_kernel" if "probe_kernel" in name else None)
         if key:
             traffic.setdefault(key, {})[counter] = avg * 1024.0
             traffic[key]["launches"] = n
@@ -73,6 +74,9 @@ for k, v in traffic.items():
         v["read_bytes_corrected"] = 2.0 * v["FETCH_SIZE"]
         v["traffic_bytes"] = 2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]
 if traffic:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import _pkg
     with open(os.path.join(out, "traffic.json"), "w") as f:
         json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/profile.sh",
+                   "source_hash": _pkg.load().source_hash(),  # bench.py quotes these numbers only when it runs the same sources
                    "bench_args": os.environ.get("PROF_BENCH_ARGS", ""), "kernels": traffic}, f, indent=1)
