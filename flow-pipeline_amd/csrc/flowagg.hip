@@ -276,7 +276,8 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     c->spill_cap = 2u * cfg.max_batch_records + (1u << 21);
     c->wide_per_record = ((cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO) ? 1u : 0u) + ((cfg.key_sets & FA_KEYS_PORT_HIST) ? 2u : 0u) +
                          ((cfg.key_sets & FA_KEYS_MINUTE_SERIES) ? 1u : 0u);
-    c->wspill_cap = c->wide_per_record * 2u * cfg.max_batch_records + (1u << 21);
+    // (capped at 2^25 entries = 1.9 GB: launches that could park more are split, fa_ingest_device)
+    c->wspill_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->wide_per_record * 2u * cfg.max_batch_records + (1u << 21), 1u << 25);
     size_t tab_bytes = sizeof(Slot) << c->cap_log2;
     if ((e = hipMalloc(&c->tab, tab_bytes)) != hipSuccess) return bail("hipMalloc(table)", e);
     if ((e = hipMemsetAsync(c->tab, 0, tab_bytes, c->stream)) != hipSuccess) return bail("memset", e);
@@ -766,6 +767,18 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     if (!d_buf || !d_off || len >= (1ull << 32) || n > c->cfg.max_batch_records ||
         ((uintptr_t)d_buf & 15) || ((uintptr_t)d_off & 3))
         return fail(c, FA_ERR_ARG, "fa_ingest_device: bad buffer (16-byte aligned, < 4 GiB, n <= max_batch_records)");
+    if (c->wide_per_record) {
+        // a launch may not be able to park more wide-table updates than the spill buffer holds: split it
+        const size_t lim = (c->wspill_cap - (1u << 20)) / c->wide_per_record;
+        if (n > lim) {
+            for (size_t i = 0; i < n; i += lim) {
+                const size_t m = std::min(lim, n - i);
+                int rc1 = fa_ingest_device(c, d_buf, (size_t)((double)len * (double)m / (double)n), (const uint32_t*)d_off + i, m);
+                if (rc1) return rc1;
+            }
+            return FA_OK;
+        }
+    }
     int rc = pre_launch_guard(c, n);
     if (rc) return rc;
     rc = ensure_exotic(c, n);
