@@ -304,4 +304,231 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     }
 }
 
+// ---- aggregation of compact tuples -----------------------------------------------------------------
+// Inside one partition a compact tuple's key is a single word: everything of the key but SrcAS[7:0] is in the
+// tuple (lo = DstAS | SrcAS[19:8] << 20, kh = tbr | etcode << 4), and SrcAS[7:0] is a function of (partition, lo,
+// kh) (table.cuh).  So the LDS table is keyed by ONE 64-bit word straight out of the tuple - no unpacking, no
+// two-word compare, one ds_read2_b64 looks at the home slot and its successor - and the full key is only rebuilt
+// once per group, when the group is added to the device-wide table.  Open addressing without wrap-around: a key
+// lives in one of the AGG_PROBES slots from its home slot on (the table has that many slots of slack at the end).
+constexpr int AGG8_SLOTS = 4096;
+constexpr int AGG8_ALL = AGG8_SLOTS + AGG_PROBES;
+struct Agg8Table {
+    unsigned long long key[AGG8_ALL], s1[AGG8_ALL], s2[AGG8_ALL];  // key = 1 << 63 | kh << 32 | lo;  sums as in AggTable
+};
+__device__ __forceinline__ unsigned long long agg8_key(const uint2& t) { return (1ull << 63) | ((unsigned long long)(t.y >> 26) << 32) | t.x; }
+__device__ __forceinline__ uint32_t agg8_home(const uint2& t) {
+    return ((t.x ^ ((t.y >> 26) * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 20;  // 12 bits; the partition came out of a different mix (t8_mix8)
+}
+__device__ __forceinline__ void agg8_global(const KArgs& a, uint32_t tb_base, uint32_t part, const uint2& t, uint32_t by, uint32_t pk) {
+    TupleVals v;
+    t8_unpack(t, part, v);
+    uint64_t k0, k1;
+    pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);
+    agg_global(a, k0, k1, key_hash(k0, k1), by, pk, 1);
+}
+// probing upsert (first occurrences, keys further than one slot from home)
+__device__ __forceinline__ void agg8_tuple(const KArgs& a, Agg8Table& lt, uint32_t tb_base, uint32_t part, const uint2& t) {
+    const unsigned long long key = agg8_key(t);
+    const uint32_t by = t.y & 0x1ffffu, pk = (t.y >> 17) & 0x1ffu;
+    uint32_t i = agg8_home(t);
+#pragma unroll 1
+    for (int probe = 0; probe < AGG_PROBES; probe++, i++) {
+        unsigned long long c = lt.key[i];
+        if (c == 0) c = atomicCAS(&lt.key[i], 0ull, key);
+        if (c != 0 && c != key) continue;
+        if (by) atomicAdd(&lt.s1[i], (unsigned long long)by);
+        atomicAdd(&lt.s2[i], ((unsigned long long)pk << 25) | 1ull);
+        return;
+    }
+    agg8_global(a, tb_base, part, t, by, pk);  // the table is full around this key
+}
+
+constexpr int AGG8_SU = 2;                 // 16-byte loads per lane and batch = 4 tuples
+constexpr int AGG8_NT = AGG8_SU * 2;
+struct Agg8Batch {
+    uint4 t[AGG8_SU];
+    uint32_t v;  // bit e: tuple e of this lane is real (e >> 1 = load, e & 1 = half)
+};
+// Loads of one work item.  Front: pieces [64j, 64j+64) of segment w0 + s, one segment per load.  Back: pieces
+// [8j, 8j+8) of the c tuples that end at the segment's last slot, eight segments per load (lane / 8).  Unconditional
+// (clamped addresses, zero counts past the end: see agg_fetch).
+template <bool BACK>
+__device__ __forceinline__ void agg8_fetch(const KArgs& a, const uint4* pbase, const uint32_t* pc, uint32_t w0, uint32_t lane, uint32_t j,
+                                           Agg8Batch& b) {
+    constexpr uint32_t SEGS = BACK ? 8u : 1u, PER = 64u / SEGS;
+    uint32_t idx[AGG8_SU], seg[AGG8_SU];
+    b.v = 0;
+#pragma unroll
+    for (int s = 0; s < AGG8_SU; s++) {
+        seg[s] = w0 + (uint32_t)s * SEGS + (BACK ? lane / PER : 0u);
+        const uint32_t c = pc[min(seg[s], (uint32_t)(AGG_MAX_NWG + AGG_PAD - 1))];
+        const uint32_t first = BACK ? a.capq - c : 0u;
+        const uint32_t piece = first / 2u + PER * j + (BACK ? lane % PER : lane);
+        const uint32_t q = piece * 2u;
+        const uint32_t valid = ((q >= first && q < first + c) ? 1u : 0u) | ((q + 1u >= first && q + 1u < first + c) ? 2u : 0u);
+        b.v |= valid << (2 * s);
+        idx[s] = valid ? piece : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < AGG8_SU; s++) b.t[s] = pbase[(size_t)min(seg[s], a.nwg - 1u) * (a.capq / 2u) + idx[s]];
+}
+__device__ __forceinline__ void agg8_drain(const KArgs& a, Agg8Table& lt, uint32_t tb_base, uint32_t part, uint32_t lane, const uint2* queue, uint32_t qn) {
+    if (lane < qn) agg8_tuple(a, lt, tb_base, part, queue[lane]);
+}
+__device__ __forceinline__ void agg8_consume(const KArgs& a, Agg8Table& lt, uint32_t tb_base, uint32_t part, uint32_t lane, const Agg8Batch& b,
+                                             uint2* queue, uint32_t& qn) {
+    uint2 t[AGG8_NT];
+    unsigned long long key[AGG8_NT], c0[AGG8_NT], c1[AGG8_NT];
+    uint32_t home[AGG8_NT];
+#pragma unroll
+    for (int e = 0; e < AGG8_NT; e++) {  // all the LDS reads of the batch fly together
+        const uint4& q = b.t[e >> 1];
+        t[e] = (e & 1) ? make_uint2(q.z, q.w) : make_uint2(q.x, q.y);
+        key[e] = agg8_key(t[e]);
+        home[e] = agg8_home(t[e]);
+        c0[e] = lt.key[home[e]];
+        c1[e] = lt.key[home[e] + 1];
+    }
+    if (a.dbg & DBG_AGG_NO_LDS) {
+        unsigned long long x = 0;
+#pragma unroll
+        for (int e = 0; e < AGG8_NT; e++) x ^= c0[e] ^ c1[e] ^ key[e];
+        if (x == 0x12345678ull) lt.s1[lane] = x;
+        return;
+    }
+    uint32_t pending = 0;
+#pragma unroll
+    for (int e = 0; e < AGG8_NT; e++) {
+        if (!((b.v >> e) & 1u)) continue;
+        const bool at0 = c0[e] == key[e], at1 = c1[e] == key[e];
+        if (at0 || at1) {
+            const uint32_t s = home[e] + (at0 ? 0u : 1u);
+            const uint32_t by = t[e].y & 0x1ffffu;
+            if (by) atomicAdd(&lt.s1[s], (unsigned long long)by);
+            atomicAdd(&lt.s2[s], ((unsigned long long)((t[e].y >> 17) & 0x1ffu) << 25) | 1ull);
+        } else {
+            pending |= 1u << e;
+        }
+    }
+    if (a.dbg & DBG_AGG_NO_SLOW) return;
+#pragma unroll
+    for (int e = 0; e < AGG8_NT; e++) {  // leftovers wait in the wave's queue and take the probing path 64 at a time
+        const bool pnd = (pending >> e) & 1u;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pnd);
+        if (m != 0ull) {
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(m);
+            if (qn + cnt > 64u) {
+                agg8_drain(a, lt, tb_base, part, lane, queue, qn);
+                qn = 0;
+            }
+            if (pnd) queue[qn + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = t[e];
+            qn += cnt;
+        }
+    }
+}
+
+__global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
+    constexpr uint32_t WAVES = AGG_BLOCK / 64;
+    constexpr uint32_t FGRP = AGG8_SU, BGRP = AGG8_SU * 8;  // segments per work item: front, back
+    constexpr uint32_t NFG = (AGG_MAX_NWG + AGG_PAD) / FGRP, NBG = (AGG_MAX_NWG + AGG_PAD) / BGRP;
+    __shared__ Agg8Table lt;
+    __shared__ uint32_t pc[AGG_MAX_NWG + AGG_PAD], pcb[AGG_MAX_NWG + AGG_PAD];  // front / back counts of this partition's segments, zero padded
+    __shared__ uint16_t flv[NFG], blv[NBG];  // levels each group of segments needs (so that a wave never walks empty levels)
+    __shared__ uint2 queues[WAVES * 64];
+    const uint32_t part = blockIdx.x;
+    for (int i = threadIdx.x; i < AGG8_ALL; i += AGG_BLOCK) {
+        lt.key[i] = 0;
+        lt.s1[i] = 0;
+        lt.s2[i] = 0;
+    }
+    for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_PAD; i += AGG_BLOCK) {
+        pc[i] = i < a.nwg ? a.seg_counts[(size_t)part * a.nwg + i] : 0u;
+        pcb[i] = i < a.nwg ? a.seg_counts[((size_t)NPART_MAX + part) * a.nwg + i] : 0u;
+    }
+    const uint32_t tb_base = a.ctr->tb_base;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint4* pbase = a.seg + (((size_t)part * a.region) >> 1);
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < NFG; g += AGG_BLOCK) {
+        uint32_t m = 0;
+        for (uint32_t s = 0; s < FGRP; s++) m = max(m, pc[g * FGRP + s]);
+        flv[g] = (uint16_t)((m + 127u) >> 7);  // 64 lanes x 2 tuples per level
+    }
+    for (uint32_t g = threadIdx.x; g < NBG; g += AGG_BLOCK) {
+        uint32_t m = 0;
+        for (uint32_t s = 0; s < BGRP; s++) m = max(m, pcb[g * BGRP + s]);
+        blv[g] = (uint16_t)(m ? (m / 2u + 1u + 7u) >> 3 : 0u);  // 8 pieces per segment and level; c tuples span up to c / 2 + 1 pieces
+    }
+    __syncthreads();
+    uint2* queue = queues + wave * 64;
+    uint32_t qn = 0;
+    // Work items of a wave: (group g, level j), g = wave, wave + WAVES, ...; j < levels(g).  The loads of the next item
+    // fly while the current one is consumed (two register buffers; every fetch is unconditional - an item past the end
+    // reads clamped addresses with zero counts).
+#define FA_AGG8_PASS(BACK, LV, NG, GSEGS, PCNT)                                                           \
+    {                                                                                                       \
+        const uint32_t ngroups = (a.nwg + (GSEGS) - 1u) / (GSEGS);                                           \
+        uint32_t g = wave, j = 0;                                                                           \
+        auto settle_item = [&]() {                                                                          \
+            while (g < ngroups && j >= (uint32_t)__builtin_amdgcn_readfirstlane((int)LV[min(g, (uint32_t)(NG) - 1u)])) { \
+                g += WAVES;                                                                                 \
+                j = 0;                                                                                      \
+            }                                                                                               \
+        };                                                                                                  \
+        settle_item();                                                                                      \
+        Agg8Batch b0, b1;                                                                                   \
+        agg8_fetch<BACK>(a, pbase, PCNT, g * (GSEGS), lane, j, b0);                                          \
+        while (g < ngroups) {                                                                               \
+            j++;                                                                                            \
+            settle_item();                                                                                  \
+            agg8_fetch<BACK>(a, pbase, PCNT, g * (GSEGS), lane, j, b1);                                      \
+            agg8_consume(a, lt, tb_base, part, lane, b0, queue, qn);                                        \
+            if (g >= ngroups) break;                                                                        \
+            j++;                                                                                            \
+            settle_item();                                                                                  \
+            agg8_fetch<BACK>(a, pbase, PCNT, g * (GSEGS), lane, j, b0);                                      \
+            agg8_consume(a, lt, tb_base, part, lane, b1, queue, qn);                                        \
+        }                                                                                                   \
+    }
+    FA_AGG8_PASS(false, flv, NFG, FGRP, pc)
+    FA_AGG8_PASS(true, blv, NBG, BGRP, pcb)
+#undef FA_AGG8_PASS
+    agg8_drain(a, lt, tb_base, part, lane, queue, qn);
+    __syncthreads();
+    if (a.dbg & DBG_AGG_NO_FLUSH) return;
+    // every group of this partition goes to the device-wide table once (quad-grouped: one atomic line transaction per
+    // group; uniform trip count: the whole wave takes part in the quad rounds)
+    constexpr int NF = (AGG8_ALL + AGG_BLOCK - 1) / AGG_BLOCK;
+    unsigned long long fk0[NF], fk1[NF], fs1[NF], fs2[NF];
+    ulonglong2 home[NF];
+    uint32_t fh[NF];
+#pragma unroll
+    for (int q = 0; q < NF; q++) {  // phase 1: the home-slot probes of this thread's groups fly together
+        const int i = q * AGG_BLOCK + threadIdx.x;
+        const unsigned long long key = i < AGG8_ALL ? lt.key[i] : 0ull;
+        fs1[q] = i < AGG8_ALL ? lt.s1[i] : 0ull;
+        fs2[q] = i < AGG8_ALL ? lt.s2[i] : 0ull;
+        TupleVals v;
+        t8_unpack(make_uint2((uint32_t)key, (uint32_t)(key >> 32) << 26), part, v);
+        uint64_t k0, k1;
+        pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);
+        fk0[q] = key ? k0 : 0ull;
+        fk1[q] = key ? k1 : 0ull;
+        fh[q] = key_hash(k0, k1);
+        home[q] = *reinterpret_cast<const ulonglong2*>(&a.tab[fh[q] & a.mask]);
+    }
+#pragma unroll
+    for (int q = 0; q < NF; q++) {
+        Slot* sp = nullptr;
+        const unsigned long long b = fs1[q], p = fs2[q] >> 25, c = fs2[q] & 0x1ffffffull;
+        if (fk0[q] != 0 && fs2[q] != 0) {
+            if (home[q].x == fk0[q] && home[q].y == fk1[q]) sp = &a.tab[fh[q] & a.mask];
+            else sp = table_find_or_claim(a, fk0[q], fk1[q], fh[q]);
+            if (!sp) spill_park(a, fk0[q], fk1[q], b, p, c);
+        }
+        quad_atomic_update(sp, b, p, c);
+    }
+}
+
 }  // namespace fa

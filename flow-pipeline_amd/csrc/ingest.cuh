@@ -95,13 +95,17 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
         uint64_t k0, k1;
         pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
-        const uint32_t h = key_hash(k0, k1);
+        // the 32-bit key hash (three quarter-rate multiplies) is only needed by the hot-key table, the wide tuple's
+        // partition and the direct path: a compact-tuple wave that has given the hot-key table up never computes it
+        const bool lt_on = lt_seen != 0xffffffffu && !(a.dbg & DBG_NO_LDS_TABLE);  // wave-uniform
+        uint32_t h = 0;
+        if (!T8 || lt_on) h = key_hash(k0, k1);
         const uint64_t b = r.bytes, p = r.packets, c = 1;
         bool pending = sure;
         // hot-key table: worth its LDS atomics only while it absorbs records.  Every wave keeps score (ballots:
         // wave-uniform, no LDS traffic) and stops offering records once fewer than 1 in 8 of its first 256 stuck
         // (64 k uniform AS pairs never do; the mocker's 9 groups always do).  lt_seen == ~0u: switched off.
-        if (lt_seen != 0xffffffffu && !(a.dbg & DBG_NO_LDS_TABLE)) {
+        if (lt_on) {
             if (pending) pending = !lds_table_add<LDS_SLOTS, LDS_PROBES>(lt, k0, k1, h, b, p, c);
             lt_seen += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sure));
             lt_hits += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sure && !pending));
@@ -181,6 +185,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             Slot* sp = nullptr;
             if (pending) {
                 tally.direct++;
+                if (T8 && !lt_on) h = key_hash(k0, k1);
                 sp = table_find_or_claim(a, k0, k1, h);
                 if (!sp) spill_park(a, k0, k1, b, p, c);
             }

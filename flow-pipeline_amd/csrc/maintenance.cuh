@@ -31,6 +31,28 @@ __global__ void extract_kernel(const Slot* tab, uint32_t nslots, uint32_t gran, 
     }
 }
 
+// ---- window close, device side: sort the extracted rows by (date, timeslot, src_as, dst_as, etype) ---------
+// Two stable radix-sort passes over 64-bit keys (hipcub, flowagg.hip): low key (DstAS, EType) first, then high key
+// (Timeslot, SrcAS); Date is a function of Timeslot.  fold_ts != ~0: the rows of a sliding window get the window's
+// start as their timeslot (the sub-buckets of one group then sort next to each other and are summed by the host).
+__global__ void row_keys_kernel(Row5m* rows, uint32_t n, uint32_t fold_ts, unsigned long long* klo, unsigned long long* khi, uint32_t* idx) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (fold_ts != 0xffffffffu) {
+            rows[i].timeslot = fold_ts;
+            rows[i].date = fold_ts / 86400u;
+        }
+        klo[i] = (unsigned long long)rows[i].dst_as << 32 | rows[i].etype;
+        khi[i] = (unsigned long long)rows[i].timeslot << 32 | rows[i].src_as;
+        idx[i] = i;
+    }
+}
+__global__ void gather_u64_kernel(const unsigned long long* src, const uint32_t* idx, uint32_t n, unsigned long long* dst) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+__global__ void gather_rows_kernel(const Row5m* src, const uint32_t* idx, uint32_t n, Row5m* dst) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+
 // Re-inserts every row outside [tb_lo, tb_hi) into a fresh table (window removal / growth).
 __global__ void rebuild_kernel(const Slot* old_tab, uint32_t old_slots, uint32_t tb_lo, uint32_t tb_hi,
                                KArgs a) {
