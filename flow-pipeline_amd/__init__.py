@@ -115,7 +115,7 @@ assert ROW_APP_DTYPE.itemsize == 56 and PORT_ROW_DTYPE.itemsize == 24 and MINUTE
 EXPORTS = [
     "fa_abi_version", "fa_create", "fa_destroy", "fa_last_error", "fa_ingest", "fa_ingest_device",
     "fa_sync", "fa_decode", "fa_decode_device", "fa_open_timeslots", "fa_close_window",
-    "fa_read_window", "fa_topk", "fa_topk_merge_keys", "fa_cms_query", "fa_cms_read", "fa_cms_reset",
+    "fa_read_window", "fa_window_rows_device", "fa_merge_rows_device", "fa_topk", "fa_topk_merge_keys", "fa_cms_query", "fa_cms_read", "fa_cms_reset",
     "fa_device_state_get", "fa_merged_view_set", "fa_merge_rows", "fa_merge_allreduce", "fa_stats",
     "fa_mock_generate_device", "fa_mock_generate_host",
     "fa_read_window_app", "fa_close_window_app", "fa_merge_rows_app", "fa_top_ports", "fa_merge_ports",
@@ -200,6 +200,8 @@ def lib():
     L.fa_open_timeslots.argtypes = [vp, vp, sz, szp]
     L.fa_close_window.argtypes = [vp, u32, vp, sz, szp]
     L.fa_read_window.argtypes = [vp, u32, vp, sz, szp]
+    L.fa_window_rows_device.argtypes = [vp, u32, C.POINTER(vp), szp]
+    L.fa_merge_rows_device.argtypes = [vp, vp, sz]
     L.fa_topk.argtypes = [vp, u32, sz, vp, sz, szp]
     L.fa_topk_merge_keys.argtypes = [vp, u32, vp, sz]
     L.fa_cms_query.argtypes = [vp, u32, C.c_char_p, C.POINTER(u64)]
@@ -364,21 +366,33 @@ class FlowAgg:
     # -- window close ---------------------------------------------------------------
     def _rows_call(self, fn, timeslot, dtype=ROW5M_DTYPE):
         n = C.c_size_t()
-        cap = 1 << 12
+        # one call in the common case: the table's group count bounds the rows of any window (a too small buffer
+        # would make the library extract and sort the window a second time)
+        st = self.stats()
+        cap = max(1 << 12, int(st["table_used"] if dtype is ROW5M_DTYPE else st["wide_used"]))
         while True:
-            out = np.zeros(cap, dtype=dtype)
+            out = np.empty(cap, dtype=dtype)
             rc = fn(self._h, timeslot, out.ctypes.data, cap, C.byref(n))
             if rc == -6:  # FA_ERR_CAPACITY: n holds the required size
                 cap = n.value
                 continue
             self._chk(rc)
-            return out[:n.value].copy()
+            return out[:n.value]
 
     def read_window(self, timeslot=ALL_TIMESLOTS) -> np.ndarray:
         return self._rows_call(self._L.fa_read_window, timeslot)
 
     def close_window(self, timeslot=ALL_TIMESLOTS) -> np.ndarray:
         return self._rows_call(self._L.fa_close_window, timeslot)
+
+    def window_rows_device(self, timeslot=ALL_TIMESLOTS):
+        """-> (device pointer, n): the window's rows sorted in HBM (valid until the ctx's next window / ingest call)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.fa_window_rows_device(self._h, timeslot, C.byref(p), C.byref(n)))
+        return p.value or 0, n.value
+
+    def merge_rows_device(self, d_rows_ptr: int, n: int):
+        self._chk(self._L.fa_merge_rows_device(self._h, d_rows_ptr, n))
 
     def open_timeslots(self) -> np.ndarray:
         n = C.c_size_t()

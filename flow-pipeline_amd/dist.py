@@ -159,10 +159,39 @@ def allgather_rows(rows: np.ndarray, group=None, device=None):
 
 
 def close_window_merged(agg, timeslot, group=None, device=None) -> np.ndarray:
-    """Window close across ranks: every rank closes `timeslot` locally, gathers all
-    partial rows and returns the merged flows_5m rows (identical on every rank)."""
-    local = agg.close_window(timeslot)
-    return merge_rows_host(allgather_rows(local, group=group, device=device))
+    """Window close across ranks; every rank returns the same merged flows_5m rows.
+
+    `nccl`: device side - every rank's rows of the window are compacted and sorted in HBM
+    (fa_window_rows_device), all-gathered over RCCL straight out of / into device memory, the other ranks' rows
+    are folded into the rank's own table by a kernel (fa_merge_rows_device) and the merged window leaves through
+    the ordinary device-sorted close.  No host sort, no Python re-aggregation.
+    Other backends (gloo on CPU tensors: the harness tests): rows travel through host memory, merged with numpy."""
+    import torch
+    import torch.distributed as dist
+    # (sliding windows keep the newer sub-buckets in the table after a close: folding other ranks' rows into it would
+    # count them again at the next close - those closes take the host path as well)
+    sliding = agg.cfg.subwindow_secs not in (0, agg.cfg.window_secs) and timeslot != 0xFFFFFFFF
+    if dist.get_backend(group) != "nccl" or sliding:
+        local = agg.close_window(timeslot)
+        return merge_rows_host(allgather_rows(local, group=group, device=device))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ptr, n = agg.window_rows_device(timeslot)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    words = max(max(counts), 1) * (ROW5M_DTYPE.itemsize // 8)
+    mine = torch.zeros(words, dtype=torch.int64, device=dev)
+    if n:
+        mine[:n * (ROW5M_DTYPE.itemsize // 8)].copy_(torch.as_tensor(_DevArray(ptr, n * (ROW5M_DTYPE.itemsize // 8)), device="cuda"))
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine, group=group)
+    torch.cuda.synchronize()
+    for r in range(world):
+        if r != rank and counts[r]:
+            agg.merge_rows_device(bufs[r].data_ptr(), counts[r])
+    return agg.close_window(timeslot)
 
 
 class _DevArray:

@@ -198,6 +198,12 @@ int fa_open_timeslots(fa_ctx*, uint32_t* out, size_t cap, size_t* n_out);
 int fa_close_window(fa_ctx*, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out);
 /* Same, without removing (peek). */
 int fa_read_window(fa_ctx*, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out);
+/* Device-side window close for an exchange across GPUs (RCCL all-gather of rows): the window's rows, sorted like
+ * fa_read_window's, stay in HBM.  *d_rows: DEVICE pointer to *n_out fa_row5m, owned by the ctx, valid until its next
+ * window / ingest call.  With sub-windows the rows are handed out per sub-bucket (not folded).  Nothing is removed. */
+int fa_window_rows_device(fa_ctx*, uint32_t timeslot, const void** d_rows, size_t* n_out);
+/* Adds n rows that sit in HBM (another rank's fa_window_rows_device, gathered over RCCL) to this ctx's table. */
+int fa_merge_rows_device(fa_ctx*, const void* d_rows, size_t n);
 
 /* ---- bulk-load sink: flows_5m rows as ClickHouse RowBinary ------------------- */
 /* Serialises rows for `INSERT INTO flows_5m FORMAT RowBinary` with the column list of
