@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -100,6 +101,8 @@ struct fa_ctx {
     size_t d_rows_cap = 0;
     void* d_sort = nullptr;          // sort scratch: 4 key arrays, 2 index arrays, hipcub temporary storage
     size_t d_sort_bytes = 0;
+    void* h_rows = nullptr;          // pinned: rows on their way to the caller
+    size_t h_rows_cap = 0;
 
     unsigned long long* cms_src = nullptr;
     unsigned long long* cms_dst = nullptr;
@@ -376,6 +379,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->d_rows);
     (void)hipFree(c->d_rows_sorted);
     (void)hipFree(c->d_sort);
+    if (c->h_rows) (void)hipHostFree(c->h_rows);
     (void)hipFree(c->cms_src);
     (void)hipFree(c->cms_dst);
     (void)hipFree(c->cms_src_m);
@@ -1220,7 +1224,14 @@ static bool bucket_range(const fa_ctx* c, uint32_t timeslot, uint32_t& lo, uint3
 }
 
 // The window's rows, sorted, into the caller's buffer.  n_out = rows (needed); FA_ERR_CAPACITY when cap is too small.
+static double wall_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 static int window_rows_out(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out, uint32_t& lo, uint32_t& hi) {
+    static const bool timing = getenv("FA_TIMING_CLOSE") != nullptr;
+    const double t0 = timing ? wall_ms() : 0.0;
     *n_out = 0;
     if (!bucket_range(c, timeslot, lo, hi)) {
         lo = hi = 0;
@@ -1234,8 +1245,24 @@ static int window_rows_out(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size_t c
     if (!fold) {
         *n_out = n;
         if (n > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
-        if (n) HIPCHK(c, hipMemcpyAsync(out, c->d_rows_sorted, n * sizeof(Row5m), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        const double t1 = timing ? wall_ms() : 0.0;
+        // D2H through the ctx's pinned row buffer (a pageable destination makes the runtime stage the copy in small
+        // pieces), then one host copy into the caller's memory
+        const size_t bytes = n * sizeof(Row5m);
+        if (c->h_rows_cap < bytes) {
+            if (c->h_rows) (void)hipHostFree(c->h_rows);
+            c->h_rows = nullptr;
+            c->h_rows_cap = 0;
+            if (hipHostMalloc(&c->h_rows, bytes + bytes / 4 + 4096) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipHostMalloc(rows) failed");
+            c->h_rows_cap = bytes + bytes / 4 + 4096;
+        }
+        if (n) HIPCHK(c, hipMemcpyAsync(c->h_rows, c->d_rows_sorted, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const double t2 = timing ? wall_ms() : 0.0;
+        if (n) memcpy(out, c->h_rows, bytes);
+        if (timing)
+            fprintf(stderr, "[flowagg close] %zu rows: settle+extract+sort %.2f ms, D2H (pinned) %.2f ms, copy out %.2f ms\n", n, t1 - t0, t2 - t1, wall_ms() - t2);
         return FA_OK;
     }
     // sliding window: the sub-buckets of a group are adjacent now - one row per (SrcAS,DstAS,EType)

@@ -125,7 +125,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             if (T8) {
                 fits = t8_fits(r.src_as, r.dst_as, tbr, b, p, r.etype);
                 tc = t8_pack(r.src_as, r.dst_as, (uint32_t)b, (uint32_t)p, tbr, r.etype, part);
-                tally.misfit8 += (!fits && tup16_fits(tbr, b, p, r.etype)) ? 1u : 0u;
+                if (FA_ANY(!fits)) tally.misfit8 += (!fits && tup16_fits(tbr, b, p, r.etype)) ? 1u : 0u;  // (format feedback; rare)
             } else {
                 fits = tup16_fits(tbr, b, p, r.etype);
                 part = h >> (32 - a.plog2);

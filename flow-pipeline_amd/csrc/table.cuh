@@ -153,10 +153,9 @@ __host__ __device__ __forceinline__ uint32_t t8_etype(uint32_t code) {
 }
 // 8 well-mixed bits of the stored part of the key (lo = DstAS | SrcAS[19:8] << 20, kh = tbr | etcode << 4)
 __host__ __device__ __forceinline__ uint32_t t8_mix8(uint32_t lo, uint32_t kh) {
-    uint32_t x = lo * 0x9E3779B1u + kh * 0x85EBCA6Bu;
-    x ^= x >> 15;
-    x *= 0x2C1B3C6Du;
-    return x >> 24;
+    // one multiply (this runs once per record in the ingest kernel): Fibonacci hashing carries lo's low bits into the
+    // top byte, kh (6 bits) enters at bits 26.. and lands there directly
+    return ((lo ^ (kh << 26)) * 0x9E3779B1u) >> 24;
 }
 __host__ __device__ __forceinline__ bool t8_fits(uint32_t src_as, uint32_t dst_as, uint32_t tbr, uint64_t b, uint64_t p, uint32_t etype) {
     return tbr < TUPLE_TB_SPAN && (src_as | dst_as) < T8_MAX_AS && b < T8_MAX_BYTES && p < T8_MAX_PACKETS &&

@@ -508,7 +508,7 @@ def test_large_device_batches_checksum_equals_oracle(gpu_lib, fa, po, monkeypatc
     assert st["wave_tile_launches"] == (0 if tile == "wg" else 3)
 
 
-@pytest.mark.parametrize("tile,cap", [("", 40), ("", 64), ("wg", 40)])
+@pytest.mark.parametrize("tile,cap", [("", 40), ("", 48), ("wg", 40)])
 def test_segment_overflow_fallbacks_stay_exact(gpu_lib, fa, po, monkeypatch, tile, cap):
     """Segments far too small for the batch (FA_SEG_CAP, a test knob): full bins that find the front part full,
     single tuples that find the back part full and the workgroup kernel's plain overflow all fall back to the

@@ -206,7 +206,7 @@ def test_all_distinct_groups_into_a_tiny_table_lose_nothing(gpu_lib, fa, po, syn
     aggregate is dropped, with or without a sync between the launches."""
     n, parts = 8_000_000, 4
     m = n // parts
-    gp = po.gen_params(mode=4, framed=1, seed=3, n_total=n, span_secs=600)
+    gp = po.gen_params(mode=4, framed=1, seed=3, n_total=n, span_secs=900)  # (_device_batch spreads the records over 900 s)
     want = po.bench_rollup(gp, 0, n, 8)
     assert want["groups"] >= n  # (>= : a group may straddle two 5-minute windows - it does not here)
     with fa.FlowAgg(framed=True, table_capacity_log2=16, max_batch_records=m) as agg:
