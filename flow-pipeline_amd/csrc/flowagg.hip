@@ -30,6 +30,10 @@ struct fa_ctx {
     fa_config cfg{};
     uint32_t gran = 300;
     hipStream_t stream = nullptr;
+    // side stream: the second-chance kernel of a scatter-sink launch runs beside the tuple aggregation (both only add
+    // to the tables with atomics; the next launch waits for both)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ingested = nullptr, ev_deferred = nullptr;
     // three events per ingest launch: before / after the tile kernel, after the aggregation kernel
     struct LaunchEvents { hipEvent_t e0, e1, e2; };
     std::vector<LaunchEvents> ev_pool;
@@ -72,6 +76,7 @@ struct fa_ctx {
     uint64_t t8_wide_until = 0;   // batches counter value up to which wide tuples are used
     uint64_t seen_misfit8 = 0, seen_ok = 0;  // counter values at the last look
     unsigned stage_threads = 8;   // host threads of the staging copy (fa_ingest)
+    bool deferred_inline = false; // env FA_DEFERRED=inline (A/B): second-chance kernel on the main stream, before the aggregation
     bool agg_generic = false;     // env FA_AGG=generic (A/B): compact tuples through the two-word-key aggregation kernel
     uint32_t par = 0;             // parity of the next launch (Counters::exotic_count / retry_count copies)
     uint32_t seg_cap_limit = 0;   // env FA_SEG_CAP (tests only): upper bound on tuples per segment
@@ -237,7 +242,8 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (cfg.key_sets == 0) cfg.key_sets = FA_KEYS_AS_PAIR;
     if (cfg.topk_capacity_log2 == 0) cfg.topk_capacity_log2 = 20;
     if (cfg.wide_capacity_log2 == 0) cfg.wide_capacity_log2 = 20;
-    if (cfg.max_batch_records == 0 || cfg.max_batch_records > AGG_MAX_BATCH) cfg.max_batch_records = AGG_MAX_BATCH;
+    if (cfg.max_batch_records == 0) cfg.max_batch_records = AGG_MAX_BATCH;
+    if (cfg.max_batch_records > AGG8_MAX_BATCH) cfg.max_batch_records = AGG8_MAX_BATCH;  // (launches of wide tuples are split at 2^24)
     uint32_t gran = cfg.subwindow_secs ? cfg.subwindow_secs : cfg.window_secs;
     if (cfg.device < 0 || cfg.device >= ndev || gran < 60 || 86400 % gran != 0 ||
         cfg.window_secs % gran != 0 || 86400 % cfg.window_secs != 0 || cfg.table_capacity_log2 < 10 ||
@@ -258,6 +264,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_TILE")) c->tile_mode = !strcmp(d, "wave") ? 1 : !strcmp(d, "wg") ? 2 : 0;
     if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
     if (const char* d = getenv("FA_AGG")) c->agg_generic = !strcmp(d, "generic");
+    if (const char* d = getenv("FA_DEFERRED")) c->deferred_inline = !strcmp(d, "inline");
     if (const char* d = getenv("FA_STAGE_THREADS")) c->stage_threads = (unsigned)std::min(64, std::max(1, atoi(d)));
     c->stage_threads = std::min(c->stage_threads, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* d = getenv("FA_TUPLE")) c->t8_mode = !strcmp(d, "8") ? 1 : !strcmp(d, "16") ? 2 : 0;
@@ -275,6 +282,10 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_ingested, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_deferred, hipEventDisableTiming)) != hipSuccess)
+        return bail("hipEventCreate", e);
     for (int i = 0; i < 2; i++)
         if ((e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming)) != hipSuccess)
             return bail("hipEventCreate", e);
@@ -330,6 +341,12 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
         const size_t hbytes = sizeof(ulonglong2) * 2 * PORT_DENSE;
         if ((e = hipMalloc(&c->port_hist, hbytes)) != hipSuccess) return bail("hipMalloc(port histograms)", e);
         if ((e = hipMemsetAsync(c->port_hist, 0, hbytes, c->stream)) != hipSuccess) return bail("memset", e);
+    }
+    {  // pinned staging of window-close rows, sized for the initial table (grows with it): pinning at the first close
+       // would cost more than the close itself
+        const size_t bytes = std::min<size_t>((size_t)sizeof(Row5m) << c->cap_log2, (size_t)64 << 20);
+        if (hipHostMalloc(&c->h_rows, bytes) == hipSuccess) c->h_rows_cap = bytes;
+        else c->h_rows = nullptr;
     }
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("sync", e);
     c->stats.table_capacity = 1ull << c->cap_log2;
@@ -395,6 +412,10 @@ extern "C" void fa_destroy(fa_ctx* c) {
             (void)hipEventDestroy(p.e1);
             (void)hipEventDestroy(p.e2);
         }
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->ev_ingested) (void)hipEventDestroy(c->ev_ingested);
+    if (c->ev_deferred) (void)hipEventDestroy(c->ev_deferred);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -655,6 +676,8 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
     c->par ^= 1u;
     const bool wave_tiles = MODE == MODE_INGEST && a.seg != nullptr && a.tile_recs <= (uint32_t)WT_RECS && c->use_wave_tiles;
     const bool t8 = wave_tiles && c->use_t8;
+    const bool beside = MODE == MODE_INGEST && a.seg != nullptr && !c->deferred_inline;  // deferred kernel beside the aggregation
+    hipStream_t dstream = beside ? c->side : c->stream;
     if (ev) (void)hipEventRecord(ev->e0, c->stream);
     if (MODE == MODE_INGEST && a.seg && !wave_tiles) hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, c->stream, a);
     if (wave_tiles) c->stats.wave_tile_launches += 1;
@@ -673,7 +696,11 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
             hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);                 \
         }                                                                                       \
         if (ev) (void)hipEventRecord(ev->e1, c->stream);                                        \
-        hipLaunchKernelGGL((deferred_kernel<MODE, KS>), ge, b, 0, c->stream, a);                \
+        if (beside) {                                                                           \
+            (void)hipEventRecord(c->ev_ingested, c->stream);                                    \
+            (void)hipStreamWaitEvent(dstream, c->ev_ingested, 0);                               \
+        }                                                                                       \
+        hipLaunchKernelGGL((deferred_kernel<MODE, KS>), ge, b, 0, dstream, a);                  \
         break;                                                                                  \
     }
     if constexpr (MODE == MODE_DECODE) {
@@ -685,7 +712,11 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
             if (wave_tiles) FA_LAUNCH_W(KS_ALL);
             else hipLaunchKernelGGL((tile_kernel<MODE, KS_ALL>), g, b, 0, c->stream, a);
             if (ev) (void)hipEventRecord(ev->e1, c->stream);
-            hipLaunchKernelGGL((deferred_kernel<MODE, KS_ALL>), ge, b, 0, c->stream, a);
+            if (beside) {
+                (void)hipEventRecord(c->ev_ingested, c->stream);
+                (void)hipStreamWaitEvent(dstream, c->ev_ingested, 0);
+            }
+            hipLaunchKernelGGL((deferred_kernel<MODE, KS_ALL>), ge, b, 0, dstream, a);
             break;
         }
     }
@@ -696,6 +727,10 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
         if (t8 && AGG_SPLIT == 1 && !c->agg_generic) hipLaunchKernelGGL(agg8_kernel, ga, dim3(AGG_BLOCK), 0, c->stream, a);
         else if (t8) hipLaunchKernelGGL(agg_kernel<true>, ga, dim3(AGG_BLOCK), 0, c->stream, a);
         else hipLaunchKernelGGL(agg_kernel<false>, ga, dim3(AGG_BLOCK), 0, c->stream, a);
+    }
+    if (beside) {  // the launch is over when both are
+        (void)hipEventRecord(c->ev_deferred, dstream);
+        (void)hipStreamWaitEvent(c->stream, c->ev_deferred, 0);
     }
     if (ev) (void)hipEventRecord(ev->e2, c->stream);
     HIPCHK(c, hipGetLastError());
@@ -791,6 +826,18 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
             return FA_OK;
         }
     }
+    // small batches are not worth a second pass: they go straight to the device-wide table
+    const bool scatter = (c->cfg.key_sets & FA_KEYS_AS_PAIR) && (c->sink_mode == 2 || (c->sink_mode == 0 && n >= (1u << 15)));
+    c->use_wave_tiles = scatter && c->tile_mode != 2;
+    // tuple format of this launch (table.cuh): compact 8-byte tuples on the wave-tile kernel with 256 partitions,
+    // unless recent launches showed that this stream's records do not fit them
+    c->use_t8 = c->use_wave_tiles && c->plog2 == 8 && c->t8_mode != 2 && (c->t8_mode == 1 || c->stats.batches >= c->t8_wide_until);
+    if (n > AGG_MAX_BATCH && !c->use_t8) {  // the packed LDS sums of the wide-tuple aggregation hold 2^24 records per launch
+        const size_t h = n / 2;
+        int rc1 = fa_ingest_device(c, d_buf, len / 2, d_off, h);
+        if (rc1) return rc1;
+        return fa_ingest_device(c, d_buf, len - len / 2, (const uint32_t*)d_off + h, n - h);
+    }
     int rc = pre_launch_guard(c, n);
     if (rc) return rc;
     rc = ensure_exotic(c, n);
@@ -801,9 +848,6 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     a.n = (uint32_t)n;
     a.tile_recs = tile_recs_for(len, n);
     int grid = tile_grid<MODE_INGEST>(c, a.n, a.tile_recs);
-    // small batches are not worth a second pass: they go straight to the device-wide table
-    const bool scatter = (c->cfg.key_sets & FA_KEYS_AS_PAIR) && (c->sink_mode == 2 || (c->sink_mode == 0 && n >= (1u << 15)));
-    c->use_wave_tiles = scatter && c->tile_mode != 2;
     if (c->use_wave_tiles) {  // wave-private tiles: <= 64 records per wave, WBLOCK / 64 waves per workgroup, WT_WG_PER_CU workgroups per CU
         double avg = (double)len / (double)n + 0.5;
         // (a tile that does not fit its buffer goes to the deferred parsers as a whole, so leave ~4 sigma of
@@ -813,10 +857,8 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         const uint32_t wtiles = (a.n + a.tile_recs - 1) / a.tile_recs;
         const uint32_t wgs = (wtiles + (WBLOCK / 64) - 1) / (WBLOCK / 64);
         grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * (uint32_t)WT_WG_PER_CU));
+        if (a.tile_recs > (uint32_t)WT_RECS) c->use_t8 = false;
     }
-    // tuple format of this launch (table.cuh): compact 8-byte tuples on the wave-tile kernel with 256 partitions,
-    // unless recent launches showed that this stream's records do not fit them
-    c->use_t8 = c->use_wave_tiles && c->plog2 == 8 && c->t8_mode != 2 && (c->t8_mode == 1 || c->stats.batches >= c->t8_wide_until);
     if (scatter) {
         rc = ensure_segments(c, n, (uint32_t)grid, c->use_t8, a);
         if (rc) return rc;

@@ -51,7 +51,8 @@ constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table
 constexpr int AGG_SLOTS = FA_AGG_SLOTS;  // 32 B of LDS per slot (4096: 128 KiB)
 constexpr int AGG_SPLIT = FA_AGG_SPLIT;  // workgroups per key partition (each with its own LDS table)
 constexpr int AGG_PROBES = 16;
-constexpr uint32_t AGG_MAX_BATCH = 1u << 24;  // count <= 2^24 per slot keeps the packed LDS sums exact
+constexpr uint32_t AGG_MAX_BATCH = 1u << 24;  // wide tuples: count <= 2^24 per slot keeps the packed LDS sums exact (Packets < 2^15: 15 + 24 + 25 bits)
+constexpr uint32_t AGG8_MAX_BATCH = (1u << 25) - 1u;  // compact tuples (Packets < 2^9): 25 bits of count
 static_assert(TILE_STRIDE % 16 == 0, "LDS tile buffers must stay 16-byte aligned");
 
 enum { MODE_INGEST = 0, MODE_DECODE = 1 };

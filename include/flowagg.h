@@ -76,7 +76,8 @@ typedef struct {
     uint32_t key_sets;            /* 0 -> FA_KEYS_AS_PAIR */
     int32_t framed;               /* 1: each record is varint(len)||payload (-proto.fixedlen=true,
                                      mocker.go:98-101); 0: bare payload (mocker.go:96-97) */
-    uint32_t max_batch_records;   /* upper bound on n per ingest launch; 0 or > 1<<24 -> 1<<24 */
+    uint32_t max_batch_records;   /* upper bound on n per ingest call; 0 -> 1<<24; at most (1<<25)-1 (a call whose records
+                                     leave as wide tuples is split into launches of <= 1<<24) */
     uint32_t topk_capacity_log2;  /* slots of each distinct-address set behind fa_topk (32 B each); 0 -> 20 */
     uint32_t wide_capacity_log2;  /* slots of the wide-key table (64 B each) behind FA_KEYS_ADDR_PORT_PROTO /
                                      PORT_HIST / MINUTE_SERIES; 0 -> 20; grows by itself like the flows_5m table */
