@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--records", type=int, default=100_000_000, help="records per GPU per step")
-    ap.add_argument("--chunk", type=int, default=16_666_667, help="records per ingest launch (<= 2^24)")
+    ap.add_argument("--chunk", type=int, default=33_333_334, help="records per ingest launch (<= 2^25 - 1: compact tuples; launches of wide tuples are split at 2^24)")
     ap.add_argument("--mode", default="aspairs", choices=["mocker", "aspairs", "zipf", "goflow", "reversed", "distinct"])
     ap.add_argument("--stage", default="ingest", choices=["ingest", "decode"],
                     help="decode: the projection stage alone (wire bytes -> 15 SoA columns in HBM, fa_decode_device)")
@@ -295,7 +295,7 @@ def main():
     expect = n_rec * total_steps * world
     assert args.no_assert or ok_total == expect, "merged count() %d != records ingested %d" % (ok_total, expect)
 
-    default_workload = (args.records == 100_000_000 and args.chunk == 16_666_667 and args.mode == "aspairs"
+    default_workload = (args.records == 100_000_000 and args.chunk == 33_333_334 and args.mode == "aspairs"
                         and not os.environ.get("FA_DEBUG_FLAGS") and args.key_sets == 1 and wave)
     traffic, traffic_all, traffic_note = pmc_traffic(fa, default_workload)
     fmt = "compact8" if compact == launches else "wide16" if compact == 0 else "mixed (%d of %d launches compact)" % (compact, launches)

@@ -30,8 +30,8 @@ struct fa_ctx {
     fa_config cfg{};
     uint32_t gran = 300;
     hipStream_t stream = nullptr;
-    // side stream: the second-chance kernel of a scatter-sink launch runs beside the tuple aggregation (both only add
-    // to the tables with atomics; the next launch waits for both)
+    // side stream (experiment, FA_DEFERRED=beside): the second-chance kernel of a scatter-sink launch beside the tuple
+    // aggregation (both only add to the tables with atomics; the next launch waits for both)
     hipStream_t side = nullptr;
     hipEvent_t ev_ingested = nullptr, ev_deferred = nullptr;
     // three events per ingest launch: before / after the tile kernel, after the aggregation kernel
@@ -76,7 +76,7 @@ struct fa_ctx {
     uint64_t t8_wide_until = 0;   // batches counter value up to which wide tuples are used
     uint64_t seen_misfit8 = 0, seen_ok = 0;  // counter values at the last look
     unsigned stage_threads = 8;   // host threads of the staging copy (fa_ingest)
-    bool deferred_inline = false; // env FA_DEFERRED=inline (A/B): second-chance kernel on the main stream, before the aggregation
+    bool deferred_beside = false; // env FA_DEFERRED=beside (A/B): second-chance kernel on the side stream, beside the aggregation
     bool agg_generic = false;     // env FA_AGG=generic (A/B): compact tuples through the two-word-key aggregation kernel
     uint32_t par = 0;             // parity of the next launch (Counters::exotic_count / retry_count copies)
     uint32_t seg_cap_limit = 0;   // env FA_SEG_CAP (tests only): upper bound on tuples per segment
@@ -264,7 +264,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_TILE")) c->tile_mode = !strcmp(d, "wave") ? 1 : !strcmp(d, "wg") ? 2 : 0;
     if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
     if (const char* d = getenv("FA_AGG")) c->agg_generic = !strcmp(d, "generic");
-    if (const char* d = getenv("FA_DEFERRED")) c->deferred_inline = !strcmp(d, "inline");
+    if (const char* d = getenv("FA_DEFERRED")) c->deferred_beside = !strcmp(d, "beside");
     if (const char* d = getenv("FA_STAGE_THREADS")) c->stage_threads = (unsigned)std::min(64, std::max(1, atoi(d)));
     c->stage_threads = std::min(c->stage_threads, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* d = getenv("FA_TUPLE")) c->t8_mode = !strcmp(d, "8") ? 1 : !strcmp(d, "16") ? 2 : 0;
@@ -676,7 +676,10 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
     c->par ^= 1u;
     const bool wave_tiles = MODE == MODE_INGEST && a.seg != nullptr && a.tile_recs <= (uint32_t)WT_RECS && c->use_wave_tiles;
     const bool t8 = wave_tiles && c->use_t8;
-    const bool beside = MODE == MODE_INGEST && a.seg != nullptr && !c->deferred_inline;  // deferred kernel beside the aggregation
+    // (measured: the second-chance kernel on a side stream beside the aggregation costs MORE than running it in line -
+    // 66 vs 58 us for deferred + aggregation per launch; the cross-stream event hand-over is slower than the 4.5 us kernel.
+    // FA_DEFERRED=beside keeps the experiment reachable.)
+    const bool beside = MODE == MODE_INGEST && a.seg != nullptr && c->deferred_beside;
     hipStream_t dstream = beside ? c->side : c->stream;
     if (ev) (void)hipEventRecord(ev->e0, c->stream);
     if (MODE == MODE_INGEST && a.seg && !wave_tiles) hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, c->stream, a);
@@ -1196,7 +1199,11 @@ static bool row_less(const fa_row5m& x, const fa_row5m& y) {
 // by (date, timeslot, src_as, dst_as, etype) in HBM (two stable 64-bit radix passes).  They stay in
 // c->d_rows_sorted; the host only copies the final rows out (393 k rows of config 2: < 2 ms instead of the 100 ms
 // the former D2H + std::sort took).
-static int collect_rows_device(fa_ctx* c, uint32_t tb_lo, uint32_t tb_hi, uint32_t fold_ts, size_t& nrows) {
+// to_host: the last gather writes the sorted rows straight into the ctx's pinned host buffer (c->h_rows, mapped into
+// the device: 393 k rows cross PCIe in ~0.4 ms; a D2H copy of the same rows took 7 ms on the bench boxes) when they
+// fit it; *in_host tells where they ended up.
+static int collect_rows_device(fa_ctx* c, uint32_t tb_lo, uint32_t tb_hi, uint32_t fold_ts, size_t& nrows, bool to_host = false, bool* in_host = nullptr) {
+    if (in_host) *in_host = false;
     int rc = settle(c);
     if (rc) return rc;
     const size_t need = std::max<uint64_t>(c->stats.table_used, 1024);
@@ -1246,8 +1253,10 @@ static int collect_rows_device(fa_ctx* c, uint32_t tb_lo, uint32_t tb_hi, uint32
     hipLaunchKernelGGL(gather_u64_kernel, g, b, 0, c->stream, khi, idx1, n, k2);
     if (hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k2, k3, idx1, idx0, (int)n, 0, 64, c->stream) != hipSuccess)
         return fail(c, FA_ERR_HIP, "radix sort (high key) failed");
-    hipLaunchKernelGGL(gather_rows_kernel, g, b, 0, c->stream, c->d_rows, idx0, n, c->d_rows_sorted);
+    const bool host = to_host && c->h_rows && (size_t)n * sizeof(Row5m) <= c->h_rows_cap;
+    hipLaunchKernelGGL(gather_rows_kernel, g, b, 0, c->stream, c->d_rows, idx0, n, host ? (Row5m*)c->h_rows : c->d_rows_sorted);
     HIPCHK(c, hipGetLastError());
+    if (in_host) *in_host = host;
     return FA_OK;
 }
 
@@ -1281,30 +1290,26 @@ static int window_rows_out(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size_t c
     }
     const bool fold = timeslot != 0xFFFFFFFFu && c->gran != c->cfg.window_secs;
     size_t n = 0;
-    int rc = collect_rows_device(c, lo, hi, fold ? timeslot : 0xFFFFFFFFu, n);
+    bool in_host = false;
+    int rc = collect_rows_device(c, lo, hi, fold ? timeslot : 0xFFFFFFFFu, n, !fold, &in_host);
     if (rc) return rc;
     static_assert(sizeof(Row5m) == sizeof(fa_row5m), "row layout");
     if (!fold) {
         *n_out = n;
         if (n > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const double t1 = timing ? wall_ms() : 0.0;
-        // D2H through the ctx's pinned row buffer (a pageable destination makes the runtime stage the copy in small
-        // pieces), then one host copy into the caller's memory
         const size_t bytes = n * sizeof(Row5m);
-        if (c->h_rows_cap < bytes) {
+        if (n && !in_host) {  // (rows beyond the pinned buffer: grow it for the next close, copy this time)
             if (c->h_rows) (void)hipHostFree(c->h_rows);
             c->h_rows = nullptr;
             c->h_rows_cap = 0;
             if (hipHostMalloc(&c->h_rows, bytes + bytes / 4 + 4096) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipHostMalloc(rows) failed");
             c->h_rows_cap = bytes + bytes / 4 + 4096;
+            HIPCHK(c, hipMemcpyAsync(c->h_rows, c->d_rows_sorted, bytes, hipMemcpyDeviceToHost, c->stream));
         }
-        if (n) HIPCHK(c, hipMemcpyAsync(c->h_rows, c->d_rows_sorted, bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        const double t2 = timing ? wall_ms() : 0.0;
+        const double t1 = timing ? wall_ms() : 0.0;
         if (n) memcpy(out, c->h_rows, bytes);
-        if (timing)
-            fprintf(stderr, "[flowagg close] %zu rows: settle+extract+sort %.2f ms, D2H (pinned) %.2f ms, copy out %.2f ms\n", n, t1 - t0, t2 - t1, wall_ms() - t2);
+        if (timing) fprintf(stderr, "[flowagg close] %zu rows: settle + extract + sort + rows to pinned host memory %.2f ms, copy out %.2f ms\n", n, t1 - t0, wall_ms() - t1);
         return FA_OK;
     }
     // sliding window: the sub-buckets of a group are adjacent now - one row per (SrcAS,DstAS,EType)
