@@ -354,7 +354,7 @@ struct Agg8Batch {
 // [8j, 8j+8) of the c tuples that end at the segment's last slot, eight segments per load (lane / 8).  Unconditional
 // (clamped addresses, zero counts past the end: see agg_fetch).
 template <bool BACK>
-__device__ __forceinline__ void agg8_fetch(const KArgs& a, const uint4* pbase, const uint32_t* pc, uint32_t w0, uint32_t lane, uint32_t j,
+__device__ __forceinline__ void agg8_fetch(uint32_t capq, uint32_t nwg, const uint4* pbase, const uint32_t* pc, uint32_t w0, uint32_t lane, uint32_t j,
                                            Agg8Batch& b) {
     constexpr uint32_t SEGS = BACK ? 8u : 1u, PER = 64u / SEGS;
     uint32_t idx[AGG8_SU], seg[AGG8_SU];
@@ -363,7 +363,7 @@ __device__ __forceinline__ void agg8_fetch(const KArgs& a, const uint4* pbase, c
     for (int s = 0; s < AGG8_SU; s++) {
         seg[s] = w0 + (uint32_t)s * SEGS + (BACK ? lane / PER : 0u);
         const uint32_t c = pc[min(seg[s], (uint32_t)(AGG_MAX_NWG + AGG_PAD - 1))];
-        const uint32_t first = BACK ? a.capq - c : 0u;
+        const uint32_t first = BACK ? capq - c : 0u;
         const uint32_t piece = first / 2u + PER * j + (BACK ? lane % PER : lane);
         const uint32_t q = piece * 2u;
         const uint32_t valid = ((q >= first && q < first + c) ? 1u : 0u) | ((q + 1u >= first && q + 1u < first + c) ? 2u : 0u);
@@ -371,7 +371,7 @@ __device__ __forceinline__ void agg8_fetch(const KArgs& a, const uint4* pbase, c
         idx[s] = valid ? piece : 0u;
     }
 #pragma unroll
-    for (int s = 0; s < AGG8_SU; s++) b.t[s] = pbase[(size_t)min(seg[s], a.nwg - 1u) * (a.capq / 2u) + idx[s]];
+    for (int s = 0; s < AGG8_SU; s++) b.t[s] = pbase[(size_t)min(seg[s], nwg - 1u) * (capq / 2u) + idx[s]];
 }
 __device__ __forceinline__ void agg8_drain(const KArgs& a, Agg8Table& lt, uint32_t tb_base, uint32_t part, uint32_t lane, const uint2* queue, uint32_t qn) {
     if (lane < qn) agg8_tuple(a, lt, tb_base, part, queue[lane]);
@@ -478,16 +478,16 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
         };                                                                                                  \
         settle_item();                                                                                      \
         Agg8Batch b0, b1;                                                                                   \
-        agg8_fetch<BACK>(a, pbase, PCNT, g * (GSEGS), lane, j, b0);                                          \
+        agg8_fetch<BACK>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                                          \
         while (g < ngroups) {                                                                               \
             j++;                                                                                            \
             settle_item();                                                                                  \
-            agg8_fetch<BACK>(a, pbase, PCNT, g * (GSEGS), lane, j, b1);                                      \
+            agg8_fetch<BACK>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b1);                                      \
             agg8_consume(a, lt, tb_base, part, lane, b0, queue, qn);                                        \
             if (g >= ngroups) break;                                                                        \
             j++;                                                                                            \
             settle_item();                                                                                  \
-            agg8_fetch<BACK>(a, pbase, PCNT, g * (GSEGS), lane, j, b0);                                      \
+            agg8_fetch<BACK>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                                      \
             agg8_consume(a, lt, tb_base, part, lane, b1, queue, qn);                                        \
         }                                                                                                   \
     }
@@ -528,6 +528,88 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
             if (!sp) spill_park(a, fk0[q], fk1[q], b, p, c);
         }
         quad_atomic_update(sp, b, p, c);
+    }
+}
+
+// ---- Count-Min scatter sink: fold the sketch tuples -------------------------------------------------
+// One workgroup per (sketch, slice): the slice's counters live in a dense LDS array for the launch, every tuple of the
+// slice's segments is one LDS add, and the array is folded into copy 0 of the sketch with plain, coalesced 64-bit
+// read-modify-writes (the slice belongs to this workgroup alone; the atomic paths use the other copies or run in other
+// kernels).  Same segment geometry and walk as agg8_kernel.
+__global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t set_mask) {
+    constexpr uint32_t WAVES = AGG_BLOCK / 64;
+    constexpr uint32_t FGRP = AGG8_SU, BGRP = AGG8_SU * 8;
+    constexpr uint32_t NFG = (AGG_MAX_NWG + AGG_PAD) / FGRP, NBG = (AGG_MAX_NWG + AGG_PAD) / BGRP;
+    __shared__ unsigned long long arr[1u << CMS_SLICE_LOG2_MAX];  // 128 KiB
+    __shared__ uint32_t pc[AGG_MAX_NWG + AGG_PAD], pcb[AGG_MAX_NWG + AGG_PAD];
+    __shared__ uint16_t flv[NFG], blv[NBG];
+    // blockIdx -> (sketch, slice): only the enabled sketches have workgroups
+    const uint32_t set = (set_mask == 3u) ? blockIdx.x / CMS_NPART : (set_mask >> 1);
+    const uint32_t part = set * CMS_NPART + blockIdx.x % CMS_NPART;
+    const uint32_t slice = 1u << a.cms_sl2;
+    for (uint32_t i = threadIdx.x; i < slice; i += AGG_BLOCK) arr[i] = 0;
+    for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_PAD; i += AGG_BLOCK) {
+        pc[i] = i < a.nwg ? a.cseg_counts[(size_t)part * a.nwg + i] : 0u;
+        pcb[i] = i < a.nwg ? a.cseg_counts[((size_t)CMS_SETS * CMS_NPART + part) * a.nwg + i] : 0u;
+    }
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint4* pbase = reinterpret_cast<const uint4*>(a.cseg + (size_t)part * a.cregion);
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < NFG; g += AGG_BLOCK) {
+        uint32_t m = 0;
+        for (uint32_t s = 0; s < FGRP; s++) m = max(m, pc[g * FGRP + s]);
+        flv[g] = (uint16_t)min((m + 127u) >> 7, 65535u);
+    }
+    for (uint32_t g = threadIdx.x; g < NBG; g += AGG_BLOCK) {
+        uint32_t m = 0;
+        for (uint32_t s = 0; s < BGRP; s++) m = max(m, pcb[g * BGRP + s]);
+        blv[g] = (uint16_t)(m ? (m / 2u + 1u + 7u) >> 3 : 0u);
+    }
+    __syncthreads();
+    auto consume = [&](const Agg8Batch& b) {
+#pragma unroll
+        for (int e = 0; e < AGG8_NT; e++) {
+            const uint4& q = b.t[e >> 1];
+            const uint32_t x = (e & 1) ? q.z : q.x, y = (e & 1) ? q.w : q.y;
+            const unsigned long long w = ((unsigned long long)y << 18) | (x >> 14);
+            if (((b.v >> e) & 1u) && w) atomicAdd(&arr[x & 0x3fffu], w);
+        }
+    };
+#define FA_CMS_PASS(BACK, LV, NG, GSEGS, PCNT)                                                            \
+    {                                                                                                       \
+        const uint32_t ngroups = (a.nwg + (GSEGS) - 1u) / (GSEGS);                                           \
+        uint32_t g = wave, j = 0;                                                                           \
+        auto settle_item = [&]() {                                                                          \
+            while (g < ngroups && j >= (uint32_t)__builtin_amdgcn_readfirstlane((int)LV[min(g, (uint32_t)(NG) - 1u)])) { \
+                g += WAVES;                                                                                 \
+                j = 0;                                                                                      \
+            }                                                                                               \
+        };                                                                                                  \
+        settle_item();                                                                                      \
+        Agg8Batch b0, b1;                                                                                   \
+        agg8_fetch<BACK>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                             \
+        while (g < ngroups) {                                                                               \
+            j++;                                                                                            \
+            settle_item();                                                                                  \
+            agg8_fetch<BACK>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b1);                         \
+            consume(b0);                                                                                    \
+            if (g >= ngroups) break;                                                                        \
+            j++;                                                                                            \
+            settle_item();                                                                                  \
+            agg8_fetch<BACK>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                         \
+            consume(b1);                                                                                    \
+        }                                                                                                   \
+    }
+    FA_CMS_PASS(false, flv, NFG, FGRP, pc)
+    FA_CMS_PASS(true, blv, NBG, BGRP, pcb)
+#undef FA_CMS_PASS
+    __syncthreads();
+    unsigned long long* sk = (set ? a.cms_dst : a.cms_src) + ((size_t)(part & (CMS_NPART - 1u)) << a.cms_sl2);
+    const size_t total = (size_t)a.cms_depth << a.cms_wl2;  // slices past the end of the sketch are empty
+    const size_t c0 = (size_t)(part & (CMS_NPART - 1u)) << a.cms_sl2;
+    for (uint32_t i = threadIdx.x; i < slice; i += AGG_BLOCK) {
+        const unsigned long long v = arr[i];
+        if (v && c0 + i < total) sk[i] += v;
     }
 }
 

@@ -66,6 +66,13 @@ struct fa_ctx {
     size_t seg_bytes = 0;
     uint32_t* seg_counts = nullptr;
     size_t seg_counts_cap = 0;
+    // Count-Min scatter sink (sinks.cuh): sketch tuples' segments
+    uint2* cseg = nullptr;
+    size_t cseg_bytes = 0;
+    uint32_t* cseg_counts = nullptr;
+    size_t cseg_counts_cap = 0;
+    bool cms_atomic = false;  // env FA_CMS=atomic (A/B, tests): every sketch update through memory-side atomics
+    uint32_t cms_sl2 = 0;     // log2(counters per sketch slice)
     int sink_mode = 0;  // 0 auto, 1 direct, 2 scatter (env FA_SINK)
     bool use_wave_tiles = false;  // decision for the batch being launched
     bool use_t8 = false;          // ... compact 8-byte tuples (table.cuh) for it
@@ -156,6 +163,7 @@ struct fa_ctx {
         if (c) (void)hipSetDevice((c)->cfg.device);    \
     } while (0)
 
+static uint32_t log2_ceil(uint64_t v);
 static int fail(fa_ctx* c, int code, const char* msg) {
     if (c) c->err = msg;
     return code;
@@ -264,6 +272,8 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_TILE")) c->tile_mode = !strcmp(d, "wave") ? 1 : !strcmp(d, "wg") ? 2 : 0;
     if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
     if (const char* d = getenv("FA_AGG")) c->agg_generic = !strcmp(d, "generic");
+    if (const char* d = getenv("FA_CMS")) c->cms_atomic = !strcmp(d, "atomic");
+    c->cms_sl2 = (uint32_t)std::max<int>(0, (int)log2_ceil((uint64_t)cfg.cms_depth << cfg.cms_width_log2) - 8);
     if (const char* d = getenv("FA_DEFERRED")) c->deferred_beside = !strcmp(d, "beside");
     if (const char* d = getenv("FA_STAGE_THREADS")) c->stage_threads = (unsigned)std::min(64, std::max(1, atoi(d)));
     c->stage_threads = std::min(c->stage_threads, std::max(1u, std::thread::hardware_concurrency()));
@@ -387,6 +397,8 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->d_exotic);
     (void)hipFree(c->seg);
     (void)hipFree(c->seg_counts);
+    (void)hipFree(c->cseg);
+    (void)hipFree(c->cseg_counts);
     for (int i = 0; i < 2; i++) {
         if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
         (void)hipFree(c->d_in[i]);
@@ -687,8 +699,8 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
     if (t8) c->stats.compact_tuple_launches += 1;
 #define FA_LAUNCH_W(KS)                                                                         \
     do {                                                                                        \
-        if (t8) hipLaunchKernelGGL((wtile_kernel<KS, true>), g, dim3(WBLOCK), 0, c->stream, a); \
-        else hipLaunchKernelGGL((wtile_kernel<KS, false>), g, dim3(WBLOCK), 0, c->stream, a);   \
+        if (t8) hipLaunchKernelGGL((wtile_kernel<KS, true>), g, dim3(wtile_block<KS>()), 0, c->stream, a); \
+        else hipLaunchKernelGGL((wtile_kernel<KS, false>), g, dim3(wtile_block<KS>()), 0, c->stream, a);   \
     } while (0)
 #define FA_LAUNCH(KS)                                                                           \
     case KS: {                                                                                  \
@@ -730,6 +742,10 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
         if (t8 && AGG_SPLIT == 1 && !c->agg_generic) hipLaunchKernelGGL(agg8_kernel, ga, dim3(AGG_BLOCK), 0, c->stream, a);
         else if (t8) hipLaunchKernelGGL(agg_kernel<true>, ga, dim3(AGG_BLOCK), 0, c->stream, a);
         else hipLaunchKernelGGL(agg_kernel<false>, ga, dim3(AGG_BLOCK), 0, c->stream, a);
+    }
+    if (MODE == MODE_INGEST && wave_tiles && a.cseg) {  // fold the sketch tuples (Count-Min scatter sink)
+        const uint32_t set_mask = (c->cfg.key_sets >> 1) & 3u;
+        hipLaunchKernelGGL(cms_agg_kernel, dim3(CMS_NPART * (set_mask == 3u ? 2u : 1u)), dim3(AGG_BLOCK), 0, c->stream, a, set_mask);
     }
     if (beside) {  // the launch is over when both are
         (void)hipEventRecord(c->ev_deferred, dstream);
@@ -809,6 +825,42 @@ static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, bool t8, KArgs& a)
     return FA_OK;
 }
 
+// Segments of the Count-Min scatter sink for a batch of n records processed by nwg workgroups: per (sketch slice,
+// workgroup) 3x the mean + 64 tuples (a heavy hitter adds up to one tuple per wave-tile to each of its slices after the
+// wave-level fold: about as much again as the slice's mean; what still overflows is added with atomics).
+static int ensure_csegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
+    const size_t nparts = (size_t)CMS_SETS * CMS_NPART;
+    const size_t mean = n * c->cfg.cms_depth / ((size_t)CMS_NPART * nwg);
+    const uint32_t capq = (uint32_t)((3 * mean + 64 + 7) & ~(size_t)7);
+    const size_t region = (size_t)nwg * capq + 24;
+    const size_t bytes = region * nparts * sizeof(uint2);
+    if (c->cseg_bytes < bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->cseg);
+        c->cseg = nullptr;
+        c->cseg_bytes = 0;
+        if (hipMalloc(&c->cseg, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(sketch tuple segments) failed");
+        c->cseg_bytes = bytes;
+    }
+    const size_t ncnt = (size_t)nwg * nparts * 2;
+    if (c->cseg_counts_cap < ncnt) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->cseg_counts);
+        c->cseg_counts = nullptr;
+        c->cseg_counts_cap = 0;
+        if (hipMalloc(&c->cseg_counts, ncnt * sizeof(uint32_t)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(sketch segment counts) failed");
+        c->cseg_counts_cap = ncnt;
+    }
+    a.cseg = c->cseg;
+    a.cseg_counts = c->cseg_counts;
+    a.ccapq = capq;
+    a.ccapb = std::min<uint32_t>(std::max<uint32_t>(16u, (capq / 8) & ~7u), 0xfff8u);
+    a.ccapf = std::min<uint32_t>(capq - a.ccapb, 0xffffu * CMS_BIN);
+    a.cregion = region;
+    a.cms_sl2 = c->cms_sl2;
+    return FA_OK;
+}
+
 extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const void* d_off, size_t n) {
     FA_ON_DEVICE(c);
     if (!c) return FA_ERR_ARG;
@@ -858,12 +910,19 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         double r = ((double)WT_STRIDE - 16.0 - 15.0 - 12.0 * 8.0 * 4.0) / avg;
         a.tile_recs = r >= (double)WT_RECS ? WT_RECS : r < 1.0 ? 1u : (uint32_t)r;
         const uint32_t wtiles = (a.n + a.tile_recs - 1) / a.tile_recs;
-        const uint32_t wgs = (wtiles + (WBLOCK / 64) - 1) / (WBLOCK / 64);
-        grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * (uint32_t)WT_WG_PER_CU));
+        // (the kernel variants that serve a sketch run one 16-wave workgroup per CU instead of two 8-wave ones: wtile_block)
+        const bool big_wg = c->cfg.key_sets != FA_KEYS_AS_PAIR;
+        const uint32_t waves = (uint32_t)(big_wg ? 2 * WBLOCK : WBLOCK) / 64u;
+        const uint32_t wgs = (wtiles + waves - 1) / waves;
+        grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * (uint32_t)(big_wg ? 1 : WT_WG_PER_CU)));
         if (a.tile_recs > (uint32_t)WT_RECS) c->use_t8 = false;
     }
     if (scatter) {
         rc = ensure_segments(c, n, (uint32_t)grid, c->use_t8, a);
+        if (rc) return rc;
+    }
+    if (c->use_wave_tiles && (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) && !c->cms_atomic && c->cms_sl2 <= CMS_SLICE_LOG2_MAX) {
+        rc = ensure_csegments(c, n, (uint32_t)grid, a);
         if (rc) return rc;
     }
     if (c->ev_used == c->ev_pool.size()) {

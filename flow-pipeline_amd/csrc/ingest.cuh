@@ -23,7 +23,8 @@ template <int MODE, uint32_t KEYSETS, uint32_t COLS, bool T8 = false, class Hook
 __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, LdsMinutes& lm, uint32_t* part_cnt, const uint32_t* tile,
                                           bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
                                           LaneTally& tally, uint32_t& pmode, uint32_t& lt_seen, uint32_t& lt_hits,
-                                          uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook()) {
+                                          uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook(),
+                                          CmsLds* cl = nullptr, uint32_t* cms_scratch = nullptr) {
     constexpr uint32_t TB = bin_cap<T8>();
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false, framed_ok = false;
@@ -200,19 +201,23 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             uint64_t ws = w;
             bool valid = sure;
             if (bins) wave_fold_lds(const_cast<uint32_t*>(tile), valid, (uint64_t)r.src[1] << 32 | r.src[0], (uint64_t)r.src[3] << 32 | r.src[2], ws);
-            if (valid) {
+            if (cl && a.cseg) {  // scatter sink: no atomics (whole wave: the bin flushes need every lane)
+                cms_scatter(a, *cl, cms_scratch, 0u, valid, r.src, ws);
+            } else if (valid) {
                 cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, ws);
-                keyset_insert(a, a.ks_src, r.src);
             }
+            if (valid) keyset_insert(a, a.ks_src, r.src);
         }
         if (ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS)) {
             uint64_t ws = w;
             bool valid = sure;
             if (bins) wave_fold_lds(const_cast<uint32_t*>(tile), valid, (uint64_t)r.dst[1] << 32 | r.dst[0], (uint64_t)r.dst[3] << 32 | r.dst[2], ws);
-            if (valid) {
+            if (cl && a.cseg) {
+                cms_scatter(a, *cl, cms_scratch, 1u, valid, r.dst, ws);
+            } else if (valid) {
                 cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, ws);
-                keyset_insert(a, a.ks_dst, r.dst);
             }
+            if (valid) keyset_insert(a, a.ks_dst, r.dst);
         }
     }
     if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb);
@@ -514,11 +519,30 @@ __device__ __forceinline__ WTileDesc wtile_desc(const KArgs& a, uint32_t t, uint
     return d;
 }
 
+// LDS of the Count-Min scatter sink: only the kernel variants that serve a sketch carry it
+template <bool ON>
+struct CmsLdsOpt {
+    CmsLds v;
+    __device__ __forceinline__ CmsLds* get() { return &v; }
+};
+template <>
+struct CmsLdsOpt<false> {
+    __device__ __forceinline__ CmsLds* get() { return nullptr; }
+};
+// workgroup size of a variant: the sketch variants need 32 KiB of LDS more per workgroup (CmsLds) than two
+// workgroups per CU leave - they run ONE workgroup of 16 waves per CU (the same 16 waves per CU)
+template <uint32_t KEYSETS>
+constexpr int wtile_block() { return (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) ? 2 * WBLOCK : WBLOCK; }
+
 template <uint32_t KEYSETS, bool T8>
-__global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
+__global__ __launch_bounds__(wtile_block<KEYSETS>()) void wtile_kernel(KArgs a) {
     constexpr uint32_t TB = bin_cap<T8>();
     constexpr uint32_t COLS = cols_for_keysets<KEYSETS>();
+    constexpr int WBLOCK = wtile_block<KEYSETS>();  // (shadows the namespace constant inside this kernel)
+    constexpr bool HAS_CMS = (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) != 0;
     constexpr int WAVES = WBLOCK / 64;
+    __shared__ CmsLdsOpt<HAS_CMS> cms_lds;
+    __shared__ uint32_t cms_scratch_all[HAS_CMS ? WAVES * 16 : 1];
     __shared__ __attribute__((aligned(16))) uint32_t tiles[WAVES * WT_STRIDE / 4];
     __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BIN_LINE];  // 256 x one 128-byte line (8 wide / 16 compact tuples)
     __shared__ uint32_t bin_cnt[NPART_MAX];
@@ -537,6 +561,12 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
         }
     }
     if (KEYSETS & FA_KEYS_MINUTE_SERIES) lds_minutes_clear(lm);
+    CmsLds* const cl = (HAS_CMS && a.cseg) ? cms_lds.get() : nullptr;
+    if (HAS_CMS && cl)
+        for (int i = tid; i < (int)(CMS_SETS * CMS_NPART); i += WBLOCK) {
+            cl->bin_cnt[i] = 0;
+            cl->part_cnt[i] = 0;
+        }
     uint32_t* tile = tiles + wave * (WT_STRIDE / 4);
 
     LaneTally tally;
@@ -611,7 +641,7 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
                 a.exotic_idx[j] = cur.r0 + lane;
             }
             lane_work<MODE_INGEST, KEYSETS, COLS, T8>(a, lt, lm, part_cnt, tb, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, tally,
-                                                      pmode, lt_seen, lt_hits, bins, bin_cnt, fill, after_parse);
+                                                      pmode, lt_seen, lt_hits, bins, bin_cnt, fill, after_parse, cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0));
         }
     };
     // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous
@@ -745,6 +775,25 @@ __global__ __launch_bounds__(WBLOCK) void wtile_kernel(KArgs a) {
             bin_cnt[tid] = 0;
         }
         __syncthreads();
+    }
+    if (HAS_CMS && cl) {  // what is left in the sketch bins (fewer than a chunk each) goes to the back part of the segments
+        __syncthreads();
+        for (uint32_t idx = tid; idx < CMS_SETS * CMS_NPART * CMS_BIN; idx += WBLOCK) {
+            const uint32_t p = idx / CMS_BIN, sl = idx % CMS_BIN;
+            const uint32_t cnt = min(cl->bin_cnt[p] & 0xffffu, CMS_BIN);
+            if (sl < cnt) {
+                const uint32_t ob = (cl->part_cnt[p] >> 16) + sl;
+                const uint2 t = cl->bins[idx];
+                if (ob < a.ccapb) a.cseg[(size_t)p * a.cregion + (size_t)blockIdx.x * a.ccapq + (a.ccapq - 1u - ob)] = t;
+                else cms_atomic_tuple(a, p, t);
+            }
+        }
+        __syncthreads();
+        for (uint32_t p = tid; p < CMS_SETS * CMS_NPART; p += WBLOCK) {
+            const uint32_t w = cl->part_cnt[p] + (min(cl->bin_cnt[p] & 0xffffu, CMS_BIN) << 16);
+            a.cseg_counts[(size_t)p * a.nwg + blockIdx.x] = min((w & 0xffffu) * CMS_BIN, a.ccapf);
+            a.cseg_counts[((size_t)CMS_SETS * CMS_NPART + p) * a.nwg + blockIdx.x] = min(w >> 16, a.ccapb);
+        }
     }
     if (KEYSETS & FA_KEYS_MINUTE_SERIES) {
         __syncthreads();

@@ -135,6 +135,12 @@ struct KArgs {
     unsigned long long region;  // tuples per partition (nwg*capq plus a skew against power-of-two strides)
     uint32_t plog2;        // log2(key partitions)
     uint32_t par;          // batch parity: which copy of the deferral counters this batch uses
+    // Count-Min scatter sink (cseg == nullptr: every sketch update is a memory-side atomic, cms_add)
+    uint2* cseg;            // [CMS_SETS * CMS_NPART][cregion] sketch tuples; partition p, workgroup w: cseg[p*cregion + w*ccapq + q]
+    uint32_t* cseg_counts;  // [2][CMS_SETS * CMS_NPART][nwg]: tuples at the front (whole 64-byte chunks) / at the back of a segment
+    uint32_t ccapq, ccapf, ccapb;
+    unsigned long long cregion;
+    uint32_t cms_sl2;       // log2(counters per sketch partition) <= CMS_SLICE_LOG2_MAX
     // wide key sets (wide.cuh)
     uint32_t key_sets;     // runtime mask (the KS_ALL kernel variant tests it)
     WSlot* wtab;
@@ -202,6 +208,100 @@ __device__ __forceinline__ void cms_add(unsigned long long* cms, uint32_t depth,
         atomicAdd(&copy[((size_t)r << wl2) + (size_t)(h >> (64 - wl2))], (unsigned long long)w);
     }
 }
+// ---- Count-Min scatter sink --------------------------------------------------------------------------
+// Memory-side atomics retire ~23.7 G line transactions/s whatever their scope (tools/atomics_bench.hip): at depth 4
+// and two sketches that is 8 per record - 2.6 G records/s, 2.5 % of the HBM roofline.  The wave-tile kernel therefore
+// treats sketch updates like flows_5m tuples: the counter space of a sketch (depth << width_log2 counters) is cut
+// into CMS_NPART slices; an update leaves the workgroup as an 8-byte tuple {slot in slice : 14, weight : 50} through
+// an LDS bin of its slice (8 tuples = one 64-byte chunk per store) into the workgroup's private segment of the slice,
+// and cms_agg_kernel (agg.cuh) adds each slice up in a dense LDS array and folds it into the sketch with plain
+// coalesced read-modify-writes - no atomics at all.  The sketch itself is unchanged: same hashes, same counters,
+// u64 sums commute, so it stays bit-identical to the CPU sketch.
+// Needs slices of <= 2^14 counters (32 MiB per sketch at the default depth 4 x 2^20) and weights < 2^50; anything
+// else (bigger sketches, deferred records, the workgroup-tile kernel) keeps the atomic path.
+constexpr uint32_t CMS_NPART = 256, CMS_SETS = 2, CMS_BIN = 8, CMS_SLICE_LOG2_MAX = 14;
+struct CmsLds {
+    uint2 bins[CMS_SETS * CMS_NPART * CMS_BIN];  // 32 KiB: one 64-byte chunk per slice
+    uint32_t bin_cnt[CMS_SETS * CMS_NPART];       // low half: slots taken, high half: slots written (like the tuple bins)
+    uint32_t part_cnt[CMS_SETS * CMS_NPART];      // low half: chunks at the front of the segment, high half: tuples at its back
+};
+
+// Full CMS bins leave as whole 64-byte chunks: lane group g (4 lanes) takes the g-th filled bin, each lane copies
+// 16 bytes - up to 16 chunks per store instruction.  Same hand-over protocol as bins_flush.  A chunk that finds the
+// front part of its segment full is added to the sketch with atomics (skewed batches).
+__device__ __forceinline__ void cms_atomic_tuple(const KArgs& a, uint32_t p, const uint2& t) {
+    unsigned long long* sk = (p >> 8) ? a.cms_dst : a.cms_src;
+    const unsigned long long w = ((unsigned long long)t.y << 18) | (t.x >> 14);
+    const size_t c = ((size_t)(p & (CMS_NPART - 1u)) << a.cms_sl2) + (t.x & 0x3fffu);
+    if (w) atomicAdd(&sk[(size_t)(blockIdx.x % CMS_REPLICAS) * ((size_t)a.cms_depth << a.cms_wl2) + c], w);
+}
+__device__ __forceinline__ void cms_bins_flush(const KArgs& a, CmsLds& cl, uint32_t* scratch, uint32_t fill_part) {
+    const unsigned long long fm = __builtin_amdgcn_ballot_w64(fill_part != 0xffffffffu);
+    if (fm == 0ull) return;
+    const uint32_t ln = __lane_id(), g = ln >> 2, sub = ln & 3u;
+    const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << ln) - 1ull));
+    const uint32_t todo = (uint32_t)__builtin_popcountll(fm);
+    const uint4* bins4 = reinterpret_cast<const uint4*>(cl.bins);
+    for (uint32_t base = 0; base < todo; base += 16u) {
+        if (fill_part != 0xffffffffu && rank - base < 16u) scratch[rank - base] = fill_part;
+        const bool act = g < min(16u, todo - base);
+        const uint32_t fp = act ? scratch[g] : 0u;
+        const uint32_t c0 = __hip_atomic_load(&cl.bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint4 tq = bins4[fp * 4u + sub];
+        uint32_t chunk = 0;
+        if (act && sub == 0) chunk = atomicAdd(&cl.part_cnt[fp], 1u) & 0xffffu;
+        bool late = false;
+        if (__builtin_amdgcn_ballot_w64(act && (c0 >> 16) < CMS_BIN) != 0ull) {
+            late = true;
+            while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&cl.bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < CMS_BIN) != 0ull) {}
+        }
+        chunk = (uint32_t)__shfl((int)chunk, (int)(ln & ~3u));
+        if (act) {
+            const uint4 tv = late ? bins4[fp * 4u + sub] : tq;
+            if ((chunk + 1u) * CMS_BIN <= a.ccapf) {
+                // (cregion and ccapq are multiples of 8 tuples: every segment starts on a 64-byte boundary)
+                uint4* dst = reinterpret_cast<uint4*>(a.cseg + (size_t)fp * a.cregion + (size_t)blockIdx.x * a.ccapq + chunk * CMS_BIN);
+                dst[sub] = tv;
+            } else {
+                cms_atomic_tuple(a, fp, make_uint2(tv.x, tv.y));
+                cms_atomic_tuple(a, fp, make_uint2(tv.z, tv.w));
+            }
+            if (sub == 0) __hip_atomic_store(&cl.bin_cnt[fp], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+// One record's updates of one sketch (set = 0 SrcAddr, 1 DstAddr): depth tuples, each through the bin of its slice.
+// valid = false lanes only take part in the flushes (which need the whole wave).  scratch: 64 bytes of wave-private LDS.
+__device__ __forceinline__ void cms_scatter(const KArgs& a, CmsLds& cl, uint32_t* scratch, uint32_t set, bool valid, const uint32_t key[4], uint64_t w) {
+    const uint64_t lo = (uint64_t)key[1] << 32 | key[0], hi = (uint64_t)key[3] << 32 | key[2];
+    const bool big = (w >> 50) != 0;
+    if (valid && big) {  // (never with real Bytes x SamplingRate values)
+        cms_add(set ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, key, w);
+        valid = false;
+    }
+    valid = valid && w != 0;
+    for (uint32_t r = 0; r < a.cms_depth; r++) {
+        uint32_t fill = 0xffffffffu;
+        if (valid) {
+            const uint64_t h = cms_hash(lo, hi, a.cms_seed, r);
+            const uint32_t c = (r << a.cms_wl2) + (uint32_t)(h >> (64 - a.cms_wl2));
+            const uint32_t p = set * CMS_NPART + (c >> a.cms_sl2);
+            const uint2 t = make_uint2((c & ((1u << a.cms_sl2) - 1u)) | ((uint32_t)w << 14), (uint32_t)(w >> 18));
+            const uint32_t slot = __hip_atomic_fetch_add(&cl.bin_cnt[p], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;
+            if (slot < CMS_BIN) {
+                cl.bins[p * CMS_BIN + slot] = t;
+                __hip_atomic_fetch_add(&cl.bin_cnt[p], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                fill = slot == CMS_BIN - 1 ? p : fill;
+            } else {  // the bin is on its way out: single store to the back part of the segment
+                const uint32_t ob = atomicAdd(&cl.part_cnt[p], 0x10000u) >> 16;
+                if (ob < a.ccapb) a.cseg[(size_t)p * a.cregion + (size_t)blockIdx.x * a.ccapq + (a.ccapq - 1u - ob)] = t;
+                else cms_atomic_tuple(a, p, t);
+            }
+        }
+        cms_bins_flush(a, cl, scratch, fill);
+    }
+}
+
 __global__ void cms_fold_kernel(unsigned long long* cms, size_t words) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) {
         unsigned long long sum = 0;

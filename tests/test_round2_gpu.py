@@ -222,6 +222,45 @@ def test_all_distinct_groups_into_a_tiny_table_lose_nothing(gpu_lib, fa, po, syn
     assert _checksum(rows) == want["checksum"]
 
 
+@pytest.mark.parametrize("path", ["scatter", "atomic"])
+@pytest.mark.parametrize("depth,wl2", [(4, 20), (4, 14), (3, 12), (5, 20)])
+def test_count_min_scatter_sink_is_bit_exact(gpu_lib, fa, po, monkeypatch, path, depth, wl2):
+    """Both sketches through the scatter sink (tuples -> LDS bins -> cms_agg_kernel, no atomics) and through the
+    memory-side atomics, at the default 32 MiB geometry, small sketches, a depth that is no power of two and one whose
+    slices exceed the LDS array (5 x 2^20: atomics again): always the CPU sketch, counter for counter.  Heavy hitters
+    (Zipf 1.1: one address carries 8 %% of the records) overflow their slices' segments into the atomic fallback."""
+    import torch
+    if path == "atomic":
+        monkeypatch.setenv("FA_CMS", "atomic")
+    else:
+        monkeypatch.delenv("FA_CMS", raising=False)
+    n = 2_000_000
+    gp = po.gen_params(mode=2, framed=1, seed=33, n_total=n, zipf_log2_universe=18, zipf_s_x100=110)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    assert status.sum() == 0
+    with np.errstate(over="ignore"):
+        w = rows["bytes"] * rows["sampling_rate"]
+    seed = 0xC0FFEE
+    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=20,
+                    max_batch_records=n) as agg:
+        d_buf, d_off, wb = _device_batch(fa, agg, 2, 33, n, zipf_log2_universe=18, zipf_s_x100=110)
+        assert wb == len(buf)
+        agg.ingest_device(d_buf.data_ptr(), wb, d_off.data_ptr(), n)
+        agg.ingest_device(d_buf.data_ptr(), wb, d_off.data_ptr(), n)
+        for col, key_set in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+            want = po.cms_sketch_numpy(rows[col], w, depth, wl2, seed) * np.uint64(2)
+            assert np.array_equal(agg.cms_read(key_set).reshape(-1), want), col
+        ref = po.Rollup(300)
+        ref.ingest(buf, off, 1)
+        got = agg.read_window()
+        st = agg.stats()
+    want_rows = ref.rows()
+    for c in ("bytes", "packets", "count"):
+        want_rows[c] *= np.uint64(2)
+    assert got.tobytes() == want_rows.tobytes() and st["wave_tile_launches"] == 2
+
+
 RCCL_WORKER = r'''
 import ctypes as C, os, sys
 sys.path.insert(0, %(root)r)
