@@ -566,13 +566,31 @@ __global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t se
         blv[g] = (uint16_t)(m ? (m / 2u + 1u + 7u) >> 3 : 0u);
     }
     __syncthreads();
+    // A heavy hitter sends one tuple per wave-tile to each of its counters: in the slices of such counters a good part
+    // of every 64 consecutive tuples carries the SAME slot, and an LDS atomic serializes the lanes that share an
+    // address.  So the lanes of a load are folded first when many of them agree with the first or the last lane's slot
+    // (two cheap wave-uniform probes): one lane adds the wave's sum.
     auto consume = [&](const Agg8Batch& b) {
 #pragma unroll
         for (int e = 0; e < AGG8_NT; e++) {
             const uint4& q = b.t[e >> 1];
             const uint32_t x = (e & 1) ? q.z : q.x, y = (e & 1) ? q.w : q.y;
-            const unsigned long long w = ((unsigned long long)y << 18) | (x >> 14);
-            if (((b.v >> e) & 1u) && w) atomicAdd(&arr[x & 0x3fffu], w);
+            unsigned long long w = ((unsigned long long)y << 18) | (x >> 14);
+            const uint32_t slot = x & 0x3fffu;
+            bool v = ((b.v >> e) & 1u) && w;
+#pragma unroll
+            for (int round = 0; round < 2; round++) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
+                if (m == 0ull) break;
+                const int leader = round == 0 ? __builtin_ctzll(m) : 63 - __builtin_clzll(m);
+                const uint32_t ls = (uint32_t)__builtin_amdgcn_readlane((int)slot, leader);
+                const bool same = v && slot == ls;
+                if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(same)) < 8) continue;
+                const unsigned long long sum = wave_sum_u64(same ? w : 0ull);
+                if ((int)lane == leader) atomicAdd(&arr[ls], sum);
+                v = v && !same;
+            }
+            if (v) atomicAdd(&arr[slot], w);
         }
     };
 #define FA_CMS_PASS(BACK, LV, NG, GSEGS, PCNT)                                                            \

@@ -1914,8 +1914,7 @@ static uint64_t cms_hash_host(const uint8_t key[16], uint64_t seed, uint32_t row
     uint64_t lo, hi;
     memcpy(&lo, key, 8);
     memcpy(&hi, key + 8, 8);
-    uint64_t h = mix64(lo ^ mix64(seed + 0x9E3779B97F4A7C15ull * (row + 1)));
-    return mix64(h ^ hi);
+    return cms_hash(lo, hi, seed, row);  // (sinks.cuh: the one definition, host and device)
 }
 
 extern "C" int fa_cms_query(fa_ctx* c, uint32_t key_set, const uint8_t key[16], uint64_t* weight) {

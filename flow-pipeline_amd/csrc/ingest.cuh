@@ -195,30 +195,35 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     }
     if (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
         // lanes of a wave that carry the same address (heavy hitters) are folded first: one sketch update and
-        // one distinct-set probe per address and wave (wave-tile kernel: its parsed tile buffer is the scratch)
+        // one distinct-set probe per address and wave (wave-tile kernel: its parsed tile buffer is the scratch).
+        // Order of work: fold both addresses, hash them, ISSUE the distinct-set probes of both (global loads), then
+        // the sketch updates (LDS work that hides the probes' latency), then look at what the probes returned.
         const uint64_t w = r.bytes * r.sampling_rate;  // viz-ch.json:233 sum(Bytes*SamplingRate), UInt64 wrap
-        if (ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS)) {
-            uint64_t ws = w;
-            bool valid = sure;
-            if (bins) wave_fold_lds(const_cast<uint32_t*>(tile), valid, (uint64_t)r.src[1] << 32 | r.src[0], (uint64_t)r.src[3] << 32 | r.src[2], ws);
+        const bool on_s = ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS), on_d = ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS);
+        const uint64_t slo = (uint64_t)r.src[1] << 32 | r.src[0], shi = (uint64_t)r.src[3] << 32 | r.src[2];
+        const uint64_t dlo = (uint64_t)r.dst[1] << 32 | r.dst[0], dhi = (uint64_t)r.dst[3] << 32 | r.dst[2];
+        uint64_t ws = w, wd = w;
+        bool vs = sure && on_s, vd = sure && on_d;
+        if (bins && on_s) wave_fold_lds(const_cast<uint32_t*>(tile), vs, slo, shi, ws);
+        if (bins && on_d) wave_fold_lds(const_cast<uint32_t*>(tile), vd, dlo, dhi, wd);
+        uint64_t sh1 = 0, sh2 = 0, dh1 = 0, dh2 = 0;
+        if (on_s) cms_hash2(slo, shi, a.cms_seed, sh1, sh2);
+        if (on_d) cms_hash2(dlo, dhi, a.cms_seed, dh1, dh2);
+        const bool keys_on = !(a.dbg & DBG_NO_KEYSET);
+        KsProbe ps{}, pd{};
+        if (vs && keys_on) ps = keyset_probe(a, a.ks_src, sh1);
+        if (vd && keys_on) pd = keyset_probe(a, a.ks_dst, dh1);
+        if (!(a.dbg & DBG_NO_CMS)) {
             if (cl && a.cseg) {  // scatter sink: no atomics (whole wave: the bin flushes need every lane)
-                cms_scatter(a, *cl, cms_scratch, 0u, valid, r.src, ws);
-            } else if (valid) {
-                cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, ws);
+                if (on_s) cms_scatter(a, *cl, cms_scratch, 0u, vs, r.src, ws, sh1, sh2);
+                if (on_d) cms_scatter(a, *cl, cms_scratch, 1u, vd, r.dst, wd, dh1, dh2);
+            } else {
+                if (vs) cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, ws);
+                if (vd) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, wd);
             }
-            if (valid) keyset_insert(a, a.ks_src, r.src);
         }
-        if (ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS)) {
-            uint64_t ws = w;
-            bool valid = sure;
-            if (bins) wave_fold_lds(const_cast<uint32_t*>(tile), valid, (uint64_t)r.dst[1] << 32 | r.dst[0], (uint64_t)r.dst[3] << 32 | r.dst[2], ws);
-            if (cl && a.cseg) {
-                cms_scatter(a, *cl, cms_scratch, 1u, valid, r.dst, ws);
-            } else if (valid) {
-                cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, ws);
-            }
-            if (valid) keyset_insert(a, a.ks_dst, r.dst);
-        }
+        if (vs && keys_on) keyset_finish(a, a.ks_src, ps, slo, shi);
+        if (vd && keys_on) keyset_finish(a, a.ks_dst, pd, dlo, dhi);
     }
     if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb);
 }

@@ -132,8 +132,10 @@ __global__ void topk_rows_kernel(const KeySlot* ks, uint32_t nslots, const unsig
         if ((ks[i].tag & KS_READY) == 0) continue;
         const unsigned long long lo = ks[i].lo, hi = ks[i].hi;
         unsigned long long best = ~0ull;
-        for (uint32_t r = 0; r < depth; r++) {
-            const unsigned long long v = cms[((size_t)r << wl2) + (size_t)(cms_hash(lo, hi, seed, r) >> (64 - wl2))];
+        uint64_t h, h2;
+        cms_hash2(lo, hi, seed, h, h2);
+        for (uint32_t r = 0; r < depth; r++, h += h2) {
+            const unsigned long long v = cms[((size_t)r << wl2) + (size_t)(h >> (64 - wl2))];
             best = v < best ? v : best;
         }
         const unsigned int j = atomicAdd(&ctr->ks_rows, 1u);

@@ -63,7 +63,7 @@ constexpr uint32_t FA_KEYS_WIDE = FA_KEYS_ADDR_PORT_PROTO | FA_KEYS_PORT_HIST | 
 constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense histograms
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
-       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072 };
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072, DBG_NO_KEYSET = 262144, DBG_NO_CMS = 524288 };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -188,9 +188,19 @@ __device__ __forceinline__ void agg_global(const KArgs& a, uint64_t k0, uint64_t
     }
 }
 
-__device__ __forceinline__ uint64_t cms_hash(uint64_t lo, uint64_t hi, uint64_t seed, uint32_t row) {
-    uint64_t h = mix64(lo ^ mix64(seed + 0x9E3779B97F4A7C15ull * (row + 1)));
-    return mix64(h ^ hi);
+// Row hashes of the sketch by double hashing (Kirsch & Mitzenmacher): two 64-bit hashes per key, row r uses
+// h1 + r * h2 - two mix64 per key instead of two per key AND row (at depth 4 and two sketches the per-row hashing
+// alone cost more issue slots than the whole protobuf parse).  column(r) = (h1 + r * h2) >> (64 - width_log2).
+// The CPU sketches of the test infrastructure (C and numpy) use the same definition (DESIGN.md "Sketch").
+__host__ __device__ __forceinline__ void cms_hash2(uint64_t lo, uint64_t hi, uint64_t seed, uint64_t& h1, uint64_t& h2) {
+    const uint64_t a = mix64(lo ^ mix64(seed + 0x9E3779B97F4A7C15ull));
+    h1 = mix64(a ^ hi);
+    h2 = a | 1ull;
+}
+__host__ __device__ __forceinline__ uint64_t cms_hash(uint64_t lo, uint64_t hi, uint64_t seed, uint32_t row) {
+    uint64_t h1, h2;
+    cms_hash2(lo, hi, seed, h1, h2);
+    return h1 + (uint64_t)row * h2;
 }
 // The sketch is kept in CMS_REPLICAS copies; a workgroup adds to copy blockIdx % CMS_REPLICAS and the copies
 // are summed into copy 0 before anything reads the sketch (cms_fold_kernel).  Counters of heavy hitters are
@@ -203,10 +213,10 @@ __device__ __forceinline__ void cms_add(unsigned long long* cms, uint32_t depth,
     if (w == 0) return;
     uint64_t lo = (uint64_t)key[1] << 32 | key[0], hi = (uint64_t)key[3] << 32 | key[2];
     unsigned long long* copy = cms + (size_t)(blockIdx.x % CMS_REPLICAS) * ((size_t)depth << wl2);
-    for (uint32_t r = 0; r < depth; r++) {
-        uint64_t h = cms_hash(lo, hi, seed, r);
+    uint64_t h, h2;
+    cms_hash2(lo, hi, seed, h, h2);
+    for (uint32_t r = 0; r < depth; r++, h += h2)
         atomicAdd(&copy[((size_t)r << wl2) + (size_t)(h >> (64 - wl2))], (unsigned long long)w);
-    }
 }
 // ---- Count-Min scatter sink --------------------------------------------------------------------------
 // Memory-side atomics retire ~23.7 G line transactions/s whatever their scope (tools/atomics_bench.hip): at depth 4
@@ -272,18 +282,17 @@ __device__ __forceinline__ void cms_bins_flush(const KArgs& a, CmsLds& cl, uint3
 }
 // One record's updates of one sketch (set = 0 SrcAddr, 1 DstAddr): depth tuples, each through the bin of its slice.
 // valid = false lanes only take part in the flushes (which need the whole wave).  scratch: 64 bytes of wave-private LDS.
-__device__ __forceinline__ void cms_scatter(const KArgs& a, CmsLds& cl, uint32_t* scratch, uint32_t set, bool valid, const uint32_t key[4], uint64_t w) {
-    const uint64_t lo = (uint64_t)key[1] << 32 | key[0], hi = (uint64_t)key[3] << 32 | key[2];
+__device__ __forceinline__ void cms_scatter(const KArgs& a, CmsLds& cl, uint32_t* scratch, uint32_t set, bool valid, const uint32_t key[4], uint64_t w,
+                                            uint64_t h, uint64_t h2) {
     const bool big = (w >> 50) != 0;
     if (valid && big) {  // (never with real Bytes x SamplingRate values)
         cms_add(set ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, key, w);
         valid = false;
     }
     valid = valid && w != 0;
-    for (uint32_t r = 0; r < a.cms_depth; r++) {
+    for (uint32_t r = 0; r < a.cms_depth; r++, h += h2) {
         uint32_t fill = 0xffffffffu;
         if (valid) {
-            const uint64_t h = cms_hash(lo, hi, a.cms_seed, r);
             const uint32_t c = (r << a.cms_wl2) + (uint32_t)(h >> (64 - a.cms_wl2));
             const uint32_t p = set * CMS_NPART + (c >> a.cms_sl2);
             const uint2 t = make_uint2((c & ((1u << a.cms_sl2) - 1u)) | ((uint32_t)w << 14), (uint32_t)(w >> 18));
@@ -357,20 +366,26 @@ __device__ __forceinline__ void wave_fold_lds(uint32_t* scratch, bool& valid, ui
 // not written yet cannot compare and moves on, so a key may (rarely) be stored twice - fa_topk removes
 // duplicates.  The set is exact in content: a key is dropped only when the table is full, and that is
 // reported (ks_overflow -> FA_ERR_TABLE_FULL).
-__device__ __forceinline__ void keyset_insert(const KArgs& a, KeySlot* tab, const uint32_t key[4]) {
-    const unsigned long long lo = (unsigned long long)key[1] << 32 | key[0], hi = (unsigned long long)key[3] << 32 | key[2];
-    uint32_t h = key[0] * 0x9E3779B1u + key[1];
-    h ^= h >> 15;
-    h = (h ^ key[2]) * 0x85EBCA6Bu + key[3];
-    h ^= h >> 13;
-    h *= 0xC2B2AE35u;
-    h ^= h >> 16;
-    uint32_t g = (key[3] ^ 0x27D4EB2Fu) * 0x165667B1u + key[2];
-    g ^= g >> 15;
-    g = (g ^ key[1]) * 0xD3A2646Du + key[0];
-    g ^= g >> 14;
-    const unsigned long long mytag = KS_CLAIMED | (((unsigned long long)g << 32 | h) & (KS_READY - 1));
-    uint32_t i = h & a.ks_mask;
+// Hash of the set: the sketch's first hash of the key (cms_hash2) - the ingest kernel has it already.  Slot index =
+// its high half, tag = its low 62 bits.
+struct KsProbe {
+    KeySlot* s;                 // home slot
+    ulonglong2 c01;             // its tag and low key word as a plain (cached, possibly stale) load saw them
+    unsigned long long chi;     // ... and its high key word
+    unsigned long long mytag;
+    uint32_t i;
+};
+// issue the home-slot loads of a key (nothing waits here: the caller does other work before keyset_finish)
+__device__ __forceinline__ KsProbe keyset_probe(const KArgs& a, KeySlot* tab, uint64_t h1) {
+    KsProbe p;
+    p.mytag = KS_CLAIMED | (h1 & (KS_READY - 1));
+    p.i = (uint32_t)(h1 >> 32) & a.ks_mask;
+    p.s = &tab[p.i];
+    p.c01 = *reinterpret_cast<const ulonglong2*>(&p.s->tag);
+    p.chi = p.s->hi;
+    return p;
+}
+__device__ __noinline__ void keyset_insert_slow(const KArgs& a, KeySlot* tab, unsigned long long lo, unsigned long long hi, unsigned long long mytag, uint32_t i) {
     for (int probe = 0; probe < 256; probe++, i = (i + 1) & a.ks_mask) {
         KeySlot* s = &tab[i];
         // fastest path: the key is already there and this XCD's L2 knows it.  Plain (cached) loads may be stale,
@@ -410,6 +425,19 @@ __device__ __forceinline__ void keyset_insert(const KArgs& a, KeySlot* tab, cons
         if (done) return;
     }
     atomicAdd(&a.ctr->ks_overflow, 1u);
+}
+// the common case - the key sits in its home slot - costs the two loads keyset_probe issued; everything else
+// (other slot, first occurrence) takes the probing path
+__device__ __forceinline__ void keyset_finish(const KArgs& a, KeySlot* tab, const KsProbe& p, unsigned long long lo, unsigned long long hi) {
+    if (p.c01.x == (p.mytag | KS_READY) && p.c01.y == lo && p.chi == hi) return;
+    keyset_insert_slow(a, tab, lo, hi, p.mytag, p.i);
+}
+__device__ __forceinline__ void keyset_insert(const KArgs& a, KeySlot* tab, const uint32_t key[4]) {
+    const unsigned long long lo = (unsigned long long)key[1] << 32 | key[0], hi = (unsigned long long)key[3] << 32 | key[2];
+    uint64_t h1, h2;
+    cms_hash2(lo, hi, a.cms_seed, h1, h2);
+    const KsProbe p = keyset_probe(a, tab, h1);
+    keyset_finish(a, tab, p, lo, hi);
 }
 
 __device__ __forceinline__ void store_columns(const ColumnPtrs& c, uint32_t idx, const Rec& r,

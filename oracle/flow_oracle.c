@@ -361,9 +361,10 @@ uint64_t fo_hash_key16(const uint8_t key[16], uint64_t seed, uint32_t row) {
     uint64_t lo, hi;
     memcpy(&lo, key, 8);
     memcpy(&hi, key + 8, 8);
-    uint64_t h = mix64(lo ^ mix64(seed + 0x9E3779B97F4A7C15ull * (row + 1)));
-    h = mix64(h ^ hi);
-    return h;
+    /* double hashing (Kirsch & Mitzenmacher): row r = h1 + r * h2 (DESIGN.md "Sketch") */
+    const uint64_t a = mix64(lo ^ mix64(seed + 0x9E3779B97F4A7C15ull));
+    const uint64_t h1 = mix64(a ^ hi), h2 = a | 1ull;
+    return h1 + (uint64_t)row * h2;
 }
 void fo_cms_update(uint64_t* cms, uint32_t depth, uint32_t wl2, uint64_t seed, const uint8_t key[16],
                    uint64_t w) {

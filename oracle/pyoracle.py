@@ -307,9 +307,12 @@ def cms_sketch_numpy(keys16: np.ndarray, weights: np.ndarray, depth: int, width_
     w = np.ascontiguousarray(weights, dtype=np.uint64)
     out = np.zeros(depth << width_log2, dtype=np.uint64)
     with np.errstate(over="ignore"):
+        s0 = mix64(np.array([(seed + 0x9E3779B97F4A7C15) & (2**64 - 1)], dtype=np.uint64))[0]
+        a = mix64(lo ^ s0)
+        h = mix64(a ^ hi)          # h1; row r uses h1 + r * h2 with h2 = a | 1 (double hashing)
+        h2 = a | np.uint64(1)
         for r in range(depth):
-            s = mix64(np.array([(seed + 0x9E3779B97F4A7C15 * (r + 1)) & (2**64 - 1)], dtype=np.uint64))[0]
-            h = mix64(mix64(lo ^ s) ^ hi)
             idx = (h >> np.uint64(64 - width_log2)).astype(np.int64) + (r << width_log2)
             np.add.at(out, idx, w)
+            h = h + h2
     return out
