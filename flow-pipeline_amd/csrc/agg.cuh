@@ -344,23 +344,32 @@ __device__ __forceinline__ void agg8_tuple(const KArgs& a, Agg8Table& lt, uint32
     agg8_global(a, tb_base, part, t, by, pk);  // the table is full around this key
 }
 
-constexpr int AGG8_SU = 2;                 // 16-byte loads per lane and batch = 4 tuples
+#ifndef FA_AGG8_SU
+#define FA_AGG8_SU 2
+#endif
+#ifndef FA_CMS_SU
+#define FA_CMS_SU 8
+#endif
+constexpr int AGG8_SU = FA_AGG8_SU;        // 16-byte loads per lane and batch (x 2 tuples)
 constexpr int AGG8_NT = AGG8_SU * 2;
-struct Agg8Batch {
-    uint4 t[AGG8_SU];
+constexpr int CMS_SU = FA_CMS_SU;          // cms_agg_kernel: more bytes in flight per wave (it is pure streaming + LDS adds, registers to spare)
+template <int SU>
+struct Agg8BatchT {
+    uint4 t[SU];
     uint32_t v;  // bit e: tuple e of this lane is real (e >> 1 = load, e & 1 = half)
 };
+typedef Agg8BatchT<AGG8_SU> Agg8Batch;
 // Loads of one work item.  Front: pieces [64j, 64j+64) of segment w0 + s, one segment per load.  Back: pieces
 // [8j, 8j+8) of the c tuples that end at the segment's last slot, eight segments per load (lane / 8).  Unconditional
 // (clamped addresses, zero counts past the end: see agg_fetch).
-template <bool BACK>
+template <bool BACK, int SU>
 __device__ __forceinline__ void agg8_fetch(uint32_t capq, uint32_t nwg, const uint4* pbase, const uint32_t* pc, uint32_t w0, uint32_t lane, uint32_t j,
-                                           Agg8Batch& b) {
+                                           Agg8BatchT<SU>& b) {
     constexpr uint32_t SEGS = BACK ? 8u : 1u, PER = 64u / SEGS;
-    uint32_t idx[AGG8_SU], seg[AGG8_SU];
+    uint32_t idx[SU], seg[SU];
     b.v = 0;
 #pragma unroll
-    for (int s = 0; s < AGG8_SU; s++) {
+    for (int s = 0; s < SU; s++) {
         seg[s] = w0 + (uint32_t)s * SEGS + (BACK ? lane / PER : 0u);
         const uint32_t c = pc[min(seg[s], (uint32_t)(AGG_MAX_NWG + AGG_PAD - 1))];
         const uint32_t first = BACK ? capq - c : 0u;
@@ -371,7 +380,7 @@ __device__ __forceinline__ void agg8_fetch(uint32_t capq, uint32_t nwg, const ui
         idx[s] = valid ? piece : 0u;
     }
 #pragma unroll
-    for (int s = 0; s < AGG8_SU; s++) b.t[s] = pbase[(size_t)min(seg[s], nwg - 1u) * (capq / 2u) + idx[s]];
+    for (int s = 0; s < SU; s++) b.t[s] = pbase[(size_t)min(seg[s], nwg - 1u) * (capq / 2u) + idx[s]];
 }
 __device__ __forceinline__ void agg8_drain(const KArgs& a, Agg8Table& lt, uint32_t tb_base, uint32_t part, uint32_t lane, const uint2* queue, uint32_t qn) {
     if (lane < qn) agg8_tuple(a, lt, tb_base, part, queue[lane]);
@@ -478,16 +487,16 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
         };                                                                                                  \
         settle_item();                                                                                      \
         Agg8Batch b0, b1;                                                                                   \
-        agg8_fetch<BACK>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                                          \
+        agg8_fetch<BACK, AGG8_SU>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                                          \
         while (g < ngroups) {                                                                               \
             j++;                                                                                            \
             settle_item();                                                                                  \
-            agg8_fetch<BACK>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b1);                                      \
+            agg8_fetch<BACK, AGG8_SU>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b1);                                      \
             agg8_consume(a, lt, tb_base, part, lane, b0, queue, qn);                                        \
             if (g >= ngroups) break;                                                                        \
             j++;                                                                                            \
             settle_item();                                                                                  \
-            agg8_fetch<BACK>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                                      \
+            agg8_fetch<BACK, AGG8_SU>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                                      \
             agg8_consume(a, lt, tb_base, part, lane, b1, queue, qn);                                        \
         }                                                                                                   \
     }
@@ -538,7 +547,8 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
 // kernels).  Same segment geometry and walk as agg8_kernel.
 __global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t set_mask) {
     constexpr uint32_t WAVES = AGG_BLOCK / 64;
-    constexpr uint32_t FGRP = AGG8_SU, BGRP = AGG8_SU * 8;
+    constexpr uint32_t FGRP = CMS_SU, BGRP = CMS_SU * 8;
+    typedef Agg8BatchT<CMS_SU> Batch;
     constexpr uint32_t NFG = (AGG_MAX_NWG + AGG_PAD) / FGRP, NBG = (AGG_MAX_NWG + AGG_PAD) / BGRP;
     __shared__ unsigned long long arr[1u << CMS_SLICE_LOG2_MAX];  // 128 KiB
     __shared__ uint32_t pc[AGG_MAX_NWG + AGG_PAD], pcb[AGG_MAX_NWG + AGG_PAD];
@@ -570,9 +580,9 @@ __global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t se
     // of every 64 consecutive tuples carries the SAME slot, and an LDS atomic serializes the lanes that share an
     // address.  So the lanes of a load are folded first when many of them agree with the first or the last lane's slot
     // (two cheap wave-uniform probes): one lane adds the wave's sum.
-    auto consume = [&](const Agg8Batch& b) {
+    auto consume = [&](const Batch& b) {
 #pragma unroll
-        for (int e = 0; e < AGG8_NT; e++) {
+        for (int e = 0; e < CMS_SU * 2; e++) {
             const uint4& q = b.t[e >> 1];
             const uint32_t x = (e & 1) ? q.z : q.x, y = (e & 1) ? q.w : q.y;
             unsigned long long w = ((unsigned long long)y << 18) | (x >> 14);
@@ -604,17 +614,17 @@ __global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t se
             }                                                                                               \
         };                                                                                                  \
         settle_item();                                                                                      \
-        Agg8Batch b0, b1;                                                                                   \
-        agg8_fetch<BACK>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                             \
+        Batch b0, b1;                                                                                       \
+        agg8_fetch<BACK, CMS_SU>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                             \
         while (g < ngroups) {                                                                               \
             j++;                                                                                            \
             settle_item();                                                                                  \
-            agg8_fetch<BACK>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b1);                         \
+            agg8_fetch<BACK, CMS_SU>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b1);                         \
             consume(b0);                                                                                    \
             if (g >= ngroups) break;                                                                        \
             j++;                                                                                            \
             settle_item();                                                                                  \
-            agg8_fetch<BACK>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                         \
+            agg8_fetch<BACK, CMS_SU>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                         \
             consume(b1);                                                                                    \
         }                                                                                                   \
     }

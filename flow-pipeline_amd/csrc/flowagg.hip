@@ -907,11 +907,12 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         double avg = (double)len / (double)n + 0.5;
         // (a tile that does not fit its buffer goes to the deferred parsers as a whole, so leave ~4 sigma of
         // headroom for a mix of 60- and 84-byte records when the buffer is tight)
-        double r = ((double)WT_STRIDE - 16.0 - 15.0 - 12.0 * 8.0 * 4.0) / avg;
+        // (the kernel variants that serve a sketch run one 16-wave workgroup per CU instead of two 8-wave ones, with
+        // slightly shorter tile buffers: wtile_block, wtile_stride)
+        const bool big_wg = c->cfg.key_sets != FA_KEYS_AS_PAIR;
+        double r = ((double)(big_wg ? WT_STRIDE_CMS : WT_STRIDE) - 16.0 - 15.0 - 12.0 * 8.0 * 4.0) / avg;
         a.tile_recs = r >= (double)WT_RECS ? WT_RECS : r < 1.0 ? 1u : (uint32_t)r;
         const uint32_t wtiles = (a.n + a.tile_recs - 1) / a.tile_recs;
-        // (the kernel variants that serve a sketch run one 16-wave workgroup per CU instead of two 8-wave ones: wtile_block)
-        const bool big_wg = c->cfg.key_sets != FA_KEYS_AS_PAIR;
         const uint32_t waves = (uint32_t)(big_wg ? 2 * WBLOCK : WBLOCK) / 64u;
         const uint32_t wgs = (wtiles + waves - 1) / waves;
         grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * (uint32_t)(big_wg ? 1 : WT_WG_PER_CU)));

@@ -24,7 +24,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                                           bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
                                           LaneTally& tally, uint32_t& pmode, uint32_t& lt_seen, uint32_t& lt_hits,
                                           uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook(),
-                                          CmsLds* cl = nullptr, uint32_t* cms_scratch = nullptr) {
+                                          CmsLds* cl = nullptr, uint32_t* cms_scratch = nullptr, HotAddrs* hot = nullptr) {
     constexpr uint32_t TB = bin_cap<T8>();
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false, framed_ok = false;
@@ -209,14 +209,20 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         uint64_t sh1 = 0, sh2 = 0, dh1 = 0, dh2 = 0;
         if (on_s) cms_hash2(slo, shi, a.cms_seed, sh1, sh2);
         if (on_d) cms_hash2(dlo, dhi, a.cms_seed, dh1, dh2);
+        if (hot && !(a.dbg & DBG_NO_HOT)) {  // heavy hitters: one LDS add, nothing else (an address may move in once a wave has seen it twice)
+            if (vs && hot_add(*hot, 0u, slo, shi, sh1, ws, ws != w)) vs = false;
+            if (vd && hot_add(*hot, 1u, dlo, dhi, dh1, wd, wd != w)) vd = false;
+        }
         const bool keys_on = !(a.dbg & DBG_NO_KEYSET);
         KsProbe ps{}, pd{};
         if (vs && keys_on) ps = keyset_probe(a, a.ks_src, sh1);
         if (vd && keys_on) pd = keyset_probe(a, a.ks_dst, dh1);
         if (!(a.dbg & DBG_NO_CMS)) {
             if (cl && a.cseg) {  // scatter sink: no atomics (whole wave: the bin flushes need every lane)
-                if (on_s) cms_scatter(a, *cl, cms_scratch, 0u, vs, r.src, ws, sh1, sh2);
-                if (on_d) cms_scatter(a, *cl, cms_scratch, 1u, vd, r.dst, wd, dh1, dh2);
+                // (bin lists: the wave's tile buffer is dead by now - behind the 768 bytes the folds used)
+                uint32_t* list = const_cast<uint32_t*>(tile) + 256;
+                if (on_s) cms_scatter(a, *cl, list, 0u, vs, r.src, ws, sh1, sh2);
+                if (on_d) cms_scatter(a, *cl, list, 1u, vd, r.dst, wd, dh1, dh2);
             } else {
                 if (vs) cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, ws);
                 if (vd) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, wd);
@@ -538,6 +544,19 @@ struct CmsLdsOpt<false> {
 // workgroups per CU leave - they run ONE workgroup of 16 waves per CU (the same 16 waves per CU)
 template <uint32_t KEYSETS>
 constexpr int wtile_block() { return (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) ? 2 * WBLOCK : WBLOCK; }
+// ... and their tile buffers are 256 bytes shorter (62 instead of 64 mocker-sized records; the LDS goes to the sketch
+// bins and the hot-address cache - the whole 160 KiB of the CU are spoken for)
+template <uint32_t KEYSETS>
+constexpr int wtile_stride() { return (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) ? WT_STRIDE_CMS : WT_STRIDE; }
+template <bool ON>
+struct HotAddrsOpt {
+    HotAddrs v;
+    __device__ __forceinline__ HotAddrs* get() { return &v; }
+};
+template <>
+struct HotAddrsOpt<false> {
+    __device__ __forceinline__ HotAddrs* get() { return nullptr; }
+};
 
 template <uint32_t KEYSETS, bool T8>
 __global__ __launch_bounds__(wtile_block<KEYSETS>()) void wtile_kernel(KArgs a) {
@@ -546,7 +565,9 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>()) void wtile_kernel(KArgs a) 
     constexpr int WBLOCK = wtile_block<KEYSETS>();  // (shadows the namespace constant inside this kernel)
     constexpr bool HAS_CMS = (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) != 0;
     constexpr int WAVES = WBLOCK / 64;
+    constexpr int WT_STRIDE = wtile_stride<KEYSETS>();  // (shadows the namespace constant inside this kernel)
     __shared__ CmsLdsOpt<HAS_CMS> cms_lds;
+    __shared__ HotAddrsOpt<HAS_CMS> hot_lds;
     __shared__ uint32_t cms_scratch_all[HAS_CMS ? WAVES * 16 : 1];
     __shared__ __attribute__((aligned(16))) uint32_t tiles[WAVES * WT_STRIDE / 4];
     __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BIN_LINE];  // 256 x one 128-byte line (8 wide / 16 compact tuples)
@@ -567,11 +588,14 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>()) void wtile_kernel(KArgs a) 
     }
     if (KEYSETS & FA_KEYS_MINUTE_SERIES) lds_minutes_clear(lm);
     CmsLds* const cl = (HAS_CMS && a.cseg) ? cms_lds.get() : nullptr;
+    HotAddrs* const hot = (HAS_CMS && (a.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) ? hot_lds.get() : nullptr;
     if (HAS_CMS && cl)
         for (int i = tid; i < (int)(CMS_SETS * CMS_NPART); i += WBLOCK) {
             cl->bin_cnt[i] = 0;
             cl->part_cnt[i] = 0;
         }
+    if (HAS_CMS && hot)
+        for (int i = tid; i < (int)(CMS_SETS * HOT_SLOTS); i += WBLOCK) hot->tag[i / HOT_SLOTS][i % HOT_SLOTS] = 0;
     uint32_t* tile = tiles + wave * (WT_STRIDE / 4);
 
     LaneTally tally;
@@ -646,7 +670,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>()) void wtile_kernel(KArgs a) 
                 a.exotic_idx[j] = cur.r0 + lane;
             }
             lane_work<MODE_INGEST, KEYSETS, COLS, T8>(a, lt, lm, part_cnt, tb, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, tally,
-                                                      pmode, lt_seen, lt_hits, bins, bin_cnt, fill, after_parse, cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0));
+                                                      pmode, lt_seen, lt_hits, bins, bin_cnt, fill, after_parse, cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0), hot);
         }
     };
     // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous
@@ -780,6 +804,18 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>()) void wtile_kernel(KArgs a) 
             bin_cnt[tid] = 0;
         }
         __syncthreads();
+    }
+    if (HAS_CMS && hot) {  // the hot addresses of this workgroup: one sketch update per row and one distinct-set insert each
+        __syncthreads();
+        for (int i = tid; i < (int)(CMS_SETS * HOT_SLOTS); i += WBLOCK) {
+            const int set = i / HOT_SLOTS, sl = i % HOT_SLOTS;
+            if (hot->tag[set][sl] >= 2u) {
+                const unsigned long long lo = hot->lo[set][sl], hi = hot->hi[set][sl];
+                const uint32_t key[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+                cms_add(set ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, key, hot->w[set][sl]);
+                if (!(a.dbg & DBG_NO_KEYSET)) keyset_insert(a, set ? a.ks_dst : a.ks_src, key);
+            }
+        }
     }
     if (HAS_CMS && cl) {  // what is left in the sketch bins (fewer than a chunk each) goes to the back part of the segments
         __syncthreads();

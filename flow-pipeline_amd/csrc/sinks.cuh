@@ -35,6 +35,7 @@ constexpr bool WT_EARLY = FA_WT_EARLY != 0;  // next DMA issued between the pars
 constexpr int WBLOCK = FA_WBLOCK;   // 8 waves, each with a private LDS tile of <= 64 records
 constexpr int WT_RECS = 64;
 constexpr int WT_STRIDE = FA_WT_STRIDE;  // 5472 = 64 records x 85 B + alignment slack (16-byte multiple); overreads land in the next tile / the bins
+constexpr int WT_STRIDE_CMS = FA_WT_STRIDE - 256;  // tile buffers of the kernel variants that serve a sketch (ingest.cuh, wtile_stride)
 constexpr int WT_WG_PER_CU = 2;
 static_assert(WBLOCK % 64 == 0 && WBLOCK >= 256 && WBLOCK <= 1024 && WT_STRIDE % 16 == 0, "wave-tile geometry");
 constexpr uint32_t BIN_LINE = 8;    // a bin = one 128-byte line of tuples per key partition = 8 uint4 (256 x 128 B = 32 KiB per workgroup)
@@ -63,7 +64,7 @@ constexpr uint32_t FA_KEYS_WIDE = FA_KEYS_ADDR_PORT_PROTO | FA_KEYS_PORT_HIST | 
 constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense histograms
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
-       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072, DBG_NO_KEYSET = 262144, DBG_NO_CMS = 524288 };
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072, DBG_NO_KEYSET = 262144, DBG_NO_CMS = 524288, DBG_NO_HOT = 1048576 };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -245,6 +246,38 @@ __device__ __forceinline__ void cms_atomic_tuple(const KArgs& a, uint32_t p, con
     const size_t c = ((size_t)(p & (CMS_NPART - 1u)) << a.cms_sl2) + (t.x & 0x3fffu);
     if (w) atomicAdd(&sk[(size_t)(blockIdx.x % CMS_REPLICAS) * ((size_t)a.cms_depth << a.cms_wl2) + c], w);
 }
+#ifndef FA_CMS_LANE_FLUSH
+#define FA_CMS_LANE_FLUSH 0
+#endif
+// (experiment) The lane that took the last slot of a sketch bin sends the bin off on its own: it waits until the other seven
+// producers have written (they may sit in other waves; they run straight-line code), copies the 64-byte chunk with
+// four 16-byte stores to the next free chunk of the front part of the segment, and reopens the bin.  No cross-lane
+// choreography (the tuple bins' flush pays ~6 dependent LDS round trips per call for it, and a record makes eight
+// sketch inserts): the L2 merges the four stores of a chunk, which follow each other within nanoseconds.
+__device__ __forceinline__ void cms_chunk_flush(const KArgs& a, CmsLds& cl, uint32_t p) {
+    while ((__hip_atomic_load(&cl.bin_cnt[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < CMS_BIN) {}
+    const uint4* src = reinterpret_cast<const uint4*>(cl.bins) + p * 4u;
+    const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+    const uint32_t chunk = atomicAdd(&cl.part_cnt[p], 1u) & 0xffffu;
+    if ((chunk + 1u) * CMS_BIN <= a.ccapf) {
+        // (cregion and ccapq are multiples of 8 tuples: every segment starts on a 64-byte boundary)
+        uint4* dst = reinterpret_cast<uint4*>(a.cseg + (size_t)p * a.cregion + (size_t)blockIdx.x * a.ccapq + chunk * CMS_BIN);
+        dst[0] = q0;
+        dst[1] = q1;
+        dst[2] = q2;
+        dst[3] = q3;
+    } else {  // front part full (a heavy hitter's slice): atomics
+        cms_atomic_tuple(a, p, make_uint2(q0.x, q0.y));
+        cms_atomic_tuple(a, p, make_uint2(q0.z, q0.w));
+        cms_atomic_tuple(a, p, make_uint2(q1.x, q1.y));
+        cms_atomic_tuple(a, p, make_uint2(q1.z, q1.w));
+        cms_atomic_tuple(a, p, make_uint2(q2.x, q2.y));
+        cms_atomic_tuple(a, p, make_uint2(q2.z, q2.w));
+        cms_atomic_tuple(a, p, make_uint2(q3.x, q3.y));
+        cms_atomic_tuple(a, p, make_uint2(q3.z, q3.w));
+    }
+    __hip_atomic_store(&cl.bin_cnt[p], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (behind the reads above)
+}
 __device__ __forceinline__ void cms_bins_flush(const KArgs& a, CmsLds& cl, uint32_t* scratch, uint32_t fill_part) {
     const unsigned long long fm = __builtin_amdgcn_ballot_w64(fill_part != 0xffffffffu);
     if (fm == 0ull) return;
@@ -280,34 +313,125 @@ __device__ __forceinline__ void cms_bins_flush(const KArgs& a, CmsLds& cl, uint3
         }
     }
 }
-// One record's updates of one sketch (set = 0 SrcAddr, 1 DstAddr): depth tuples, each through the bin of its slice.
-// valid = false lanes only take part in the flushes (which need the whole wave).  scratch: 64 bytes of wave-private LDS.
-__device__ __forceinline__ void cms_scatter(const KArgs& a, CmsLds& cl, uint32_t* scratch, uint32_t set, bool valid, const uint32_t key[4], uint64_t w,
+// ---- per-workgroup hot-address cache ----------------------------------------------------------------
+// Heavy hitters (Zipf 1.1: the top address carries 8 % of the records, the top 64 carry 40 %) would send one tuple per
+// wave-tile to each of their counters - twice the load of an average sketch slice on the few slices they hit, and the
+// slowest slice sets the pace of cms_agg_kernel - and one distinct-set probe each.  An address that shows up at least
+// twice inside one wave-tile (the wave-level fold tells) may claim a slot here; from then on every occurrence in this
+// workgroup is ONE LDS add.  At the end of the launch each slot is worth one sketch update per row and one
+// distinct-set insert.  Slot = 6 bits of the key hash; tag: 0 empty, 1 being written, else a fingerprint (>= 2).
+constexpr int HOT_SLOTS = 64;
+struct HotAddrs {
+    unsigned int tag[CMS_SETS][HOT_SLOTS];
+    unsigned long long lo[CMS_SETS][HOT_SLOTS], hi[CMS_SETS][HOT_SLOTS], w[CMS_SETS][HOT_SLOTS];
+};
+// true = absorbed (the caller neither updates the sketch nor probes the distinct set for this record)
+__device__ __forceinline__ bool hot_add(HotAddrs& ht, uint32_t set, uint64_t lo, uint64_t hi, uint64_t h1, uint64_t w, bool admit) {
+    const uint32_t slot = (uint32_t)(h1 >> 8) & (HOT_SLOTS - 1);
+    const unsigned int fp = (unsigned int)(h1 >> 32) | 2u;
+    unsigned int t = __hip_atomic_load(&ht.tag[set][slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (t == fp) {
+        if (ht.lo[set][slot] != lo || ht.hi[set][slot] != hi) return false;
+        if (w) atomicAdd(&ht.w[set][slot], (unsigned long long)w);
+        return true;
+    }
+    if (t == 0u && admit && atomicCAS(&ht.tag[set][slot], 0u, 1u) == 0u) {
+        ht.lo[set][slot] = lo;
+        ht.hi[set][slot] = hi;
+        ht.w[set][slot] = w;
+        __hip_atomic_store(&ht.tag[set][slot], fp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (behind the key and the weight)
+        return true;
+    }
+    return false;
+}
+
+// Flush of the sketch bins that the lanes of this wave have just filled - several per lane: fills[k] = bin or ~0.
+// The bins are listed in wave-private LDS (list: >= 4 x 64 words) and leave 16 per pass (cms_bins_flush's protocol).
+template <int NB>
+__device__ __forceinline__ void cms_bins_flush_multi(const KArgs& a, CmsLds& cl, uint32_t* list, const uint32_t (&fills)[NB]) {
+    const uint32_t ln = __lane_id(), g = ln >> 2, sub = ln & 3u;
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const unsigned long long fm = __builtin_amdgcn_ballot_w64(fills[k] != 0xffffffffu);
+        if (fills[k] != 0xffffffffu) list[total + (uint32_t)__builtin_popcountll(fm & ((1ull << ln) - 1ull))] = fills[k];
+        total += (uint32_t)__builtin_popcountll(fm);
+    }
+    if (total == 0) return;
+    const uint4* bins4 = reinterpret_cast<const uint4*>(cl.bins);
+    for (uint32_t base = 0; base < total; base += 16u) {
+        const bool act = base + g < total;
+        const uint32_t fp = act ? list[base + g] : 0u;
+        const uint32_t c0 = __hip_atomic_load(&cl.bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint4 tq = bins4[fp * 4u + sub];
+        uint32_t chunk = 0;
+        if (act && sub == 0) chunk = atomicAdd(&cl.part_cnt[fp], 1u) & 0xffffu;
+        bool late = false;
+        if (__builtin_amdgcn_ballot_w64(act && (c0 >> 16) < CMS_BIN) != 0ull) {
+            late = true;
+            while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&cl.bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < CMS_BIN) != 0ull) {}
+        }
+        chunk = (uint32_t)__shfl((int)chunk, (int)(ln & ~3u));
+        if (act) {
+            const uint4 tv = late ? bins4[fp * 4u + sub] : tq;
+            if ((chunk + 1u) * CMS_BIN <= a.ccapf) {
+                uint4* dst = reinterpret_cast<uint4*>(a.cseg + (size_t)fp * a.cregion + (size_t)blockIdx.x * a.ccapq + chunk * CMS_BIN);
+                dst[sub] = tv;
+            } else {
+                cms_atomic_tuple(a, fp, make_uint2(tv.x, tv.y));
+                cms_atomic_tuple(a, fp, make_uint2(tv.z, tv.w));
+            }
+            if (sub == 0) __hip_atomic_store(&cl.bin_cnt[fp], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// One record's updates of one sketch (set = 0 SrcAddr, 1 DstAddr): depth tuples, each through the bin of its slice,
+// four rows at a time - the slot claims of the four rows are issued together, then the tuple writes, then ONE flush
+// for every bin the wave has filled (row by row this was ~5 dependent LDS round trips per row and wave: at depth 4
+// and two sketches more latency than the whole protobuf parse).  valid = false lanes only take part in the flushes
+// (which need the whole wave).  list: >= 256 words of wave-private LDS (the wave's dead tile buffer).
+__device__ __forceinline__ void cms_scatter(const KArgs& a, CmsLds& cl, uint32_t* list, uint32_t set, bool valid, const uint32_t key[4], uint64_t w,
                                             uint64_t h, uint64_t h2) {
+    constexpr int NB = 4;
     const bool big = (w >> 50) != 0;
     if (valid && big) {  // (never with real Bytes x SamplingRate values)
         cms_add(set ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, key, w);
         valid = false;
     }
     valid = valid && w != 0;
-    for (uint32_t r = 0; r < a.cms_depth; r++, h += h2) {
-        uint32_t fill = 0xffffffffu;
-        if (valid) {
+    for (uint32_t r0 = 0; r0 < a.cms_depth; r0 += NB) {
+        uint32_t p[NB], slot[NB], fills[NB];
+        uint2 t[NB];
+        bool act[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++, h += h2) {  // claim a slot in each row's bin
+            const uint32_t r = r0 + k;
+            act[k] = valid && r < a.cms_depth;
             const uint32_t c = (r << a.cms_wl2) + (uint32_t)(h >> (64 - a.cms_wl2));
-            const uint32_t p = set * CMS_NPART + (c >> a.cms_sl2);
-            const uint2 t = make_uint2((c & ((1u << a.cms_sl2) - 1u)) | ((uint32_t)w << 14), (uint32_t)(w >> 18));
-            const uint32_t slot = __hip_atomic_fetch_add(&cl.bin_cnt[p], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;
-            if (slot < CMS_BIN) {
-                cl.bins[p * CMS_BIN + slot] = t;
-                __hip_atomic_fetch_add(&cl.bin_cnt[p], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                fill = slot == CMS_BIN - 1 ? p : fill;
-            } else {  // the bin is on its way out: single store to the back part of the segment
-                const uint32_t ob = atomicAdd(&cl.part_cnt[p], 0x10000u) >> 16;
-                if (ob < a.ccapb) a.cseg[(size_t)p * a.cregion + (size_t)blockIdx.x * a.ccapq + (a.ccapq - 1u - ob)] = t;
-                else cms_atomic_tuple(a, p, t);
+            p[k] = act[k] ? set * CMS_NPART + (c >> a.cms_sl2) : 0u;
+            t[k] = make_uint2((c & ((1u << a.cms_sl2) - 1u)) | ((uint32_t)w << 14), (uint32_t)(w >> 18));
+            slot[k] = 0xffffu;
+            if (act[k]) slot[k] = __hip_atomic_fetch_add(&cl.bin_cnt[p[k]], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+            if (act[k] && slot[k] < CMS_BIN) cl.bins[p[k] * CMS_BIN + slot[k]] = t[k];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            fills[k] = 0xffffffffu;
+            if (act[k]) {
+                if (slot[k] < CMS_BIN) {
+                    __hip_atomic_fetch_add(&cl.bin_cnt[p[k]], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (slot[k] == CMS_BIN - 1) fills[k] = p[k];
+                } else {  // the bin is on its way out: single store to the back part of the segment
+                    const uint32_t ob = atomicAdd(&cl.part_cnt[p[k]], 0x10000u) >> 16;
+                    if (ob < a.ccapb) a.cseg[(size_t)p[k] * a.cregion + (size_t)blockIdx.x * a.ccapq + (a.ccapq - 1u - ob)] = t[k];
+                    else cms_atomic_tuple(a, p[k], t[k]);
+                }
             }
         }
-        cms_bins_flush(a, cl, scratch, fill);
+        cms_bins_flush_multi<NB>(a, cl, list, fills);
     }
 }
 
@@ -385,7 +509,7 @@ __device__ __forceinline__ KsProbe keyset_probe(const KArgs& a, KeySlot* tab, ui
     p.chi = p.s->hi;
     return p;
 }
-__device__ __noinline__ void keyset_insert_slow(const KArgs& a, KeySlot* tab, unsigned long long lo, unsigned long long hi, unsigned long long mytag, uint32_t i) {
+__device__ __forceinline__ void keyset_insert_slow(const KArgs& a, KeySlot* tab, unsigned long long lo, unsigned long long hi, unsigned long long mytag, uint32_t i) {
     for (int probe = 0; probe < 256; probe++, i = (i + 1) & a.ks_mask) {
         KeySlot* s = &tab[i];
         // fastest path: the key is already there and this XCD's L2 knows it.  Plain (cached) loads may be stale,
