@@ -263,6 +263,8 @@ def main():
         return
 
     launches = st1["kernel_launches"] - st0["kernel_launches"]
+    # (the library splits a call into several launches when its records leave as wide tuples: > 2^24 per launch)
+    bytes_per_launch = (st1["bytes_in"] - st0["bytes_in"]) / max(launches, 1)
     kern_s = (st1["kernel_ns_total"] - st0["kernel_ns_total"]) * 1e-9
     batch_s = (st1["batch_ns_total"] - st0["batch_ns_total"]) * 1e-9  # ingest kernel + second-chance parsers + tuple aggregation
     avg_launch_s = kern_s / max(launches, 1)
@@ -311,7 +313,7 @@ def main():
         "bytes_per_record": wire_bytes / n_rec,
         "generator": args.mode,
         "key_sets": args.key_sets,
-        "launches_per_step": len(chunks),
+        "launches_per_step": int(launches // max(args.steps, 1)),
         "tuple_format": fmt,
         "partitioning": "one Kafka partition per GPU, no data-path collective; rows all-gathered at window close",
         "window_close_merge_ms": merge_ms,

@@ -837,3 +837,68 @@ double fo_bench_rollup(const fo_gen_params* g, uint64_t i0, uint64_t n, int thre
     free(th);
     return dt;
 }
+
+/* ------------------------------------------------- config 3 at full scale */
+void fo_zipf_key(uint64_t rank, int dst, int v6, uint8_t out[16]) { zipf_key(rank, dst ? 0x2222 : 0x1111, out, !v6); }
+
+typedef struct {
+    const fo_gen_params* g;
+    uint64_t i0, n;
+    uint32_t depth, wl2;
+    uint64_t seed;
+    uint64_t *src, *dst;          /* private sketch copies */
+    uint64_t *ex_src, *ex_dst;    /* shared exact arrays (atomic adds) or NULL */
+} cjob;
+static void* cjob_run(void* a) {
+    cjob* j = (cjob*)a;
+    const fo_gen_params* g = j->g;
+    const uint32_t L = g->zipf_log2_universe ? g->zipf_log2_universe : 24;
+    for (uint64_t k = 0; k < j->n; k++) {
+        fo_row r;
+        const uint64_t i = j->i0 + k;
+        fo_gen_row(g, i, &r);
+        const uint64_t w = r.bytes * r.sampling_rate; /* UInt64 wrap */
+        if (w) {
+            fo_cms_update(j->src, j->depth, j->wl2, j->seed, r.src_addr, w);
+            fo_cms_update(j->dst, j->depth, j->wl2, j->seed, r.dst_addr, w);
+        }
+        if (j->ex_src && g->mode == FO_GEN_ZIPF) { /* the ranks behind the two addresses: the generator's own draws */
+            const uint64_t r3 = gen_rnd(g, i, 3), r4 = gen_rnd(g, i, 4);
+            const uint64_t v6 = r.etype == 0x86dd;
+            __atomic_fetch_add(&j->ex_src[zipf_rank(g, r3) + (v6 << L)], w, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&j->ex_dst[zipf_rank(g, r4) + (v6 << L)], w, __ATOMIC_RELAXED);
+        }
+    }
+    return NULL;
+}
+void fo_cms_stream(const fo_gen_params* g, uint64_t i0, uint64_t n, int threads, uint32_t depth, uint32_t wl2,
+                   uint64_t seed, uint64_t* cms_src, uint64_t* cms_dst, uint64_t* exact_src, uint64_t* exact_dst) {
+    if (threads < 1) threads = 1;
+    const size_t words = (size_t)depth << wl2;
+    cjob* jobs = (cjob*)calloc(threads, sizeof(cjob));
+    pthread_t* th = (pthread_t*)calloc(threads, sizeof(pthread_t));
+    for (int t = 0; t < threads; t++) {
+        jobs[t].g = g;
+        jobs[t].i0 = i0 + n * t / threads;
+        jobs[t].n = n * (t + 1) / threads - n * t / threads;
+        jobs[t].depth = depth;
+        jobs[t].wl2 = wl2;
+        jobs[t].seed = seed;
+        jobs[t].src = (uint64_t*)calloc(words, 8);
+        jobs[t].dst = (uint64_t*)calloc(words, 8);
+        jobs[t].ex_src = exact_src;
+        jobs[t].ex_dst = exact_dst;
+        pthread_create(&th[t], NULL, cjob_run, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        for (size_t k = 0; k < words; k++) {
+            cms_src[k] += jobs[t].src[k];
+            cms_dst[k] += jobs[t].dst[k];
+        }
+        free(jobs[t].src);
+        free(jobs[t].dst);
+    }
+    free(jobs);
+    free(th);
+}

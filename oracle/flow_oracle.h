@@ -134,6 +134,17 @@ size_t fo_gen_records(const fo_gen_params*, uint64_t i0, uint64_t n, uint8_t* ou
 /* The decoded truth for record i (what a correct decoder must produce). */
 void fo_gen_row(const fo_gen_params*, uint64_t i, fo_row* out);
 
+/* ---- BASELINE config 3 at full scale: both Count-Min sketches (and, optionally, the exact per-address weights) of
+ * the generator stream [i0, i0+n), straight from the generator's truth rows (fo_gen_row - what a correct decoder
+ * yields; decode parity is established elsewhere), on `threads` threads with private sketch copies that are summed at
+ * the end.  cms_src / cms_dst: depth << width_log2 uint64 each, ADDED to.  exact_src / exact_dst (may be NULL, ZIPF
+ * mode only): 2 << zipf_log2_universe uint64 each, indexed [v6][rank] = rank + (v6 << zipf_log2_universe): the exact
+ * sum(Bytes*SamplingRate) GROUP BY address (viz-ch.json:233,479) - the address of (rank, v6) is fo_zipf_key(). */
+void fo_cms_stream(const fo_gen_params* g, uint64_t i0, uint64_t n, int threads, uint32_t depth, uint32_t width_log2,
+                   uint64_t seed, uint64_t* cms_src, uint64_t* cms_dst, uint64_t* exact_src, uint64_t* exact_dst);
+/* The 16-byte address the ZIPF generator gives rank `rank` (dst = 0: SrcAddr, 1: DstAddr; v6 = 0: 4-byte IPv4 form). */
+void fo_zipf_key(uint64_t rank, int dst, int v6, uint8_t out[16]);
+
 /* ---- cpu_baseline helper: generate + decode + rollup on `threads` threads.
  * Records [i0,i0+n) are generated up front (untimed), then decode+rollup is
  * timed.  Returns seconds of the timed region; *rows_out/bad_out optional. */

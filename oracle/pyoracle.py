@@ -193,6 +193,27 @@ def cms_query(cms: np.ndarray, depth, width_log2, seed, key: bytes) -> int:
     return lib().fo_cms_query(cms.ctypes.data, depth, width_log2, seed, key)
 
 
+def cms_stream(gp: GenParams, i0: int, n: int, threads: int, depth: int, width_log2: int, seed: int, cms_src, cms_dst,
+               exact_src=None, exact_dst=None):
+    """Adds the sketches (and optionally the exact per-(rank, v6) weights) of generator records [i0, i0+n) - see
+    fo_cms_stream in flow_oracle.h.  Arrays are uint64 numpy arrays, modified in place."""
+    L = lib()
+    L.fo_cms_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.fo_cms_stream.restype = None
+    L.fo_cms_stream(C.byref(gp), i0, n, threads, depth, width_log2, seed, cms_src.ctypes.data, cms_dst.ctypes.data,
+                    None if exact_src is None else exact_src.ctypes.data, None if exact_dst is None else exact_dst.ctypes.data)
+
+
+def zipf_key(rank: int, dst: int, v6: int) -> bytes:
+    out = C.create_string_buffer(16)
+    L = lib()
+    L.fo_zipf_key.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_char_p]
+    L.fo_zipf_key.restype = None
+    L.fo_zipf_key(rank, dst, v6, out)
+    return out.raw
+
+
 def bench_rollup(gp: GenParams, i0: int, n: int, threads: int):
     wire, groups, bad, cs = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
     dt = lib().fo_bench_rollup(C.byref(gp), i0, n, threads, C.byref(wire), C.byref(groups),

@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""BASELINE config 3 as specified: 1xMI355X, Count-Min heavy hitters over SrcAddr / DstAddr,
+1 B framed FlowMessages with Zipf-1.1 addresses (universe 2^24), regenerated in 16.67 M-record chunks in HBM and
+ingested with key_sets = flows_5m rollup + both sketches.  Checks (the CPU side is oracle/, test infrastructure):
+  * both sketches BIT-EXACT against the CPU sketch of the same stream - on the first 100 M records and on the full stream;
+  * top-100 by estimate == the ranking of every address of the universe by the CPU sketch's estimate;
+  * on the 100 M prefix: estimates never below the exact GROUP BY weight, and within eps * total weight (eps = e / width)
+    for at least a 1 - e^-depth share of the addresses.
+Prints one JSON line (commit it under profiles/)."""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _pkg  # noqa: E402
+
+
+def mix64(z):
+    z = z.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xbf58476d1ce4e5b9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94d049bb133111eb)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+def universe_keys(L, dst):
+    """(lo, hi) of the generator's address for every (v6, rank): index = rank + (v6 << L)  (gen.cuh gen_zipf_key)."""
+    rank = np.arange(1 << L, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        a = mix64(rank * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x2222 if dst else 0x1111))
+        b = mix64(a ^ np.uint64(0xD1B54A32D192ED03))
+    lo = np.concatenate([a & np.uint64(0xFFFFFFFF), a])   # v4: the low 4 bytes of a, rest zero; v6: a || b
+    hi = np.concatenate([np.zeros(1 << L, dtype=np.uint64), b])
+    return lo, hi
+
+
+def estimates(cms, lo, hi, depth, wl2, seed):
+    with np.errstate(over="ignore"):
+        s0 = mix64(np.array([(seed + 0x9E3779B97F4A7C15) & (2**64 - 1)], dtype=np.uint64))[0]
+        a = mix64(lo ^ s0)
+        h = mix64(a ^ hi)
+        h2 = a | np.uint64(1)
+        best = np.full(len(lo), np.uint64(2**64 - 1), dtype=np.uint64)
+        for r in range(depth):
+            idx = (h >> np.uint64(64 - wl2)).astype(np.int64) + (r << wl2)
+            best = np.minimum(best, cms[idx])
+            h = h + h2
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--records", type=int, default=1_000_000_000)
+    ap.add_argument("--chunk", type=int, default=16_666_667)
+    ap.add_argument("--prefix", type=int, default=100_000_000)
+    ap.add_argument("--universe-log2", type=int, default=24)
+    ap.add_argument("--threads", type=int, default=0)
+    args = ap.parse_args()
+    import torch
+    fa = _pkg.load()
+    po = _pkg.load_oracle()
+    fa.build()
+    dev = torch.device("cuda", 0)
+    n, L = args.records, args.universe_log2
+    depth, wl2, seed = 4, 20, 0x5EED
+    threads = args.threads or min(64, len(os.sched_getaffinity(0)))
+    KS = (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS)
+    mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=3, n_total=n, span_secs=900, zipf_log2_universe=L, zipf_s_x100=110)
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=3, n_total=n, span_secs=900, zipf_log2_universe=L, zipf_s_x100=110)
+    out = {"config": "BASELINE configs[2]: 1xMI355X, Count-Min heavy hitters SrcAddr/DstAddr, %d framed FlowMessages, Zipf-1.1 over 2^%d addresses, "
+                     "regenerated in %d-record chunks; sketch depth %d x 2^%d x u64 per key set" % (n, L, args.chunk, depth, wl2)}
+    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=L + 2,
+                    max_batch_records=args.chunk) as agg:
+        cap = args.chunk * 96 + 4096
+        d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(args.chunk + 1, dtype=torch.int32, device=dev)
+        prefix_sk = None
+        wire = 0
+        t_gen = t_ing = 0.0
+        i0 = 0
+        st0 = agg.stats()
+        while i0 < n:
+            m = min(args.chunk, n - i0)
+            if prefix_sk is None and i0 >= args.prefix:
+                prefix_sk = [agg.cms_read(k).reshape(-1).copy() for k in KS]
+                out["prefix_records"] = i0
+            t0 = time.perf_counter()
+            w = agg.mock_generate_device(mp, i0, m, d_buf.data_ptr(), cap, d_off.data_ptr())
+            t1 = time.perf_counter()
+            agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
+            agg.sync()
+            t_gen += t1 - t0
+            t_ing += time.perf_counter() - t1
+            wire += w
+            i0 += m
+        st1 = agg.stats()
+        full_sk = [agg.cms_read(k).reshape(-1).copy() for k in KS]
+        tops = [agg.topk(k, 100) for k in KS]
+        rows = agg.read_window()
+    assert int(rows["count"].sum()) == n and st1["records_ok"] == n and st1["records_bad"] == 0
+    launches = st1["kernel_launches"] - st0["kernel_launches"]
+    path_s = (st1["batch_ns_total"] - st0["batch_ns_total"]) * 1e-9
+    out.update({
+        "records": n, "wire_bytes": wire, "launches": int(launches),
+        "path_ms_per_launch": path_s / launches * 1e3,
+        "records_per_s_device_path": n / path_s,
+        "roofline_frac_path": wire / path_s / 8e12,
+        "ingest_wall_s_with_sync_per_chunk": t_ing, "generator_wall_s": t_gen,
+        "records_direct_path": int(st1["records_direct"]), "flows_5m_rows": int(len(rows)),
+    })
+    # ---- CPU side (oracle): the same stream, sketches + exact weights of the prefix
+    t0 = time.perf_counter()
+    words = depth << wl2
+    c_src = np.zeros(words, dtype=np.uint64)
+    c_dst = np.zeros(words, dtype=np.uint64)
+    ex_src = np.zeros(2 << L, dtype=np.uint64)
+    ex_dst = np.zeros(2 << L, dtype=np.uint64)
+    npre = out.get("prefix_records", 0)
+    if npre:
+        po.cms_stream(gp, 0, npre, threads, depth, wl2, seed, c_src, c_dst, ex_src, ex_dst)
+    p_src, p_dst = c_src.copy(), c_dst.copy()
+    po.cms_stream(gp, npre, n - npre, threads, depth, wl2, seed, c_src, c_dst)
+    out["cpu_oracle_seconds"] = time.perf_counter() - t0
+    out["cpu_oracle_threads"] = threads
+    out["sketch_bit_exact_full_stream"] = bool(np.array_equal(full_sk[0], c_src) and np.array_equal(full_sk[1], c_dst))
+    if npre:
+        out["sketch_bit_exact_prefix"] = bool(np.array_equal(prefix_sk[0], p_src) and np.array_equal(prefix_sk[1], p_dst))
+    # ---- top-100: GPU ranking vs the ranking of the whole universe by the CPU sketch
+    ok_top = True
+    for dst, (cms, top) in enumerate(zip((c_src, c_dst), tops)):
+        lo, hi = universe_keys(L, dst)
+        est = estimates(cms, lo, hi, depth, wl2, seed)
+        # order: weight descending, then key bytes ascending (memcmp order = big-endian value of (lo, hi) byte strings)
+        cand = np.argpartition(est, len(est) - 400)[-400:]
+        keyb = [lo[i].tobytes() + hi[i].tobytes() for i in cand]
+        order = sorted(range(len(cand)), key=lambda k: (-int(est[cand[k]]), keyb[k]))[:100]
+        want = [(keyb[k], int(est[cand[k]])) for k in order]
+        got = [(bytes(r["key"]), int(r["weight"])) for r in top]
+        ok_top = ok_top and got == want
+        if dst == 0:
+            out["top3_src"] = [(k.hex(), w) for k, w in got[:3]]
+    out["top100_equals_ranking_of_the_whole_universe"] = bool(ok_top)
+    # ---- error bound on the prefix (overestimate-only; eps = e / width, confidence 1 - e^-depth)
+    if npre:
+        for dst, (cms, ex) in enumerate(zip((p_src, p_dst), (ex_src, ex_dst))):
+            lo, hi = universe_keys(L, dst)
+            seen = np.nonzero(ex)[0]
+            est = estimates(cms, lo[seen], hi[seen], depth, wl2, seed)
+            total_w = int(ex.sum(dtype=np.uint64))
+            eps_w = math.e / (1 << wl2) * total_w
+            never_below = bool((est >= ex[seen]).all())
+            within = float(((est - ex[seen]).astype(np.float64) <= eps_w).mean())
+            tag = "dst" if dst else "src"
+            out["prefix_%s_addresses" % tag] = int(len(seen))
+            out["prefix_%s_never_underestimates" % tag] = never_below
+            out["prefix_%s_share_within_eps" % tag] = within
+            out["prefix_%s_required_share" % tag] = 1 - math.exp(-depth)
+    print(json.dumps(out))
+    ok = out["sketch_bit_exact_full_stream"] and out.get("sketch_bit_exact_prefix", True) and ok_top
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""BASELINE config 5, single-GPU shape, at scale: two concurrent key sets - flows_5m
+(SrcAS,DstAS) and (SrcAddr,DstPort,Proto) - over 60-second sub-buckets, 5-minute windows tumbling AND sliding by
+60 s, Zipf-0.8 addresses, seed 5; records regenerated in HBM chunk by chunk.  Checks (CPU side = oracle/):
+  * every 5-minute-aligned window of flows_5m: rows bit-exact (order-independent checksum over keys and sums,
+    row count) against the C oracle's rollup of the same records;
+  * one sliding window (start not 5-minute aligned): rows byte-identical to the oracle rollup of exactly the records
+    whose TimeReceived falls into [start, start+300);
+  * (SrcAddr,DstPort,Proto): count() and sum(Bytes) over all rows == the stream's totals, one row set per window.
+Prints one JSON line (commit it under profiles/)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _pkg  # noqa: E402
+
+
+def mix64(z):
+    z = z.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xbf58476d1ce4e5b9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94d049bb133111eb)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+def checksum(rows):
+    with np.errstate(over="ignore"):
+        a = (rows["timeslot"].astype(np.uint64) << np.uint64(32)) | rows["etype"].astype(np.uint64)
+        b = (rows["src_as"].astype(np.uint64) << np.uint64(32)) | rows["dst_as"].astype(np.uint64)
+        h = mix64(a ^ mix64(b))
+        v = rows["bytes"] * np.uint64(3) + rows["packets"] * np.uint64(5) + rows["count"] * np.uint64(7) + np.uint64(1)
+        return int((h * v).sum(dtype=np.uint64))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--records", type=int, default=100_000_000)
+    ap.add_argument("--chunk", type=int, default=16_666_667)
+    ap.add_argument("--span", type=int, default=1800, help="seconds of event time the stream covers (6 windows)")
+    args = ap.parse_args()
+    import torch
+    fa = _pkg.load()
+    po = _pkg.load_oracle()
+    fa.build()
+    dev = torch.device("cuda", 0)
+    n = args.records
+    threads = min(64, len(os.sched_getaffinity(0)))
+    mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=5, n_total=n, span_secs=args.span, zipf_log2_universe=24, zipf_s_x100=80)
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=5, n_total=n, span_secs=args.span, zipf_log2_universe=24, zipf_s_x100=80)
+    ks = fa.FA_KEYS_AS_PAIR | fa.FA_KEYS_ADDR_PORT_PROTO
+    out = {"config": "BASELINE configs[4], single-GPU shape: (SrcAS,DstAS) + (SrcAddr,DstPort,Proto), 60-s sub-buckets, 5-min windows "
+                     "(tumbling + sliding by 60 s), %d framed FlowMessages, Zipf-0.8, seed 5, %d s of event time" % (n, args.span)}
+    with fa.FlowAgg(framed=True, key_sets=ks, window_secs=300, subwindow_secs=60, wide_capacity_log2=28, table_capacity_log2=22,
+                    max_batch_records=args.chunk) as agg:
+        cap = args.chunk * 96 + 4096
+        d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(args.chunk + 1, dtype=torch.int32, device=dev)
+        wire = 0
+        i0 = 0
+        st0 = agg.stats()
+        t_ing = 0.0
+        while i0 < n:
+            m = min(args.chunk, n - i0)
+            w = agg.mock_generate_device(mp, i0, m, d_buf.data_ptr(), cap, d_off.data_ptr())
+            t1 = time.perf_counter()
+            agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
+            agg.sync()
+            t_ing += time.perf_counter() - t1
+            wire += w
+            i0 += m
+        st1 = agg.stats()
+        launches = st1["kernel_launches"] - st0["kernel_launches"]
+        path_s = (st1["batch_ns_total"] - st0["batch_ns_total"]) * 1e-9
+        out.update({"records": n, "wire_bytes": wire, "launches": int(launches), "path_ms_per_launch": path_s / launches * 1e3,
+                    "records_per_s_device_path": n / path_s, "roofline_frac_path": wire / path_s / 8e12,
+                    "ingest_wall_s_with_sync_per_chunk": t_ing, "flows_5m_groups_in_table": int(st1["table_used"]),
+                    "wide_rows_in_table": int(st1["wide_used"]), "wide_table_capacity": int(st1["wide_capacity"])})
+        assert st1["records_ok"] == n and st1["records_bad"] == 0
+        # ---- flows_5m, every aligned window (peek: nothing removed)
+        t0 = fa.T0
+        aligned = [t0 + 300 * k for k in range((args.span + 299) // 300)]
+        tw = time.perf_counter()
+        wins = [agg.read_window(ts) for ts in aligned]
+        out["read_5_aligned_windows_ms_each"] = (time.perf_counter() - tw) * 1e3 / len(aligned)
+        allrows = np.concatenate(wins)
+        ref = po.bench_rollup(gp, 0, n, threads)
+        out["flows_5m_rows"] = int(len(allrows))
+        out["flows_5m_aligned_windows_bit_exact"] = bool(ref["bad"] == 0 and ref["groups"] == len(allrows) and checksum(allrows) == ref["checksum"]
+                                                       and int(allrows["count"].sum()) == n)
+        # ---- one sliding window: [t0 + 420, t0 + 720)
+        start = t0 + 420
+        got = agg.read_window(start)
+        ia = -(-(start - t0) * n // args.span)          # first record with TimeReceived >= start  (t = t0 + span*i // n)
+        ib = -(-(start + 300 - t0) * n // args.span)
+        rr = po.Rollup(300)
+        step = 8_000_000
+        for a in range(ia, ib, step):
+            buf, off = po.gen_records(gp, a, min(step, ib - a))
+            assert rr.ingest(buf, off, 1) == 0
+        want = rr.rows()
+        # fold the oracle's two aligned timeslots into the window (the window start is the row's timeslot)
+        key = np.stack([want[c].astype(np.uint64) for c in ("src_as", "dst_as", "etype")], axis=1)
+        order = np.lexsort((key[:, 2], key[:, 1], key[:, 0]))
+        want = want[order]
+        key = key[order]
+        first = np.ones(len(want), dtype=bool)
+        first[1:] = (key[1:] != key[:-1]).any(axis=1)
+        starts = np.nonzero(first)[0]
+        folded = want[starts].copy()
+        for c in ("bytes", "packets", "count"):
+            folded[c] = np.add.reduceat(want[c], starts)
+        folded["timeslot"] = start
+        folded["date"] = start // 86400
+        out["sliding_window_rows"] = int(len(got))
+        out["sliding_window_bit_exact"] = bool(got.tobytes() == folded.tobytes())
+        # ---- (SrcAddr,DstPort,Proto): totals over all windows
+        cnt = by = 0
+        nrows = 0
+        for ts in aligned:
+            app = agg.read_window_app(ts)
+            cnt += int(app["count"].sum())
+            by += int(app["bytes"].sum(dtype=np.uint64))
+            nrows += len(app)
+        out["app_rows"] = nrows
+        out["app_count_equals_records"] = bool(cnt == n)
+        out["app_sum_bytes_equals_flows_5m"] = bool(by == int(allrows["bytes"].sum(dtype=np.uint64)))
+    print(json.dumps(out))
+    ok = out["flows_5m_aligned_windows_bit_exact"] and out["sliding_window_bit_exact"] and out["app_count_equals_records"] and out["app_sum_bytes_equals_flows_5m"]
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
