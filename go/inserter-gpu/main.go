@@ -30,6 +30,7 @@ import (
 	"net/http"
 	"os"
 	"os/signal"
+	"runtime"
 	"strings"
 	"sync"
 	"syscall"
@@ -132,15 +133,22 @@ func (p *partitionState) flush(session sarama.ConsumerGroupSession) {
 // closeWindows emits finished flows_5m rows (create.sh:70-90) as one RowBinary payload per window
 // (`INSERT INTO flows_5m FORMAT RowBinary`) instead of the reference's per-row db.Exec
 // (inserter.go:100-106).  Same logic as flow-pipeline_amd/host/inserter_gpu.cpp, which is built and tested.
-func (p *partitionState) closeWindows(now time.Time) {
-	var slots [64]C.uint32_t
+func (p *partitionState) closeWindows(now time.Time, all bool) {
+	// every open timeslot: retry with the size the library reports (a backlog replay can hold hundreds of windows);
+	// any other error is a sink error and fatal, like the reference's failed db.Exec (inserter.go:102-105)
+	slots := make([]C.uint32_t, 64)
 	var ns C.size_t
-	if C.fa_open_timeslots(p.ctx, &slots[0], 64, &ns) != 0 {
-		return
+	rc := C.fa_open_timeslots(p.ctx, &slots[0], C.size_t(len(slots)), &ns)
+	if rc == C.FA_ERR_CAPACITY {
+		slots = make([]C.uint32_t, int(ns))
+		rc = C.fa_open_timeslots(p.ctx, &slots[0], C.size_t(len(slots)), &ns)
+	}
+	if rc != 0 {
+		log.Fatalf("fa_open_timeslots: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
 	}
 	for i := 0; i < int(ns); i++ {
 		ts := uint32(slots[i])
-		if int64(ts)+int64(*WindowSecs)+int64(*CloseLagSec) > now.Unix() {
+		if !all && int64(ts)+int64(*WindowSecs)+int64(*CloseLagSec) > now.Unix() {
 			continue
 		}
 		rows := make([]C.fa_row5m, 1<<16)
@@ -188,6 +196,11 @@ func (s *state) ConsumeClaim(session sarama.ConsumerGroupSession, claim sarama.C
 		s.parts[claim.Partition()] = p
 	}
 	s.lock.Unlock()
+	// one OS thread per partition for the life of the claim: the library selects the ctx's GPU at every entry
+	// point anyway, but HIP keeps per-thread state (current device, error state) - a goroutine that hops between OS
+	// threads would drag other partitions' state along
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
 	timer := time.NewTimer(*FlushTime)
 	for {
 		select {
@@ -204,7 +217,7 @@ func (s *state) ConsumeClaim(session sarama.ConsumerGroupSession, claim sarama.C
 			}
 		case <-timer.C: // inserter.go:189-191
 			p.flush(session)
-			p.closeWindows(time.Now().UTC())
+			p.closeWindows(time.Now().UTC(), false)
 			timer.Reset(*FlushTime)
 		}
 	}
@@ -251,6 +264,9 @@ func main() {
 		log.Fatal(fmt.Sprintf("Error closing client: %v", err))
 	}
 	for _, p := range s.parts {
+		// the offsets of everything ingested are committed: what the GPU still holds must reach the sink before the
+		// contexts go away (the C++ twin: CloseAllAtEnd)
+		p.closeWindows(time.Now().UTC(), true)
 		C.fa_destroy(p.ctx)
 	}
 }

@@ -141,11 +141,17 @@ def main():
         est = estimates(cms, lo, hi, depth, wl2, seed)
         # order: weight descending, then key bytes ascending (memcmp order = big-endian value of (lo, hi) byte strings)
         cand = np.argpartition(est, len(est) - 400)[-400:]
-        keyb = [lo[i].tobytes() + hi[i].tobytes() for i in cand]
-        order = sorted(range(len(cand)), key=lambda k: (-int(est[cand[k]]), keyb[k]))[:100]
-        want = [(keyb[k], int(est[cand[k]])) for k in order]
+        # (two ranks may share a 4-byte IPv4 form - 2^24 ranks into 32 bits: one address, listed once)
+        uniq = {}
+        for i in cand:
+            uniq[lo[i].tobytes() + hi[i].tobytes()] = int(est[i])
+        want = sorted(uniq.items(), key=lambda kv: (-kv[1], kv[0]))[:100]
         got = [(bytes(r["key"]), int(r["weight"])) for r in top]
         ok_top = ok_top and got == want
+        if got != want:
+            k = next((i for i in range(min(len(got), len(want))) if got[i] != want[i]), -1)
+            out["top100_first_difference_%s" % ("dst" if dst else "src")] = [k, got[k][0].hex() if k >= 0 else None, got[k][1] if k >= 0 else None,
+                                                                            want[k][0].hex() if k >= 0 else None, want[k][1] if k >= 0 else None, len(got), len(want)]
         if dst == 0:
             out["top3_src"] = [(k.hex(), w) for k, w in got[:3]]
     out["top100_equals_ranking_of_the_whole_universe"] = bool(ok_top)
