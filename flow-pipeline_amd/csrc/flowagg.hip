@@ -722,7 +722,7 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
         switch (1u) { FA_LAUNCH(1u) }
     } else {
         switch (c->cfg.key_sets) {
-            FA_LAUNCH(1u) FA_LAUNCH(2u) FA_LAUNCH(3u) FA_LAUNCH(4u) FA_LAUNCH(5u) FA_LAUNCH(6u) FA_LAUNCH(7u)
+            FA_LAUNCH(1u) FA_LAUNCH(2u) FA_LAUNCH(3u) FA_LAUNCH(4u) FA_LAUNCH(5u) FA_LAUNCH(6u) FA_LAUNCH(7u) FA_LAUNCH(9u)
         default:  // any wide key set: the generic variant (runtime mask)
             if (wave_tiles) FA_LAUNCH_W(KS_ALL);
             else hipLaunchKernelGGL((tile_kernel<MODE, KS_ALL>), g, b, 0, c->stream, a);
@@ -767,6 +767,7 @@ static int tile_grid(fa_ctx* c, uint32_t n, uint32_t tile_recs) {
     case 5u: return grid_for(c, tile_kernel<MODE_INGEST, 5u>, n, tile_recs);
     case 6u: return grid_for(c, tile_kernel<MODE_INGEST, 6u>, n, tile_recs);
     case 7u: return grid_for(c, tile_kernel<MODE_INGEST, 7u>, n, tile_recs);
+    case 9u: return grid_for(c, tile_kernel<MODE_INGEST, 9u>, n, tile_recs);
     default: return grid_for(c, tile_kernel<MODE_INGEST, KS_ALL>, n, tile_recs);
     }
 }
@@ -791,7 +792,7 @@ static int ensure_exotic(fa_ctx* c, size_t n) {
 static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, bool t8, KArgs& a) {
     const size_t NPART = (size_t)1 << c->plog2;
     const size_t avg = n / ((size_t)nwg * NPART);
-    const uint32_t tpl = t8 ? 16u : 8u;  // tuples per line
+    const uint32_t tpl = (t8 ? 2u : 1u) * bin_line(c->cfg.key_sets);  // tuples per store unit (a 128-byte line; flows_5m alone: half a line)
     uint32_t capq = (uint32_t)((2 * avg + 32 + tpl - 1) & ~(size_t)(tpl - 1));
     if (c->seg_cap_limit) capq = std::max<uint32_t>(std::min(capq, c->seg_cap_limit) & ~(tpl - 1), 2 * tpl);  // (tests: force the segment-overflow fallbacks)
     const size_t region = (size_t)nwg * capq + 3 * tpl;
@@ -909,11 +910,11 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         // headroom for a mix of 60- and 84-byte records when the buffer is tight)
         // (the kernel variants that serve a sketch run one 16-wave workgroup per CU instead of two 8-wave ones, with
         // slightly shorter tile buffers: wtile_block, wtile_stride)
-        const bool big_wg = c->cfg.key_sets != FA_KEYS_AS_PAIR;
+        const bool big_wg = !wt_lean(c->cfg.key_sets);
         double r = ((double)(big_wg ? WT_STRIDE_CMS : WT_STRIDE) - 16.0 - 15.0 - 12.0 * 8.0 * 4.0) / avg;
         a.tile_recs = r >= (double)WT_RECS ? WT_RECS : r < 1.0 ? 1u : (uint32_t)r;
         const uint32_t wtiles = (a.n + a.tile_recs - 1) / a.tile_recs;
-        const uint32_t waves = (uint32_t)(big_wg ? 2 * WBLOCK : WBLOCK) / 64u;
+        const uint32_t waves = (uint32_t)(big_wg ? WBLOCK_CMS : WBLOCK) / 64u;
         const uint32_t wgs = (wtiles + waves - 1) / waves;
         grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * (uint32_t)(big_wg ? 1 : WT_WG_PER_CU)));
         if (a.tile_recs > (uint32_t)WT_RECS) c->use_t8 = false;

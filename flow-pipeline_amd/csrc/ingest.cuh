@@ -25,7 +25,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                                           LaneTally& tally, uint32_t& pmode, uint32_t& lt_seen, uint32_t& lt_hits,
                                           uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook(),
                                           CmsLds* cl = nullptr, uint32_t* cms_scratch = nullptr, HotAddrs* hot = nullptr) {
-    constexpr uint32_t TB = bin_cap<T8>();
+    constexpr uint32_t TB = bin_cap<T8, bin_line(KEYSETS)>();
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false, framed_ok = false;
     Rec r;
@@ -543,11 +543,11 @@ struct CmsLdsOpt<false> {
 // workgroup size of a variant: the sketch variants need 32 KiB of LDS more per workgroup (CmsLds) than two
 // workgroups per CU leave - they run ONE workgroup of 16 waves per CU (the same 16 waves per CU)
 template <uint32_t KEYSETS>
-constexpr int wtile_block() { return (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) ? 2 * WBLOCK : WBLOCK; }
+constexpr int wtile_block() { return wt_lean(KEYSETS) ? WBLOCK : WBLOCK_CMS; }
 // ... and their tile buffers are 256 bytes shorter (62 instead of 64 mocker-sized records; the LDS goes to the sketch
 // bins and the hot-address cache - the whole 160 KiB of the CU are spoken for)
 template <uint32_t KEYSETS>
-constexpr int wtile_stride() { return (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) ? WT_STRIDE_CMS : WT_STRIDE; }
+constexpr int wtile_stride() { return wt_lean(KEYSETS) ? WT_STRIDE : WT_STRIDE_CMS; }
 template <bool ON>
 struct HotAddrsOpt {
     HotAddrs v;
@@ -559,8 +559,9 @@ struct HotAddrsOpt<false> {
 };
 
 template <uint32_t KEYSETS, bool T8>
-__global__ __launch_bounds__(wtile_block<KEYSETS>()) void wtile_kernel(KArgs a) {
-    constexpr uint32_t TB = bin_cap<T8>();
+__global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) void wtile_kernel(KArgs a) {
+    constexpr uint32_t BL = bin_line(KEYSETS);
+    constexpr uint32_t TB = bin_cap<T8, BL>();
     constexpr uint32_t COLS = cols_for_keysets<KEYSETS>();
     constexpr int WBLOCK = wtile_block<KEYSETS>();  // (shadows the namespace constant inside this kernel)
     constexpr bool HAS_CMS = (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) != 0;
@@ -570,10 +571,10 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>()) void wtile_kernel(KArgs a) 
     __shared__ HotAddrsOpt<HAS_CMS> hot_lds;
     __shared__ uint32_t cms_scratch_all[HAS_CMS ? WAVES * 16 : 1];
     __shared__ __attribute__((aligned(16))) uint32_t tiles[WAVES * WT_STRIDE / 4];
-    __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BIN_LINE];  // 256 x one 128-byte line (8 wide / 16 compact tuples)
+    __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BL];  // 256 x one store unit (sinks.cuh, bin_line)
     __shared__ uint32_t bin_cnt[NPART_MAX];
     __shared__ uint32_t part_cnt[NPART_MAX];
-    __shared__ uint32_t flush_scratch[WAVES * 8];
+    __shared__ uint32_t flush_scratch[WAVES * 16];
     __shared__ LdsTable<LDS_SLOTS> lt;
     __shared__ LdsMinutes lm;
 
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>()) void wtile_kernel(KArgs a) 
             FA_WT_CLK(c0);
             dma_wait_all();
             FA_WT_CLK(c1);
-            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, tally.direct);
+            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8, BL>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 16, fill, tb_base, tally.direct);
             fill = 0xffffffffu;
             FA_WT_CLK(c2);
             WTileDesc d1{0, 0, 0, 0};
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>()) void wtile_kernel(KArgs a) 
             o1 = p1;
         }
         dma_wait_all();
-        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, tally.direct);
+        if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8, BL>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 16, fill, tb_base, tally.direct);
     } else {
         for (uint32_t round = 0; FA_WT_MORE(round); round++, t += stride) {
             FA_WT_CLK(c0);
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>()) void wtile_kernel(KArgs a) 
             FA_WT_CLK(c2);
             // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
             // queue and the wave would wait for the write acknowledgements on top of its tile (measured: +15 %)
-            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 8, fill, tb_base, tally.direct);
+            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8, BL>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 16, fill, tb_base, tally.direct);
             const uint32_t t2 = tile_after_next();  // (dynamic: an LDS atomic - before the DMA, or the compiler drains vmcnt for it)
             cur = tile_current(nxt);
             o0 = n0;

@@ -22,11 +22,19 @@ constexpr int PART_LOG2_MAX = 8;   // key partitions of the scatter sink (<= 256
 constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
 // wave-tile kernel residency: 2 workgroups x 8 waves per CU, one LDS tile per wave (what the 160 KiB of LDS admit
 // next to the tuple bins).  FA_WBLOCK / FA_WT_STRIDE: geometry experiments (tools/wave_scaling.sh).
+// Geometry of the wave-tile kernel, AS-rollup variant: 2 workgroups x 12 waves per CU = 6 waves per SIMD, tile buffers
+// of 4864 bytes (64 records of 76 bytes), half-line bins (64 bytes = 8 compact tuples).  Round 1 ran 2 x 8 waves with
+// 5472-byte tiles and full-line bins (all the LDS there was next to 16-byte tuples); with compact tuples a half-line bin
+// holds as many tuples as a full one did, and the LDS this frees goes to 8 more waves per CU: +3.5 % on config 2
+// (same-box A/B: half-line bins alone -2.8 %, 24 waves with them +3.3..3.6 %, 20 waves -23 % - uneven over the 4 SIMDs).
 #ifndef FA_WBLOCK
-#define FA_WBLOCK 512
+#define FA_WBLOCK 768
 #endif
 #ifndef FA_WT_STRIDE
-#define FA_WT_STRIDE 5472
+#define FA_WT_STRIDE 4864
+#endif
+#ifndef FA_BIN_BYTES
+#define FA_BIN_BYTES 64
 #endif
 #ifndef FA_WT_EARLY
 #define FA_WT_EARLY 0
@@ -35,13 +43,22 @@ constexpr bool WT_EARLY = FA_WT_EARLY != 0;  // next DMA issued between the pars
 constexpr int WBLOCK = FA_WBLOCK;   // 8 waves, each with a private LDS tile of <= 64 records
 constexpr int WT_RECS = 64;
 constexpr int WT_STRIDE = FA_WT_STRIDE;  // 5472 = 64 records x 85 B + alignment slack (16-byte multiple); overreads land in the next tile / the bins
-constexpr int WT_STRIDE_CMS = FA_WT_STRIDE - 256;  // tile buffers of the kernel variants that serve a sketch (ingest.cuh, wtile_stride)
+constexpr int WT_STRIDE_CMS = 5216;  // tile buffers of the kernel variants that serve a sketch (ingest.cuh, wtile_stride): 16 waves, what the 160 KiB leave
 constexpr int WT_WG_PER_CU = 2;
+constexpr int WBLOCK_CMS = 2 * FA_WBLOCK > 1024 ? 1024 : 2 * FA_WBLOCK;  // sketch variants: one big workgroup per CU (ingest.cuh, wtile_block)
 static_assert(WBLOCK % 64 == 0 && WBLOCK >= 256 && WBLOCK <= 1024 && WT_STRIDE % 16 == 0, "wave-tile geometry");
-constexpr uint32_t BIN_LINE = 8;    // a bin = one 128-byte line of tuples per key partition = 8 uint4 (256 x 128 B = 32 KiB per workgroup)
-// tuples per bin / per 128-byte line of a segment: 8 wide (16 B) or 16 compact (8 B) ones (table.cuh)
-template <bool T8>
-constexpr uint32_t bin_cap() { return T8 ? 16u : 8u; }
+// A bin = one store unit of tuples per key partition, in uint4 (16-byte) words: a whole 128-byte line (8) in every kernel
+// variant that serves a sketch or a wide key set (16 waves per workgroup; half-line bins measured -6 % there), half a
+// line (4 = 8 compact tuples) in the flows_5m-only variant (24 waves per CU, see FA_WBLOCK above).  One function for
+// the kernel templates and the host (segment geometry): what launch_tiles dispatches on is the key-set mask.
+static_assert(FA_BIN_BYTES == 128 || FA_BIN_BYTES == 64, "bin = one or half a cache line");
+// (wt_lean: the variants without a sketch - 12-wave workgroups, two per CU: flows_5m alone, and config 5's pair
+// flows_5m + (SrcAddr,DstPort,Proto); every other mask runs the 16-wave geometry, WBLOCK_CMS / WT_STRIDE_CMS)
+__host__ __device__ constexpr bool wt_lean(uint32_t key_sets) { return key_sets == FA_KEYS_AS_PAIR || key_sets == (FA_KEYS_AS_PAIR | FA_KEYS_ADDR_PORT_PROTO); }
+__host__ __device__ constexpr uint32_t bin_line(uint32_t key_sets) { return wt_lean(key_sets) ? FA_BIN_BYTES / 16u : 8u; }
+// tuples per bin: wide (16-byte) or compact (8-byte) tuples
+template <bool T8, uint32_t BL>
+constexpr uint32_t bin_cap() { return (T8 ? 2u : 1u) * BL; }
 constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table
 #ifndef FA_AGG_SLOTS
 #define FA_AGG_SLOTS 4096
@@ -809,18 +826,19 @@ __device__ __forceinline__ bool frame_short(uint32_t x, uint32_t rec_len, uint32
 // spin below only ever waits for straight-line code of waves that never wait for us (producers of this wave
 // finished in lockstep inside lane_work).  fill_part: the bin this lane filled (or ~0); scratch: 32 bytes of
 // wave-private LDS.  Must be called by the full wave.
-template <bool T8>
+template <bool T8, uint32_t BL>
 __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t* bin_cnt, uint32_t* part_cnt, uint32_t* scratch,
                                            uint32_t fill_part, uint32_t tb_base, uint32_t& n_direct) {
-    constexpr uint32_t TB = bin_cap<T8>();
+    constexpr uint32_t TB = bin_cap<T8, BL>();
     const unsigned long long fm = __builtin_amdgcn_ballot_w64(fill_part != 0xffffffffu);
     if (fm == 0ull) return;
-    const uint32_t ln = __lane_id(), g = ln >> 3, sub = ln & 7u;
+    constexpr uint32_t LPB = BL, GROUPS = 64u / LPB;  // lanes per bin (16 bytes each), bins per pass
+    const uint32_t ln = __lane_id(), g = ln / LPB, sub = ln % LPB;
     const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << ln) - 1ull));
     const uint32_t todo = (uint32_t)__builtin_popcountll(fm);
-    for (uint32_t base = 0; base < todo; base += 8u) {
-        if (fill_part != 0xffffffffu && rank - base < 8u) scratch[rank - base] = fill_part;
-        const bool act = g < min(8u, todo - base);
+    for (uint32_t base = 0; base < todo; base += GROUPS) {
+        if (fill_part != 0xffffffffu && rank - base < GROUPS) scratch[rank - base] = fill_part;
+        const bool act = g < min(GROUPS, todo - base);
         const uint32_t fp = act ? scratch[g] : 0u;
         // the written-slot check, the tuple read and the line allocation are issued back to back (LDS operations
         // of a wave complete in order, so the read sees what the check saw); only a bin that is still being
@@ -828,7 +846,7 @@ __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t
         // (acquire / release pair with the producers' written-slot count: without it the COMPILER may move the
         // tuple read above the check - it did, and rows differed from the oracle at 16 M records)
         const uint32_t c0 = __hip_atomic_load(&bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint4 tq = bins[fp * BIN_LINE + sub];
+        const uint4 tq = bins[fp * BL + sub];
         uint32_t line = 0;
         if (act && sub == 0) line = atomicAdd(&part_cnt[fp], 1u) & 0xffffu;  // low half: lines at the front
         bool late = false;
@@ -836,13 +854,13 @@ __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t
             late = true;
             while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < TB) != 0ull) {}
         }
-        line = (uint32_t)__shfl((int)line, (int)(ln & ~7u));
+        line = (uint32_t)__shfl((int)line, (int)(ln - sub));
         if (act) {
-            const uint4 tv = late ? bins[fp * BIN_LINE + sub] : tq;
+            const uint4 tv = late ? bins[fp * BL + sub] : tq;
             if ((line + 1u) * TB <= a.capf) {
                 // (compact tuples: region and capq are even, so the segment starts on a uint4 boundary)
                 const size_t seg0 = ((size_t)fp * a.region + (size_t)blockIdx.x * a.capq) >> (T8 ? 1 : 0);
-                if (!(a.dbg & DBG_NO_TUPLE_STORE)) a.seg[seg0 + line * BIN_LINE + sub] = tv;
+                if (!(a.dbg & DBG_NO_TUPLE_STORE)) a.seg[seg0 + line * BL + sub] = tv;
             } else {  // front part full (skewed batch): straight to the device-wide table
                 TupleVals v[2];
                 if (T8) {

@@ -518,7 +518,7 @@ def test_segment_overflow_fallbacks_stay_exact(gpu_lib, fa, po, monkeypatch, til
         monkeypatch.setenv("FA_TILE", tile)
     st = _large_batch_checksum_run(fa, po, 1)
     if not tile:  # (the workgroup kernel's 1536 segments per partition hold ~10 tuples each here: rarely above 40)
-        assert st["records_direct"] > (1_000_000 if cap == 40 else 10_000), st  # the fallbacks really ran (of 12 M records)
+        assert st["records_direct"] > (500_000 if cap == 40 else 10_000), st  # the fallbacks really ran (of 12 M records)
 
 
 def test_config3_shape_sketches_and_topk_at_scale(gpu_lib, fa, po):
