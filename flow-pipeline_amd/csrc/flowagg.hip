@@ -71,6 +71,12 @@ struct fa_ctx {
     size_t cseg_bytes = 0;
     uint32_t* cseg_counts = nullptr;
     size_t cseg_counts_cap = 0;
+    // scatter sink of the (SrcAddr,DstPort,Proto) key set (wagg.cuh)
+    uint4* wseg = nullptr;
+    size_t wseg_bytes = 0;
+    uint32_t* wseg_counts = nullptr;
+    size_t wseg_counts_cap = 0;
+    bool wide_atomic = false;  // env FA_WIDE=atomic (A/B, tests): every update of the key set through memory-side atomics
     bool cms_atomic = false;  // env FA_CMS=atomic (A/B, tests): every sketch update through memory-side atomics
     uint32_t cms_sl2 = 0;     // log2(counters per sketch slice)
     int sink_mode = 0;  // 0 auto, 1 direct, 2 scatter (env FA_SINK)
@@ -198,6 +204,7 @@ static KArgs make_args(fa_ctx* c) {
     a.key_sets = c->cfg.key_sets;
     a.wtab = c->wtab;
     a.wmask = (1u << c->wcap_log2) - 1;
+    a.wplog2 = wide_plog2(c->wcap_log2);
     a.wspill = c->wspill;
     a.wspill_cap = c->wspill_cap;
     a.port_hist = c->port_hist;
@@ -273,6 +280,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
     if (const char* d = getenv("FA_AGG")) c->agg_generic = !strcmp(d, "generic");
     if (const char* d = getenv("FA_CMS")) c->cms_atomic = !strcmp(d, "atomic");
+    if (const char* d = getenv("FA_WIDE")) c->wide_atomic = !strcmp(d, "atomic");
     c->cms_sl2 = (uint32_t)std::max<int>(0, (int)log2_ceil((uint64_t)cfg.cms_depth << cfg.cms_width_log2) - 8);
     if (const char* d = getenv("FA_DEFERRED")) c->deferred_beside = !strcmp(d, "beside");
     if (const char* d = getenv("FA_STAGE_THREADS")) c->stage_threads = (unsigned)std::min(64, std::max(1, atoi(d)));
@@ -399,6 +407,8 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->seg_counts);
     (void)hipFree(c->cseg);
     (void)hipFree(c->cseg_counts);
+    (void)hipFree(c->wseg);
+    (void)hipFree(c->wseg_counts);
     for (int i = 0; i < 2; i++) {
         if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
         (void)hipFree(c->d_in[i]);
@@ -751,6 +761,9 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
         (void)hipEventRecord(c->ev_deferred, dstream);
         (void)hipStreamWaitEvent(c->stream, c->ev_deferred, 0);
     }
+    // fold the (SrcAddr,DstPort,Proto) tuples: one workgroup per table region, plain loads and stores - behind every
+    // dispatch of this launch that updates the wide table with atomics (wagg.cuh)
+    if (MODE == MODE_INGEST && wave_tiles && a.wseg) hipLaunchKernelGGL(wagg_kernel, dim3(1u << a.wplog2), dim3(WAGG_BLOCK), 0, c->stream, a);
     if (ev) (void)hipEventRecord(ev->e2, c->stream);
     HIPCHK(c, hipGetLastError());
     return FA_OK;
@@ -862,6 +875,40 @@ static int ensure_csegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     return FA_OK;
 }
 
+// Segments of the wide scatter sink for a batch of n records processed by nwg workgroups: per (table region, workgroup)
+// 2x the mean + 32 tuples of 32 bytes (what overflows - a heavy key's region - takes the atomic path).
+static int ensure_wsegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
+    const size_t nparts = (size_t)1 << a.wplog2;
+    const size_t mean = n / (nparts * nwg);
+    uint32_t capq = (uint32_t)(2 * mean + 32);
+    if (c->seg_cap_limit) capq = std::max<uint32_t>(std::min(capq, c->seg_cap_limit), 4u);  // (tests: force the overflow fallback)
+    const size_t region = (size_t)nwg * capq + 6;  // (skew against power-of-two strides)
+    const size_t bytes = region * nparts * 2 * sizeof(uint4);
+    if (c->wseg_bytes < bytes) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->wseg);
+        c->wseg = nullptr;
+        c->wseg_bytes = 0;
+        if (hipMalloc(&c->wseg, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide tuple segments) failed");
+        c->wseg_bytes = bytes;
+    }
+    const size_t ncnt = (size_t)nwg * nparts;
+    if (c->wseg_counts_cap < ncnt) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->wseg_counts);
+        c->wseg_counts = nullptr;
+        c->wseg_counts_cap = 0;
+        if (hipMalloc(&c->wseg_counts, ncnt * sizeof(uint32_t)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide segment counts) failed");
+        c->wseg_counts_cap = ncnt;
+    }
+    a.wseg = c->wseg;
+    a.wseg_counts = c->wseg_counts;
+    a.wcapq = capq;
+    a.wregion = region;
+    a.nwg = nwg;
+    return FA_OK;
+}
+
 extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const void* d_off, size_t n) {
     FA_ON_DEVICE(c);
     if (!c) return FA_ERR_ARG;
@@ -925,6 +972,10 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     }
     if (c->use_wave_tiles && (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) && !c->cms_atomic && c->cms_sl2 <= CMS_SLICE_LOG2_MAX) {
         rc = ensure_csegments(c, n, (uint32_t)grid, a);
+        if (rc) return rc;
+    }
+    if (c->use_wave_tiles && c->wtab && (c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO) && !c->wide_atomic && grid <= WAGG_MAX_NWG) {
+        rc = ensure_wsegments(c, n, (uint32_t)grid, a);
         if (rc) return rc;
     }
     if (c->ev_used == c->ev_pool.size()) {

@@ -24,7 +24,8 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                                           bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
                                           LaneTally& tally, uint32_t& pmode, uint32_t& lt_seen, uint32_t& lt_hits,
                                           uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook(),
-                                          CmsLds* cl = nullptr, uint32_t* cms_scratch = nullptr, HotAddrs* hot = nullptr) {
+                                          CmsLds* cl = nullptr, uint32_t* cms_scratch = nullptr, HotAddrs* hot = nullptr,
+                                          uint32_t* wpart_cnt = nullptr) {
     constexpr uint32_t TB = bin_cap<T8, bin_line(KEYSETS)>();
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false, framed_ok = false;
@@ -231,7 +232,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         if (vs && keys_on) keyset_finish(a, a.ks_src, ps, slo, shi);
         if (vd && keys_on) keyset_finish(a, a.ks_dst, pd, dlo, dhi);
     }
-    if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb);
+    if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb, tb_base, wpart_cnt);
 }
 
 // End-of-kernel counters: one global atomic per WORKGROUP.  All waves of the grid finish at about the same
@@ -575,6 +576,8 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
     __shared__ uint32_t bin_cnt[NPART_MAX];
     __shared__ uint32_t part_cnt[NPART_MAX];
     __shared__ uint32_t flush_scratch[WAVES * 16];
+    constexpr bool HAS_APP = (KEYSETS & FA_KEYS_ADDR_PORT_PROTO) != 0;
+    __shared__ uint32_t wpart_cnt[HAS_APP ? (1u << WIDE_PLOG2_MAX) : 1u];  // tuples per region of the wide table (scatter sink, wagg.cuh)
     __shared__ LdsTable<LDS_SLOTS> lt;
     __shared__ LdsMinutes lm;
 
@@ -588,6 +591,8 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
         }
     }
     if (KEYSETS & FA_KEYS_MINUTE_SERIES) lds_minutes_clear(lm);
+    if (HAS_APP)
+        for (int i = tid; i < (1 << WIDE_PLOG2_MAX); i += WBLOCK) wpart_cnt[i] = 0;
     CmsLds* const cl = (HAS_CMS && a.cseg) ? cms_lds.get() : nullptr;
     HotAddrs* const hot = (HAS_CMS && (a.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) ? hot_lds.get() : nullptr;
     if (HAS_CMS && cl)
@@ -671,7 +676,8 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
                 a.exotic_idx[j] = cur.r0 + lane;
             }
             lane_work<MODE_INGEST, KEYSETS, COLS, T8>(a, lt, lm, part_cnt, tb, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, tally,
-                                                      pmode, lt_seen, lt_hits, bins, bin_cnt, fill, after_parse, cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0), hot);
+                                                      pmode, lt_seen, lt_hits, bins, bin_cnt, fill, after_parse, cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0), hot,
+                                                      (HAS_APP && a.wseg) ? wpart_cnt : nullptr);
         }
     };
     // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous
@@ -844,6 +850,10 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
             wkey_pack(WK_MINUTE, 0, 0, 0, lm.key[tid] - 1u, 0, k);
             wagg_global(wargs(a), k, lm.w[tid], 0, lm.c[tid]);
         }
+    }
+    if (HAS_APP && a.wseg) {  // how many wide tuples this workgroup left in each region's segment
+        __syncthreads();
+        for (int i = tid; i < (1 << a.wplog2); i += WBLOCK) a.wseg_counts[(size_t)i * a.nwg + blockIdx.x] = min(wpart_cnt[i], a.wcapq);
     }
     if (KEYSETS & FA_KEYS_AS_PAIR) {
         __syncthreads();

@@ -23,4 +23,5 @@
 #include "sinks.cuh"
 #include "ingest.cuh"
 #include "agg.cuh"
+#include "wagg.cuh"
 #include "maintenance.cuh"

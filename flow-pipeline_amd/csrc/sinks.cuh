@@ -165,11 +165,17 @@ struct KArgs {
     uint32_t wmask;
     WSpillEntry* wspill;
     uint32_t wspill_cap;
+    // scatter sink of the (SrcAddr,DstPort,Proto) key set (wseg == nullptr: every update is a chain of memory-side atomics)
+    uint4* wseg;             // [2^wplog2][wregion] 32-byte tuples (wide.cuh, wtup_pack); region p, workgroup w: tuple p*wregion + w*wcapq + q
+    uint32_t* wseg_counts;   // [2^wplog2][nwg]
+    uint32_t wcapq;
+    uint32_t wplog2;         // log2(regions of the wide table) = wide_plog2(log2 slots)
+    unsigned long long wregion;
     ulonglong2* port_hist;  // [2][PORT_DENSE] {sum(Bytes*SamplingRate), count()}: SrcPort, then DstPort
 };
 
 __device__ __forceinline__ WArgs wargs(const KArgs& a) {
-    return WArgs{a.wtab, a.wmask, a.wspill, a.wspill_cap, &a.ctr->wspill_count, &a.ctr->wspill_lost, &a.ctr->wused};
+    return WArgs{a.wtab, a.wmask, a.wmask >> a.wplog2, a.wspill, a.wspill_cap, &a.ctr->wspill_count, &a.ctr->wspill_lost, &a.ctr->wused};
 }
 // does this kernel variant serve key set X for this launch?
 template <uint32_t KEYSETS>
@@ -189,7 +195,7 @@ __device__ __forceinline__ void agg_global(const KArgs& a, uint64_t k0, uint64_t
         unsigned long long c1 = s->k1;
         if (c1 == 0) {
             c1 = atomicCAS(&s->k1, 0ull, (unsigned long long)k1);
-            if (c1 == 0) atomicAdd(&a.ctr->used, 1ull);  // this lane created the group
+            if (c1 == 0) count_created(&a.ctr->used);  // this lane created the group
         }
         if (c1 != 0 && c1 != k1) continue;
         if (b) atomicAdd(&s->bytes, (unsigned long long)b);
@@ -647,7 +653,7 @@ __device__ __forceinline__ Slot* table_find_or_claim(const KArgs& a, uint64_t k0
         if (c0 != 0 && c0 != k0) continue;
         if (c1 == 0) {
             c1 = atomicCAS(&s->k1, 0ull, (unsigned long long)k1);
-            if (c1 == 0) atomicAdd(&a.ctr->used, 1ull);  // this lane created the group
+            if (c1 == 0) count_created(&a.ctr->used);  // this lane created the group
         }
         if (c1 != 0 && c1 != k1) continue;
         return s;
@@ -750,7 +756,8 @@ __device__ __forceinline__ void wide_sink_slow(const KArgs& a, const Rec& r, uin
 
 // Full-wave form (tile kernel): one atomic line transaction per record and key set.
 template <uint32_t KEYSETS>
-__device__ __forceinline__ void wide_sink_wave(const KArgs& a, LdsMinutes& lm, const Rec& r, bool sure, uint32_t tb) {
+__device__ __forceinline__ void wide_sink_wave(const KArgs& a, LdsMinutes& lm, const Rec& r, bool sure, uint32_t tb, uint32_t tb_base = 0,
+                                               uint32_t* wpart_cnt = nullptr) {
     const WArgs t = wargs(a);
     const uint64_t wgt = r.bytes * r.sampling_rate;
     if (ks_on<KEYSETS>(a, FA_KEYS_ADDR_PORT_PROTO)) {
@@ -758,10 +765,28 @@ __device__ __forceinline__ void wide_sink_wave(const KArgs& a, LdsMinutes& lm, c
         if (sure) {
             WKey k;
             app_key(a, r, tb, k);
-            sp = wtable_find_or_claim(t, k, wkey_hash(k));
-            if (!sp) wspill_park(t, k, r.bytes, r.packets, 1);
+            const uint32_t h = wkey_hash(k);
+            bool done = false;
+            // wave-tile kernel: the update leaves as one 32-byte tuple into this workgroup's segment of the key's table
+            // region (one sector store; wagg_kernel folds the region's tuples without atomics on the sums)
+            if (wpart_cnt && a.wseg && wtup_fits(tb - tb_base, r.packets, r.dst_port, r.proto)) {
+                const uint32_t part = (h & t.mask) >> __builtin_popcount(t.rmask);  // region of the home slot
+                const uint32_t pos = atomicAdd(&wpart_cnt[part], 1u);
+                if (pos < a.wcapq) {
+                    uint4 q0, q1;
+                    wtup_pack(r.src, tb - tb_base, r.bytes, r.packets, r.dst_port, r.proto, q0, q1);
+                    uint4* dst = a.wseg + 2u * ((size_t)part * a.wregion + (size_t)blockIdx.x * a.wcapq + pos);
+                    dst[0] = q0;
+                    dst[1] = q1;
+                    done = true;
+                }
+            }
+            if (!done) {
+                sp = wtable_find_or_claim(t, k, h);
+                if (!sp) wspill_park(t, k, r.bytes, r.packets, 1);
+            }
         }
-        quad_atomic_update_at<4>((uint64_t)sp, r.bytes, r.packets, 1);
+        if (__builtin_amdgcn_ballot_w64(sp != nullptr) != 0ull) quad_atomic_update_at<4>((uint64_t)sp, r.bytes, r.packets, 1);
     }
     if (ks_on<KEYSETS>(a, FA_KEYS_PORT_HIST)) {
         uint64_t ps = 0, pd = 0;

@@ -35,6 +35,15 @@
 
 namespace fa {
 
+// One more group in a table: called by every lane that has just created one, from divergent code.  The lanes that
+// are active here are counted with one atomic by the first of them (a per-lane atomicAdd on the one counter word
+// serialises the whole chip when most records open a new group - config 5's (SrcAddr,DstPort,Proto) rows).
+__device__ __forceinline__ void count_created(unsigned long long* used) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+    if (__lane_id() == (uint32_t)__builtin_ctzll(m)) atomicAdd(used, (unsigned long long)__builtin_popcountll(m));
+}
+
+
 #if FA_WT_EARLY && defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;

@@ -65,9 +65,18 @@ __host__ __device__ __forceinline__ uint32_t wkey_hash(const WKey& k) {
     return h1 ^ (h0 >> 7);
 }
 
+// The table is cut into 2^wide_plog2 aligned regions and a probe sequence never leaves the region of the key's home
+// slot (it wraps inside it).  Nothing changes for the atomic paths; it is what lets wagg_kernel (wagg.cuh) hand each
+// region to ONE workgroup that updates it with plain loads and stores.  Regions hold at least 64 slots.
+constexpr uint32_t WIDE_PLOG2_MAX = 8;
+__host__ __device__ constexpr uint32_t wide_plog2(uint32_t cap_log2) {
+    return cap_log2 >= WIDE_PLOG2_MAX + 6u ? WIDE_PLOG2_MAX : cap_log2 > 6u ? cap_log2 - 6u : 0u;
+}
+
 struct WArgs {
     WSlot* tab;
     uint32_t mask;
+    uint32_t rmask;  // slots per region - 1
     WSpillEntry* spill;
     uint32_t spill_cap;
     unsigned int* spill_count;        // Counters::wspill_count
@@ -75,10 +84,29 @@ struct WArgs {
     unsigned long long* used;         // Counters::wused
 };
 
+// ---- scattered form of a (SrcAddr,DstPort,Proto) update: 32 bytes = two uint4 -------------------------------
+//   q0 = SrcAddr (16 bytes)      q1 = { Bytes lo, Bytes hi, Packets (32 bits), DstPort | Proto << 16 | tbr << 24 }
+// tbr = time bucket relative to the launch's tb_base.  count() is 1 per tuple.  What does not fit (ports >= 2^16 and
+// protocol numbers >= 2^8 - the columns are UInt32, create.sh:19-22 -, Packets >= 2^32, a record 256 buckets away
+// from the batch) takes the atomic path.
+__host__ __device__ __forceinline__ bool wtup_fits(uint32_t tbr, uint64_t packets, uint32_t port, uint32_t proto) {
+    return tbr < 256u && (packets >> 32) == 0 && port < 65536u && proto < 256u;
+}
+__host__ __device__ __forceinline__ void wtup_pack(const uint32_t addr[4], uint32_t tbr, uint64_t bytes, uint64_t packets, uint32_t port,
+                                                   uint32_t proto, uint4& q0, uint4& q1) {
+    q0 = make_uint4(addr[0], addr[1], addr[2], addr[3]);
+    q1 = make_uint4((uint32_t)bytes, (uint32_t)(bytes >> 32), (uint32_t)packets, port | proto << 16 | tbr << 24);
+}
+__host__ __device__ __forceinline__ void wtup_unpack(const uint4& q0, const uint4& q1, uint32_t tb_base, WKey& k, uint64_t& bytes, uint64_t& packets) {
+    wkey_pack(WK_APP, tb_base + (q1.w >> 24), (uint64_t)q0.y << 32 | q0.x, (uint64_t)q0.w << 32 | q0.z, q1.w & 0xffffu, (q1.w >> 16) & 0xffu, k);
+    bytes = (uint64_t)q1.y << 32 | q1.x;
+    packets = q1.z;
+}
+
 // Finds or claims the slot of k; nullptr when the probe limit is hit (the caller parks the update).
 __device__ __forceinline__ WSlot* wtable_find_or_claim(const WArgs& t, const WKey& k, uint32_t h) {
     uint32_t i = h & t.mask;
-    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i + 1) & t.mask) {
+    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i & ~t.rmask) | ((i + 1) & t.rmask)) {
         WSlot* s = &t.tab[i];
         const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&s->w[0]);
         const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&s->w[2]);
@@ -92,7 +120,7 @@ __device__ __forceinline__ WSlot* wtable_find_or_claim(const WArgs& t, const WKe
                 c[j] = atomicCAS(&s->w[j], 0ull, k.w[j]);
                 if (c[j] == 0) {
                     c[j] = k.w[j];
-                    if (j == 3) atomicAdd(t.used, 1ull);  // this lane created the group
+                    if (j == 3) count_created(t.used);  // this lane created the group
                 }
             }
             mine = c[j] == k.w[j];

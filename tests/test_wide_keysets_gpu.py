@@ -211,3 +211,47 @@ def test_config5_shape_at_scale(gpu_lib, fa, po):
         for d in (0, 1):
             _same(agg.top_ports(d), po.top_ports(rows, status, d), ("port", "weight", "count"))
         _same(agg.minute_series(), po.minute_series(rows, status), ("minute", "weight", "count"))
+
+
+def _app_device_run(fa, po, n, chunk, **kw):
+    """n records generated in HBM, ingested in chunks with key sets flows_5m + (SrcAddr,DstPort,Proto); returns
+    (flows_5m rows, app rows, stats)."""
+    import torch
+    mp = fa.mock_params(**kw)
+    dev = torch.device("cuda", 0)
+    ks = fa.FA_KEYS_AS_PAIR | fa.FA_KEYS_ADDR_PORT_PROTO
+    with fa.FlowAgg(framed=True, key_sets=ks, wide_capacity_log2=16, max_batch_records=chunk) as agg:
+        d_buf = torch.empty(chunk * 96 + 4096, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(chunk + 1, dtype=torch.int32, device=dev)
+        for i0 in range(0, n, chunk):
+            m = min(chunk, n - i0)
+            w = agg.mock_generate_device(mp, i0, m, d_buf.data_ptr(), d_buf.numel(), d_off.data_ptr())
+            agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
+        return agg.read_window(), agg.read_window_app(), agg.stats()
+
+
+@pytest.mark.parametrize("variant", ["default", "atomic", "tiny_segments"])
+@pytest.mark.parametrize("zs,lu", [(80, 22), (140, 10)])
+def test_app_scatter_sink_equals_oracle(gpu_lib, fa, po, monkeypatch, variant, zs, lu):
+    """The (SrcAddr,DstPort,Proto) scatter sink (wagg.cuh: tuples per table region, one workgroup per region, plain
+    loads and stores) against the oracle on 2 M records in four launches, with table growth from 2^16 slots between
+    them: almost-all-distinct keys (Zipf 0.8 over 2^22 addresses) and heavy duplicates (Zipf 1.4 over 2^10: the LDS
+    deduplication and the segment-overflow fallback of a heavy key's region).  The same through the atomic path
+    (FA_WIDE=atomic) and with segments far too small (FA_SEG_CAP: most tuples overflow into the atomic path)."""
+    if variant == "atomic":
+        monkeypatch.setenv("FA_WIDE", "atomic")
+    if variant == "tiny_segments":
+        monkeypatch.setenv("FA_SEG_CAP", "40")
+    n, chunk = 2_000_000, 500_000
+    kw = dict(mode=2, framed=1, seed=77, n_total=n, span_secs=900, zipf_log2_universe=lu, zipf_s_x100=zs)
+    gp = po.gen_params(**kw)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    assert status.sum() == 0
+    ref = po.Rollup(300)
+    ref.ingest(buf, off, 1)
+    want_app = po.rollup_app(rows, status, 300)
+    got, got_app, st = _app_device_run(fa, po, n, chunk, **kw)
+    assert got.tobytes() == ref.rows().tobytes()
+    _same(got_app, want_app, APP_COLS)
+    assert st["wide_used"] == len(want_app) and st["records_ok"] == n

@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--records", type=int, default=100_000_000)
     ap.add_argument("--chunk", type=int, default=16_666_667)
     ap.add_argument("--span", type=int, default=1800, help="seconds of event time the stream covers (6 windows)")
+    ap.add_argument("--wide-log2", type=int, default=28, help="slots of the (SrcAddr,DstPort,Proto) table, log2")
+    ap.add_argument("--universe-log2", type=int, default=24)
     args = ap.parse_args()
     import torch
     fa = _pkg.load()
@@ -54,12 +56,12 @@ def main():
     dev = torch.device("cuda", 0)
     n = args.records
     threads = min(64, len(os.sched_getaffinity(0)))
-    mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=5, n_total=n, span_secs=args.span, zipf_log2_universe=24, zipf_s_x100=80)
-    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=5, n_total=n, span_secs=args.span, zipf_log2_universe=24, zipf_s_x100=80)
+    mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=5, n_total=n, span_secs=args.span, zipf_log2_universe=args.universe_log2, zipf_s_x100=80)
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=5, n_total=n, span_secs=args.span, zipf_log2_universe=args.universe_log2, zipf_s_x100=80)
     ks = fa.FA_KEYS_AS_PAIR | fa.FA_KEYS_ADDR_PORT_PROTO
     out = {"config": "BASELINE configs[4], single-GPU shape: (SrcAS,DstAS) + (SrcAddr,DstPort,Proto), 60-s sub-buckets, 5-min windows "
                      "(tumbling + sliding by 60 s), %d framed FlowMessages, Zipf-0.8, seed 5, %d s of event time" % (n, args.span)}
-    with fa.FlowAgg(framed=True, key_sets=ks, window_secs=300, subwindow_secs=60, wide_capacity_log2=28, table_capacity_log2=22,
+    with fa.FlowAgg(framed=True, key_sets=ks, window_secs=300, subwindow_secs=60, wide_capacity_log2=args.wide_log2, table_capacity_log2=22,
                     max_batch_records=args.chunk) as agg:
         cap = args.chunk * 96 + 4096
         d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Instruction counts of the wave-tile kernel per section, by ablation (FA_DEBUG_FLAGS): one PMC pass per flag set.
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/inst
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+for f in ${FLAGS:-0 16 1 17}; do
+  FA_DEBUG_FLAGS=$f rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/f$f -o p -- \
+    python $ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-verify --no-host-fed --no-assert $BENCH_ARGS > $OUT/f$f.log 2>&1
+done
+cd $ROOT
+python - <<'PY'
+import csv, glob, os, collections
+root = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out/inst")
+for d in sorted(glob.glob(root + "/f*/")):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "wtile" not in k and "agg8" not in k: continue
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "SQ_INSTS_VALU": n[k] += 1
+    for k in acc:
+        print(os.path.basename(d.rstrip("/")), k[:40], "launches", n[k], " ".join("%s=%.1fM" % (c.replace("SQ_", ""), v / max(n[k], 1) / 1e6) for c, v in sorted(acc[k].items())))
+PY
