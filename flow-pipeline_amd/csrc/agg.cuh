@@ -317,9 +317,12 @@ struct Agg8Table {
     unsigned long long key[AGG8_ALL], s1[AGG8_ALL], s2[AGG8_ALL];  // key = 1 << 63 | kh << 32 | lo;  sums as in AggTable
 };
 __device__ __forceinline__ unsigned long long agg8_key(const uint2& t) { return (1ull << 63) | ((unsigned long long)(t.y >> 26) << 32) | t.x; }
+__device__ __forceinline__ uint32_t agg8_mix(const uint2& t) { return (t.x ^ ((t.y >> 26) * 0x9E3779B1u)) * 0x85EBCA6Bu; }
 __device__ __forceinline__ uint32_t agg8_home(const uint2& t) {
-    return ((t.x ^ ((t.y >> 26) * 0x9E3779B1u)) * 0x85EBCA6Bu) >> 20;  // 12 bits; the partition came out of a different mix (t8_mix8)
+    return agg8_mix(t) >> 20;  // 12 bits; the partition came out of a different mix (t8_mix8)
 }
+// which pass of a multi-pass aggregation takes this tuple (bits of the mix below the home slot's)
+__device__ __forceinline__ uint32_t agg8_sub(const uint2& t) { return (agg8_mix(t) >> 17) & 7u; }
 __device__ __forceinline__ void agg8_global(const KArgs& a, uint32_t tb_base, uint32_t part, const uint2& t, uint32_t by, uint32_t pk) {
     TupleVals v;
     t8_unpack(t, part, v);
@@ -385,8 +388,9 @@ __device__ __forceinline__ void agg8_fetch(uint32_t capq, uint32_t nwg, const ui
 __device__ __forceinline__ void agg8_drain(const KArgs& a, Agg8Table& lt, uint32_t tb_base, uint32_t part, uint32_t lane, const uint2* queue, uint32_t qn) {
     if (lane < qn) agg8_tuple(a, lt, tb_base, part, queue[lane]);
 }
+// (pmask, pass: this pass takes the tuples with agg8_sub & pmask == pass; pmask = 0: all of them)
 __device__ __forceinline__ void agg8_consume(const KArgs& a, Agg8Table& lt, uint32_t tb_base, uint32_t part, uint32_t lane, const Agg8Batch& b,
-                                             uint2* queue, uint32_t& qn) {
+                                             uint2* queue, uint32_t& qn, uint32_t pmask, uint32_t pass) {
     uint2 t[AGG8_NT];
     unsigned long long key[AGG8_NT], c0[AGG8_NT], c1[AGG8_NT];
     uint32_t home[AGG8_NT];
@@ -410,6 +414,7 @@ __device__ __forceinline__ void agg8_consume(const KArgs& a, Agg8Table& lt, uint
 #pragma unroll
     for (int e = 0; e < AGG8_NT; e++) {
         if (!((b.v >> e) & 1u)) continue;
+        if (pmask && (agg8_sub(t[e]) & pmask) != pass) continue;
         const bool at0 = c0[e] == key[e], at1 = c1[e] == key[e];
         if (at0 || at1) {
             const uint32_t s = home[e] + (at0 ? 0u : 1u);
@@ -471,6 +476,16 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
     }
     __syncthreads();
     uint2* queue = queues + wave * 64;
+    // Multi-pass form (a.agg_passes > 1, chosen by the host from the groups the previous launches produced): when a
+    // partition holds more groups than the LDS table, every tuple that finds the table full is a chain of memory-side
+    // atomics (config 5: 60-second sub-buckets, 5 k groups per partition and launch - 2.6 ms instead of 0.1).  Pass s
+    // takes the tuples whose key mixes to s, folds them, adds the groups to the device table and clears the LDS table;
+    // the tuples of a partition (0.5 MB) are re-read from L2.
+    const uint32_t npass = max(a.agg_passes, 1u), pmask = npass - 1u;
+    uint32_t my_groups = 0;
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < npass; pass++) {
+    const unsigned long long tm0 = (a.dbg & DBG_TIMING) ? clock64() : 0ull;
     uint32_t qn = 0;
     // Work items of a wave: (group g, level j), g = wave, wave + WAVES, ...; j < levels(g).  The loads of the next item
     // fly while the current one is consumed (two register buffers; every fetch is unconditional - an item past the end
@@ -492,12 +507,12 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
             j++;                                                                                            \
             settle_item();                                                                                  \
             agg8_fetch<BACK, AGG8_SU>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b1);                                      \
-            agg8_consume(a, lt, tb_base, part, lane, b0, queue, qn);                                        \
+            agg8_consume(a, lt, tb_base, part, lane, b0, queue, qn, pmask, pass);                                       \
             if (g >= ngroups) break;                                                                        \
             j++;                                                                                            \
             settle_item();                                                                                  \
             agg8_fetch<BACK, AGG8_SU>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                                      \
-            agg8_consume(a, lt, tb_base, part, lane, b1, queue, qn);                                        \
+            agg8_consume(a, lt, tb_base, part, lane, b1, queue, qn, pmask, pass);                                       \
         }                                                                                                   \
     }
     FA_AGG8_PASS(false, flv, NFG, FGRP, pc)
@@ -505,38 +520,95 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
 #undef FA_AGG8_PASS
     agg8_drain(a, lt, tb_base, part, lane, queue, qn);
     __syncthreads();
+    const unsigned long long tm1 = (a.dbg & DBG_TIMING) ? clock64() : 0ull;
     if (a.dbg & DBG_AGG_NO_FLUSH) return;
     // every group of this partition goes to the device-wide table once (quad-grouped: one atomic line transaction per
     // group; uniform trip count: the whole wave takes part in the quad rounds)
-    constexpr int NF = (AGG8_ALL + AGG_BLOCK - 1) / AGG_BLOCK;
-    unsigned long long fk0[NF], fk1[NF], fs1[NF], fs2[NF];
-    ulonglong2 home[NF];
-    uint32_t fh[NF];
+    constexpr int NF = (AGG8_ALL + AGG_BLOCK - 1) / AGG_BLOCK, FB = 3;  // slots per thread, in blocks of FB (registers)
+#pragma unroll 1
+    for (int q0 = 0; q0 < NF; q0 += FB) {
+        unsigned long long fk0[FB], fk1[FB], fs1[FB], fs2[FB];
+        ulonglong2 home[FB];
+        uint32_t fh[FB];
 #pragma unroll
-    for (int q = 0; q < NF; q++) {  // phase 1: the home-slot probes of this thread's groups fly together
-        const int i = q * AGG_BLOCK + threadIdx.x;
-        const unsigned long long key = i < AGG8_ALL ? lt.key[i] : 0ull;
-        fs1[q] = i < AGG8_ALL ? lt.s1[i] : 0ull;
-        fs2[q] = i < AGG8_ALL ? lt.s2[i] : 0ull;
-        TupleVals v;
-        t8_unpack(make_uint2((uint32_t)key, (uint32_t)(key >> 32) << 26), part, v);
-        uint64_t k0, k1;
-        pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);
-        fk0[q] = key ? k0 : 0ull;
-        fk1[q] = key ? k1 : 0ull;
-        fh[q] = key_hash(k0, k1);
-        home[q] = *reinterpret_cast<const ulonglong2*>(&a.tab[fh[q] & a.mask]);
-    }
-#pragma unroll
-    for (int q = 0; q < NF; q++) {
-        Slot* sp = nullptr;
-        const unsigned long long b = fs1[q], p = fs2[q] >> 25, c = fs2[q] & 0x1ffffffull;
-        if (fk0[q] != 0 && fs2[q] != 0) {
-            if (home[q].x == fk0[q] && home[q].y == fk1[q]) sp = &a.tab[fh[q] & a.mask];
-            else sp = table_find_or_claim(a, fk0[q], fk1[q], fh[q]);
-            if (!sp) spill_park(a, fk0[q], fk1[q], b, p, c);
+        for (int q = 0; q < FB; q++) {  // phase 1: the home-slot probes of this thread's groups fly together
+            const int i = (q0 + q) * AGG_BLOCK + threadIdx.x;
+            const unsigned long long key = i < AGG8_ALL ? lt.key[i] : 0ull;
+            fs1[q] = i < AGG8_ALL ? lt.s1[i] : 0ull;
+            fs2[q] = i < AGG8_ALL ? lt.s2[i] : 0ull;
+            TupleVals v;
+            t8_unpack(make_uint2((uint32_t)key, (uint32_t)(key >> 32) << 26), part, v);
+            uint64_t k0, k1;
+            pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);
+            fk0[q] = key ? k0 : 0ull;
+            fk1[q] = key ? k1 : 0ull;
+            fh[q] = key_hash(k0, k1);
+            home[q] = *reinterpret_cast<const ulonglong2*>(&a.tab[fh[q] & a.mask]);
         }
-        quad_atomic_update(sp, b, p, c);
+        // phase 2: groups whose home slot is empty claim it - the two key words with one CAS each, issued for all FB
+        // groups of the thread before the first answer is awaited (a launch that opens a million new groups - a new
+        // time bucket - would otherwise walk FB x 2 dependent memory-side round trips of ~15 us under load)
+        unsigned long long r0[FB], r1[FB];
+        bool valid[FB], claim[FB];
+#pragma unroll
+        for (int q = 0; q < FB; q++) {
+            valid[q] = fk0[q] != 0 && fs2[q] != 0;
+            claim[q] = valid[q] && home[q].x == 0;
+            r0[q] = home[q].x;
+            r1[q] = home[q].y;
+            if (claim[q]) r0[q] = atomicCAS(&a.tab[fh[q] & a.mask].k0, 0ull, fk0[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < FB; q++) {
+            if (claim[q]) {
+                if (r0[q] == 0) r0[q] = fk0[q];
+                claim[q] = r0[q] == fk0[q];  // (lost the slot to another key: the probing path below)
+                if (claim[q]) r1[q] = atomicCAS(&a.tab[fh[q] & a.mask].k1, 0ull, fk1[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < FB; q++) {
+            Slot* sp = nullptr;
+            const unsigned long long b = fs1[q], p = fs2[q] >> 25, c = fs2[q] & 0x1ffffffull;
+            if (valid[q]) {
+                my_groups++;
+                if (claim[q] && r1[q] == 0) {  // this lane created the group
+                    count_created(&a.ctr->used);
+                    r1[q] = fk1[q];
+                }
+                if (r0[q] == fk0[q] && r1[q] == fk1[q]) sp = &a.tab[fh[q] & a.mask];
+                else sp = table_find_or_claim(a, fk0[q], fk1[q], fh[q]);
+                if (!sp) spill_park(a, fk0[q], fk1[q], b, p, c);
+            }
+            quad_atomic_update(sp, b, p, c);
+        }
+    }
+    if ((a.dbg & DBG_TIMING) && threadIdx.x == 0) {  // (FA_DEBUG_FLAGS=1024: core clocks per workgroup and pass - fold / add to the device table)
+        __builtin_amdgcn_s_waitcnt(0);
+        atomicAdd(&a.ctr->t_wait, tm1 - tm0);
+        atomicAdd(&a.ctr->t_work, (unsigned long long)clock64() - tm1);
+        atomicAdd(&a.ctr->t_tiles, 1ull);
+    }
+    if (pass + 1 < npass) {  // next pass: empty table
+        __syncthreads();
+        for (int i = threadIdx.x; i < AGG8_ALL; i += AGG_BLOCK) {
+            lt.key[i] = 0;
+            lt.s1[i] = 0;
+            lt.s2[i] = 0;
+        }
+        __syncthreads();
+    }
+    }
+    // pass-count feedback: groups this launch added to the device table
+    const uint32_t gw = (uint32_t)wave_sum_u64(my_groups);
+    __syncthreads();
+    if (threadIdx.x == 0) pc[0] = 0;
+    __syncthreads();
+    if (lane == 0 && gw) atomicAdd(&pc[0], gw);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (pc[0]) atomicAdd(&a.ctr->agg_groups, (unsigned long long)pc[0]);
+        if (blockIdx.x == 0) atomicAdd(&a.ctr->agg_launches, 1ull);
     }
 }
 

@@ -88,6 +88,9 @@ struct fa_ctx {
     int t8_mode = 0;              // env FA_TUPLE: 0 adaptive, 1 always compact ("8"), 2 always wide ("16")
     uint64_t t8_wide_until = 0;   // batches counter value up to which wide tuples are used
     uint64_t seen_misfit8 = 0, seen_ok = 0;  // counter values at the last look
+    uint64_t seen_agg_groups = 0, seen_agg_launches = 0;
+    uint32_t agg_passes_forced = 0;  // env FA_AGG_PASSES (tests, A/B)
+    uint32_t agg_passes = 1;      // agg8_kernel passes for the next launch (1, 2, 4, 8): groups per launch / (partitions x passes) <= half the LDS table
     unsigned stage_threads = 8;   // host threads of the staging copy (fa_ingest)
     bool deferred_beside = false; // env FA_DEFERRED=beside (A/B): second-chance kernel on the side stream, beside the aggregation
     bool agg_generic = false;     // env FA_AGG=generic (A/B): compact tuples through the two-word-key aggregation kernel
@@ -210,6 +213,7 @@ static KArgs make_args(fa_ctx* c) {
     a.port_hist = c->port_hist;
     a.gran_recip = (1.0 / (double)c->gran) * (1.0 + 1.0 / 1099511627776.0);
     a.par = c->par;
+    a.agg_passes = c->agg_passes_forced ? c->agg_passes_forced : c->agg_passes;
     return a;
 }
 
@@ -281,6 +285,10 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_AGG")) c->agg_generic = !strcmp(d, "generic");
     if (const char* d = getenv("FA_CMS")) c->cms_atomic = !strcmp(d, "atomic");
     if (const char* d = getenv("FA_WIDE")) c->wide_atomic = !strcmp(d, "atomic");
+    if (const char* d = getenv("FA_AGG_PASSES")) {
+        const int v = atoi(d);
+        c->agg_passes_forced = (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 0u;
+    }
     c->cms_sl2 = (uint32_t)std::max<int>(0, (int)log2_ceil((uint64_t)cfg.cms_depth << cfg.cms_width_log2) - 8);
     if (const char* d = getenv("FA_DEFERRED")) c->deferred_beside = !strcmp(d, "beside");
     if (const char* d = getenv("FA_STAGE_THREADS")) c->stage_threads = (unsigned)std::min(64, std::max(1, atoi(d)));
@@ -376,6 +384,10 @@ extern "C" void fa_destroy(fa_ctx* c) {
     FA_ON_DEVICE(c);
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (getenv("FA_VERBOSE") && c->d_ctr && c->h_ctr && hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost) == hipSuccess)
+        fprintf(stderr, "[flowagg] agg8: %llu groups added in %llu launches, passes now %u; direct %llu, ok %llu, wide rows %llu\n",
+                (unsigned long long)c->h_ctr->agg_groups, (unsigned long long)c->h_ctr->agg_launches, c->agg_passes,
+                (unsigned long long)c->h_ctr->direct, (unsigned long long)c->h_ctr->ok, (unsigned long long)(c->wused_base + c->h_ctr->wused));
     if ((c->dbg & DBG_TIMING) && c->d_ctr && c->h_ctr && hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost) == hipSuccess &&
         c->h_ctr->t_tiles)
         fprintf(stderr, "[flowagg timing] per tile (wave 0 of every workgroup, core clocks): wait %.0f  work %.0f  | tiles %llu  total/wg-launch %.0f\n",
@@ -550,6 +562,19 @@ static void format_feedback(fa_ctx* c, const Counters& h) {
     if (d_ok && d_mis * 16 > d_ok) c->t8_wide_until = c->stats.batches + 64;
     c->seen_misfit8 = h.misfit8;
     c->seen_ok = h.ok;
+    // passes of agg8_kernel: the groups a launch adds to the device table, per partition and pass, against the LDS table
+    if (h.agg_launches < c->seen_agg_launches || h.agg_groups < c->seen_agg_groups) c->seen_agg_launches = c->seen_agg_groups = 0;
+    const uint64_t d_l = h.agg_launches - c->seen_agg_launches, d_g = h.agg_groups - c->seen_agg_groups;
+    if (d_l) {
+        const uint64_t per_part = d_g / d_l >> c->plog2;
+        uint32_t want = 1;
+        while (want < 8 && per_part > (uint64_t)(AGG8_SLOTS / 2) * want) want *= 2;
+        // (a launch that overflowed its table under-counts: move up one step at a time, down only when clearly below)
+        if (want > c->agg_passes) c->agg_passes = std::min(want, c->agg_passes * 2);
+        else if (want < c->agg_passes && per_part * 3 < (uint64_t)(AGG8_SLOTS / 2) * c->agg_passes) c->agg_passes = std::max(want, c->agg_passes / 2);
+        c->seen_agg_launches = h.agg_launches;
+        c->seen_agg_groups = h.agg_groups;
+    }
 }
 
 // Waits for the stream, folds device counters into stats, replays spills after growing.

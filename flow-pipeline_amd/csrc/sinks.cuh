@@ -97,6 +97,7 @@ struct Counters {
     unsigned long long t_wait, t_work, t_tiles, t_total;  // DBG_TIMING: core-clock cycles of wave 0 of every workgroup
     unsigned long long wused, wspill_lost;  // wide table (wide.cuh)
     unsigned int wspill_count, wrows_count;
+    unsigned long long agg_groups, agg_launches;  // agg8_kernel: groups it added to the device table, launches (pass-count feedback)
 #ifdef FA_WT_TIMING  // measurement builds: per wave slot of the wave-tile kernel {wait, parse+sink, flush+issue, tiles, loop clocks}
     unsigned long long t_slot[16][5];
 #endif
@@ -153,6 +154,7 @@ struct KArgs {
     unsigned long long region;  // tuples per partition (nwg*capq plus a skew against power-of-two strides)
     uint32_t plog2;        // log2(key partitions)
     uint32_t par;          // batch parity: which copy of the deferral counters this batch uses
+    uint32_t agg_passes;   // agg8_kernel: passes over a partition's tuples (1, 2, 4, 8), each with 1 / passes of the groups in the LDS table
     // Count-Min scatter sink (cseg == nullptr: every sketch update is a memory-side atomic, cms_add)
     uint2* cseg;            // [CMS_SETS * CMS_NPART][cregion] sketch tuples; partition p, workgroup w: cseg[p*cregion + w*ccapq + q]
     uint32_t* cseg_counts;  // [2][CMS_SETS * CMS_NPART][nwg]: tuples at the front (whole 64-byte chunks) / at the back of a segment

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--span", type=int, default=1800, help="seconds of event time the stream covers (6 windows)")
     ap.add_argument("--wide-log2", type=int, default=28, help="slots of the (SrcAddr,DstPort,Proto) table, log2")
     ap.add_argument("--universe-log2", type=int, default=24)
+    ap.add_argument("--table-log2", type=int, default=24, help="slots of the flows_5m table, log2 (3.9 M groups at the default span)")
     args = ap.parse_args()
     import torch
     fa = _pkg.load()
@@ -61,7 +62,7 @@ def main():
     ks = fa.FA_KEYS_AS_PAIR | fa.FA_KEYS_ADDR_PORT_PROTO
     out = {"config": "BASELINE configs[4], single-GPU shape: (SrcAS,DstAS) + (SrcAddr,DstPort,Proto), 60-s sub-buckets, 5-min windows "
                      "(tumbling + sliding by 60 s), %d framed FlowMessages, Zipf-0.8, seed 5, %d s of event time" % (n, args.span)}
-    with fa.FlowAgg(framed=True, key_sets=ks, window_secs=300, subwindow_secs=60, wide_capacity_log2=args.wide_log2, table_capacity_log2=22,
+    with fa.FlowAgg(framed=True, key_sets=ks, window_secs=300, subwindow_secs=60, wide_capacity_log2=args.wide_log2, table_capacity_log2=args.table_log2,
                     max_batch_records=args.chunk) as agg:
         cap = args.chunk * 96 + 4096
         d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
