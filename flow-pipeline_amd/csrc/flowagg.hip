@@ -1674,7 +1674,7 @@ static int collect_wide(fa_ctx* c, uint32_t kind_mask, uint32_t tb_lo, uint32_t 
     if (hipMalloc(&d, need * sizeof(WRow)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide rows) failed");
     hipError_t e = hipMemsetAsync(&c->d_ctr->wrows_count, 0, sizeof(unsigned int), c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(wextract_kernel, dim3(1024), dim3(256), 0, c->stream, c->wtab, 1u << c->wcap_log2, kind_mask, tb_lo,
+        hipLaunchKernelGGL(wextract_kernel, dim3(2048), dim3(256), 0, c->stream, c->wtab, 1u << c->wcap_log2, kind_mask, tb_lo,
                            tb_hi, d, (uint32_t)need, c->d_ctr);
         e = hipGetLastError();
     }

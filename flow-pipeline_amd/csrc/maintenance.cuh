@@ -14,19 +14,49 @@ struct Row5m {
     unsigned long long bytes, packets, count;
 };
 
-// Appends rows whose time bucket lies in [tb_lo, tb_hi) to `rows`.
-__global__ void extract_kernel(const Slot* tab, uint32_t nslots, uint32_t gran, uint32_t tb_lo,
-                               uint32_t tb_hi, Row5m* rows, uint32_t rows_cap, Counters* ctr) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) {
-        const Slot& s = tab[i];
-        if (s.k0 == 0 || s.k1 == 0 || s.count == 0) continue;
-        uint32_t tb, sa, da, et;
-        unpack_key(s.k0, s.k1, tb, sa, da, et);
-        if (tb < tb_lo || tb >= tb_hi) continue;
-        unsigned int j = atomicAdd(&ctr->rows_count, 1u);
-        if (j < rows_cap) {
-            uint32_t ts = tb * gran;
-            rows[j] = Row5m{ts / 86400u, ts, sa, da, et, 0, s.bytes, s.packets, s.count};
+// Appends rows whose time bucket lies in [tb_lo, tb_hi) to `rows`.  A wave looks at EX_U x 64 slots per round (all
+// loads first) and takes the positions of the round's rows with one returning atomic - the scan waits for that round
+// trip, not for bandwidth (same as wextract_kernel below).
+constexpr int EX_U = 4;
+__global__ __launch_bounds__(256) void extract_kernel(const Slot* tab, uint32_t nslots, uint32_t gran, uint32_t tb_lo,
+                                                      uint32_t tb_hi, Row5m* rows, uint32_t rows_cap, Counters* ctr) {
+    const uint32_t nthr = gridDim.x * blockDim.x, lane = __lane_id();
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nslots; i0 += EX_U * nthr) {
+        ulonglong2 k[EX_U], bp[EX_U];
+        unsigned long long cnt[EX_U], m[EX_U];
+        bool sel[EX_U];
+        uint32_t total = 0;
+#pragma unroll
+        for (int u = 0; u < EX_U; u++) {
+            const Slot* sp = &tab[min(i0 + (uint32_t)u * nthr, nslots - 1u)];
+            k[u] = *reinterpret_cast<const ulonglong2*>(&sp->k0);
+            bp[u] = *reinterpret_cast<const ulonglong2*>(&sp->bytes);
+            cnt[u] = sp->count;
+        }
+#pragma unroll
+        for (int u = 0; u < EX_U; u++) {
+            uint32_t tb, sa, da, et;
+            unpack_key(k[u].x, k[u].y, tb, sa, da, et);
+            sel[u] = i0 + (uint32_t)u * nthr < nslots && k[u].x != 0 && k[u].y != 0 && cnt[u] != 0 && tb >= tb_lo && tb < tb_hi;
+            m[u] = __builtin_amdgcn_ballot_w64(sel[u]);
+            total += (uint32_t)__builtin_popcountll(m[u]);
+        }
+        if (total != 0u) {  // (wave-uniform)
+            const uint32_t leader = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+            unsigned int base = 0;
+            if (lane == leader) base = atomicAdd(&ctr->rows_count, total);
+            base = (unsigned int)__builtin_amdgcn_readlane((int)base, (int)leader);
+#pragma unroll
+            for (int u = 0; u < EX_U; u++) {
+                const unsigned int j = base + (unsigned int)__builtin_popcountll(m[u] & ((1ull << lane) - 1ull));
+                base += (unsigned int)__builtin_popcountll(m[u]);
+                if (sel[u] && j < rows_cap) {
+                    uint32_t tb, sa, da, et;
+                    unpack_key(k[u].x, k[u].y, tb, sa, da, et);
+                    const uint32_t ts = tb * gran;
+                    rows[j] = Row5m{ts / 86400u, ts, sa, da, et, 0, bp[u].x, bp[u].y, cnt[u]};
+                }
+            }
         }
     }
 }
@@ -93,14 +123,58 @@ __device__ __forceinline__ bool wrow_selected(const unsigned long long w[4], uin
     if (!((kind_mask >> kind) & 1u)) return false;
     return kind != WK_APP || (tb >= tb_lo && tb < tb_hi);
 }
-__global__ void wextract_kernel(const WSlot* tab, uint32_t nslots, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, WRow* rows,
-                                uint32_t rows_cap, Counters* ctr) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) {
-        const WSlot& s = tab[i];
-        if (s.w[0] == 0 || s.w[1] == 0 || s.w[2] == 0 || s.w[3] == 0 || s.v2 == 0) continue;
-        if (!wrow_selected(s.w, kind_mask, tb_lo, tb_hi)) continue;
-        const unsigned int j = atomicAdd(&ctr->wrows_count, 1u);
-        if (j < rows_cap) rows[j] = WRow{{s.w[0], s.w[1], s.w[2], s.w[3]}, s.v0, s.v1, s.v2};
+// A wave looks at WX_U x 64 slots per round (each slot with four independent 16-byte loads) and takes the positions of
+// the round's rows with ONE returning atomic: the scan itself runs at 6 TB/s (tools/micro/scan64.hip), what it waits
+// for is that round trip (41 ms for a 16 GiB table with one atomic per selected row).
+constexpr int WX_U = 4;
+__global__ __launch_bounds__(256) void wextract_kernel(const WSlot* tab, uint32_t nslots, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, WRow* rows,
+                                                       uint32_t rows_cap, Counters* ctr) {
+    const uint32_t nthr = gridDim.x * blockDim.x, lane = __lane_id();
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nslots; i0 += WX_U * nthr) {
+        uint4 q[WX_U][4];
+        bool sel[WX_U];
+        unsigned long long m[WX_U];
+        uint32_t total = 0;
+#pragma unroll
+        for (int u = 0; u < WX_U; u++) {
+            const uint32_t i = i0 + (uint32_t)u * nthr;
+            const uint4* p = reinterpret_cast<const uint4*>(&tab[min(i, nslots - 1u)]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[u][k] = p[k];
+        }
+#pragma unroll
+        for (int u = 0; u < WX_U; u++) {
+            const unsigned long long w[4] = {(unsigned long long)q[u][0].y << 32 | q[u][0].x, (unsigned long long)q[u][0].w << 32 | q[u][0].z,
+                                             (unsigned long long)q[u][1].y << 32 | q[u][1].x, (unsigned long long)q[u][1].w << 32 | q[u][1].z};
+            const unsigned long long v2 = (unsigned long long)q[u][3].y << 32 | q[u][3].x;
+            sel[u] = i0 + (uint32_t)u * nthr < nslots && w[0] != 0 && w[1] != 0 && w[2] != 0 && w[3] != 0 && v2 != 0 &&
+                     wrow_selected(w, kind_mask, tb_lo, tb_hi);
+            m[u] = __builtin_amdgcn_ballot_w64(sel[u]);
+            total += (uint32_t)__builtin_popcountll(m[u]);
+        }
+        if (total != 0u) {  // (wave-uniform)
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+            const uint32_t leader = (uint32_t)__builtin_ctzll(act);
+            unsigned int base = 0;
+            if (lane == leader) base = atomicAdd(&ctr->wrows_count, total);
+            base = (unsigned int)__builtin_amdgcn_readlane((int)base, (int)leader);
+#pragma unroll
+            for (int u = 0; u < WX_U; u++) {
+                const unsigned int j = base + (unsigned int)__builtin_popcountll(m[u] & ((1ull << lane) - 1ull));
+                base += (unsigned int)__builtin_popcountll(m[u]);
+                if (sel[u] && j < rows_cap) {
+                    uint4* d = reinterpret_cast<uint4*>(&rows[j]);  // 56-byte rows: 8-byte aligned only
+                    unsigned long long* d8 = reinterpret_cast<unsigned long long*>(d);
+                    d8[0] = (unsigned long long)q[u][0].y << 32 | q[u][0].x;
+                    d8[1] = (unsigned long long)q[u][0].w << 32 | q[u][0].z;
+                    d8[2] = (unsigned long long)q[u][1].y << 32 | q[u][1].x;
+                    d8[3] = (unsigned long long)q[u][1].w << 32 | q[u][1].z;
+                    d8[4] = (unsigned long long)q[u][2].y << 32 | q[u][2].x;
+                    d8[5] = (unsigned long long)q[u][2].w << 32 | q[u][2].z;
+                    d8[6] = (unsigned long long)q[u][3].y << 32 | q[u][3].x;
+                }
+            }
+        }
     }
 }
 // Re-inserts every row that is NOT selected into a fresh table (window removal / reset / growth).
