@@ -76,7 +76,11 @@ struct fa_ctx {
     size_t wseg_bytes = 0;
     uint32_t* wseg_counts = nullptr;
     size_t wseg_counts_cap = 0;
-    bool wide_atomic = false;  // env FA_WIDE=atomic (A/B, tests): every update of the key set through memory-side atomics
+    int wide_mode = 0;         // env FA_WIDE: 0 adaptive, 1 "atomic" (every update through memory-side atomics), 2 "scatter" (always the scatter sink)
+    bool wide_scatter = true;  // adaptive: the scatter sink while a good share of the records open new rows (7 atomics each
+                               // on the atomic path); a stream that mostly hits existing rows (one atomic line transaction
+                               // each) is cheaper without the detour through the segments
+    uint64_t seen_wused = 0, seen_ok_w = 0;
     bool cms_atomic = false;  // env FA_CMS=atomic (A/B, tests): every sketch update through memory-side atomics
     uint32_t cms_sl2 = 0;     // log2(counters per sketch slice)
     int sink_mode = 0;  // 0 auto, 1 direct, 2 scatter (env FA_SINK)
@@ -284,7 +288,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
     if (const char* d = getenv("FA_AGG")) c->agg_generic = !strcmp(d, "generic");
     if (const char* d = getenv("FA_CMS")) c->cms_atomic = !strcmp(d, "atomic");
-    if (const char* d = getenv("FA_WIDE")) c->wide_atomic = !strcmp(d, "atomic");
+    if (const char* d = getenv("FA_WIDE")) c->wide_mode = !strcmp(d, "atomic") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
     if (const char* d = getenv("FA_AGG_PASSES")) {
         const int v = atoi(d);
         c->agg_passes_forced = (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 0u;
@@ -562,6 +566,17 @@ static void format_feedback(fa_ctx* c, const Counters& h) {
     if (d_ok && d_mis * 16 > d_ok) c->t8_wide_until = c->stats.batches + 64;
     c->seen_misfit8 = h.misfit8;
     c->seen_ok = h.ok;
+    if (c->wtab) {  // (SrcAddr,DstPort,Proto): scatter sink or atomics, by the share of records that opened a row lately
+        if (h.wused < c->seen_wused) c->seen_wused = h.wused;  // (table rebuilt: the count starts over)
+        if (h.ok < c->seen_ok_w) c->seen_ok_w = h.ok;
+        const uint64_t dw = h.wused - c->seen_wused, dn = h.ok - c->seen_ok_w;
+        if (dn >= (1u << 20)) {
+            if (dw * 5 > dn) c->wide_scatter = true;
+            else if (dw * 10 < dn) c->wide_scatter = false;
+            c->seen_wused = h.wused;
+            c->seen_ok_w = h.ok;
+        }
+    }
     // passes of agg8_kernel: the groups a launch adds to the device table, per partition and pass, against the LDS table
     if (h.agg_launches < c->seen_agg_launches || h.agg_groups < c->seen_agg_groups) c->seen_agg_launches = c->seen_agg_groups = 0;
     const uint64_t d_l = h.agg_launches - c->seen_agg_launches, d_g = h.agg_groups - c->seen_agg_groups;
@@ -999,7 +1014,8 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         rc = ensure_csegments(c, n, (uint32_t)grid, a);
         if (rc) return rc;
     }
-    if (c->use_wave_tiles && c->wtab && (c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO) && !c->wide_atomic && grid <= WAGG_MAX_NWG) {
+    if (c->use_wave_tiles && c->wtab && (c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO) && grid <= WAGG_MAX_NWG &&
+        (c->wide_mode == 2 || (c->wide_mode == 0 && c->wide_scatter))) {
         rc = ensure_wsegments(c, n, (uint32_t)grid, a);
         if (rc) return rc;
     }

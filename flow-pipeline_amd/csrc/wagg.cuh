@@ -23,22 +23,37 @@
 namespace fa {
 
 constexpr int WAGG_BLOCK = 1024;
-constexpr int WAGG_SLOTS = 2048;  // LDS table of representatives: load <= 0.5
+constexpr int WAGG_U = 2;                              // tuples per thread and chunk
+constexpr int WAGG_CHUNK = WAGG_BLOCK * WAGG_U;
+constexpr int WAGG_SLOTS = 2 * WAGG_CHUNK;             // LDS table of representatives: load <= 0.5
 constexpr int WAGG_MAX_NWG = 1536;
 
 struct WAggLds {
     uint32_t prefix[WAGG_MAX_NWG + 1];
-    unsigned long long k[4][WAGG_BLOCK];
-    unsigned long long accb[WAGG_BLOCK], accp[WAGG_BLOCK];
-    uint32_t accc[WAGG_BLOCK];
+    unsigned long long k[4][WAGG_CHUNK];
+    unsigned long long accb[WAGG_CHUNK], accp[WAGG_CHUNK];
+    uint32_t accc[WAGG_CHUNK];
     uint32_t rep[WAGG_SLOTS];
     uint32_t created;
 };
+static_assert(sizeof(WAggLds) <= 160 * 1024, "wagg_kernel LDS");
 
-// Upsert of one key into the region this workgroup owns.  false: probe limit (the caller parks the update).
-__device__ __forceinline__ bool wagg_upsert(const WArgs& t, const WKey& k, uint32_t h, uint64_t b, uint64_t p, uint64_t c, uint32_t& created) {
-    uint32_t i = h & t.mask;
-    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i & ~t.rmask) | ((i + 1) & t.rmask)) {
+__device__ __forceinline__ uint32_t wagg_next(const WArgs& t, uint32_t i) { return (i & ~t.rmask) | ((i + 1) & t.rmask); }
+__device__ __forceinline__ void wagg_fill(WSlot* s, const WKey& k, uint64_t b, uint64_t p, uint64_t c) {
+    s->w[1] = k.w[1];
+    *reinterpret_cast<ulonglong2*>(&s->w[2]) = make_ulonglong2(k.w[2], k.w[3]);
+    *reinterpret_cast<ulonglong2*>(&s->v0) = make_ulonglong2(b, p);
+    s->v2 = c;
+}
+__device__ __forceinline__ bool wagg_claim(WSlot* s, const WKey& k) {
+    unsigned long long expect = 0ull;
+    return __hip_atomic_compare_exchange_strong(&s->w[0], &expect, k.w[0], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Upsert of one key into the region this workgroup owns, probing from slot i.  false: probe limit (the caller parks
+// the update).
+__device__ __forceinline__ bool wagg_upsert(const WArgs& t, const WKey& k, uint32_t i, uint64_t b, uint64_t p, uint64_t c, uint32_t& created) {
+    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = wagg_next(t, i)) {
         WSlot* s = &t.tab[i];
         const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&s->w[0]);
         const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&s->w[2]);
@@ -49,19 +64,13 @@ __device__ __forceinline__ bool wagg_upsert(const WArgs& t, const WKey& k, uint3
             s->v2 = v2 + c;
             return true;
         }
-        if (k01.x == 0) {
-            unsigned long long expect = 0ull;
-            if (__hip_atomic_compare_exchange_strong(&s->w[0], &expect, k.w[0], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                s->w[1] = k.w[1];
-                *reinterpret_cast<ulonglong2*>(&s->w[2]) = make_ulonglong2(k.w[2], k.w[3]);
-                *reinterpret_cast<ulonglong2*>(&s->v0) = make_ulonglong2(b, p);
-                s->v2 = c;
-                created++;
-                return true;
-            }
-            // lost to another key of this chunk (keys of a chunk are unique, so it is not this one - its words may still
-            // be on their way): next slot
+        if (k01.x == 0 && wagg_claim(s, k)) {
+            wagg_fill(s, k, b, p, c);
+            created++;
+            return true;
         }
+        // (an empty slot lost to another key of this chunk - keys of a chunk are unique, so it is not this one; its
+        // other words may still be on their way): next slot
     }
     return false;
 }
@@ -95,59 +104,124 @@ __global__ __launch_bounds__(WAGG_BLOCK) void wagg_kernel(KArgs a) {
     const uint32_t total = L.prefix[nwg];
     const uint4* pseg = a.wseg + 2u * (size_t)part * a.wregion;
     uint32_t created = 0;
-    for (uint32_t base = 0; base < total; base += WAGG_BLOCK) {
-        const uint32_t idx = base + tid;
-        const bool have = idx < total;
-        WKey k{{0, 0, 0, 0}};
-        uint64_t b = 0, p = 0;
-        uint32_t h = 0;
-        if (have) {
-            uint32_t lo = 0, hi = nwg;  // the segment that holds tuple idx: largest j with prefix[j] <= idx
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (L.prefix[mid] <= idx) lo = mid;
-                else hi = mid;
-            }
-            const uint4* q = pseg + 2u * ((size_t)lo * a.wcapq + (idx - L.prefix[lo]));
-            const uint4 q0 = q[0], q1 = q[1];
-            wtup_unpack(q0, q1, tb_base, k, b, p);
-            h = wkey_hash(k);
-        }
-        L.k[0][tid] = k.w[0];
-        L.k[1][tid] = k.w[1];
-        L.k[2][tid] = k.w[2];
-        L.k[3][tid] = k.w[3];
-        L.accb[tid] = b;
-        L.accp[tid] = p;
-        L.accc[tid] = have ? 1u : 0u;
-        __syncthreads();
-        bool is_rep = false;
-        uint32_t myslot = 0;
-        if (have) {
-            uint32_t s = (h ^ (h >> 13)) & (WAGG_SLOTS - 1);
-            for (;;) {
-                uint32_t r = L.rep[s];
-                if (r == 0) r = atomicCAS(&L.rep[s], 0u, tid + 1u);
-                if (r == 0) {
-                    is_rep = true;
-                    myslot = s;
-                    break;
+    // the tuples of the NEXT chunk are loaded while this one is folded (two 16-byte loads per tuple; a tuple past
+    // the end re-reads tuple 0 of the region's first segment)
+    uint4 n0[WAGG_U], n1[WAGG_U];
+    auto fetch = [&](uint32_t base) {
+#pragma unroll
+        for (int u = 0; u < WAGG_U; u++) {
+            const uint32_t idx = base + (uint32_t)u * WAGG_BLOCK + tid;
+            size_t at = 0;
+            if (idx < total) {
+                uint32_t lo = 0, hi = nwg;  // the segment that holds tuple idx: largest j with prefix[j] <= idx
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (L.prefix[mid] <= idx) lo = mid;
+                    else hi = mid;
                 }
-                r -= 1u;
-                if (L.k[0][r] == k.w[0] && L.k[1][r] == k.w[1] && L.k[2][r] == k.w[2] && L.k[3][r] == k.w[3]) {
-                    if (b) atomicAdd(&L.accb[r], (unsigned long long)b);
-                    if (p) atomicAdd(&L.accp[r], (unsigned long long)p);
-                    atomicAdd(&L.accc[r], 1u);
-                    break;
+                at = (size_t)lo * a.wcapq + (idx - L.prefix[lo]);
+            }
+            n0[u] = pseg[2u * at];
+            n1[u] = pseg[2u * at + 1u];
+        }
+    };
+    if (total) fetch(0);
+    for (uint32_t base = 0; base < total; base += WAGG_CHUNK) {
+        WKey k[WAGG_U];
+        uint64_t b[WAGG_U], p[WAGG_U];
+        uint32_t h[WAGG_U];
+        bool have[WAGG_U];
+#pragma unroll
+        for (int u = 0; u < WAGG_U; u++) {
+            const uint32_t e = (uint32_t)u * WAGG_BLOCK + tid;
+            have[u] = base + e < total;
+            wtup_unpack(n0[u], n1[u], tb_base, k[u], b[u], p[u]);
+            h[u] = wkey_hash(k[u]);
+            L.k[0][e] = k[u].w[0];
+            L.k[1][e] = k[u].w[1];
+            L.k[2][e] = k[u].w[2];
+            L.k[3][e] = k[u].w[3];
+            L.accb[e] = b[u];
+            L.accp[e] = p[u];
+            L.accc[e] = have[u] ? 1u : 0u;
+        }
+        if (base + WAGG_CHUNK < total) fetch(base + WAGG_CHUNK);
+        __syncthreads();
+        bool is_rep[WAGG_U];
+        uint32_t myslot[WAGG_U];
+#pragma unroll
+        for (int u = 0; u < WAGG_U; u++) {
+            const uint32_t e = (uint32_t)u * WAGG_BLOCK + tid;
+            is_rep[u] = false;
+            myslot[u] = 0;
+            if (have[u]) {
+                uint32_t s = (h[u] ^ (h[u] >> 13)) & (WAGG_SLOTS - 1);
+                for (;;) {
+                    uint32_t r = L.rep[s];
+                    if (r == 0) r = atomicCAS(&L.rep[s], 0u, e + 1u);
+                    if (r == 0) {
+                        is_rep[u] = true;
+                        myslot[u] = s;
+                        break;
+                    }
+                    r -= 1u;
+                    if (L.k[0][r] == k[u].w[0] && L.k[1][r] == k[u].w[1] && L.k[2][r] == k[u].w[2] && L.k[3][r] == k[u].w[3]) {
+                        if (b[u]) atomicAdd(&L.accb[r], (unsigned long long)b[u]);
+                        if (p[u]) atomicAdd(&L.accp[r], (unsigned long long)p[u]);
+                        atomicAdd(&L.accc[r], 1u);
+                        break;
+                    }
+                    s = (s + 1) & (WAGG_SLOTS - 1);
                 }
-                s = (s + 1) & (WAGG_SLOTS - 1);
             }
         }
         __syncthreads();
-        if (is_rep) {
-            const uint64_t sb = L.accb[tid], sp = L.accp[tid], sc = L.accc[tid];
-            if (!wagg_upsert(t, k, h, sb, sp, sc, created)) wspill_park(t, k, sb, sp, sc);
-            L.rep[myslot] = 0;
+        // the representatives' upserts: the home-slot step of all of this thread's keys together (loads, then the
+        // claims / the sums' loads, then the stores), what is left - the home slot holds another key - one by one
+        WSlot* hs[WAGG_U];
+        ulonglong2 k01[WAGG_U], k23[WAGG_U], v01[WAGG_U];
+        unsigned long long v2[WAGG_U], sb[WAGG_U], sp[WAGG_U], sc[WAGG_U];
+        bool match[WAGG_U], won[WAGG_U];
+#pragma unroll
+        for (int u = 0; u < WAGG_U; u++) {
+            const uint32_t e = (uint32_t)u * WAGG_BLOCK + tid;
+            hs[u] = &t.tab[h[u] & t.mask];
+            k01[u] = *reinterpret_cast<const ulonglong2*>(&hs[u]->w[0]);
+            k23[u] = *reinterpret_cast<const ulonglong2*>(&hs[u]->w[2]);
+            sb[u] = L.accb[e];
+            sp[u] = L.accp[e];
+            sc[u] = L.accc[e];
+        }
+#pragma unroll
+        for (int u = 0; u < WAGG_U; u++) {
+            match[u] = is_rep[u] && k01[u].x == k[u].w[0] && k01[u].y == k[u].w[1] && k23[u].x == k[u].w[2] && k23[u].y == k[u].w[3];
+            won[u] = false;
+            v01[u] = make_ulonglong2(0, 0);
+            v2[u] = 0;
+            if (match[u]) {
+                v01[u] = *reinterpret_cast<const ulonglong2*>(&hs[u]->v0);
+                v2[u] = hs[u]->v2;
+            } else if (is_rep[u] && k01[u].x == 0) {
+                won[u] = wagg_claim(hs[u], k[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WAGG_U; u++) {
+            if (match[u]) {
+                *reinterpret_cast<ulonglong2*>(&hs[u]->v0) = make_ulonglong2(v01[u].x + sb[u], v01[u].y + sp[u]);
+                hs[u]->v2 = v2[u] + sc[u];
+            } else if (won[u]) {
+                wagg_fill(hs[u], k[u], sb[u], sp[u], sc[u]);
+                created++;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WAGG_U; u++) {
+            if (is_rep[u]) {
+                if (!match[u] && !won[u] && !wagg_upsert(t, k[u], wagg_next(t, h[u] & t.mask), sb[u], sp[u], sc[u], created))
+                    wspill_park(t, k[u], sb[u], sp[u], sc[u]);
+                L.rep[myslot[u]] = 0;
+            }
         }
         __syncthreads();  // (workgroup-scope release / acquire: the next chunk sees this chunk's rows)
     }

@@ -230,17 +230,20 @@ def _app_device_run(fa, po, n, chunk, **kw):
         return agg.read_window(), agg.read_window_app(), agg.stats()
 
 
-@pytest.mark.parametrize("variant", ["default", "atomic", "tiny_segments"])
+@pytest.mark.parametrize("variant", ["default", "scatter", "atomic", "tiny_segments"])
 @pytest.mark.parametrize("zs,lu", [(80, 22), (140, 10)])
 def test_app_scatter_sink_equals_oracle(gpu_lib, fa, po, monkeypatch, variant, zs, lu):
     """The (SrcAddr,DstPort,Proto) scatter sink (wagg.cuh: tuples per table region, one workgroup per region, plain
     loads and stores) against the oracle on 2 M records in four launches, with table growth from 2^16 slots between
     them: almost-all-distinct keys (Zipf 0.8 over 2^22 addresses) and heavy duplicates (Zipf 1.4 over 2^10: the LDS
-    deduplication and the segment-overflow fallback of a heavy key's region).  The same through the atomic path
-    (FA_WIDE=atomic) and with segments far too small (FA_SEG_CAP: most tuples overflow into the atomic path)."""
-    if variant == "atomic":
-        monkeypatch.setenv("FA_WIDE", "atomic")
+    deduplication and the segment-overflow fallback of a heavy key's region).  default = the library chooses per launch
+    (scatter sink while many records open new rows, atomics otherwise); the same with the sink forced on
+    (FA_WIDE=scatter), off (FA_WIDE=atomic) and with segments far too small (FA_SEG_CAP: most tuples overflow into
+    the atomic path)."""
+    if variant in ("atomic", "scatter"):
+        monkeypatch.setenv("FA_WIDE", variant)
     if variant == "tiny_segments":
+        monkeypatch.setenv("FA_WIDE", "scatter")
         monkeypatch.setenv("FA_SEG_CAP", "40")
     n, chunk = 2_000_000, 500_000
     kw = dict(mode=2, framed=1, seed=77, n_total=n, span_secs=900, zipf_log2_universe=lu, zipf_s_x100=zs)

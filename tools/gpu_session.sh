@@ -22,6 +22,10 @@ run config5_pair --mode zipf --zipf-s 80 --key-sets 9 --records 50000000 --chunk
 FA_TUPLE=16 run wide_tuples --chunk 16666667 --no-verify
 run c16 --chunk 16666667 --no-verify
 PROF_SQ=${PROF_SQ:-} timeout 900 bash tools/profile.sh $TAG > $OUT/profile.log 2>&1
+if [ -n "$FULL" ]; then  # the full-scale runs of configs 3 and 5 (profiles/<tag>_config3_1B.json, <tag>_config5_100M.json)
+  timeout 900 python tools/config5_run.py > $OUT/config5_100M.json 2> $OUT/config5_100M.err; echo "config5 rc=$?"
+  timeout 1500 python tools/config3_run.py > $OUT/config3_1B.json 2> $OUT/config3_1B.err; echo "config3 rc=$?"
+fi
 for f in $OUT/bench_*.json; do echo "== $f"; python - "$f" <<'PY'
 import json,sys
 try:
