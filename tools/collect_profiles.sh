@@ -16,5 +16,6 @@ done
 cp $P/summary.txt $D/${TAG}_rocprof_summary.txt
 cp $P/traffic.json $D/${TAG}_traffic.json
 [ -s $S/config3_1B.json ] && grep '^{' $S/config3_1B.json | tail -1 > $D/${TAG}_config3_1B.json
+[ -s $S/config4_8ranks_1gpu.json ] && grep '^{' $S/config4_8ranks_1gpu.json | tail -1 > $D/${TAG}_config4_8ranks_1gpu.json
 [ -s $S/config5_100M.json ] && grep '^{' $S/config5_100M.json | tail -1 > $D/${TAG}_config5_100M.json
 ls -la $D/${TAG}_*
