@@ -89,10 +89,10 @@ __device__ __forceinline__ void agg_fetch(const KArgs& a, const uint4* pbase, co
 
 // tuple e of a batch, as values (wide: e = piece; compact: e >> 1 = piece, e & 1 = half)
 template <bool T8>
-__device__ __forceinline__ void agg_vals(const AggBatch& b, int e, uint32_t part, TupleVals& v) {
+__device__ __forceinline__ void agg_vals(const AggBatch& b, int e, uint32_t part, uint32_t tb_base, TupleVals& v) {
     if (T8) {
         const uint4& q = b.t[e >> 1];
-        t8_unpack((e & 1) ? make_uint2(q.z, q.w) : make_uint2(q.x, q.y), part, v);
+        t8_unpack((e & 1) ? make_uint2(q.z, q.w) : make_uint2(q.x, q.y), part, tb_base, v);
     } else {
         tup16_unpack(b.t[e], v);
     }
@@ -136,7 +136,7 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
     unsigned long long d0[AGG_CH], d1[AGG_CH];
 #pragma unroll
     for (int s = 0; s < AGG_CH; s++) {
-        agg_vals<T8>(b, E0 + s, part, tv[s]);
+        agg_vals<T8>(b, E0 + s, part, tb_base, tv[s]);
         pack_key(tb_base + tv[s].tbr, tv[s].src_as, tv[s].dst_as, tv[s].etype, k0[s], k1[s]);
         h[s] = key_hash(k0[s], k1[s]);
         const uint32_t i = h[s] & (AGG_SLOTS - 1), j = (i + 1) & (AGG_SLOTS - 1);
@@ -289,14 +289,14 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
         fs1[q] = lt.s1[i];
         fs2[q] = lt.s2[i];
         fh[q] = key_hash(fk0[q], fk1[q]);
-        home[q] = *reinterpret_cast<const ulonglong2*>(&a.tab[fh[q] & a.mask]);
+        home[q] = *reinterpret_cast<const ulonglong2*>(&a.tab[as_home(fk0[q], fk1[q], fh[q], a.mask, a.rlog2)]);
     }
 #pragma unroll
     for (int q = 0; q < NF; q++) {
         Slot* sp = nullptr;
         const unsigned long long b = fs1[q], p = fs2[q] >> 25, c = fs2[q] & 0x1ffffffull;
         if (fk0[q] != 0 && fk1[q] != 0 && fs2[q] != 0) {
-            if (home[q].x == fk0[q] && home[q].y == fk1[q]) sp = &a.tab[fh[q] & a.mask];
+            if (home[q].x == fk0[q] && home[q].y == fk1[q]) sp = &a.tab[as_home(fk0[q], fk1[q], fh[q], a.mask, a.rlog2)];
             else sp = table_find_or_claim(a, fk0[q], fk1[q], fh[q]);
             if (!sp) spill_park(a, fk0[q], fk1[q], b, p, c);
         }
@@ -325,7 +325,7 @@ __device__ __forceinline__ uint32_t agg8_home(const uint2& t) {
 __device__ __forceinline__ uint32_t agg8_sub(const uint2& t) { return (agg8_mix(t) >> 17) & 7u; }
 __device__ __forceinline__ void agg8_global(const KArgs& a, uint32_t tb_base, uint32_t part, const uint2& t, uint32_t by, uint32_t pk) {
     TupleVals v;
-    t8_unpack(t, part, v);
+    t8_unpack(t, part, tb_base, v);
     uint64_t k0, k1;
     pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);
     agg_global(a, k0, k1, key_hash(k0, k1), by, pk, 1);
@@ -345,6 +345,36 @@ __device__ __forceinline__ void agg8_tuple(const KArgs& a, Agg8Table& lt, uint32
         return;
     }
     agg8_global(a, tb_base, part, t, by, pk);  // the table is full around this key
+}
+
+// Upsert into the table region THIS workgroup owns (compact-tuple launches: region = partition, table.cuh as_region8),
+// probing from slot i: plain loads and stores, one workgroup-scope CAS where a slot is claimed (two keys of the workgroup
+// may want the same empty slot; nobody else writes the region while this kernel runs).  false: probe limit.
+__device__ __forceinline__ bool agg8_upsert_owned(const KArgs& a, uint64_t k0, uint64_t k1, uint32_t i, uint64_t b, uint64_t p, uint64_t c,
+                                                  uint32_t& created) {
+    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = as_next(i, a.mask, a.rlog2)) {
+        Slot* s = &a.tab[i];
+        const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&s->k0);
+        if (kk.x == k0 && kk.y == k1) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(&s->bytes);
+            const unsigned long long cnt = s->count;
+            *reinterpret_cast<ulonglong2*>(&s->bytes) = make_ulonglong2(v.x + b, v.y + p);
+            s->count = cnt + c;
+            return true;
+        }
+        if (kk.x == 0) {
+            unsigned long long expect = 0ull;
+            if (__hip_atomic_compare_exchange_strong(&s->k0, &expect, (unsigned long long)k0, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                s->k1 = k1;
+                *reinterpret_cast<ulonglong2*>(&s->bytes) = make_ulonglong2(b, p);
+                s->count = c;
+                created++;
+                return true;
+            }
+        }
+        // (a slot another key of this workgroup holds - the groups of a flush are distinct - or has just claimed)
+    }
+    return false;
 }
 
 #ifndef FA_AGG8_SU
@@ -482,7 +512,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
     // takes the tuples whose key mixes to s, folds them, adds the groups to the device table and clears the LDS table;
     // the tuples of a partition (0.5 MB) are re-read from L2.
     const uint32_t npass = max(a.agg_passes, 1u), pmask = npass - 1u;
-    uint32_t my_groups = 0;
+    uint32_t my_groups = 0, my_created = 0;
 #pragma unroll 1
     for (uint32_t pass = 0; pass < npass; pass++) {
     const unsigned long long tm0 = (a.dbg & DBG_TIMING) ? clock64() : 0ull;
@@ -525,45 +555,93 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
     // every group of this partition goes to the device-wide table once (quad-grouped: one atomic line transaction per
     // group; uniform trip count: the whole wave takes part in the quad rounds)
     constexpr int NF = (AGG8_ALL + AGG_BLOCK - 1) / AGG_BLOCK, FB = 3;  // slots per thread, in blocks of FB (registers)
+    auto group_of = [&](int i, uint64_t& k0, uint64_t& k1, unsigned long long& s1, unsigned long long& s2) -> bool {
+        const unsigned long long key = i < AGG8_ALL ? lt.key[i] : 0ull;
+        s1 = i < AGG8_ALL ? lt.s1[i] : 0ull;
+        s2 = i < AGG8_ALL ? lt.s2[i] : 0ull;
+        TupleVals v;
+        t8_unpack(make_uint2((uint32_t)key, (uint32_t)(key >> 32) << 26), part, tb_base, v);
+        pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);
+        return key != 0ull && s2 != 0ull;
+    };
+    if (a.rlog2 == AS_RLOG2_MAX && !(a.dbg & DBG_AGG_ATOMIC_FLUSH)) {
+        // This workgroup OWNS region `part` of the device table (table.cuh: the region of a compact-eligible key is its
+        // partition, and the overflow path above only reaches keys of this partition too): plain loads and stores, no
+        // atomics on the sums - three memory-side atomics per group were the whole cost of this flush.
+        const uint32_t rmask = a.mask >> AS_RLOG2_MAX;
+#pragma unroll 1
+        for (int q0 = 0; q0 < NF; q0 += FB) {
+            uint64_t fk0[FB], fk1[FB];
+            unsigned long long fs1[FB], fs2[FB], cnt[FB];
+            ulonglong2 kk[FB], vv[FB];
+            Slot* hs[FB];
+            bool valid[FB];
+#pragma unroll
+            for (int q = 0; q < FB; q++) {  // the home slots of this thread's groups: keys and sums, all loads together
+                valid[q] = group_of((q0 + q) * AGG_BLOCK + (int)threadIdx.x, fk0[q], fk1[q], fs1[q], fs2[q]);
+                hs[q] = &a.tab[part * (rmask + 1u) + (key_hash(fk0[q], fk1[q]) & rmask)];
+                kk[q] = *reinterpret_cast<const ulonglong2*>(&hs[q]->k0);
+                vv[q] = *reinterpret_cast<const ulonglong2*>(&hs[q]->bytes);
+                cnt[q] = hs[q]->count;
+            }
+#pragma unroll
+            for (int q = 0; q < FB; q++) {
+                if (!valid[q]) continue;
+                my_groups++;
+                const unsigned long long b = fs1[q], p = fs2[q] >> 25, c = fs2[q] & 0x1ffffffull;
+                bool done = false;
+                if (kk[q].x == fk0[q] && kk[q].y == fk1[q]) {
+                    *reinterpret_cast<ulonglong2*>(&hs[q]->bytes) = make_ulonglong2(vv[q].x + b, vv[q].y + p);
+                    hs[q]->count = cnt[q] + c;
+                    done = true;
+                } else if (kk[q].x == 0) {
+                    unsigned long long expect = 0ull;
+                    if (__hip_atomic_compare_exchange_strong(&hs[q]->k0, &expect, (unsigned long long)fk0[q], __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        hs[q]->k1 = fk1[q];
+                        *reinterpret_cast<ulonglong2*>(&hs[q]->bytes) = make_ulonglong2(b, p);
+                        hs[q]->count = c;
+                        my_created++;
+                        done = true;
+                    }
+                }
+                if (!done && !agg8_upsert_owned(a, fk0[q], fk1[q], as_next((uint32_t)(hs[q] - a.tab), a.mask, a.rlog2), b, p, c, my_created))
+                    spill_park(a, fk0[q], fk1[q], b, p, c);
+            }
+        }
+    } else {
+    // (small tables - fewer than 256 regions: a region is shared by several partitions - keep the atomic protocol)
 #pragma unroll 1
     for (int q0 = 0; q0 < NF; q0 += FB) {
         unsigned long long fk0[FB], fk1[FB], fs1[FB], fs2[FB];
         ulonglong2 home[FB];
         uint32_t fh[FB];
-#pragma unroll
-        for (int q = 0; q < FB; q++) {  // phase 1: the home-slot probes of this thread's groups fly together
-            const int i = (q0 + q) * AGG_BLOCK + threadIdx.x;
-            const unsigned long long key = i < AGG8_ALL ? lt.key[i] : 0ull;
-            fs1[q] = i < AGG8_ALL ? lt.s1[i] : 0ull;
-            fs2[q] = i < AGG8_ALL ? lt.s2[i] : 0ull;
-            TupleVals v;
-            t8_unpack(make_uint2((uint32_t)key, (uint32_t)(key >> 32) << 26), part, v);
-            uint64_t k0, k1;
-            pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);
-            fk0[q] = key ? k0 : 0ull;
-            fk1[q] = key ? k1 : 0ull;
-            fh[q] = key_hash(k0, k1);
-            home[q] = *reinterpret_cast<const ulonglong2*>(&a.tab[fh[q] & a.mask]);
-        }
-        // phase 2: groups whose home slot is empty claim it - the two key words with one CAS each, issued for all FB
-        // groups of the thread before the first answer is awaited (a launch that opens a million new groups - a new
-        // time bucket - would otherwise walk FB x 2 dependent memory-side round trips of ~15 us under load)
-        unsigned long long r0[FB], r1[FB];
         bool valid[FB], claim[FB];
 #pragma unroll
+        for (int q = 0; q < FB; q++) {  // phase 1: the home-slot probes of this thread's groups fly together
+            uint64_t k0, k1;
+            valid[q] = group_of((q0 + q) * AGG_BLOCK + (int)threadIdx.x, k0, k1, fs1[q], fs2[q]);
+            fk0[q] = k0;
+            fk1[q] = k1;
+            fh[q] = as_home(k0, k1, key_hash(k0, k1), a.mask, a.rlog2);
+            home[q] = *reinterpret_cast<const ulonglong2*>(&a.tab[fh[q]]);
+        }
+        // phase 2: groups whose home slot is empty claim it - the two key words with one CAS each, issued for all FB
+        // groups of the thread before the first answer is awaited
+        unsigned long long r0[FB], r1[FB];
+#pragma unroll
         for (int q = 0; q < FB; q++) {
-            valid[q] = fk0[q] != 0 && fs2[q] != 0;
             claim[q] = valid[q] && home[q].x == 0;
             r0[q] = home[q].x;
             r1[q] = home[q].y;
-            if (claim[q]) r0[q] = atomicCAS(&a.tab[fh[q] & a.mask].k0, 0ull, fk0[q]);
+            if (claim[q]) r0[q] = atomicCAS(&a.tab[fh[q]].k0, 0ull, fk0[q]);
         }
 #pragma unroll
         for (int q = 0; q < FB; q++) {
             if (claim[q]) {
                 if (r0[q] == 0) r0[q] = fk0[q];
                 claim[q] = r0[q] == fk0[q];  // (lost the slot to another key: the probing path below)
-                if (claim[q]) r1[q] = atomicCAS(&a.tab[fh[q] & a.mask].k1, 0ull, fk1[q]);
+                if (claim[q]) r1[q] = atomicCAS(&a.tab[fh[q]].k1, 0ull, fk1[q]);
             }
         }
 #pragma unroll
@@ -576,12 +654,13 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
                     count_created(&a.ctr->used);
                     r1[q] = fk1[q];
                 }
-                if (r0[q] == fk0[q] && r1[q] == fk1[q]) sp = &a.tab[fh[q] & a.mask];
-                else sp = table_find_or_claim(a, fk0[q], fk1[q], fh[q]);
+                if (r0[q] == fk0[q] && r1[q] == fk1[q]) sp = &a.tab[fh[q]];
+                else sp = table_find_or_claim(a, fk0[q], fk1[q], key_hash(fk0[q], fk1[q]));
                 if (!sp) spill_park(a, fk0[q], fk1[q], b, p, c);
             }
             quad_atomic_update(sp, b, p, c);
         }
+    }
     }
     if ((a.dbg & DBG_TIMING) && threadIdx.x == 0) {  // (FA_DEBUG_FLAGS=1024: core clocks per workgroup and pass - fold / add to the device table)
         __builtin_amdgcn_s_waitcnt(0);
@@ -600,13 +679,15 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
     }
     }
     // pass-count feedback: groups this launch added to the device table
-    const uint32_t gw = (uint32_t)wave_sum_u64(my_groups);
+    const uint32_t gw = (uint32_t)wave_sum_u64(my_groups), cw = (uint32_t)wave_sum_u64(my_created);
     __syncthreads();
-    if (threadIdx.x == 0) pc[0] = 0;
+    if (threadIdx.x == 0) pc[0] = pc[1] = 0;
     __syncthreads();
     if (lane == 0 && gw) atomicAdd(&pc[0], gw);
+    if (lane == 0 && cw) atomicAdd(&pc[1], cw);
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (pc[1]) atomicAdd(&a.ctr->used, (unsigned long long)pc[1]);
         if (pc[0]) atomicAdd(&a.ctr->agg_groups, (unsigned long long)pc[0]);
         if (blockIdx.x == 0) atomicAdd(&a.ctr->agg_launches, 1ull);
     }

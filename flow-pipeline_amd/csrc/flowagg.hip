@@ -192,6 +192,7 @@ static KArgs make_args(fa_ctx* c) {
     a.gran = c->gran;
     a.tab = c->tab;
     a.mask = (1u << c->cap_log2) - 1;
+    a.rlog2 = as_rlog2(c->cap_log2);
     a.spill = c->spill;
     a.spill_cap = c->spill_cap;
     a.ctr = c->d_ctr;

@@ -126,7 +126,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             uint2 tc = make_uint2(0, 0);
             if (T8) {
                 fits = t8_fits(r.src_as, r.dst_as, tbr, b, p, r.etype);
-                tc = t8_pack(r.src_as, r.dst_as, (uint32_t)b, (uint32_t)p, tbr, r.etype, part);
+                tc = t8_pack(r.src_as, r.dst_as, (uint32_t)b, (uint32_t)p, tbr, r.etype, tb_base, part);
                 if (FA_ANY(!fits)) tally.misfit8 += (!fits && tup16_fits(tbr, b, p, r.etype)) ? 1u : 0u;  // (format feedback; rare)
             } else {
                 fits = tup16_fits(tbr, b, p, r.etype);
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
                     }
                 } else {  // back part full (skewed batch): straight to the device-wide table
                     TupleVals v;
-                    if (T8) t8_unpack(tc, p, v);
+                    if (T8) t8_unpack(tc, p, tb_base, v);
                     else tup16_unpack(tv, v);
                     uint64_t k0, k1;
                     pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);

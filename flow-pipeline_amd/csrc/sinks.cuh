@@ -81,7 +81,7 @@ constexpr uint32_t FA_KEYS_WIDE = FA_KEYS_ADDR_PORT_PROTO | FA_KEYS_PORT_HIST | 
 constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense histograms
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
-       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072, DBG_NO_KEYSET = 262144, DBG_NO_CMS = 524288, DBG_NO_HOT = 1048576 };
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072, DBG_NO_KEYSET = 262144, DBG_NO_CMS = 524288, DBG_NO_HOT = 1048576, DBG_AGG_ATOMIC_FLUSH = 2097152 /* exact: agg8_kernel adds its groups with atomics although it owns the region (A/B) */ };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -154,6 +154,7 @@ struct KArgs {
     unsigned long long region;  // tuples per partition (nwg*capq plus a skew against power-of-two strides)
     uint32_t plog2;        // log2(key partitions)
     uint32_t par;          // batch parity: which copy of the deferral counters this batch uses
+    uint32_t rlog2;        // log2(regions of the device-wide table) = as_rlog2(log2 slots)  (table.cuh)
     uint32_t agg_passes;   // agg8_kernel: passes over a partition's tuples (1, 2, 4, 8), each with 1 / passes of the groups in the LDS table
     // Count-Min scatter sink (cseg == nullptr: every sketch update is a memory-side atomic, cms_add)
     uint2* cseg;            // [CMS_SETS * CMS_NPART][cregion] sketch tuples; partition p, workgroup w: cseg[p*cregion + w*ccapq + q]
@@ -188,8 +189,8 @@ __device__ __forceinline__ bool ks_on(const KArgs& a, uint32_t x) {
 // ---- sinks ------------------------------------------------------------------
 __device__ __forceinline__ void agg_global(const KArgs& a, uint64_t k0, uint64_t k1, uint32_t h,
                                            uint64_t b, uint64_t p, uint64_t c) {
-    uint32_t i = h & a.mask;
-    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i + 1) & a.mask) {
+    uint32_t i = as_home(k0, k1, h, a.mask, a.rlog2);
+    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = as_next(i, a.mask, a.rlog2)) {
         Slot* s = &a.tab[i];
         unsigned long long c0 = s->k0;
         if (c0 == 0) c0 = atomicCAS(&s->k0, 0ull, (unsigned long long)k0);
@@ -645,8 +646,8 @@ __device__ __forceinline__ void dma_wait_all() { __builtin_amdgcn_s_waitcnt(0x0F
 // ---- device-wide table probe ------------------------------------------------------
 // Finds or claims the slot of (k0,k1); returns nullptr when the probe limit is hit.
 __device__ __forceinline__ Slot* table_find_or_claim(const KArgs& a, uint64_t k0, uint64_t k1, uint32_t h) {
-    uint32_t i = h & a.mask;
-    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i + 1) & a.mask) {
+    uint32_t i = as_home(k0, k1, h, a.mask, a.rlog2);
+    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = as_next(i, a.mask, a.rlog2)) {
         Slot* s = &a.tab[i];
         const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(s);  // one 16-byte load: k0,k1
         unsigned long long c0 = kk.x, c1 = kk.y;
@@ -891,8 +892,8 @@ __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t
             } else {  // front part full (skewed batch): straight to the device-wide table
                 TupleVals v[2];
                 if (T8) {
-                    t8_unpack(make_uint2(tv.x, tv.y), fp, v[0]);
-                    t8_unpack(make_uint2(tv.z, tv.w), fp, v[1]);
+                    t8_unpack(make_uint2(tv.x, tv.y), fp, tb_base, v[0]);
+                    t8_unpack(make_uint2(tv.z, tv.w), fp, tb_base, v[1]);
                 } else {
                     tup16_unpack(tv, v[0]);
                 }

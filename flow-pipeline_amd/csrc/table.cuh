@@ -131,8 +131,11 @@ __host__ __device__ __forceinline__ uint32_t key_hash(uint64_t k0, uint64_t k1) 
 //                   part = SrcAS[7:0] ^ mix8(everything else of the key), a bijection for fixed "everything else",
 //                   so the aggregation workgroup of partition `part` recovers them - 72 bits of record in 64.
 //                   (Balanced whenever either SrcAS[7:0] or the rest of the key varies.)
-//                   lo = DstAS | SrcAS[19:8] << 20;  hi = Bytes | Packets << 17 | tbr << 26 | etcode << 30
-// tbr = time bucket relative to the launch's tb_base (< 16).
+//                   lo = DstAS | SrcAS[19:8] << 20;  hi = Bytes | Packets << 17 | (tb & 15) << 26 | etcode << 30
+// tbr = time bucket relative to the launch's tb_base (< 16); the compact tuple stores tb & 15 - the ABSOLUTE bucket's low
+// bits, from which tb_base recovers the bucket - so that the partition is a function of the key alone: the same group
+// lands in the same partition in every launch, and that partition's workgroup owns the group's region of the device
+// table (as_region below).
 constexpr uint32_t TUPLE_TB_SPAN = 16;
 constexpr uint32_t TUPLE_MAX_BYTES = 1u << 28, TUPLE_MAX_PACKETS = 1u << 15, TUPLE_MAX_ETYPE = 1u << 16;
 constexpr uint32_t T8_MAX_AS = 1u << 20, T8_MAX_BYTES = 1u << 17, T8_MAX_PACKETS = 1u << 9;
@@ -160,7 +163,7 @@ __host__ __device__ __forceinline__ uint32_t t8_etcode(uint32_t etype) {
 __host__ __device__ __forceinline__ uint32_t t8_etype(uint32_t code) {
     return (code & 2u) ? ((code & 1u) ? 0x0806u : 0x86ddu) : ((code & 1u) ? 0x0800u : 0u);
 }
-// 8 well-mixed bits of the stored part of the key (lo = DstAS | SrcAS[19:8] << 20, kh = tbr | etcode << 4)
+// 8 well-mixed bits of the stored part of the key (lo = DstAS | SrcAS[19:8] << 20, kh = (tb & 15) | etcode << 4)
 __host__ __device__ __forceinline__ uint32_t t8_mix8(uint32_t lo, uint32_t kh) {
     // one multiply (this runs once per record in the ingest kernel): Fibonacci hashing carries lo's low bits into the
     // top byte, kh (6 bits) enters at bits 26.. and lands there directly
@@ -170,45 +173,55 @@ __host__ __device__ __forceinline__ bool t8_fits(uint32_t src_as, uint32_t dst_a
     return tbr < TUPLE_TB_SPAN && (src_as | dst_as) < T8_MAX_AS && b < T8_MAX_BYTES && p < T8_MAX_PACKETS &&
            (etype == 0u || t8_etcode(etype) != 0u);
 }
+// the partition of a compact-eligible key: a function of the key alone (tb = absolute time bucket)
+__host__ __device__ __forceinline__ uint32_t t8_part(uint32_t src_as, uint32_t dst_as, uint32_t tb, uint32_t etype) {
+    return (src_as & 0xffu) ^ t8_mix8(dst_as | ((src_as >> 8) << 20), (tb & 15u) | (t8_etcode(etype) << 4));
+}
 __host__ __device__ __forceinline__ uint2 t8_pack(uint32_t src_as, uint32_t dst_as, uint32_t b, uint32_t p, uint32_t tbr, uint32_t etype,
-                                                  uint32_t& part) {
+                                                  uint32_t tb_base, uint32_t& part) {
     const uint32_t lo = dst_as | ((src_as >> 8) << 20);
-    const uint32_t kh = tbr | (t8_etcode(etype) << 4);
+    const uint32_t kh = ((tb_base + tbr) & 15u) | (t8_etcode(etype) << 4);
     part = (src_as & 0xffu) ^ t8_mix8(lo, kh);
     return make_uint2(lo, b | (p << 17) | (kh << 26));
 }
-__host__ __device__ __forceinline__ void t8_unpack(const uint2& t, uint32_t part, TupleVals& v) {
+__host__ __device__ __forceinline__ void t8_unpack(const uint2& t, uint32_t part, uint32_t tb_base, TupleVals& v) {
     const uint32_t kh = t.y >> 26;
     v.dst_as = t.x & 0xfffffu;
     v.src_as = ((t.x >> 20) << 8) | ((part ^ t8_mix8(t.x, kh)) & 0xffu);
     v.bytes = t.y & 0x1ffffu;
     v.packets = (t.y >> 17) & 0x1ffu;
-    v.tbr = kh & 15u;
+    v.tbr = (kh - tb_base) & 15u;
     v.etype = t8_etype(kh >> 4);
 }
 
-#define FA_MAX_PROBES 128
-
-// Upsert into the device-wide table.  Returns false on overflow (probe limit).
-__device__ __forceinline__ bool table_upsert(Slot* tab, uint32_t mask, uint64_t k0, uint64_t k1,
-                                             uint32_t h, uint64_t bytes, uint64_t packets,
-                                             uint64_t count) {
-    uint32_t i = h & mask;
-    for (int probe = 0; probe < FA_MAX_PROBES; probe++, i = (i + 1) & mask) {
-        Slot* s = &tab[i];
-        unsigned long long c0 = s->k0;  // may be stale-EMPTY; never a wrong non-empty value
-        if (c0 == 0) c0 = atomicCAS(&s->k0, 0ull, (unsigned long long)k0);
-        if (c0 != 0 && c0 != k0) continue;
-        unsigned long long c1 = s->k1;
-        if (c1 == 0) c1 = atomicCAS(&s->k1, 0ull, (unsigned long long)k1);
-        if (c1 != 0 && c1 != k1) continue;
-        if (bytes) atomicAdd(&s->bytes, (unsigned long long)bytes);
-        if (packets) atomicAdd(&s->packets, (unsigned long long)packets);
-        atomicAdd(&s->count, (unsigned long long)count);
-        return true;
-    }
-    return false;
+// ---- regions of the device-wide table ---------------------------------------------------------------------
+// The table is cut into 2^rlog2 aligned regions (256 once it has 2^14 slots; never fewer than 64 slots each) and a key
+// only ever lives in ITS region: home slot = region << (log2 slots - rlog2) | hash bits, and probing wraps inside the
+// region.  The region of a compact-eligible key is its compact-tuple partition (t8_part), of any other key the top bits
+// of its hash.  Every path agrees on this through as_home / as_next; what it buys: in a compact-tuple launch the
+// aggregation workgroup of partition p is the only writer of region p for the duration of its kernel and adds its
+// groups with plain loads and stores (agg.cuh) instead of three memory-side atomics per group.
+constexpr uint32_t AS_RLOG2_MAX = 8;
+__host__ __device__ constexpr uint32_t as_rlog2(uint32_t cap_log2) {
+    return cap_log2 >= AS_RLOG2_MAX + 6u ? AS_RLOG2_MAX : cap_log2 > 6u ? cap_log2 - 6u : 0u;
 }
+__host__ __device__ __forceinline__ uint32_t as_region8(uint64_t k0, uint64_t k1, uint32_t h) {
+    uint32_t tb, sa, da, et;
+    unpack_key(k0, k1, tb, sa, da, et);
+    const bool eligible = (sa | da) < T8_MAX_AS && (et == 0u || t8_etcode(et) != 0u);
+    return eligible ? t8_part(sa, da, tb, et) : h >> 24;
+}
+// home slot of a key (h = key_hash(k0, k1); mask = slots - 1; rlog2 = as_rlog2(log2 slots))
+__host__ __device__ __forceinline__ uint32_t as_home(uint64_t k0, uint64_t k1, uint32_t h, uint32_t mask, uint32_t rlog2) {
+    const uint32_t rmask = mask >> rlog2;
+    return ((as_region8(k0, k1, h) >> (AS_RLOG2_MAX - rlog2)) * (rmask + 1u)) | (h & rmask);
+}
+__host__ __device__ __forceinline__ uint32_t as_next(uint32_t i, uint32_t mask, uint32_t rlog2) {
+    const uint32_t rmask = mask >> rlog2;
+    return (i & ~rmask) | ((i + 1u) & rmask);
+}
+
+#define FA_MAX_PROBES 128
 
 // ---- per-workgroup LDS pre-aggregation table --------------------------------
 // Absorbs hot keys (mocker mode has 9 groups, mocker.go:61-62) before they reach
@@ -250,18 +263,6 @@ __device__ __forceinline__ bool lds_table_add(LdsTable<SLOTS>& t, uint64_t k0, u
     return false;
 }
 
-// Flush every occupied LDS slot into the device-wide table; counts overflows.
-template <int SLOTS>
-__device__ __forceinline__ uint32_t lds_table_flush(LdsTable<SLOTS>& t, Slot* tab, uint32_t mask) {
-    uint32_t ovf = 0;
-    for (int i = threadIdx.x; i < SLOTS; i += blockDim.x) {
-        unsigned long long k0 = t.k0[i], k1 = t.k1[i], c = t.count[i];
-        if (k0 != 0 && k1 != 0 && c != 0) {
-            if (!table_upsert(tab, mask, k0, k1, key_hash(k0, k1), t.bytes[i], t.packets[i], c)) ovf++;
-        }
-    }
-    return ovf;
-}
 
 // ---- wavefront helpers -------------------------------------------------------
 // 64-lane sum of a u64 with DPP row shifts inside each 16-lane row and scalar

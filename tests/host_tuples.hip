@@ -37,9 +37,18 @@ int main() {
         if (f8 != want8) fails++;
         if (f8) {
             uint32_t part = 0;
-            const uint2 t = t8_pack(src, dst, (uint32_t)b, (uint32_t)p, tbr, et, part);
+            const uint32_t tb_base = (uint32_t)(rnd() & 0x3ffffff);  // any batch position: the tuple stores (tb_base + tbr) & 15
+            const uint2 t = t8_pack(src, dst, (uint32_t)b, (uint32_t)p, tbr, et, tb_base, part);
             if (part > 255) fails++;
-            t8_unpack(t, part, v);
+            // the partition is a function of the KEY alone (absolute bucket): the same group from a launch with another
+            // tb_base lands in the same partition, and that partition is the key's region of the device table
+            if (part != t8_part(src, dst, tb_base + tbr, et)) fails++;
+            uint64_t k0, k1;
+            pack_key(tb_base + tbr, src, dst, et, k0, k1);
+            if (as_region8(k0, k1, key_hash(k0, k1)) != part) fails++;
+            const uint32_t home = as_home(k0, k1, key_hash(k0, k1), (1u << 20) - 1, as_rlog2(20));
+            if ((home >> 12) != part || as_next(home | 0xfff, (1u << 20) - 1, 8) != (home & ~0xfffu)) fails++;
+            t8_unpack(t, part, tb_base, v);
             if (v.src_as != src || v.dst_as != dst || v.bytes != b || v.packets != p || v.tbr != tbr || v.etype != et) {
                 if (fails++ < 5) printf("t8 round trip: src %u dst %u b %llu p %llu tbr %u et %x -> %u %u %u %u %u %x (part %u)\n", src, dst,
                                         (unsigned long long)b, (unsigned long long)p, tbr, et, v.src_as, v.dst_as, v.bytes, v.packets, v.tbr, v.etype, part);
@@ -53,7 +62,7 @@ int main() {
             uint32_t src, dst, tbr, et;
             gen(k, src, dst, tbr, et);
             uint32_t part;
-            (void)t8_pack(src, dst, 1, 1, tbr, et, part);
+            (void)t8_pack(src, dst, 1, 1, tbr, et, 5666666u, part);
             cnt[part]++;
         }
         uint32_t mx = 0;
@@ -70,6 +79,21 @@ int main() {
         s = 13335; d = k; e = 0x86dd; t = 2; }, 1 << 20);
     balance("random public ASNs", [&](uint32_t k, uint32_t& s, uint32_t& d, uint32_t& t, uint32_t& e) {
         s = (uint32_t)(rnd() % 400000); d = (uint32_t)(rnd() % 400000); e = 0x800; t = 2; (void)k; }, 1 << 20);
+    // 3. keys outside the compact format: region = top bits of the hash; tiny tables have fewer regions of >= 64 slots
+    for (int it = 0; it < 200000; it++) {
+        const uint32_t src = (uint32_t)rnd(), dst = (uint32_t)rnd() | (1u << 20), tb = (uint32_t)(rnd() & 0x3ffffff), et = etypes[rnd() % 8];
+        uint64_t k0, k1;
+        pack_key(tb, src, dst, et, k0, k1);
+        const uint32_t h = key_hash(k0, k1);
+        if (as_region8(k0, k1, h) != (h >> 24)) fails++;
+        for (uint32_t lg = 6; lg <= 22; lg += 4) {
+            const uint32_t mask = (1u << lg) - 1, rl = as_rlog2(lg), home = as_home(k0, k1, h, mask, rl);
+            if (home > mask || (rl && (home >> (lg - rl)) != ((h >> 24) >> (8 - rl))) || ((mask >> rl) + 1) < 64) fails++;
+            uint32_t i = home;
+            for (int k = 0; k < 70; k++) i = as_next(i, mask, rl);
+            if ((i >> (lg - rl)) != (home >> (lg - rl))) fails++;  // probing never leaves the region
+        }
+    }
     printf(fails ? "FAILED (%llu)\n" : "OK\n", (unsigned long long)fails);
     return fails ? 1 : 0;
 }
