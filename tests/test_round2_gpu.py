@@ -199,17 +199,19 @@ def test_goflow_device_generator_matches_oracle(gpu_lib, fa, po):
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("sync_between", [True, False])
-def test_all_distinct_groups_into_a_tiny_table_lose_nothing(gpu_lib, fa, po, sync_between):
+@pytest.mark.parametrize("sync_between,cap_log2", [(True, 16), (False, 16), (False, 10)])
+def test_all_distinct_groups_into_a_tiny_table_lose_nothing(gpu_lib, fa, po, sync_between, cap_log2):
     """8 M records, every one its own (SrcAS,DstAS) group, into a 2^16-slot table: the aggregation kernel's LDS
     tables overflow, the device table fills up, updates are parked and replayed after the table has grown - no
-    aggregate is dropped, with or without a sync between the launches."""
+    aggregate is dropped, with or without a sync between the launches.  From 2^10 slots the table also walks
+    through every region geometry (16 regions of 64 slots -> 256 regions: below 2^14 slots a region is shared by several
+    partitions and the aggregation kernel keeps the atomic protocol; from there on it owns its region)."""
     n, parts = 8_000_000, 4
     m = n // parts
     gp = po.gen_params(mode=4, framed=1, seed=3, n_total=n, span_secs=900)  # (_device_batch spreads the records over 900 s)
     want = po.bench_rollup(gp, 0, n, 8)
     assert want["groups"] >= n  # (>= : a group may straddle two 5-minute windows - it does not here)
-    with fa.FlowAgg(framed=True, table_capacity_log2=16, max_batch_records=m) as agg:
+    with fa.FlowAgg(framed=True, table_capacity_log2=cap_log2, max_batch_records=m) as agg:
         bufs = [_device_batch(fa, agg, 4, 3, m, i0=k * m, n_total=n) for k in range(parts)]
         for d_buf, d_off, w in bufs:
             agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
@@ -394,3 +396,29 @@ def test_bench_side_measurements_run(gpu_lib):
             assert out["config"]["records_second_chance_parser"] == 0 and out["parity"]["ok"]
         if extra == ["--mode", "reversed"]:
             assert out["config"]["records_second_chance_parser"] == 2_000_000 and out["parity"]["ok"]
+
+
+@pytest.mark.parametrize("cap_log2", [10, 12, 13, 14])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_small_tables_every_region_geometry(gpu_lib, fa, po, cap_log2, mode):
+    """flows_5m into tables of 2^10 .. 2^14 slots (16 .. 256 regions: below 256 the aggregation kernel shares regions and
+    keeps atomics; the direct, second-chance and merge paths always go through as_home): mocker's 9 groups stay inside
+    the small table, config 2's 393 k groups make it grow through every geometry; rows == oracle either way, also
+    after a window was closed (rebuild) and ingest went on."""
+    n = 600_000
+    gp = po.gen_params(mode=mode, framed=1, seed=90 + mode, n_total=n, span_secs=900)
+    buf, off = po.gen_records(gp, 0, n)
+    ref = po.Rollup(300)
+    ref.ingest(buf, off, 1)
+    want = ref.rows()
+    h = n // 2
+    with fa.FlowAgg(framed=True, table_capacity_log2=cap_log2, max_batch_records=h) as agg:
+        agg.ingest(buf[:int(off[h])], off[:h + 1])
+        first_slot = int(want["timeslot"].min())
+        closed = agg.close_window(first_slot)  # everything of the first window seen so far leaves the table
+        agg.ingest(buf[int(off[h]):], off[h:] - off[h])
+        rest = agg.read_window()
+        st = agg.stats()
+        assert st["records_ok"] == n and st["records_bad"] == 0
+    both = fa.dist.merge_rows_host([closed, rest])
+    assert both.tobytes() == want.tobytes()
