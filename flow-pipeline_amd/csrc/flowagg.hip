@@ -996,7 +996,7 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         double avg = (double)len / (double)n + 0.5;
         // (a tile that does not fit its buffer goes to the deferred parsers as a whole, so leave ~4 sigma of
         // headroom for a mix of 60- and 84-byte records when the buffer is tight)
-        // (the kernel variants that serve a sketch run one 16-wave workgroup per CU instead of two 8-wave ones, with
+        // (the kernel variants that serve a sketch run one 16-wave workgroup per CU instead of two 12-wave ones, with
         // slightly shorter tile buffers: wtile_block, wtile_stride)
         const bool big_wg = !wt_lean(c->cfg.key_sets);
         double r = ((double)(big_wg ? WT_STRIDE_CMS : WT_STRIDE) - 16.0 - 15.0 - 12.0 * 8.0 * 4.0) / avg;

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
 
 // ---- the wave-tile kernel ---------------------------------------------------------------------------
 // The production ingest kernel of the scatter sink.  Same per-record work as tile_kernel, different
-// residency: 2 workgroups of 8 waves per CU; every WAVE stages its own tile of <= 64 records into a private
+// residency: 2 workgroups of 12 waves per CU (sketch variants: one of 16); every WAVE stages its own tile of <= 64 records into a private
 // LDS buffer (its next DMA is issued the moment the tile is consumed) and parses it - there is no workgroup
 // barrier anywhere in the steady state.  The LDS this frees (the 256-thread kernel spends all of it on
 // co-resident tiles) holds the tuple bins: a tuple waits in the 8-slot bin of its key partition, and a full bin

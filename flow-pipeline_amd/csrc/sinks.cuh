@@ -20,8 +20,7 @@ constexpr int LDS_SLOTS = 64;      // per-workgroup hot-key slots (2.5 KiB)
 constexpr int LDS_PROBES = 2;
 constexpr int PART_LOG2_MAX = 8;   // key partitions of the scatter sink (<= 256: see tools/scatter_bench.hip)
 constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
-// wave-tile kernel residency: 2 workgroups x 8 waves per CU, one LDS tile per wave (what the 160 KiB of LDS admit
-// next to the tuple bins).  FA_WBLOCK / FA_WT_STRIDE: geometry experiments (tools/wave_scaling.sh).
+// FA_WBLOCK / FA_WT_STRIDE / FA_BIN_BYTES: geometry experiments (tools/gpu_ab.sh builds variants of the library).
 // Geometry of the wave-tile kernel, AS-rollup variant: 2 workgroups x 12 waves per CU = 6 waves per SIMD, tile buffers
 // of 4864 bytes (64 records of 76 bytes), half-line bins (64 bytes = 8 compact tuples).  Round 1 ran 2 x 8 waves with
 // 5472-byte tiles and full-line bins (all the LDS there was next to 16-byte tuples); with compact tuples a half-line bin
@@ -40,9 +39,9 @@ constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
 #define FA_WT_EARLY 0
 #endif
 constexpr bool WT_EARLY = FA_WT_EARLY != 0;  // next DMA issued between the parse and the sink (experiment): 1 always, 2 while the hot-key table is on
-constexpr int WBLOCK = FA_WBLOCK;   // 8 waves, each with a private LDS tile of <= 64 records
+constexpr int WBLOCK = FA_WBLOCK;   // 12 waves, each with a private LDS tile of <= 64 records
 constexpr int WT_RECS = 64;
-constexpr int WT_STRIDE = FA_WT_STRIDE;  // 5472 = 64 records x 85 B + alignment slack (16-byte multiple); overreads land in the next tile / the bins
+constexpr int WT_STRIDE = FA_WT_STRIDE;  // 4864 = 64 records x 76 B (16-byte multiple); longer records: fewer per tile; overreads land in the next tile / the bins
 constexpr int WT_STRIDE_CMS = 5216;  // tile buffers of the kernel variants that serve a sketch (ingest.cuh, wtile_stride): 16 waves, what the 160 KiB leave
 constexpr int WT_WG_PER_CU = 2;
 constexpr int WBLOCK_CMS = 2 * FA_WBLOCK > 1024 ? 1024 : 2 * FA_WBLOCK;  // sketch variants: one big workgroup per CU (ingest.cuh, wtile_block)
