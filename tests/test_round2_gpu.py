@@ -422,3 +422,72 @@ def test_small_tables_every_region_geometry(gpu_lib, fa, po, cap_log2, mode):
         assert st["records_ok"] == n and st["records_bad"] == 0
     both = fa.dist.merge_rows_host([closed, rest])
     assert both.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configurations_against_the_oracle(gpu_lib, fa, po, seed):
+    """Differential run over randomly drawn configurations - key-set mask, generator mode, table sizes (every region
+    geometry), window / sub-bucket length, launch sizes, host-fed vs device-resident input - everything the library
+    produces against the oracle restatements of the same records: flows_5m rows, (SrcAddr,DstPort,Proto) rows, port
+    group-bys, per-minute series, both sketches."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    ks = int(rng.choice([1, 3, 7, 9, 25, 41, 63]))
+    mode = int(rng.choice([0, 1, 2, 3, 5]))
+    n = int(rng.integers(150_000, 900_000))
+    sub = int(rng.choice([60, 300]))
+    kw = dict(mode=mode, framed=1, seed=500 + seed, n_total=n, span_secs=int(rng.choice([600, 900, 1500])),
+              zipf_log2_universe=int(rng.integers(8, 19)), zipf_s_x100=int(rng.choice([80, 110, 140])))
+    gp = po.gen_params(**kw)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    assert status.sum() == 0
+    depth, wl2, cseed = int(rng.integers(2, 6)), int(rng.integers(10, 17)), int(rng.integers(1, 1 << 30))
+    cuts = np.sort(rng.choice(np.arange(1, n), size=int(rng.integers(1, 5)), replace=False))
+    bounds = [0] + [int(c) for c in cuts] + [n]
+    cfg = dict(framed=True, key_sets=ks, window_secs=300, subwindow_secs=sub, table_capacity_log2=int(rng.integers(10, 21)),
+               wide_capacity_log2=int(rng.integers(8, 19)), cms_depth=depth, cms_width_log2=wl2, cms_seed=cseed, topk_capacity_log2=20,
+               max_batch_records=max(b - a for a, b in zip(bounds, bounds[1:])))
+    device_fed = bool(rng.integers(0, 2))
+    with fa.FlowAgg(**cfg) as agg:
+        for a, b in zip(bounds, bounds[1:]):
+            if device_fed:
+                mp = fa.mock_params(**kw)
+                d_buf = torch.empty((b - a) * 256 + 4096, dtype=torch.uint8, device="cuda")
+                d_off = torch.empty(b - a + 1, dtype=torch.int32, device="cuda")
+                w = agg.mock_generate_device(mp, a, b - a, d_buf.data_ptr(), d_buf.numel(), d_off.data_ptr())
+                assert w == int(off[b] - off[a])
+                agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), b - a)
+            else:
+                agg.ingest(buf[int(off[a]):int(off[b])], off[a:b + 1] - off[a])
+        st = agg.stats()
+        assert st["records_ok"] == n and st["records_bad"] == 0, (cfg, kw)
+        # flows_5m: every window of the granule the ctx aggregates at (sub-buckets folded by the library at read time)
+        ref = po.Rollup(sub)
+        ref.ingest(buf, off, 1)
+        want = ref.rows()
+        if sub == 300:
+            assert agg.read_window().tobytes() == want.tobytes(), (cfg, kw)
+        else:
+            assert int(agg.read_window()["count"].sum()) == n
+        if ks & fa.FA_KEYS_ADDR_PORT_PROTO:
+            if sub == 300:
+                got_app, want_app = agg.read_window_app(), po.rollup_app(rows, status, 300)
+            else:  # 60-second sub-buckets: the 5-minute window that starts one minute into the stream (sliding)
+                got_app = agg.read_window_app(po.T0 + 60)
+                want_app = po.rollup_app(rows, status, 60, window=300, timeslot=po.T0 + 60)
+            assert len(got_app) == len(want_app), (len(got_app), len(want_app), cfg, kw)
+            for c in ("timeslot", "src_addr", "dst_port", "proto", "bytes", "packets", "count"):
+                assert np.array_equal(got_app[c], want_app[c]), (c, cfg, kw)
+        if ks & fa.FA_KEYS_PORT_HIST:
+            for d in (0, 1):
+                g, w_ = agg.top_ports(d), po.top_ports(rows, status, d)
+                assert all(np.array_equal(g[c], w_[c]) for c in ("port", "weight", "count")), (d, cfg, kw)
+        if ks & fa.FA_KEYS_MINUTE_SERIES:
+            g, w_ = agg.minute_series(), po.minute_series(rows, status)
+            assert all(np.array_equal(g[c], w_[c]) for c in ("minute", "weight", "count")), (cfg, kw)
+        with np.errstate(over="ignore"):
+            wgt = rows["bytes"] * rows["sampling_rate"]
+        for col, key_set in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+            if ks & key_set:
+                assert np.array_equal(agg.cms_read(key_set).reshape(-1), po.cms_sketch_numpy(rows[col], wgt, depth, wl2, cseed)), (col, cfg, kw)
