@@ -15,6 +15,9 @@ for f in $S/bench_*.json; do
 done
 cp $P/summary.txt $D/${TAG}_rocprof_summary.txt
 cp $P/traffic.json $D/${TAG}_traffic.json
+for v in ks7 ks9; do  # profiles of the sketch variant (config 3 shape) and of the (SrcAddr,DstPort,Proto) sink (tools/profile.sh <tag>_<v> ...)
+  [ -s ${P}_$v/summary.txt ] && cp ${P}_$v/summary.txt $D/${TAG}_${v}_rocprof_summary.txt
+done
 [ -s $S/config3_1B.json ] && grep '^{' $S/config3_1B.json | tail -1 > $D/${TAG}_config3_1B.json
 [ -s $S/config4_8ranks_1gpu.json ] && grep '^{' $S/config4_8ranks_1gpu.json | tail -1 > $D/${TAG}_config4_8ranks_1gpu.json
 [ -s $S/config5_100M.json ] && grep '^{' $S/config5_100M.json | tail -1 > $D/${TAG}_config5_100M.json

@@ -63,7 +63,7 @@ for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
          "where counter_name=? group by kernel_name")
     for name, n, avg, dur in d.execute(q, (counter,)):
         key = ("wtile_kernel" if "wtile_kernel" in name else "tile_kernel" if "tile_kernel<0" in name
-               else "cms_agg_kernel" if "cms_agg_kernel" in name else "agg8_kernel" if "agg8_kernel" in name
+               else "cms_agg_kernel" if "cms_agg_kernel" in name else "wagg_kernel" if "wagg_kernel" in name else "agg8_kernel" if "agg8_kernel" in name
                else "agg_kernel" if "fa::agg_kernel" in name else "deferred_kernel" if "deferred_kernel<0" in name
                else "probe_kernel" if "probe_kernel" in name else None)
         if key:

@@ -13,6 +13,10 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python $ROOT/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python $ROOT/bench.py $ARGS > $OUT/pmc_write.log 2>&1
+if [ -n "$PROF_TCC" ]; then  # memory-side atomics / L2 requests (counter names as this rocprofv3 lists them; a pass with an unknown name just fails)
+  rocprofv3 -L 2>/dev/null | grep -i -o "TCC_[A-Z0-9_]*ATOMIC[A-Za-z0-9_]*\|TCC_REQ_sum\|TCC_HIT_sum\|TCC_MISS_sum" | sort -u > $OUT/tcc_counter_names.txt
+  rocprofv3 --kernel-trace --pmc TCC_ATOMIC_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_tcc -o tcc -- python $ROOT/bench.py $ARGS > $OUT/pmc_tcc.log 2>&1
+fi
 if [ -n "$PROF_SQ" ]; then
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq1 -o sq1 -- python $ROOT/bench.py $ARGS > $OUT/pmc_sq1.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS -d $OUT/pmc_sq2 -o sq2 -- python $ROOT/bench.py $ARGS > $OUT/pmc_sq2.log 2>&1
