@@ -424,7 +424,7 @@ def test_small_tables_every_region_geometry(gpu_lib, fa, po, cap_log2, mode):
     assert both.tobytes() == want.tobytes()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FA_FUZZ_SEEDS", "24"))))  # (soak runs: FA_FUZZ_SEEDS=200)
 def test_random_configurations_against_the_oracle(gpu_lib, fa, po, seed):
     """Differential run over randomly drawn configurations - key-set mask, generator mode, table sizes (every region
     geometry), window / sub-bucket length, launch sizes, host-fed vs device-resident input - everything the library
