@@ -694,103 +694,108 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
 }
 
 // ---- Count-Min scatter sink: fold the sketch tuples -------------------------------------------------
-// One workgroup per (sketch, slice): the slice's counters live in a dense LDS array for the launch, every tuple of the
-// slice's segments is one LDS add, and the array is folded into copy 0 of the sketch with plain, coalesced 64-bit
-// read-modify-writes (the slice belongs to this workgroup alone; the atomic paths use the other copies or run in other
-// kernels).  Same segment geometry and walk as agg8_kernel.
+// One workgroup per (sketch, partition): the partition's counters (depth rows x 2^sub columns) live in a dense LDS array
+// for the launch, every tuple {l1, l2, weight} of the partition's segments is `depth` LDS adds, and the array is folded
+// into copy 0 of the sketch with plain, coalesced 64-bit read-modify-writes (the partition's `depth` blocks of 2^sub
+// counters belong to this workgroup alone; the atomic paths use the other copies or run in other kernels).  Segment
+// geometry and walk of the wide (16-byte) flows_5m tuples: agg_fetch<BACK, false>.
 __global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t set_mask) {
-    constexpr uint32_t WAVES = AGG_BLOCK / 64;
-    constexpr uint32_t FGRP = CMS_SU, BGRP = CMS_SU * 8;
-    typedef Agg8BatchT<CMS_SU> Batch;
-    constexpr uint32_t NFG = (AGG_MAX_NWG + AGG_PAD) / FGRP, NBG = (AGG_MAX_NWG + AGG_PAD) / BGRP;
-    __shared__ unsigned long long arr[1u << CMS_SLICE_LOG2_MAX];  // 128 KiB
+    __shared__ unsigned long long arr[1u << CMS_PART_LOG2_MAX];  // 128 KiB
     __shared__ uint32_t pc[AGG_MAX_NWG + AGG_PAD], pcb[AGG_MAX_NWG + AGG_PAD];
-    __shared__ uint16_t flv[NFG], blv[NBG];
-    // blockIdx -> (sketch, slice): only the enabled sketches have workgroups
+    __shared__ uint32_t maxc_s[2];
+    // blockIdx -> (sketch, partition): only the enabled sketches have workgroups
     const uint32_t set = (set_mask == 3u) ? blockIdx.x / CMS_NPART : (set_mask >> 1);
-    const uint32_t part = set * CMS_NPART + blockIdx.x % CMS_NPART;
-    const uint32_t slice = 1u << a.cms_sl2;
-    for (uint32_t i = threadIdx.x; i < slice; i += AGG_BLOCK) arr[i] = 0;
+    const uint32_t prefix = blockIdx.x % CMS_NPART, part = set * CMS_NPART + prefix;
+    const uint32_t sub = a.cms_sub, ncnt = a.cms_depth << sub;
+    for (uint32_t i = threadIdx.x; i < ncnt; i += AGG_BLOCK) arr[i] = 0;
+    if (threadIdx.x < 2) maxc_s[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t mymax = 0, mymaxb = 0;
     for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_PAD; i += AGG_BLOCK) {
-        pc[i] = i < a.nwg ? a.cseg_counts[(size_t)part * a.nwg + i] : 0u;
-        pcb[i] = i < a.nwg ? a.cseg_counts[((size_t)CMS_SETS * CMS_NPART + part) * a.nwg + i] : 0u;
+        const uint32_t c = i < a.nwg ? a.cseg_counts[(size_t)part * a.nwg + i] : 0u;
+        const uint32_t cb = i < a.nwg ? a.cseg_counts[((size_t)CMS_SETS * CMS_NPART + part) * a.nwg + i] : 0u;
+        pc[i] = c;
+        pcb[i] = cb;
+        mymax = max(mymax, c);
+        mymaxb = max(mymaxb, cb);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, o));
+        mymaxb = max(mymaxb, (uint32_t)__shfl_xor((int)mymaxb, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&maxc_s[0], mymax);
+        atomicMax(&maxc_s[1], mymaxb);
     }
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint4* pbase = reinterpret_cast<const uint4*>(a.cseg + (size_t)part * a.cregion);
+    const uint4* pbase = a.cseg + (size_t)part * a.cregion;
+    KArgs g = a;  // (agg_fetch reads the segment geometry from capq / nwg)
+    g.capq = a.ccapq;
     __syncthreads();
-    for (uint32_t g = threadIdx.x; g < NFG; g += AGG_BLOCK) {
-        uint32_t m = 0;
-        for (uint32_t s = 0; s < FGRP; s++) m = max(m, pc[g * FGRP + s]);
-        flv[g] = (uint16_t)min((m + 127u) >> 7, 65535u);
-    }
-    for (uint32_t g = threadIdx.x; g < NBG; g += AGG_BLOCK) {
-        uint32_t m = 0;
-        for (uint32_t s = 0; s < BGRP; s++) m = max(m, pcb[g * BGRP + s]);
-        blv[g] = (uint16_t)(m ? (m / 2u + 1u + 7u) >> 3 : 0u);
-    }
-    __syncthreads();
-    // A heavy hitter sends one tuple per wave-tile to each of its counters: in the slices of such counters a good part
-    // of every 64 consecutive tuples carries the SAME slot, and an LDS atomic serializes the lanes that share an
-    // address.  So the lanes of a load are folded first when many of them agree with the first or the last lane's slot
-    // (two cheap wave-uniform probes): one lane adds the wave's sum.
-    auto consume = [&](const Batch& b) {
+    const uint32_t maxc = maxc_s[0], maxcb = maxc_s[1];
+    // A heavy hitter sends one tuple per wave-tile: a good part of every 64 consecutive tuples of its partition carries
+    // the SAME key, and an LDS atomic serializes the lanes that share an address.  So the lanes of a load are folded
+    // first when many of them agree with the first or the last lane's key (two cheap wave-uniform probes): one lane
+    // adds the wave's sum.
+    auto consume = [&](const AggBatch& b) {
 #pragma unroll
-        for (int e = 0; e < CMS_SU * 2; e++) {
-            const uint4& q = b.t[e >> 1];
-            const uint32_t x = (e & 1) ? q.z : q.x, y = (e & 1) ? q.w : q.y;
-            unsigned long long w = ((unsigned long long)y << 18) | (x >> 14);
-            const uint32_t slot = x & 0x3fffu;
+        for (int e = 0; e < AGG_SU; e++) {
+            const uint4& q = b.t[e];
+            unsigned long long w = (unsigned long long)q.w << 32 | q.z;
             bool v = ((b.v >> e) & 1u) && w;
 #pragma unroll
             for (int round = 0; round < 2; round++) {
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
                 if (m == 0ull) break;
                 const int leader = round == 0 ? __builtin_ctzll(m) : 63 - __builtin_clzll(m);
-                const uint32_t ls = (uint32_t)__builtin_amdgcn_readlane((int)slot, leader);
-                const bool same = v && slot == ls;
+                const uint32_t lx = (uint32_t)__builtin_amdgcn_readlane((int)q.x, leader), ly = (uint32_t)__builtin_amdgcn_readlane((int)q.y, leader);
+                const bool same = v && q.x == lx && q.y == ly;
                 if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(same)) < 8) continue;
                 const unsigned long long sum = wave_sum_u64(same ? w : 0ull);
-                if ((int)lane == leader) atomicAdd(&arr[ls], sum);
+                if ((int)lane == leader)
+                    for (uint32_t r = 0; r < a.cms_depth; r++) atomicAdd(&arr[(r << sub) + cms_low(lx, ly, r, sub)], sum);
                 v = v && !same;
             }
-            if (v) atomicAdd(&arr[slot], w);
+            if (v)
+                for (uint32_t r = 0; r < a.cms_depth; r++) atomicAdd(&arr[(r << sub) + cms_low(q.x, q.y, r, sub)], w);
         }
     };
-#define FA_CMS_PASS(BACK, LV, NG, GSEGS, PCNT)                                                            \
-    {                                                                                                       \
-        const uint32_t ngroups = (a.nwg + (GSEGS) - 1u) / (GSEGS);                                           \
-        uint32_t g = wave, j = 0;                                                                           \
-        auto settle_item = [&]() {                                                                          \
-            while (g < ngroups && j >= (uint32_t)__builtin_amdgcn_readfirstlane((int)LV[min(g, (uint32_t)(NG) - 1u)])) { \
-                g += WAVES;                                                                                 \
-                j = 0;                                                                                      \
-            }                                                                                               \
-        };                                                                                                  \
-        settle_item();                                                                                      \
-        Batch b0, b1;                                                                                       \
-        agg8_fetch<BACK, CMS_SU>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                             \
-        while (g < ngroups) {                                                                               \
-            j++;                                                                                            \
-            settle_item();                                                                                  \
-            agg8_fetch<BACK, CMS_SU>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b1);                         \
-            consume(b0);                                                                                    \
-            if (g >= ngroups) break;                                                                        \
-            j++;                                                                                            \
-            settle_item();                                                                                  \
-            agg8_fetch<BACK, CMS_SU>(a.ccapq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                         \
-            consume(b1);                                                                                    \
-        }                                                                                                   \
+    constexpr uint32_t STEP = (AGG_BLOCK / 64) * AGG_SU;
+    const uint32_t levels = (__builtin_amdgcn_readfirstlane(maxc) + 63u) / 64u;  // level j: tuples [64j, 64j+64) of every segment
+    for (uint32_t j = 0; j < levels; j++) {
+        AggBatch b0, b1;
+        uint32_t w0 = wave * AGG_SU;
+        agg_fetch<false, false>(g, pbase, pc, w0, lane, j, b0);
+        while (true) {
+            agg_fetch<false, false>(g, pbase, pc, w0 + STEP, lane, j, b1);
+            consume(b0);
+            agg_fetch<false, false>(g, pbase, pc, w0 + 2 * STEP, lane, j, b0);
+            consume(b1);
+            w0 += 2 * STEP;
+            if (w0 >= a.nwg) break;
+        }
     }
-    FA_CMS_PASS(false, flv, NFG, FGRP, pc)
-    FA_CMS_PASS(true, blv, NBG, BGRP, pcb)
-#undef FA_CMS_PASS
+    const uint32_t levels_b = (__builtin_amdgcn_readfirstlane(maxcb) + 7u) >> 3;  // back parts: 8 tuples per segment and level
+    constexpr uint32_t STEP_B = STEP * 8u;
+    for (uint32_t j = 0; j < (maxcb ? levels_b : 0u); j++) {
+        AggBatch b0, b1;
+        uint32_t w0 = wave * AGG_SU * 8u;
+        agg_fetch<true, false>(g, pbase, pcb, w0, lane, j, b0);
+        while (true) {
+            agg_fetch<true, false>(g, pbase, pcb, w0 + STEP_B, lane, j, b1);
+            consume(b0);
+            agg_fetch<true, false>(g, pbase, pcb, w0 + 2 * STEP_B, lane, j, b0);
+            consume(b1);
+            w0 += 2 * STEP_B;
+            if (w0 >= a.nwg) break;
+        }
+    }
     __syncthreads();
-    unsigned long long* sk = (set ? a.cms_dst : a.cms_src) + ((size_t)(part & (CMS_NPART - 1u)) << a.cms_sl2);
-    const size_t total = (size_t)a.cms_depth << a.cms_wl2;  // slices past the end of the sketch are empty
-    const size_t c0 = (size_t)(part & (CMS_NPART - 1u)) << a.cms_sl2;
-    for (uint32_t i = threadIdx.x; i < slice; i += AGG_BLOCK) {
+    unsigned long long* sk = set ? a.cms_dst : a.cms_src;
+    for (uint32_t i = threadIdx.x; i < ncnt; i += AGG_BLOCK) {
         const unsigned long long v = arr[i];
-        if (v && c0 + i < total) sk[i] += v;
+        const uint32_t r = i >> sub, col = i & ((1u << sub) - 1u);
+        if (v) sk[((size_t)r << a.cms_wl2) + ((size_t)prefix << sub) + col] += v;
     }
 }
 

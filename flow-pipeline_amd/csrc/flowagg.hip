@@ -67,7 +67,7 @@ struct fa_ctx {
     uint32_t* seg_counts = nullptr;
     size_t seg_counts_cap = 0;
     // Count-Min scatter sink (sinks.cuh): sketch tuples' segments
-    uint2* cseg = nullptr;
+    uint4* cseg = nullptr;
     size_t cseg_bytes = 0;
     uint32_t* cseg_counts = nullptr;
     size_t cseg_counts_cap = 0;
@@ -82,7 +82,7 @@ struct fa_ctx {
                                // each) is cheaper without the detour through the segments
     uint64_t seen_wused = 0, seen_ok_w = 0;
     bool cms_atomic = false;  // env FA_CMS=atomic (A/B, tests): every sketch update through memory-side atomics
-    uint32_t cms_sl2 = 0;     // log2(counters per sketch slice)
+    bool cms_scatter_ok = false;  // the sketch geometry fits the scatter sink (256 partitions of <= 2^14 counters)
     int sink_mode = 0;  // 0 auto, 1 direct, 2 scatter (env FA_SINK)
     bool use_wave_tiles = false;  // decision for the batch being launched
     bool use_t8 = false;          // ... compact 8-byte tuples (table.cuh) for it
@@ -294,7 +294,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
         const int v = atoi(d);
         c->agg_passes_forced = (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 0u;
     }
-    c->cms_sl2 = (uint32_t)std::max<int>(0, (int)log2_ceil((uint64_t)cfg.cms_depth << cfg.cms_width_log2) - 8);
+    c->cms_scatter_ok = cms_scatterable(cfg.cms_depth, cfg.cms_width_log2);
     if (const char* d = getenv("FA_DEFERRED")) c->deferred_beside = !strcmp(d, "beside");
     if (const char* d = getenv("FA_STAGE_THREADS")) c->stage_threads = (unsigned)std::min(64, std::max(1, atoi(d)));
     c->stage_threads = std::min(c->stage_threads, std::max(1u, std::thread::hardware_concurrency()));
@@ -880,15 +880,15 @@ static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, bool t8, KArgs& a)
     return FA_OK;
 }
 
-// Segments of the Count-Min scatter sink for a batch of n records processed by nwg workgroups: per (sketch slice,
-// workgroup) 3x the mean + 64 tuples (a heavy hitter adds up to one tuple per wave-tile to each of its slices after the
-// wave-level fold: about as much again as the slice's mean; what still overflows is added with atomics).
+// Segments of the Count-Min scatter sink for a batch of n records processed by nwg workgroups: per (sketch partition,
+// workgroup) 3x the mean + 32 tuples of 16 bytes (a heavy hitter adds up to one tuple per wave-tile to its partition after
+// the wave-level fold: about as much again as the partition's mean; what still overflows is added with atomics).
 static int ensure_csegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     const size_t nparts = (size_t)CMS_SETS * CMS_NPART;
-    const size_t mean = n * c->cfg.cms_depth / ((size_t)CMS_NPART * nwg);
-    const uint32_t capq = (uint32_t)((3 * mean + 64 + 7) & ~(size_t)7);
-    const size_t region = (size_t)nwg * capq + 24;
-    const size_t bytes = region * nparts * sizeof(uint2);
+    const size_t mean = n / ((size_t)CMS_NPART * nwg);
+    const uint32_t capq = (uint32_t)((3 * mean + 32 + 3) & ~(size_t)3);
+    const size_t region = (size_t)nwg * capq + 12;
+    const size_t bytes = region * nparts * sizeof(uint4);
     if (c->cseg_bytes < bytes) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->cseg);
@@ -909,10 +909,10 @@ static int ensure_csegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     a.cseg = c->cseg;
     a.cseg_counts = c->cseg_counts;
     a.ccapq = capq;
-    a.ccapb = std::min<uint32_t>(std::max<uint32_t>(16u, (capq / 8) & ~7u), 0xfff8u);
+    a.ccapb = std::min<uint32_t>(std::max<uint32_t>(8u, (capq / 8) & ~3u), 0xfffcu);
     a.ccapf = std::min<uint32_t>(capq - a.ccapb, 0xffffu * CMS_BIN);
     a.cregion = region;
-    a.cms_sl2 = c->cms_sl2;
+    a.cms_sub = c->cfg.cms_width_log2 - 8u;
     return FA_OK;
 }
 
@@ -1011,7 +1011,7 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         rc = ensure_segments(c, n, (uint32_t)grid, c->use_t8, a);
         if (rc) return rc;
     }
-    if (c->use_wave_tiles && (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) && !c->cms_atomic && c->cms_sl2 <= CMS_SLICE_LOG2_MAX) {
+    if (c->use_wave_tiles && (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) && !c->cms_atomic && c->cms_scatter_ok) {
         rc = ensure_csegments(c, n, (uint32_t)grid, a);
         if (rc) return rc;
     }
@@ -2005,11 +2005,12 @@ extern "C" int fa_cms_reset(fa_ctx* c, uint32_t key_set) {
     return FA_OK;
 }
 
-static uint64_t cms_hash_host(const uint8_t key[16], uint64_t seed, uint32_t row) {
-    uint64_t lo, hi;
+static uint32_t cms_column_host(const uint8_t key[16], uint64_t seed, uint32_t wl2, uint32_t row) {
+    uint64_t lo, hi, h1, h2;
     memcpy(&lo, key, 8);
     memcpy(&hi, key + 8, 8);
-    return cms_hash(lo, hi, seed, row);  // (sinks.cuh: the one definition, host and device)
+    cms_hash2(lo, hi, seed, h1, h2);  // (sinks.cuh: the one definition, host and device)
+    return cms_column(cms_key(h1, h2, wl2), row, wl2);
 }
 
 extern "C" int fa_cms_query(fa_ctx* c, uint32_t key_set, const uint8_t key[16], uint64_t* weight) {
@@ -2021,7 +2022,7 @@ extern "C" int fa_cms_query(fa_ctx* c, uint32_t key_set, const uint8_t key[16], 
     if (rc) return rc;
     uint64_t best = ~0ull;
     for (uint32_t r = 0; r < c->cfg.cms_depth; r++) {
-        size_t idx = ((size_t)r << c->cfg.cms_width_log2) + (size_t)(cms_hash_host(key, c->cfg.cms_seed, r) >> (64 - c->cfg.cms_width_log2));
+        size_t idx = ((size_t)r << c->cfg.cms_width_log2) + cms_column_host(key, c->cfg.cms_seed, c->cfg.cms_width_log2, r);
         unsigned long long v;
         HIPCHK(c, hipMemcpy(&v, p + idx, 8, hipMemcpyDeviceToHost));
         best = std::min<uint64_t>(best, v);

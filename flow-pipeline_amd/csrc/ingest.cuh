@@ -222,8 +222,8 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             if (cl && a.cseg) {  // scatter sink: no atomics (whole wave: the bin flushes need every lane)
                 // (bin lists: the wave's tile buffer is dead by now - behind the 768 bytes the folds used)
                 uint32_t* list = const_cast<uint32_t*>(tile) + 256;
-                if (on_s) cms_scatter(a, *cl, list, 0u, vs, r.src, ws, sh1, sh2);
-                if (on_d) cms_scatter(a, *cl, list, 1u, vd, r.dst, wd, dh1, dh2);
+                if (on_s) cms_scatter(a, *cl, list, 0u, vs, ws, sh1, sh2);
+                if (on_d) cms_scatter(a, *cl, list, 1u, vd, wd, dh1, dh2);
             } else {
                 if (vs) cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, ws);
                 if (vd) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, wd);
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
             const uint32_t cnt = min(cl->bin_cnt[p] & 0xffffu, CMS_BIN);
             if (sl < cnt) {
                 const uint32_t ob = (cl->part_cnt[p] >> 16) + sl;
-                const uint2 t = cl->bins[idx];
+                const uint4 t = cl->bins[idx];
                 if (ob < a.ccapb) a.cseg[(size_t)p * a.cregion + (size_t)blockIdx.x * a.ccapq + (a.ccapq - 1u - ob)] = t;
                 else cms_atomic_tuple(a, p, t);
             }

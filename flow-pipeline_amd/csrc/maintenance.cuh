@@ -208,8 +208,9 @@ __global__ void topk_rows_kernel(const KeySlot* ks, uint32_t nslots, const unsig
         unsigned long long best = ~0ull;
         uint64_t h, h2;
         cms_hash2(lo, hi, seed, h, h2);
-        for (uint32_t r = 0; r < depth; r++, h += h2) {
-            const unsigned long long v = cms[((size_t)r << wl2) + (size_t)(h >> (64 - wl2))];
+        const CmsKey k = cms_key(h, h2, wl2);
+        for (uint32_t r = 0; r < depth; r++) {
+            const unsigned long long v = cms[((size_t)r << wl2) + cms_column(k, r, wl2)];
             best = v < best ? v : best;
         }
         const unsigned int j = atomicAdd(&ctr->ks_rows, 1u);

@@ -156,11 +156,11 @@ struct KArgs {
     uint32_t rlog2;        // log2(regions of the device-wide table) = as_rlog2(log2 slots)  (table.cuh)
     uint32_t agg_passes;   // agg8_kernel: passes over a partition's tuples (1, 2, 4, 8), each with 1 / passes of the groups in the LDS table
     // Count-Min scatter sink (cseg == nullptr: every sketch update is a memory-side atomic, cms_add)
-    uint2* cseg;            // [CMS_SETS * CMS_NPART][cregion] sketch tuples; partition p, workgroup w: cseg[p*cregion + w*ccapq + q]
+    uint4* cseg;            // [CMS_SETS * CMS_NPART][cregion] sketch tuples {l1, l2, weight}; partition p, workgroup w: cseg[p*cregion + w*ccapq + q]
     uint32_t* cseg_counts;  // [2][CMS_SETS * CMS_NPART][nwg]: tuples at the front (whole 64-byte chunks) / at the back of a segment
     uint32_t ccapq, ccapf, ccapb;
     unsigned long long cregion;
-    uint32_t cms_sl2;       // log2(counters per sketch partition) <= CMS_SLICE_LOG2_MAX
+    uint32_t cms_sub;       // log2(counters per row of a sketch partition) = cms_wl2 - 8 on the scatter path
     // wide key sets (wide.cuh)
     uint32_t key_sets;     // runtime mask (the KS_ALL kernel variant tests it)
     WSlot* wtab;
@@ -214,19 +214,33 @@ __device__ __forceinline__ void agg_global(const KArgs& a, uint64_t k0, uint64_t
     }
 }
 
-// Row hashes of the sketch by double hashing (Kirsch & Mitzenmacher): two 64-bit hashes per key, row r uses
-// h1 + r * h2 - two mix64 per key instead of two per key AND row (at depth 4 and two sketches the per-row hashing
-// alone cost more issue slots than the whole protobuf parse).  column(r) = (h1 + r * h2) >> (64 - width_log2).
-// The CPU sketches of the test infrastructure (C and numpy) use the same definition (DESIGN.md "Sketch").
+// The sketch (DESIGN.md "Sketch"; the test infrastructure restates it in C and in numpy): a PREFIX-PARTITIONED
+// Count-Min sketch.  Two 64-bit hashes per key (two mix64 per key, not per key and row):
+//   a = mix64(lo ^ mix64(seed + phi));  h1 = mix64(a ^ hi);  h2 = a | 1
+//   pbits = min(8, width_log2 - 4), sub = width_log2 - pbits
+//   prefix = h1 & (2^pbits - 1);  l1 = h1 >> 32;  l2 = (h2 >> 32) | 1      (32-bit double hashing, Kirsch & Mitzenmacher)
+//   column(r) = prefix << sub | (uint32)(l1 + r * l2) >> (32 - sub)
+// = 2^pbits independent sketches of width 2^sub; the key picks one with hash bits that take no part in the row hashes.
+// Same expected error e / 2^width_log2 * sum(W) as the flat layout, rows independent given the prefix - and all `depth`
+// counters of a key sit in ONE partition: an update is one 16-byte tuple {l1, l2, weight} for the scatter sink below
+// instead of `depth` tuples (round 2 measured the sink at 4 tuples per address: 40 % of the ingest kernel's time).
 __host__ __device__ __forceinline__ void cms_hash2(uint64_t lo, uint64_t hi, uint64_t seed, uint64_t& h1, uint64_t& h2) {
     const uint64_t a = mix64(lo ^ mix64(seed + 0x9E3779B97F4A7C15ull));
     h1 = mix64(a ^ hi);
     h2 = a | 1ull;
 }
-__host__ __device__ __forceinline__ uint64_t cms_hash(uint64_t lo, uint64_t hi, uint64_t seed, uint32_t row) {
-    uint64_t h1, h2;
-    cms_hash2(lo, hi, seed, h1, h2);
-    return h1 + (uint64_t)row * h2;
+__host__ __device__ __forceinline__ uint32_t cms_pbits(uint32_t wl2) { return wl2 - 4u < 8u ? wl2 - 4u : 8u; }
+struct CmsKey {
+    uint32_t prefix, l1, l2;
+};
+__host__ __device__ __forceinline__ CmsKey cms_key(uint64_t h1, uint64_t h2, uint32_t wl2) {
+    return CmsKey{(uint32_t)h1 & ((1u << cms_pbits(wl2)) - 1u), (uint32_t)(h1 >> 32), (uint32_t)(h2 >> 32) | 1u};
+}
+// column of row r inside the key's partition (sub = width_log2 - pbits bits)
+__host__ __device__ __forceinline__ uint32_t cms_low(uint32_t l1, uint32_t l2, uint32_t r, uint32_t sub) { return (l1 + r * l2) >> (32u - sub); }
+__host__ __device__ __forceinline__ uint32_t cms_column(const CmsKey& k, uint32_t r, uint32_t wl2) {
+    const uint32_t sub = wl2 - cms_pbits(wl2);
+    return (k.prefix << sub) | cms_low(k.l1, k.l2, r, sub);
 }
 // The sketch is kept in CMS_REPLICAS copies; a workgroup adds to copy blockIdx % CMS_REPLICAS and the copies
 // are summed into copy 0 before anything reads the sketch (cms_fold_kernel).  Counters of heavy hitters are
@@ -234,82 +248,55 @@ __host__ __device__ __forceinline__ uint64_t cms_hash(uint64_t lo, uint64_t hi, 
 // 1.9 M updates of the top Zipf-1.1 key per launch cost ~19 ms on one copy); u64 sums commute, so the folded
 // sketch is bit-identical to a single-copy one.
 constexpr uint32_t CMS_REPLICAS = 8;
+__device__ __forceinline__ void cms_add_key(unsigned long long* cms, uint32_t depth, uint32_t wl2, const CmsKey& k, uint64_t w) {
+    if (w == 0) return;
+    unsigned long long* copy = cms + (size_t)(blockIdx.x % CMS_REPLICAS) * ((size_t)depth << wl2);
+    for (uint32_t r = 0; r < depth; r++) atomicAdd(&copy[((size_t)r << wl2) + cms_column(k, r, wl2)], (unsigned long long)w);
+}
 __device__ __forceinline__ void cms_add(unsigned long long* cms, uint32_t depth, uint32_t wl2,
                                         uint64_t seed, const uint32_t key[4], uint64_t w) {
     if (w == 0) return;
     uint64_t lo = (uint64_t)key[1] << 32 | key[0], hi = (uint64_t)key[3] << 32 | key[2];
-    unsigned long long* copy = cms + (size_t)(blockIdx.x % CMS_REPLICAS) * ((size_t)depth << wl2);
     uint64_t h, h2;
     cms_hash2(lo, hi, seed, h, h2);
-    for (uint32_t r = 0; r < depth; r++, h += h2)
-        atomicAdd(&copy[((size_t)r << wl2) + (size_t)(h >> (64 - wl2))], (unsigned long long)w);
+    cms_add_key(cms, depth, wl2, cms_key(h, h2, wl2), w);
 }
 // ---- Count-Min scatter sink --------------------------------------------------------------------------
-// Memory-side atomics retire ~23.7 G line transactions/s whatever their scope (tools/atomics_bench.hip): at depth 4
-// and two sketches that is 8 per record - 2.6 G records/s, 2.5 % of the HBM roofline.  The wave-tile kernel therefore
-// treats sketch updates like flows_5m tuples: the counter space of a sketch (depth << width_log2 counters) is cut
-// into CMS_NPART slices; an update leaves the workgroup as an 8-byte tuple {slot in slice : 14, weight : 50} through
-// an LDS bin of its slice (8 tuples = one 64-byte chunk per store) into the workgroup's private segment of the slice,
-// and cms_agg_kernel (agg.cuh) adds each slice up in a dense LDS array and folds it into the sketch with plain
-// coalesced read-modify-writes - no atomics at all.  The sketch itself is unchanged: same hashes, same counters,
-// u64 sums commute, so it stays bit-identical to the CPU sketch.
-// Needs slices of <= 2^14 counters (32 MiB per sketch at the default depth 4 x 2^20) and weights < 2^50; anything
-// else (bigger sketches, deferred records, the workgroup-tile kernel) keeps the atomic path.
-constexpr uint32_t CMS_NPART = 256, CMS_SETS = 2, CMS_BIN = 8, CMS_SLICE_LOG2_MAX = 14;
+// Memory-side atomics retire ~24 G/s whatever their scope (tools/atomics_bench.hip): at depth 4 and two sketches that is
+// 8 per record - 2.6 G records/s, 2.5 % of the HBM roofline.  The wave-tile kernel therefore treats sketch updates like
+// flows_5m tuples: a key's counters all sit in the partition its prefix names (256 partitions per sketch), an update
+// leaves the workgroup as ONE 16-byte tuple {l1, l2, weight} through an LDS bin of its partition (4 tuples = one 64-byte
+// chunk per store) into the workgroup's private segment of the partition, and cms_agg_kernel (agg.cuh) adds each
+// partition up in a dense LDS array (depth x 2^sub counters) and folds it into the sketch with plain coalesced
+// read-modify-writes - no atomics at all.  u64 sums commute: bit-identical to the CPU sketch.
+// Needs 256 partitions (width_log2 >= 12) of <= 2^14 counters (depth 4: width_log2 <= 20, the default 32 MiB sketch);
+// anything else (bigger sketches, deferred records, the workgroup-tile kernel) keeps the atomic path.
+constexpr uint32_t CMS_NPART = 256, CMS_SETS = 2, CMS_BIN = 4, CMS_PART_LOG2_MAX = 14;
 struct CmsLds {
-    uint2 bins[CMS_SETS * CMS_NPART * CMS_BIN];  // 32 KiB: one 64-byte chunk per slice
+    uint4 bins[CMS_SETS * CMS_NPART * CMS_BIN];   // 32 KiB: one 64-byte chunk per partition
     uint32_t bin_cnt[CMS_SETS * CMS_NPART];       // low half: slots taken, high half: slots written (like the tuple bins)
     uint32_t part_cnt[CMS_SETS * CMS_NPART];      // low half: chunks at the front of the segment, high half: tuples at its back
 };
+// does this sketch geometry go through the scatter sink?
+__host__ __device__ __forceinline__ bool cms_scatterable(uint32_t depth, uint32_t wl2) {
+    return wl2 >= 12u && ((uint64_t)depth << (wl2 - 8u)) <= (1ull << CMS_PART_LOG2_MAX);
+}
 
+// a tuple that found no room in its segment (a heavy hitter's partition): atomics
+__device__ __forceinline__ void cms_atomic_tuple(const KArgs& a, uint32_t p, const uint4& t) {
+    const unsigned long long w = (unsigned long long)t.w << 32 | t.z;
+    cms_add_key((p >> 8) ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, CmsKey{p & (CMS_NPART - 1u), t.x, t.y}, w);
+}
 // Full CMS bins leave as whole 64-byte chunks: lane group g (4 lanes) takes the g-th filled bin, each lane copies
-// 16 bytes - up to 16 chunks per store instruction.  Same hand-over protocol as bins_flush.  A chunk that finds the
-// front part of its segment full is added to the sketch with atomics (skewed batches).
-__device__ __forceinline__ void cms_atomic_tuple(const KArgs& a, uint32_t p, const uint2& t) {
-    unsigned long long* sk = (p >> 8) ? a.cms_dst : a.cms_src;
-    const unsigned long long w = ((unsigned long long)t.y << 18) | (t.x >> 14);
-    const size_t c = ((size_t)(p & (CMS_NPART - 1u)) << a.cms_sl2) + (t.x & 0x3fffu);
-    if (w) atomicAdd(&sk[(size_t)(blockIdx.x % CMS_REPLICAS) * ((size_t)a.cms_depth << a.cms_wl2) + c], w);
-}
-#ifndef FA_CMS_LANE_FLUSH
-#define FA_CMS_LANE_FLUSH 0
-#endif
-// (experiment) The lane that took the last slot of a sketch bin sends the bin off on its own: it waits until the other seven
-// producers have written (they may sit in other waves; they run straight-line code), copies the 64-byte chunk with
-// four 16-byte stores to the next free chunk of the front part of the segment, and reopens the bin.  No cross-lane
-// choreography (the tuple bins' flush pays ~6 dependent LDS round trips per call for it, and a record makes eight
-// sketch inserts): the L2 merges the four stores of a chunk, which follow each other within nanoseconds.
-__device__ __forceinline__ void cms_chunk_flush(const KArgs& a, CmsLds& cl, uint32_t p) {
-    while ((__hip_atomic_load(&cl.bin_cnt[p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < CMS_BIN) {}
-    const uint4* src = reinterpret_cast<const uint4*>(cl.bins) + p * 4u;
-    const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-    const uint32_t chunk = atomicAdd(&cl.part_cnt[p], 1u) & 0xffffu;
-    if ((chunk + 1u) * CMS_BIN <= a.ccapf) {
-        // (cregion and ccapq are multiples of 8 tuples: every segment starts on a 64-byte boundary)
-        uint4* dst = reinterpret_cast<uint4*>(a.cseg + (size_t)p * a.cregion + (size_t)blockIdx.x * a.ccapq + chunk * CMS_BIN);
-        dst[0] = q0;
-        dst[1] = q1;
-        dst[2] = q2;
-        dst[3] = q3;
-    } else {  // front part full (a heavy hitter's slice): atomics
-        cms_atomic_tuple(a, p, make_uint2(q0.x, q0.y));
-        cms_atomic_tuple(a, p, make_uint2(q0.z, q0.w));
-        cms_atomic_tuple(a, p, make_uint2(q1.x, q1.y));
-        cms_atomic_tuple(a, p, make_uint2(q1.z, q1.w));
-        cms_atomic_tuple(a, p, make_uint2(q2.x, q2.y));
-        cms_atomic_tuple(a, p, make_uint2(q2.z, q2.w));
-        cms_atomic_tuple(a, p, make_uint2(q3.x, q3.y));
-        cms_atomic_tuple(a, p, make_uint2(q3.z, q3.w));
-    }
-    __hip_atomic_store(&cl.bin_cnt[p], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (behind the reads above)
-}
+// 16 bytes (one tuple) - up to 16 chunks per store instruction.  Same hand-over protocol as bins_flush.  A chunk that
+// finds the front part of its segment full is added to the sketch with atomics (skewed batches).
 __device__ __forceinline__ void cms_bins_flush(const KArgs& a, CmsLds& cl, uint32_t* scratch, uint32_t fill_part) {
     const unsigned long long fm = __builtin_amdgcn_ballot_w64(fill_part != 0xffffffffu);
     if (fm == 0ull) return;
     const uint32_t ln = __lane_id(), g = ln >> 2, sub = ln & 3u;
     const uint32_t rank = (uint32_t)__builtin_popcountll(fm & ((1ull << ln) - 1ull));
     const uint32_t todo = (uint32_t)__builtin_popcountll(fm);
-    const uint4* bins4 = reinterpret_cast<const uint4*>(cl.bins);
+    const uint4* bins4 = cl.bins;
     for (uint32_t base = 0; base < todo; base += 16u) {
         if (fill_part != 0xffffffffu && rank - base < 16u) scratch[rank - base] = fill_part;
         const bool act = g < min(16u, todo - base);
@@ -327,12 +314,10 @@ __device__ __forceinline__ void cms_bins_flush(const KArgs& a, CmsLds& cl, uint3
         if (act) {
             const uint4 tv = late ? bins4[fp * 4u + sub] : tq;
             if ((chunk + 1u) * CMS_BIN <= a.ccapf) {
-                // (cregion and ccapq are multiples of 8 tuples: every segment starts on a 64-byte boundary)
-                uint4* dst = reinterpret_cast<uint4*>(a.cseg + (size_t)fp * a.cregion + (size_t)blockIdx.x * a.ccapq + chunk * CMS_BIN);
-                dst[sub] = tv;
+                // (cregion and ccapq are multiples of 4 tuples: every segment starts on a 64-byte boundary)
+                a.cseg[(size_t)fp * a.cregion + (size_t)blockIdx.x * a.ccapq + chunk * CMS_BIN + sub] = tv;
             } else {
-                cms_atomic_tuple(a, fp, make_uint2(tv.x, tv.y));
-                cms_atomic_tuple(a, fp, make_uint2(tv.z, tv.w));
+                cms_atomic_tuple(a, fp, tv);
             }
             if (sub == 0) __hip_atomic_store(&cl.bin_cnt[fp], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -370,94 +355,28 @@ __device__ __forceinline__ bool hot_add(HotAddrs& ht, uint32_t set, uint64_t lo,
     return false;
 }
 
-// Flush of the sketch bins that the lanes of this wave have just filled - several per lane: fills[k] = bin or ~0.
-// The bins are listed in wave-private LDS (list: >= 4 x 64 words) and leave 16 per pass (cms_bins_flush's protocol).
-template <int NB>
-__device__ __forceinline__ void cms_bins_flush_multi(const KArgs& a, CmsLds& cl, uint32_t* list, const uint32_t (&fills)[NB]) {
-    const uint32_t ln = __lane_id(), g = ln >> 2, sub = ln & 3u;
-    uint32_t total = 0;
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-        const unsigned long long fm = __builtin_amdgcn_ballot_w64(fills[k] != 0xffffffffu);
-        if (fills[k] != 0xffffffffu) list[total + (uint32_t)__builtin_popcountll(fm & ((1ull << ln) - 1ull))] = fills[k];
-        total += (uint32_t)__builtin_popcountll(fm);
-    }
-    if (total == 0) return;
-    const uint4* bins4 = reinterpret_cast<const uint4*>(cl.bins);
-    for (uint32_t base = 0; base < total; base += 16u) {
-        const bool act = base + g < total;
-        const uint32_t fp = act ? list[base + g] : 0u;
-        const uint32_t c0 = __hip_atomic_load(&cl.bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint4 tq = bins4[fp * 4u + sub];
-        uint32_t chunk = 0;
-        if (act && sub == 0) chunk = atomicAdd(&cl.part_cnt[fp], 1u) & 0xffffu;
-        bool late = false;
-        if (__builtin_amdgcn_ballot_w64(act && (c0 >> 16) < CMS_BIN) != 0ull) {
-            late = true;
-            while (__builtin_amdgcn_ballot_w64(act && (__hip_atomic_load(&cl.bin_cnt[fp], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >> 16) < CMS_BIN) != 0ull) {}
-        }
-        chunk = (uint32_t)__shfl((int)chunk, (int)(ln & ~3u));
-        if (act) {
-            const uint4 tv = late ? bins4[fp * 4u + sub] : tq;
-            if ((chunk + 1u) * CMS_BIN <= a.ccapf) {
-                uint4* dst = reinterpret_cast<uint4*>(a.cseg + (size_t)fp * a.cregion + (size_t)blockIdx.x * a.ccapq + chunk * CMS_BIN);
-                dst[sub] = tv;
-            } else {
-                cms_atomic_tuple(a, fp, make_uint2(tv.x, tv.y));
-                cms_atomic_tuple(a, fp, make_uint2(tv.z, tv.w));
-            }
-            if (sub == 0) __hip_atomic_store(&cl.bin_cnt[fp], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-}
-
-// One record's updates of one sketch (set = 0 SrcAddr, 1 DstAddr): depth tuples, each through the bin of its slice,
-// four rows at a time - the slot claims of the four rows are issued together, then the tuple writes, then ONE flush
-// for every bin the wave has filled (row by row this was ~5 dependent LDS round trips per row and wave: at depth 4
-// and two sketches more latency than the whole protobuf parse).  valid = false lanes only take part in the flushes
-// (which need the whole wave).  list: >= 256 words of wave-private LDS (the wave's dead tile buffer).
-__device__ __forceinline__ void cms_scatter(const KArgs& a, CmsLds& cl, uint32_t* list, uint32_t set, bool valid, const uint32_t key[4], uint64_t w,
-                                            uint64_t h, uint64_t h2) {
-    constexpr int NB = 4;
-    const bool big = (w >> 50) != 0;
-    if (valid && big) {  // (never with real Bytes x SamplingRate values)
-        cms_add(set ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, key, w);
-        valid = false;
-    }
+// One record's update of one sketch (set = 0 SrcAddr, 1 DstAddr): ONE tuple through the bin of the key's partition - slot
+// claim, tuple write, and a flush of every bin the wave has filled.  valid = false lanes only take part in the flush
+// (which needs the whole wave).  list: >= 16 words of wave-private LDS (the wave's dead tile buffer).
+__device__ __forceinline__ void cms_scatter(const KArgs& a, CmsLds& cl, uint32_t* list, uint32_t set, bool valid, uint64_t w, uint64_t h1, uint64_t h2) {
     valid = valid && w != 0;
-    for (uint32_t r0 = 0; r0 < a.cms_depth; r0 += NB) {
-        uint32_t p[NB], slot[NB], fills[NB];
-        uint2 t[NB];
-        bool act[NB];
-#pragma unroll
-        for (int k = 0; k < NB; k++, h += h2) {  // claim a slot in each row's bin
-            const uint32_t r = r0 + k;
-            act[k] = valid && r < a.cms_depth;
-            const uint32_t c = (r << a.cms_wl2) + (uint32_t)(h >> (64 - a.cms_wl2));
-            p[k] = act[k] ? set * CMS_NPART + (c >> a.cms_sl2) : 0u;
-            t[k] = make_uint2((c & ((1u << a.cms_sl2) - 1u)) | ((uint32_t)w << 14), (uint32_t)(w >> 18));
-            slot[k] = 0xffffu;
-            if (act[k]) slot[k] = __hip_atomic_fetch_add(&cl.bin_cnt[p[k]], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;
+    const CmsKey k = cms_key(h1, h2, a.cms_wl2);
+    const uint32_t p = set * CMS_NPART + k.prefix;
+    const uint4 t = make_uint4(k.l1, k.l2, (uint32_t)w, (uint32_t)(w >> 32));
+    uint32_t fill = 0xffffffffu;
+    if (valid) {
+        const uint32_t slot = __hip_atomic_fetch_add(&cl.bin_cnt[p], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;
+        if (slot < CMS_BIN) {
+            cl.bins[p * CMS_BIN + slot] = t;
+            __hip_atomic_fetch_add(&cl.bin_cnt[p], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (slot == CMS_BIN - 1) fill = p;
+        } else {  // the bin is on its way out: single store to the back part of the segment
+            const uint32_t ob = atomicAdd(&cl.part_cnt[p], 0x10000u) >> 16;
+            if (ob < a.ccapb) a.cseg[(size_t)p * a.cregion + (size_t)blockIdx.x * a.ccapq + (a.ccapq - 1u - ob)] = t;
+            else cms_atomic_tuple(a, p, t);
         }
-#pragma unroll
-        for (int k = 0; k < NB; k++)
-            if (act[k] && slot[k] < CMS_BIN) cl.bins[p[k] * CMS_BIN + slot[k]] = t[k];
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            fills[k] = 0xffffffffu;
-            if (act[k]) {
-                if (slot[k] < CMS_BIN) {
-                    __hip_atomic_fetch_add(&cl.bin_cnt[p[k]], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (slot[k] == CMS_BIN - 1) fills[k] = p[k];
-                } else {  // the bin is on its way out: single store to the back part of the segment
-                    const uint32_t ob = atomicAdd(&cl.part_cnt[p[k]], 0x10000u) >> 16;
-                    if (ob < a.ccapb) a.cseg[(size_t)p[k] * a.cregion + (size_t)blockIdx.x * a.ccapq + (a.ccapq - 1u - ob)] = t[k];
-                    else cms_atomic_tuple(a, p[k], t[k]);
-                }
-            }
-        }
-        cms_bins_flush_multi<NB>(a, cl, list, fills);
     }
+    cms_bins_flush(a, cl, list, fill);
 }
 
 __global__ void cms_fold_kernel(unsigned long long* cms, size_t words) {

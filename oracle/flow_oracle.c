@@ -355,27 +355,33 @@ size_t fo_rollup_rows(const fo_rollup* r, uint32_t filter, fo_row5m* out, size_t
 /* There is no Count-Min sketch in the reference; the exact contract is the
  * dashboard query `GROUP BY SrcAddr ORDER BY sum(Bytes*SamplingRate) DESC`
  * (compose/grafana/dashboards/viz-ch.json:233,479).  The sketch is defined by
- * this repository: row r of key k hits column
- * fo_hash_key16(k, seed, r) >> (64 - width_log2). */
-uint64_t fo_hash_key16(const uint8_t key[16], uint64_t seed, uint32_t row) {
+ * this repository (DESIGN.md "Sketch"): a PREFIX-PARTITIONED Count-Min sketch.
+ *   a = mix64(lo ^ mix64(seed + phi)); h1 = mix64(a ^ hi); h2 = a | 1
+ *   pbits = min(8, width_log2 - 4); sub = width_log2 - pbits
+ *   prefix = h1 & (2^pbits - 1); l1 = h1 >> 32; l2 = (h2 >> 32) | 1        (32-bit double hashing, Kirsch & Mitzenmacher)
+ *   column(r) = prefix << sub | (uint32)(l1 + r * l2) >> (32 - sub)
+ * i.e. 2^pbits independent sketches of width 2^sub, the key picks one with bits that take no part in the row hashes:
+ * all rows of a key share the top pbits of the column (so an update touches one 2^sub-wide block per row). */
+uint32_t fo_cms_column(const uint8_t key[16], uint64_t seed, uint32_t wl2, uint32_t row) {
     uint64_t lo, hi;
     memcpy(&lo, key, 8);
     memcpy(&hi, key + 8, 8);
-    /* double hashing (Kirsch & Mitzenmacher): row r = h1 + r * h2 (DESIGN.md "Sketch") */
     const uint64_t a = mix64(lo ^ mix64(seed + 0x9E3779B97F4A7C15ull));
     const uint64_t h1 = mix64(a ^ hi), h2 = a | 1ull;
-    return h1 + (uint64_t)row * h2;
+    const uint32_t pbits = wl2 - 4u < 8u ? wl2 - 4u : 8u, sub = wl2 - pbits;
+    const uint32_t prefix = (uint32_t)h1 & ((1u << pbits) - 1u), l1 = (uint32_t)(h1 >> 32), l2 = (uint32_t)(h2 >> 32) | 1u;
+    return (prefix << sub) | ((uint32_t)(l1 + row * l2) >> (32u - sub));
 }
 void fo_cms_update(uint64_t* cms, uint32_t depth, uint32_t wl2, uint64_t seed, const uint8_t key[16],
                    uint64_t w) {
     for (uint32_t r = 0; r < depth; r++)
-        cms[((size_t)r << wl2) + (size_t)(fo_hash_key16(key, seed, r) >> (64 - wl2))] += w;
+        cms[((size_t)r << wl2) + fo_cms_column(key, seed, wl2, r)] += w;
 }
 uint64_t fo_cms_query(const uint64_t* cms, uint32_t depth, uint32_t wl2, uint64_t seed,
                       const uint8_t key[16]) {
     uint64_t best = ~0ull;
     for (uint32_t r = 0; r < depth; r++) {
-        uint64_t v = cms[((size_t)r << wl2) + (size_t)(fo_hash_key16(key, seed, r) >> (64 - wl2))];
+        uint64_t v = cms[((size_t)r << wl2) + fo_cms_column(key, seed, wl2, r)];
         if (v < best) best = v;
     }
     return best;

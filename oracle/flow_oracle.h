@@ -99,7 +99,7 @@ size_t fo_rollup_rows(const fo_rollup*, uint32_t timeslot_filter, fo_row5m* out,
 
 /* ---- Count-Min sketch + exact weights (viz-ch.json:233,479 "top talkers") */
 /* weight = Bytes * SamplingRate (u64 wrap), key = FixedString(16) address.   */
-uint64_t fo_hash_key16(const uint8_t key[16], uint64_t seed, uint32_t row);
+uint32_t fo_cms_column(const uint8_t key[16], uint64_t seed, uint32_t width_log2, uint32_t row);
 void fo_cms_update(uint64_t* cms, uint32_t depth, uint32_t width_log2, uint64_t seed,
                    const uint8_t key[16], uint64_t weight);
 uint64_t fo_cms_query(const uint64_t* cms, uint32_t depth, uint32_t width_log2, uint64_t seed,

@@ -100,8 +100,8 @@ def lib():
     L.fo_rollup_size.restype = C.c_size_t
     L.fo_rollup_rows.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]
     L.fo_rollup_rows.restype = C.c_size_t
-    L.fo_hash_key16.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32]
-    L.fo_hash_key16.restype = C.c_uint64
+    L.fo_cms_column.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.fo_cms_column.restype = C.c_uint32
     L.fo_cms_update.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_char_p, C.c_uint64]
     L.fo_cms_query.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_char_p]
     L.fo_cms_query.restype = C.c_uint64
@@ -310,7 +310,7 @@ def minute_series(rows, status):
 
 
 def cms_sketch_numpy(keys16: np.ndarray, weights: np.ndarray, depth: int, width_log2: int, seed: int) -> np.ndarray:
-    """Vectorised Count-Min sketch over uint8[n,16] keys (the same hash as fo_hash_key16 / fo_cms_update in
+    """Vectorised Count-Min sketch over uint8[n,16] keys (the same columns as fo_cms_column / fo_cms_update in
     flow_oracle.c, restated in numpy so that bench-scale inputs can be checked; pinned against the C functions by
     tests/test_oracle_golden.py).  -> uint64[depth << width_log2]."""
     def mix64(z):
@@ -330,10 +330,19 @@ def cms_sketch_numpy(keys16: np.ndarray, weights: np.ndarray, depth: int, width_
     with np.errstate(over="ignore"):
         s0 = mix64(np.array([(seed + 0x9E3779B97F4A7C15) & (2**64 - 1)], dtype=np.uint64))[0]
         a = mix64(lo ^ s0)
-        h = mix64(a ^ hi)          # h1; row r uses h1 + r * h2 with h2 = a | 1 (double hashing)
-        h2 = a | np.uint64(1)
         for r in range(depth):
-            idx = (h >> np.uint64(64 - width_log2)).astype(np.int64) + (r << width_log2)
-            np.add.at(out, idx, w)
-            h = h + h2
+            np.add.at(out, cms_columns(a, mix64(a ^ hi), width_log2, r) + (r << width_log2), w)
     return out
+
+
+def cms_columns(a, h1, width_log2: int, row: int):
+    """Columns of row `row` for keys given by their two hashes (a = mix64(lo ^ mix64(seed + phi)), h1 = mix64(a ^ hi)):
+    the prefix-partitioned sketch of flow_oracle.c (fo_cms_column), vectorised.  -> int64 array."""
+    pbits = min(8, width_log2 - 4)
+    sub = width_log2 - pbits
+    with np.errstate(over="ignore"):
+        prefix = (h1 & np.uint64((1 << pbits) - 1)).astype(np.int64)
+        l1 = (h1 >> np.uint64(32)).astype(np.uint32)
+        l2 = ((a | np.uint64(1)) >> np.uint64(32)).astype(np.uint32) | np.uint32(1)
+        low = ((l1 + np.uint32(row) * l2) >> np.uint32(32 - sub)).astype(np.int64)
+    return (prefix << sub) | low

@@ -48,6 +48,24 @@ def test_tuple_formats_round_trip_and_balance():
     assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
 
 
+def test_sketch_definition_kernel_headers_equal_oracle(po):
+    """sinks.cuh's sketch definition (cms_hash2 / cms_key / cms_column / cms_low, host-compiled) == oracle/flow_oracle.c
+    fo_cms_column for every width, and the partition invariants of the scatter sink (tests/host_sketch.hip)."""
+    po.build()
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "host_sketch")
+    src = os.path.join(ROOT, "tests", "host_sketch.hip")
+    csrc = os.path.join(ROOT, "flow-pipeline_amd", "csrc")
+    deps = [src, os.path.join(ROOT, "oracle", "liboracle.so")] + [os.path.join(csrc, f) for f in ("sinks.cuh", "table.cuh", "wide.cuh", "wire.cuh")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.check_call([
+            "/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-value", "-o", exe, src,
+            "-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
+
+
 def test_time_bucket_reciprocal_is_exact():
     """sinks.cuh time_bucket(): floor(double(t) * (1/g)(1+2^-40)) == t // g for every u32 t.
     Checked at every multiple of g (+-1) near the ends of the range and on random t."""

@@ -43,17 +43,26 @@ def universe_keys(L, dst):
     return lo, hi
 
 
+def columns(a, h1, wl2, row):
+    """(oracle/pyoracle.py cms_columns, restated: the tools do not import the oracle's numpy helpers at module level)"""
+    pbits = min(8, wl2 - 4)
+    sub = wl2 - pbits
+    with np.errstate(over="ignore"):
+        prefix = (h1 & np.uint64((1 << pbits) - 1)).astype(np.int64)
+        l1 = (h1 >> np.uint64(32)).astype(np.uint32)
+        l2 = ((a | np.uint64(1)) >> np.uint64(32)).astype(np.uint32) | np.uint32(1)
+        low = ((l1 + np.uint32(row) * l2) >> np.uint32(32 - sub)).astype(np.int64)
+    return (prefix << sub) | low
+
+
 def estimates(cms, lo, hi, depth, wl2, seed):
     with np.errstate(over="ignore"):
         s0 = mix64(np.array([(seed + 0x9E3779B97F4A7C15) & (2**64 - 1)], dtype=np.uint64))[0]
         a = mix64(lo ^ s0)
-        h = mix64(a ^ hi)
-        h2 = a | np.uint64(1)
+        h1 = mix64(a ^ hi)
         best = np.full(len(lo), np.uint64(2**64 - 1), dtype=np.uint64)
         for r in range(depth):
-            idx = (h >> np.uint64(64 - wl2)).astype(np.int64) + (r << wl2)
-            best = np.minimum(best, cms[idx])
-            h = h + h2
+            best = np.minimum(best, cms[columns(a, h1, wl2, r) + (r << wl2)])
     return best
 
 
