@@ -234,6 +234,36 @@ def test_numpy_sketch_restatement_matches_c_oracle(po):
     assert np.array_equal(po.cms_sketch_numpy(keys, w, depth, wl2, seed), want)
 
 
+def test_sketch_definition_is_pinned(po):
+    """The sketch definition (DESIGN.md "Sketch": prefix-partitioned Count-Min) against the committed columns of a few
+    fixed keys (tests/golden/sketch_columns.json, made by tests/golden/make_sketch_columns.py): the C oracle, the numpy
+    restatement and the tools' restatement (tools/config3_run.py) all give exactly these.  A change of the definition has
+    to change the fixture - deliberately."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = json.load(open(os.path.join(root, "tests", "golden", "sketch_columns.json")))["vectors"]
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import config3_run
+    L = po.lib()
+    phi = 0x9E3779B97F4A7C15
+    for v in fx:
+        key, seed, wl2, want = bytes.fromhex(v["key"]), v["seed"], v["width_log2"], v["columns"]
+        assert [int(L.fo_cms_column(key, seed, wl2, r)) for r in range(len(want))] == want, v
+        lo = np.frombuffer(key[:8], dtype="<u8").copy()
+        hi = np.frombuffer(key[8:], dtype="<u8").copy()
+        with np.errstate(over="ignore"):
+            a = config3_run.mix64(lo ^ config3_run.mix64(np.array([(seed + phi) & (2**64 - 1)], dtype=np.uint64))[0])
+            h1 = config3_run.mix64(a ^ hi)
+        for r, c in enumerate(want):
+            assert int(po.cms_columns(a, h1, wl2, r)[0]) == c and int(config3_run.columns(a, h1, wl2, r)[0]) == c, (v, r)
+            assert c >> wl2 == 0
+        # all rows of a key share the partition prefix
+        pbits = min(8, wl2 - 4)
+        assert len({c >> (wl2 - pbits) for c in want}) == 1
+
+
 def readme_render(fa, fx, decoded_rows, rows5m):
     """Renders decoded rows / flows_5m rows the way clickhouse-client printed them in the reference's README and
     compares cell by cell with the README's own table rows (tests/golden/readme_samples.json)."""
