@@ -7,16 +7,18 @@ BASELINE config 2 = 100 M mocker-shaped framed FlowMessages, 64 k SrcAS/DstAS
 pairs, 3 five-minute windows, 2 ETypes, per GPU (weak scaling: every rank is one
 Kafka partition with its own 100 M records).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      (N > 1 without a torchrun environment: starts its own ranks)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (see the contract in the task description):
   roofline      wire bytes / hipEvent time of the WHOLE decode+aggregate path of a launch (ingest kernel +
                 second-chance parsers + tuple aggregation; SURVEY.md 8(d): t_kernel = decode + aggregate) vs the
                 8 TB/s HBM peak; the ingest kernel alone is reported beside it as `dominant_kernel`;
-  cpu_baseline  the C oracle on this box's cores (affinity mask), thread sweep, best run; N=1 only;
+  cpu_baseline  the C oracle on this box's usable CPUs (affinity mask cut by the cgroup quota), thread sweep with
+                per-thread decode times, best run; N=1 only;
   parity        every record of the step verified against the oracle (per-chunk row checksums), outside the
-                timed region; N=1 only;
+                timed region, on every rank; N>1: also the rows merged across ranks at window close against the
+                oracle's rollup of all partitions;
   host_fed      the PCIe-inclusive rate through fa_ingest (host buffers) - a secondary figure, never `value`.
 Other workloads (side measurements, their JSON goes to profiles/): --mode zipf --key-sets 7 (config 3 shape),
 --key-sets 9 (config 5 shape), --mode goflow / reversed (67-field producer / order-free parser), --stage decode
@@ -38,7 +40,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per launch from rocprofv3 PMC passes of THIS command line (tools/profile.sh; PMC counters cannot be
 # read from inside the process).  Quoted only for the default workload AND when the file was produced by the very
 # sources this process runs (source_hash stamp).
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 SOA_BYTES_PER_RECORD = 5 * 8 + 7 * 4 + 3 * 16 + 1  # fa_columns: 15 columns + status byte
 
 
@@ -51,7 +53,7 @@ def pmc_traffic(fa, default_workload):
     with open(TRAFFIC_FILE) as f:
         t = json.load(f)
     if t.get("source_hash") != fa.source_hash():
-        return None, None, "profiles/r02_traffic.json was measured on other sources (%s != %s)" % (t.get("source_hash"), fa.source_hash())
+        return None, None, "profiles/r03_traffic.json was measured on other sources (%s != %s)" % (t.get("source_hash"), fa.source_hash())
     k = t.get("kernels", {})
     total = sum(v.get("traffic_bytes", 0.0) for v in k.values())
     return total or None, k, None
@@ -78,43 +80,110 @@ def rows_checksum(rows):
         return int((h * v).sum(dtype=np.uint64))
 
 
-def cpu_baseline(po, gp, sample, n_rec):
+def effective_cpus():
+    """CPUs this process can really use: the affinity mask, cut by a cgroup CPU quota when there is one (a
+    barrier-synchronised job with more threads than the quota allows only measures the scheduler)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:  # cgroup v2
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    if quota is None:
+        try:  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    eff = aff if quota is None else max(1, min(aff, int(quota)))
+    return eff, aff, quota
+
+
+def cpu_baseline(po, gp, sample, n_rec, groups_hint):
     """The C oracle (decode + 15-column projection + hash rollup, one shard per thread, merge by key partition) on
-    the cores this process may use.  Thread sweep, best run reported; the per-core figure stays beside it."""
-    cores = len(os.sched_getaffinity(0))
-    sweep = {}
-    one_n = min(sample, 4_000_000)
-    res = None
-    for th in sorted({1, 8, 32, cores} & set(range(1, cores + 1)) | {1}):
-        n = one_n if th == 1 else sample
-        r = po.bench_rollup(gp, 0, n, th)
+    the CPUs this process may really use (affinity mask cut by the cgroup quota).  Thread sweep; the sample grows with
+    the thread count (>= 1 M records per thread, up to the whole step) so that every shard still aggregates - with
+    fewer records per shard than there are groups the job degenerates into a merge; shard tables are sized from the
+    group count, allocated and first-touched before the start barrier, and sit on 2 MiB pages (round 2's sweep got
+    slower past 8 threads: page faults inside the timed region and one TLB miss per record under the hypervisor)."""
+    cores, aff, quota = effective_cpus()
+    sweep, detail = {}, {}
+    points = sorted({1, 8, 32, max(1, cores // 2), cores} & set(range(1, cores + 1)) | {1})
+    best = None
+    for th in points:
+        n = min(n_rec, max(4_000_000 if th == 1 else sample, 1_000_000 * th))
+        r = po.bench_rollup_ex(gp, 0, n, th, groups_hint)
         assert r["bad"] == 0
-        sweep[th] = n / r["seconds"]
-        if th != 1 and (res is None or sweep[th] > res[1]):
-            res = (th, sweep[th], r)
-    if res is None or sweep[1] >= res[1]:  # (a 1-core box, or threads that do not pay off)
-        r1 = po.bench_rollup(gp, 0, one_n, 1)
-        res = (1, max(sweep[1], one_n / r1["seconds"]), r1)
-        sample_used = one_n
-    else:
-        sample_used = sample
-    th, best, r = res
+        rate = n / r["seconds"]
+        sweep[th] = rate
+        detail[th] = {"records": n, "seconds": r["seconds"], "decode_seconds_min": r["decode_seconds_min"],
+                      "decode_seconds_max": r["decode_seconds_max"], "decode_seconds_mean": r["decode_seconds_mean"],
+                      "merge_seconds": r["merge_seconds"], "wire_bytes": r["wire_bytes"]}
+        if best is None or rate > best[1]:
+            best = (th, rate, n, r)
+    th, rate, n_used, r = best
+    single = sweep[1]
+    eff = rate / (th * single) if single > 0 else 0.0
+    # what bounds the best point: the slowest shard's decode + rollup, or the merge behind it
+    limiter = ("per-shard decode + hash rollup (slowest thread %.3f s of %.3f s; the rest is the key-partitioned merge)"
+               % (r["decode_seconds_max"], r["seconds"]))
+    if th > 1 and eff < 0.7:
+        limiter += ("; %.2f of linear scaling: threads share the memory system - per-thread decode time grows from %.0f ns "
+                    "per record at 1 thread to %.0f ns at %d" % (eff, 1e9 * detail[1]["decode_seconds_max"] / detail[1]["records"],
+                                                                 1e9 * r["decode_seconds_max"] / (n_used / th), th))
     out = {
-        "value": best,
+        "value": rate,
         "unit": "FlowMessages/s",
         "cores": th,
         "cores_available": cores,
+        "cores_affinity": aff,
+        "cgroup_cpu_quota": quota,
         "kind": "port",
         "sample": "first %d records of the same workload (%.2f GB wire), C oracle restatement (generic protobuf walk + "
-                  "15-column projection + open-addressing rollup), one shard per thread, shard tables merged by key "
-                  "partition; best of a thread sweep; the Go inserter + ClickHouse cannot run in this image"
-                  % (sample_used, r["wire_bytes"] / 1e9),
+                  "15-column projection + open-addressing rollup), one shard per thread, shard tables sized from the group "
+                  "count and first-touched before the start barrier (2 MiB pages), merged by key partition; best of a thread "
+                  "sweep; the Go inserter + ClickHouse cannot run in this image"
+                  % (n_used, r["wire_bytes"] / 1e9),
         "seconds": r["seconds"],
         "thread_sweep_records_per_s": {str(k): v for k, v in sorted(sweep.items())},
-        "single_core_value": sweep[1],
+        "thread_sweep_detail": {str(k): v for k, v in sorted(detail.items())},
+        "single_core_value": single,
+        "scaling_efficiency_vs_single_core": eff,
+        "limiter": limiter,
     }
-    assert out["value"] >= out["single_core_value"] * 0.999, out
     return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (the driver's N=1
+    command shape with another N must not die at argument parsing).  One rank per GPU over RCCL; on a box with fewer
+    GPUs FA_BENCH_SHARE_GPU=1 puts every rank on device 0 and moves the window-close exchange to gloo - a dry run of
+    the N>1 code path, never a reported configuration."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ndev < args.gpus:
+        if not env.get("FA_BENCH_SHARE_GPU"):
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible (FA_BENCH_SHARE_GPU=1 runs every rank on "
+                             "device 0 over gloo: harness dry run only)" % (args.gpus, ndev))
+        env.setdefault("FA_BENCH_BACKEND", "gloo")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -142,12 +211,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)  # (does not return)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run --nproc-per-node N")
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # FA_BENCH_BACKEND=gloo + FA_BENCH_SHARE_GPU=1: dry run of the N>1 code path on a 1-GPU box (all ranks on
     # device 0, exchange over gloo) - for testing the harness only, never a reported configuration
-    backend = os.environ.get("FA_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("FA_BENCH_BACKEND", "gloo" if os.environ.get("FA_BENCH_SHARE_GPU") else "nccl")
     if os.environ.get("FA_BENCH_SHARE_GPU"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -326,6 +396,8 @@ def main():
         "wire_GBps_whole_job": wire_bytes * args.steps * world / elapsed / 1e9,
     }
     t8 = "true" if compact else "false"
+    # (compact tuples are folded by agg8_kernel unless FA_AGG=generic forces the two-word-key kernel)
+    agg_name = "fa::agg8_kernel" if compact and os.environ.get("FA_AGG") != "generic" else "fa::agg_kernel<%s>" % t8
     out["roofline"] = {
         "bound": "hbm",
         # t_kernel = decode + aggregate -> every kernel of a launch, first event to last
@@ -334,9 +406,9 @@ def main():
         "unit": "GB/s",
         "frac": achieved_path / HBM_PEAK_GBS,
         "traffic": traffic,
-        "traffic_source": ("profiles/r02_traffic.json (sources %s): rocprofv3 --pmc, 2*FETCH_SIZE (gfx950 wide-read correction) + "
+        "traffic_source": ("profiles/r03_traffic.json (sources %s): rocprofv3 --pmc, 2*FETCH_SIZE (gfx950 wide-read correction) + "
                            "WRITE_SIZE, bytes per launch, summed over the path's kernels" % fa.source_hash()) if traffic else traffic_note,
-        "kernel": ("decode+aggregate path of one launch: fa::wtile_kernel<%s, %s> + fa::deferred_kernel + fa::agg_kernel<%s>" % (ks_name, t8, t8)) if wave
+        "kernel": ("decode+aggregate path of one launch: fa::wtile_kernel<%s, %s> + fa::deferred_kernel + %s" % (ks_name, t8, agg_name)) if wave
                   else "decode+aggregate path of one launch: fa::tile_kernel<MODE_INGEST, %s> + fa::deferred_kernel" % ks_name,
         "algorithmic_bytes_per_launch": bytes_per_launch,
         "avg_launch_ms": avg_batch_s * 1e3,
@@ -351,14 +423,26 @@ def main():
         "traffic_by_kernel": {k: v.get("traffic_bytes") for k, v in (traffic_all or {}).items()} or None,
     }
 
-    if rank == 0 and world == 1 and not args.no_verify and not args.no_assert:
-        # parity on the WHOLE step: every chunk again through a fresh ctx, its rows against the oracle's rows for the
-        # same records (order-independent checksum of (key, sums); u64 sums commute, so equal chunk results = equal step)
+    if world > 1:  # every rank's own path time beside rank 0's roofline block
+        t = torch.tensor([avg_batch_s * 1e3, avg_launch_s * 1e3], dtype=torch.float64, device=xdev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        out["roofline"]["per_rank_path_ms"] = [float(x[0].item()) for x in allt]
+        out["roofline"]["per_rank_dominant_kernel_ms"] = [float(x[1].item()) for x in allt]
+        out["roofline"]["note"] = "achieved / frac are rank 0's; value is the whole job over the slowest rank's wall clock"
+
+    if not args.no_verify and not args.no_assert:
+        # parity on the WHOLE step, every rank its own partition: every chunk again through a fresh ctx, its rows against
+        # the oracle's rows for the same records (order-independent checksum of (key, sums); u64 sums commute, so equal
+        # chunk results = equal step).  N > 1 additionally: the rows the ranks merged at window close (RCCL all-gather +
+        # device merge) against the oracle's rollup of ALL partitions (every rank's oracle rows gathered, merged with
+        # numpy, sums x the number of steps ingested) - byte for byte.
         po = _pkg.load_oracle()
-        gp = po.gen_params(mode=mode, framed=1, seed=2, n_total=n_rec, span_secs=900, per_sec=400_000, zipf_s_x100=args.zipf_s)
-        cores = len(os.sched_getaffinity(0))
+        gp = po.gen_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000, zipf_s_x100=args.zipf_s)
+        threads = max(1, min(effective_cpus()[0] // world, 64))
         ok = True
         verified = 0
+        oracle_parts = []
         t_v = time.perf_counter()
         for d_buf, d_off, w, m, first in chunks:
             check = fa.FlowAgg(device=local_rank, framed=True, table_capacity_log2=20, max_batch_records=args.chunk)
@@ -366,19 +450,41 @@ def main():
             rows = check.read_window()
             cst = check.stats()
             check.close()
-            ref = po.bench_rollup(gp, first, m, max(1, min(cores, 64)))
+            ref = po.bench_rollup_ex(gp, first, m, threads, groups_hint=len(rows), want_rows=world > 1)
             ok = ok and rows_checksum(rows) == ref["checksum"] and ref["bad"] == 0 and cst["records_bad"] == 0 \
                 and ref["wire_bytes"] == w and ref["groups"] == len(rows)
+            if world > 1:
+                oracle_parts.append(ref["rows"])
             verified += m
-        out["parity"] = {"ok": bool(ok), "records_verified": int(verified), "of_records_per_step": n_rec,
-                         "how": "per launch: GPU flows_5m rows vs C-oracle rows of the same records (row count, wire bytes, "
-                                "order-independent checksum over keys and sums)", "seconds": time.perf_counter() - t_v}
-        assert ok, "GPU rows differ from the oracle"
+        parity = {"ok": bool(ok), "records_verified": int(verified), "of_records_per_step": n_rec,
+                  "how": "per launch: GPU flows_5m rows vs C-oracle rows of the same records (row count, wire bytes, "
+                         "order-independent checksum over keys and sums)"}
+        if world > 1:
+            mine = fa.dist.merge_rows_host(oracle_parts)
+            want = fa.dist.merge_rows_host(fa.dist.allgather_struct(mine, fa.dist.ROW5M_DTYPE, device=xdev))
+            with np.errstate(over="ignore"):
+                for f in ("bytes", "packets", "count"):
+                    want[f] = want[f] * np.uint64(total_steps)
+            merged_ok = want.tobytes() == np.ascontiguousarray(merged).tobytes()
+            flags = torch.tensor([1 if ok else 0, 1 if merged_ok else 0, verified], dtype=torch.int64, device=xdev)
+            allf = [torch.zeros_like(flags) for _ in range(world)]
+            dist.all_gather(allf, flags)
+            parity["ok"] = all(int(f[0].item()) == 1 and int(f[1].item()) == 1 for f in allf)
+            parity["ranks_ok"] = [bool(int(f[0].item())) for f in allf]
+            parity["merged_rows_equal_oracle_rollup_of_all_partitions"] = [bool(int(f[1].item())) for f in allf]
+            parity["records_verified"] = int(sum(int(f[2].item()) for f in allf))
+            parity["of_records_per_step"] = n_rec * world
+            parity["merged_rows"] = int(len(merged))
+            parity["how"] += ("; N>1: the rows merged across ranks at window close vs the oracle's rollup of all %d partitions "
+                              "(byte-identical rows, on every rank)" % world)
+        parity["seconds"] = time.perf_counter() - t_v
+        out["parity"] = parity
+        assert parity["ok"], "GPU rows differ from the oracle: %r" % (parity,)
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         po = _pkg.load_oracle()
         gp = po.gen_params(mode=mode, framed=1, seed=2, n_total=n_rec, span_secs=900, per_sec=400_000, zipf_s_x100=args.zipf_s)
-        out["cpu_baseline"] = cpu_baseline(po, gp, min(args.cpu_sample, n_rec), n_rec)
+        out["cpu_baseline"] = cpu_baseline(po, gp, min(args.cpu_sample, n_rec), n_rec, int(len(merged)))
 
     if rank == 0 and world == 1 and not args.no_host_fed and not args.no_assert:
         # the path a Kafka consumer uses: host buffers -> pinned staging -> H2D -> the same kernels (never `value`)

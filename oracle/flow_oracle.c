@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <sys/mman.h>
 
 /* ------------------------------------------------------------------ decode */
 
@@ -242,13 +243,14 @@ size_t fo_rollup_size(const fo_rollup* r) { return r->n; }
 
 static void rollup_put(fo_rollup* r, uint32_t ts, uint32_t sa, uint32_t da, uint32_t et, uint64_t b,
                        uint64_t p, uint64_t c);
+static slot* table_alloc(size_t cap);
 
 static void rollup_grow(fo_rollup* r) {
     slot* old = r->t;
     size_t oc = r->cap;
     r->cap *= 2;
     r->n = 0;
-    r->t = (slot*)calloc(r->cap, sizeof(slot));
+    r->t = table_alloc(r->cap);
     for (size_t i = 0; i < oc; i++)
         if (old[i].used)
             rollup_put(r, old[i].timeslot, old[i].src_as, old[i].dst_as, old[i].etype, old[i].bytes,
@@ -700,6 +702,8 @@ typedef struct job {
     fo_rollup* part;  /* final table part t */
     bentry* ent;      /* this shard's groups, sorted by destination part */
     size_t* ent_off;  /* threads + 1 */
+    size_t ent_cap;   /* entries `ent` holds */
+    size_t groups_hint; /* expected number of distinct groups of the whole range (0: unknown) */
     uint64_t bad;
     int t, threads, failed;
     double t_start, t_end, t_ingest;
@@ -717,11 +721,27 @@ static size_t pow2_at_least(size_t v) {
     while (c < v) c <<= 1;
     return c;
 }
+/* Large tables sit on 2 MiB pages where the kernel offers them (THP "madvise"): a random probe into a table of
+ * tens of MB is a TLB miss per record on 4 KiB pages, and under a hypervisor a TLB miss is a two-dimensional page
+ * walk - with 8 shard tables that walk, not the cores, bounded the sweep (measured here: 8 threads 1.8x one). */
+static slot* table_alloc(size_t cap) {
+    const size_t bytes = cap * sizeof(slot);
+    if (bytes >= ((size_t)4 << 20)) {
+        void* p = NULL;
+        const size_t huge = (size_t)2 << 20;
+        if (posix_memalign(&p, huge, (bytes + huge - 1) & ~(huge - 1)) == 0) {
+            (void)madvise(p, (bytes + huge - 1) & ~(huge - 1), MADV_HUGEPAGE);
+            memset(p, 0, bytes);
+            return (slot*)p;
+        }
+    }
+    return (slot*)calloc(cap, sizeof(slot));
+}
 static fo_rollup* rollup_new_sized(uint32_t gran, size_t groups) {
     fo_rollup* r = (fo_rollup*)calloc(1, sizeof *r);
     r->gran = gran ? gran : 300;
     r->cap = pow2_at_least(groups * 2 + 2);
-    r->t = (slot*)calloc(r->cap, sizeof(slot));
+    r->t = table_alloc(r->cap);
     return r;
 }
 static uint64_t slot_hash(const slot* s) {
@@ -731,21 +751,38 @@ static uint64_t slot_hash(const slot* s) {
 static void* job_run(void* a) {
     job* j = (job*)a;
     const int T = j->threads;
-    /* untimed: this shard's records */
+    /* untimed: this shard's records, and the tables - allocated AND first-touched here (round 2 allocated the shard
+     * table inside the timed region: 100 MB of calloc page faults per thread, serialised in the kernel on a many-core
+     * host), sized from the caller's group-count hint (config 2: 393 216 groups, whatever the shard length). */
     const size_t cap = j->n * (j->g->mode == FO_GEN_GOFLOW ? 200 : 96) + 256;
     j->buf = (uint8_t*)malloc(cap);
     j->off = (uint64_t*)malloc((j->n + 1) * sizeof(uint64_t));
     j->wire = j->buf && j->off ? fo_gen_records(j->g, j->i0, j->n, j->buf, cap, j->off) : (size_t)-1;
     j->failed = j->wire == (size_t)-1;
+    {
+        size_t shard_groups = j->groups_hint ? j->groups_hint : (1u << 20);
+        if (shard_groups > j->n) shard_groups = j->n;
+        j->r = rollup_new_sized(300, shard_groups);
+        memset(j->r->t, 0, j->r->cap * sizeof(slot)); /* first touch */
+        const size_t part_groups = j->groups_hint ? j->groups_hint / (size_t)T + j->groups_hint / (size_t)(4 * T) + 1024 : 1024;
+        j->part = rollup_new_sized(300, part_groups);
+        memset(j->part->t, 0, j->part->cap * sizeof(slot));
+        j->ent_off = (size_t*)calloc((size_t)T + 1, sizeof(size_t));
+        j->ent = (bentry*)malloc((shard_groups + 1) * sizeof(bentry));
+        if (j->ent) memset(j->ent, 0, (shard_groups + 1) * sizeof(bentry));
+        j->ent_cap = shard_groups + 1;
+    }
     pthread_barrier_wait(j->bar);
     j->t_start = now_s();
     /* (1) decode + roll up */
-    j->r = rollup_new_sized(300, j->n < (1u << 20) ? j->n : (1u << 20));
     if (!j->failed) j->bad = fo_rollup_ingest(j->r, j->buf, j->off, j->n, (int)j->g->framed);
     j->t_ingest = now_s() - j->t_start;
     /* (2a) this shard's groups, ordered by destination part */
-    j->ent_off = (size_t*)calloc((size_t)T + 1, sizeof(size_t));
-    j->ent = (bentry*)malloc((j->r->n + 1) * sizeof(bentry));
+    if (j->r->n + 1 > j->ent_cap) { /* (only when the hint was too small) */
+        free(j->ent);
+        j->ent = (bentry*)malloc((j->r->n + 1) * sizeof(bentry));
+        j->ent_cap = j->r->n + 1;
+    }
     for (size_t i = 0; i < j->r->cap; i++)
         if (j->r->t[i].used) j->ent_off[(slot_hash(&j->r->t[i]) >> 40) % (uint64_t)T + 1]++;
     for (int p = 0; p < T; p++) j->ent_off[p + 1] += j->ent_off[p];
@@ -762,10 +799,7 @@ static void* job_run(void* a) {
         free(cur);
     }
     pthread_barrier_wait(j->bar);
-    /* (2b) fold partition t of every shard */
-    size_t mine = 0;
-    for (int u = 0; u < T; u++) mine += j->all[u].ent_off[j->t + 1] - j->all[u].ent_off[j->t];
-    j->part = rollup_new_sized(300, mine);
+    /* (2b) fold partition t of every shard (the part table grows by itself if the hint was too small) */
     for (int u = 0; u < T; u++) {
         const job* o = &j->all[u];
         for (size_t k = o->ent_off[j->t]; k < o->ent_off[j->t + 1]; k++) {
@@ -778,9 +812,8 @@ static void* job_run(void* a) {
     return NULL;
 }
 
-double fo_bench_rollup(const fo_gen_params* g, uint64_t i0, uint64_t n, int threads,
-                       uint64_t* wire_out, uint64_t* groups_out, uint64_t* bad_out,
-                       uint64_t* checksum_out) {
+int fo_bench_rollup_ex(const fo_gen_params* g, uint64_t i0, uint64_t n, int threads, uint64_t groups_hint,
+                       fo_bench_result* res, fo_row5m* rows, size_t rows_cap) {
     if (threads < 1) threads = 1;
     if ((uint64_t)threads > n && n) threads = (int)n;
     job* jobs = (job*)calloc(threads, sizeof(job));
@@ -796,12 +829,14 @@ double fo_bench_rollup(const fo_gen_params* g, uint64_t i0, uint64_t n, int thre
         jobs[t].threads = threads;
         jobs[t].all = jobs;
         jobs[t].bar = &bar;
+        jobs[t].groups_hint = (size_t)groups_hint;
     }
     for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, job_run, &jobs[t]);
     for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
     double t0 = jobs[0].t_start, t1 = jobs[0].t_end;
     uint64_t bad = 0, wire = 0, groups = 0, cs = 0;
     int failed = 0;
+    size_t w = 0;
     for (int t = 0; t < threads; t++) {
         if (jobs[t].t_start < t0) t0 = jobs[t].t_start;
         if (jobs[t].t_end > t1) t1 = jobs[t].t_end;
@@ -811,26 +846,50 @@ double fo_bench_rollup(const fo_gen_params* g, uint64_t i0, uint64_t n, int thre
         groups += jobs[t].part->n;
         for (size_t i = 0; i < jobs[t].part->cap; i++) {
             const slot* s = &jobs[t].part->t[i];
-            if (s->used)
-                cs += mix64(((uint64_t)s->timeslot << 32 | s->etype) ^
-                            mix64((uint64_t)s->src_as << 32 | s->dst_as)) *
-                      (s->bytes * 3 + s->packets * 5 + s->count * 7 + 1);
+            if (!s->used) continue;
+            cs += mix64(((uint64_t)s->timeslot << 32 | s->etype) ^
+                        mix64((uint64_t)s->src_as << 32 | s->dst_as)) *
+                  (s->bytes * 3 + s->packets * 5 + s->count * 7 + 1);
+            if (rows && w < rows_cap) {
+                fo_row5m* o = &rows[w];
+                o->date = s->timeslot / 86400u;
+                o->timeslot = s->timeslot;
+                o->src_as = s->src_as;
+                o->dst_as = s->dst_as;
+                o->etype = s->etype;
+                o->_pad = 0;
+                o->bytes = s->bytes;
+                o->packets = s->packets;
+                o->count = s->count;
+            }
+            w++;
         }
     }
+    if (rows && w <= rows_cap) qsort(rows, w, sizeof(fo_row5m), row5m_cmp);
     const double dt = t1 - t0;
-    if (getenv("FO_BENCH_VERBOSE")) {
-        double lo = 1e9, hi = 0;
-        for (int t = 0; t < threads; t++) {
-            if (jobs[t].t_ingest < lo) lo = jobs[t].t_ingest;
-            if (jobs[t].t_ingest > hi) hi = jobs[t].t_ingest;
-        }
-        fprintf(stderr, "[oracle bench] %d threads: shard decode+rollup %.3f..%.3f s, whole timed region %.3f s\n", threads, lo, hi, dt);
+    double lo = 1e99, hi = 0, sum = 0;
+    for (int t = 0; t < threads; t++) {
+        if (jobs[t].t_ingest < lo) lo = jobs[t].t_ingest;
+        if (jobs[t].t_ingest > hi) hi = jobs[t].t_ingest;
+        sum += jobs[t].t_ingest;
     }
+    if (getenv("FO_BENCH_VERBOSE"))
+        fprintf(stderr, "[oracle bench] %d threads: shard decode+rollup %.3f..%.3f s, whole timed region %.3f s\n", threads, lo, hi, dt);
     pthread_barrier_destroy(&bar);
-    if (wire_out) *wire_out = wire;
-    if (groups_out) *groups_out = groups;
-    if (bad_out) *bad_out = failed ? ~0ull : bad;
-    if (checksum_out) *checksum_out = cs;
+    if (res) {
+        res->seconds = dt;
+        res->decode_min = lo;
+        res->decode_max = hi;
+        res->decode_mean = sum / threads;
+        res->merge_seconds = dt - hi;
+        res->wire_bytes = wire;
+        res->groups = groups;
+        res->bad = failed ? ~0ull : bad;
+        res->checksum = cs;
+        res->rows = w;
+        res->threads = (uint32_t)threads;
+        res->_pad = 0;
+    }
     for (int t = 0; t < threads; t++) {
         fo_rollup_free(jobs[t].r);
         fo_rollup_free(jobs[t].part);
@@ -841,7 +900,19 @@ double fo_bench_rollup(const fo_gen_params* g, uint64_t i0, uint64_t n, int thre
     }
     free(jobs);
     free(th);
-    return dt;
+    return (rows && w > rows_cap) ? FO_BAD : FO_OK;
+}
+
+double fo_bench_rollup(const fo_gen_params* g, uint64_t i0, uint64_t n, int threads,
+                       uint64_t* wire_out, uint64_t* groups_out, uint64_t* bad_out,
+                       uint64_t* checksum_out) {
+    fo_bench_result r;
+    fo_bench_rollup_ex(g, i0, n, threads, 0, &r, NULL, 0);
+    if (wire_out) *wire_out = r.wire_bytes;
+    if (groups_out) *groups_out = r.groups;
+    if (bad_out) *bad_out = r.bad;
+    if (checksum_out) *checksum_out = r.checksum;
+    return r.seconds;
 }
 
 /* ------------------------------------------------- config 3 at full scale */

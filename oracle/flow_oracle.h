@@ -152,6 +152,20 @@ double fo_bench_rollup(const fo_gen_params*, uint64_t i0, uint64_t n, int thread
                        uint64_t* wire_bytes_out, uint64_t* groups_out, uint64_t* bad_out,
                        uint64_t* checksum_out);
 
+/* Same job with the harness details exposed: `groups_hint` = expected distinct groups of the range (0: unknown)
+ * sizes the shard and part tables, which are allocated and first-touched BEFORE the start barrier; the result
+ * carries the per-thread decode+rollup times and what is left for the merge; rows (optional, cap rows_cap) receives
+ * the merged rows sorted by (date,timeslot,src_as,dst_as,etype).  Returns FO_BAD when rows_cap is too small. */
+typedef struct {
+    double seconds;      /* timed region: first thread's start to last thread's end */
+    double decode_min, decode_max, decode_mean; /* per-thread decode + shard rollup, seconds */
+    double merge_seconds; /* seconds - decode_max: partition sort + fold */
+    uint64_t wire_bytes, groups, bad, checksum, rows;
+    uint32_t threads, _pad;
+} fo_bench_result;
+int fo_bench_rollup_ex(const fo_gen_params*, uint64_t i0, uint64_t n, int threads, uint64_t groups_hint,
+                       fo_bench_result* res, fo_row5m* rows, size_t rows_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -222,6 +222,39 @@ def bench_rollup(gp: GenParams, i0: int, n: int, threads: int):
             "checksum": cs.value}
 
 
+class BenchResult(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("decode_min", C.c_double), ("decode_max", C.c_double), ("decode_mean", C.c_double),
+                ("merge_seconds", C.c_double), ("wire_bytes", C.c_uint64), ("groups", C.c_uint64), ("bad", C.c_uint64),
+                ("checksum", C.c_uint64), ("rows", C.c_uint64), ("threads", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+def bench_rollup_ex(gp: GenParams, i0: int, n: int, threads: int, groups_hint: int = 0, want_rows: bool = False):
+    """fo_bench_rollup_ex: tables sized from `groups_hint` and first-touched before the start barrier; per-thread
+    decode times in the result; want_rows: also the merged rows (ROW5M_DTYPE, sorted) under "rows"."""
+    L = lib()
+    L.fo_bench_rollup_ex.argtypes = [C.POINTER(GenParams), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64, C.POINTER(BenchResult),
+                                     C.c_void_p, C.c_size_t]
+    L.fo_bench_rollup_ex.restype = C.c_int
+    res = BenchResult()
+    rows = None
+    cap = 0
+    if want_rows:
+        cap = max(int(groups_hint) * 2, 1 << 20)
+        rows = np.zeros(cap, dtype=ROW5M_DTYPE)
+    rc = L.fo_bench_rollup_ex(C.byref(gp), i0, n, threads, groups_hint, C.byref(res), None if rows is None else rows.ctypes.data, cap)
+    if rc != 0 and want_rows:  # more groups than guessed: again with room for all of them
+        cap = int(res.rows)
+        rows = np.zeros(cap, dtype=ROW5M_DTYPE)
+        rc = L.fo_bench_rollup_ex(C.byref(gp), i0, n, threads, groups_hint, C.byref(res), rows.ctypes.data, cap)
+    assert rc == 0
+    out = {"seconds": res.seconds, "wire_bytes": res.wire_bytes, "groups": res.groups, "bad": res.bad, "checksum": res.checksum,
+           "threads": res.threads, "decode_seconds_min": res.decode_min, "decode_seconds_max": res.decode_max,
+           "decode_seconds_mean": res.decode_mean, "merge_seconds": res.merge_seconds}
+    if want_rows:
+        out["rows"] = rows[:int(res.rows)].copy()
+    return out
+
+
 # ---- wide key sets and dashboard read side (numpy restatements over decoded rows) -----------------
 # Same status as the flows_5m rollup: "parity unpinned" (restated from the SQL; ClickHouse cannot run
 # here).  Input = (rows ROW_DTYPE, status) of decode_batch(); bad records are dropped

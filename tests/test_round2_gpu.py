@@ -382,6 +382,32 @@ def test_bench_harness_two_ranks_dry_run(gpu_lib):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["topk_src_addr_rows"] == 100
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
+    assert out["parity"]["ok"] and all(out["parity"]["merged_rows_equal_oracle_rollup_of_all_partitions"])
+
+
+def test_bench_launches_its_own_ranks(gpu_lib):
+    """`python bench.py --gpus 2` without torchrun (the shape of the driver's N=1 command with another N) starts its
+    ranks itself; on the 1-GPU box FA_BENCH_SHARE_GPU=1 puts both on device 0 (exchange over gloo).  The line carries
+    a parity statement: every rank's partition verified and the merged rows == the oracle's rollup of both partitions."""
+    env = dict(os.environ, FA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--records", "3000000",
+                        "--chunk", "1000000"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    par = out["parity"]
+    assert par["ok"] and par["ranks_ok"] == [True, True] and par["records_verified"] == 6_000_000
+    assert par["merged_rows_equal_oracle_rollup_of_all_partitions"] == [True, True]
+    assert len(out["roofline"]["per_rank_path_ms"]) == 2 and "cpu_baseline" not in out
+    # without the sharing switch the same command refuses to oversubscribe the GPU instead of hanging in RCCL
+    env.pop("FA_BENCH_SHARE_GPU")
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                           timeout=300, env=env, cwd=ROOT)
+        assert r.returncode != 0 and "FA_BENCH_SHARE_GPU" in (r.stderr + r.stdout)
 
 
 def test_bench_side_measurements_run(gpu_lib):
