@@ -110,6 +110,7 @@ PORT_ROW_DTYPE = np.dtype([("port", "<u4"), ("_pad", "<u4"), ("weight", "<u8"), 
 MINUTE_ROW_DTYPE = np.dtype([("minute", "<u4"), ("_pad", "<u4"), ("weight", "<u8"), ("count", "<u8")])
 assert ROW5M_DTYPE.itemsize == 48 and FLOW_ROW_DTYPE.itemsize == 120
 assert ROW_APP_DTYPE.itemsize == 56 and PORT_ROW_DTYPE.itemsize == 24 and MINUTE_ROW_DTYPE.itemsize == 24
+ROW_DTYPES = [ROW5M_DTYPE, ROW_APP_DTYPE, PORT_ROW_DTYPE, PORT_ROW_DTYPE, MINUTE_ROW_DTYPE, TOPK_DTYPE, TOPK_DTYPE]  # by row kind
 
 # every symbol include/flowagg.h declares (checked by the CPU test-suite)
 EXPORTS = [
@@ -120,7 +121,10 @@ EXPORTS = [
     "fa_mock_generate_device", "fa_mock_generate_host",
     "fa_read_window_app", "fa_close_window_app", "fa_merge_rows_app", "fa_top_ports", "fa_merge_ports",
     "fa_minute_series", "fa_merge_minutes", "fa_dashboard_reset", "fa_rows_to_rowbinary", "fa_format_addr",
+    "fa_row_bytes", "fa_rows_device", "fa_rows_merge_device", "fa_rows_fetch", "fa_drop_window",
 ]
+# row kinds of the device-resident window close (include/flowagg.h, ABI 5)
+ROWS_5M, ROWS_APP, ROWS_PORT_SRC, ROWS_PORT_DST, ROWS_MINUTE, ROWS_TOPK_SRC, ROWS_TOPK_DST = range(7)
 
 _LIB = None
 
@@ -169,7 +173,7 @@ def source_hash() -> str:
     srcdir = os.path.join(_HERE, "csrc")
     h = hashlib.sha256()
     for f in sorted(os.listdir(srcdir)) + [os.path.join("..", "..", "include", "flowagg.h")]:
-        if f.endswith((".cuh", ".hip", ".h", "Makefile")):
+        if f.endswith((".cuh", ".hip", ".h", ".inc", "Makefile")):
             with open(os.path.join(srcdir, f), "rb") as fh:
                 h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
@@ -224,6 +228,12 @@ def lib():
     L.fa_dashboard_reset.argtypes = [vp]
     L.fa_rows_to_rowbinary.argtypes = [vp, sz, vp, sz, szp]
     L.fa_format_addr.argtypes = [C.c_char_p, u32, C.c_char_p, sz]
+    L.fa_row_bytes.argtypes = [C.c_int]
+    L.fa_row_bytes.restype = sz
+    L.fa_rows_device.argtypes = [vp, C.c_int, u32, sz, C.POINTER(vp), szp]
+    L.fa_rows_merge_device.argtypes = [vp, C.c_int, vp, sz, sz, C.POINTER(vp), szp]
+    L.fa_rows_fetch.argtypes = [vp, C.c_int, vp, sz, vp, sz]
+    L.fa_drop_window.argtypes = [vp, C.c_int, u32]
     _LIB = L
     return L
 
@@ -393,6 +403,30 @@ class FlowAgg:
 
     def merge_rows_device(self, d_rows_ptr: int, n: int):
         self._chk(self._L.fa_merge_rows_device(self._h, d_rows_ptr, n))
+
+    # -- device-resident window close (ABI 5) -----------------------------------------------
+    def rows_device(self, kind: int, timeslot=ALL_TIMESLOTS, k: int = 0):
+        """-> (device pointer, n): this ctx's result for (kind, timeslot) as the matching read call returns it, left
+        in HBM (valid until the ctx's next call)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.fa_rows_device(self._h, kind, timeslot, k, C.byref(p), C.byref(n)))
+        return p.value or 0, n.value
+
+    def rows_merge_device(self, kind: int, d_rows_ptr: int, n: int, k: int = 0):
+        """Merges n rows in HBM (several ranks' rows_device results back to back) -> (device pointer, n) in emit order."""
+        p, m = C.c_void_p(), C.c_size_t()
+        self._chk(self._L.fa_rows_merge_device(self._h, kind, d_rows_ptr, n, k, C.byref(p), C.byref(m)))
+        return p.value or 0, m.value
+
+    def rows_fetch(self, kind: int, d_rows_ptr: int, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=ROW_DTYPES[kind])
+        if n:
+            self._chk(self._L.fa_rows_fetch(self._h, kind, d_rows_ptr, n, out.ctypes.data, n))
+        return out
+
+    def drop_window(self, kind: int, timeslot=ALL_TIMESLOTS):
+        """Removes what close_window / close_window_app would remove after emitting `timeslot`."""
+        self._chk(self._L.fa_drop_window(self._h, kind, timeslot))
 
     def open_timeslots(self) -> np.ndarray:
         n = C.c_size_t()

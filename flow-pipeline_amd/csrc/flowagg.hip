@@ -30,10 +30,6 @@ struct fa_ctx {
     fa_config cfg{};
     uint32_t gran = 300;
     hipStream_t stream = nullptr;
-    // side stream (experiment, FA_DEFERRED=beside): the second-chance kernel of a scatter-sink launch beside the tuple
-    // aggregation (both only add to the tables with atomics; the next launch waits for both)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_ingested = nullptr, ev_deferred = nullptr;
     // three events per ingest launch: before / after the tile kernel, after the aggregation kernel
     struct LaunchEvents { hipEvent_t e0, e1, e2; };
     std::vector<LaunchEvents> ev_pool;
@@ -96,7 +92,6 @@ struct fa_ctx {
     uint32_t agg_passes_forced = 0;  // env FA_AGG_PASSES (tests, A/B)
     uint32_t agg_passes = 1;      // agg8_kernel passes for the next launch (1, 2, 4, 8): groups per launch / (partitions x passes) <= half the LDS table
     unsigned stage_threads = 8;   // host threads of the staging copy (fa_ingest)
-    bool deferred_beside = false; // env FA_DEFERRED=beside (A/B): second-chance kernel on the side stream, beside the aggregation
     bool agg_generic = false;     // env FA_AGG=generic (A/B): compact tuples through the two-word-key aggregation kernel
     uint32_t par = 0;             // parity of the next launch (Counters::exotic_count / retry_count copies)
     uint32_t seg_cap_limit = 0;   // env FA_SEG_CAP (tests only): upper bound on tuples per segment
@@ -120,12 +115,15 @@ struct fa_ctx {
     size_t col_cap = 0;
     ColumnPtrs cols{};
 
-    // window close
-    Row5m* d_rows = nullptr;         // extracted rows (unsorted)
-    Row5m* d_rows_sorted = nullptr;  // ... sorted by key: what window close hands out
-    size_t d_rows_cap = 0;
-    void* d_sort = nullptr;          // sort scratch: 4 key arrays, 2 index arrays, hipcub temporary storage
-    size_t d_sort_bytes = 0;
+    // window close (rows_host.inc): rows collected out of the device state, merge scratch, merged / ordered rows
+    void* rc_buf = nullptr;          // collected rows (public format, unsorted)
+    size_t rc_cap = 0;
+    void* rw_buf = nullptr;          // port / minute rows (wide-table rows + the dense histogram's entries)
+    size_t rw_cap = 0;
+    void* m_scratch = nullptr;       // sort scratch: 2 key arrays, 4 index arrays, hipcub temporary storage
+    size_t m_scratch_cap = 0;
+    void* m_out[2] = {nullptr, nullptr};  // merged rows; rows in emit order
+    size_t m_out_cap[2] = {0, 0};
     void* h_rows = nullptr;          // pinned: rows on their way to the caller
     size_t h_rows_cap = 0;
 
@@ -295,7 +293,6 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
         c->agg_passes_forced = (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 0u;
     }
     c->cms_scatter_ok = cms_scatterable(cfg.cms_depth, cfg.cms_width_log2);
-    if (const char* d = getenv("FA_DEFERRED")) c->deferred_beside = !strcmp(d, "beside");
     if (const char* d = getenv("FA_STAGE_THREADS")) c->stage_threads = (unsigned)std::min(64, std::max(1, atoi(d)));
     c->stage_threads = std::min(c->stage_threads, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* d = getenv("FA_TUPLE")) c->t8_mode = !strcmp(d, "8") ? 1 : !strcmp(d, "16") ? 2 : 0;
@@ -313,10 +310,6 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     }
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
-    if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    if ((e = hipEventCreateWithFlags(&c->ev_ingested, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_deferred, hipEventDisableTiming)) != hipSuccess)
-        return bail("hipEventCreate", e);
     for (int i = 0; i < 2; i++)
         if ((e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming)) != hipSuccess)
             return bail("hipEventCreate", e);
@@ -432,9 +425,11 @@ extern "C" void fa_destroy(fa_ctx* c) {
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
     }
     (void)hipFree(c->col_block);
-    (void)hipFree(c->d_rows);
-    (void)hipFree(c->d_rows_sorted);
-    (void)hipFree(c->d_sort);
+    (void)hipFree(c->rc_buf);
+    (void)hipFree(c->rw_buf);
+    (void)hipFree(c->m_scratch);
+    (void)hipFree(c->m_out[0]);
+    (void)hipFree(c->m_out[1]);
     if (c->h_rows) (void)hipHostFree(c->h_rows);
     (void)hipFree(c->cms_src);
     (void)hipFree(c->cms_dst);
@@ -451,10 +446,6 @@ extern "C" void fa_destroy(fa_ctx* c) {
             (void)hipEventDestroy(p.e1);
             (void)hipEventDestroy(p.e2);
         }
-    if (c->side) (void)hipStreamSynchronize(c->side);
-    if (c->ev_ingested) (void)hipEventDestroy(c->ev_ingested);
-    if (c->ev_deferred) (void)hipEventDestroy(c->ev_deferred);
-    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -739,11 +730,10 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
     c->par ^= 1u;
     const bool wave_tiles = MODE == MODE_INGEST && a.seg != nullptr && a.tile_recs <= (uint32_t)WT_RECS && c->use_wave_tiles;
     const bool t8 = wave_tiles && c->use_t8;
-    // (measured: the second-chance kernel on a side stream beside the aggregation costs MORE than running it in line -
-    // 66 vs 58 us for deferred + aggregation per launch; the cross-stream event hand-over is slower than the 4.5 us kernel.
-    // FA_DEFERRED=beside keeps the experiment reachable.)
-    const bool beside = MODE == MODE_INGEST && a.seg != nullptr && c->deferred_beside;
-    hipStream_t dstream = beside ? c->side : c->stream;
+    // (the second-chance kernel runs in line: on a side stream beside the aggregation it cost MORE - 66 vs 58 us for
+    // deferred + aggregation per launch, the cross-stream hand-over being slower than the 4.5 us kernel - and its atomic
+    // upserts would race with the region-owned plain stores of agg8_kernel / cms_agg_kernel; the knob is gone)
+    hipStream_t dstream = c->stream;
     if (ev) (void)hipEventRecord(ev->e0, c->stream);
     if (MODE == MODE_INGEST && a.seg && !wave_tiles) hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, c->stream, a);
     if (wave_tiles) c->stats.wave_tile_launches += 1;
@@ -762,10 +752,6 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
             hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);                 \
         }                                                                                       \
         if (ev) (void)hipEventRecord(ev->e1, c->stream);                                        \
-        if (beside) {                                                                           \
-            (void)hipEventRecord(c->ev_ingested, c->stream);                                    \
-            (void)hipStreamWaitEvent(dstream, c->ev_ingested, 0);                               \
-        }                                                                                       \
         hipLaunchKernelGGL((deferred_kernel<MODE, KS>), ge, b, 0, dstream, a);                  \
         break;                                                                                  \
     }
@@ -778,10 +764,6 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
             if (wave_tiles) FA_LAUNCH_W(KS_ALL);
             else hipLaunchKernelGGL((tile_kernel<MODE, KS_ALL>), g, b, 0, c->stream, a);
             if (ev) (void)hipEventRecord(ev->e1, c->stream);
-            if (beside) {
-                (void)hipEventRecord(c->ev_ingested, c->stream);
-                (void)hipStreamWaitEvent(dstream, c->ev_ingested, 0);
-            }
             hipLaunchKernelGGL((deferred_kernel<MODE, KS_ALL>), ge, b, 0, dstream, a);
             break;
         }
@@ -797,10 +779,6 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
     if (MODE == MODE_INGEST && wave_tiles && a.cseg) {  // fold the sketch tuples (Count-Min scatter sink)
         const uint32_t set_mask = (c->cfg.key_sets >> 1) & 3u;
         hipLaunchKernelGGL(cms_agg_kernel, dim3(CMS_NPART * (set_mask == 3u ? 2u : 1u)), dim3(AGG_BLOCK), 0, c->stream, a, set_mask);
-    }
-    if (beside) {  // the launch is over when both are
-        (void)hipEventRecord(c->ev_deferred, dstream);
-        (void)hipStreamWaitEvent(c->stream, c->ev_deferred, 0);
     }
     // fold the (SrcAddr,DstPort,Proto) tuples: one workgroup per table region, plain loads and stores - behind every
     // dispatch of this launch that updates the wide table with atomics (wagg.cuh)
@@ -871,9 +849,11 @@ static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, bool t8, KArgs& a)
     a.seg = c->seg;
     a.seg_counts = c->seg_counts;
     a.capq = capq;
-    a.capb = std::min<uint32_t>(std::max<uint32_t>(2 * tpl, (capq / 4) & ~(tpl - 1)), 0x10000u - tpl);  // back part: single tuples, bin leftovers
+    // (the LDS position counters are 16-bit halves of one word: caps leave room for the few increments that are in
+    // flight before a full segment's overflow is taken back - sinks.cuh)
+    a.capb = std::min<uint32_t>(std::max<uint32_t>(2 * tpl, (capq / 4) & ~(tpl - 1)), 0xff00u - tpl);  // back part: single tuples, bin leftovers
     a.capb = std::min(a.capb, capq - tpl);
-    a.capf = std::min<uint32_t>(capq - a.capb, 0xffffu * tpl);                                           // front part: full lines
+    a.capf = std::min<uint32_t>(capq - a.capb, 0xff00u * tpl);                                           // front part: full lines
     a.nwg = nwg;
     a.region = region;
     a.plog2 = c->plog2;
@@ -886,7 +866,8 @@ static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, bool t8, KArgs& a)
 static int ensure_csegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     const size_t nparts = (size_t)CMS_SETS * CMS_NPART;
     const size_t mean = n / ((size_t)CMS_NPART * nwg);
-    const uint32_t capq = (uint32_t)((3 * mean + 32 + 3) & ~(size_t)3);
+    uint32_t capq = (uint32_t)((3 * mean + 32 + 3) & ~(size_t)3);
+    if (c->seg_cap_limit) capq = std::max<uint32_t>(std::min(capq, c->seg_cap_limit) & ~3u, 32u);  // (tests: force the overflow fallbacks)
     const size_t region = (size_t)nwg * capq + 12;
     const size_t bytes = region * nparts * sizeof(uint4);
     if (c->cseg_bytes < bytes) {
@@ -909,8 +890,8 @@ static int ensure_csegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     a.cseg = c->cseg;
     a.cseg_counts = c->cseg_counts;
     a.ccapq = capq;
-    a.ccapb = std::min<uint32_t>(std::max<uint32_t>(8u, (capq / 8) & ~3u), 0xfffcu);
-    a.ccapf = std::min<uint32_t>(capq - a.ccapb, 0xffffu * CMS_BIN);
+    a.ccapb = std::min<uint32_t>(std::max<uint32_t>(8u, (capq / 8) & ~3u), 0xff00u);
+    a.ccapf = std::min<uint32_t>(capq - a.ccapb, 0xff00u * CMS_BIN);
     a.cregion = region;
     a.cms_sub = c->cfg.cms_width_log2 - 8u;
     return FA_OK;
@@ -1340,80 +1321,7 @@ extern "C" int fa_decode(fa_ctx* c, const uint8_t* buf, size_t len, const uint64
     return FA_OK;
 }
 
-// ---- window close ------------------------------------------------------------------------
-static bool row_less(const fa_row5m& x, const fa_row5m& y) {
-    if (x.date != y.date) return x.date < y.date;
-    if (x.timeslot != y.timeslot) return x.timeslot < y.timeslot;
-    if (x.src_as != y.src_as) return x.src_as < y.src_as;
-    if (x.dst_as != y.dst_as) return x.dst_as < y.dst_as;
-    return x.etype < y.etype;
-}
-
-// Window close, device side: the rows with time bucket in [tb_lo,tb_hi) are compacted out of the table and sorted
-// by (date, timeslot, src_as, dst_as, etype) in HBM (two stable 64-bit radix passes).  They stay in
-// c->d_rows_sorted; the host only copies the final rows out (393 k rows of config 2: < 2 ms instead of the 100 ms
-// the former D2H + std::sort took).
-// to_host: the last gather writes the sorted rows straight into the ctx's pinned host buffer (c->h_rows, mapped into
-// the device: 393 k rows cross PCIe in ~0.4 ms; a D2H copy of the same rows took 7 ms on the bench boxes) when they
-// fit it; *in_host tells where they ended up.
-static int collect_rows_device(fa_ctx* c, uint32_t tb_lo, uint32_t tb_hi, uint32_t fold_ts, size_t& nrows, bool to_host = false, bool* in_host = nullptr) {
-    if (in_host) *in_host = false;
-    int rc = settle(c);
-    if (rc) return rc;
-    const size_t need = std::max<uint64_t>(c->stats.table_used, 1024);
-    if (c->d_rows_cap < need) {
-        (void)hipFree(c->d_rows);
-        (void)hipFree(c->d_rows_sorted);
-        c->d_rows = c->d_rows_sorted = nullptr;
-        c->d_rows_cap = 0;
-        if (hipMalloc(&c->d_rows, need * sizeof(Row5m)) != hipSuccess || hipMalloc(&c->d_rows_sorted, need * sizeof(Row5m)) != hipSuccess)
-            return fail(c, FA_ERR_NOMEM, "hipMalloc(rows) failed");
-        c->d_rows_cap = need;
-    }
-    HIPCHK(c, hipMemsetAsync(&c->d_ctr->rows_count, 0, sizeof(unsigned int), c->stream));
-    hipLaunchKernelGGL(extract_kernel, dim3(1024), dim3(256), 0, c->stream, c->tab, 1u << c->cap_log2, c->gran,
-                       tb_lo, tb_hi, c->d_rows, (uint32_t)c->d_rows_cap, c->d_ctr);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    nrows = c->h_ctr->rows_count;
-    if (nrows > c->d_rows_cap) return fail(c, FA_ERR_HIP, "internal: row buffer too small");
-    if (!nrows) return FA_OK;
-    const uint32_t n = (uint32_t)nrows;
-    size_t tmp_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 64, c->stream);
-    const size_t karr = ((size_t)n * 8 + 255) & ~(size_t)255, iarr = ((size_t)n * 4 + 255) & ~(size_t)255;
-    const size_t want = 4 * karr + 2 * iarr + tmp_bytes + 256;
-    if (c->d_sort_bytes < want) {
-        (void)hipFree(c->d_sort);
-        c->d_sort = nullptr;
-        c->d_sort_bytes = 0;
-        if (hipMalloc(&c->d_sort, want) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(sort scratch) failed");
-        c->d_sort_bytes = want;
-    }
-    uint8_t* base = (uint8_t*)c->d_sort;
-    unsigned long long* klo = (unsigned long long*)base;
-    unsigned long long* khi = (unsigned long long*)(base + karr);
-    unsigned long long* k2 = (unsigned long long*)(base + 2 * karr);
-    unsigned long long* k3 = (unsigned long long*)(base + 3 * karr);
-    uint32_t* idx0 = (uint32_t*)(base + 4 * karr);
-    uint32_t* idx1 = (uint32_t*)(base + 4 * karr + iarr);
-    void* tmp = base + 4 * karr + 2 * iarr;
-    const dim3 g(std::min<uint32_t>(1024, (n + 255) / 256)), b(256);
-    hipLaunchKernelGGL(row_keys_kernel, g, b, 0, c->stream, c->d_rows, n, fold_ts, klo, khi, idx0);
-    if (hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, klo, k2, idx0, idx1, (int)n, 0, 64, c->stream) != hipSuccess)
-        return fail(c, FA_ERR_HIP, "radix sort (low key) failed");
-    hipLaunchKernelGGL(gather_u64_kernel, g, b, 0, c->stream, khi, idx1, n, k2);
-    if (hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k2, k3, idx1, idx0, (int)n, 0, 64, c->stream) != hipSuccess)
-        return fail(c, FA_ERR_HIP, "radix sort (high key) failed");
-    const bool host = to_host && c->h_rows && (size_t)n * sizeof(Row5m) <= c->h_rows_cap;
-    hipLaunchKernelGGL(gather_rows_kernel, g, b, 0, c->stream, c->d_rows, idx0, n, host ? (Row5m*)c->h_rows : c->d_rows_sorted);
-    HIPCHK(c, hipGetLastError());
-    if (in_host) *in_host = host;
-    return FA_OK;
-}
-
+// ---- window close: see rows_host.inc (included below) ------------------------------------------------
 // timeslot -> bucket range.  With sub-windows a window [timeslot, timeslot+window_secs)
 // is the sum of window_secs/gran consecutive sub-buckets (sliding windows share them).
 static bool bucket_range(const fa_ctx* c, uint32_t timeslot, uint32_t& lo, uint32_t& hi) {
@@ -1428,162 +1336,6 @@ static bool bucket_range(const fa_ctx* c, uint32_t timeslot, uint32_t& lo, uint3
     return true;
 }
 
-// The window's rows, sorted, into the caller's buffer.  n_out = rows (needed); FA_ERR_CAPACITY when cap is too small.
-static double wall_ms() {
-    timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-}
-static int window_rows_out(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out, uint32_t& lo, uint32_t& hi) {
-    static const bool timing = getenv("FA_TIMING_CLOSE") != nullptr;
-    const double t0 = timing ? wall_ms() : 0.0;
-    *n_out = 0;
-    if (!bucket_range(c, timeslot, lo, hi)) {
-        lo = hi = 0;
-        return FA_OK;  // not a bucket boundary: no rows
-    }
-    const bool fold = timeslot != 0xFFFFFFFFu && c->gran != c->cfg.window_secs;
-    size_t n = 0;
-    bool in_host = false;
-    int rc = collect_rows_device(c, lo, hi, fold ? timeslot : 0xFFFFFFFFu, n, !fold, &in_host);
-    if (rc) return rc;
-    static_assert(sizeof(Row5m) == sizeof(fa_row5m), "row layout");
-    if (!fold) {
-        *n_out = n;
-        if (n > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
-        const size_t bytes = n * sizeof(Row5m);
-        if (n && !in_host) {  // (rows beyond the pinned buffer: grow it for the next close, copy this time)
-            if (c->h_rows) (void)hipHostFree(c->h_rows);
-            c->h_rows = nullptr;
-            c->h_rows_cap = 0;
-            if (hipHostMalloc(&c->h_rows, bytes + bytes / 4 + 4096) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipHostMalloc(rows) failed");
-            c->h_rows_cap = bytes + bytes / 4 + 4096;
-            HIPCHK(c, hipMemcpyAsync(c->h_rows, c->d_rows_sorted, bytes, hipMemcpyDeviceToHost, c->stream));
-        }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const double t1 = timing ? wall_ms() : 0.0;
-        if (n) memcpy(out, c->h_rows, bytes);
-        if (timing) fprintf(stderr, "[flowagg close] %zu rows: settle + extract + sort + rows to pinned host memory %.2f ms, copy out %.2f ms\n", n, t1 - t0, wall_ms() - t1);
-        return FA_OK;
-    }
-    // sliding window: the sub-buckets of a group are adjacent now - one row per (SrcAS,DstAS,EType)
-    std::vector<fa_row5m> rows(n);
-    if (n) HIPCHK(c, hipMemcpyAsync(rows.data(), c->d_rows_sorted, n * sizeof(Row5m), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    size_t w = 0;
-    for (size_t i = 0; i < rows.size(); i++) {
-        if (w && !row_less(rows[w - 1], rows[i]) && !row_less(rows[i], rows[w - 1])) {
-            rows[w - 1].bytes += rows[i].bytes;
-            rows[w - 1].packets += rows[i].packets;
-            rows[w - 1].count += rows[i].count;
-        } else {
-            rows[w++] = rows[i];
-        }
-    }
-    *n_out = w;
-    if (w > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
-    if (w) memcpy(out, rows.data(), w * sizeof(fa_row5m));
-    return FA_OK;
-}
-
-extern "C" int fa_read_window(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out) {
-    FA_ON_DEVICE(c);
-    if (!c || !n_out || (!out && cap)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    uint32_t lo, hi;
-    return window_rows_out(c, timeslot, out, cap, n_out, lo, hi);
-}
-
-extern "C" int fa_close_window(fa_ctx* c, uint32_t timeslot, fa_row5m* out, size_t cap, size_t* n_out) {
-    FA_ON_DEVICE(c);
-    if (!c || !n_out || (!out && cap)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    uint32_t lo, hi;
-    int rc = window_rows_out(c, timeslot, out, cap, n_out, lo, hi);
-    if (rc) return rc;
-    if (lo == hi) return FA_OK;
-    // remove what no later window needs: everything for tumbling windows / close-all,
-    // only the oldest sub-bucket when windows slide over sub-buckets.
-    uint32_t rm_hi = (timeslot != 0xFFFFFFFFu && c->gran != c->cfg.window_secs) ? lo + 1 : hi;
-    return rebuild_table(c, c->cap_log2, lo, rm_hi);
-}
-
-// Window close for a device-side exchange (RCCL all-gather of rows across GPUs): the window's rows, sorted, stay in
-// HBM.  *d_rows: DEVICE pointer to *n fa_row5m, owned by the ctx, valid until its next window / ingest call.  Rows of
-// sub-buckets are handed out as stored (not folded): the receiving ctx re-aggregates them (fa_merge_rows_device).
-extern "C" int fa_window_rows_device(fa_ctx* c, uint32_t timeslot, const void** d_rows, size_t* n_out) {
-    FA_ON_DEVICE(c);
-    if (!c || !d_rows || !n_out) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    *d_rows = nullptr;
-    *n_out = 0;
-    uint32_t lo, hi;
-    if (!bucket_range(c, timeslot, lo, hi)) return FA_OK;
-    size_t n = 0;
-    int rc = collect_rows_device(c, lo, hi, 0xFFFFFFFFu, n);
-    if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    *d_rows = c->d_rows_sorted;
-    *n_out = n;
-    return FA_OK;
-}
-
-extern "C" int fa_merge_rows_device(fa_ctx* c, const void* d_rows, size_t n) {
-    FA_ON_DEVICE(c);
-    if (!c || (!d_rows && n)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    if (!n) return FA_OK;
-    if (n >= (1ull << 32)) return fail(c, FA_ERR_ARG, "fa_merge_rows_device: too many rows");
-    KArgs a = make_args(c);
-    hipLaunchKernelGGL(merge_rows_kernel, dim3(1024), dim3(256), 0, c->stream, (const Row5m*)d_rows, (uint32_t)n, a);
-    HIPCHK(c, hipGetLastError());
-    return settle(c);
-}
-
-extern "C" int fa_open_timeslots(fa_ctx* c, uint32_t* out, size_t cap, size_t* n_out) {
-    FA_ON_DEVICE(c);
-    if (!c || !n_out) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    size_t nr = 0;
-    int rc = collect_rows_device(c, 0, 0xFFFFFFFFu, 0xFFFFFFFFu, nr);
-    if (rc) return rc;
-    std::vector<fa_row5m> rows(nr);
-    if (nr) HIPCHK(c, hipMemcpyAsync(rows.data(), c->d_rows_sorted, nr * sizeof(Row5m), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<uint32_t> ts;
-    ts.reserve(rows.size());
-    for (auto& r : rows) ts.push_back(r.timeslot);
-    std::sort(ts.begin(), ts.end());
-    ts.erase(std::unique(ts.begin(), ts.end()), ts.end());
-    *n_out = ts.size();
-    if (ts.size() > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
-    if (!ts.empty()) memcpy(out, ts.data(), ts.size() * 4);
-    return FA_OK;
-}
-
-extern "C" int fa_merge_rows(fa_ctx* c, const fa_row5m* rows, size_t n) {
-    FA_ON_DEVICE(c);
-    if (!c || (!rows && n)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    if (!n) return FA_OK;
-    for (size_t i = 0; i < n; i++)
-        if (rows[i].timeslot % c->gran) return fail(c, FA_ERR_ARG, "fa_merge_rows: timeslot not on this ctx's bucket grid");
-    Row5m* d = nullptr;
-    if (hipMalloc(&d, n * sizeof(Row5m)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc failed");
-    hipError_t e = hipMemcpyAsync(d, rows, n * sizeof(Row5m), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        KArgs a = make_args(c);
-        hipLaunchKernelGGL(merge_rows_kernel, dim3(256), dim3(256), 0, c->stream, d, (uint32_t)n, a);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    if (e != hipSuccess) {
-        c->err = std::string("fa_merge_rows: ") + hipGetErrorString(e);
-        return FA_ERR_HIP;
-    }
-    return settle(c);
-}
 
 // ---- RowBinary sink -------------------------------------------------------------------------------
 // ClickHouse RowBinary: fixed-width little-endian integers, arrays as LEB128 length + elements; Nested
@@ -1680,40 +1432,6 @@ extern "C" int fa_format_addr(const uint8_t addr[16], uint32_t etype, char* out,
 }
 
 // ---- wide key sets: window close and dashboard reads -----------------------------------------------
-// Collects the selected rows of the wide table into a host vector (unsorted).
-static int collect_wide(fa_ctx* c, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, std::vector<WRow>& rows) {
-    rows.clear();
-    if (!c->wtab) return fail(c, FA_ERR_ARG, "key set not enabled");
-    int rc = settle(c);
-    if (rc) return rc;
-    size_t need = std::max<uint64_t>(c->stats.wide_used, 1024);
-    WRow* d = nullptr;
-    if (hipMalloc(&d, need * sizeof(WRow)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide rows) failed");
-    hipError_t e = hipMemsetAsync(&c->d_ctr->wrows_count, 0, sizeof(unsigned int), c->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(wextract_kernel, dim3(2048), dim3(256), 0, c->stream, c->wtab, 1u << c->wcap_log2, kind_mask, tb_lo,
-                           tb_hi, d, (uint32_t)need, c->d_ctr);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    size_t n = e == hipSuccess ? c->h_ctr->wrows_count : 0;
-    if (e == hipSuccess && n > need) {
-        (void)hipFree(d);
-        return fail(c, FA_ERR_HIP, "internal: wide row buffer too small");
-    }
-    if (e == hipSuccess && n) {
-        rows.resize(n);
-        e = hipMemcpy(rows.data(), d, n * sizeof(WRow), hipMemcpyDeviceToHost);
-    }
-    (void)hipFree(d);
-    if (e != hipSuccess) {
-        c->err = std::string("collect_wide: ") + hipGetErrorString(e);
-        return FA_ERR_HIP;
-    }
-    return FA_OK;
-}
-
 // rows (already packed keys) -> device -> wmerge_kernel
 static int merge_wide(fa_ctx* c, const std::vector<WRow>& rows) {
     if (!c->wtab) return fail(c, FA_ERR_ARG, "key set not enabled");
@@ -1735,86 +1453,6 @@ static int merge_wide(fa_ctx* c, const std::vector<WRow>& rows) {
     return settle(c);
 }
 
-static bool app_less(const fa_row_app& x, const fa_row_app& y) {
-    if (x.date != y.date) return x.date < y.date;
-    if (x.timeslot != y.timeslot) return x.timeslot < y.timeslot;
-    int m = memcmp(x.src_addr, y.src_addr, 16);
-    if (m) return m < 0;
-    if (x.dst_port != y.dst_port) return x.dst_port < y.dst_port;
-    return x.proto < y.proto;
-}
-
-static int window_rows_app(fa_ctx* c, uint32_t timeslot, std::vector<fa_row_app>& out, uint32_t& lo, uint32_t& hi) {
-    out.clear();
-    if (!(c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO)) return fail(c, FA_ERR_ARG, "FA_KEYS_ADDR_PORT_PROTO not enabled");
-    if (!bucket_range(c, timeslot, lo, hi)) {
-        lo = hi = 0;
-        return FA_OK;
-    }
-    std::vector<WRow> raw;
-    int rc = collect_wide(c, 1u << WK_APP, lo, hi, raw);
-    if (rc) return rc;
-    out.resize(raw.size());
-    for (size_t i = 0; i < raw.size(); i++) {
-        uint32_t kind, tb, port, proto;
-        uint64_t alo, ahi;
-        wkey_unpack(raw[i].w, kind, tb, alo, ahi, port, proto);
-        fa_row_app& r = out[i];
-        r.timeslot = (timeslot != 0xFFFFFFFFu && c->gran != c->cfg.window_secs) ? timeslot : tb * c->gran;
-        r.date = r.timeslot / 86400u;
-        memcpy(r.src_addr, &alo, 8);
-        memcpy(r.src_addr + 8, &ahi, 8);
-        r.dst_port = port;
-        r.proto = proto;
-        r.bytes = raw[i].v0;
-        r.packets = raw[i].v1;
-        r.count = raw[i].v2;
-    }
-    std::sort(out.begin(), out.end(), app_less);
-    size_t w = 0;  // fold the sub-buckets of a sliding window
-    for (size_t i = 0; i < out.size(); i++) {
-        if (w && !app_less(out[w - 1], out[i]) && !app_less(out[i], out[w - 1])) {
-            out[w - 1].bytes += out[i].bytes;
-            out[w - 1].packets += out[i].packets;
-            out[w - 1].count += out[i].count;
-        } else {
-            out[w++] = out[i];
-        }
-    }
-    out.resize(w);
-    return FA_OK;
-}
-
-extern "C" int fa_read_window_app(fa_ctx* c, uint32_t timeslot, fa_row_app* out, size_t cap, size_t* n_out) {
-    FA_ON_DEVICE(c);
-    if (!c || !n_out) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    std::vector<fa_row_app> rows;
-    uint32_t lo, hi;
-    int rc = window_rows_app(c, timeslot, rows, lo, hi);
-    if (rc) return rc;
-    *n_out = rows.size();
-    if (rows.size() > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
-    if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(fa_row_app));
-    return FA_OK;
-}
-
-extern "C" int fa_close_window_app(fa_ctx* c, uint32_t timeslot, fa_row_app* out, size_t cap, size_t* n_out) {
-    FA_ON_DEVICE(c);
-    if (!c || !n_out) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    std::vector<fa_row_app> rows;
-    uint32_t lo, hi;
-    int rc = window_rows_app(c, timeslot, rows, lo, hi);
-    if (rc) return rc;
-    *n_out = rows.size();
-    if (rows.size() > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
-    if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(fa_row_app));
-    if (lo == hi) return FA_OK;
-    uint32_t rm_hi = (timeslot != 0xFFFFFFFFu && c->gran != c->cfg.window_secs) ? lo + 1 : hi;
-    return rebuild_wide(c, c->wcap_log2, 1u << WK_APP, lo, rm_hi);
-}
-
 extern "C" int fa_merge_rows_app(fa_ctx* c, const fa_row_app* rows, size_t n) {
     FA_ON_DEVICE(c);
     if (!c || (!rows && n)) return FA_ERR_ARG;
@@ -1831,36 +1469,6 @@ extern "C" int fa_merge_rows_app(fa_ctx* c, const fa_row_app* rows, size_t n) {
         w[i] = WRow{{k.w[0], k.w[1], k.w[2], k.w[3]}, rows[i].bytes, rows[i].packets, rows[i].count};
     }
     return merge_wide(c, w);
-}
-
-extern "C" int fa_top_ports(fa_ctx* c, int dst, size_t k, fa_port_row* out, size_t cap, size_t* n_out) {
-    FA_ON_DEVICE(c);
-    if (!c || !n_out || (!out && cap) || (dst != 0 && dst != 1)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    if (!c->port_hist) return fail(c, FA_ERR_ARG, "FA_KEYS_PORT_HIST not enabled");
-    std::vector<WRow> big;
-    int rc = collect_wide(c, 1u << (dst ? WK_DSTPORT : WK_SRCPORT), 0, 0, big);  // settles the stream
-    if (rc) return rc;
-    std::vector<ulonglong2> dense(PORT_DENSE);
-    HIPCHK(c, hipMemcpy(dense.data(), c->port_hist + (size_t)dst * PORT_DENSE, sizeof(ulonglong2) * PORT_DENSE, hipMemcpyDeviceToHost));
-    std::vector<fa_port_row> rows;
-    for (uint32_t p = 0; p < PORT_DENSE; p++)
-        if (dense[p].y) rows.push_back(fa_port_row{p, 0, dense[p].x, dense[p].y});
-    for (auto& r : big) {
-        uint32_t kind, tb, port, proto;
-        uint64_t lo, hi;
-        wkey_unpack(r.w, kind, tb, lo, hi, port, proto);
-        rows.push_back(fa_port_row{port, 0, r.v0, r.v2});
-    }
-    std::sort(rows.begin(), rows.end(), [](const fa_port_row& x, const fa_port_row& y) {
-        if (x.weight != y.weight) return x.weight > y.weight;
-        return x.port < y.port;
-    });
-    const size_t m = std::min(k, rows.size());
-    *n_out = m;
-    if (m > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
-    if (m) memcpy(out, rows.data(), m * sizeof(fa_port_row));
-    return FA_OK;
 }
 
 __global__ void port_merge_kernel(const fa_port_row* rows, uint32_t n, ulonglong2* hist) {
@@ -1904,28 +1512,6 @@ extern "C" int fa_merge_ports(fa_ctx* c, int dst, const fa_port_row* rows, size_
         }
     }
     return merge_wide(c, big);
-}
-
-extern "C" int fa_minute_series(fa_ctx* c, fa_minute_row* out, size_t cap, size_t* n_out) {
-    FA_ON_DEVICE(c);
-    if (!c || !n_out || (!out && cap)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    if (!(c->cfg.key_sets & FA_KEYS_MINUTE_SERIES)) return fail(c, FA_ERR_ARG, "FA_KEYS_MINUTE_SERIES not enabled");
-    std::vector<WRow> raw;
-    int rc = collect_wide(c, 1u << WK_MINUTE, 0, 0, raw);
-    if (rc) return rc;
-    std::vector<fa_minute_row> rows(raw.size());
-    for (size_t i = 0; i < raw.size(); i++) {
-        uint32_t kind, tb, port, proto;
-        uint64_t lo, hi;
-        wkey_unpack(raw[i].w, kind, tb, lo, hi, port, proto);
-        rows[i] = fa_minute_row{port * 60u, 0, raw[i].v0, raw[i].v2};
-    }
-    std::sort(rows.begin(), rows.end(), [](const fa_minute_row& x, const fa_minute_row& y) { return x.minute < y.minute; });
-    *n_out = rows.size();
-    if (rows.size() > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
-    if (!rows.empty()) memcpy(out, rows.data(), rows.size() * sizeof(fa_minute_row));
-    return FA_OK;
 }
 
 extern "C" int fa_merge_minutes(fa_ctx* c, const fa_minute_row* rows, size_t n) {
@@ -2031,63 +1617,6 @@ extern "C" int fa_cms_query(fa_ctx* c, uint32_t key_set, const uint8_t key[16], 
     return FA_OK;
 }
 
-extern "C" int fa_topk(fa_ctx* c, uint32_t key_set, size_t k, fa_topk_row* out, size_t cap, size_t* n_out) {
-    FA_ON_DEVICE(c);
-    if (!c || !n_out || (!out && cap)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    unsigned long long* cms = cms_of(c, key_set);
-    KeySlot* ks = key_set == FA_KEYS_SRCADDR_CMS ? c->ks_src : key_set == FA_KEYS_DSTADDR_CMS ? c->ks_dst : nullptr;
-    if (!cms || !ks) return fail(c, FA_ERR_ARG, "fa_topk: key set not enabled");
-    int rc = settle(c);
-    if (rc) return rc;
-    if (c->h_ctr->ks_overflow) return fail(c, FA_ERR_TABLE_FULL, "fa_topk: distinct-address set overflowed (raise topk_capacity_log2)");
-    const uint32_t nslots = 1u << c->ks_log2;
-    TopkRow* d_rows = nullptr;
-    if (hipMalloc(&d_rows, (size_t)nslots * sizeof(TopkRow)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "fa_topk: hipMalloc failed");
-    std::vector<TopkRow> rows;
-    hipError_t e = hipMemsetAsync(&c->d_ctr->ks_rows, 0, sizeof(unsigned int), c->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(topk_rows_kernel, dim3(1024), dim3(256), 0, c->stream, ks, nslots, cms, c->cfg.cms_depth,
-                           c->cfg.cms_width_log2, c->cfg.cms_seed, d_rows, nslots, c->d_ctr);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) {
-        rows.resize(c->h_ctr->ks_rows);
-        if (!rows.empty()) e = hipMemcpy(rows.data(), d_rows, rows.size() * sizeof(TopkRow), hipMemcpyDeviceToHost);
-    }
-    (void)hipFree(d_rows);
-    if (e != hipSuccess) {
-        c->err = std::string("fa_topk: ") + hipGetErrorString(e);
-        return FA_ERR_HIP;
-    }
-    // order: weight descending, then key bytes ascending (memcmp order of the FixedString(16))
-    auto key_less = [](const TopkRow& x, const TopkRow& y) {
-        uint8_t a[16], b[16];
-        memcpy(a, &x.lo, 8); memcpy(a + 8, &x.hi, 8);
-        memcpy(b, &y.lo, 8); memcpy(b + 8, &y.hi, 8);
-        return memcmp(a, b, 16) < 0;
-    };
-    auto row_less = [&](const TopkRow& x, const TopkRow& y) {
-        if (x.weight != y.weight) return x.weight > y.weight;
-        return key_less(x, y);
-    };
-    std::sort(rows.begin(), rows.end(), row_less);
-    // a key stored twice (see keyset_insert) has the same estimate twice: adjacent after the sort
-    rows.erase(std::unique(rows.begin(), rows.end(), [](const TopkRow& x, const TopkRow& y) { return x.lo == y.lo && x.hi == y.hi; }),
-               rows.end());
-    const size_t m = std::min(k, rows.size());
-    *n_out = m;
-    if (m > cap) return fail(c, FA_ERR_CAPACITY, "output buffer too small");
-    for (size_t i = 0; i < m; i++) {
-        memcpy(out[i].key, &rows[i].lo, 8);
-        memcpy(out[i].key + 8, &rows[i].hi, 8);
-        out[i].weight = rows[i].weight;
-    }
-    return FA_OK;
-}
-
 extern "C" int fa_topk_merge_keys(fa_ctx* c, uint32_t key_set, const uint8_t* keys, size_t n) {
     FA_ON_DEVICE(c);
     if (!c || (!keys && n)) return FA_ERR_ARG;
@@ -2111,6 +1640,8 @@ extern "C" int fa_topk_merge_keys(fa_ctx* c, uint32_t key_set, const uint8_t* ke
     }
     return FA_OK;
 }
+
+#include "rows_host.inc"
 
 extern "C" int fa_device_state_get(fa_ctx* c, fa_device_state* out) {
     FA_ON_DEVICE(c);

@@ -163,6 +163,8 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                                 else a.seg[at] = tv;
                             }
                             pending = false;
+                        } else {
+                            lds_add_u32(&part_cnt[part], 0xffff0000u);  // (not stored: -1 on the back count, which never wraps into stored tuples)
                         }
                     }
                 } else if (!T8) {

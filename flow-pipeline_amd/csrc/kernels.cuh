@@ -25,3 +25,4 @@
 #include "agg.cuh"
 #include "wagg.cuh"
 #include "maintenance.cuh"
+#include "merge.cuh"

@@ -1,0 +1,221 @@
+// merge.cuh - window close on the device: row sets (flows_5m rows, (SrcAddr,DstPort,Proto) rows, port / minute rows,
+// top-k candidates) are sorted, rows with equal keys summed and the result put into the order the read side emits -
+// all in HBM.  One code path serves a single ctx's close (the sub-buckets of a sliding window fold here) and the merge
+// of several ranks' row sets gathered over RCCL (SummingMergeTree collapse, compose/clickhouse/create.sh:70-90;
+// read-side orders: README.md:164-184, compose/grafana/dashboards/viz-ch.json:74,233,358,479,604).
+//
+// Shape: LSD radix sort over the key words of a row kind (hipcub SortPairs of {key word, row index}; the next word is
+// gathered through the permutation between passes), head flags + exclusive scan, one thread per run sums its rows
+// (runs are as long as there are ranks x sub-buckets: short), optional second sort into the emit order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "maintenance.cuh"
+
+namespace fa {
+
+enum { RK_5M = 0, RK_APP = 1, RK_PORT_SRC = 2, RK_PORT_DST = 3, RK_MINUTE = 4, RK_TOPK_SRC = 5, RK_TOPK_DST = 6, RK_COUNT = 7 };
+
+struct RowApp {  // == fa_row_app
+    uint32_t date, timeslot;
+    uint32_t addr[4];
+    uint32_t dst_port, proto;
+    unsigned long long bytes, packets, count;
+};
+static_assert(sizeof(RowApp) == 56, "fa_row_app layout");
+struct RowW {  // == fa_port_row == fa_minute_row
+    uint32_t key, pad;
+    unsigned long long weight, count;
+};
+static_assert(sizeof(RowW) == 24, "fa_port_row layout");
+static_assert(sizeof(TopkRow) == 24, "fa_topk_row layout");
+
+// memcmp order of 8 key bytes held as a little-endian u64
+__host__ __device__ __forceinline__ unsigned long long bytes_order(unsigned long long le) {
+    return __builtin_bswap64(le);
+}
+
+// Per row kind: the words of the MERGE order (equal words <=> same group; least significant word first), how two rows
+// of one group combine, and - where the read side wants another order - the words of the EMIT order.
+// fold = the window start every row is assigned to (sliding windows: the sub-buckets of a group become one row), ~0: none.
+template <int KIND>
+struct RowOps;
+
+template <>
+struct RowOps<RK_5M> {
+    typedef Row5m Row;
+    static constexpr int NK = 2, NK2 = 0;
+    __device__ static unsigned long long key(const Row& r, int w, uint32_t fold) {
+        return w == 0 ? ((unsigned long long)r.dst_as << 32 | r.etype) : ((unsigned long long)(fold != 0xffffffffu ? fold : r.timeslot) << 32 | r.src_as);
+    }
+    __host__ __device__ static int bits(int) { return 64; }
+    __device__ static unsigned long long key2(const Row&, int) { return 0; }
+    __device__ static bool same(const Row& a, const Row& b, uint32_t fold) {
+        return a.src_as == b.src_as && a.dst_as == b.dst_as && a.etype == b.etype && (fold != 0xffffffffu || a.timeslot == b.timeslot);
+    }
+    __device__ static void add(Row& a, const Row& b) {
+        a.bytes += b.bytes;
+        a.packets += b.packets;
+        a.count += b.count;
+    }
+    __device__ static void finish(Row& r, uint32_t fold) {
+        if (fold != 0xffffffffu) r.timeslot = fold;
+        r.date = r.timeslot / 86400u;
+        r.pad = 0;
+    }
+};
+
+template <>
+struct RowOps<RK_APP> {
+    typedef RowApp Row;
+    static constexpr int NK = 4, NK2 = 0;
+    // order: date, timeslot, src_addr (bytes), dst_port, proto (fa_read_window_app)
+    __device__ static unsigned long long key(const Row& r, int w, uint32_t fold) {
+        switch (w) {
+        case 0: return (unsigned long long)r.dst_port << 32 | r.proto;
+        case 1: return bytes_order((unsigned long long)r.addr[3] << 32 | r.addr[2]);
+        case 2: return bytes_order((unsigned long long)r.addr[1] << 32 | r.addr[0]);
+        default: return fold != 0xffffffffu ? fold : r.timeslot;
+        }
+    }
+    __host__ __device__ static int bits(int w) { return w == 3 ? 32 : 64; }
+    __device__ static unsigned long long key2(const Row&, int) { return 0; }
+    __device__ static bool same(const Row& a, const Row& b, uint32_t fold) {
+        return a.addr[0] == b.addr[0] && a.addr[1] == b.addr[1] && a.addr[2] == b.addr[2] && a.addr[3] == b.addr[3] &&
+               a.dst_port == b.dst_port && a.proto == b.proto && (fold != 0xffffffffu || a.timeslot == b.timeslot);
+    }
+    __device__ static void add(Row& a, const Row& b) {
+        a.bytes += b.bytes;
+        a.packets += b.packets;
+        a.count += b.count;
+    }
+    __device__ static void finish(Row& r, uint32_t fold) {
+        if (fold != 0xffffffffu) r.timeslot = fold;
+        r.date = r.timeslot / 86400u;
+    }
+};
+
+// GROUP BY port ORDER BY sum(Bytes*SamplingRate) DESC, port (viz-ch.json:358,604) / GROUP BY minute ORDER BY minute (:74)
+template <bool BY_WEIGHT>
+struct RowOpsW {
+    typedef RowW Row;
+    static constexpr int NK = 1, NK2 = BY_WEIGHT ? 2 : 0;
+    __device__ static unsigned long long key(const Row& r, int, uint32_t) { return r.key; }
+    __host__ __device__ static int bits(int) { return 32; }
+    __device__ static unsigned long long key2(const Row& r, int w) { return w == 0 ? (unsigned long long)r.key : ~r.weight; }
+    __host__ __device__ static int bits2(int w) { return w == 0 ? 32 : 64; }
+    __device__ static bool same(const Row& a, const Row& b, uint32_t) { return a.key == b.key; }
+    __device__ static void add(Row& a, const Row& b) {
+        a.weight += b.weight;
+        a.count += b.count;
+    }
+    __device__ static void finish(Row& r, uint32_t) { r.pad = 0; }
+};
+template <>
+struct RowOps<RK_PORT_SRC> : RowOpsW<true> {};
+template <>
+struct RowOps<RK_PORT_DST> : RowOpsW<true> {};
+template <>
+struct RowOps<RK_MINUTE> : RowOpsW<false> {};
+
+// heavy hitters: one row per address (a key stored twice in the distinct set, or reported by several ranks, carries the
+// same estimate everywhere: the first one stands), ORDER BY estimate DESC, address bytes (fa_topk)
+struct RowOpsTopk {
+    typedef TopkRow Row;
+    static constexpr int NK = 2, NK2 = 3;
+    __device__ static unsigned long long key(const Row& r, int w, uint32_t) { return w == 0 ? bytes_order(r.hi) : bytes_order(r.lo); }
+    __host__ __device__ static int bits(int) { return 64; }
+    __device__ static unsigned long long key2(const Row& r, int w) { return w == 0 ? bytes_order(r.hi) : w == 1 ? bytes_order(r.lo) : ~r.weight; }
+    __host__ __device__ static int bits2(int) { return 64; }
+    __device__ static bool same(const Row& a, const Row& b, uint32_t) { return a.lo == b.lo && a.hi == b.hi; }
+    __device__ static void add(Row& a, const Row& b) { a.weight = a.weight > b.weight ? a.weight : b.weight; }
+    __device__ static void finish(Row&, uint32_t) {}
+};
+template <>
+struct RowOps<RK_TOPK_SRC> : RowOpsTopk {};
+template <>
+struct RowOps<RK_TOPK_DST> : RowOpsTopk {};
+
+// key word w of every row, in the order idx gives (idx == nullptr: identity, which also initialises idx_out)
+template <int KIND, bool EMIT>
+__global__ void row_word_kernel(const typename RowOps<KIND>::Row* rows, const uint32_t* idx, uint32_t n, int w, uint32_t fold,
+                                unsigned long long* out, uint32_t* idx_out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t j = idx ? idx[i] : i;
+        if constexpr (EMIT) out[i] = RowOps<KIND>::key2(rows[j], w);
+        else out[i] = RowOps<KIND>::key(rows[j], w, fold);
+        if (!idx) idx_out[i] = i;
+    }
+}
+// head flags of the sorted sequence
+template <int KIND>
+__global__ void row_heads_kernel(const typename RowOps<KIND>::Row* rows, const uint32_t* idx, uint32_t n, uint32_t fold, uint32_t* flags) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        flags[i] = (i == 0 || !RowOps<KIND>::same(rows[idx[i]], rows[idx[i - 1]], fold)) ? 1u : 0u;
+}
+// one thread per run: sum its rows, write the group's row
+template <int KIND>
+__global__ void row_reduce_kernel(const typename RowOps<KIND>::Row* rows, const uint32_t* idx, const uint32_t* flags, const uint32_t* pos,
+                                  uint32_t n, uint32_t fold, typename RowOps<KIND>::Row* out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (!flags[i]) continue;
+        typename RowOps<KIND>::Row acc = rows[idx[i]];
+        for (uint32_t j = i + 1; j < n && !flags[j]; j++) RowOps<KIND>::add(acc, rows[idx[j]]);
+        RowOps<KIND>::finish(acc, fold);
+        out[pos[i]] = acc;
+    }
+}
+template <class Row>
+__global__ void row_gather_kernel(const Row* src, const uint32_t* idx, uint32_t n, Row* dst) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+
+// ---- public-format rows out of the device state ------------------------------------------------------------------
+// wide-table rows (packed keys) -> fa_row_app, in place (both 56 bytes; every thread rewrites its own element)
+__global__ void wrows_to_app_kernel(WRow* rows, uint32_t n, uint32_t gran) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const WRow r = rows[i];
+        uint32_t kind, tb, port, proto;
+        uint64_t lo, hi;
+        wkey_unpack(r.w, kind, tb, lo, hi, port, proto);
+        RowApp o;
+        o.timeslot = tb * gran;
+        o.date = o.timeslot / 86400u;
+        o.addr[0] = (uint32_t)lo;
+        o.addr[1] = (uint32_t)(lo >> 32);
+        o.addr[2] = (uint32_t)hi;
+        o.addr[3] = (uint32_t)(hi >> 32);
+        o.dst_port = port;
+        o.proto = proto;
+        o.bytes = r.v0;
+        o.packets = r.v1;
+        o.count = r.v2;
+        *reinterpret_cast<RowApp*>(&rows[i]) = o;
+    }
+}
+// wide-table rows of a port / minute kind -> {key, weight, count}; scale: 1 for ports, 60 for minutes
+__global__ void wrows_to_w_kernel(const WRow* rows, uint32_t n, uint32_t scale, RowW* out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t kind, tb, port, proto;
+        uint64_t lo, hi;
+        wkey_unpack(rows[i].w, kind, tb, lo, hi, port, proto);
+        out[i] = RowW{port * scale, 0u, rows[i].v0, rows[i].v2};
+    }
+}
+// the dense port histogram's occupied entries, appended behind `base` rows (count in *n_out, starts at base)
+__global__ void port_dense_rows_kernel(const ulonglong2* hist, uint32_t nports, RowW* out, unsigned int* n_out) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < nports; p += gridDim.x * blockDim.x) {
+        const ulonglong2 e = hist[p];
+        if (e.y) out[atomicAdd(n_out, 1u)] = RowW{p, 0u, e.x, e.y};
+    }
+}
+
+// rows gathered from other ranks are checked before they are trusted: a timeslot off this ctx's bucket grid would be
+// folded into the wrong bucket silently
+__global__ void rows5m_check_kernel(const Row5m* rows, uint32_t n, uint32_t gran, unsigned int* bad) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (rows[i].timeslot % gran) atomicAdd(bad, 1u);
+}
+
+}  // namespace fa

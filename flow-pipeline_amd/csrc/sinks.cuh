@@ -318,6 +318,7 @@ __device__ __forceinline__ void cms_bins_flush(const KArgs& a, CmsLds& cl, uint3
                 a.cseg[(size_t)fp * a.cregion + (size_t)blockIdx.x * a.ccapq + chunk * CMS_BIN + sub] = tv;
             } else {
                 cms_atomic_tuple(a, fp, tv);
+                if (sub == 0) atomicSub(&cl.part_cnt[fp], 1u);  // (the chunk was not stored: the 16-bit counter stays <= its cap, never carries)
             }
             if (sub == 0) __hip_atomic_store(&cl.bin_cnt[fp], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -372,8 +373,12 @@ __device__ __forceinline__ void cms_scatter(const KArgs& a, CmsLds& cl, uint32_t
             if (slot == CMS_BIN - 1) fill = p;
         } else {  // the bin is on its way out: single store to the back part of the segment
             const uint32_t ob = atomicAdd(&cl.part_cnt[p], 0x10000u) >> 16;
-            if (ob < a.ccapb) a.cseg[(size_t)p * a.cregion + (size_t)blockIdx.x * a.ccapq + (a.ccapq - 1u - ob)] = t;
-            else cms_atomic_tuple(a, p, t);
+            if (ob < a.ccapb) {
+                a.cseg[(size_t)p * a.cregion + (size_t)blockIdx.x * a.ccapq + (a.ccapq - 1u - ob)] = t;
+            } else {
+                cms_atomic_tuple(a, p, t);
+                atomicSub(&cl.part_cnt[p], 0x10000u);  // (not stored: the back count never wraps into stored tuples)
+            }
         }
     }
     cms_bins_flush(a, cl, list, fill);
@@ -822,6 +827,7 @@ __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t
                     agg_global(a, q0, q1, key_hash(q0, q1), v[e].bytes, v[e].packets, 1);
                     n_direct++;
                 }
+                if (sub == 0) atomicSub(&part_cnt[fp], 1u);  // (the line was not stored: the 16-bit counter stays <= its cap)
             }
             // (release: behind the tuple reads above)
             if (sub == 0) __hip_atomic_store(&bin_cnt[fp], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -118,88 +118,109 @@ def allgather_struct(rows: np.ndarray, dtype, group=None, device=None):
     return [b.view(dtype).copy() for b in allgather_bytes(rows.view(np.uint8).reshape(-1), group=group, device=device)]
 
 
-def close_window_app_merged(agg, timeslot, group=None, device=None) -> np.ndarray:
-    """Window close of the (SrcAddr,DstPort,Proto) key set across ranks (identical result on every rank)."""
-    local = agg.close_window_app(timeslot)
-    return merge_rows_app_host(allgather_struct(local, ROW_APP_DTYPE, group=group, device=device))
+class _DevArray:
+    """Minimal __cuda_array_interface__ view of library-owned HBM."""
+
+    def __init__(self, ptr: int, n: int, typestr: str = "<i8"):
+        self.__cuda_array_interface__ = {
+            "shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
 
 
-def top_ports_merged(agg, dst, k=None, group=None, device=None) -> np.ndarray:
-    rows = merge_ports_host(allgather_struct(agg.top_ports(dst), PORT_ROW_DTYPE, group=group, device=device))
-    return rows if k is None else rows[:k]
-
-
-def minute_series_merged(agg, group=None, device=None) -> np.ndarray:
-    return merge_minutes_host(allgather_struct(agg.minute_series(), MINUTE_ROW_DTYPE, group=group, device=device))
-
-
-def allgather_rows(rows: np.ndarray, group=None, device=None):
-    """All ranks receive every rank's rows (list indexed by rank)."""
+def allgather_device_rows(ptr: int, n: int, row_bytes: int, group=None):
+    """Every rank's n rows (row_bytes each, sitting in HBM at ptr) back to back in ONE device buffer on every rank.
+    -> (uint8 cuda tensor, total rows).  Counts travel first; the payload is gathered into slices of the destination
+    buffer - no padding to the largest rank, no host copy of the rows.  `nccl`: RCCL moves HBM to HBM (uneven
+    all_gather).  Any other backend (gloo: two ranks sharing the one GPU of a test box) only replaces the transport:
+    rows are staged through host memory for the collective and land in the same device buffer."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    dev = torch.device(device) if device is not None else torch.device("cpu")
-    rows = np.ascontiguousarray(rows, dtype=ROW5M_DTYPE)
-    n = torch.tensor([len(rows)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
+    on_device = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xdev = dev if on_device else torch.device("cpu")
+    cnt = torch.tensor([n], dtype=torch.int64, device=xdev)
+    counts = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
     counts = [int(c.item()) for c in counts]
-    cap = max(max(counts), 1)
-    mine = torch.zeros(cap * ROW5M_DTYPE.itemsize, dtype=torch.uint8)
-    if len(rows):
-        mine[:rows.nbytes] = torch.from_numpy(rows.view(np.uint8).reshape(-1))
-    mine = mine.to(dev)
-    bufs = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(bufs, mine, group=group)
-    out = []
-    for c, b in zip(counts, bufs):
-        a = b.cpu().numpy()[:c * ROW5M_DTYPE.itemsize]
-        out.append(a.view(ROW5M_DTYPE).copy())
-    return out
+    total = sum(counts)
+    out = torch.empty(max(total, 1) * row_bytes, dtype=torch.uint8, device=dev)
+    mine = (torch.as_tensor(_DevArray(ptr, n * row_bytes, "|u1"), device=dev) if n
+            else torch.empty(0, dtype=torch.uint8, device=dev))
+    if total == 0:
+        return out[:0], 0
+    starts = np.concatenate([[0], np.cumsum(counts)]) * row_bytes
+    if on_device:
+        # all-gather with uneven counts = one broadcast per rank into that rank's slice of the destination (queued
+        # together on the RCCL stream; what ProcessGroupNCCL itself does for uneven all_gather outputs)
+        rank = dist.get_rank(group)
+        work = []
+        for r in range(world):
+            if not counts[r]:
+                continue
+            sl = out[int(starts[r]):int(starts[r + 1])]
+            if r == rank:
+                sl.copy_(mine)
+            src = r if group is None else dist.get_global_rank(group, r)
+            work.append(dist.broadcast(sl, src=src, group=group, async_op=True))
+        for w in work:
+            w.wait()
+    else:
+        h = mine.cpu()
+        cap = max(counts) * row_bytes
+        pad = torch.zeros(cap, dtype=torch.uint8)
+        pad[:h.numel()] = h
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+        for r in range(world):
+            if counts[r]:
+                out[int(starts[r]):int(starts[r + 1])].copy_(bufs[r][:counts[r] * row_bytes])
+    torch.cuda.synchronize()
+    return out[:total * row_bytes], total
+
+
+def rows_merged(agg, kind, timeslot=0xFFFFFFFF, k_local=0, k=0, group=None) -> np.ndarray:
+    """One kind of rows merged across ranks at window close, identical on every rank: fa_rows_device (this rank's
+    result in HBM: extracted, sub-buckets folded, sorted) -> all-gather of the device buffers -> fa_rows_merge_device
+    (radix sort + segmented sums in HBM, emit order) -> one copy of the result to the host."""
+    from . import ROW_DTYPES
+    ptr, n = agg.rows_device(kind, timeslot, k_local)
+    buf, total = allgather_device_rows(ptr, n, ROW_DTYPES[kind].itemsize, group=group)
+    mptr, m = agg.rows_merge_device(kind, buf.data_ptr(), total, k)
+    return agg.rows_fetch(kind, mptr, m)
 
 
 def close_window_merged(agg, timeslot, group=None, device=None) -> np.ndarray:
-    """Window close across ranks; every rank returns the same merged flows_5m rows.
-
-    `nccl`: device side - every rank's rows of the window are compacted and sorted in HBM
-    (fa_window_rows_device), all-gathered over RCCL straight out of / into device memory, the other ranks' rows
-    are folded into the rank's own table by a kernel (fa_merge_rows_device) and the merged window leaves through
-    the ordinary device-sorted close.  No host sort, no Python re-aggregation.
-    Other backends (gloo on CPU tensors: the harness tests): rows travel through host memory, merged with numpy."""
-    import torch
-    import torch.distributed as dist
-    # (sliding windows keep the newer sub-buckets in the table after a close: folding other ranks' rows into it would
-    # count them again at the next close - those closes take the host path as well)
-    sliding = agg.cfg.subwindow_secs not in (0, agg.cfg.window_secs) and timeslot != 0xFFFFFFFF
-    if dist.get_backend(group) != "nccl" or sliding:
-        local = agg.close_window(timeslot)
-        return merge_rows_host(allgather_rows(local, group=group, device=device))
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    ptr, n = agg.window_rows_device(timeslot)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    cnt = torch.tensor([n], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, cnt, group=group)
-    counts = [int(c.item()) for c in counts]
-    words = max(max(counts), 1) * (ROW5M_DTYPE.itemsize // 8)
-    mine = torch.zeros(words, dtype=torch.int64, device=dev)
-    if n:
-        mine[:n * (ROW5M_DTYPE.itemsize // 8)].copy_(torch.as_tensor(_DevArray(ptr, n * (ROW5M_DTYPE.itemsize // 8)), device="cuda"))
-    bufs = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(bufs, mine, group=group)
-    torch.cuda.synchronize()
-    for r in range(world):
-        if r != rank and counts[r]:
-            agg.merge_rows_device(bufs[r].data_ptr(), counts[r])
-    return agg.close_window(timeslot)
+    """Window close across ranks; every rank returns the same merged flows_5m rows and drops the window from its
+    table (sliding windows: the oldest sub-bucket, like fa_close_window).  The ranks' own tables are never mixed, so
+    sliding windows take the same path as tumbling ones."""
+    from . import ROWS_5M
+    rows = rows_merged(agg, ROWS_5M, timeslot, group=group)
+    agg.drop_window(ROWS_5M, timeslot)
+    return rows
 
 
-class _DevArray:
-    """Minimal __cuda_array_interface__ view of library-owned HBM (int64 words)."""
+def close_window_app_merged(agg, timeslot, group=None, device=None) -> np.ndarray:
+    """Window close of the (SrcAddr,DstPort,Proto) key set across ranks (identical result on every rank)."""
+    from . import ROWS_APP
+    rows = rows_merged(agg, ROWS_APP, timeslot, group=group)
+    agg.drop_window(ROWS_APP, timeslot)
+    return rows
 
-    def __init__(self, ptr: int, words: int):
-        self.__cuda_array_interface__ = {
-            "shape": (words,), "typestr": "<i8", "data": (ptr, False), "version": 2, "strides": None}
+
+def top_ports_merged(agg, dst, k=None, group=None, device=None) -> np.ndarray:
+    """GROUP BY port across ranks (every rank's port rows travel: a port just below the cut everywhere can lead overall)."""
+    from . import ROWS_PORT_DST, ROWS_PORT_SRC
+    return rows_merged(agg, ROWS_PORT_DST if dst else ROWS_PORT_SRC, k_local=0, k=0 if k is None else max(int(k), 1), group=group)[:k]
+
+
+def minute_series_merged(agg, group=None, device=None) -> np.ndarray:
+    from . import ROWS_MINUTE
+    return rows_merged(agg, ROWS_MINUTE, group=group)
+
+
+def allgather_rows(rows: np.ndarray, group=None, device=None):
+    """All ranks receive every rank's rows (list indexed by rank) - host rows (tests, oracle rows in bench.py)."""
+    return allgather_struct(rows, ROW5M_DTYPE, group=group, device=device)
 
 
 def allreduce_sketches(agg, group=None):
@@ -246,23 +267,15 @@ def allgather_bytes(arr: np.ndarray, group=None, device=None):
     return [b.cpu().numpy()[:c].copy() for c, b in zip(counts, bufs)]
 
 
-def merge_topk_candidates(parts, k_keep=None) -> np.ndarray:
-    """Union of per-rank candidate keys (uint8[n,16] each), duplicates removed, sorted."""
-    keys = [np.ascontiguousarray(p, dtype=np.uint8).reshape(-1, 16) for p in parts if len(p)]
-    if not keys:
-        return np.zeros((0, 16), dtype=np.uint8)
-    allk = np.unique(np.concatenate(keys).view([("k", "u1", 16)]).reshape(-1))
-    return allk.view(np.uint8).reshape(-1, 16)
-
-
 def topk_merged(agg, key_set, k, candidates_per_rank=None, group=None, device=None):
-    """Heavy hitters across ranks at window close: all-reduce the sketches (dense, exact), exchange
-    every rank's local candidates (its top `candidates_per_rank` keys; all distinct keys when None),
-    add the union to the local set and rank by the merged estimate.  With candidates_per_rank=None
-    the result equals the single-GPU result bit for bit."""
-    ncand = candidates_per_rank if candidates_per_rank is not None else (1 << 30)
-    local = agg.topk(key_set, ncand)
+    """Heavy hitters across ranks at window close, exact with respect to the merged sketch: all-reduce the sketches
+    (dense, RCCL) into the merged view, then every rank ranks ITS distinct addresses by the merged estimate and sends
+    its first k rows; the merged top k is the top k of their union.  (A key of the global top k ranks at least as high
+    among the keys of any rank that saw it - and the merged estimate of a key is the same on every rank - so it is in
+    that rank's k rows.  Round 2 exchanged every distinct key: 16 M per rank, 95 s over host memory.)
+    candidates_per_rank is kept for callers of the old interface; values below k would make the result approximate
+    and are raised to k."""
+    from . import FA_KEYS_SRCADDR_CMS, ROWS_TOPK_DST, ROWS_TOPK_SRC
     allreduce_sketches(agg, group=group)
-    parts = allgather_bytes(local["key"], group=group, device=device)
-    agg.topk_merge_keys(key_set, merge_topk_candidates(parts))
-    return agg.topk(key_set, k)
+    kind = ROWS_TOPK_SRC if key_set == FA_KEYS_SRCADDR_CMS else ROWS_TOPK_DST
+    return rows_merged(agg, kind, k_local=max(int(k), 1), k=max(int(k), 1), group=group)[:k]

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 4
+#define FA_ABI_VERSION 5
 
 typedef struct fa_ctx fa_ctx;
 
@@ -205,6 +205,40 @@ int fa_read_window(fa_ctx*, uint32_t timeslot, fa_row5m* out, size_t cap, size_t
 int fa_window_rows_device(fa_ctx*, uint32_t timeslot, const void** d_rows, size_t* n_out);
 /* Adds n rows that sit in HBM (another rank's fa_window_rows_device, gathered over RCCL) to this ctx's table. */
 int fa_merge_rows_device(fa_ctx*, const void* d_rows, size_t n);
+
+/* ---- ABI 5: device-resident window close (every read above is built from these two steps) ------------------------
+ * Row kinds and their emit order (what the matching read call returns):
+ *   FA_ROWS_5M        fa_row5m      ORDER BY date, timeslot, src_as, dst_as, etype          (fa_read_window)
+ *   FA_ROWS_APP       fa_row_app    ORDER BY date, timeslot, src_addr bytes, dst_port, proto (fa_read_window_app)
+ *   FA_ROWS_PORT_SRC / _DST  fa_port_row   ORDER BY weight DESC, port                       (fa_top_ports; viz-ch.json:358,604)
+ *   FA_ROWS_MINUTE    fa_minute_row ORDER BY minute                                         (fa_minute_series; viz-ch.json:74)
+ *   FA_ROWS_TOPK_SRC / _DST  fa_topk_row   ORDER BY weight DESC, key bytes                  (fa_topk; viz-ch.json:233,479)
+ * Multi-GPU window close (one ctx per GPU / Kafka partition, inserter.go:176): every rank calls fa_rows_device,
+ * the ranks all-gather the device buffers over RCCL (counts first, no padding), every rank calls
+ * fa_rows_merge_device on the concatenation - sum is a commutative monoid, so the result equals the single-ctx
+ * result bit for bit (SummingMergeTree collapse, create.sh:70-90) - and fa_drop_window removes what was closed. */
+enum {
+    FA_ROWS_5M = 0, FA_ROWS_APP = 1, FA_ROWS_PORT_SRC = 2, FA_ROWS_PORT_DST = 3, FA_ROWS_MINUTE = 4,
+    FA_ROWS_TOPK_SRC = 5, FA_ROWS_TOPK_DST = 6
+};
+size_t fa_row_bytes(int kind); /* bytes of one row of the kind; 0 for an unknown kind */
+/* This ctx's result for (kind, timeslot) exactly as the matching read call would return it - the sub-buckets of a
+ * sliding window folded, rows in emit order, cut after k rows (k = 0: all; timeslot is ignored by the kinds that
+ * are not windowed) - left in HBM.  *d_rows: DEVICE pointer to *n_out rows, owned by the ctx, valid until its next
+ * call.  Nothing is removed.  For FA_ROWS_TOPK_* after fa_merge_allreduce / fa_merged_view_set(1) the estimates come
+ * from the merged sketch: the union of every rank's k rows then contains the global top k (a key of the global top k
+ * ranks at least as high among the keys of any rank that saw it). */
+int fa_rows_device(fa_ctx*, int kind, uint32_t timeslot, size_t k, const void** d_rows, size_t* n_out);
+/* Merges n rows of `kind` sitting in HBM (several ranks' fa_rows_device results back to back, any order): rows with
+ * equal keys are summed (top-k rows: kept once), the result is put into emit order and cut after k rows (0: all).
+ * *d_out: DEVICE pointer to *n_out rows, owned by the ctx, valid until its next call.  The ctx's own state is not
+ * touched.  FA_ROWS_5M rows must lie on this ctx's bucket grid (FA_ERR_ARG otherwise). */
+int fa_rows_merge_device(fa_ctx*, int kind, const void* d_rows, size_t n, size_t k, const void** d_out, size_t* n_out);
+/* Copies n rows of `kind` from HBM into the caller's host buffer (cap in rows). */
+int fa_rows_fetch(fa_ctx*, int kind, const void* d_rows, size_t n, void* out, size_t cap);
+/* Removes what fa_close_window / fa_close_window_app would remove after emitting `timeslot` (kind FA_ROWS_5M or
+ * FA_ROWS_APP): the whole window for tumbling windows and close-all, the oldest sub-bucket when windows slide. */
+int fa_drop_window(fa_ctx*, int kind, uint32_t timeslot);
 
 /* ---- bulk-load sink: flows_5m rows as ClickHouse RowBinary ------------------- */
 /* Serialises rows for `INSERT INTO flows_5m FORMAT RowBinary` with the column list of

@@ -74,10 +74,27 @@ def _worker(rank, world, port, q):
     ts = torch.from_numpy(mysk.view(np.int64))
     dist.all_reduce(ts, op=dist.ReduceOp.SUM)
     ok = ok and mysk.tobytes() == po.cms_sketch_numpy(rows["src_addr"][good], w[good], 4, 12, 7).tobytes()
-    mykeys = np.unique(np.ascontiguousarray(rows["src_addr"][sel & good]).view([("k", "u1", 16)]).reshape(-1)).view(np.uint8).reshape(-1, 16)
-    union = d.merge_topk_candidates(d.allgather_bytes(mykeys, device="cpu"))
-    allkeys = np.unique(np.ascontiguousarray(rows["src_addr"][good]).view([("k", "u1", 16)]).reshape(-1)).view(np.uint8).reshape(-1, 16)
-    ok = ok and union.tobytes() == allkeys.tobytes() and len(union) > len(mykeys)
+    # dist.topk_merged's exchange: every rank ranks ITS distinct keys by the MERGED sketch and sends its first k rows;
+    # the top k of the union == the top k over every distinct key of the whole stream (ties: key bytes ascending)
+    def estimates(keys16):
+        cols = [po.cms_sketch_numpy(keys16[i:i + 1], np.ones(1, dtype=np.uint64), 4, 12, 7).reshape(4, -1).argmax(axis=1) for i in range(len(keys16))]
+        sk = mysk.reshape(4, -1)
+        return np.array([min(int(sk[r, c[r]]) for r in range(4)) for c in cols], dtype=np.uint64)
+
+    def topk(keys16, k):
+        est = estimates(keys16)
+        order = sorted(range(len(keys16)), key=lambda i: (-int(est[i]), bytes(keys16[i])))[:k]
+        return [(bytes(keys16[i]), int(est[i])) for i in order]
+
+    def uniq(a):
+        return np.unique(np.ascontiguousarray(a).view([("k", "u1", 16)]).reshape(-1)).view(np.uint8).reshape(-1, 16)
+    k = 25
+    mykeys = uniq(rows["src_addr"][sel & good])
+    mine_top = topk(mykeys, k)
+    sent = np.array([list(x[0]) for x in mine_top], dtype=np.uint8).reshape(-1, 16)
+    union = uniq(np.concatenate(d.allgather_bytes(sent, device="cpu")).reshape(-1, 16))
+    allkeys = uniq(rows["src_addr"][good])
+    ok = ok and topk(union, k) == topk(allkeys, k) and len(allkeys) > len(mykeys) > k
     q.put((rank, ok, len(merged), len(mine)))
     dist.destroy_process_group()
 

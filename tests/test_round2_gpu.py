@@ -347,6 +347,17 @@ with fa.FlowAgg(**kw) as agg, fa.FlowAgg(**kw) as whole:
     assert fa.dist.minute_series_merged(agg, device=dev).tobytes() == whole.minute_series().tobytes()
     assert fa.dist.close_window_app_merged(agg, fa.ALL_TIMESLOTS, device=dev).tobytes() == whole.close_window_app().tobytes()
     assert fa.dist.close_window_merged(agg, fa.ALL_TIMESLOTS, device=dev).tobytes() == whole.close_window().tobytes()
+# sliding windows over 60-s sub-buckets across ranks: the same device path (round 2 sent these through host memory)
+kw2 = dict(framed=True, key_sets=9, subwindow_secs=60)
+with fa.FlowAgg(**kw2) as agg, fa.FlowAgg(**kw2) as whole:
+    b, o = shard(fa.dist.partitions_of(rank, world, nparts))
+    agg.ingest(b, o)
+    whole.ingest(buf, off)
+    ts = int(whole.open_timeslots()[0])
+    for t in (ts, ts + 60, ts + 120):
+        assert fa.dist.close_window_merged(agg, t).tobytes() == whole.close_window(t).tobytes(), t
+        assert fa.dist.close_window_app_merged(agg, t).tobytes() == whole.close_window_app(t).tobytes(), t
+    assert fa.dist.close_window_merged(agg, fa.ALL_TIMESLOTS).tobytes() == whole.close_window().tobytes()
 dist.destroy_process_group()
 print("TWO_RANK_OK", rank)
 '''

@@ -1,0 +1,236 @@
+"""Round-3 GPU tests: the device-resident window close (ABI 5: fa_rows_device / fa_rows_merge_device / fa_drop_window).
+
+Two ctxs on the one GPU stand for two ranks: each ingests half of the Kafka partitions, their device row buffers are
+concatenated in HBM (what the RCCL all-gather leaves on every rank) and merged by the library's kernels - every row
+kind, tumbling and sliding windows - against a ctx that ingested everything and against the oracle.  The transport
+(nccl world 1, gloo with two processes) is covered in test_dist_nccl_gpu.py / test_round2_gpu.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _shards(po, n, seed, nparts=8, zipf_log2=14):
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=seed, n_total=n, zipf_log2_universe=zipf_log2, span_secs=900)
+    buf, off = po.gen_records(gp, 0, n)
+    raw = bytes(buf)
+
+    def shard(parts):
+        idx = np.concatenate([np.arange(p, n, nparts) for p in parts])
+        idx.sort()
+        recs = [raw[int(off[k]):int(off[k + 1])] for k in idx]
+        o = np.zeros(len(recs) + 1, dtype=np.uint64)
+        o[1:] = np.cumsum([len(r) for r in recs])
+        return np.frombuffer(b"".join(recs), dtype=np.uint8), o
+    return buf, off, shard(range(0, nparts, 2)), shard(range(1, nparts, 2))
+
+
+def _cat_device(fa, torch, ctxs, kind, timeslot, k=0):
+    """every ctx's fa_rows_device result, back to back in one device buffer (the all-gather's destination)"""
+    rb = fa.ROW_DTYPES[kind].itemsize
+    parts = []
+    for c in ctxs:
+        ptr, n = c.rows_device(kind, timeslot, k)
+        if n:
+            parts.append(torch.as_tensor(fa.dist._DevArray(ptr, n * rb, "|u1"), device="cuda").clone())
+    if not parts:
+        return torch.empty(0, dtype=torch.uint8, device="cuda"), 0
+    buf = torch.cat(parts)
+    return buf, buf.numel() // rb
+
+
+@pytest.mark.parametrize("sub", [0, 60])
+def test_device_merge_of_two_ctxs_equals_single_ctx(gpu_lib, fa, po, sub):
+    import torch
+    n = 300_000
+    buf, off, (b0, o0), (b1, o1) = _shards(po, n, seed=91)
+    kw = dict(framed=True, key_sets=63, cms_width_log2=14, topk_capacity_log2=16, subwindow_secs=sub)
+    with fa.FlowAgg(**kw) as a0, fa.FlowAgg(**kw) as a1, fa.FlowAgg(**kw) as whole:
+        a0.ingest(b0, o0)
+        a1.ingest(b1, o1)
+        whole.ingest(buf, off)
+        slots = whole.open_timeslots()
+        windows = [fa.ALL_TIMESLOTS, int(slots[0])] + ([int(slots[0]) + 60, int(slots[0]) + 240] if sub else [int(slots[0]) + 300])
+        for ts in windows:
+            for kind, read in ((fa.ROWS_5M, whole.read_window), (fa.ROWS_APP, whole.read_window_app)):
+                dbuf, tot = _cat_device(fa, torch, (a0, a1), kind, ts)
+                ptr, m = a0.rows_merge_device(kind, dbuf.data_ptr(), tot)
+                got = a0.rows_fetch(kind, ptr, m)
+                want = read(ts)
+                assert len(want) > 0 and got.tobytes() == want.tobytes(), (kind, ts, len(got), len(want))
+        for kind, want in ((fa.ROWS_PORT_SRC, whole.top_ports(0)), (fa.ROWS_PORT_DST, whole.top_ports(1)), (fa.ROWS_MINUTE, whole.minute_series())):
+            dbuf, tot = _cat_device(fa, torch, (a0, a1), kind, 0)
+            ptr, m = a1.rows_merge_device(kind, dbuf.data_ptr(), tot)
+            assert a1.rows_fetch(kind, ptr, m).tobytes() == want.tobytes(), kind
+        # the oracle's word on the merged flows_5m rows and the (SrcAddr,DstPort,Proto) rows of the whole stream
+        ref = po.Rollup(sub or 300)
+        ref.ingest(buf, off, 1)
+        dbuf, tot = _cat_device(fa, torch, (a0, a1), fa.ROWS_5M, fa.ALL_TIMESLOTS)
+        ptr, m = a0.rows_merge_device(fa.ROWS_5M, dbuf.data_ptr(), tot)
+        assert a0.rows_fetch(fa.ROWS_5M, ptr, m).tobytes() == ref.rows().tobytes()
+        rows, status = po.decode_batch(buf, off, 1)
+        dbuf, tot = _cat_device(fa, torch, (a0, a1), fa.ROWS_APP, fa.ALL_TIMESLOTS)
+        ptr, m = a0.rows_merge_device(fa.ROWS_APP, dbuf.data_ptr(), tot)
+        assert a0.rows_fetch(fa.ROWS_APP, ptr, m).tobytes() == po.rollup_app(rows, status, sub or 300).astype(fa.ROW_APP_DTYPE).tobytes()
+        # heavy hitters: merged sketch view on both (the all-reduce's result), each ctx's first k rows, merged
+        for key_set, kind in ((fa.FA_KEYS_SRCADDR_CMS, fa.ROWS_TOPK_SRC), (fa.FA_KEYS_DSTADDR_CMS, fa.ROWS_TOPK_DST)):
+            for c in (a0, a1):
+                st = c.device_state()
+                for own, merged, wh in ((st.cms_src, st.cms_src_merged, whole.device_state().cms_src), (st.cms_dst, st.cms_dst_merged, whole.device_state().cms_dst)):
+                    t = torch.as_tensor(fa.dist._DevArray(merged, st.cms_words), device="cuda")
+                    t.copy_(torch.as_tensor(fa.dist._DevArray(wh, st.cms_words), device="cuda"))  # = sum over the two shards (checked below)
+                c.merged_view_set(True)
+            assert np.array_equal(a0.cms_read(key_set), whole.cms_read(key_set))
+            k = 60
+            dbuf, tot = _cat_device(fa, torch, (a0, a1), kind, 0, k)
+            assert tot == 2 * k
+            ptr, m = a0.rows_merge_device(kind, dbuf.data_ptr(), tot, k)
+            assert a0.rows_fetch(kind, ptr, m).tobytes() == whole.topk(key_set, k).tobytes()
+            for c in (a0, a1):
+                c.merged_view_set(False)
+        # the shards' own sketches do add up to the whole stream's (what the RCCL all-reduce computes)
+        for key_set in (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS):
+            with np.errstate(over="ignore"):
+                assert np.array_equal(a0.cms_read(key_set) + a1.cms_read(key_set), whole.cms_read(key_set))
+        # drop_window removes what a close removes: afterwards the merged remainder == the single ctx after its close
+        ts = int(slots[0])
+        whole.close_window(ts)
+        whole.close_window_app(ts)
+        for c in (a0, a1):
+            c.drop_window(fa.ROWS_5M, ts)
+            c.drop_window(fa.ROWS_APP, ts)
+        for kind, read in ((fa.ROWS_5M, whole.read_window), (fa.ROWS_APP, whole.read_window_app)):
+            dbuf, tot = _cat_device(fa, torch, (a0, a1), kind, fa.ALL_TIMESLOTS)
+            ptr, m = a1.rows_merge_device(kind, dbuf.data_ptr(), tot)
+            assert a1.rows_fetch(kind, ptr, m).tobytes() == read(fa.ALL_TIMESLOTS).tobytes(), kind
+
+
+def test_merge_rows_device_between_two_ctxs(gpu_lib, fa, po):
+    """fa_window_rows_device of shard A folded into ctx B by fa_merge_rows_device (the ABI-4 exchange), tumbling
+    and sub-bucketed, == the oracle's rollup of the whole stream; rows off the bucket grid are refused."""
+    import torch
+    n = 200_000
+    buf, off, (b0, o0), (b1, o1) = _shards(po, n, seed=92)
+    for sub in (0, 60):
+        with fa.FlowAgg(framed=True, subwindow_secs=sub) as a0, fa.FlowAgg(framed=True, subwindow_secs=sub) as a1:
+            a0.ingest(b0, o0)
+            a1.ingest(b1, o1)
+            ptr, m = a0.window_rows_device(fa.ALL_TIMESLOTS)
+            mine = torch.as_tensor(fa.dist._DevArray(ptr, m * 48, "|u1"), device="cuda").clone()
+            a1.merge_rows_device(mine.data_ptr(), m)
+            ref = po.Rollup(sub or 300)
+            ref.ingest(buf, off, 1)
+            assert a1.close_window().tobytes() == ref.rows().tobytes()
+    with fa.FlowAgg(framed=True) as a:
+        bad = np.zeros(4, dtype=fa.ROW5M_DTYPE)
+        bad["timeslot"] = [300, 600, 601, 900]
+        bad["count"] = 1
+        t = torch.from_numpy(bad.view(np.uint8)).cuda()
+        with pytest.raises(fa.FlowAggError):
+            a.merge_rows_device(t.data_ptr(), 4)
+        with pytest.raises(fa.FlowAggError):
+            a.rows_merge_device(fa.ROWS_5M, t.data_ptr(), 4)
+        assert len(a.read_window()) == 0
+
+
+def test_rows_merge_device_random_rows_against_dict_groupby(gpu_lib, fa):
+    """fa_rows_merge_device on random row sets of every kind (duplicate keys, u64 wrap-around, address byte order, weight
+    ties) against a row-at-a-time dict group-by."""
+    import torch
+    rng = np.random.default_rng(7)
+    M = 2**64
+
+    def u64(n, big):
+        return rng.integers(0, 2**64 if big else 1000, n, dtype=np.uint64)
+    with fa.FlowAgg(framed=True, key_sets=63, cms_width_log2=10, topk_capacity_log2=10) as agg:
+        def merged(kind, rows, k=0):
+            t = torch.from_numpy(np.ascontiguousarray(rows).view(np.uint8).reshape(-1).copy()).cuda()
+            ptr, m = agg.rows_merge_device(kind, t.data_ptr(), len(rows), k)
+            return agg.rows_fetch(kind, ptr, m)
+        for trial in range(6):
+            big = trial % 2 == 0
+            n = int(rng.integers(1, 5000))
+            r = np.zeros(n, dtype=fa.ROW5M_DTYPE)
+            r["timeslot"] = rng.integers(0, 3, n) * 300 + 86400 * rng.integers(0, 2, n)
+            r["date"] = r["timeslot"] // 86400
+            r["src_as"], r["dst_as"] = rng.integers(0, 5, n), rng.choice([0, 7, 2**31, 2**32 - 1], n)
+            r["etype"] = rng.choice([0x800, 0x86dd], n)
+            r["bytes"], r["packets"], r["count"] = u64(n, big), u64(n, big), u64(n, False)
+            ref = {}
+            for x in r:
+                key = (int(x["date"]), int(x["timeslot"]), int(x["src_as"]), int(x["dst_as"]), int(x["etype"]))
+                b, p, c = ref.get(key, (0, 0, 0))
+                ref[key] = ((b + int(x["bytes"])) % M, (p + int(x["packets"])) % M, (c + int(x["count"])) % M)
+            got = merged(fa.ROWS_5M, r)
+            assert [(int(x["date"]), int(x["timeslot"]), int(x["src_as"]), int(x["dst_as"]), int(x["etype"])) for x in got] == sorted(ref)
+            assert [(int(x["bytes"]), int(x["packets"]), int(x["count"])) for x in got] == [ref[key] for key in sorted(ref)]
+            r = np.zeros(n, dtype=fa.ROW_APP_DTYPE)
+            r["timeslot"] = rng.integers(0, 2, n) * 300
+            r["src_addr"] = rng.integers(0, 2, (n, 16)) * rng.integers(1, 256, (n, 16))
+            r["src_addr"][:, 2:7] = 0
+            r["src_addr"][:, 9:15] = 0
+            r["dst_port"], r["proto"] = rng.integers(0, 3, n), rng.integers(0, 2, n)
+            r["bytes"], r["packets"], r["count"] = u64(n, big), u64(n, big), u64(n, False)
+            ref = {}
+            for x in r:
+                key = (int(x["date"]), int(x["timeslot"]), bytes(x["src_addr"]), int(x["dst_port"]), int(x["proto"]))
+                b, p, c = ref.get(key, (0, 0, 0))
+                ref[key] = ((b + int(x["bytes"])) % M, (p + int(x["packets"])) % M, (c + int(x["count"])) % M)
+            got = merged(fa.ROWS_APP, r)
+            assert [(int(x["date"]), int(x["timeslot"]), bytes(x["src_addr"]), int(x["dst_port"]), int(x["proto"])) for x in got] == sorted(ref)
+            assert [(int(x["bytes"]), int(x["packets"]), int(x["count"])) for x in got] == [ref[key] for key in sorted(ref)]
+            for kind, dtype, key in ((fa.ROWS_PORT_DST, fa.PORT_ROW_DTYPE, "port"), (fa.ROWS_MINUTE, fa.MINUTE_ROW_DTYPE, "minute")):
+                r = np.zeros(n, dtype=dtype)
+                r[key] = rng.choice([0, 1, 5, 65535, 65536, 2**32 - 1], n) if key == "port" else rng.integers(0, 12, n) * 60
+                r["weight"], r["count"] = u64(n, big) if trial else np.uint64(3), u64(n, False)
+                ref = {}
+                for x in r:
+                    w, c = ref.get(int(x[key]), (0, 0))
+                    ref[int(x[key])] = ((w + int(x["weight"])) % M, (c + int(x["count"])) % M)
+                order = sorted(ref, key=(lambda q: (-ref[q][0], q)) if key == "port" else (lambda q: q))
+                got = merged(kind, r)
+                assert [int(x[key]) for x in got] == order
+                assert [(int(x["weight"]), int(x["count"])) for x in got] == [ref[q] for q in order]
+                if key == "port":
+                    assert merged(kind, r, 3).tobytes() == got[:3].tobytes()
+            r = np.zeros(n, dtype=fa.TOPK_DTYPE)
+            keys = rng.integers(0, 256, (40, 16)).astype(np.uint8)
+            keys[:, 1:15] = 0
+            pick = rng.integers(0, 40, n)
+            r["key"] = keys[pick]
+            wts = rng.integers(0, 4, 40).astype(np.uint64)  # the same key carries the same estimate everywhere; ties between keys
+            r["weight"] = wts[pick]
+            ref = {bytes(keys[i]): int(wts[i]) for i in set(pick.tolist())}
+            order = sorted(ref, key=lambda q: (-ref[q], q))
+            got = merged(fa.ROWS_TOPK_SRC, r, 25)
+            assert [bytes(x["key"]) for x in got] == order[:25] and [int(x["weight"]) for x in got] == [ref[q] for q in order[:25]]
+
+
+def test_count_min_scatter_sink_segment_overflow_is_bit_exact(gpu_lib, fa, po, monkeypatch):
+    """the Count-Min scatter sink with segments far too small (FA_SEG_CAP now also caps the sketch
+    segments): full front parts send chunks to the atomic fallback, full back parts single tuples, the end-of-kernel
+    drain too - and the position counters stay at their caps (taken back when nothing was stored).  Counter for counter
+    the CPU sketch."""
+    import torch
+    monkeypatch.setenv("FA_SEG_CAP", "40")
+    n = 1_000_000
+    gp = po.gen_params(mode=2, framed=1, seed=35, n_total=n, zipf_log2_universe=18, zipf_s_x100=110)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    with np.errstate(over="ignore"):
+        w = rows["bytes"] * rows["sampling_rate"]
+    seed = 0xBEEF
+    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=4, cms_width_log2=16, cms_seed=seed, topk_capacity_log2=20, max_batch_records=n) as agg:
+        mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=35, n_total=n, zipf_log2_universe=18, zipf_s_x100=110)
+        cap = n * fa.mock_record_cap(fa.MOCK_ZIPF) + 4096
+        d_buf = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        d_off = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        wb = agg.mock_generate_device(mp, 0, n, d_buf.data_ptr(), cap, d_off.data_ptr())
+        assert wb == len(buf)
+        agg.ingest_device(d_buf.data_ptr(), wb, d_off.data_ptr(), n)
+        for col, key_set in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+            assert np.array_equal(agg.cms_read(key_set).reshape(-1), po.cms_sketch_numpy(rows[col], w, 4, 16, seed)), col
+        ref = po.Rollup(300)
+        ref.ingest(buf, off, 1)
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+        assert agg.stats()["wave_tile_launches"] == 1
