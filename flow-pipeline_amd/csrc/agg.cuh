@@ -123,7 +123,7 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
     uint32_t h[AGG_CH];
     TupleVals tv[AGG_CH];
     unsigned long long c0[AGG_CH], c1[AGG_CH];
-    if (a.dbg & DBG_AGG_NO_LDS) {  // ablation: consume the loads only
+    if (FA_DBG(a, DBG_AGG_NO_LDS)) {  // ablation: consume the loads only
         uint32_t x = 0;
 #pragma unroll
         for (int s = 0; s < agg_su<T8>(); s++) x ^= b.t[s].x ^ b.t[s].y ^ b.t[s].z ^ b.t[s].w;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void agg_consume_chunk(const KArgs& a, AggTable& lt, 
             pending |= 1u << s;
         }
     }
-    if (a.dbg & DBG_AGG_NO_SLOW) return;
+    if (FA_DBG(a, DBG_AGG_NO_SLOW)) return;
     // The leftovers (first occurrences of a group, keys two or more slots from home: ~5 % of the tuples) wait in
     // the wave's queue (as wide tuples) and take the probing path 64 at a time: handled on the spot, each round of
     // the probing loop would run with one or two active lanes.
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     __syncthreads();
     // every group of this partition goes to the device-wide table once; quad-grouped: one atomic line
     // transaction per group.  Uniform trip count: the whole wave takes part in the quad rounds.
-    if (a.dbg & DBG_AGG_NO_FLUSH) return;
+    if (FA_DBG(a, DBG_AGG_NO_FLUSH)) return;
     constexpr int NF = AGG_SLOTS / AGG_BLOCK;  // slots per thread
     unsigned long long fk0[NF], fk1[NF], fs1[NF], fs2[NF];
     ulonglong2 home[NF];
@@ -433,7 +433,7 @@ __device__ __forceinline__ void agg8_consume(const KArgs& a, Agg8Table& lt, uint
         c0[e] = lt.key[home[e]];
         c1[e] = lt.key[home[e] + 1];
     }
-    if (a.dbg & DBG_AGG_NO_LDS) {
+    if (FA_DBG(a, DBG_AGG_NO_LDS)) {
         unsigned long long x = 0;
 #pragma unroll
         for (int e = 0; e < AGG8_NT; e++) x ^= c0[e] ^ c1[e] ^ key[e];
@@ -455,7 +455,7 @@ __device__ __forceinline__ void agg8_consume(const KArgs& a, Agg8Table& lt, uint
             pending |= 1u << e;
         }
     }
-    if (a.dbg & DBG_AGG_NO_SLOW) return;
+    if (FA_DBG(a, DBG_AGG_NO_SLOW)) return;
 #pragma unroll
     for (int e = 0; e < AGG8_NT; e++) {  // leftovers wait in the wave's queue and take the probing path 64 at a time
         const bool pnd = (pending >> e) & 1u;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
     uint32_t my_groups = 0, my_created = 0;
 #pragma unroll 1
     for (uint32_t pass = 0; pass < npass; pass++) {
-    const unsigned long long tm0 = (a.dbg & DBG_TIMING) ? clock64() : 0ull;
+    const unsigned long long tm0 = (FA_DBG(a, DBG_TIMING)) ? clock64() : 0ull;
     uint32_t qn = 0;
     // Work items of a wave: (group g, level j), g = wave, wave + WAVES, ...; j < levels(g).  The loads of the next item
     // fly while the current one is consumed (two register buffers; every fetch is unconditional - an item past the end
@@ -550,8 +550,8 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
 #undef FA_AGG8_PASS
     agg8_drain(a, lt, tb_base, part, lane, queue, qn);
     __syncthreads();
-    const unsigned long long tm1 = (a.dbg & DBG_TIMING) ? clock64() : 0ull;
-    if (a.dbg & DBG_AGG_NO_FLUSH) return;
+    const unsigned long long tm1 = (FA_DBG(a, DBG_TIMING)) ? clock64() : 0ull;
+    if (FA_DBG(a, DBG_AGG_NO_FLUSH)) return;
     // every group of this partition goes to the device-wide table once (quad-grouped: one atomic line transaction per
     // group; uniform trip count: the whole wave takes part in the quad rounds)
     constexpr int NF = (AGG8_ALL + AGG_BLOCK - 1) / AGG_BLOCK, FB = 3;  // slots per thread, in blocks of FB (registers)
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
         }
     }
     }
-    if ((a.dbg & DBG_TIMING) && threadIdx.x == 0) {  // (FA_DEBUG_FLAGS=1024: core clocks per workgroup and pass - fold / add to the device table)
+    if ((FA_DBG(a, DBG_TIMING)) && threadIdx.x == 0) {  // (FA_DEBUG_FLAGS=1024: core clocks per workgroup and pass - fold / add to the device table)
         __builtin_amdgcn_s_waitcnt(0);
         atomicAdd(&a.ctr->t_wait, tm1 - tm0);
         atomicAdd(&a.ctr->t_work, (unsigned long long)clock64() - tm1);

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,6 +96,7 @@ struct fa_ctx {
     bool agg_generic = false;     // env FA_AGG=generic (A/B): compact tuples through the two-word-key aggregation kernel
     uint32_t par = 0;             // parity of the next launch (Counters::exotic_count / retry_count copies)
     uint32_t seg_cap_limit = 0;   // env FA_SEG_CAP (tests only): upper bound on tuples per segment
+    uint32_t last_nwg = 0;        // workgroups of the last scatter-sink launch (FA_VERBOSE: reads its segment counts back)
     // ingest kernel (env FA_TILE=wave|wg, measurement / tests): wave-private tiles + LDS tuple bins is the
     // production kernel of the scatter sink (never slower than the 256-thread workgroup-tile kernel on the
     // workloads measured, 15-20 % faster when most records leave as tuples); the workgroup kernel serves the
@@ -391,20 +393,14 @@ extern "C" void fa_destroy(fa_ctx* c) {
         fprintf(stderr, "[flowagg timing] per tile (wave 0 of every workgroup, core clocks): wait %.0f  work %.0f  | tiles %llu  total/wg-launch %.0f\n",
                 (double)c->h_ctr->t_wait / (double)c->h_ctr->t_tiles, (double)c->h_ctr->t_work / (double)c->h_ctr->t_tiles,
                 (unsigned long long)c->h_ctr->t_tiles, (double)c->h_ctr->t_total);
-#ifdef FA_WT_TIMING
-    if ((c->dbg & DBG_TIMING) && c->h_ctr && c->h_ctr->t_tiles)
-        fprintf(stderr, "[flowagg wave-tile timing] per round: wait %.0f  parse+sink %.0f  flush+issue %.0f  (%d waves/wg)\n",
-                (double)c->h_ctr->t_wait / (double)c->h_ctr->t_tiles, (double)c->h_ctr->t_work / (double)c->h_ctr->t_tiles,
-                (double)c->h_ctr->t_total / (double)c->h_ctr->t_tiles, WBLOCK / 64);
-    if ((c->dbg & DBG_TIMING) && c->h_ctr && c->h_ctr->t_tiles)
-        for (int w = 0; w < WBLOCK / 64 && w < 16; w++) {
-            const unsigned long long* t = c->h_ctr->t_slot[w];
-            if (t[3])
-                fprintf(stderr, "[flowagg wave-tile timing] wave slot %2d: %9llu tiles  per tile: wait %.0f  parse+sink %.0f  flush+issue %.0f  | loop clocks (sum over workgroups) per launch %.0f\n",
-                        w, t[3], (double)t[0] / (double)t[3], (double)t[1] / (double)t[3], (double)t[2] / (double)t[3],
-                        (double)t[4] / (double)std::max<uint64_t>(c->stats.wave_tile_launches, 1));
+    if (getenv("FA_VERBOSE") && c->seg_counts && c->last_nwg) {  // how the last launch's tuples left: whole store units (front) or single tuples (back)
+        std::vector<uint32_t> cnt((size_t)c->last_nwg * NPART_MAX * 2);
+        if (hipMemcpy(cnt.data(), c->seg_counts, cnt.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long front = 0, back = 0;
+            for (size_t i = 0; i < cnt.size() / 2; i++) front += cnt[i], back += cnt[cnt.size() / 2 + i];
+            fprintf(stderr, "[flowagg] last launch's tuples: %llu in whole store units, %llu single (%.2f %%)\n", front, back, 100.0 * (double)back / (double)std::max(1ull, front + back));
         }
-#endif
+    }
     (void)hipFree(c->tab);
     (void)hipFree(c->spill);
     (void)hipFree(c->d_ctr);
@@ -857,6 +853,7 @@ static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, bool t8, KArgs& a)
     a.nwg = nwg;
     a.region = region;
     a.plog2 = c->plog2;
+    c->last_nwg = nwg;
     return FA_OK;
 }
 
@@ -974,13 +971,18 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     a.tile_recs = tile_recs_for(len, n);
     int grid = tile_grid<MODE_INGEST>(c, a.n, a.tile_recs);
     if (c->use_wave_tiles) {  // wave-private tiles: <= 64 records per wave, WBLOCK / 64 waves per workgroup, WT_WG_PER_CU workgroups per CU
-        double avg = (double)len / (double)n + 0.5;
-        // (a tile that does not fit its buffer goes to the deferred parsers as a whole, so leave ~4 sigma of
-        // headroom for a mix of 60- and 84-byte records when the buffer is tight)
+        const double avg = (double)len / (double)n;
+        // Tiles are sized by RECORDS: 64 (one per lane) whenever the mean record allows, otherwise as many as fit the
+        // buffer with about two sigma of byte headroom (sigma of a tile ~ 12 B x sqrt(records): a mix of 60- and 84-byte
+        // records).  A tile whose bytes still exceed the buffer is not lost to the slow path any more: the wave takes
+        // its rest as one more part (ingest.cuh) - about 1 tile in 80 on BASELINE config 2, where this fills all 64
+        // lanes instead of 61.
         // (the kernel variants that serve a sketch run one 16-wave workgroup per CU instead of two 12-wave ones, with
         // slightly shorter tile buffers: wtile_block, wtile_stride)
         const bool big_wg = !wt_lean(c->cfg.key_sets);
-        double r = ((double)(big_wg ? WT_STRIDE_CMS : WT_STRIDE) - 16.0 - 15.0 - 12.0 * 8.0 * 4.0) / avg;
+        const double cap = (double)(big_wg ? WT_STRIDE_CMS : WT_STRIDE) - 16.0 - 15.0;
+        double r = cap / avg;
+        r = (cap - 2.0 * 12.0 * std::sqrt(std::min(r, (double)WT_RECS))) / avg;
         a.tile_recs = r >= (double)WT_RECS ? WT_RECS : r < 1.0 ? 1u : (uint32_t)r;
         const uint32_t wtiles = (a.n + a.tile_recs - 1) / a.tile_recs;
         const uint32_t waves = (uint32_t)(big_wg ? WBLOCK_CMS : WBLOCK) / 64u;

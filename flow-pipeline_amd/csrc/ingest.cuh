@@ -13,7 +13,7 @@ struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 // after_parse: called by the whole wave between the parse and the sink (the tile buffer is dead from there on,
-// unless the sketches use it as scratch) - the wave-tile kernel's early DMA issue (FA_WT_EARLY)
+// unless the sketches use it as scratch)
 // Per-wave tallies that reach the device counters once per workgroup (block_counters_add).
 struct LaneTally {
     uint32_t ok = 0, direct = 0, second = 0, misfit8 = 0;
@@ -34,47 +34,59 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     if (mine) {
         LdsSrc src{tile};
         framed_ok = true;
-        if (a.framed && !(a.dbg & DBG_NO_FRAME)) {
+        if (a.framed && !(FA_DBG(a, DBG_NO_FRAME))) {
             uint32_t pl = 0;
             const uint32_t i = pos >> 2;
             framed_ok = frame_short(fa_alignbyte(src.dw(i + 1), src.dw(i), pos), end - pos, pl);
             pos += pl;
         }
-        sure = framed_ok && (a.dbg & DBG_NO_PARSE) != 0;
+        sure = framed_ok && (FA_DBG(a, DBG_NO_PARSE)) != 0;
     }
-    // Three parsers, each "exact or not sure", tried in the order the wave has learnt from its previous tiles
-    // (pmode, wave-uniform: 0 lean canonical walk first, 1 full canonical walk first, 2 order-free parser first):
-    //  * parse_canon<lean>: the 27 fields of pb-ext/flow.proto in ascending order - what the mocker emits;
-    //  * parse_canon<FULL>: + every other field up to number 2047 as generic runs - what GoFlow emits
-    //    (pb-ext/flow.pb.go:57-147); a wave that needed it once starts with it from then on;
-    //  * parse_fast: any field order, duplicates, unknown fields - IN PLACE, while the bytes still sit in the wave's
+    // Four tiers, each "exact or not sure", tried from the one the wave has learnt from its previous tiles (pmode, wave-uniform):
+    //  0 parse_tmpl<MOCKER>: the template walk over the 13 fields mocker/mocker.go:76-91 sets (+ Proto) - no per-field
+    //    question to the wave, no step for fields that producer never emits;
+    //  1 parse_tmpl<GOFLOW>: the template walk over the 33 fields GoFlow fills for an sFlow sample (a superset of tier 0);
+    //  2 parse_canon<FULL>: every schema field in ascending order and any other field up to number 2047 as generic runs
+    //    (pb-ext/flow.pb.go:57-147) - whatever else marshals in field order;
+    //  3 parse_fast: any field order, duplicates, unknown fields - IN PLACE, while the bytes still sit in the wave's
     //    LDS tile.  Only what that one cannot decide either (varints above 2^42 in projected fields, groups, 3-byte
     //    tags; broken frames) is deferred to deferred_kernel, which reads it back from HBM one record per lane.
-    // Every step is a wave-uniform branch: a stream of one kind pays one ballot per tile for the tiers it never needs.
-    if (!(a.dbg & DBG_NO_PARSE)) {
+    // A tier runs only for the lanes the tier before left unsure (wave-uniform branches: a stream of one kind pays one
+    // ballot per tile for the tiers it never needs); a wave moves its starting tier up when more than half of a tile
+    // needed the next one.
+    if (!FA_DBG(a, DBG_NO_PARSE)) {
         LdsSrc src{tile};
-        if (pmode == 0u && !(a.dbg & DBG_LOOP_PARSER)) {
-            if (framed_ok) sure = parse_canon<COLS, false>(src, pos, end, r);
+        const uint32_t n_mine = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(framed_ok));
+        auto most = [&](bool c) { return 2u * (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c)) > n_mine; };
+        if (pmode == 0u && !FA_DBG(a, DBG_LOOP_PARSER)) {
+            if (framed_ok) sure = parse_tmpl<COLS, SHAPE_MOCKER>(src, pos, end, r);
         }
-        const bool need_full = framed_ok && !sure;
-        if (pmode <= 1u && FA_ANY(need_full) && !(a.dbg & (DBG_LOOP_PARSER | DBG_NO_SECOND))) {
-            if (need_full) {
+        bool need = framed_ok && !sure;
+        if (pmode <= 1u && FA_ANY(need) && !FA_DBG(a, DBG_LOOP_PARSER | DBG_NO_SECOND)) {
+            if (need) {
+                rec_clear(r);
+                sure = parse_tmpl<COLS, SHAPE_GOFLOW>(src, pos, end, r);
+            }
+            if (pmode < 1u && most(need && sure)) pmode = 1u;
+        }
+        need = framed_ok && !sure;
+        if (pmode <= 2u && FA_ANY(need) && !FA_DBG(a, DBG_LOOP_PARSER | DBG_NO_SECOND)) {
+            if (need) {
                 rec_clear(r);
                 sure = parse_canon<COLS, true>(src, pos, end, r);
             }
-            if (FA_ANY(need_full && sure)) pmode = 1u;
+            if (pmode < 2u && most(need && sure)) pmode = 2u;
         }
         const bool need_fast = framed_ok && !sure;
-        const unsigned long long fm = __builtin_amdgcn_ballot_w64(need_fast);
-        if (fm != 0ull && !(a.dbg & DBG_NO_SECOND)) {
+        if (FA_ANY(need_fast) && !FA_DBG(a, DBG_NO_SECOND)) {
             if (need_fast) {
                 rec_clear(r);
                 sure = parse_fast<COLS>(src, pos, end, r);
-                if (!(a.dbg & DBG_LOOP_PARSER)) tally.second += sure ? 1u : 0u;
+                if (!FA_DBG(a, DBG_LOOP_PARSER)) tally.second += sure ? 1u : 0u;
                 if (!sure) rec_clear(r);
             }
             // most of a tile needed the order-free parser and it worked: start with it from now on
-            if (pmode != 2u && __builtin_popcountll(__builtin_amdgcn_ballot_w64(need_fast && sure)) > 32) pmode = 2u;
+            if (pmode != 3u && most(need_fast && sure)) pmode = 3u;
         }
     }
     if (mine && !sure) {  // (one counter atomic per wave: the compiler folds the lanes' adds - s_bcnt1 + mbcnt)
@@ -88,7 +100,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         return;
     }
     tally.ok += sure ? 1 : 0;
-    if (a.dbg & DBG_NO_SINK) {
+    if (FA_DBG(a, DBG_NO_SINK)) {
         tally.ok += (uint32_t)(r.time_received ^ r.bytes ^ r.packets ^ r.src_as ^ r.dst_as ^ r.etype) & 1;
         return;
     }
@@ -99,7 +111,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
         // the 32-bit key hash (three quarter-rate multiplies) is only needed by the hot-key table, the wide tuple's
         // partition and the direct path: a compact-tuple wave that has given the hot-key table up never computes it
-        const bool lt_on = lt_seen != 0xffffffffu && !(a.dbg & DBG_NO_LDS_TABLE);  // wave-uniform
+        const bool lt_on = lt_seen != 0xffffffffu && !(FA_DBG(a, DBG_NO_LDS_TABLE));  // wave-uniform
         uint32_t h = 0;
         if (!T8 || lt_on) h = key_hash(k0, k1);
         const uint64_t b = r.bytes, p = r.packets, c = 1;
@@ -118,74 +130,69 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         }
         // tuple path: one tuple to this workgroup's private segment of the key's partition
         uint32_t fill_part = 0xffffffffu;  // wave-tile kernel: the bin this lane has just filled
+        bool fits = false;
+        uint32_t part = 0;
+        uint4 tv = make_uint4(0, 0, 0, 0);  // (compact tuples: .x, .y)
         if (pending && a.seg) {
             const uint32_t tbr = tb - tb_base;
-            bool fits;
-            uint32_t part;
-            uint4 tv = make_uint4(0, 0, 0, 0);
-            uint2 tc = make_uint2(0, 0);
             if (T8) {
                 fits = t8_fits(r.src_as, r.dst_as, tbr, b, p, r.etype);
-                tc = t8_pack(r.src_as, r.dst_as, (uint32_t)b, (uint32_t)p, tbr, r.etype, tb_base, part);
+                const uint2 tc = t8_pack(r.src_as, r.dst_as, (uint32_t)b, (uint32_t)p, tbr, r.etype, tb_base, part);
+                tv.x = tc.x;
+                tv.y = tc.y;
                 if (FA_ANY(!fits)) tally.misfit8 += (!fits && tup16_fits(tbr, b, p, r.etype)) ? 1u : 0u;  // (format feedback; rare)
             } else {
                 fits = tup16_fits(tbr, b, p, r.etype);
                 part = h >> (32 - a.plog2);
                 tv = tup16_pack(r.src_as, r.dst_as, (uint32_t)b, (uint32_t)p, tbr, r.etype);
             }
-            if (fits) {
-                if (bins) {
-                    // wave-tile kernel: the tuple waits in the workgroup's LDS bin of its partition; the lane that takes
-                    // the last slot of a bin sends the whole bin off as one full, aligned 128-byte line (bins_flush)
-                    // (acquire: the tuple write below must not move above the claim - the previous occupants of the bin
-                    // are read by the flusher until it resets the word; release: the tuple is written before it counts)
-#if FA_WT_EARLY
-                    const uint32_t slot = lds_add_rtn_u32(&bin_cnt[part], 1u) & 0xffffu;  // (asm: see table.cuh; in-order LDS + compiler barrier = the same acquire / release)
-#else
-                    const uint32_t slot = __hip_atomic_fetch_add(&bin_cnt[part], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;  // low half: slots taken, high half: slots written
-#endif
-                    if (slot < TB) {
-                        if (T8) reinterpret_cast<uint2*>(bins)[part * TB + slot] = tc;
-                        else bins[part * TB + slot] = tv;
-#if FA_WT_EARLY
-                        lds_add_u32(&bin_cnt[part], 0x10000u);
-#else
-                        __hip_atomic_fetch_add(&bin_cnt[part], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-                        fill_part = slot == TB - 1 ? part : fill_part;
-                        pending = false;
-                    } else {  // the bin is on its way out: single store to the back part of the segment
-                        const uint32_t ob = lds_add_rtn_u32(&part_cnt[part], 0x10000u) >> 16;
-                        if (ob < a.capb) {
-                            const size_t at = (size_t)part * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob);
-                            if (!(a.dbg & DBG_NO_TUPLE_STORE)) {
-                                if (T8) reinterpret_cast<uint2*>(a.seg)[at] = tc;
-                                else a.seg[at] = tv;
-                            }
-                            pending = false;
-                        } else {
-                            lds_add_u32(&part_cnt[part], 0xffff0000u);  // (not stored: -1 on the back count, which never wraps into stored tuples)
-                        }
-                    }
-                } else if (!T8) {
-                    const uint32_t q = atomicAdd(&part_cnt[part], 1u);
-                    if (q < a.capq) {
-                        if (!(a.dbg & DBG_NO_TUPLE_STORE)) {
-                            uint4* dstp = &a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + q];
-                            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                            const v4u tvv = {tv.x, tv.y, tv.z, tv.w};
-                            if (a.dbg & DBG_TUPLE_NT) __builtin_nontemporal_store(tvv, reinterpret_cast<v4u*>(dstp));
-                            else if (a.dbg & DBG_TUPLE_SC) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dstp), "v"(tvv) : "memory");
-                            else *dstp = tv;
+        }
+        if (bins) {
+            // wave-tile kernel: the tuple waits in the workgroup's LDS bin of its partition; the lane that takes the last
+            // slot of a bin sends the whole bin off as one full store unit (bins_flush)
+            // (acquire: the tuple write must not move above the claim - the previous occupants of the bin are read by
+            // the flusher until it resets the word; release: the tuple is written before it counts)
+            auto claim = [&]() {
+                const uint32_t slot = __hip_atomic_fetch_add(&bin_cnt[part], 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & 0xffffu;  // low half: slots taken, high half: slots written
+                if (slot < TB) {
+                    if (T8) reinterpret_cast<uint2*>(bins)[part * TB + slot] = make_uint2(tv.x, tv.y);
+                    else bins[part * TB + slot] = tv;
+                    __hip_atomic_fetch_add(&bin_cnt[part], 0x10000u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    fill_part = slot == TB - 1 ? part : fill_part;
+                    pending = false;
+                }
+            };
+            if (pending && fits) {
+                claim();
+                // A tuple that meets a closing bin (full, not yet reset by the wave that filled it: ~7 % of the tuples on
+                // BASELINE config 2, where 24 waves share 256 bins) leaves as a single store into the back part of its
+                // segment.  (Round 3 measured the alternative - let the tile's full bins go first, then claim again:
+                // singles 7.4 % -> 1.5 %, kernel +1.5 %: the L2 combines the back parts' stores, the second flush pass costs
+                // more than they do.)
+                if (pending) {
+                    const uint32_t ob = lds_add_rtn_u32(&part_cnt[part], 0x10000u) >> 16;
+                    if (ob < a.capb) {
+                        const size_t at = (size_t)part * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob);
+                        if (!(FA_DBG(a, DBG_NO_TUPLE_STORE))) {
+                            if (T8) reinterpret_cast<uint2*>(a.seg)[at] = make_uint2(tv.x, tv.y);
+                            else a.seg[at] = tv;
                         }
                         pending = false;
+                    } else {
+                        lds_add_u32(&part_cnt[part], 0xffff0000u);  // (not stored: -1 on the back count, which never wraps into stored tuples)
                     }
                 }
+            }
+        } else if (!T8 && pending && fits) {  // workgroup-tile kernel: straight into the segment
+            const uint32_t q = atomicAdd(&part_cnt[part], 1u);
+            if (q < a.capq) {
+                if (!(FA_DBG(a, DBG_NO_TUPLE_STORE))) a.seg[(size_t)part * a.region + (size_t)blockIdx.x * a.capq + q] = tv;
+                pending = false;
             }
         }
         fill_out = fill_part;  // full bins leave in bins_flush(), which the wave-tile kernel runs right after this call
         // direct path (what is left): device-wide table, one atomic line transaction per record
-        if (__builtin_amdgcn_ballot_w64(pending) != 0ull && !(a.dbg & DBG_NO_GLOBAL)) {  // wave-uniform
+        if (__builtin_amdgcn_ballot_w64(pending) != 0ull && !(FA_DBG(a, DBG_NO_GLOBAL))) {  // wave-uniform
             Slot* sp = nullptr;
             if (pending) {
                 tally.direct++;
@@ -212,15 +219,15 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         uint64_t sh1 = 0, sh2 = 0, dh1 = 0, dh2 = 0;
         if (on_s) cms_hash2(slo, shi, a.cms_seed, sh1, sh2);
         if (on_d) cms_hash2(dlo, dhi, a.cms_seed, dh1, dh2);
-        if (hot && !(a.dbg & DBG_NO_HOT)) {  // heavy hitters: one LDS add, nothing else (an address may move in once a wave has seen it twice)
+        if (hot && !(FA_DBG(a, DBG_NO_HOT))) {  // heavy hitters: one LDS add, nothing else (an address may move in once a wave has seen it twice)
             if (vs && hot_add(*hot, 0u, slo, shi, sh1, ws, ws != w)) vs = false;
             if (vd && hot_add(*hot, 1u, dlo, dhi, dh1, wd, wd != w)) vd = false;
         }
-        const bool keys_on = !(a.dbg & DBG_NO_KEYSET);
+        const bool keys_on = !(FA_DBG(a, DBG_NO_KEYSET));
         KsProbe ps{}, pd{};
         if (vs && keys_on) ps = keyset_probe(a, a.ks_src, sh1);
         if (vd && keys_on) pd = keyset_probe(a, a.ks_dst, dh1);
-        if (!(a.dbg & DBG_NO_CMS)) {
+        if (!(FA_DBG(a, DBG_NO_CMS))) {
             if (cl && a.cseg) {  // scatter sink: no atomics (whole wave: the bin flushes need every lane)
                 // (bin lists: the wave's tile buffer is dead by now - behind the 768 bytes the folds used)
                 uint32_t* list = const_cast<uint32_t*>(tile) + 256;
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     }
     __syncthreads();  // LDS table cleared
 
-    const bool timing = (a.dbg & DBG_TIMING) != 0 && tid == 0;
+    const bool timing = (FA_DBG(a, DBG_TIMING)) != 0 && tid == 0;
     uint32_t tm_wait = 0, tm_work = 0, tm_tiles = 0;
     const uint32_t tm_start = timing ? (uint32_t)clock64() : 0u;
     for (; t < ntiles; t += stride) {
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
         if (cur_fits) {
             // nt: the wire bytes are read exactly once; keeping them out of the way of the L2's open tuple lines
             // is worth 11 % of the launch (MI355X, tools/knobs.sh FA_DEBUG_FLAGS=512)
-            if (a.dbg & DBG_DMA_NO_NT) dma_to_lds<0>(a.buf + (cur.lo & ~15u), cur.hi - (cur.lo & ~15u), tile);
+            if (FA_DBG(a, DBG_DMA_NO_NT)) dma_to_lds<0>(a.buf + (cur.lo & ~15u), cur.hi - (cur.lo & ~15u), tile);
             else dma_to_lds<2>(a.buf + (cur.lo & ~15u), cur.hi - (cur.lo & ~15u), tile);
         }
         // ... and meanwhile fetch the next tile's descriptor and offsets
@@ -514,25 +521,6 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
 // front part of whole lines and a back part for the odd tuples (bin leftovers at the end of the launch, tuples
 // that met a bin on its way out).  The workgroup's segments are 3x longer than tile_kernel's, which also
 // suits agg_kernel's 64-lane loads.
-typedef TileDesc WTileDesc;  // (same rule: the loaded bounds are not looked at before the tile's turn)
-__device__ __forceinline__ WTileDesc wtile_desc(const KArgs& a, uint32_t t, uint32_t ntiles) {
-    WTileDesc d{0, 0, 0, 0};
-    if (t < ntiles) {
-        d.r0 = t * a.tile_recs;
-        d.nrec = min(a.tile_recs, a.n - d.r0);
-        if (a.dbg & DBG_SYNTH_TILES) {  // measurement only: fixed-size aligned tiles, no descriptor loads
-            d.lo = t * 4608u;
-            d.hi = d.lo + 4608u;
-            return d;
-        }
-        uint32_t i0 = d.r0, i1 = d.r0 + d.nrec;
-        asm volatile("" : "+v"(i0), "+v"(i1));  // (see tile_desc)
-        d.lo = a.off[i0];
-        d.hi = a.off[i1];
-    }
-    return d;
-}
-
 // LDS of the Count-Min scatter sink: only the kernel variants that serve a sketch carry it
 template <bool ON>
 struct CmsLdsOpt {
@@ -610,174 +598,107 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
     uint32_t lt_seen = 0, lt_hits = 0, pmode = 0;
     uint32_t tb_base = 0;  // (set in the prologue below, wave-uniform)
     const uint32_t ntiles = (a.n + a.tile_recs - 1) / a.tile_recs;
-    const uint32_t stride = gridDim.x * WAVES;
-    const uint32_t rounds = (ntiles + stride - 1) / stride;  // the same for every wave of the grid (flush barriers)
-#if FA_WT_DYN
-    // Dynamic tile assignment inside the workgroup (default; -DFA_WT_DYN=0 restores the static split): workgroup b
-    // owns the tiles k * gridDim.x + b and its waves draw k from an LDS counter two rounds ahead (the bounds of a
-    // tile are prefetched a round before its DMA), so a wave that runs slower (crowded SIMD, younger wave slot)
-    // simply takes fewer tiles - with the static split every wave runs the same number of rounds and the launch
-    // lasts as long as its slowest wave.
+    // Dynamic tile assignment inside the workgroup: workgroup b owns the tiles k * gridDim.x + b and its waves draw k
+    // from an LDS counter two rounds ahead (a tile's offsets are prefetched a round before its DMA), so a wave that runs
+    // slower (crowded SIMD, younger wave slot) simply takes fewer tiles.  Neighbouring tiles share a 128-byte line:
+    // XCD-aware numbering keeps them on one XCD (workgroups go to the XCDs round-robin), so the line is fetched into one L2.
     __shared__ uint32_t next_k;
     if (tid == 0) next_k = 2u * WAVES;
-#if FA_WT_XCD
-    // neighbouring tiles share a 128-byte line: keep them on one XCD (workgroups go to the XCDs round-robin), so
-    // that the line is fetched into one L2
     const uint32_t wg_pos = (gridDim.x & 7u) == 0u ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-#else
-    const uint32_t wg_pos = blockIdx.x;
-#endif
-    uint32_t t = wave * gridDim.x + wg_pos;
-    const uint32_t t_second = (wave + WAVES) * gridDim.x + wg_pos;
     auto tile_after_next = [&]() {
         uint32_t k = 0;
         if (lane == 0) k = lds_add_rtn_u32(&next_k, 1u);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)k) * gridDim.x + wg_pos;
     };
-#define FA_WT_MORE(round) ((void)(round), (void)rounds, cur.nrec != 0)
-#else
-    uint32_t t = blockIdx.x * WAVES + wave;
-    const uint32_t t_second = t + stride;
-    auto tile_after_next = [&]() { return t + 2 * stride; };  // (t advances by stride per round)
-#define FA_WT_MORE(round) ((round) < rounds)
-#endif
-    WTileDesc cur = tile_current(wtile_desc(a, t, ntiles));
-    uint32_t o0 = 0, o1 = 0;
-    const bool lane_off = !(a.dbg & DBG_NO_LANE_OFF);
-    // one offset load per lane: a record's end is its neighbour's start (lane nrec-1: the tile's end, already known)
-    if (lane_off && lane < cur.nrec) o0 = a.off[cur.r0 + lane];
-    o1 = (uint32_t)__shfl_down((int)o0, 1);
-    if (lane + 1 >= cur.nrec) o1 = cur.hi;
-    __syncthreads();  // LDS state cleared
-
-    auto issue_dma = [&](const WTileDesc& d, uint32_t* dst) {
-        if (tile_fits<WT_STRIDE - 16>(d)) {
-            const uint32_t cbase = d.lo & ~15u, nbytes = d.hi - cbase;
-            for (uint32_t o = lane * 16u; o < nbytes; o += 1024u)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.buf + cbase + o),
-                                                 (__attribute__((address_space(3))) void*)(dst + (o - lane * 16u) / 4u), 16, 0, 2);
-        }
+    // A tile = tile_recs consecutive records, one per lane.  Every lane loads its own record's bounds with ONE 8-byte
+    // load (off[r], off[r+1]); the tile's byte range is lane 0's start and the last lane's end, read out of those
+    // registers when the tile's turn comes (no separate descriptor loads, no lane shuffle).  The loaded values must NOT
+    // be looked at before that: any arithmetic on them right after the load makes the compiler wait for it - and, vmcnt
+    // being in-order, for the DMA issued just before.
+    struct __attribute__((packed, aligned(4))) OffPair {
+        uint32_t lo, hi;
     };
-#ifdef FA_WT_TIMING  // measurement builds only (tools/ab_db.sh): core clocks of wave 0 of every workgroup per round
-    uint32_t tm_wait = 0, tm_work = 0, tm_rest = 0, tm_tiles = 0;
-    const uint32_t tm_start = (uint32_t)clock64();
-#define FA_WT_CLK(x) const uint32_t x = (uint32_t)clock64()
-#define FA_WT_ACC(w, k, r) (tm_wait += (w), tm_work += (k), tm_rest += (r), tm_tiles++)
-#else
-#define FA_WT_CLK(x)
-#define FA_WT_ACC(w, k, r)
-#endif
-    // parse + sink of the wave's current tile (staged in buffer tb)
-    auto consume = [&](uint32_t* tb, uint32_t& fill, auto&& after_parse) {
-        if (cur.nrec != 0) {
-            const uint32_t cbase = cur.lo & ~15u;
-            bool mine = tile_fits<WT_STRIDE - 16>(cur) && lane < cur.nrec && o1 >= o0 && o0 >= cur.lo && o1 <= cur.hi;
-            if (a.dbg & DBG_NOT_MINE) mine = mine && o0 == 0x7fffffffu;
-            if (lane < cur.nrec && !mine && !(a.dbg & (DBG_NO_LANE_OFF | DBG_SYNTH_TILES | DBG_NOT_MINE))) {  // tile larger than the buffer / broken offsets
-                unsigned int j = atomicAdd(&a.ctr->exotic_count[a.par], 1u);
-                a.exotic_idx[j] = cur.r0 + lane;
+    struct Tile {
+        uint32_t r0, nrec;  // records [r0, r0 + nrec)   (wave-uniform)
+        uint32_t q0, q1;    // this lane's record: wire bytes [q0, q1)
+    };
+    auto tile_load = [&](uint32_t t) {
+        Tile d{0, 0, 0, 0};
+        if (t < ntiles) {
+            d.r0 = t * a.tile_recs;
+            d.nrec = min(a.tile_recs, a.n - d.r0);
+            if (lane < d.nrec) {
+                const OffPair v = *reinterpret_cast<const OffPair*>(a.off + d.r0 + lane);
+                d.q0 = v.lo;
+                d.q1 = v.hi;
             }
-            lane_work<MODE_INGEST, KEYSETS, COLS, T8>(a, lt, lm, part_cnt, tb, mine, o0 - cbase, o1 - cbase, cur.r0 + lane, tb_base, tally,
-                                                      pmode, lt_seen, lt_hits, bins, bin_cnt, fill, after_parse, cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0), hot,
-                                                      (HAS_APP && a.wseg) ? wpart_cnt : nullptr);
         }
+        return d;
     };
-    // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous
-    // tile was consumed, BEFORE the flush barriers, so that the memory system stays busy during a flush) and
-    // the descriptor + offsets of the tile after it are in flight
-    issue_dma(cur, tile);
-    WTileDesc nxt = wtile_desc(a, t_second, ntiles);
-    uint32_t n0 = 0;
-    if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
+    constexpr uint32_t CAP = (uint32_t)WT_STRIDE - 16u;  // bytes of a tile buffer the DMA may fill (the part's start is rounded down to 16)
+    // stage wire bytes [lo & ~15, min(hi, (lo & ~15) + CAP)) into the wave's buffer
+    auto issue_dma = [&](uint32_t lo, uint32_t hi) {
+        const uint32_t cbase = lo & ~15u;
+        const uint32_t nbytes = hi > cbase ? min(hi - cbase, CAP) : 0u;
+        for (uint32_t o = lane * 16u; o < nbytes; o += 1024u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.buf + cbase + o),
+                                             (__attribute__((address_space(3))) void*)(tile + (o - lane * 16u) / 4u), 16, 0, 2);
+    };
+    // the current tile (part): live = lanes whose record is still to be parsed
+    Tile cur = tile_load(wave * gridDim.x + wg_pos);
+    uint32_t cur_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.q0);
+    uint32_t cur_hi = cur.nrec ? (uint32_t)__builtin_amdgcn_readlane((int)cur.q1, (int)(cur.nrec - 1u)) : 0u;
+    bool live = lane < cur.nrec;
+    __syncthreads();  // LDS state cleared
+    // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous tile was
+    // consumed) and the offsets of the tile after it are in flight
+    issue_dma(cur_lo, cur_hi);
+    Tile nxt = tile_load((wave + WAVES) * gridDim.x + wg_pos);
     // where in time does this batch sit?  Every wave decodes the same 64 samples while its first tile is in flight
     // (no probe dispatch, no cross-workgroup hand-over: the answer is identical all over the grid)
     tb_base = probe_tb_base(a);
     if (blockIdx.x == 0 && tid == 0) a.ctr->tb_base = tb_base;  // (for agg_kernel)
-    if constexpr (WT_EARLY && !(KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
-        // One buffer, early issue: the tile buffer is dead once the wave has parsed it, so the next DMA is issued
-        // between the parse and the sink and flies while the tuples are sunk.  The full bins of a round leave at the
-        // top of the NEXT round, behind the wait and before the parse: their line stores are then older than the
-        // DMA (the in-order vmcnt wait never sits behind fresh write acknowledgements).  The sink's LDS atomics are
-        // issued from inline asm (table.cuh) - the compiler would drain vmcnt before each of them.
-        uint32_t fill = 0xffffffffu;
-        for (uint32_t round = 0; FA_WT_MORE(round); round++, t += stride) {
-            FA_WT_CLK(c0);
-            dma_wait_all();
-            FA_WT_CLK(c1);
-            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8, BL>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 16, fill, tb_base, tally.direct);
-            fill = 0xffffffffu;
-            FA_WT_CLK(c2);
-            WTileDesc d1{0, 0, 0, 0};
-            uint32_t p0 = 0, p1 = 0;
-            bool issued = false;
-            auto issue_next = [&]() {
-                d1 = tile_current(nxt);
-                p0 = n0;
-                p1 = (uint32_t)__shfl_down((int)p0, 1);
-                if (lane + 1 >= d1.nrec) p1 = d1.hi;
-                issue_dma(d1, tile);
-                nxt = wtile_desc(a, tile_after_next(), ntiles);
-                n0 = 0;
-                if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
-                issued = true;
-            };
-            // FA_WT_EARLY=1: always early.  =2: early only while this wave's hot-key table absorbs its records (then the
-            // sink is a handful of LDS atomics and the DMA gains a head start); once the wave has given the table up
-            // (lt_seen == ~0: the tuples go through the bins) the DMA is issued after the sink as in the default kernel.
-            consume(tile, fill, [&]() {
-                if (FA_WT_EARLY == 1 || lt_seen != 0xffffffffu) issue_next();
-            });
-            if (!issued) issue_next();
-            FA_WT_CLK(c3);
-            FA_WT_ACC(c1 - c0, c3 - c2, c2 - c1);
-            cur = d1;
-            o0 = p0;
-            o1 = p1;
+    while (cur.nrec != 0) {
+        dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
+        const uint32_t cbase = cur_lo & ~15u;
+        // sane bounds (the offsets come from the caller): inside the tile's byte range, end >= start
+        const bool valid = live && cur.q1 >= cur.q0 && cur.q0 >= cur_lo && cur.q1 <= cur_hi;
+        const bool staged = valid && cur.q1 - cbase <= CAP;  // the whole record sits in the buffer
+        // Tiles are sized by records (64 of them when the mean record allows) with about two sigma of byte headroom, so
+        // now and then a tile's last records do not fit the buffer: they stay live and the wave takes the tile's rest as
+        // one more part (re-staged from the first record left) before it moves on.  A record that does not fit an EMPTY
+        // buffer, and records with broken bounds, go to the generic path (deferred_kernel).
+        bool rest = valid && !staged;
+        const bool hopeless = (live && !valid) || (rest && cur.q0 == cur_lo);
+        if (FA_ANY(hopeless)) {
+            if (hopeless) {
+                unsigned int j = atomicAdd(&a.ctr->exotic_count[a.par], 1u);
+                a.exotic_idx[j] = cur.r0 + lane;
+            }
+            rest = rest && !hopeless;
         }
-        dma_wait_all();
+        uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
+        lane_work<MODE_INGEST, KEYSETS, COLS, T8>(a, lt, lm, part_cnt, tile, staged, cur.q0 - cbase, cur.q1 - cbase, cur.r0 + lane, tb_base, tally,
+                                                  pmode, lt_seen, lt_hits, bins, bin_cnt, fill, NoHook(), cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0), hot,
+                                                  (HAS_APP && a.wseg) ? wpart_cnt : nullptr);
+        // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
+        // queue and the wave would wait for the write acknowledgements on top of its tile (measured: +15 %)
         if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8, BL>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 16, fill, tb_base, tally.direct);
-    } else {
-        for (uint32_t round = 0; FA_WT_MORE(round); round++, t += stride) {
-            FA_WT_CLK(c0);
-            dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
-            FA_WT_CLK(c1);
-            uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
-            consume(tile, fill, NoHook());
-            FA_WT_CLK(c2);
-            // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
-            // queue and the wave would wait for the write acknowledgements on top of its tile (measured: +15 %)
-            if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) bins_flush<T8, BL>(a, bins, bin_cnt, part_cnt, flush_scratch + wave * 16, fill, tb_base, tally.direct);
-            const uint32_t t2 = tile_after_next();  // (dynamic: an LDS atomic - before the DMA, or the compiler drains vmcnt for it)
-            cur = tile_current(nxt);
-            o0 = n0;
-            o1 = (uint32_t)__shfl_down((int)o0, 1);
-            if (lane + 1 >= cur.nrec) o1 = cur.hi;
-            issue_dma(cur, tile);  // next tile (the buffer is free: every read of the old tile has returned)
-            nxt = wtile_desc(a, t2, ntiles);
-            n0 = 0;
-            if (lane_off && lane < nxt.nrec) n0 = a.off[nxt.r0 + lane];
-            FA_WT_CLK(c3);
-            FA_WT_ACC(c1 - c0, c2 - c1, c3 - c2);
+        const unsigned long long restm = __builtin_amdgcn_ballot_w64(rest);
+        if (restm != 0ull) {  // (rare) the rest of this tile: same records, same lanes, staged from the first one left
+            live = rest;
+            cur_lo = (uint32_t)__builtin_amdgcn_readlane((int)cur.q0, (int)__builtin_ctzll(restm));
+            issue_dma(cur_lo, cur_hi);
+            continue;
         }
+        const uint32_t t2 = tile_after_next();  // (an LDS atomic - before the DMA, or the compiler drains vmcnt for it)
+        cur = nxt;
+        cur_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.q0);
+        cur_hi = cur.nrec ? (uint32_t)__builtin_amdgcn_readlane((int)cur.q1, (int)(cur.nrec - 1u)) : 0u;
+        live = lane < cur.nrec;
+        issue_dma(cur_lo, cur_hi);  // next tile (the buffer is free: every read of the old tile has returned)
+        nxt = tile_load(t2);
     }
-#ifdef FA_WT_TIMING
-    if (tid == 0) {  // wait: DMA wait at the top of a round; work: parse + sink; rest (reported as "total"): flush + DMA issue + bounds
-        atomicAdd(&a.ctr->t_wait, (unsigned long long)tm_wait);
-        atomicAdd(&a.ctr->t_work, (unsigned long long)tm_work);
-        atomicAdd(&a.ctr->t_total, (unsigned long long)tm_rest);
-        atomicAdd(&a.ctr->t_tiles, (unsigned long long)tm_tiles);
-    }
-    if (lane == 0 && wave < 16u) {  // every wave slot: how even is the work, when does each slot leave the loop
-        atomicAdd(&a.ctr->t_slot[wave][0], (unsigned long long)tm_wait);
-        atomicAdd(&a.ctr->t_slot[wave][1], (unsigned long long)tm_work);
-        atomicAdd(&a.ctr->t_slot[wave][2], (unsigned long long)tm_rest);
-        atomicAdd(&a.ctr->t_slot[wave][3], (unsigned long long)tm_tiles);
-        atomicAdd(&a.ctr->t_slot[wave][4], (unsigned long long)((uint32_t)clock64() - tm_start));
-    }
-#endif
-#undef FA_WT_CLK
-#undef FA_WT_ACC
-#undef FA_WT_MORE
     // what is left in the bins (fewer than a line each) goes to the back part of the segments
     if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {
         __syncthreads();
@@ -792,7 +713,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
                 else tv = bins[idx];
                 if (ob < a.capb) {
                     const size_t at = (size_t)p * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob);
-                    if (!(a.dbg & DBG_NO_TUPLE_STORE)) {
+                    if (!(FA_DBG(a, DBG_NO_TUPLE_STORE))) {
                         if (T8) reinterpret_cast<uint2*>(a.seg)[at] = tc;
                         else a.seg[at] = tv;
                     }
@@ -822,7 +743,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
                 const unsigned long long lo = hot->lo[set][sl], hi = hot->hi[set][sl];
                 const uint32_t key[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
                 cms_add(set ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, key, hot->w[set][sl]);
-                if (!(a.dbg & DBG_NO_KEYSET)) keyset_insert(a, set ? a.ks_dst : a.ks_src, key);
+                if (!(FA_DBG(a, DBG_NO_KEYSET))) keyset_insert(a, set ? a.ks_dst : a.ks_src, key);
             }
         }
     }

@@ -35,10 +35,6 @@ constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
 #ifndef FA_BIN_BYTES
 #define FA_BIN_BYTES 64
 #endif
-#ifndef FA_WT_EARLY
-#define FA_WT_EARLY 0
-#endif
-constexpr bool WT_EARLY = FA_WT_EARLY != 0;  // next DMA issued between the parse and the sink (experiment): 1 always, 2 while the hot-key table is on
 constexpr int WBLOCK = FA_WBLOCK;   // 12 waves, each with a private LDS tile of <= 64 records
 constexpr int WT_RECS = 64;
 constexpr int WT_STRIDE = FA_WT_STRIDE;  // 4864 = 64 records x 76 B (16-byte multiple); longer records: fewer per tile; overreads land in the next tile / the bins
@@ -79,6 +75,14 @@ constexpr uint32_t KS_ALL = 0xFFu;
 constexpr uint32_t FA_KEYS_WIDE = FA_KEYS_ADDR_PORT_PROTO | FA_KEYS_PORT_HIST | FA_KEYS_MINUTE_SERIES;
 constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense histograms
 // ablation switches (env FA_DEBUG_FLAGS; measurement only - results are wrong when set)
+// FA_DEBUG_FLAGS ablation switches (results are wrong by design).  Production builds compile them OUT (FA_ABLATE 0:
+// every test below folds to false - no scalar tests, no dead branches in the hot kernels); the measurement scripts under
+// tools/ build a variant with EXTRA=-DFA_ABLATE=1.  DBG_AGG_ATOMIC_FLUSH stays a runtime switch (exact: an A/B of two
+// correct flush protocols).
+#ifndef FA_ABLATE
+#define FA_ABLATE 0
+#endif
+#define FA_DBG(a, flags) (FA_ABLATE != 0 && ((a).dbg & (flags)) != 0)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
        DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072, DBG_NO_KEYSET = 262144, DBG_NO_CMS = 524288, DBG_NO_HOT = 1048576, DBG_AGG_ATOMIC_FLUSH = 2097152 /* exact: agg8_kernel adds its groups with atomics although it owns the region (A/B) */ };
 
@@ -97,9 +101,6 @@ struct Counters {
     unsigned long long wused, wspill_lost;  // wide table (wide.cuh)
     unsigned int wspill_count, wrows_count;
     unsigned long long agg_groups, agg_launches;  // agg8_kernel: groups it added to the device table, launches (pass-count feedback)
-#ifdef FA_WT_TIMING  // measurement builds: per wave slot of the wave-tile kernel {wait, parse+sink, flush+issue, tiles, loop clocks}
-    unsigned long long t_slot[16][5];
-#endif
 };
 
 // Distinct-address set behind fa_topk (the dashboards rank EVERY address,
@@ -811,7 +812,7 @@ __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t
             if ((line + 1u) * TB <= a.capf) {
                 // (compact tuples: region and capq are even, so the segment starts on a uint4 boundary)
                 const size_t seg0 = ((size_t)fp * a.region + (size_t)blockIdx.x * a.capq) >> (T8 ? 1 : 0);
-                if (!(a.dbg & DBG_NO_TUPLE_STORE)) a.seg[seg0 + line * BL + sub] = tv;
+                if (!(FA_DBG(a, DBG_NO_TUPLE_STORE))) a.seg[seg0 + line * BL + sub] = tv;
             } else {  // front part full (skewed batch): straight to the device-wide table
                 TupleVals v[2];
                 if (T8) {

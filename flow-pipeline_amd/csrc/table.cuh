@@ -19,20 +19,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// FA_WT_EARLY (early DMA issue in the wave-tile kernel, ingest.cuh) also selects how the per-record LDS atomics are
-// issued: a tile DMA is then in flight while records are sunk, and the compiler drains vmcnt before EVERY LDS atomic
-// it emits while an LDS-DMA is outstanding (atomics carry no alias scope, so it cannot tell the tile buffers from
-// the tables).  Issued from inline asm they do not wait.
-#ifndef FA_WT_EARLY
-#define FA_WT_EARLY 0
-#endif
-#ifndef FA_WT_XCD
-#define FA_WT_XCD 1  // XCD-aware tile numbering of the dynamic draw (ingest.cuh): -2 % on config 2
-#endif
-#ifndef FA_WT_DYN
-#define FA_WT_DYN 1  // dynamic tile assignment inside a workgroup (ingest.cuh): -2..3 % launch time, see DESIGN.md
-#endif
-
 namespace fa {
 
 // One more group in a table: called by every lane that has just created one, from divergent code.  The lanes that
@@ -44,36 +30,12 @@ __device__ __forceinline__ void count_created(unsigned long long* used) {
 }
 
 
-#if FA_WT_EARLY && defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-    return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
-}
-// (LDS operations of a wave execute in order; the "memory" clobber keeps the compiler's own LDS accesses on
-// their side of the atomic; an lgkmcnt(0) more than the compiler expects only makes its later waits stricter)
-__device__ __forceinline__ uint32_t lds_add_rtn_u32(uint32_t* p, uint32_t v) {
-    uint32_t r;
-    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(lds_addr(p)), "v"(v) : "memory");
-    return r;
-}
-__device__ __forceinline__ void lds_add_u32(uint32_t* p, uint32_t v) {
-    asm volatile("ds_add_u32 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
-}
-__device__ __forceinline__ void lds_add_u64(unsigned long long* p, unsigned long long v) {
-    asm volatile("ds_add_u64 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
-}
-__device__ __forceinline__ unsigned long long lds_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long val) {
-    unsigned long long r;
-    asm volatile("ds_cmpst_rtn_b64 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(lds_addr(p)), "v"(cmp), "v"(val) : "memory");
-    return r;
-}
-#else
 __device__ __forceinline__ uint32_t lds_add_rtn_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void lds_add_u32(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 __device__ __forceinline__ void lds_add_u64(unsigned long long* p, unsigned long long v) { atomicAdd(p, v); }
 __device__ __forceinline__ unsigned long long lds_cas_u64(unsigned long long* p, unsigned long long cmp, unsigned long long val) {
     return atomicCAS(p, cmp, val);
 }
-#endif
 
 struct __attribute__((aligned(64))) Slot {
     unsigned long long k0, k1;

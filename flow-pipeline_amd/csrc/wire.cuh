@@ -370,7 +370,7 @@ FA_HD bool parse_canon(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
     uint32_t d32 = 0;  // discarded captures
     uint64_t d64 = 0;
     uint32_t sr32 = 0, by32 = 0, pk32 = 0;
-    canon_short<0x08u, false>(s, c, end, d32);                                              //  1 Type
+    canon_short<0x08u, false>(s, c, end, d32);  //  1 Type
     canon_long<0x10u, (COLS & COL_TIME_RECEIVED) != 0>(s, c, end, r.time_received);         //  2 TimeReceived
     canon_short<0x18u, (COLS & COL_SAMPLING_RATE) != 0>(s, c, end, sr32);                   //  3 SamplingRate
     {
@@ -393,33 +393,197 @@ FA_HD bool parse_canon(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
     // instead of one test per field: 18..20, 23..26, 31..37.  (A lane can only be inside a run if its tag was
     // in the run's range when the run started - fields come in ascending order.)
     if (FA_ANY(((c.x & 0xffffu) - 0x0190u) <= 0x0010u)) {
-        canon_short<0x0190u, false>(s, c, end, d32);                                        // 18 InIf
-        canon_short<0x0198u, false>(s, c, end, d32);                                        // 19 OutIf
+        canon_short<0x0190u, false>(s, c, end, d32);  // 18 InIf
+        canon_short<0x0198u, false>(s, c, end, d32);  // 19 OutIf
         canon_short<0x01a0u, (COLS & COL_PROTO) != 0>(s, c, end, r.proto);                  // 20 Proto
     }
     canon_short<0x01a8u, (COLS & COL_SRC_PORT) != 0>(s, c, end, r.src_port);                // 21 SrcPort
     canon_short<0x01b0u, (COLS & COL_DST_PORT) != 0>(s, c, end, r.dst_port);                // 22 DstPort
     if (FA_ANY(((c.x & 0xffffu) - 0x01b8u) <= 0x0018u)) {
-        canon_short<0x01b8u, false>(s, c, end, d32);                                        // 23 IPTos
-        canon_short<0x01c0u, false>(s, c, end, d32);                                        // 24 ForwardingStatus
-        canon_short<0x01c8u, false>(s, c, end, d32);                                        // 25 IPTTL
-        canon_short<0x01d0u, false>(s, c, end, d32);                                        // 26 TCPFlags
+        canon_short<0x01b8u, false>(s, c, end, d32);  // 23 IPTos
+        canon_short<0x01c0u, false>(s, c, end, d32);  // 24 ForwardingStatus
+        canon_short<0x01c8u, false>(s, c, end, d32);  // 25 IPTTL
+        canon_short<0x01d0u, false>(s, c, end, d32);  // 26 TCPFlags
     }
     if (FULL) canon_run<0x01d8u, 0x01efu>(s, c, end);                                       // 27 SrcMac, 28 DstMac, 29 VlanId
     canon_short<0x01f0u, (COLS & COL_ETYPE) != 0>(s, c, end, r.etype);                      // 30 Etype
     if (FULL) {
         canon_run<0x01f8u, 0x02afu>(s, c, end);                                             // 31 IcmpType .. 37 IPv6FlowLabel
     } else if (FA_ANY(((c.x & 0xffffu) - 0x01f8u) <= 0x00b0u)) {
-        canon_short<0x01f8u, false>(s, c, end, d32);                                        // 31 IcmpType
-        canon_short<0x0280u, false>(s, c, end, d32);                                        // 32 IcmpCode
-        canon_short<0x02a8u, false>(s, c, end, d32);                                        // 37 IPv6FlowLabel
+        canon_short<0x01f8u, false>(s, c, end, d32);  // 31 IcmpType
+        canon_short<0x0280u, false>(s, c, end, d32);  // 32 IcmpCode
+        canon_short<0x02a8u, false>(s, c, end, d32);  // 37 IPv6FlowLabel
     }
     canon_long<0x02b0u, (COLS & COL_TIME_FLOW_START) != 0>(s, c, end, r.time_flow_start);   // 38 TimeFlowStart
     if (FULL) canon_run<0x02b8u, 0x7fffu>(s, c, end);                                       // 39 .. 2047 (VRF, 42 FlowDirection, encap, MPLS, PPP, country, ASDB)
-    else canon_short<0x02d0u, false>(s, c, end, d32);                                       // 42 FlowDirection
+    else canon_short<0x02d0u, false>(s, c, end, d32);  // 42 FlowDirection
     r.sampling_rate = sr32;
     r.bytes = by32;
     r.packets = pk32;
+    return c.pos == end;
+}
+
+// ---- template walks --------------------------------------------------------------------------------------
+// The canonical walk above asks, for each of the 27 schema fields, "does any lane carry it?" - on the streams the
+// reference's own producers emit, 13 of those questions are always answered "no" and the other 14 "yes, every lane".
+// A template walk is the same walk compiled for ONE producer's field list: no wave-level question per field (every
+// lane executes every step; a lane whose record omits the field - proto3 zero omission - simply does not move), no
+// step for fields the producer never sets, and per field the cheapest exact step for its shape:
+//   tw_time5   a varint of exactly 5 bytes (a Unix timestamp between 1978 and 3058) - tag and continuation bits checked
+//              with two masked compares;
+//   tw_short   a varint whose value fits 4 bytes (< 2^28);            tw_skip   a varint that ends inside the window;
+//   tw_addr    a bytes field with a one-byte length <= 16;            canon_skip (above) for 7-byte MAC varints.
+// Same contract as every tier: a step only moves the cursor over a field it has validated completely, steps come in
+// ascending field order, so "cursor == end" means the record is exactly a sub-sequence of the template's fields - decoded
+// exactly - and anything else (another field, another order, a longer varint, a timestamp outside 1978..3058) is "not
+// sure" and goes to the general tiers.  Shapes: what mocker/mocker.go:76-91 sets (+ Proto, which BASELINE's Zipf
+// configurations set), and the 33 fields GoFlow fills for an sFlow sample (pb-ext/flow.pb.go:57-147).
+FA_HD uint32_t fa_ubfe(uint32_t v, uint32_t off, uint32_t width) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, off, width);  // uses off[4:0], width[4:0]
+#else
+    off &= 31u;
+    width &= 31u;
+    return width ? (v >> off) & ((1u << width) - 1u) : 0u;
+#endif
+}
+// value (< 2^28) of a varint of <= 4 bytes: v = its bytes (little endian, anything above), sb = bit index of the stop
+// byte's bit 7 (7, 15, 23, 31)
+FA_HD uint32_t varint28b(uint32_t v, uint32_t sb) {
+    const uint32_t m = fa_ubfe(v, 0u, sb) & 0x7f7f7f7fu;  // (sb = 31: bits 0..30; bit 31 is the stop byte's clear bit 7)
+    const uint32_t t = m - ((m & 0x7f007f00u) >> 1);      // two 14-bit halves
+    return t - (t >> 16) * 0xC000u;                        // lo14 | hi14 << 14
+}
+
+template <uint32_t TAG, bool WANT, bool LAST = false, class Src>
+FA_HD void tw_short(const Src& s, Cursor& c, uint32_t end, uint32_t& out) {
+    constexpr uint32_t TL = TAG > 0xffu ? 2u : 1u;
+    const bool m = (c.x & (TL == 1 ? 0xffu : 0xffffu)) == TAG;
+    const uint32_t v = fa_alignbyte(c.y, c.x, TL);  // value bytes 0..3
+    const uint32_t sb = fa_ffbl(~v & 0x80808080u);
+    const uint32_t pn = c.pos + (sb >> 3) + (TL + 1u);  // sb = 0xffffffff (no stop) -> far beyond end
+    const bool ok = m && pn <= end;
+    if (WANT) {
+        const uint32_t val = varint28b(v, sb);
+        out = ok ? val : out;
+    }
+    c.pos = ok ? pn : c.pos;
+    if (!LAST) cur_load(s, c);
+}
+// a varint outside the projection that ends inside the window (value of <= 8 - TL bytes)
+template <uint32_t TAG, bool LAST = false, class Src>
+FA_HD void tw_skip(const Src& s, Cursor& c, uint32_t end) {
+    constexpr uint32_t TL = TAG > 0xffu ? 2u : 1u;
+    const bool m = (c.x & (TL == 1 ? 0xffu : 0xffffu)) == TAG;
+    const uint32_t s0 = fa_ffbl(~c.x & (TL == 1 ? 0x80808000u : 0x80800000u));
+    const uint32_t s1 = fa_ffbl(~c.y & 0x80808080u) | 32u;  // stays 0xffffffff when there is no stop
+    const uint32_t sb = s0 < s1 ? s0 : s1;
+    const uint32_t pn = c.pos + (sb >> 3) + 1u;
+    const bool ok = m && pn <= end;
+    c.pos = ok ? pn : c.pos;
+    if (!LAST) cur_load(s, c);
+}
+// a varint of exactly 5 bytes (value in [2^28, 2^35)): timestamps
+template <uint32_t TAG, bool WANT, bool LAST = false, class Src>
+FA_HD void tw_time5(const Src& s, Cursor& c, uint32_t end, uint64_t& out) {
+    constexpr uint32_t TL = TAG > 0xffu ? 2u : 1u;
+    // tag bytes equal, value bytes 0..3 with the continuation bit, byte 4 without: two masked compares
+    const bool m = TL == 1 ? ((c.x & 0x808080ffu) == (0x80808000u | TAG) && (c.y & 0x00008080u) == 0x00000080u)
+                           : ((c.x & 0x8080ffffu) == (0x80800000u | TAG) && (c.y & 0x00808080u) == 0x00008080u);
+    const uint32_t pn = c.pos + TL + 5u;
+    const bool ok = m && pn <= end;
+    if (WANT) {
+        const uint32_t v = fa_alignbyte(c.y, c.x, TL) & 0x7f7f7f7fu;  // value bytes 0..3, payload bits
+        const uint32_t t = v - ((v & 0x7f007f00u) >> 1);
+        const uint32_t lo28 = t - (t >> 16) * 0xC000u;
+        const uint32_t b4 = fa_ubfe(c.y, 8u * TL, 7u);
+        const uint64_t val = (uint64_t)lo28 | ((uint64_t)b4 << 28);
+        out = ok ? val : out;
+    }
+    c.pos = ok ? pn : c.pos;
+    if (!LAST) cur_load(s, c);
+}
+template <uint32_t TAG, bool WANT, class Src>
+FA_HD void tw_addr(const Src& s, Cursor& c, uint32_t end, uint32_t out[4]) {
+    const bool m = (c.x & 0xffu) == TAG;
+    const uint32_t len = fa_ubfe(c.x, 8u, 8u);
+    const uint32_t pn = c.pos + 2u + len;
+    const bool ok = m && len <= 16u && pn <= end;
+    if (WANT) {
+        uint32_t a16[4];
+        load_fixed16(s, c.pos + 2u, len > 16u ? 16u : len, a16);
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[k] = ok ? a16[k] : out[k];
+    }
+    c.pos = ok ? pn : c.pos;
+    cur_load(s, c);
+}
+
+enum : int { SHAPE_MOCKER = 0, SHAPE_GOFLOW = 1 };
+// r must be cleared by the caller.  Returns true iff [pos,end) is exactly an encoding of (a sub-sequence of) the shape's
+// fields, in field-number order.
+template <uint32_t COLS, int SHAPE, class Src>
+FA_HD bool parse_tmpl(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
+    constexpr bool GF = SHAPE == SHAPE_GOFLOW;
+    Cursor c;
+    c.pos = pos;
+    cur_load(s, c);
+    uint32_t d32 = 0, sr32 = 0, by32 = 0, pk32 = 0;
+    uint64_t d64 = 0;
+    if (GF) tw_short<0x08u, false>(s, c, end, d32);  //  1 Type
+    tw_time5<0x10u, (COLS & COL_TIME_RECEIVED) != 0>(s, c, end, r.time_received);              //  2 TimeReceived
+    tw_short<0x18u, (COLS & COL_SAMPLING_RATE) != 0>(s, c, end, sr32);                         //  3 SamplingRate
+    if (COLS & COL_SEQUENCE_NUM) {                                                             //  4 SequenceNum (uint32: <= 5 bytes)
+        uint64_t seq = 0;
+        canon_long<0x20u, true>(s, c, end, seq);
+        r.sequence_num = (uint32_t)seq;
+    } else {
+        tw_skip<0x20u>(s, c, end);
+    }
+    if (GF) tw_time5<0x28u, false>(s, c, end, d64);                                            //  5 TimeFlowEnd
+    tw_addr<0x32u, (COLS & COL_SRC_ADDR) != 0>(s, c, end, r.src);                              //  6 SrcAddr
+    tw_addr<0x3au, (COLS & COL_DST_ADDR) != 0>(s, c, end, r.dst);                              //  7 DstAddr
+    tw_short<0x48u, (COLS & COL_BYTES) != 0>(s, c, end, by32);                                 //  9 Bytes
+    tw_short<0x50u, (COLS & COL_PACKETS) != 0>(s, c, end, pk32);                               // 10 Packets
+    if (GF) {
+        tw_addr<0x5au, (COLS & COL_SAMPLER_ADDRESS) != 0>(s, c, end, r.sampler);               // 11 SamplerAddress
+        uint32_t nh[4];
+        tw_addr<0x62u, false>(s, c, end, nh);                                                  // 12 NextHop
+        tw_short<0x68u, false>(s, c, end, d32);  // 13 NextHopAS
+    }
+    tw_short<0x70u, (COLS & COL_SRC_AS) != 0>(s, c, end, r.src_as);                            // 14 SrcAS
+    tw_short<0x78u, (COLS & COL_DST_AS) != 0>(s, c, end, r.dst_as);                            // 15 DstAS
+    if (GF) {
+        tw_short<0x0180u, false>(s, c, end, d32);  // 16 SrcNet
+        tw_short<0x0188u, false>(s, c, end, d32);  // 17 DstNet
+        tw_short<0x0190u, false>(s, c, end, d32);  // 18 InIf
+        tw_short<0x0198u, false>(s, c, end, d32);  // 19 OutIf
+        tw_short<0x01a0u, (COLS & COL_PROTO) != 0>(s, c, end, r.proto);                        // 20 Proto
+    } else if (FA_ANY((c.x & 0xffffu) == 0x01a0u)) {  // (mocker.go never sets it; BASELINE's Zipf configurations do)
+        tw_short<0x01a0u, (COLS & COL_PROTO) != 0>(s, c, end, r.proto);
+    }
+    tw_short<0x01a8u, (COLS & COL_SRC_PORT) != 0>(s, c, end, r.src_port);                      // 21 SrcPort
+    tw_short<0x01b0u, (COLS & COL_DST_PORT) != 0>(s, c, end, r.dst_port);                      // 22 DstPort
+    if (GF) {
+        tw_short<0x01b8u, false>(s, c, end, d32);  // 23 IPTos
+        tw_short<0x01c8u, false>(s, c, end, d32);  // 25 IPTTL
+        tw_short<0x01d0u, false>(s, c, end, d32);  // 26 TCPFlags
+        canon_skip<true>(s, c, end, (c.x & 0xffffu) == 0x01d8u);                               // 27 SrcMac (7-byte varint)
+        canon_skip<true>(s, c, end, (c.x & 0xffffu) == 0x01e0u);                               // 28 DstMac
+        tw_short<0x01e8u, false>(s, c, end, d32);  // 29 VlanId
+    }
+    tw_short<0x01f0u, (COLS & COL_ETYPE) != 0>(s, c, end, r.etype);                            // 30 Etype
+    if (GF) {
+        tw_short<0x0288u, false>(s, c, end, d32);  // 33 SrcVlan
+        tw_short<0x0290u, false>(s, c, end, d32);  // 34 DstVlan
+        tw_short<0x0298u, false>(s, c, end, d32);  // 35 FragmentId
+        tw_short<0x02a8u, false>(s, c, end, d32);  // 37 IPv6FlowLabel
+    }
+    tw_time5<0x02b0u, (COLS & COL_TIME_FLOW_START) != 0, true>(s, c, end, r.time_flow_start);  // 38 TimeFlowStart
+    r.sampling_rate = sr32;
+    r.bytes = by32;
+    r.packets = pk32;
+    (void)d32;
     return c.pos == end;
 }
 

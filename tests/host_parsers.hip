@@ -48,7 +48,7 @@ static bool same(const Rec& r, const fo_row& o, uint32_t cols) {
 }
 
 struct Stats {
-    uint64_t cases = 0, canon_sure = 0, full_sure = 0, fast_sure = 0, oracle_ok = 0, fail = 0;
+    uint64_t cases = 0, canon_sure = 0, full_sure = 0, fast_sure = 0, oracle_ok = 0, fail = 0, tm_sure = 0, tg_sure = 0;
 };
 
 static void hexdump(const uint8_t* p, size_t n) {
@@ -57,7 +57,7 @@ static void hexdump(const uint8_t* p, size_t n) {
 }
 
 // payload = bare FlowMessage bytes
-static void check(const uint8_t* payload, size_t n, Stats& st, bool must_be_canon, bool must_be_full = false) {
+static void check(const uint8_t* payload, size_t n, Stats& st, bool must_be_canon, bool must_be_full = false, int must_tmpl = -1) {
     // aligned, padded copy at a random byte offset (the parsers read ~32 bytes past the end)
     static std::vector<uint32_t> buf(4096);
     const uint32_t shift = (uint32_t)(rnd() & 15);
@@ -98,6 +98,28 @@ static void check(const uint8_t* payload, size_t n, Stats& st, bool must_be_cano
         const bool sure2 = parse_canon<COLS_AS_ROLLUP>(src, shift, shift + (uint32_t)n, r2);
         if (sure2 != sure || (sure2 && !same(r2, want, COLS_AS_ROLLUP))) {
             if (st.fail++ < 10) { printf("parse_canon<AS_ROLLUP> mismatch: "); hexdump(payload, n); }
+        }
+    }
+    {  // template walks (mocker.go's field list, GoFlow's 33 fields): exact or not sure; the GoFlow shape is a superset
+        bool sm[2], sg[2];
+        const uint32_t colsets[2] = {COL_ALL, COLS_AS_ROLLUP};
+        for (int k = 0; k < 2; k++) {
+            Rec rm, rg;
+            rec_clear(rm);
+            rec_clear(rg);
+            sm[k] = k == 0 ? parse_tmpl<COL_ALL, SHAPE_MOCKER>(src, shift, shift + (uint32_t)n, rm) : parse_tmpl<COLS_AS_ROLLUP, SHAPE_MOCKER>(src, shift, shift + (uint32_t)n, rm);
+            sg[k] = k == 0 ? parse_tmpl<COL_ALL, SHAPE_GOFLOW>(src, shift, shift + (uint32_t)n, rg) : parse_tmpl<COLS_AS_ROLLUP, SHAPE_GOFLOW>(src, shift, shift + (uint32_t)n, rg);
+            if ((sm[k] && (orc != FO_OK || !same(rm, want, colsets[k]))) || (sg[k] && (orc != FO_OK || !same(rg, want, colsets[k]))) || (sm[k] && !sg[k])) {
+                if (st.fail++ < 10) { printf("parse_tmpl mismatch (cols %d mocker=%d goflow=%d oracle=%d): ", k, sm[k], sg[k], orc); hexdump(payload, n); }
+            }
+        }
+        if (sm[0] != sm[1] || sg[0] != sg[1]) {
+            if (st.fail++ < 10) { printf("parse_tmpl verdict depends on the column set: "); hexdump(payload, n); }
+        }
+        st.tm_sure += sm[0];
+        st.tg_sure += sg[0];
+        if ((must_tmpl == 0 && !sm[0]) || (must_tmpl == 1 && !sg[0])) {
+            if (st.fail++ < 10) { printf("parse_tmpl not sure on its own producer's record (shape %d): ", must_tmpl); hexdump(payload, n); }
         }
     }
     {
@@ -219,7 +241,7 @@ int main(int argc, char** argv) {
         std::vector<uint64_t> off(iters + 1);
         const size_t w = fo_gen_records(&gp, 0, iters, buf.data(), buf.size(), off.data());
         if (w == (size_t)-1) { printf("generator overflow\n"); return 2; }
-        for (uint64_t i = 0; i < iters; i++) check(buf.data() + off[i], off[i + 1] - off[i], mode == 3 ? goflow : gen, mode != 3, true);
+        for (uint64_t i = 0; i < iters; i++) check(buf.data() + off[i], off[i + 1] - off[i], mode == 3 ? goflow : gen, mode != 3, true, mode == 3 ? 1 : 0);
         // 2. byte-level mutations of generator output
         for (uint64_t i = 0; i < iters; i++) {
             uint8_t tmp[256];
@@ -250,8 +272,9 @@ int main(int argc, char** argv) {
         if (n < 900) check(tmp, n, wide67nc, false);
     }
     auto pr = [](const char* name, const Stats& s) {
-        printf("%-28s cases=%llu oracle_ok=%llu canon_sure=%llu full_sure=%llu fast_sure=%llu FAIL=%llu\n", name, (unsigned long long)s.cases,
-               (unsigned long long)s.oracle_ok, (unsigned long long)s.canon_sure, (unsigned long long)s.full_sure, (unsigned long long)s.fast_sure, (unsigned long long)s.fail);
+        printf("%-28s cases=%llu oracle_ok=%llu canon_sure=%llu full_sure=%llu fast_sure=%llu tmpl_mocker_sure=%llu tmpl_goflow_sure=%llu FAIL=%llu\n", name, (unsigned long long)s.cases,
+               (unsigned long long)s.oracle_ok, (unsigned long long)s.canon_sure, (unsigned long long)s.full_sure, (unsigned long long)s.fast_sure,
+               (unsigned long long)s.tm_sure, (unsigned long long)s.tg_sure, (unsigned long long)s.fail);
     };
     pr("generator (4 modes)", gen);
     pr("generator (goflow)", goflow);

@@ -28,6 +28,12 @@ def test_parsers_fuzz_against_oracle(po):
     for name in ("generator (4 modes)", "random schema, canonical small"):
         f = dict(kv.split("=") for kv in lines[name].split() if "=" in kv)
         assert f["canon_sure"] == f["cases"] and f["full_sure"] == f["cases"] and f["FAIL"] == "0", lines[name]
+    # the template walks take every record of the producer they are compiled for (mocker.go's field list: the mocker,
+    # ASPAIRS, ZIPF and DISTINCT generators; GoFlow's 33 fields: both)
+    f = dict(kv.split("=") for kv in lines["generator (4 modes)"].split() if "=" in kv)
+    assert f["tmpl_mocker_sure"] == f["cases"] and f["tmpl_goflow_sure"] == f["cases"], lines["generator (4 modes)"]
+    f = dict(kv.split("=") for kv in lines["generator (goflow)"].split() if "=" in kv)
+    assert f["tmpl_goflow_sure"] == f["cases"] and f["tmpl_mocker_sure"] == "0", lines["generator (goflow)"]
     # the 67-field producer (pb-ext/flow.pb.go:57-147): the FULL canonical walk must take every record
     for name in ("generator (goflow)", "67-field, canonical small"):
         f = dict(kv.split("=") for kv in lines[name].split() if "=" in kv)
