@@ -968,6 +968,7 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     a.buf = (const uint8_t*)d_buf;
     a.off = (const uint32_t*)d_off;
     a.n = (uint32_t)n;
+    a.len = (uint32_t)len;
     a.tile_recs = tile_recs_for(len, n);
     int grid = tile_grid<MODE_INGEST>(c, a.n, a.tile_recs);
     if (c->use_wave_tiles) {  // wave-private tiles: <= 64 records per wave, WBLOCK / 64 waves per workgroup, WT_WG_PER_CU workgroups per CU
@@ -1221,6 +1222,7 @@ extern "C" int fa_decode_device(fa_ctx* c, const void* d_buf, size_t len, const 
         a.buf = (const uint8_t*)d_buf;
         a.off = (const uint32_t*)d_off;
         a.n = (uint32_t)n;
+        a.len = (uint32_t)len;
         a.tile_recs = tile_recs_for(len, n);
         if (c->dev_used == c->dev_pool.size()) {
             if (c->dev_pool.size() >= 1024) {  // bound the pool: fold what is pending

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
     uint32_t tm_wait = 0, tm_work = 0, tm_tiles = 0;
     const uint32_t tm_start = timing ? (uint32_t)clock64() : 0u;
     for (; t < ntiles; t += stride) {
-        const bool cur_fits = tile_fits<TILE_BYTES>(cur);
+        const bool cur_sane = cur.hi >= cur.lo && cur.hi <= a.len;  // (bounds come from the caller: nothing beyond the buffer is ever read)
+        const bool cur_fits = cur_sane && tile_fits<TILE_BYTES>(cur);
         const uint32_t tm0 = timing ? (uint32_t)clock64() : 0u;
         // (1) stream this tile's wire bytes into LDS (async DMA) ...
         if (cur_fits) {
@@ -419,6 +420,11 @@ __global__ __launch_bounds__(BLOCK) void tile_kernel(KArgs a) {
                 a.exotic_idx[j] = cur.r0 + tid;
             }
             lane_work<MODE, KEYSETS, COLS>(a, lt, lm, part_cnt, tile, mine, o0 - cbase, o1 - cbase, cur.r0 + tid, tb_base, tally, pmode, lt_seen, lt_hits, nullptr, nullptr, no_fill);
+        } else if (!cur_sane) {  // broken bounds: every record of the tile to the generic path (which checks them one by one)
+            if (tid < cur.nrec) {
+                unsigned int j = atomicAdd(&a.ctr->exotic_count[a.par], 1u);
+                a.exotic_idx[j] = cur.r0 + tid;
+            }
         } else {
             // rare: the tile's bytes exceed the LDS buffer (big records): stage it in passes
             uint32_t done = 0;
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
     // the current tile (part): live = lanes whose record is still to be parsed
     Tile cur = tile_load(wave * gridDim.x + wg_pos);
     uint32_t cur_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.q0);
-    uint32_t cur_hi = cur.nrec ? (uint32_t)__builtin_amdgcn_readlane((int)cur.q1, (int)(cur.nrec - 1u)) : 0u;
+    uint32_t cur_hi = cur.nrec ? min((uint32_t)__builtin_amdgcn_readlane((int)cur.q1, (int)(cur.nrec - 1u)), a.len) : 0u;  // (bounds come from the caller: nothing beyond the buffer is ever read)
     bool live = lane < cur.nrec;
     __syncthreads();  // LDS state cleared
     // pipeline: at the top of a round the wave's tile is already on its way (issued right after the previous tile was
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
         const uint32_t t2 = tile_after_next();  // (an LDS atomic - before the DMA, or the compiler drains vmcnt for it)
         cur = nxt;
         cur_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.q0);
-        cur_hi = cur.nrec ? (uint32_t)__builtin_amdgcn_readlane((int)cur.q1, (int)(cur.nrec - 1u)) : 0u;
+        cur_hi = cur.nrec ? min((uint32_t)__builtin_amdgcn_readlane((int)cur.q1, (int)(cur.nrec - 1u)), a.len) : 0u;
         live = lane < cur.nrec;
         issue_dma(cur_lo, cur_hi);  // next tile (the buffer is free: every read of the old tile has returned)
         nxt = tile_load(t2);
@@ -813,9 +819,10 @@ __device__ __forceinline__ void exotic_pass(const KArgs& a) {
     const uint32_t cnt = a.ctr->exotic_count[a.par];
     for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < cnt; j += gridDim.x * BLOCK) {
         uint32_t idx = a.exotic_idx[j];
-        const uint8_t* p = a.buf + a.off[idx];
-        const uint8_t* end = a.buf + a.off[idx + 1];
-        bool ok = end >= p;
+        const uint32_t x0 = a.off[idx], x1 = a.off[idx + 1];
+        const uint8_t* p = a.buf + min(x0, a.len);
+        const uint8_t* end = a.buf + min(x1, a.len);
+        bool ok = x1 >= x0 && x1 <= a.len;  // (broken bounds: a bad record, never dereferenced)
         if (ok && a.framed) ok = frame_generic(p, end);
         Rec r;
         if (ok)
@@ -871,7 +878,7 @@ __global__ __launch_bounds__(BLOCK) void deferred_kernel(KArgs a) {
             idx = a.retry_idx[j];
             uint32_t pos = a.off[idx], end = a.off[idx + 1];
             GlobalSrc src{reinterpret_cast<const uint32_t*>(a.buf)};
-            sure = end >= pos;
+            sure = end >= pos && end <= a.len;
             if (sure && a.framed) {
                 uint32_t pl = 0;
                 sure = frame_fast(window64(src, pos), end - pos, pl);
@@ -879,9 +886,10 @@ __global__ __launch_bounds__(BLOCK) void deferred_kernel(KArgs a) {
             }
             if (sure) sure = parse_fast<COLS>(src, pos, end, r);
             if (!sure) {  // third tier, in place: the complete parser decides
-                const uint8_t* p = a.buf + a.off[idx];
-                const uint8_t* pe = a.buf + a.off[idx + 1];
-                bool ok = pe >= p;
+                const uint32_t x0 = a.off[idx], x1 = a.off[idx + 1];
+                const uint8_t* p = a.buf + min(x0, a.len);
+                const uint8_t* pe = a.buf + min(x1, a.len);
+                bool ok = x1 >= x0 && x1 <= a.len;
                 if (ok && a.framed) ok = frame_generic(p, pe);
                 if (ok) ok = parse_generic(p, pe, r);
                 if (!ok) rec_clear(r);

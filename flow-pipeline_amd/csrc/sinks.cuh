@@ -125,6 +125,7 @@ struct KArgs {
     const uint8_t* buf;   // 16-byte aligned device pointer
     const uint32_t* off;  // n+1 offsets
     uint32_t n;
+    uint32_t len;     // wire bytes in buf: record bounds beyond it are broken offsets (never dereferenced)
     uint32_t framed;
     uint32_t gran;
     Slot* tab;

@@ -8,8 +8,17 @@
 // ConsumerGroupHandler shape (Setup/Cleanup/ConsumeClaim, inserter.go:167-196).
 //
 // Differences from the reference, on purpose:
-//   - messages are marked AFTER fa_ingest returns (the reference marks before the
-//     insert, inserter.go:188: at-most-once on crash);
+//   - delivery: the reference marks a message before its row is inserted
+//     (inserter.go:188: at-most-once on crash).  Here a record sits in HBM until its
+//     5-minute window closes, so "the sink accepted it" has two meanings, chosen by
+//     -mark.after.close:
+//       true  (default): a flush batch is marked only once EVERY window that was open
+//              when it was ingested has been emitted (closeWindows) - a crash replays
+//              at most the batches whose windows had not reached the sink;
+//       false: marked as soon as fa_ingest returns (the reference's timing: what the
+//              GPU holds and has not emitted is lost with the process);
+//     a fatal sink error closes every partition's windows (best effort) before exit,
+//     and a claim that ends (rebalance) emits its partition's windows at once;
 //   - one fa_ctx per claimed partition, no global mutex (inserter.go:84,115);
 //   - insert_count is actually incremented (registered but never Inc()'d at
 //     inserter.go:44-49).
@@ -33,6 +42,7 @@ import (
 	"runtime"
 	"strings"
 	"sync"
+	"sync/atomic"
 	"syscall"
 	"time"
 	"unsafe"
@@ -71,6 +81,7 @@ var (
 	CloseLagSec = flag.Int("window.lag", 30, "Close a window this many seconds after it ended")
 	KeySets     = flag.Int("key.sets", 1, "fa key_sets mask (1 = flows_5m rollup; see include/flowagg.h)")
 	OutRowBin   = flag.String("out.rowbinary", "", "Append closed flows_5m rows to this file as ClickHouse RowBinary")
+	MarkAfter   = flag.Bool("mark.after.close", true, "Commit a batch's offsets only after every window it touched has been emitted")
 
 	Inserts = prometheus.NewCounter(prometheus.CounterOpts{Name: "insert_count", Help: "Flow messages aggregated on the GPU."})
 )
@@ -81,6 +92,15 @@ type partitionState struct {
 	buf     []byte   // message values back to back
 	offsets []uint64 // n+1 entries
 	pending []*sarama.ConsumerMessage
+	// -mark.after.close: flush batches whose records still sit in open windows, oldest first.  Offsets of one
+	// partition are monotone and MarkMessage commits "everything up to here", so a batch is one message (its
+	// last) plus the timeslots that were open right after it was ingested.
+	unmarked []batchMark
+}
+
+type batchMark struct {
+	last  *sarama.ConsumerMessage
+	slots map[uint32]bool
 }
 
 type state struct {
@@ -121,21 +141,28 @@ func (p *partitionState) flush(session sarama.ConsumerGroupSession) {
 	rc := C.fa_ingest(p.ctx, (*C.uint8_t)(unsafe.Pointer(&p.buf[0])), C.size_t(len(p.buf)),
 		(*C.uint64_t)(unsafe.Pointer(&p.offsets[0])), C.size_t(n))
 	if rc != 0 {
-		log.Fatalf("fa_ingest: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
+		sinkFatal("fa_ingest: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
 	}
 	Inserts.Add(float64(n))
-	for _, m := range p.pending {
-		session.MarkMessage(m, "") // after the sink accepted the batch
+	if *MarkAfter {
+		// the batch's records can only sit in timeslots that are open now
+		open := p.openTimeslots()
+		set := make(map[uint32]bool, len(open))
+		for _, ts := range open {
+			set[ts] = true
+		}
+		p.unmarked = append(p.unmarked, batchMark{last: p.pending[len(p.pending)-1], slots: set})
+	} else {
+		for _, m := range p.pending {
+			session.MarkMessage(m, "") // after fa_ingest accepted the batch (the reference's timing)
+		}
 	}
 	p.buf, p.offsets, p.pending = p.buf[:0], p.offsets[:1], p.pending[:0]
 }
 
-// closeWindows emits finished flows_5m rows (create.sh:70-90) as one RowBinary payload per window
-// (`INSERT INTO flows_5m FORMAT RowBinary`) instead of the reference's per-row db.Exec
-// (inserter.go:100-106).  Same logic as flow-pipeline_amd/host/inserter_gpu.cpp, which is built and tested.
-func (p *partitionState) closeWindows(now time.Time, all bool) {
-	// every open timeslot: retry with the size the library reports (a backlog replay can hold hundreds of windows);
-	// any other error is a sink error and fatal, like the reference's failed db.Exec (inserter.go:102-105)
+// openTimeslots lists the windows the context holds; retried with the size the library reports (a backlog
+// replay can hold hundreds of windows).  Errors are sink errors.
+func (p *partitionState) openTimeslots() []uint32 {
 	slots := make([]C.uint32_t, 64)
 	var ns C.size_t
 	rc := C.fa_open_timeslots(p.ctx, &slots[0], C.size_t(len(slots)), &ns)
@@ -144,10 +171,73 @@ func (p *partitionState) closeWindows(now time.Time, all bool) {
 		rc = C.fa_open_timeslots(p.ctx, &slots[0], C.size_t(len(slots)), &ns)
 	}
 	if rc != 0 {
-		log.Fatalf("fa_open_timeslots: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
+		sinkFatal("fa_open_timeslots: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
 	}
-	for i := 0; i < int(ns); i++ {
-		ts := uint32(slots[i])
+	out := make([]uint32, int(ns))
+	for i := range out {
+		out[i] = uint32(slots[i])
+	}
+	return out
+}
+
+// markEmitted commits the batches (oldest first) none of whose windows is open any more.
+func (p *partitionState) markEmitted(session sarama.ConsumerGroupSession) {
+	if len(p.unmarked) == 0 || session == nil {
+		return
+	}
+	open := make(map[uint32]bool)
+	for _, ts := range p.openTimeslots() {
+		open[ts] = true
+	}
+	done := 0
+	for _, b := range p.unmarked {
+		still := false
+		for ts := range b.slots {
+			if open[ts] {
+				still = true
+				break
+			}
+		}
+		if still {
+			break // offsets commit in order: a later batch cannot overtake this one
+		}
+		session.MarkMessage(b.last, "")
+		done++
+	}
+	p.unmarked = p.unmarked[done:]
+}
+
+// A sink error is fatal like the reference's failed db.Exec (inserter.go:102-105) - but the other partitions'
+// contexts hold aggregates too.  A context is not thread-safe, so nobody closes another goroutine's windows: the
+// failing goroutine raises `dying`, every ConsumeClaim loop notices it within a second, emits what its own context
+// holds (closeWindows(all)) and returns; the failing goroutine waits for them (bounded) and then exits the process.
+var (
+	dying        int32 // 1 once a sink error has been seen
+	activeClaims int32 // goroutines inside ConsumeClaim
+)
+
+func sinkFatal(format string, args ...interface{}) {
+	msg := fmt.Sprintf(format, args...)
+	if atomic.CompareAndSwapInt32(&dying, 0, 1) {
+		log.Error(msg)
+		deadline := time.Now().Add(10 * time.Second)
+		for atomic.LoadInt32(&activeClaims) > 1 && time.Now().Before(deadline) {
+			time.Sleep(50 * time.Millisecond)
+		}
+		log.Fatal(msg)
+	}
+	// a second failure while the process is going down: this goroutine just stops (deferred calls run)
+	log.Error(msg)
+	runtime.Goexit()
+}
+
+// closeWindows emits finished flows_5m rows (create.sh:70-90) as one RowBinary payload per window
+// (`INSERT INTO flows_5m FORMAT RowBinary`) instead of the reference's per-row db.Exec
+// (inserter.go:100-106).  Same logic as flow-pipeline_amd/host/inserter_gpu.cpp, which is built and tested.
+func (p *partitionState) closeWindows(now time.Time, all bool) {
+	// any error below is a sink error and fatal, like the reference's failed db.Exec (inserter.go:102-105)
+	slots := p.openTimeslots()
+	for _, ts := range slots {
 		if !all && int64(ts)+int64(*WindowSecs)+int64(*CloseLagSec) > now.Unix() {
 			continue
 		}
@@ -159,21 +249,21 @@ func (p *partitionState) closeWindows(now time.Time, all bool) {
 			rc = C.fa_close_window(p.ctx, C.uint32_t(ts), &rows[0], C.size_t(len(rows)), &nr)
 		}
 		if rc != 0 {
-			log.Fatalf("fa_close_window: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
+			sinkFatal("fa_close_window: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
 		}
 		log.Infof("flows_5m timeslot %d: %d rows", ts, int(nr))
 		if *OutRowBin != "" && nr > 0 {
 			buf := make([]byte, int(nr)*C.FA_ROWBINARY_ROW5M_BYTES)
 			var nb C.size_t
 			if rc := C.fa_rows_to_rowbinary(&rows[0], nr, (*C.uint8_t)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)), &nb); rc != 0 {
-				log.Fatalf("fa_rows_to_rowbinary: %d", int(rc))
+				sinkFatal("fa_rows_to_rowbinary: %d", int(rc))
 			}
 			f, err := os.OpenFile(*OutRowBin, os.O_APPEND|os.O_CREATE|os.O_WRONLY, 0644)
 			if err != nil {
-				log.Fatal(err)
+				sinkFatal("%v", err)
 			}
 			if _, err = f.Write(buf[:int(nb)]); err != nil {
-				log.Fatal(err)
+				sinkFatal("%v", err)
 			}
 			f.Close()
 		}
@@ -201,12 +291,27 @@ func (s *state) ConsumeClaim(session sarama.ConsumerGroupSession, claim sarama.C
 	// threads would drag other partitions' state along
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
+	atomic.AddInt32(&activeClaims, 1)
+	defer atomic.AddInt32(&activeClaims, -1)
 	timer := time.NewTimer(*FlushTime)
+	alive := time.NewTicker(time.Second)
+	defer alive.Stop()
 	for {
+		if atomic.LoadInt32(&dying) != 0 { // another partition hit a sink error: emit what this context holds, then stop
+			p.flush(session)
+			p.closeWindows(time.Now().UTC(), true)
+			p.markEmitted(session)
+			return nil
+		}
 		select {
+		case <-alive.C:
 		case message, open := <-claim.Messages():
 			if !open {
+				// the claim ends (rebalance / shutdown): whoever owns the partition next starts from the committed
+				// offsets, so what this context holds goes to the sink now and its batches are committed
 				p.flush(session)
+				p.closeWindows(time.Now().UTC(), true)
+				p.markEmitted(session)
 				return nil
 			}
 			p.buf = append(p.buf, message.Value...)
@@ -218,6 +323,7 @@ func (s *state) ConsumeClaim(session sarama.ConsumerGroupSession, claim sarama.C
 		case <-timer.C: // inserter.go:189-191
 			p.flush(session)
 			p.closeWindows(time.Now().UTC(), false)
+			p.markEmitted(session)
 			timer.Reset(*FlushTime)
 		}
 	}
@@ -264,8 +370,8 @@ func main() {
 		log.Fatal(fmt.Sprintf("Error closing client: %v", err))
 	}
 	for _, p := range s.parts {
-		// the offsets of everything ingested are committed: what the GPU still holds must reach the sink before the
-		// contexts go away (the C++ twin: CloseAllAtEnd)
+		// what the GPU still holds must reach the sink before the contexts go away (the C++ twin: CloseAllAtEnd);
+		// claims that ended have emitted already (ConsumeClaim), this is the safety net
 		p.closeWindows(time.Now().UTC(), true)
 		C.fa_destroy(p.ctx)
 	}

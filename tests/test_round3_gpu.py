@@ -234,3 +234,41 @@ def test_count_min_scatter_sink_segment_overflow_is_bit_exact(gpu_lib, fa, po, m
         ref.ingest(buf, off, 1)
         assert agg.read_window().tobytes() == ref.rows().tobytes()
         assert agg.stats()["wave_tile_launches"] == 1
+
+
+@pytest.mark.parametrize("n", [3000, 200_000])
+def test_broken_device_offsets_are_bad_records_not_faults(gpu_lib, fa, po, n):
+    """fa_ingest_device trusts nobody's offsets: bounds beyond the buffer or running backwards make the records that own
+    them bad (counted, dropped) - nothing outside the buffer is read - and every other record of the batch, including the
+    rest of a tile whose first or last bound is broken, is aggregated exactly (wave-tile kernel and workgroup-tile kernel)."""
+    import torch
+    gp = po.gen_params(mode=po.GEN_ASPAIRS, framed=1, seed=44, n_total=n, span_secs=600)
+    buf, off = po.gen_records(gp, 0, n)
+    off32 = off.astype(np.uint32)
+    rng = np.random.default_rng(3)
+    picks = np.sort(rng.choice(np.arange(2, n - 2, 3), size=min(200, n // 20), replace=False))
+    picks = np.concatenate([picks, [64, 128, 191]]) if n > 1000 else picks   # tile boundaries of the wave-tile kernel among them
+    picks = np.unique(picks)
+    broken = off32.copy()
+    kinds = rng.integers(0, 3, len(picks))
+    for k, kind in zip(picks, kinds):
+        broken[k] = [np.uint32(len(buf) + 5000), np.uint32(0xfffffff0), np.uint32(max(int(off32[k]) - 5000, 0) if off32[k] > 5000 else len(buf) + 77)][kind]
+    bad_recs = set()
+    for k in picks:
+        bad_recs.add(int(k) - 1)
+        bad_recs.add(int(k))
+    good = np.array(sorted(set(range(n)) - bad_recs))
+    ref = po.Rollup(300)
+    raw = bytes(buf)
+    recs = [raw[int(off[i]):int(off[i + 1])] for i in good]
+    o = np.zeros(len(recs) + 1, dtype=np.uint64)
+    o[1:] = np.cumsum([len(r) for r in recs])
+    assert ref.ingest(np.frombuffer(b"".join(recs), dtype=np.uint8), o, 1) == 0
+    with fa.FlowAgg(framed=True, max_batch_records=n) as agg:
+        d_buf = torch.zeros(len(buf) + 64, dtype=torch.uint8, device="cuda")
+        d_buf[:len(buf)] = torch.from_numpy(np.ascontiguousarray(buf)).cuda()
+        d_off = torch.from_numpy(broken.view(np.int32)).cuda()
+        agg.ingest_device(d_buf.data_ptr(), len(buf), d_off.data_ptr(), n)
+        st = agg.stats()
+        assert st["records_bad"] == len(bad_recs) and st["records_ok"] == n - len(bad_recs), (st["records_bad"], len(bad_recs), st["records_ok"])
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
