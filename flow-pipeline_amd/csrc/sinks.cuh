@@ -813,6 +813,8 @@ __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t
             if ((line + 1u) * TB <= a.capf) {
                 // (compact tuples: region and capq are even, so the segment starts on a uint4 boundary)
                 const size_t seg0 = ((size_t)fp * a.region + (size_t)blockIdx.x * a.capq) >> (T8 ? 1 : 0);
+                // (plain stores: the L2 merges the half lines of a bin's two flushes and the back parts' single tuples before
+                // they go to HBM - streaming (nt) stores measured 6-11 % slower on BASELINE config 2, round 3)
                 if (!(FA_DBG(a, DBG_NO_TUPLE_STORE))) a.seg[seg0 + line * BL + sub] = tv;
             } else {  // front part full (skewed batch): straight to the device-wide table
                 TupleVals v[2];

@@ -1,12 +1,14 @@
 #!/bin/bash
 # Instruction counts of the wave-tile kernel per section, by ablation (FA_DEBUG_FLAGS): one PMC pass per flag set.
+# The switches are compiled out of the production library: build the measurement variant first
+#   make -C flow-pipeline_amd/csrc OUT=../libflowagg_ablate.so EXTRA=-DFA_ABLATE=1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/inst
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 for f in ${FLAGS:-0 16 1 17}; do
-  FA_DEBUG_FLAGS=$f rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/f$f -o p -- \
+  FA_LIB_VARIANT=ablate FA_DEBUG_FLAGS=$f rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/f$f -o p -- \
     python $ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-verify --no-host-fed --no-assert $BENCH_ARGS > $OUT/f$f.log 2>&1
 done
 cd $ROOT
