@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--key-sets", type=int, default=1, help="fa key_sets mask (must include 1 = flows_5m rollup); 9 = config 5's "
                     "two concurrent key sets; side measurements only - the default is the BASELINE metric")
     ap.add_argument("--zipf-s", type=int, default=110, help="zipf exponent x100 for --mode zipf")
+    ap.add_argument("--zipf-universe-log2", type=int, default=24, help="address universe of --mode zipf (side measurements)")
     ap.add_argument("--no-verify", action="store_true", help="skip the full-step parity check against the oracle")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive fa_ingest measurement")
     ap.add_argument("--no-assert", action="store_true", help="ablation runs (FA_DEBUG_FLAGS): skip result checks")
@@ -237,13 +238,13 @@ def main():
     n_rec = args.records
     # every rank = one Kafka partition with its own stream (seed 2 = config 2, + rank)
     mp = fa.mock_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000,
-                        zipf_s_x100=args.zipf_s)
+                        zipf_s_x100=args.zipf_s, zipf_log2_universe=args.zipf_universe_log2)
     assert args.key_sets & fa.FA_KEYS_AS_PAIR, "--key-sets must include the flows_5m rollup"
 
     def new_ctx():
         return fa.FlowAgg(device=local_rank, framed=True, table_capacity_log2=20, key_sets=args.key_sets,
                           max_batch_records=args.chunk, wide_capacity_log2=26 if args.key_sets & 8 else 0,
-                          topk_capacity_log2=25 if args.key_sets & 6 else 0)  # distinct addresses: 2^24 in the zipf / aspairs generators
+                          topk_capacity_log2=max(args.zipf_universe_log2 + 1, 25 if args.zipf_universe_log2 == 24 else args.zipf_universe_log2 + 2) if args.key_sets & 6 else 0)  # distinct addresses: the universe in v4 and v6 form (2^25 slots at the default universe, as in rounds 1-2)
 
     agg = new_ctx()
     chunks = []
@@ -438,7 +439,8 @@ def main():
         # device merge) against the oracle's rollup of ALL partitions (every rank's oracle rows gathered, merged with
         # numpy, sums x the number of steps ingested) - byte for byte.
         po = _pkg.load_oracle()
-        gp = po.gen_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000, zipf_s_x100=args.zipf_s)
+        gp = po.gen_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000, zipf_s_x100=args.zipf_s,
+                           zipf_log2_universe=args.zipf_universe_log2)
         threads = max(1, min(effective_cpus()[0] // world, 64))
         ok = True
         verified = 0
@@ -483,7 +485,8 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         po = _pkg.load_oracle()
-        gp = po.gen_params(mode=mode, framed=1, seed=2, n_total=n_rec, span_secs=900, per_sec=400_000, zipf_s_x100=args.zipf_s)
+        gp = po.gen_params(mode=mode, framed=1, seed=2, n_total=n_rec, span_secs=900, per_sec=400_000, zipf_s_x100=args.zipf_s,
+                           zipf_log2_universe=args.zipf_universe_log2)
         out["cpu_baseline"] = cpu_baseline(po, gp, min(args.cpu_sample, n_rec), n_rec, int(len(merged)))
 
     if rank == 0 and world == 1 and not args.no_host_fed and not args.no_assert:

@@ -463,12 +463,18 @@ __device__ __forceinline__ KsProbe keyset_probe(const KArgs& a, KeySlot* tab, ui
 __device__ __forceinline__ void keyset_insert_slow(const KArgs& a, KeySlot* tab, unsigned long long lo, unsigned long long hi, unsigned long long mytag, uint32_t i) {
     for (int probe = 0; probe < 256; probe++, i = (i + 1) & a.ks_mask) {
         KeySlot* s = &tab[i];
-        // fastest path: the key is already there and this XCD's L2 knows it.  Plain (cached) loads may be stale,
-        // but a slot never changes once READY, so a complete match is always true; anything else is looked at
-        // again through the memory side below.
+        // fastest paths, on plain (cached) loads.  They may be stale - but stale only ever means OLDER, and a slot never
+        // changes once READY: a READY slot seen here is final.  So (a) a complete match is always true, and (b) a READY
+        // slot that holds another tag (a displaced key walks over those: ~12 % of the probes at a quarter load) or the
+        // same tag with another key is skipped without consulting the memory side - round 2 paid a system-scope load, a
+        // ~2 us round trip, for every occupied slot a displaced key walked over; the ingest kernel spent a third of
+        // its time there (profiles/r03_config3_ablation.txt).  Only EMPTY or claimed-but-not-ready views go on below.
         {
             const ulonglong2 c01 = *reinterpret_cast<const ulonglong2*>(&s->tag);  // tag, lo
-            if (c01.x == (mytag | KS_READY) && c01.y == lo && s->hi == hi) return;
+            if (c01.x & KS_READY) {
+                if (c01.x == (mytag | KS_READY) && c01.y == lo && s->hi == hi) return;
+                continue;
+            }
         }
         // the key may be there: system-scope loads are served by the memory side, past the (incoherent) per-XCD
         // L2s

@@ -272,3 +272,25 @@ def test_broken_device_offsets_are_bad_records_not_faults(gpu_lib, fa, po, n):
         st = agg.stats()
         assert st["records_bad"] == len(bad_recs) and st["records_ok"] == n - len(bad_recs), (st["records_bad"], len(bad_recs), st["records_ok"])
         assert agg.read_window().tobytes() == ref.rows().tobytes()
+
+
+def test_sketch_error_bound_at_100M_records(gpu_lib):
+    """the epsilon bound of the prefix-partitioned Count-Min sketch checked inside the suite at >= 100 M records
+    (tools/config3_run.py, the runner of the 1 B-record evidence, on a 117 M-record Zipf-1.1 stream): both sketches
+    bit-exact against the CPU sketch on the 100 M prefix and on the whole stream, top-100 == the ranking of the whole
+    2^25-address universe, estimates never below the exact GROUP BY weight and within eps * total weight (eps = e / width)
+    for at least 1 - e^-depth of the addresses."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "config3_run.py"), "--records", "116666669", "--prefix", "100000000"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["prefix_records"] >= 100_000_000 and out["records"] == 116666669
+    assert out["sketch_bit_exact_prefix"] and out["sketch_bit_exact_full_stream"] and out["top100_equals_ranking_of_the_whole_universe"]
+    for tag in ("src", "dst"):
+        assert out["prefix_%s_never_underestimates" % tag]
+        assert out["prefix_%s_share_within_eps" % tag] >= out["prefix_%s_required_share" % tag]

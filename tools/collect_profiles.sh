@@ -1,11 +1,11 @@
 #!/bin/bash
-# Copies the evidence of a tools/gpu_session.sh run (gpurun_out/<tag>/, gpurun_out/prof/<tag>/) into profiles/ (tracked).
-TAG=${1:-r02}
+# Copies the evidence of a tools/gpu_session.sh run (gpurun_out/<tag>/, gpurun_out/prof/<tag>*/) into profiles/ (tracked).
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 S=$ROOT/gpurun_out/$TAG
 P=$ROOT/gpurun_out/prof/$TAG
 D=$ROOT/profiles
-grep '^{' $S/bench_default.json | tail -1 > $D/${TAG}_bench_default.json
+[ -s $S/bench_default.json ] && grep '^{' $S/bench_default.json | tail -1 > $D/${TAG}_bench_default.json
 : > $D/${TAG}_bench_side_measurements.jsonl
 for f in $S/bench_*.json; do
   n=$(basename $f .json); n=${n#bench_}
@@ -13,12 +13,13 @@ for f in $S/bench_*.json; do
   l=$(grep '^{' $f | tail -1)
   [ -n "$l" ] && echo "{\"run\": \"$n\", \"line\": $l}" >> $D/${TAG}_bench_side_measurements.jsonl
 done
-cp $P/summary.txt $D/${TAG}_rocprof_summary.txt
-cp $P/traffic.json $D/${TAG}_traffic.json
-for v in ks7 ks9; do  # profiles of the sketch variant (config 3 shape) and of the (SrcAddr,DstPort,Proto) sink (tools/profile.sh <tag>_<v> ...)
+[ -s $P/summary.txt ] && cp $P/summary.txt $D/${TAG}_rocprof_summary.txt
+[ -s $P/traffic.json ] && cp $P/traffic.json $D/${TAG}_traffic.json
+for v in decode goflow reversed ks7 ks9; do  # projection stage, collector-shaped producers, sketch variant (config 3 shape), (SrcAddr,DstPort,Proto) sink
   [ -s ${P}_$v/summary.txt ] && cp ${P}_$v/summary.txt $D/${TAG}_${v}_rocprof_summary.txt
 done
-[ -s $S/config3_1B.json ] && grep '^{' $S/config3_1B.json | tail -1 > $D/${TAG}_config3_1B.json
-[ -s $S/config4_8ranks_1gpu.json ] && grep '^{' $S/config4_8ranks_1gpu.json | tail -1 > $D/${TAG}_config4_8ranks_1gpu.json
-[ -s $S/config5_100M.json ] && grep '^{' $S/config5_100M.json | tail -1 > $D/${TAG}_config5_100M.json
+[ -s $S/pcie_rate.json ] && cp $S/pcie_rate.json $D/${TAG}_pcie_rate.json
+for f in config3_1B config4_8ranks_1gpu config5_100M config5_8ranks_1gpu; do
+  [ -s $S/$f.json ] && grep '^{' $S/$f.json | tail -1 > $D/${TAG}_$f.json
+done
 ls -la $D/${TAG}_*

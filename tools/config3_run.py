@@ -19,6 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import _pkg  # noqa: E402
+from bench import effective_cpus  # noqa: E402  (CPUs this process can really use: affinity cut by the cgroup quota)
 
 
 def mix64(z):
@@ -81,7 +82,7 @@ def main():
     dev = torch.device("cuda", 0)
     n, L = args.records, args.universe_log2
     depth, wl2, seed = 4, 20, 0x5EED
-    threads = args.threads or min(64, len(os.sched_getaffinity(0)))
+    threads = args.threads or min(64, effective_cpus()[0])
     KS = (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS)
     mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=3, n_total=n, span_secs=900, zipf_log2_universe=L, zipf_s_x100=110)
     gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=3, n_total=n, span_secs=900, zipf_log2_universe=L, zipf_s_x100=110)

@@ -8,10 +8,11 @@ or scaling (the driver's bench.py --gpus 8 does).  Partition p = the 4 M-record 
 Checks at window close (CPU side = oracle/, on rank 0):
   * merged sketches (all-reduce of the 8 ranks' sketches into each rank's merged view) BIT-EXACT against the CPU sketch
     of the whole 1 B-record stream, identical on every rank;
-  * merged top-100 (every rank's distinct addresses exchanged, ranked by the merged estimate) == the ranking of the whole
-    address universe by the CPU sketch, identical on every rank;
-  * merged flows_5m rows (all-gather + fold) == the C oracle's rollup of the whole stream (row count, order-independent
-    checksum over keys and sums), identical on every rank.
+  * merged top-100 (every rank ranks ITS distinct addresses by the merged estimate and sends its first 100 rows; the
+    union is merged on the device - exact, see dist.topk_merged) == the ranking of the whole address universe by the CPU
+    sketch, identical on every rank;
+  * merged flows_5m rows (device buffers gathered, merged by fa_rows_merge_device) == the C oracle's rollup of the whole
+    stream (row count, order-independent checksum over keys and sums), identical on every rank.
 Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P tools/config4_run.py
 Prints one JSON line on rank 0 (commit it under profiles/)."""
 import argparse
@@ -27,6 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _pkg  # noqa: E402
+from bench import effective_cpus  # noqa: E402  (CPUs this process can really use: affinity cut by the cgroup quota)
 from config3_run import estimates, universe_keys  # noqa: E402
 from config5_run import checksum  # noqa: E402
 
@@ -53,7 +55,7 @@ def main():
     nchunks = (n + args.chunk - 1) // args.chunk
     out = {"config": "BASELINE configs[3] on one GPU: %d ranks (one context each, gloo exchange) x partitions of a %d-record Zipf-1.1 stream "
                      "(2^%d addresses, chunks of %d records dealt round-robin), key sets flows_5m + both sketches (depth %d x 2^%d); "
-                     "merge at window close: sketches all-reduced into the merged view, distinct addresses and rows all-gathered"
+                     "merge at window close: sketches all-reduced into the merged view, each rank's top rows and flows_5m rows gathered and merged on the device"
                      % (world, n, L, args.chunk, depth, wl2)}
     with fa.FlowAgg(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=L + 2,
                     max_batch_records=args.chunk) as agg:
@@ -110,7 +112,7 @@ def main():
             "flows_5m_rows": int(len(rows)),
         })
         assert out["records"] == n
-        threads = min(64, len(os.sched_getaffinity(0)))
+        threads = min(64, effective_cpus()[0])
         t0 = time.perf_counter()
         words = depth << wl2
         c_src = np.zeros(words, dtype=np.uint64)

@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _pkg  # noqa: E402
+from bench import effective_cpus  # noqa: E402  (CPUs this process can really use: affinity cut by the cgroup quota)
 from config5_run import checksum  # noqa: E402
 
 
@@ -128,7 +129,7 @@ def main():
             "flows_5m_rows": int(len(allrows)), "app_rows": int(nrows), "sliding_window_rows": int(len(slide5m)), "sliding_window_app_rows": int(len(slide_app)),
         })
         assert out["records"] == n
-        threads = min(64, len(os.sched_getaffinity(0)))
+        threads = min(64, effective_cpus()[0])
         t0c = time.perf_counter()
         ref = po.bench_rollup(gp, 0, n, threads)
         out["flows_5m_aligned_windows_bit_exact"] = bool(ref["bad"] == 0 and ref["groups"] == len(allrows) and checksum(allrows) == ref["checksum"]

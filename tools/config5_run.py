@@ -19,6 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import _pkg  # noqa: E402
+from bench import effective_cpus  # noqa: E402  (CPUs this process can really use: affinity cut by the cgroup quota)
 
 
 def mix64(z):
@@ -56,7 +57,7 @@ def main():
     fa.build()
     dev = torch.device("cuda", 0)
     n = args.records
-    threads = min(64, len(os.sched_getaffinity(0)))
+    threads = min(64, effective_cpus()[0])
     mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=5, n_total=n, span_secs=args.span, zipf_log2_universe=args.universe_log2, zipf_s_x100=80)
     gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=5, n_total=n, span_secs=args.span, zipf_log2_universe=args.universe_log2, zipf_s_x100=80)
     ks = fa.FA_KEYS_AS_PAIR | fa.FA_KEYS_ADDR_PORT_PROTO

@@ -2,7 +2,7 @@
 # rocprofv3 evidence for bench.py (run on the GPU box via gpurun).  Separate passes: kernel trace +
 # stats, then one PMC pass per counter group (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950;
 # PMC passes never carry sys/hip/hsa trace options).  Output: gpurun_out/prof/<tag>/...
-TAG=${1:-r02}
+TAG=${1:-r03}
 shift
 ARGS=${@:---steps 3 --warmup 1 --cpu-sample 0 --no-verify --no-host-fed}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
