@@ -1,7 +1,8 @@
 """RCCL on the GPU box (1 GPU => world size 1): the window-close exchange of dist.py through the `nccl` backend on
-library-owned device buffers - in-place all-reduce of the sketches and dense port histograms, all-gather of
-compacted rows - must leave the single-rank results untouched, bit for bit.  (World size 2 is covered by the
-gloo tests on CPU; 8-GPU runs belong to the driver.)"""
+library-owned device buffers - out-of-place all-reduce of the sketches into the merged view, uneven all-gather of
+every row kind's device buffer (fa_rows_device) followed by fa_rows_merge_device - must reproduce the single-rank
+results bit for bit.  (The same code with two ranks runs over the gloo transport on the shared GPU in
+test_round2_gpu.py, the device merge of two contexts' rows in test_round3_gpu.py; 8-GPU runs belong to the driver.)"""
 import os
 import subprocess
 import sys
@@ -30,7 +31,7 @@ with fa.FlowAgg(framed=True, key_sets=ks, cms_width_log2=12, topk_capacity_log2=
     agg.ingest(buf, off)
     before = [agg.cms_read(k).copy() for k in (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS)]
     ports = [agg.top_ports(d) for d in (0, 1)]
-    fa.dist.allreduce_sketches(agg)                      # RCCL all-reduce in place, world 1: identity
+    fa.dist.allreduce_sketches(agg)                      # RCCL all-reduce into the merged view, world 1: identity
     after = [agg.cms_read(k) for k in (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS)]
     assert all(np.array_equal(a, b) for a, b in zip(before, after))
     assert all(fa.dist.top_ports_merged(agg, d, device=dev).tobytes() == ports[d].tobytes() for d in (0, 1))

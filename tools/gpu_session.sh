@@ -12,7 +12,7 @@ cd $ROOT
 export TMPDIR=/tmp
 if [ -z "$SKIP_TESTS" ]; then
   ( time timeout 1500 python -m pytest tests -m gpu -q ) > $OUT/pytest.log 2>&1
-  tail -4 $OUT/pytest.log
+  grep -E "passed|failed|error" $OUT/pytest.log | tail -3
 fi
 if [ -z "$ONLY_FULL" ]; then
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
@@ -49,6 +49,7 @@ PY
   timeout 2400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port $(port) tools/config4_run.py > $OUT/config4_8ranks_1gpu.json 2> $OUT/config4_8ranks_1gpu.err; echo "config4 rc=$?"
   for f in config5_100M config3_1B config5_8ranks_1gpu config4_8ranks_1gpu; do echo "== $f"; grep '^{' $OUT/$f.json | tail -1 | cut -c1-1500; tail -3 $OUT/$f.err; done
 fi
+du -sh $ROOT/gpurun_out 2>/dev/null
 for f in $OUT/bench_*.json; do echo "== $f"; python - "$f" <<'PY'
 import json,sys
 try:

@@ -25,3 +25,6 @@ fi
 cd $ROOT
 PROF_BENCH_ARGS="$ARGS" python $ROOT/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# (gpurun copies at most 64 MiB back: the databases stay on the box, the summary and traffic.json travel)
+find $OUT -name "*.db" -delete 2>/dev/null
+find $OUT -type f -size +2M -delete 2>/dev/null
