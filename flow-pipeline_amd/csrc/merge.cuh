@@ -59,6 +59,11 @@ struct RowOps<RK_5M> {
         a.packets += b.packets;
         a.count += b.count;
     }
+    __device__ static void add_atomic(Row& a, const Row& b) {
+        atomicAdd(&a.bytes, b.bytes);
+        atomicAdd(&a.packets, b.packets);
+        atomicAdd(&a.count, b.count);
+    }
     __device__ static void finish(Row& r, uint32_t fold) {
         if (fold != 0xffffffffu) r.timeslot = fold;
         r.date = r.timeslot / 86400u;
@@ -90,6 +95,11 @@ struct RowOps<RK_APP> {
         a.packets += b.packets;
         a.count += b.count;
     }
+    __device__ static void add_atomic(Row& a, const Row& b) {
+        atomicAdd(&a.bytes, b.bytes);
+        atomicAdd(&a.packets, b.packets);
+        atomicAdd(&a.count, b.count);
+    }
     __device__ static void finish(Row& r, uint32_t fold) {
         if (fold != 0xffffffffu) r.timeslot = fold;
         r.date = r.timeslot / 86400u;
@@ -109,6 +119,10 @@ struct RowOpsW {
     __device__ static void add(Row& a, const Row& b) {
         a.weight += b.weight;
         a.count += b.count;
+    }
+    __device__ static void add_atomic(Row& a, const Row& b) {
+        atomicAdd(&a.weight, b.weight);
+        atomicAdd(&a.count, b.count);
     }
     __device__ static void finish(Row& r, uint32_t) { r.pad = 0; }
 };
@@ -130,6 +144,7 @@ struct RowOpsTopk {
     __host__ __device__ static int bits2(int) { return 64; }
     __device__ static bool same(const Row& a, const Row& b, uint32_t) { return a.lo == b.lo && a.hi == b.hi; }
     __device__ static void add(Row& a, const Row& b) { a.weight = a.weight > b.weight ? a.weight : b.weight; }
+    __device__ static void add_atomic(Row& a, const Row& b) { atomicMax(&a.weight, b.weight); }
     __device__ static void finish(Row&, uint32_t) {}
 };
 template <>
@@ -154,16 +169,34 @@ __global__ void row_heads_kernel(const typename RowOps<KIND>::Row* rows, const u
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         flags[i] = (i == 0 || !RowOps<KIND>::same(rows[idx[i]], rows[idx[i - 1]], fold)) ? 1u : 0u;
 }
-// one thread per run: sum its rows, write the group's row
+// One thread per run sums its rows and writes the group's row.  Runs are as long as there are ranks x sub-buckets -
+// short - but the input of fa_rows_merge_device is the caller's: a head only walks the first RUN_SERIAL rows of its
+// run; what lies beyond (row_tail_kernel, launched only when a longer run exists) is added by the rows themselves
+// with memory-side atomics, so a degenerate input (every row the same key) costs n atomics, not one thread's n steps.
+constexpr uint32_t RUN_SERIAL = 32;
 template <int KIND>
 __global__ void row_reduce_kernel(const typename RowOps<KIND>::Row* rows, const uint32_t* idx, const uint32_t* flags, const uint32_t* pos,
-                                  uint32_t n, uint32_t fold, typename RowOps<KIND>::Row* out) {
+                                  uint32_t n, uint32_t fold, typename RowOps<KIND>::Row* out, unsigned int* long_runs) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (!flags[i]) continue;
         typename RowOps<KIND>::Row acc = rows[idx[i]];
-        for (uint32_t j = i + 1; j < n && !flags[j]; j++) RowOps<KIND>::add(acc, rows[idx[j]]);
+        uint32_t j = i + 1;
+        for (; j < n && j < i + RUN_SERIAL && !flags[j]; j++) RowOps<KIND>::add(acc, rows[idx[j]]);
+        if (j < n && !flags[j]) atomicAdd(long_runs, 1u);  // (the run goes on: row_tail_kernel adds the rest)
         RowOps<KIND>::finish(acc, fold);
         out[pos[i]] = acc;
+    }
+}
+// rows that sit RUN_SERIAL or more rows behind their run's head (no head among the RUN_SERIAL - 1 rows before them)
+template <int KIND>
+__global__ void row_tail_kernel(const typename RowOps<KIND>::Row* rows, const uint32_t* idx, const uint32_t* flags, const uint32_t* pos,
+                                uint32_t n, typename RowOps<KIND>::Row* out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (flags[i]) continue;
+        bool covered = false;
+        for (uint32_t b = 1; b < RUN_SERIAL && b <= i && !covered; b++) covered = flags[i - b] != 0u;
+        if (covered) continue;
+        RowOps<KIND>::add_atomic(out[pos[i] - 1u], rows[idx[i]]);  // (pos = heads before row i: its group is the last of them)
     }
 }
 template <class Row>

@@ -294,3 +294,51 @@ def test_sketch_error_bound_at_100M_records(gpu_lib):
     for tag in ("src", "dst"):
         assert out["prefix_%s_never_underestimates" % tag]
         assert out["prefix_%s_share_within_eps" % tag] >= out["prefix_%s_required_share" % tag]
+
+
+def test_rows_merge_device_long_runs(gpu_lib, fa):
+    """Degenerate input of fa_rows_merge_device: thousands of rows with ONE key (and a second key with a medium run) - the
+    heads sum the first rows of a run, the rest is added by the rows themselves with atomics; sums wrap mod 2^64."""
+    import torch
+    M = 2**64
+    rng = np.random.default_rng(11)
+    with fa.FlowAgg(framed=True, key_sets=63, cms_width_log2=10, topk_capacity_log2=10) as agg:
+        def merged(kind, rows):
+            t = torch.from_numpy(np.ascontiguousarray(rows).view(np.uint8).reshape(-1).copy()).cuda()
+            ptr, m = agg.rows_merge_device(kind, t.data_ptr(), len(rows))
+            return agg.rows_fetch(kind, ptr, m)
+        n = 20000
+        which = np.where(np.arange(n) % 400 == 7, 1, 0)           # key 1: a run of 50 rows; key 0: the rest
+        r = np.zeros(n, dtype=fa.ROW5M_DTYPE)
+        r["timeslot"] = 600
+        r["date"] = 0
+        r["src_as"] = which
+        r["bytes"] = rng.integers(0, 2**64, n, dtype=np.uint64)
+        r["packets"] = rng.integers(0, 1000, n, dtype=np.uint64)
+        r["count"] = 1
+        got = merged(fa.ROWS_5M, r)
+        assert len(got) == 2 and list(got["src_as"]) == [0, 1]
+        for k in (0, 1):
+            sel = r[which == k]
+            assert int(got["bytes"][k]) == int(sum(int(x) for x in sel["bytes"]) % M)
+            assert int(got["packets"][k]) == int(sel["packets"].sum()) and int(got["count"][k]) == len(sel)
+        a = np.zeros(n, dtype=fa.ROW_APP_DTYPE)
+        a["timeslot"] = 300
+        a["src_addr"][:, 0] = 9
+        a["dst_port"] = which
+        a["bytes"] = 3
+        a["count"] = 2
+        got = merged(fa.ROWS_APP, a)
+        assert len(got) == 2 and list(got["count"]) == [2 * int((which == 0).sum()), 2 * int((which == 1).sum())]
+        p = np.zeros(n, dtype=fa.PORT_ROW_DTYPE)
+        p["port"] = which * 70000
+        p["weight"] = rng.integers(0, 2**40, n, dtype=np.uint64)
+        p["count"] = 1
+        got = merged(fa.ROWS_PORT_SRC, p)
+        want = {k: int(p["weight"][which == k].sum()) for k in (0, 1)}
+        assert {int(x["port"]) // 70000: int(x["weight"]) for x in got} == want and int(got["weight"][0]) >= int(got["weight"][1])
+        t = np.zeros(n, dtype=fa.TOPK_DTYPE)
+        t["key"][:, 3] = which
+        t["weight"] = np.where(which == 1, 5, 9).astype(np.uint64)
+        got = merged(fa.ROWS_TOPK_DST, t)
+        assert len(got) == 2 and list(got["weight"]) == [9, 5]
