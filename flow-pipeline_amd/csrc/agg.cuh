@@ -209,9 +209,9 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
     __shared__ uint32_t pcb[AGG_MAX_NWG + AGG_PAD];  // ... and the counts of the segments' back parts
     __shared__ uint4 queues[(AGG_BLOCK / 64) * 64];  // per wave: tuples that need the probing path
     __shared__ uint32_t maxc_s[2];
-    if (threadIdx.x < 2) maxc_s[threadIdx.x] = 0;
+    if (threadIdx.x < 3) maxc_s[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t mymax = 0, mymaxb = 0;
+    uint32_t mymax = 0, mymaxb = 0, mysum = 0;
     for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_PAD; i += AGG_BLOCK) {
         const uint32_t c = i < a.nwg ? a.seg_counts[(size_t)part * a.nwg + i] : 0u;
         const uint32_t cb = i < a.nwg ? a.seg_counts[((size_t)NPART_MAX + part) * a.nwg + i] : 0u;
@@ -219,14 +219,17 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg_kernel(KArgs a) {
         pcb[i] = cb;
         mymax = max(mymax, c);
         mymaxb = max(mymaxb, cb);
+        mysum += c + cb;
     }
     for (int o = 32; o > 0; o >>= 1) {
         mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, o));
         mymaxb = max(mymaxb, (uint32_t)__shfl_xor((int)mymaxb, o));
+        mysum += (uint32_t)__shfl_xor((int)mysum, o);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicMax(&maxc_s[0], mymax);
         atomicMax(&maxc_s[1], mymaxb);
+        if (mysum) atomicAdd(&maxc_s[2], mysum);
     }
     const uint32_t tb_base = a.ctr->tb_base;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -702,15 +705,37 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
 __global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t set_mask) {
     __shared__ unsigned long long arr[1u << CMS_PART_LOG2_MAX];  // 128 KiB
     __shared__ uint32_t pc[AGG_MAX_NWG + AGG_PAD], pcb[AGG_MAX_NWG + AGG_PAD];
-    __shared__ uint32_t maxc_s[2];
-    // blockIdx -> (sketch, partition): only the enabled sketches have workgroups
-    const uint32_t set = (set_mask == 3u) ? blockIdx.x / CMS_NPART : (set_mask >> 1);
-    const uint32_t prefix = blockIdx.x % CMS_NPART, part = set * CMS_NPART + prefix;
+    __shared__ uint32_t maxc_s[3];
+    constexpr uint32_t CNFG = (AGG_MAX_NWG + AGG_PAD) / AGG_SU, CNBG = (AGG_MAX_NWG + AGG_PAD) / (AGG_SU * 8);
+    __shared__ uint16_t flv[CNFG], blv[CNBG + 1];  // levels each group of segments needs: front parts, back parts
+    __shared__ uint32_t fold_scr[(AGG_BLOCK / 64) * 192];  // 768 bytes per wave: wave_fold_lds
+    // Which (sketch, partition) this workgroup takes: the HEAVIEST first.  A partition that holds a heavy hitter's key gets 3-4x
+    // the mean number of tuples (every wave tile of the chip that is not served by its workgroup's hot-address cache sends
+    // one), the grid is two rounds of workgroups over the CUs, and the kernel lasted as long as the one workgroup that
+    // started such a partition in the second round.  The sizes are the PREVIOUS launch's (streams are stationary; copy
+    // `par` of cms_psize, constant during this launch - this launch's sizes go to copy `par ^ 1`): every workgroup ranks
+    // the same array, ties by index, so the ranks are a permutation whatever the sizes.
+    __shared__ uint32_t psz[CMS_SETS * CMS_NPART];
+    __shared__ uint32_t mine_s;
+    const uint32_t nlog = gridDim.x;  // logical ids: enabled sketches x partitions
+    for (uint32_t i = threadIdx.x; i < nlog; i += AGG_BLOCK) psz[i] = a.cms_psize[a.par * (CMS_SETS * CMS_NPART) + i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nlog; i += AGG_BLOCK) {
+        const uint32_t v = psz[i];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < nlog; q++) rank += (psz[q] > v || (psz[q] == v && q < i)) ? 1u : 0u;
+        if (rank == blockIdx.x) mine_s = i;
+    }
+    __syncthreads();
+    const uint32_t logical = mine_s;
+    // logical id -> (sketch, partition): only the enabled sketches have workgroups
+    const uint32_t set = (set_mask == 3u) ? logical / CMS_NPART : (set_mask >> 1);
+    const uint32_t prefix = logical % CMS_NPART, part = set * CMS_NPART + prefix;
     const uint32_t sub = a.cms_sub, ncnt = a.cms_depth << sub;
     for (uint32_t i = threadIdx.x; i < ncnt; i += AGG_BLOCK) arr[i] = 0;
-    if (threadIdx.x < 2) maxc_s[threadIdx.x] = 0;
+    if (threadIdx.x < 3) maxc_s[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t mymax = 0, mymaxb = 0;
+    uint32_t mymax = 0, mymaxb = 0, mysum = 0;
     for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_PAD; i += AGG_BLOCK) {
         const uint32_t c = i < a.nwg ? a.cseg_counts[(size_t)part * a.nwg + i] : 0u;
         const uint32_t cb = i < a.nwg ? a.cseg_counts[((size_t)CMS_SETS * CMS_NPART + part) * a.nwg + i] : 0u;
@@ -718,78 +743,90 @@ __global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t se
         pcb[i] = cb;
         mymax = max(mymax, c);
         mymaxb = max(mymaxb, cb);
+        mysum += c + cb;
     }
     for (int o = 32; o > 0; o >>= 1) {
         mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, o));
         mymaxb = max(mymaxb, (uint32_t)__shfl_xor((int)mymaxb, o));
+        mysum += (uint32_t)__shfl_xor((int)mysum, o);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicMax(&maxc_s[0], mymax);
         atomicMax(&maxc_s[1], mymaxb);
+        if (mysum) atomicAdd(&maxc_s[2], mysum);
     }
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint4* pbase = a.cseg + (size_t)part * a.cregion;
     KArgs g = a;  // (agg_fetch reads the segment geometry from capq / nwg)
     g.capq = a.ccapq;
     __syncthreads();
-    const uint32_t maxc = maxc_s[0], maxcb = maxc_s[1];
-    // A heavy hitter sends one tuple per wave-tile: a good part of every 64 consecutive tuples of its partition carries
-    // the SAME key, and an LDS atomic serializes the lanes that share an address.  So the lanes of a load are folded
-    // first when many of them agree with the first or the last lane's key (two cheap wave-uniform probes): one lane
-    // adds the wave's sum.
+    const uint32_t maxcb = maxc_s[1];
+    if (threadIdx.x == 0) a.cms_psize[(a.par ^ 1u) * (CMS_SETS * CMS_NPART) + logical] = maxc_s[2];  // (the next launch's schedule)
+    for (uint32_t gq = threadIdx.x; gq < CNFG; gq += AGG_BLOCK) {
+        uint32_t m = 0;
+        for (uint32_t q = 0; q < (uint32_t)AGG_SU; q++) m = max(m, pc[gq * AGG_SU + q]);
+        flv[gq] = (uint16_t)((m + 63u) >> 6);  // level j: tuples [64j, 64j+64) of a segment
+    }
+    for (uint32_t gq = threadIdx.x; gq < CNBG; gq += AGG_BLOCK) {
+        uint32_t m = 0;
+        for (uint32_t q = 0; q < (uint32_t)AGG_SU * 8u; q++) m = max(m, pcb[gq * AGG_SU * 8u + q]);
+        blv[gq] = (uint16_t)((m + 7u) >> 3);   // back parts: 8 tuples per segment and level
+    }
+    __syncthreads();
+    // A heavy hitter sends one tuple per wave tile: a good part of every 64 consecutive tuples of its partition carries the
+    // SAME key, and LDS atomics on one address serialize - across the lanes of a wave and across the 16 waves of the
+    // workgroup: the partition of the stream's heaviest key set the duration of the whole kernel (2.5x the mean workgroup).
+    // So the 64 tuples of a load are folded by key first, whatever their mix (wave_fold_lds: one hash-claim round in a
+    // wave-private LDS table - the first lane of a key keeps it and receives the others' weights): one lane per distinct
+    // key adds the row's sum.  (Round 2 probed only the first and the last lane's key: a heavy key that holds a third of
+    // the lanes was caught half of the time.)
+    uint32_t* const fscr = fold_scr + wave * 192u;
     auto consume = [&](const AggBatch& b) {
 #pragma unroll
         for (int e = 0; e < AGG_SU; e++) {
             const uint4& q = b.t[e];
-            unsigned long long w = (unsigned long long)q.w << 32 | q.z;
+            uint64_t w = (uint64_t)q.w << 32 | q.z;
             bool v = ((b.v >> e) & 1u) && w;
-#pragma unroll
-            for (int round = 0; round < 2; round++) {
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
-                if (m == 0ull) break;
-                const int leader = round == 0 ? __builtin_ctzll(m) : 63 - __builtin_clzll(m);
-                const uint32_t lx = (uint32_t)__builtin_amdgcn_readlane((int)q.x, leader), ly = (uint32_t)__builtin_amdgcn_readlane((int)q.y, leader);
-                const bool same = v && q.x == lx && q.y == ly;
-                if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(same)) < 8) continue;
-                const unsigned long long sum = wave_sum_u64(same ? w : 0ull);
-                if ((int)lane == leader)
-                    for (uint32_t r = 0; r < a.cms_depth; r++) atomicAdd(&arr[(r << sub) + cms_low(lx, ly, r, sub)], sum);
-                v = v && !same;
-            }
+            if (__builtin_amdgcn_ballot_w64(v) == 0ull) continue;
+            wave_fold_lds(fscr, v, (uint64_t)q.y << 32 | q.x, (uint64_t)0, w);
             if (v)
-                for (uint32_t r = 0; r < a.cms_depth; r++) atomicAdd(&arr[(r << sub) + cms_low(q.x, q.y, r, sub)], w);
+                for (uint32_t r = 0; r < a.cms_depth; r++) atomicAdd(&arr[(r << sub) + cms_low(q.x, q.y, r, sub)], (unsigned long long)w);
         }
     };
-    constexpr uint32_t STEP = (AGG_BLOCK / 64) * AGG_SU;
-    const uint32_t levels = (__builtin_amdgcn_readfirstlane(maxc) + 63u) / 64u;  // level j: tuples [64j, 64j+64) of every segment
-    for (uint32_t j = 0; j < levels; j++) {
-        AggBatch b0, b1;
-        uint32_t w0 = wave * AGG_SU;
-        agg_fetch<false, false>(g, pbase, pc, w0, lane, j, b0);
-        while (true) {
-            agg_fetch<false, false>(g, pbase, pc, w0 + STEP, lane, j, b1);
-            consume(b0);
-            agg_fetch<false, false>(g, pbase, pc, w0 + 2 * STEP, lane, j, b0);
-            consume(b1);
-            w0 += 2 * STEP;
-            if (w0 >= a.nwg) break;
-        }
+    // Work items of a wave: (group g of AGG_SU segments, level j), g = wave, wave + WAVES, ...; j < levels(g) - a wave never
+    // walks the empty levels of short segments up to the partition's longest one (a heavy hitter's workgroup fills its
+    // segment of the key's partition 4-5x beyond the mean: round 2 walked every segment to that length).  The loads of
+    // the next item fly while the current one is consumed (two register buffers; every fetch is unconditional - an item
+    // past the end reads clamped addresses with zero counts).
+    constexpr uint32_t WAVES = AGG_BLOCK / 64;
+#define FA_CMS_PASS(BACK, LV, GSEGS, PCNT)                                                       \
+    {                                                                                              \
+        const uint32_t ngroups = (a.nwg + (GSEGS) - 1u) / (GSEGS);                                  \
+        uint32_t gi = wave, j = 0;                                                                 \
+        auto settle_item = [&]() {                                                                 \
+            while (gi < ngroups && j >= (uint32_t)__builtin_amdgcn_readfirstlane((int)LV[gi])) {   \
+                gi += WAVES;                                                                       \
+                j = 0;                                                                             \
+            }                                                                                      \
+        };                                                                                         \
+        settle_item();                                                                             \
+        AggBatch b0, b1;                                                                           \
+        agg_fetch<BACK, false>(g, pbase, PCNT, gi * (GSEGS), lane, j, b0);                         \
+        while (gi < ngroups) {                                                                     \
+            j++;                                                                                   \
+            settle_item();                                                                         \
+            agg_fetch<BACK, false>(g, pbase, PCNT, gi * (GSEGS), lane, j, b1);                     \
+            consume(b0);                                                                           \
+            if (gi >= ngroups) break;                                                              \
+            j++;                                                                                   \
+            settle_item();                                                                         \
+            agg_fetch<BACK, false>(g, pbase, PCNT, gi * (GSEGS), lane, j, b0);                     \
+            consume(b1);                                                                           \
+        }                                                                                          \
     }
-    const uint32_t levels_b = (__builtin_amdgcn_readfirstlane(maxcb) + 7u) >> 3;  // back parts: 8 tuples per segment and level
-    constexpr uint32_t STEP_B = STEP * 8u;
-    for (uint32_t j = 0; j < (maxcb ? levels_b : 0u); j++) {
-        AggBatch b0, b1;
-        uint32_t w0 = wave * AGG_SU * 8u;
-        agg_fetch<true, false>(g, pbase, pcb, w0, lane, j, b0);
-        while (true) {
-            agg_fetch<true, false>(g, pbase, pcb, w0 + STEP_B, lane, j, b1);
-            consume(b0);
-            agg_fetch<true, false>(g, pbase, pcb, w0 + 2 * STEP_B, lane, j, b0);
-            consume(b1);
-            w0 += 2 * STEP_B;
-            if (w0 >= a.nwg) break;
-        }
-    }
+    FA_CMS_PASS(false, flv, (uint32_t)AGG_SU, pc)
+    if (maxcb) FA_CMS_PASS(true, blv, (uint32_t)AGG_SU * 8u, pcb)
+#undef FA_CMS_PASS
     __syncthreads();
     unsigned long long* sk = set ? a.cms_dst : a.cms_src;
     for (uint32_t i = threadIdx.x; i < ncnt; i += AGG_BLOCK) {

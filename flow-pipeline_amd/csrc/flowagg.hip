@@ -68,6 +68,7 @@ struct fa_ctx {
     size_t cseg_bytes = 0;
     uint32_t* cseg_counts = nullptr;
     size_t cseg_counts_cap = 0;
+    uint32_t* cms_psize = nullptr;  // [2][CMS_SETS * CMS_NPART] tuples per sketch partition, last launch / this launch (cms_agg_kernel: heaviest first)
     // scatter sink of the (SrcAddr,DstPort,Proto) key set (wagg.cuh)
     uint4* wseg = nullptr;
     size_t wseg_bytes = 0;
@@ -401,6 +402,25 @@ extern "C" void fa_destroy(fa_ctx* c) {
             fprintf(stderr, "[flowagg] last launch's tuples: %llu in whole store units, %llu single (%.2f %%)\n", front, back, 100.0 * (double)back / (double)std::max(1ull, front + back));
         }
     }
+    if (getenv("FA_VERBOSE") && c->cseg_counts && c->last_nwg) {  // balance of the last launch's sketch tuples over the 2 x 256 partitions
+        const size_t np = (size_t)CMS_SETS * CMS_NPART;
+        std::vector<uint32_t> cnt(np * c->last_nwg * 2);
+        if (hipMemcpy(cnt.data(), c->cseg_counts, cnt.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long tot = 0, mx = 0, mxseg = 0;
+            for (size_t p = 0; p < np; p++) {
+                unsigned long long s = 0;
+                for (uint32_t w = 0; w < c->last_nwg; w++) {
+                    const unsigned long long v = (unsigned long long)cnt[p * c->last_nwg + w] + cnt[(np + p) * c->last_nwg + w];
+                    s += v;
+                    mxseg = std::max(mxseg, v);
+                }
+                tot += s;
+                mx = std::max(mx, s);
+            }
+            fprintf(stderr, "[flowagg] last launch's sketch tuples: %llu, per partition mean %.0f max %llu (%.2fx), longest segment %llu (mean %.1f)\n", tot,
+                    (double)tot / (double)np, mx, (double)mx * (double)np / (double)std::max(1ull, tot), mxseg, (double)tot / (double)(np * c->last_nwg));
+        }
+    }
     (void)hipFree(c->tab);
     (void)hipFree(c->spill);
     (void)hipFree(c->d_ctr);
@@ -413,6 +433,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->seg_counts);
     (void)hipFree(c->cseg);
     (void)hipFree(c->cseg_counts);
+    (void)hipFree(c->cms_psize);
     (void)hipFree(c->wseg);
     (void)hipFree(c->wseg_counts);
     for (int i = 0; i < 2; i++) {
@@ -884,6 +905,12 @@ static int ensure_csegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
         if (hipMalloc(&c->cseg_counts, ncnt * sizeof(uint32_t)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(sketch segment counts) failed");
         c->cseg_counts_cap = ncnt;
     }
+    if (!c->cms_psize) {
+        const size_t bytes = 2 * (size_t)CMS_SETS * CMS_NPART * sizeof(uint32_t);
+        if (hipMalloc(&c->cms_psize, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(sketch partition sizes) failed");
+        HIPCHK(c, hipMemsetAsync(c->cms_psize, 0, bytes, c->stream));
+    }
+    a.cms_psize = c->cms_psize;
     a.cseg = c->cseg;
     a.cseg_counts = c->cseg_counts;
     a.ccapq = capq;

@@ -163,6 +163,7 @@ struct KArgs {
     uint32_t ccapq, ccapf, ccapb;
     unsigned long long cregion;
     uint32_t cms_sub;       // log2(counters per row of a sketch partition) = cms_wl2 - 8 on the scatter path
+    uint32_t* cms_psize;    // [2][CMS_SETS * CMS_NPART]: sketch tuples per partition in the previous launch (copy `par`) / this one (copy `par ^ 1`): cms_agg_kernel's schedule
     // wide key sets (wide.cuh)
     uint32_t key_sets;     // runtime mask (the KS_ALL kernel variant tests it)
     WSlot* wtab;
