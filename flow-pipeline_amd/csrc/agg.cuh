@@ -384,11 +384,11 @@ __device__ __forceinline__ bool agg8_upsert_owned(const KArgs& a, uint64_t k0, u
 #define FA_AGG8_SU 2
 #endif
 #ifndef FA_CMS_SU
-#define FA_CMS_SU 8
+#define FA_CMS_SU 4
 #endif
 constexpr int AGG8_SU = FA_AGG8_SU;        // 16-byte loads per lane and batch (x 2 tuples)
 constexpr int AGG8_NT = AGG8_SU * 2;
-constexpr int CMS_SU = FA_CMS_SU;          // cms_agg_kernel: more bytes in flight per wave (it is pure streaming + LDS adds, registers to spare)
+constexpr int CMS_SU = FA_CMS_SU;          // cms_agg_kernel: segments per batch (see cms_fetch)
 template <int SU>
 struct Agg8BatchT {
     uint4 t[SU];
@@ -697,37 +697,123 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
 }
 
 // ---- Count-Min scatter sink: fold the sketch tuples -------------------------------------------------
-// One workgroup per (sketch, partition): the partition's counters (depth rows x 2^sub columns) live in a dense LDS array
-// for the launch, every tuple {l1, l2, weight} of the partition's segments is `depth` LDS adds, and the array is folded
-// into copy 0 of the sketch with plain, coalesced 64-bit read-modify-writes (the partition's `depth` blocks of 2^sub
-// counters belong to this workgroup alone; the atomic paths use the other copies or run in other kernels).  Segment
-// geometry and walk of the wide (16-byte) flows_5m tuples: agg_fetch<BACK, false>.
-__global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t set_mask) {
+// One work unit per (sketch, partition) - or per slice of a heavy one: the partition's counters (depth rows x 2^sub
+// columns) live in a dense LDS array for the unit, every tuple {l1, l2, weight} of the partition's segments is `depth`
+// LDS adds, and the array is folded into copy 0 of the sketch with plain, coalesced 64-bit read-modify-writes (the
+// partition's `depth` blocks of 2^sub counters belong to this unit alone; slices of one partition use atomics; the
+// atomic paths of other kernels use the other copies).  One persistent workgroup per CU takes units heaviest first.
+// Segment geometry and walk: those of the wide (16-byte) flows_5m tuples, agg_fetch<BACK, false>.
+// Batches of CMS_SU segments (round 3 measured 8 against 4 - twice the loads in flight per wave: the segment walk of a
+// workgroup went from 41.6 to 44.7 us; it is not the latency of the loads that bounds it).
+constexpr int CMS_PAD = CMS_SU * 8;  // zero counts behind the last segment (the back pass reads 8 segments per load)
+struct CmsBatch {
+    uint4 t[CMS_SU];
+    uint32_t v;  // bit s = t[s] is a tuple of this lane (not a dummy load)
+};
+// agg_fetch<BACK, false> for batches of CMS_SU segments (same geometry, same unconditional loads)
+template <bool BACK>
+__device__ __forceinline__ void cms_fetch(const KArgs& a, const uint4* pbase, const uint32_t* pc, uint32_t w0, uint32_t lane, uint32_t j, CmsBatch& b) {
+    constexpr uint32_t SEGS = BACK ? 8u : 1u, PER = 64u / SEGS;
+    uint32_t idx[CMS_SU], seg[CMS_SU];
+    b.v = 0;
+#pragma unroll
+    for (int s = 0; s < CMS_SU; s++) {
+        seg[s] = w0 + (uint32_t)s * SEGS + (BACK ? lane / PER : 0u);
+        const uint32_t c = pc[min(seg[s], (uint32_t)(AGG_MAX_NWG + CMS_PAD - 1))];  // 0 past nwg
+        const uint32_t first = BACK ? a.capq - c : 0u;
+        const uint32_t piece = first + PER * j + (BACK ? lane % PER : lane);
+        const uint32_t valid = piece < first + c ? 1u : 0u;
+        b.v |= valid << s;
+        idx[s] = valid ? piece : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < CMS_SU; s++) b.t[s] = pbase[(size_t)min(seg[s], a.nwg - 1u) * a.capq + idx[s]];
+}
+
+__global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t set_mask, uint32_t cpar) {
     __shared__ unsigned long long arr[1u << CMS_PART_LOG2_MAX];  // 128 KiB
-    __shared__ uint32_t pc[AGG_MAX_NWG + AGG_PAD], pcb[AGG_MAX_NWG + AGG_PAD];
+    __shared__ uint32_t pc[AGG_MAX_NWG + CMS_PAD], pcb[AGG_MAX_NWG + CMS_PAD];
     __shared__ uint32_t maxc_s[3];
-    constexpr uint32_t CNFG = (AGG_MAX_NWG + AGG_PAD) / AGG_SU, CNBG = (AGG_MAX_NWG + AGG_PAD) / (AGG_SU * 8);
+    constexpr uint32_t CNFG = (AGG_MAX_NWG + CMS_PAD) / CMS_SU, CNBG = (AGG_MAX_NWG + CMS_PAD) / (CMS_SU * 8);
     __shared__ uint16_t flv[CNFG], blv[CNBG + 1];  // levels each group of segments needs: front parts, back parts
     __shared__ uint32_t fold_scr[(AGG_BLOCK / 64) * 192];  // 768 bytes per wave: wave_fold_lds
-    // Which (sketch, partition) this workgroup takes: the HEAVIEST first.  A partition that holds a heavy hitter's key gets 3-4x
-    // the mean number of tuples (every wave tile of the chip that is not served by its workgroup's hot-address cache sends
-    // one), the grid is two rounds of workgroups over the CUs, and the kernel lasted as long as the one workgroup that
-    // started such a partition in the second round.  The sizes are the PREVIOUS launch's (streams are stationary; copy
-    // `par` of cms_psize, constant during this launch - this launch's sizes go to copy `par ^ 1`): every workgroup ranks
-    // the same array, ties by index, so the ranks are a permutation whatever the sizes.
+    // Which (sketch, partition) this workgroup takes: the HEAVIEST first, and the heavy ones in SLICES.  A partition that
+    // holds a heavy hitter's key gets 3-4x the mean number of tuples (every wave tile of the chip that is not served by
+    // its workgroup's hot-address cache sends one), one workgroup fits a CU, the grid is two rounds of them - and the
+    // kernel lasted as long as the one workgroup of the heaviest partition.  So the schedule has cms_extra_units(nlog) spare
+    // units: a partition above 1.25x the mean is cut into k <= 8 slices (every k-th group of segments; each slice
+    // folds into its own LDS array and adds it to the sketch with atomics), heaviest first while spares last.  The sizes
+    // are the PREVIOUS launch's (streams are stationary; copy `cpar` of cms_psize - the parity of THIS kernel's launches -
+    // constant during this launch; this launch's sizes go to copy `cpar ^ 1`): every workgroup derives the same schedule from the same array - ranks with
+    // ties by index are a permutation whatever the sizes, unit u of the schedule belongs to workgroup u.
     __shared__ uint32_t psz[CMS_SETS * CMS_NPART];
-    __shared__ uint32_t mine_s;
-    const uint32_t nlog = gridDim.x;  // logical ids: enabled sketches x partitions
-    for (uint32_t i = threadIdx.x; i < nlog; i += AGG_BLOCK) psz[i] = a.cms_psize[a.par * (CMS_SETS * CMS_NPART) + i];
+    __shared__ uint16_t byrank[CMS_SETS * CMS_NPART], want[CMS_SETS * CMS_NPART];  // partition of rank r; slices it wants
+    __shared__ uint16_t ustart[CMS_SETS * CMS_NPART + 1];                          // first unit of rank r
+    __shared__ uint32_t mine_s[4];
+    const unsigned long long tk00 = FA_DBG(a, DBG_CMS_TIMING) ? wall_clock64() : 0ull;
+    const uint32_t nlog = CMS_NPART * (set_mask == 3u ? 2u : 1u);  // logical ids: enabled sketches x partitions
+    const uint32_t spare = cms_extra_units(nlog);
+    for (uint32_t i = threadIdx.x; i < nlog; i += AGG_BLOCK) psz[i] = a.cms_psize[cpar * (CMS_SETS * CMS_NPART) + i];
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nlog; i += AGG_BLOCK) {
         const uint32_t v = psz[i];
-        uint32_t rank = 0;
-        for (uint32_t q = 0; q < nlog; q++) rank += (psz[q] > v || (psz[q] == v && q < i)) ? 1u : 0u;
-        if (rank == blockIdx.x) mine_s = i;
+        uint32_t rank = 0, tot = 0;
+        for (uint32_t q = 0; q < nlog; q++) {
+            rank += (psz[q] > v || (psz[q] == v && q < i)) ? 1u : 0u;
+            tot += psz[q];
+        }
+        // slices: ceil(size / (1.25 x mean)); "heavy" (fold the rows by key first): above 1.5x the mean
+        const unsigned long long vn = (unsigned long long)v * nlog;
+        const uint32_t k = tot ? (uint32_t)min((vn * 4ull + 5ull * tot - 1ull) / (5ull * tot), 8ull) : 1u;
+        byrank[rank] = (uint16_t)i;
+        want[rank] = (uint16_t)(max(k, 1u) | (vn * 2ull > (unsigned long long)tot * 3ull ? 0x100u : 0u));
     }
     __syncthreads();
-    const uint32_t logical = mine_s;
+    if (threadIdx.x < 64) {  // exclusive prefix of the extra slices over the ranks: 8 ranks per lane (nlog <= 512)
+        uint32_t e[8], sum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+            const uint32_t r = threadIdx.x * 8u + q;
+            e[q] = r < nlog ? (want[r] & 0xffu) - 1u : 0u;
+            sum += e[q];
+        }
+        uint32_t inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+            if ((int)threadIdx.x >= o) inc += t;
+        }
+        uint32_t ex = inc - sum;
+        if (threadIdx.x == 0) ustart[0] = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+            const uint32_t r = threadIdx.x * 8u + q;
+            ex += e[q];
+            if (r < nlog) ustart[r + 1] = (uint16_t)(r + 1u + min(ex, spare));  // (extras granted in rank order until the spares are gone)
+        }
+    }
+    __syncthreads();
+    // The workgroups are PERSISTENT (one per CU: the 128 KiB array fills its LDS): unit blockIdx.x first, then whatever
+    // unit the launch's counter hands out next - no second round of workgroups that all start together and wait for the
+    // slowest, and the schedule above is worked out once per CU.  (Counter: word `cpar` behind the sizes; workgroup 0
+    // clears word `cpar ^ 1` for the next launch of this kernel.)
+    uint32_t* const next_unit = a.cms_psize + 2u * (CMS_SETS * CMS_NPART);
+    if (blockIdx.x == 0 && threadIdx.x == 0) next_unit[cpar ^ 1u] = 0u;
+    const uint32_t nunits = ustart[nlog];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    unsigned long long tk0 = tk00;
+    for (uint32_t unit = blockIdx.x; unit < nunits;) {  // (workgroup-uniform)
+    for (uint32_t r = threadIdx.x; r < nlog; r += AGG_BLOCK) {
+        const uint32_t u0 = ustart[r], u1 = ustart[r + 1];
+        if (unit >= u0 && unit < u1) {
+            mine_s[0] = byrank[r];
+            mine_s[1] = unit - u0;  // slice
+            mine_s[2] = u1 - u0;    // of k
+            mine_s[3] = want[r] >> 8;
+        }
+    }
+    __syncthreads();
+    const uint32_t logical = mine_s[0], slice = mine_s[1], nslice = mine_s[2];
+    const bool heavy = mine_s[3] != 0u;  // workgroup-uniform
     // logical id -> (sketch, partition): only the enabled sketches have workgroups
     const uint32_t set = (set_mask == 3u) ? logical / CMS_NPART : (set_mask >> 1);
     const uint32_t prefix = logical % CMS_NPART, part = set * CMS_NPART + prefix;
@@ -736,7 +822,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t se
     if (threadIdx.x < 3) maxc_s[threadIdx.x] = 0;
     __syncthreads();
     uint32_t mymax = 0, mymaxb = 0, mysum = 0;
-    for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + AGG_PAD; i += AGG_BLOCK) {
+    for (uint32_t i = threadIdx.x; i < AGG_MAX_NWG + CMS_PAD; i += AGG_BLOCK) {
         const uint32_t c = i < a.nwg ? a.cseg_counts[(size_t)part * a.nwg + i] : 0u;
         const uint32_t cb = i < a.nwg ? a.cseg_counts[((size_t)CMS_SETS * CMS_NPART + part) * a.nwg + i] : 0u;
         pc[i] = c;
@@ -755,21 +841,20 @@ __global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t se
         atomicMax(&maxc_s[1], mymaxb);
         if (mysum) atomicAdd(&maxc_s[2], mysum);
     }
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint4* pbase = a.cseg + (size_t)part * a.cregion;
-    KArgs g = a;  // (agg_fetch reads the segment geometry from capq / nwg)
+    KArgs g = a;  // (cms_fetch reads the segment geometry from capq / nwg)
     g.capq = a.ccapq;
     __syncthreads();
     const uint32_t maxcb = maxc_s[1];
-    if (threadIdx.x == 0) a.cms_psize[(a.par ^ 1u) * (CMS_SETS * CMS_NPART) + logical] = maxc_s[2];  // (the next launch's schedule)
+    if (threadIdx.x == 0 && slice == 0u) a.cms_psize[(cpar ^ 1u) * (CMS_SETS * CMS_NPART) + logical] = maxc_s[2];  // (the next launch's schedule)
     for (uint32_t gq = threadIdx.x; gq < CNFG; gq += AGG_BLOCK) {
         uint32_t m = 0;
-        for (uint32_t q = 0; q < (uint32_t)AGG_SU; q++) m = max(m, pc[gq * AGG_SU + q]);
+        for (uint32_t q = 0; q < (uint32_t)CMS_SU; q++) m = max(m, pc[gq * CMS_SU + q]);
         flv[gq] = (uint16_t)((m + 63u) >> 6);  // level j: tuples [64j, 64j+64) of a segment
     }
     for (uint32_t gq = threadIdx.x; gq < CNBG; gq += AGG_BLOCK) {
         uint32_t m = 0;
-        for (uint32_t q = 0; q < (uint32_t)AGG_SU * 8u; q++) m = max(m, pcb[gq * AGG_SU * 8u + q]);
+        for (uint32_t q = 0; q < (uint32_t)CMS_SU * 8u; q++) m = max(m, pcb[gq * CMS_SU * 8u + q]);
         blv[gq] = (uint16_t)((m + 7u) >> 3);   // back parts: 8 tuples per segment and level
     }
     __syncthreads();
@@ -781,58 +866,106 @@ __global__ __launch_bounds__(AGG_BLOCK) void cms_agg_kernel(KArgs a, uint32_t se
     // key adds the row's sum.  (Round 2 probed only the first and the last lane's key: a heavy key that holds a third of
     // the lanes was caught half of the time.)
     uint32_t* const fscr = fold_scr + wave * 192u;
-    auto consume = [&](const AggBatch& b) {
+    auto consume = [&](const CmsBatch& b) {
 #pragma unroll
-        for (int e = 0; e < AGG_SU; e++) {
+        for (int e = 0; e < CMS_SU; e++) {
             const uint4& q = b.t[e];
             uint64_t w = (uint64_t)q.w << 32 | q.z;
             bool v = ((b.v >> e) & 1u) && w;
             if (__builtin_amdgcn_ballot_w64(v) == 0ull) continue;
-            wave_fold_lds(fscr, v, (uint64_t)q.y << 32 | q.x, (uint64_t)0, w);
+            if (FA_DBG(a, DBG_AGG_NO_LDS)) {  // (ablation: the loads only)
+                if (v && (q.x ^ q.y ^ q.z) == 0x12345u && q.w == 0x777u) arr[0] = 1;
+                continue;
+            }
+            if (heavy) wave_fold_lds(fscr, v, (uint64_t)q.y << 32 | q.x, (uint64_t)0, w);
             if (v)
                 for (uint32_t r = 0; r < a.cms_depth; r++) atomicAdd(&arr[(r << sub) + cms_low(q.x, q.y, r, sub)], (unsigned long long)w);
         }
     };
-    // Work items of a wave: (group g of AGG_SU segments, level j), g = wave, wave + WAVES, ...; j < levels(g) - a wave never
-    // walks the empty levels of short segments up to the partition's longest one (a heavy hitter's workgroup fills its
-    // segment of the key's partition 4-5x beyond the mean: round 2 walked every segment to that length).  The loads of
-    // the next item fly while the current one is consumed (two register buffers; every fetch is unconditional - an item
-    // past the end reads clamped addresses with zero counts).
+    // Work items of a wave: (group g of CMS_SU segments, level j), g = the wave's share of this slice's groups; j <
+    // levels(g) - a wave never walks the empty levels of short segments up to the partition's longest one (a heavy
+    // hitter's workgroup fills its segment of the key's partition 4-5x beyond the mean: round 2 walked every segment to
+    // that length).  The loads of the next item fly while the current one is consumed (two register buffers; every fetch
+    // is unconditional - an item past the end reads clamped addresses with zero counts).
+    // (Round 3 measured: items drawn one at a time from an LDS counter even the waves out - the slowest wave of a
+    // workgroup walks 1.2x the mean here - and the walk takes as long as before; so does a walk with the LDS adds
+    // removed (47.7 vs 52.7 us per unit) and one with twice the loads in flight.  What bounds it is the CU's share of the
+    // memory system: ~0.7 MB of 1-KiB pieces per unit.)
     constexpr uint32_t WAVES = AGG_BLOCK / 64;
 #define FA_CMS_PASS(BACK, LV, GSEGS, PCNT)                                                       \
     {                                                                                              \
         const uint32_t ngroups = (a.nwg + (GSEGS) - 1u) / (GSEGS);                                  \
-        uint32_t gi = wave, j = 0;                                                                 \
+        uint32_t gi = wave * nslice + slice, j = 0;  /* this slice: groups = slice (mod nslice) */   \
         auto settle_item = [&]() {                                                                 \
             while (gi < ngroups && j >= (uint32_t)__builtin_amdgcn_readfirstlane((int)LV[gi])) {   \
-                gi += WAVES;                                                                       \
+                gi += WAVES * nslice;                                                              \
                 j = 0;                                                                             \
             }                                                                                      \
         };                                                                                         \
         settle_item();                                                                             \
-        AggBatch b0, b1;                                                                           \
-        agg_fetch<BACK, false>(g, pbase, PCNT, gi * (GSEGS), lane, j, b0);                         \
+        CmsBatch b0, b1;                                                                           \
+        cms_fetch<BACK>(g, pbase, PCNT, gi * (GSEGS), lane, j, b0);                                \
         while (gi < ngroups) {                                                                     \
             j++;                                                                                   \
             settle_item();                                                                         \
-            agg_fetch<BACK, false>(g, pbase, PCNT, gi * (GSEGS), lane, j, b1);                     \
+            cms_fetch<BACK>(g, pbase, PCNT, gi * (GSEGS), lane, j, b1);                            \
             consume(b0);                                                                           \
             if (gi >= ngroups) break;                                                              \
             j++;                                                                                   \
             settle_item();                                                                         \
-            agg_fetch<BACK, false>(g, pbase, PCNT, gi * (GSEGS), lane, j, b0);                     \
+            cms_fetch<BACK>(g, pbase, PCNT, gi * (GSEGS), lane, j, b0);                            \
             consume(b1);                                                                           \
         }                                                                                          \
     }
-    FA_CMS_PASS(false, flv, (uint32_t)AGG_SU, pc)
-    if (maxcb) FA_CMS_PASS(true, blv, (uint32_t)AGG_SU * 8u, pcb)
+    const unsigned long long tk1 = FA_DBG(a, DBG_CMS_TIMING) ? wall_clock64() : 0ull;
+    FA_CMS_PASS(false, flv, (uint32_t)CMS_SU, pc)
+    if (maxcb) FA_CMS_PASS(true, blv, (uint32_t)CMS_SU * 8u, pcb)
 #undef FA_CMS_PASS
+    if (FA_DBG(a, DBG_CMS_TIMING) && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        atomicAdd(&a.ctr->t_total, wall_clock64() - tk1);  // (sum over the waves: mean wave vs the workgroup's walk = imbalance)
+    }
     __syncthreads();
+    const unsigned long long tk2 = FA_DBG(a, DBG_CMS_TIMING) ? wall_clock64() : 0ull;
+    // (eight counters per thread and round: the loads of a round are issued together - a load behind the previous
+    // counter's conditional store cannot move above it, and sixteen dependent round trips to HBM were a tenth of a
+    // workgroup's time)
     unsigned long long* sk = set ? a.cms_dst : a.cms_src;
-    for (uint32_t i = threadIdx.x; i < ncnt; i += AGG_BLOCK) {
-        const unsigned long long v = arr[i];
-        const uint32_t r = i >> sub, col = i & ((1u << sub) - 1u);
-        if (v) sk[((size_t)r << a.cms_wl2) + ((size_t)prefix << sub) + col] += v;
+    constexpr uint32_t FL = 8;
+    for (uint32_t i0 = threadIdx.x; i0 < ncnt; i0 += AGG_BLOCK * FL) {
+        unsigned long long v[FL], old[FL];
+        size_t at[FL];
+#pragma unroll
+        for (uint32_t q = 0; q < FL; q++) {
+            const uint32_t i = min(i0 + q * AGG_BLOCK, ncnt - 1u);
+            v[q] = i0 + q * AGG_BLOCK < ncnt ? arr[i] : 0ull;
+            at[q] = ((size_t)(i >> sub) << a.cms_wl2) + ((size_t)prefix << sub) + (i & ((1u << sub) - 1u));
+        }
+        if (nslice > 1u) {  // (workgroup-uniform) the partition's other slices add to the same counters
+#pragma unroll
+            for (uint32_t q = 0; q < FL; q++)
+                if (v[q]) atomicAdd(&sk[at[q]], v[q]);
+            continue;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < FL; q++) old[q] = sk[at[q]];
+#pragma unroll
+        for (uint32_t q = 0; q < FL; q++)
+            if (v[q]) sk[at[q]] = old[q] + v[q];
+    }
+    if (FA_DBG(a, DBG_CMS_TIMING) && threadIdx.x == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long tk3 = wall_clock64();
+        atomicAdd(&a.ctr->t_wait, (tk1 - tk0) + (tk3 - tk2));
+        atomicAdd(&a.ctr->t_work, tk2 - tk1);
+        atomicAdd(&a.ctr->t_tiles, 1ull);
+        tk0 = tk3;
+    }
+    __syncthreads();  // (the array, the counts and mine_s are the next unit's from here)
+    if (threadIdx.x == 0) mine_s[0] = gridDim.x + atomicAdd(&next_unit[cpar], 1u);
+    __syncthreads();
+    unit = mine_s[0];
+    __syncthreads();
     }
 }
 

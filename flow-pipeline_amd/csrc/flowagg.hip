@@ -68,6 +68,7 @@ struct fa_ctx {
     size_t cseg_bytes = 0;
     uint32_t* cseg_counts = nullptr;
     size_t cseg_counts_cap = 0;
+    uint32_t cms_par = 0;          // parity of the next cms_agg_kernel launch (its size copies and unit counters)
     uint32_t* cms_psize = nullptr;  // [2][CMS_SETS * CMS_NPART] tuples per sketch partition, last launch / this launch (cms_agg_kernel: heaviest first)
     // scatter sink of the (SrcAddr,DstPort,Proto) key set (wagg.cuh)
     uint4* wseg = nullptr;
@@ -394,6 +395,11 @@ extern "C" void fa_destroy(fa_ctx* c) {
         fprintf(stderr, "[flowagg timing] per tile (wave 0 of every workgroup, core clocks): wait %.0f  work %.0f  | tiles %llu  total/wg-launch %.0f\n",
                 (double)c->h_ctr->t_wait / (double)c->h_ctr->t_tiles, (double)c->h_ctr->t_work / (double)c->h_ctr->t_tiles,
                 (unsigned long long)c->h_ctr->t_tiles, (double)c->h_ctr->t_total);
+    if ((c->dbg & DBG_CMS_TIMING) && c->d_ctr && c->h_ctr && hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost) == hipSuccess &&
+        c->h_ctr->t_tiles)
+        fprintf(stderr, "[flowagg timing] cms_agg_kernel per workgroup (us): schedule + counts + flush %.2f  segment walk %.2f  | workgroups %llu  mean wave's walk %.2f\n",
+                (double)c->h_ctr->t_wait / (double)c->h_ctr->t_tiles * 0.01, (double)c->h_ctr->t_work / (double)c->h_ctr->t_tiles * 0.01,
+                (unsigned long long)c->h_ctr->t_tiles, (double)c->h_ctr->t_total / (double)c->h_ctr->t_tiles / (double)(AGG_BLOCK / 64) * 0.01);
     if (getenv("FA_VERBOSE") && c->seg_counts && c->last_nwg) {  // how the last launch's tuples left: whole store units (front) or single tuples (back)
         std::vector<uint32_t> cnt((size_t)c->last_nwg * NPART_MAX * 2);
         if (hipMemcpy(cnt.data(), c->seg_counts, cnt.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -795,7 +801,9 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
     }
     if (MODE == MODE_INGEST && wave_tiles && a.cseg) {  // fold the sketch tuples (Count-Min scatter sink)
         const uint32_t set_mask = (c->cfg.key_sets >> 1) & 3u;
-        hipLaunchKernelGGL(cms_agg_kernel, dim3(CMS_NPART * (set_mask == 3u ? 2u : 1u)), dim3(AGG_BLOCK), 0, c->stream, a, set_mask);
+        const uint32_t nlog = CMS_NPART * (set_mask == 3u ? 2u : 1u);
+        hipLaunchKernelGGL(cms_agg_kernel, dim3(std::min<uint32_t>((uint32_t)c->num_cus, nlog)), dim3(AGG_BLOCK), 0, c->stream, a, set_mask, c->cms_par);  // persistent: one per CU
+        c->cms_par ^= 1u;
     }
     // fold the (SrcAddr,DstPort,Proto) tuples: one workgroup per table region, plain loads and stores - behind every
     // dispatch of this launch that updates the wide table with atomics (wagg.cuh)
@@ -906,7 +914,7 @@ static int ensure_csegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
         c->cseg_counts_cap = ncnt;
     }
     if (!c->cms_psize) {
-        const size_t bytes = 2 * (size_t)CMS_SETS * CMS_NPART * sizeof(uint32_t);
+        const size_t bytes = (2 * (size_t)CMS_SETS * CMS_NPART + 2) * sizeof(uint32_t);  // (+ the two unit counters)
         if (hipMalloc(&c->cms_psize, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(sketch partition sizes) failed");
         HIPCHK(c, hipMemsetAsync(c->cms_psize, 0, bytes, c->stream));
     }
@@ -1008,7 +1016,8 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         // (the kernel variants that serve a sketch run one 16-wave workgroup per CU instead of two 12-wave ones, with
         // slightly shorter tile buffers: wtile_block, wtile_stride)
         const bool big_wg = !wt_lean(c->cfg.key_sets);
-        const double cap = (double)(big_wg ? WT_STRIDE_CMS : WT_STRIDE) - 16.0 - 15.0;
+        const uint32_t ks = c->cfg.key_sets;
+        const double cap = (double)wt_stride((ks >= 1u && ks <= 7u) || ks == 9u ? ks : KS_ALL) - 16.0 - 15.0;  // (the instantiation launch_tiles picks)
         double r = cap / avg;
         r = (cap - 2.0 * 12.0 * std::sqrt(std::min(r, (double)WT_RECS))) / avg;
         a.tile_recs = r >= (double)WT_RECS ? WT_RECS : r < 1.0 ? 1u : (uint32_t)r;

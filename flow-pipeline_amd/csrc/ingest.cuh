@@ -544,7 +544,7 @@ constexpr int wtile_block() { return wt_lean(KEYSETS) ? WBLOCK : WBLOCK_CMS; }
 // ... and their tile buffers are 256 bytes shorter (62 instead of 64 mocker-sized records; the LDS goes to the sketch
 // bins and the hot-address cache - the whole 160 KiB of the CU are spoken for)
 template <uint32_t KEYSETS>
-constexpr int wtile_stride() { return wt_lean(KEYSETS) ? WT_STRIDE : WT_STRIDE_CMS; }
+constexpr int wtile_stride() { return wt_stride(KEYSETS); }
 template <bool ON>
 struct HotAddrsOpt {
     HotAddrs v;

@@ -50,6 +50,11 @@ static_assert(FA_BIN_BYTES == 128 || FA_BIN_BYTES == 64, "bin = one or half a ca
 // (wt_lean: the variants without a sketch - 12-wave workgroups, two per CU: flows_5m alone, and config 5's pair
 // flows_5m + (SrcAddr,DstPort,Proto); every other mask runs the 16-wave geometry, WBLOCK_CMS / WT_STRIDE_CMS)
 __host__ __device__ constexpr bool wt_lean(uint32_t key_sets) { return key_sets == FA_KEYS_AS_PAIR || key_sets == (FA_KEYS_AS_PAIR | FA_KEYS_ADDR_PORT_PROTO); }
+// tile buffer of a variant; the ones that scatter (SrcAddr,DstPort,Proto) tuples give 64-128 bytes per wave to the 512 region
+// counters (two wagg_kernel workgroups per CU) - and still fit two workgroups per CU / the 160 KiB
+__host__ __device__ constexpr int wt_stride(uint32_t key_sets) {
+    return (wt_lean(key_sets) ? WT_STRIDE : WT_STRIDE_CMS) - ((key_sets & FA_KEYS_ADDR_PORT_PROTO) ? (wt_lean(key_sets) ? 128 : 64) : 0);
+}
 __host__ __device__ constexpr uint32_t bin_line(uint32_t key_sets) { return wt_lean(key_sets) ? FA_BIN_BYTES / 16u : 8u; }
 // tuples per bin: wide (16-byte) or compact (8-byte) tuples
 template <bool T8, uint32_t BL>
@@ -84,7 +89,8 @@ constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense hi
 #endif
 #define FA_DBG(a, flags) (FA_ABLATE != 0 && ((a).dbg & (flags)) != 0)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
-       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072, DBG_NO_KEYSET = 262144, DBG_NO_CMS = 524288, DBG_NO_HOT = 1048576, DBG_AGG_ATOMIC_FLUSH = 2097152 /* exact: agg8_kernel adds its groups with atomics although it owns the region (A/B) */ };
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072, DBG_NO_KEYSET = 262144, DBG_NO_CMS = 524288, DBG_NO_HOT = 1048576, DBG_AGG_ATOMIC_FLUSH = 2097152 /* exact: agg8_kernel adds its groups with atomics although it owns the region (A/B) */,
+       DBG_CMS_TIMING = 4194304 /* cms_agg_kernel: 100 MHz ticks per workgroup - schedule + counts + flush / segment walk; the waves' own walk times (imbalance) */ };
 
 struct SpillEntry {
     unsigned long long k0, k1, bytes, packets, count;
@@ -163,7 +169,7 @@ struct KArgs {
     uint32_t ccapq, ccapf, ccapb;
     unsigned long long cregion;
     uint32_t cms_sub;       // log2(counters per row of a sketch partition) = cms_wl2 - 8 on the scatter path
-    uint32_t* cms_psize;    // [2][CMS_SETS * CMS_NPART]: sketch tuples per partition in the previous launch (copy `par`) / this one (copy `par ^ 1`): cms_agg_kernel's schedule
+    uint32_t* cms_psize;    // [2][CMS_SETS * CMS_NPART] (+ 2 words: the unit counters of cms_agg_kernel's persistent workgroups): sketch tuples per partition in the previous launch (copy `par`) / this one (copy `par ^ 1`): cms_agg_kernel's schedule
     // wide key sets (wide.cuh)
     uint32_t key_sets;     // runtime mask (the KS_ALL kernel variant tests it)
     WSlot* wtab;
@@ -275,6 +281,7 @@ __device__ __forceinline__ void cms_add(unsigned long long* cms, uint32_t depth,
 // Needs 256 partitions (width_log2 >= 12) of <= 2^14 counters (depth 4: width_log2 <= 20, the default 32 MiB sketch);
 // anything else (bigger sketches, deferred records, the workgroup-tile kernel) keeps the atomic path.
 constexpr uint32_t CMS_NPART = 256, CMS_SETS = 2, CMS_BIN = 4, CMS_PART_LOG2_MAX = 14;
+__host__ __device__ constexpr uint32_t cms_extra_units(uint32_t nlog) { return nlog / 8u; }  // cms_agg_kernel: spare work units for the slices of heavy partitions
 struct CmsLds {
     uint4 bins[CMS_SETS * CMS_NPART * CMS_BIN];   // 32 KiB: one 64-byte chunk per partition
     uint32_t bin_cnt[CMS_SETS * CMS_NPART];       // low half: slots taken, high half: slots written (like the tuple bins)

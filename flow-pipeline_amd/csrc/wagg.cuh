@@ -6,7 +6,7 @@
 // 3.5 G/s for the bare sequence, 17 G/s for one CAS + plain stores).  Here the wave-tile kernel only scatters one
 // 32-byte tuple per record into the segment of the key's table REGION (wide.cuh: probe sequences never leave a region),
 // and this kernel runs one workgroup per region, which therefore owns its slots for the duration of the launch:
-//   * a chunk of 1024 tuples is staged in LDS and deduplicated there (an LDS table of representatives: the first lane
+//   * a chunk of WAGG_CHUNK tuples is staged in LDS and deduplicated there (an LDS table of representatives: the first lane
 //     that claims a slot for a key represents it, later lanes with the same key add their sums to its LDS accumulators);
 //   * each representative then upserts its key with PLAIN loads and stores: keys of a chunk are unique, chunks are
 //     separated by workgroup barriers, and no other workgroup touches the region.  The only atomic left is one
@@ -22,8 +22,19 @@
 
 namespace fa {
 
-constexpr int WAGG_BLOCK = 1024;
-constexpr int WAGG_U = 2;                              // tuples per thread and chunk
+#ifndef FA_WAGG_BLOCK
+#define FA_WAGG_BLOCK 512
+#endif
+#ifndef FA_WAGG_U
+#define FA_WAGG_U 2
+#endif
+#ifndef FA_WAGG_EARLY
+#define FA_WAGG_EARLY 1
+#endif
+// Two workgroups per CU (512 regions, 66 KiB of LDS each): a chunk's LDS phases (staging, dedup) and its table phase
+// (random 64-byte lines: latency) alternate, and with one workgroup per CU nothing was in flight during the former.
+constexpr int WAGG_BLOCK = FA_WAGG_BLOCK;
+constexpr int WAGG_U = FA_WAGG_U;                      // tuples per thread and chunk
 constexpr int WAGG_CHUNK = WAGG_BLOCK * WAGG_U;
 constexpr int WAGG_SLOTS = 2 * WAGG_CHUNK;             // LDS table of representatives: load <= 0.5
 constexpr int WAGG_MAX_NWG = 1536;
@@ -145,6 +156,18 @@ __global__ __launch_bounds__(WAGG_BLOCK) void wagg_kernel(KArgs a) {
             L.accp[e] = p[u];
             L.accc[e] = have[u] ? 1u : 0u;
         }
+        // the home slots' key words: issued now, looked at behind the dedup (the previous chunk's rows are visible - the
+        // barrier that ended it; what this chunk changes in between is caught by the claim's compare-and-swap)
+        WSlot* hs[WAGG_U];
+        ulonglong2 k01[WAGG_U], k23[WAGG_U];
+#pragma unroll
+        for (int u = 0; u < WAGG_U; u++) {
+            hs[u] = &t.tab[h[u] & t.mask];
+#if FA_WAGG_EARLY
+            k01[u] = *reinterpret_cast<const ulonglong2*>(&hs[u]->w[0]);
+            k23[u] = *reinterpret_cast<const ulonglong2*>(&hs[u]->w[2]);
+#endif
+        }
         if (base + WAGG_CHUNK < total) fetch(base + WAGG_CHUNK);
         __syncthreads();
         bool is_rep[WAGG_U];
@@ -178,16 +201,16 @@ __global__ __launch_bounds__(WAGG_BLOCK) void wagg_kernel(KArgs a) {
         __syncthreads();
         // the representatives' upserts: the home-slot step of all of this thread's keys together (loads, then the
         // claims / the sums' loads, then the stores), what is left - the home slot holds another key - one by one
-        WSlot* hs[WAGG_U];
-        ulonglong2 k01[WAGG_U], k23[WAGG_U], v01[WAGG_U];
+        ulonglong2 v01[WAGG_U];
         unsigned long long v2[WAGG_U], sb[WAGG_U], sp[WAGG_U], sc[WAGG_U];
         bool match[WAGG_U], won[WAGG_U];
 #pragma unroll
         for (int u = 0; u < WAGG_U; u++) {
             const uint32_t e = (uint32_t)u * WAGG_BLOCK + tid;
-            hs[u] = &t.tab[h[u] & t.mask];
+#if !FA_WAGG_EARLY
             k01[u] = *reinterpret_cast<const ulonglong2*>(&hs[u]->w[0]);
             k23[u] = *reinterpret_cast<const ulonglong2*>(&hs[u]->w[2]);
+#endif
             sb[u] = L.accb[e];
             sp[u] = L.accp[e];
             sc[u] = L.accc[e];

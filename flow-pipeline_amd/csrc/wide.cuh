@@ -68,7 +68,10 @@ __host__ __device__ __forceinline__ uint32_t wkey_hash(const WKey& k) {
 // The table is cut into 2^wide_plog2 aligned regions and a probe sequence never leaves the region of the key's home
 // slot (it wraps inside it).  Nothing changes for the atomic paths; it is what lets wagg_kernel (wagg.cuh) hand each
 // region to ONE workgroup that updates it with plain loads and stores.  Regions hold at least 64 slots.
-constexpr uint32_t WIDE_PLOG2_MAX = 8;
+#ifndef FA_WIDE_PLOG2_MAX
+#define FA_WIDE_PLOG2_MAX 9
+#endif
+constexpr uint32_t WIDE_PLOG2_MAX = FA_WIDE_PLOG2_MAX;  // 512 regions: two wagg_kernel workgroups per CU
 __host__ __device__ constexpr uint32_t wide_plog2(uint32_t cap_log2) {
     return cap_log2 >= WIDE_PLOG2_MAX + 6u ? WIDE_PLOG2_MAX : cap_log2 > 6u ? cap_log2 - 6u : 0u;
 }
