@@ -68,6 +68,9 @@ struct fa_ctx {
     size_t cseg_bytes = 0;
     uint32_t* cseg_counts = nullptr;
     size_t cseg_counts_cap = 0;
+    HotSeed* hot_seed = nullptr;   // [hot_seed_wgs][CMS_SETS][HOT_SLOTS] entries of the hot-address caches that survive a launch
+    uint32_t* hot_seed_tag = nullptr;
+    uint32_t hot_seed_wgs = 0, hot_epoch = 0;
     uint32_t cms_par = 0;          // parity of the next cms_agg_kernel launch (its size copies and unit counters)
     uint32_t* cms_psize = nullptr;  // [2][CMS_SETS * CMS_NPART] tuples per sketch partition, last launch / this launch (cms_agg_kernel: heaviest first)
     // scatter sink of the (SrcAddr,DstPort,Proto) key set (wagg.cuh)
@@ -440,6 +443,8 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->cseg);
     (void)hipFree(c->cseg_counts);
     (void)hipFree(c->cms_psize);
+    (void)hipFree(c->hot_seed);
+    (void)hipFree(c->hot_seed_tag);
     (void)hipFree(c->wseg);
     (void)hipFree(c->wseg_counts);
     for (int i = 0; i < 2; i++) {
@@ -913,6 +918,22 @@ static int ensure_csegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
         if (hipMalloc(&c->cseg_counts, ncnt * sizeof(uint32_t)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(sketch segment counts) failed");
         c->cseg_counts_cap = ncnt;
     }
+    if (c->hot_seed_wgs < nwg) {  // the hot-address caches' surviving entries, one set per workgroup (sinks.cuh, HotAddrs)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->hot_seed);
+        (void)hipFree(c->hot_seed_tag);
+        c->hot_seed = nullptr;
+        c->hot_seed_tag = nullptr;
+        c->hot_seed_wgs = 0;
+        const size_t ne = (size_t)nwg * CMS_SETS * HOT_SLOTS;
+        if (hipMalloc(&c->hot_seed, ne * sizeof(HotSeed)) != hipSuccess || hipMalloc(&c->hot_seed_tag, ne * sizeof(uint32_t)) != hipSuccess)
+            return fail(c, FA_ERR_NOMEM, "hipMalloc(hot-address seeds) failed");
+        HIPCHK(c, hipMemsetAsync(c->hot_seed_tag, 0, ne * sizeof(uint32_t), c->stream));
+        c->hot_seed_wgs = nwg;
+    }
+    a.hot_seed = c->hot_seed;
+    a.hot_seed_tag = c->hot_seed_tag;
+    a.hot_epoch = c->hot_epoch++;
     if (!c->cms_psize) {
         const size_t bytes = (2 * (size_t)CMS_SETS * CMS_NPART + 2) * sizeof(uint32_t);  // (+ the two unit counters)
         if (hipMalloc(&c->cms_psize, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(sketch partition sizes) failed");

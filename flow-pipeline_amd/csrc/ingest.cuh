@@ -238,8 +238,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 if (vd) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, wd);
             }
         }
-        if (vs && keys_on) keyset_finish(a, a.ks_src, ps, slo, shi);
-        if (vd && keys_on) keyset_finish(a, a.ks_dst, pd, dlo, dhi);
+        if (keys_on) keyset_finish2(a, vs, ps, slo, shi, vd, pd, dlo, dhi);
     }
     if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb, tb_base, wpart_cnt);
 }
@@ -596,8 +595,20 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
             cl->bin_cnt[i] = 0;
             cl->part_cnt[i] = 0;
         }
-    if (HAS_CMS && hot)
-        for (int i = tid; i < (int)(CMS_SETS * HOT_SLOTS); i += WBLOCK) hot->tag[i / HOT_SLOTS][i % HOT_SLOTS] = 0;
+    if (HAS_CMS && hot)  // the entries this workgroup's cache held at the end of the previous launch (sinks.cuh, HotAddrs)
+        for (int i = tid; i < (int)(CMS_SETS * HOT_SLOTS); i += WBLOCK) {
+            const int set = i / HOT_SLOTS, sl = i % HOT_SLOTS;
+            const size_t at = (size_t)blockIdx.x * (CMS_SETS * HOT_SLOTS) + i;
+            const uint32_t tg = a.hot_seed_tag ? a.hot_seed_tag[at] : 0u;
+            if (tg >= 2u) {
+                const HotSeed sd = a.hot_seed[at];
+                hot->lo[set][sl] = sd.lo;
+                hot->hi[set][sl] = sd.hi;
+                hot->w[set][sl] = 0;
+            }
+            hot->touched[set][sl] = 0;
+            *hot->tag(set, sl) = tg >= 2u ? tg : 0u;
+        }
     uint32_t* tile = tiles + wave * (WT_STRIDE / 4);
 
     LaneTally tally;
@@ -745,11 +756,33 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
         __syncthreads();
         for (int i = tid; i < (int)(CMS_SETS * HOT_SLOTS); i += WBLOCK) {
             const int set = i / HOT_SLOTS, sl = i % HOT_SLOTS;
-            if (hot->tag[set][sl] >= 2u) {
-                const unsigned long long lo = hot->lo[set][sl], hi = hot->hi[set][sl];
+            const uint32_t tg = *hot->tag(set, sl);
+            const bool hit = tg >= 2u && hot->touched[set][sl] != 0;
+            const unsigned long long lo = hot->lo[set][sl], hi = hot->hi[set][sl];
+            if (hit) {
                 const uint32_t key[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
                 cms_add(set ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, key, hot->w[set][sl]);
                 if (!(FA_DBG(a, DBG_NO_KEYSET))) keyset_insert(a, set ? a.ks_dst : a.ks_src, key);
+            }
+            if (a.hot_seed_tag) {  // the next launch's entries: the ones that were hit, minus the lightest of a full set (every other launch)
+                const size_t at = (size_t)blockIdx.x * (CMS_SETS * HOT_SLOTS) + i;
+                // (the four ways of a set are four neighbouring lanes: HOT_SLOTS and WBLOCK are multiples of 4)
+                const unsigned long long wv = hit ? hot->w[set][sl] : ~0ull;
+                unsigned long long wmin = wv;
+                uint32_t nhit = hit ? 1u : 0u, amin = (uint32_t)sl;
+#pragma unroll
+                for (int o = 1; o <= 2; o <<= 1) {
+                    const unsigned long long ow = (unsigned long long)__shfl_xor((long long)wmin, o);
+                    const uint32_t oa = (uint32_t)__shfl_xor((int)amin, o);
+                    nhit += (uint32_t)__shfl_xor((int)nhit, o);
+                    if (ow < wmin || (ow == wmin && oa < amin)) {
+                        wmin = ow;
+                        amin = oa;
+                    }
+                }
+                const bool keep = hit && !(nhit == (uint32_t)HOT_WAYS && amin == (uint32_t)sl && (((uint32_t)sl / HOT_WAYS + a.hot_epoch) & 1u) == 0u);
+                a.hot_seed_tag[at] = keep ? tg : 0u;
+                if (keep) a.hot_seed[at] = HotSeed{lo, hi};
             }
         }
     }

@@ -38,7 +38,7 @@ constexpr int NPART_MAX = 1 << PART_LOG2_MAX;
 constexpr int WBLOCK = FA_WBLOCK;   // 12 waves, each with a private LDS tile of <= 64 records
 constexpr int WT_RECS = 64;
 constexpr int WT_STRIDE = FA_WT_STRIDE;  // 4864 = 64 records x 76 B (16-byte multiple); longer records: fewer per tile; overreads land in the next tile / the bins
-constexpr int WT_STRIDE_CMS = 5216;  // tile buffers of the kernel variants that serve a sketch (ingest.cuh, wtile_stride): 16 waves, what the 160 KiB leave
+constexpr int WT_STRIDE_CMS = 5056;  // tile buffers of the kernel variants that serve a sketch (ingest.cuh, wtile_stride): 16 waves, what the 160 KiB leave
 constexpr int WT_WG_PER_CU = 2;
 constexpr int WBLOCK_CMS = 2 * FA_WBLOCK > 1024 ? 1024 : 2 * FA_WBLOCK;  // sketch variants: one big workgroup per CU (ingest.cuh, wtile_block)
 static_assert(WBLOCK % 64 == 0 && WBLOCK >= 256 && WBLOCK <= 1024 && WT_STRIDE % 16 == 0, "wave-tile geometry");
@@ -50,10 +50,10 @@ static_assert(FA_BIN_BYTES == 128 || FA_BIN_BYTES == 64, "bin = one or half a ca
 // (wt_lean: the variants without a sketch - 12-wave workgroups, two per CU: flows_5m alone, and config 5's pair
 // flows_5m + (SrcAddr,DstPort,Proto); every other mask runs the 16-wave geometry, WBLOCK_CMS / WT_STRIDE_CMS)
 __host__ __device__ constexpr bool wt_lean(uint32_t key_sets) { return key_sets == FA_KEYS_AS_PAIR || key_sets == (FA_KEYS_AS_PAIR | FA_KEYS_ADDR_PORT_PROTO); }
-// tile buffer of a variant; the ones that scatter (SrcAddr,DstPort,Proto) tuples give 64-128 bytes per wave to the 512 region
+// tile buffer of a variant; the ones that scatter (SrcAddr,DstPort,Proto) tuples give 128-160 bytes per wave to the 512 region
 // counters (two wagg_kernel workgroups per CU) - and still fit two workgroups per CU / the 160 KiB
 __host__ __device__ constexpr int wt_stride(uint32_t key_sets) {
-    return (wt_lean(key_sets) ? WT_STRIDE : WT_STRIDE_CMS) - ((key_sets & FA_KEYS_ADDR_PORT_PROTO) ? (wt_lean(key_sets) ? 128 : 64) : 0);
+    return (wt_lean(key_sets) ? WT_STRIDE : WT_STRIDE_CMS) - ((key_sets & FA_KEYS_ADDR_PORT_PROTO) ? (wt_lean(key_sets) ? 128 : 160) : 0);
 }
 __host__ __device__ constexpr uint32_t bin_line(uint32_t key_sets) { return wt_lean(key_sets) ? FA_BIN_BYTES / 16u : 8u; }
 // tuples per bin: wide (16-byte) or compact (8-byte) tuples
@@ -127,6 +127,7 @@ struct ColumnPtrs {
     uint8_t* status;
 };
 
+struct HotSeed;
 struct KArgs {
     const uint8_t* buf;   // 16-byte aligned device pointer
     const uint32_t* off;  // n+1 offsets
@@ -169,6 +170,9 @@ struct KArgs {
     uint32_t ccapq, ccapf, ccapb;
     unsigned long long cregion;
     uint32_t cms_sub;       // log2(counters per row of a sketch partition) = cms_wl2 - 8 on the scatter path
+    HotSeed* hot_seed;       // [nwg][CMS_SETS][HOT_SLOTS] the hot-address caches' entries of the previous launch (tags: hot_seed_tag)
+    uint32_t* hot_seed_tag;  // [nwg][CMS_SETS][HOT_SLOTS] 0 = empty
+    uint32_t hot_epoch;      // launches of the sketch variants so far (which entries have to re-earn their admission)
     uint32_t* cms_psize;    // [2][CMS_SETS * CMS_NPART] (+ 2 words: the unit counters of cms_agg_kernel's persistent workgroups): sketch tuples per partition in the previous launch (copy `par`) / this one (copy `par ^ 1`): cms_agg_kernel's schedule
     // wide key sets (wide.cuh)
     uint32_t key_sets;     // runtime mask (the KS_ALL kernel variant tests it)
@@ -336,32 +340,62 @@ __device__ __forceinline__ void cms_bins_flush(const KArgs& a, CmsLds& cl, uint3
 }
 // ---- per-workgroup hot-address cache ----------------------------------------------------------------
 // Heavy hitters (Zipf 1.1: the top address carries 8 % of the records, the top 64 carry 40 %) would send one tuple per
-// wave-tile to each of their counters - twice the load of an average sketch slice on the few slices they hit, and the
-// slowest slice sets the pace of cms_agg_kernel - and one distinct-set probe each.  An address that shows up at least
-// twice inside one wave-tile (the wave-level fold tells) may claim a slot here; from then on every occurrence in this
-// workgroup is ONE LDS add.  At the end of the launch each slot is worth one sketch update per row and one
-// distinct-set insert.  Slot = 6 bits of the key hash; tag: 0 empty, 1 being written, else a fingerprint (>= 2).
-constexpr int HOT_SLOTS = 64;
+// wave-tile to each of their counters - twice the load of an average sketch slice on the few slices they hit - and one
+// distinct-set probe each.  An address that shows up at least twice inside one wave-tile (the wave-level fold tells) may
+// claim an entry here; from then on every occurrence in this workgroup is ONE LDS add.  At the end of the launch each
+// entry that was hit is worth one sketch update per row and one distinct-set insert.
+// 32 sets x 4 ways per sketch (set = 5 bits of the key hash); tag: 0 empty, 1 being written, else a fingerprint (>= 2).
+// The entries SURVIVE the launch (KArgs::hot_seed, one copy per workgroup): an address of rank 60-130 shows up twice in
+// a wave-tile once or twice per launch and workgroup - admitted anew every launch it was absorbed for half of it or
+// never (round 3 measured: 70 % of the address instances still left as tuples, against 54 % for a perfect 64-entry
+// cache).  An entry is dropped at the end of a launch in which it was never hit; of a set whose four ways are all taken
+// the LIGHTEST entry (weight added during the launch) has to earn its admission again every other launch - a heavy
+// address is back within a few tiles, a colder one makes room for whatever shows up twice in a tile first.
+constexpr int HOT_SETS = 32, HOT_WAYS = 4, HOT_SLOTS = HOT_SETS * HOT_WAYS;
 struct HotAddrs {
-    unsigned int tag[CMS_SETS][HOT_SLOTS];
+    unsigned long long tag2[CMS_SETS][HOT_SLOTS / 2];  // 32-bit tags, the four ways of a set side by side: two 8-byte reads
+    __device__ __forceinline__ unsigned int* tag(uint32_t set, uint32_t slot) { return reinterpret_cast<unsigned int*>(&tag2[set][0]) + slot; }
     unsigned long long lo[CMS_SETS][HOT_SLOTS], hi[CMS_SETS][HOT_SLOTS], w[CMS_SETS][HOT_SLOTS];
+    unsigned char touched[CMS_SETS][HOT_SLOTS];  // hit during this launch (a seeded entry nobody hits adds nothing and is dropped)
+};
+struct HotSeed {  // what survives (+ the tag): 20 bytes per entry
+    unsigned long long lo, hi;
 };
 // true = absorbed (the caller neither updates the sketch nor probes the distinct set for this record)
 __device__ __forceinline__ bool hot_add(HotAddrs& ht, uint32_t set, uint64_t lo, uint64_t hi, uint64_t h1, uint64_t w, bool admit) {
-    const uint32_t slot = (uint32_t)(h1 >> 8) & (HOT_SLOTS - 1);
+    const uint32_t base = ((uint32_t)(h1 >> 8) & (HOT_SETS - 1)) * HOT_WAYS;
     const unsigned int fp = (unsigned int)(h1 >> 32) | 2u;
-    unsigned int t = __hip_atomic_load(&ht.tag[set][slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (t == fp) {
-        if (ht.lo[set][slot] != lo || ht.hi[set][slot] != hi) return false;
-        if (w) atomicAdd(&ht.w[set][slot], (unsigned long long)w);
-        return true;
+    const unsigned long long ta = __hip_atomic_load(&ht.tag2[set][base / 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long tb = __hip_atomic_load(&ht.tag2[set][base / 2 + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned int t[4] = {(unsigned int)ta, (unsigned int)(ta >> 32), (unsigned int)tb, (unsigned int)(tb >> 32)};
+    uint32_t way = 4u, free_way = 4u;
+    bool busy = false;
+#pragma unroll
+    for (int q = 3; q >= 0; q--) {
+        way = t[q] == fp ? (uint32_t)q : way;
+        free_way = t[q] == 0u ? (uint32_t)q : free_way;
+        busy = busy || t[q] == 1u;
     }
-    if (t == 0u && admit && atomicCAS(&ht.tag[set][slot], 0u, 1u) == 0u) {
-        ht.lo[set][slot] = lo;
-        ht.hi[set][slot] = hi;
-        ht.w[set][slot] = w;
-        __hip_atomic_store(&ht.tag[set][slot], fp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (behind the key and the weight)
-        return true;
+    if (way < 4u) {
+        const uint32_t slot = base + way;
+        if (ht.lo[set][slot] == lo && ht.hi[set][slot] == hi) {
+            if (w) atomicAdd(&ht.w[set][slot], (unsigned long long)w);
+            ht.touched[set][slot] = 1;
+            return true;
+        }
+        return false;  // (a different address with this fingerprint: 2^-31)
+    }
+    // admission: a free way, and none of the set being written right now (it might be this very address, from another wave)
+    if (admit && !busy && free_way < 4u) {
+        const uint32_t slot = base + free_way;
+        if (atomicCAS(ht.tag(set, slot), 0u, 1u) == 0u) {
+            ht.lo[set][slot] = lo;
+            ht.hi[set][slot] = hi;
+            ht.w[set][slot] = w;
+            ht.touched[set][slot] = 1;
+            __hip_atomic_store(ht.tag(set, slot), fp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (behind the key and the weight)
+            return true;
+        }
     }
     return false;
 }
@@ -468,58 +502,104 @@ __device__ __forceinline__ KsProbe keyset_probe(const KArgs& a, KeySlot* tab, ui
     p.chi = p.s->hi;
     return p;
 }
-__device__ __forceinline__ void keyset_insert_slow(const KArgs& a, KeySlot* tab, unsigned long long lo, unsigned long long hi, unsigned long long mytag, uint32_t i) {
-    for (int probe = 0; probe < 256; probe++, i = (i + 1) & a.ks_mask) {
-        KeySlot* s = &tab[i];
-        // fastest paths, on plain (cached) loads.  They may be stale - but stale only ever means OLDER, and a slot never
-        // changes once READY: a READY slot seen here is final.  So (a) a complete match is always true, and (b) a READY
-        // slot that holds another tag (a displaced key walks over those: ~12 % of the probes at a quarter load) or the
-        // same tag with another key is skipped without consulting the memory side - round 2 paid a system-scope load, a
-        // ~2 us round trip, for every occupied slot a displaced key walked over; the ingest kernel spent a third of
-        // its time there (profiles/r03_config3_ablation.txt).  Only EMPTY or claimed-but-not-ready views go on below.
-        {
-            const ulonglong2 c01 = *reinterpret_cast<const ulonglong2*>(&s->tag);  // tag, lo
-            if (c01.x & KS_READY) {
-                if (c01.x == (mytag | KS_READY) && c01.y == lo && s->hi == hi) return;
-                continue;
-            }
+// One step of the probing path: looks at slots i and i + 1 (one 64-byte line when i is even; both plain loads are in
+// flight together) and returns true when the key is in the set - found or inserted; otherwise i has moved on.
+// Fastest paths, on plain (cached) loads: they may be stale - but stale only ever means OLDER, and a slot never changes
+// once READY: a READY slot seen here is final.  So (a) a complete match is always true, and (b) a READY slot that holds
+// another tag (a displaced key walks over those: ~12 % of the probes at a quarter load) or the same tag with another
+// key is skipped without consulting the memory side.  Only EMPTY or claimed-but-not-ready views go to the memory side
+// (system-scope loads and atomics are served past the incoherent per-XCD L2s).
+__device__ __forceinline__ bool keyset_step(const KArgs& a, KeySlot* tab, unsigned long long lo, unsigned long long hi, unsigned long long mytag, uint32_t& i) {
+    const uint32_t i1 = (i + 1) & a.ks_mask;
+    const ulonglong2 c0 = *reinterpret_cast<const ulonglong2*>(&tab[i].tag);  // tag, lo
+    const ulonglong2 c1 = *reinterpret_cast<const ulonglong2*>(&tab[i1].tag);
+    const unsigned long long h0 = tab[i].hi, h1 = tab[i1].hi;
+    KeySlot* s = &tab[i];
+    if (c0.x & KS_READY) {
+        if (c0.x == (mytag | KS_READY) && c0.y == lo && h0 == hi) return true;
+        if (c1.x & KS_READY) {
+            if (c1.x == (mytag | KS_READY) && c1.y == lo && h1 == hi) return true;
+            i = (i + 2) & a.ks_mask;
+            return false;
         }
-        // the key may be there: system-scope loads are served by the memory side, past the (incoherent) per-XCD
-        // L2s
-        unsigned long long t = __hip_atomic_load(&s->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (t == (mytag | KS_READY)) {
-            const unsigned long long l = __hip_atomic_load(&s->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const unsigned long long q = __hip_atomic_load(&s->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (l == lo && q == hi) return;
-            continue;  // equal tag, different key
-        }
-        if (t != 0 && t != mytag) continue;  // somebody else's slot
-        bool done = false;
-        if (t == 0) {
-            t = atomicCAS(&s->tag, 0ull, mytag);
-            if (t == 0) {  // claimed: publish the key, then mark it readable
-                const unsigned long long o1 = atomicExch(&s->lo, lo), o2 = atomicExch(&s->hi, hi);
-                if ((o1 & o2) != ~0ull) atomicOr(&s->tag, KS_READY);  // (always true: orders the OR behind both writes)
-                done = true;
-            }
-        }
-        // (claimers of this wave have published by now; owners in other waves are a few instructions away)
-        if (!done && (t | KS_READY) == (mytag | KS_READY)) {
-            for (int spin = 0; spin < 4096 && !(t & KS_READY); spin++) t = atomicOr(&s->tag, 0ull);
-            if (t & KS_READY) {
-                const unsigned long long l = atomicAdd(&s->lo, 0ull), q = atomicAdd(&s->hi, 0ull);  // memory-side reads
-                done = l == lo && q == hi;
-            }
-        }
-        if (done) return;
+        s = &tab[i1];
+        i = i1;
     }
+    i = (i + 1) & a.ks_mask;  // (where the walk goes on if slot s is not the one)
+    unsigned long long t = __hip_atomic_load(&s->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == (mytag | KS_READY)) {
+        const unsigned long long l = __hip_atomic_load(&s->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long q = __hip_atomic_load(&s->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return l == lo && q == hi;  // (false: equal tag, different key)
+    }
+    if (t != 0 && t != mytag) return false;  // somebody else's slot
+    if (t == 0) {
+        t = atomicCAS(&s->tag, 0ull, mytag);
+        if (t == 0) {  // claimed: publish the key, then mark it readable
+            const unsigned long long o1 = atomicExch(&s->lo, lo), o2 = atomicExch(&s->hi, hi);
+            if ((o1 & o2) != ~0ull) atomicOr(&s->tag, KS_READY);  // (always true: orders the OR behind both writes)
+            return true;
+        }
+    }
+    // (claimers of this wave have published by now; owners in other waves are a few instructions away)
+    if ((t | KS_READY) == (mytag | KS_READY)) {
+        for (int spin = 0; spin < 4096 && !(t & KS_READY); spin++) t = atomicOr(&s->tag, 0ull);
+        if (t & KS_READY) {
+            const unsigned long long l = atomicAdd(&s->lo, 0ull), q = atomicAdd(&s->hi, 0ull);  // memory-side reads
+            return l == lo && q == hi;
+        }
+    }
+    return false;
+}
+__device__ __forceinline__ void keyset_insert_slow(const KArgs& a, KeySlot* tab, unsigned long long lo, unsigned long long hi, unsigned long long mytag, uint32_t i) {
+    for (int step = 0; step < 256; step++)
+        if (keyset_step(a, tab, lo, hi, mytag, i)) return;
     atomicAdd(&a.ctr->ks_overflow, 1u);
 }
 // the common case - the key sits in its home slot - costs the two loads keyset_probe issued; everything else
 // (other slot, first occurrence) takes the probing path
+__device__ __forceinline__ bool keyset_at_home(const KsProbe& p, unsigned long long lo, unsigned long long hi) {
+    return p.c01.x == (p.mytag | KS_READY) && p.c01.y == lo && p.chi == hi;
+}
 __device__ __forceinline__ void keyset_finish(const KArgs& a, KeySlot* tab, const KsProbe& p, unsigned long long lo, unsigned long long hi) {
-    if (p.c01.x == (p.mytag | KS_READY) && p.c01.y == lo && p.chi == hi) return;
+    if (keyset_at_home(p, lo, hi)) return;
     keyset_insert_slow(a, tab, lo, hi, p.mytag, p.i);
+}
+// Both addresses of a record (the ingest kernel's form): ONE probing loop for what is left of the two sets.  A wave almost
+// always has a lane whose key is not in its home slot (12 % of the keys at a quarter load), every step of the probing
+// path is a round trip to memory with the whole wave waiting, and two loops in a row - source set, then destination set
+// - were two such chains per tile; a lane with both takes them one after the other, different lanes side by side.
+__device__ __forceinline__ void keyset_finish2(const KArgs& a, bool vs, const KsProbe& ps, unsigned long long slo, unsigned long long shi, bool vd,
+                                               const KsProbe& pd, unsigned long long dlo, unsigned long long dhi) {
+    const bool ns = vs && !keyset_at_home(ps, slo, shi);
+    bool nd = vd && !keyset_at_home(pd, dlo, dhi);
+    if (__builtin_amdgcn_ballot_w64(ns || nd) == 0ull) return;
+    KeySlot* tab = ns ? a.ks_src : a.ks_dst;
+    unsigned long long lo = ns ? slo : dlo, hi = ns ? shi : dhi, mytag = ns ? ps.mytag : pd.mytag;
+    uint32_t i = ns ? ps.i : pd.i, steps = 0;
+    bool active = ns || nd;
+    nd = nd && ns;  // (from here on: the destination address still waits behind the source address)
+    while (__builtin_amdgcn_ballot_w64(active) != 0ull) {
+        if (active) {
+            bool done = keyset_step(a, tab, lo, hi, mytag, i);
+            if (!done && ++steps >= 256u) {
+                atomicAdd(&a.ctr->ks_overflow, 1u);
+                done = true;
+            }
+            if (done) {
+                active = nd;
+                if (nd) {
+                    tab = a.ks_dst;
+                    lo = dlo;
+                    hi = dhi;
+                    mytag = pd.mytag;
+                    i = pd.i;
+                    steps = 0;
+                    nd = false;
+                }
+            }
+        }
+    }
 }
 __device__ __forceinline__ void keyset_insert(const KArgs& a, KeySlot* tab, const uint32_t key[4]) {
     const unsigned long long lo = (unsigned long long)key[1] << 32 | key[0], hi = (unsigned long long)key[3] << 32 | key[2];
