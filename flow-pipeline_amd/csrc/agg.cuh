@@ -422,8 +422,25 @@ __device__ __forceinline__ void agg8_drain(const KArgs& a, Agg8Table& lt, uint32
     if (lane < qn) agg8_tuple(a, lt, tb_base, part, queue[lane]);
 }
 // (pmask, pass: this pass takes the tuples with agg8_sub & pmask == pass; pmask = 0: all of them)
+// hk: the wave's HEAVY key (< 4: none found yet, 4: none).  A stream with one dominant (SrcAS, DstAS) pair - Zipf-1.1 addresses: the
+// top pair is 0.6 % of the records, half of the tuples of its partition - makes that partition's workgroup the last one
+// of the kernel (1.85x the mean tuples, and its LDS adds queue up on ONE slot: 147 us against 100 us for twice the
+// tuples spread evenly).  So a wave looks for a key that holds an eighth of a row (agg8_find_heavy, until it has one) and
+// from then on adds that key's tuples of a row up first (two 32-bit wave sums): one pair of LDS adds per row.
+__device__ __forceinline__ unsigned long long agg8_find_heavy(unsigned long long key, bool valid) {
+    unsigned long long rest = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2 && rest != 0ull; attempt++) {
+        const int l = __builtin_ctzll(rest);
+        const unsigned long long k = readlane_u64(key, l);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(valid && key == k);
+        if (__builtin_popcountll(same) >= 8) return k;
+        rest &= ~same;
+    }
+    return 0ull;
+}
 __device__ __forceinline__ void agg8_consume(const KArgs& a, Agg8Table& lt, uint32_t tb_base, uint32_t part, uint32_t lane, const Agg8Batch& b,
-                                             uint2* queue, uint32_t& qn, uint32_t pmask, uint32_t pass) {
+                                             uint2* queue, uint32_t& qn, uint32_t pmask, uint32_t pass, unsigned long long& hk) {
     uint2 t[AGG8_NT];
     unsigned long long key[AGG8_NT], c0[AGG8_NT], c1[AGG8_NT];
     uint32_t home[AGG8_NT];
@@ -444,18 +461,53 @@ __device__ __forceinline__ void agg8_consume(const KArgs& a, Agg8Table& lt, uint
         return;
     }
     uint32_t pending = 0;
+    if (hk < 4ull) {  // (still looking: hk counts the batches tried; 4 = gave up - an even stream pays for four looks per wave)
+        const unsigned long long f = agg8_find_heavy(key[0], (b.v & 1u) && !(pmask && (agg8_sub(t[0]) & pmask) != pass));
+        hk = f ? f : hk + 1ull;
+    }
+    if (hk >> 63) {  // (wave-uniform; every key has bit 63 set) this wave has a heavy key: its tuples of a row are added up first
 #pragma unroll
-    for (int e = 0; e < AGG8_NT; e++) {
-        if (!((b.v >> e) & 1u)) continue;
-        if (pmask && (agg8_sub(t[e]) & pmask) != pass) continue;
-        const bool at0 = c0[e] == key[e], at1 = c1[e] == key[e];
-        if (at0 || at1) {
-            const uint32_t s = home[e] + (at0 ? 0u : 1u);
-            const uint32_t by = t[e].y & 0x1ffffu;
-            if (by) atomicAdd(&lt.s1[s], (unsigned long long)by);
-            atomicAdd(&lt.s2[s], ((unsigned long long)((t[e].y >> 17) & 0x1ffu) << 25) | 1ull);
-        } else {
-            pending |= 1u << e;
+        for (int e = 0; e < AGG8_NT; e++) {
+            const bool act = ((b.v >> e) & 1u) && !(pmask && (agg8_sub(t[e]) & pmask) != pass);
+            const bool at0 = c0[e] == key[e], at1 = c1[e] == key[e];
+            uint32_t by = t[e].y & 0x1ffffu;
+            unsigned long long s2 = ((unsigned long long)((t[e].y >> 17) & 0x1ffu) << 25) | 1ull;
+            bool mine = act;
+            const bool hv = act && key[e] == hk && (at0 || at1);  // (the key's first tuple ever goes the normal way and opens its slot)
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(hv);
+            if (__builtin_popcountll(m) >= 2) {
+                // bytes < 2^17 and packets < 2^9 per tuple, 64 lanes: both sums and the count fit 32 bits
+                const uint32_t sb = wave_sum_u32(hv ? by : 0u);
+                const uint32_t sq = wave_sum_u32(hv ? (((t[e].y >> 17) & 0x1ffu) << 8) | 1u : 0u);  // packets << 8 | count
+                if (hv) {
+                    mine = lane == (uint32_t)__builtin_ctzll(m);
+                    by = sb;
+                    s2 = ((unsigned long long)(sq >> 8) << 25) | (unsigned long long)(sq & 0xffu);
+                }
+            }
+            if (!mine) continue;
+            if (at0 || at1) {
+                const uint32_t s = home[e] + (at0 ? 0u : 1u);
+                if (by) atomicAdd(&lt.s1[s], (unsigned long long)by);
+                atomicAdd(&lt.s2[s], s2);
+            } else {
+                pending |= 1u << e;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < AGG8_NT; e++) {
+            if (!((b.v >> e) & 1u)) continue;
+            if (pmask && (agg8_sub(t[e]) & pmask) != pass) continue;
+            const bool at0 = c0[e] == key[e], at1 = c1[e] == key[e];
+            if (at0 || at1) {
+                const uint32_t s = home[e] + (at0 ? 0u : 1u);
+                const uint32_t by = t[e].y & 0x1ffffu;
+                if (by) atomicAdd(&lt.s1[s], (unsigned long long)by);
+                atomicAdd(&lt.s2[s], ((unsigned long long)((t[e].y >> 17) & 0x1ffu) << 25) | 1ull);
+            } else {
+                pending |= 1u << e;
+            }
         }
     }
     if (FA_DBG(a, DBG_AGG_NO_SLOW)) return;
@@ -520,6 +572,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
     for (uint32_t pass = 0; pass < npass; pass++) {
     const unsigned long long tm0 = (FA_DBG(a, DBG_TIMING)) ? clock64() : 0ull;
     uint32_t qn = 0;
+    unsigned long long hk = 0ull;  // this wave's heavy key, once it has met one (agg8_consume)
     // Work items of a wave: (group g, level j), g = wave, wave + WAVES, ...; j < levels(g).  The loads of the next item
     // fly while the current one is consumed (two register buffers; every fetch is unconditional - an item past the end
     // reads clamped addresses with zero counts).
@@ -540,12 +593,12 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
             j++;                                                                                            \
             settle_item();                                                                                  \
             agg8_fetch<BACK, AGG8_SU>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b1);                                      \
-            agg8_consume(a, lt, tb_base, part, lane, b0, queue, qn, pmask, pass);                                       \
+            agg8_consume(a, lt, tb_base, part, lane, b0, queue, qn, pmask, pass, hk);                                       \
             if (g >= ngroups) break;                                                                        \
             j++;                                                                                            \
             settle_item();                                                                                  \
             agg8_fetch<BACK, AGG8_SU>(a.capq, a.nwg, pbase, PCNT, g * (GSEGS), lane, j, b0);                                      \
-            agg8_consume(a, lt, tb_base, part, lane, b1, queue, qn, pmask, pass);                                       \
+            agg8_consume(a, lt, tb_base, part, lane, b1, queue, qn, pmask, pass, hk);                                       \
         }                                                                                                   \
     }
     FA_AGG8_PASS(false, flv, NFG, FGRP, pc)

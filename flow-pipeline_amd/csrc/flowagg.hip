@@ -409,6 +409,15 @@ extern "C" void fa_destroy(fa_ctx* c) {
             unsigned long long front = 0, back = 0;
             for (size_t i = 0; i < cnt.size() / 2; i++) front += cnt[i], back += cnt[cnt.size() / 2 + i];
             fprintf(stderr, "[flowagg] last launch's tuples: %llu in whole store units, %llu single (%.2f %%)\n", front, back, 100.0 * (double)back / (double)std::max(1ull, front + back));
+            // (layout [2][NPART_MAX][nwg]: balance over the key partitions - agg8_kernel runs one workgroup per partition)
+            unsigned long long mx = 0;
+            for (size_t p = 0; p < (size_t)NPART_MAX; p++) {
+                unsigned long long sp = 0;
+                for (uint32_t w = 0; w < c->last_nwg; w++) sp += (unsigned long long)cnt[p * c->last_nwg + w] + cnt[((size_t)NPART_MAX + p) * c->last_nwg + w];
+                mx = std::max(mx, sp);
+            }
+            fprintf(stderr, "[flowagg] ... per key partition: mean %.0f max %llu (%.2fx)\n", (double)(front + back) / NPART_MAX, mx,
+                    (double)mx * NPART_MAX / (double)std::max(1ull, front + back));
         }
     }
     if (getenv("FA_VERBOSE") && c->cseg_counts && c->last_nwg) {  // balance of the last launch's sketch tuples over the 2 x 256 partitions

@@ -6,6 +6,9 @@
 
 #include "sinks.cuh"
 
+#ifndef FA_LT_KEEP
+#define FA_LT_KEEP 8u
+#endif
 namespace fa {
 
 // ---- per-lane work on a staged record (called by every lane of the workgroup) ------
@@ -124,7 +127,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             lt_seen += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sure));
             lt_hits += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sure && !pending));
             if (lt_seen >= 256u) {
-                if (lt_hits * 8u < lt_seen) lt_seen = 0xffffffffu;
+                if (lt_hits * FA_LT_KEEP < lt_seen) lt_seen = 0xffffffffu;
                 else lt_seen = lt_hits = 0;
             }
         }

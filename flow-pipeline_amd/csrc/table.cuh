@@ -252,6 +252,16 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     }
     return tot;  // wave-uniform
 }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {  // (sums that fit 32 bits: half the DPP steps of wave_sum_u64)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    uint32_t tot = 0;
+#pragma unroll
+    for (int row = 0; row < 4; row++) tot += (uint32_t)__builtin_amdgcn_readlane((int)v, row * 16 + 15);
+    return tot;  // wave-uniform
+}
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
     uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
     uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
