@@ -342,3 +342,45 @@ def test_rows_merge_device_long_runs(gpu_lib, fa):
         t["weight"] = np.where(which == 1, 5, 9).astype(np.uint64)
         got = merged(fa.ROWS_TOPK_DST, t)
         assert len(got) == 2 and list(got["weight"]) == [9, 5]
+
+
+def test_hot_address_cache_survives_launches_and_a_reset(gpu_lib, fa, po):
+    """The per-workgroup hot-address caches of the sketch variants keep their entries from launch to launch (sinks.cuh,
+    HotAddrs / KArgs::hot_seed).  Whatever they hold: sketches and distinct sets stay exact - over several launches of one
+    stream (the later ones start with seeded caches) and across fa_cms_reset (seeded addresses that the next stream never
+    carries must not reappear in its set, the ones it does carry must)."""
+    n = 600_000
+    depth, wl2, seed = 4, 16, 0xBEEF
+    KS = (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS))
+
+    def stream(gseed, log2):
+        gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=gseed, n_total=n, zipf_log2_universe=log2, zipf_s_x100=110)
+        buf, off = po.gen_records(gp, 0, n)
+        rows, status = po.decode_batch(buf, off, 1)
+        assert status.sum() == 0
+        return buf, off, rows
+
+    def check(agg, rows, times, what):
+        with np.errstate(over="ignore"):
+            w = rows["bytes"] * rows["sampling_rate"]
+        for col, ks in KS:
+            want = po.cms_sketch_numpy(rows[col], w, depth, wl2, seed) * np.uint64(times)
+            assert np.array_equal(agg.cms_read(ks).reshape(-1), want), (what, col)
+            distinct = {bytes(k) for k in np.unique(rows[col], axis=0)}
+            got = agg.topk(ks, 1 << 16)
+            assert {bytes(r["key"]) for r in got} == distinct and len(got) == len(distinct), (what, col)
+
+    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=16,
+                    max_batch_records=n) as agg:
+        buf, off, rows = stream(5, 11)
+        for rep in range(4):   # launches 2..4 run on seeded caches
+            agg.ingest(buf, off)
+        check(agg, rows, 4, "four launches")
+        for _, ks in KS:
+            agg.cms_reset(ks)
+        buf2, off2, rows2 = stream(6, 9)   # 512 addresses: the head is shared with the first stream, its tail is gone
+        agg.ingest(buf2, off2)
+        check(agg, rows2, 1, "after the reset")
+        agg.ingest(buf2, off2)
+        check(agg, rows2, 2, "after the reset, seeded")
+        assert agg.stats()["records_bad"] == 0
