@@ -232,7 +232,8 @@ int fa_rows_device(fa_ctx*, int kind, uint32_t timeslot, size_t k, const void** 
 /* Merges n rows of `kind` sitting in HBM (several ranks' fa_rows_device results back to back, any order): rows with
  * equal keys are summed (top-k rows: kept once), the result is put into emit order and cut after k rows (0: all).
  * *d_out: DEVICE pointer to *n_out rows, owned by the ctx, valid until its next call.  The ctx's own state is not
- * touched.  FA_ROWS_5M rows must lie on this ctx's bucket grid (FA_ERR_ARG otherwise). */
+ * touched.  FA_ROWS_5M rows must lie on this ctx's bucket grid (FA_ERR_ARG otherwise).  The ctx reads d_rows on its own
+ * stream: whatever wrote them (a collective, a copy on another stream) must have completed when the call is made. */
 int fa_rows_merge_device(fa_ctx*, int kind, const void* d_rows, size_t n, size_t k, const void** d_out, size_t* n_out);
 /* Copies n rows of `kind` from HBM into the caller's host buffer (cap in rows). */
 int fa_rows_fetch(fa_ctx*, int kind, const void* d_rows, size_t n, void* out, size_t cap);

@@ -36,6 +36,7 @@ def _cat_device(fa, torch, ctxs, kind, timeslot, k=0):
     if not parts:
         return torch.empty(0, dtype=torch.uint8, device="cuda"), 0
     buf = torch.cat(parts)
+    torch.cuda.synchronize()  # the ctx reads the buffer on ITS stream: torch's copies must have landed (as dist.allgather_device_rows does)
     return buf, buf.numel() // rb
 
 
@@ -80,6 +81,7 @@ def test_device_merge_of_two_ctxs_equals_single_ctx(gpu_lib, fa, po, sub):
                     t = torch.as_tensor(fa.dist._DevArray(merged, st.cms_words), device="cuda")
                     t.copy_(torch.as_tensor(fa.dist._DevArray(wh, st.cms_words), device="cuda"))  # = sum over the two shards (checked below)
                 c.merged_view_set(True)
+            torch.cuda.synchronize()  # (torch wrote the merged views on its stream; the ctxs read them on theirs)
             assert np.array_equal(a0.cms_read(key_set), whole.cms_read(key_set))
             k = 60
             dbuf, tot = _cat_device(fa, torch, (a0, a1), kind, 0, k)
@@ -117,6 +119,7 @@ def test_merge_rows_device_between_two_ctxs(gpu_lib, fa, po):
             a1.ingest(b1, o1)
             ptr, m = a0.window_rows_device(fa.ALL_TIMESLOTS)
             mine = torch.as_tensor(fa.dist._DevArray(ptr, m * 48, "|u1"), device="cuda").clone()
+            torch.cuda.synchronize()  # (a1 reads the copy on its own stream)
             a1.merge_rows_device(mine.data_ptr(), m)
             ref = po.Rollup(sub or 300)
             ref.ingest(buf, off, 1)
@@ -268,6 +271,7 @@ def test_broken_device_offsets_are_bad_records_not_faults(gpu_lib, fa, po, n):
         d_buf = torch.zeros(len(buf) + 64, dtype=torch.uint8, device="cuda")
         d_buf[:len(buf)] = torch.from_numpy(np.ascontiguousarray(buf)).cuda()
         d_off = torch.from_numpy(broken.view(np.int32)).cuda()
+        torch.cuda.synchronize()  # (torch's fills and copies run on its stream, the ingest on the ctx's)
         agg.ingest_device(d_buf.data_ptr(), len(buf), d_off.data_ptr(), n)
         st = agg.stats()
         assert st["records_bad"] == len(bad_recs) and st["records_ok"] == n - len(bad_recs), (st["records_bad"], len(bad_recs), st["records_ok"])
