@@ -4,6 +4,7 @@
 #   make -C flow-pipeline_amd/csrc OUT=../libflowagg_ablate.so EXTRA=-DFA_ABLATE=1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/inst
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
@@ -13,9 +14,16 @@ for f in ${FLAGS:-0 16 1 17}; do
 done
 cd $ROOT
 python - <<'PY'
-import csv, glob, os, collections
+import csv, glob, os, collections, statistics
 root = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out/inst")
 for d in sorted(glob.glob(root + "/f*/")):
+    dur = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "wtile" in k or "agg8" in k or "cms_agg" in k or "wagg" in k:
+                dur[k[:40]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print(os.path.basename(d.rstrip("/")), "durations under PMC (us):", " | ".join("%s median %.1f min %.1f" % (k, statistics.median(v), min(v)) for k, v in sorted(dur.items())))
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
