@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--prefix", type=int, default=100_000_000)
     ap.add_argument("--universe-log2", type=int, default=24)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--topk-log2", type=int, default=0, help="slots of each distinct-address set (default: universe + 2)")
     args = ap.parse_args()
     import torch
     fa = _pkg.load()
@@ -88,7 +89,7 @@ def main():
     gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=3, n_total=n, span_secs=900, zipf_log2_universe=L, zipf_s_x100=110)
     out = {"config": "BASELINE configs[2]: 1xMI355X, Count-Min heavy hitters SrcAddr/DstAddr, %d framed FlowMessages, Zipf-1.1 over 2^%d addresses, "
                      "regenerated in %d-record chunks; sketch depth %d x 2^%d x u64 per key set" % (n, L, args.chunk, depth, wl2)}
-    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=L + 2,
+    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=args.topk_log2 or L + 2,
                     max_batch_records=args.chunk) as agg:
         cap = args.chunk * 96 + 4096
         d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
