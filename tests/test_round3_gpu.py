@@ -388,3 +388,37 @@ def test_hot_address_cache_survives_launches_and_a_reset(gpu_lib, fa, po):
         agg.ingest(buf2, off2)
         check(agg, rows2, 2, "after the reset, seeded")
         assert agg.stats()["records_bad"] == 0
+
+
+@pytest.mark.parametrize("key_sets", [3, 5, 6])
+def test_one_sketch_alone_through_the_scheduled_fold(gpu_lib, fa, po, key_sets):
+    """cms_agg_kernel's schedule (persistent workgroups, heaviest partition first, heavy partitions in slices - sizes of the
+    previous launch) with ONE sketch enabled (256 logical partitions instead of 512) and without the flows_5m key set: three
+    launches of a skewed stream (the second and third run on a real schedule), counters against the CPU sketch."""
+    n = 1_500_000
+    depth, wl2, seed = 4, 20, 0x51CE
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=44, n_total=n, zipf_log2_universe=16, zipf_s_x100=110)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    assert status.sum() == 0
+    with np.errstate(over="ignore"):
+        w = rows["bytes"] * rows["sampling_rate"]
+    with fa.FlowAgg(framed=True, key_sets=key_sets, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=18,
+                    max_batch_records=n) as agg:
+        for rep in range(3):
+            agg.ingest(buf, off)
+        for col, ks in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+            if key_sets & ks:
+                want = po.cms_sketch_numpy(rows[col], w, depth, wl2, seed) * np.uint64(3)
+                assert np.array_equal(agg.cms_read(ks).reshape(-1), want), col
+                distinct = {bytes(k) for k in np.unique(rows[col], axis=0)}
+                assert {bytes(r["key"]) for r in agg.topk(ks, 1 << 18)} == distinct, col
+        st = agg.stats()
+        assert st["records_ok"] == 3 * n and st["records_bad"] == 0
+        if key_sets & fa.FA_KEYS_AS_PAIR:
+            ref = po.Rollup(300)
+            ref.ingest(buf, off, 1)
+            want_rows = ref.rows()
+            for c in ("bytes", "packets", "count"):
+                want_rows[c] *= np.uint64(3)
+            assert agg.read_window().tobytes() == want_rows.tobytes()
