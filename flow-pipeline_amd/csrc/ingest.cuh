@@ -113,6 +113,45 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     }
     const uint32_t t32 = (uint32_t)r.time_received;  // UInt64 -> DateTime (create.sh:39)
     const uint32_t tb = time_bucket(a, t32);
+    // state of the sketch path between its two halves (below: in front of and behind the flows_5m sink)
+    uint64_t cw = 0, ws = 0, wd = 0, slo = 0, shi = 0, dlo = 0, dhi = 0, sh1 = 0, sh2 = 0, dh1 = 0, dh2 = 0;
+    bool on_s = false, on_d = false, vs = false, vd = false;
+    const bool keys_on = !(FA_DBG(a, DBG_NO_KEYSET));
+    KsProbe ps{}, pd{};
+    if (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
+        // (this half - folds, hashes, hot-address cache, the distinct sets' home-slot loads ISSUED - runs in front of the
+        // flows_5m sink: a streaming batch probes cold lines, and the sink's LDS work is what hides their way to HBM;
+        // the sketch tuples and the look at what the probes returned follow behind the sink)
+        // lanes of a wave that carry the same address (heavy hitters) are folded first: one sketch update and
+        // one distinct-set probe per address and wave (wave-tile kernel: its parsed tile buffer is the scratch).
+        // Order of work: fold both addresses, hash them, ISSUE the distinct-set probes of both (global loads), then
+        // the sketch updates (LDS work that hides the probes' latency), then look at what the probes returned.
+        cw = r.bytes * r.sampling_rate;  // viz-ch.json:233 sum(Bytes*SamplingRate), UInt64 wrap
+        on_s = ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS);
+        on_d = ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS);
+        slo = (uint64_t)r.src[1] << 32 | r.src[0];
+        shi = (uint64_t)r.src[3] << 32 | r.src[2];
+        dlo = (uint64_t)r.dst[1] << 32 | r.dst[0];
+        dhi = (uint64_t)r.dst[3] << 32 | r.dst[2];
+        ws = wd = cw;
+        vs = sure && on_s;
+        vd = sure && on_d;
+        // (the folds run on every FA_FOLD_EVERY-th tile of a wave: with the hot-address cache in front of the sink what a
+        // fold still finds is mostly an address that deserves an entry there - the admission signal - and that can wait
+        // a few tiles; equal addresses of an unfolded tile leave as separate tuples (+1 % tuples), sums commute.  Same-box:
+        // every tile 0.999 ms per launch of the config-3 shape, every 4th 0.984, every 8th 0.984.)
+        const bool fold_now = bins && (__builtin_amdgcn_readfirstlane((int)tally.tick++) % FA_FOLD_EVERY) == 0;
+        if (fold_now && on_s) wave_fold_lds(const_cast<uint32_t*>(tile), vs, slo, shi, ws);
+        if (fold_now && on_d) wave_fold_lds(const_cast<uint32_t*>(tile), vd, dlo, dhi, wd);
+        if (on_s) cms_hash2(slo, shi, a.cms_seed, sh1, sh2);
+        if (on_d) cms_hash2(dlo, dhi, a.cms_seed, dh1, dh2);
+        if (hot && !(FA_DBG(a, DBG_NO_HOT))) {  // heavy hitters: one LDS add, nothing else (an address may move in once a wave has seen it twice)
+            if (vs && hot_add(*hot, 0u, slo, shi, sh1, ws, ws != cw)) vs = false;
+            if (vd && hot_add(*hot, 1u, dlo, dhi, dh1, wd, wd != cw)) vd = false;
+        }
+        if (vs && keys_on) ps = keyset_probe(a, a.ks_src, sh1);
+        if (vd && keys_on) pd = keyset_probe(a, a.ks_dst, dh1);
+    }
     if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
         uint64_t k0, k1;
         pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
@@ -211,34 +250,6 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         }
     }
     if (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
-        // lanes of a wave that carry the same address (heavy hitters) are folded first: one sketch update and
-        // one distinct-set probe per address and wave (wave-tile kernel: its parsed tile buffer is the scratch).
-        // Order of work: fold both addresses, hash them, ISSUE the distinct-set probes of both (global loads), then
-        // the sketch updates (LDS work that hides the probes' latency), then look at what the probes returned.
-        const uint64_t w = r.bytes * r.sampling_rate;  // viz-ch.json:233 sum(Bytes*SamplingRate), UInt64 wrap
-        const bool on_s = ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS), on_d = ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS);
-        const uint64_t slo = (uint64_t)r.src[1] << 32 | r.src[0], shi = (uint64_t)r.src[3] << 32 | r.src[2];
-        const uint64_t dlo = (uint64_t)r.dst[1] << 32 | r.dst[0], dhi = (uint64_t)r.dst[3] << 32 | r.dst[2];
-        uint64_t ws = w, wd = w;
-        bool vs = sure && on_s, vd = sure && on_d;
-        // (the folds run on every FA_FOLD_EVERY-th tile of a wave: with the hot-address cache in front of the sink what a
-        // fold still finds is mostly an address that deserves an entry there - the admission signal - and that can wait
-        // a few tiles; equal addresses of an unfolded tile leave as separate tuples (+1 % tuples), sums commute.  Same-box:
-        // every tile 0.999 ms per launch of the config-3 shape, every 4th 0.984, every 8th 0.984.)
-        const bool fold_now = bins && (__builtin_amdgcn_readfirstlane((int)tally.tick++) % FA_FOLD_EVERY) == 0;
-        if (fold_now && on_s) wave_fold_lds(const_cast<uint32_t*>(tile), vs, slo, shi, ws);
-        if (fold_now && on_d) wave_fold_lds(const_cast<uint32_t*>(tile), vd, dlo, dhi, wd);
-        uint64_t sh1 = 0, sh2 = 0, dh1 = 0, dh2 = 0;
-        if (on_s) cms_hash2(slo, shi, a.cms_seed, sh1, sh2);
-        if (on_d) cms_hash2(dlo, dhi, a.cms_seed, dh1, dh2);
-        if (hot && !(FA_DBG(a, DBG_NO_HOT))) {  // heavy hitters: one LDS add, nothing else (an address may move in once a wave has seen it twice)
-            if (vs && hot_add(*hot, 0u, slo, shi, sh1, ws, ws != w)) vs = false;
-            if (vd && hot_add(*hot, 1u, dlo, dhi, dh1, wd, wd != w)) vd = false;
-        }
-        const bool keys_on = !(FA_DBG(a, DBG_NO_KEYSET));
-        KsProbe ps{}, pd{};
-        if (vs && keys_on) ps = keyset_probe(a, a.ks_src, sh1);
-        if (vd && keys_on) pd = keyset_probe(a, a.ks_dst, dh1);
         if (!(FA_DBG(a, DBG_NO_CMS))) {
             if (cl && a.cseg) {  // scatter sink: no atomics (whole wave: the bin flushes need every lane)
                 // (bin lists: the wave's tile buffer is dead by now - behind the 768 bytes the folds used)
@@ -250,7 +261,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 if (vd) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, wd);
             }
         }
-        if (keys_on) keyset_finish2(a, vs, ps, slo, shi, vd, pd, dlo, dhi);
+        if (keys_on) keyset_finish2(a, vs, ps, sh1, slo, shi, vd, pd, dh1, dlo, dhi);
     }
     if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb, tb_base, wpart_cnt);
 }

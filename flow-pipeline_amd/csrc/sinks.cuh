@@ -485,21 +485,19 @@ __device__ __forceinline__ void wave_fold_lds(uint32_t* scratch, bool& valid, ui
 // reported (ks_overflow -> FA_ERR_TABLE_FULL).
 // Hash of the set: the sketch's first hash of the key (cms_hash2) - the ingest kernel has it already.  Slot index =
 // its high half, tag = its low 62 bits.
-struct KsProbe {
-    KeySlot* s;                 // home slot
-    ulonglong2 c01;             // its tag and low key word as a plain (cached, possibly stale) load saw them
-    unsigned long long chi;     // ... and its high key word
-    unsigned long long mytag;
-    uint32_t i;
+struct KsProbe {                // the home slot as a plain (cached, possibly stale) load saw it
+    ulonglong2 c01;             // tag and low key word
+    unsigned long long chi;     // high key word
 };
-// issue the home-slot loads of a key (nothing waits here: the caller does other work before keyset_finish)
+__device__ __forceinline__ unsigned long long keyset_tag(uint64_t h1) { return KS_CLAIMED | (h1 & (KS_READY - 1)); }
+__device__ __forceinline__ uint32_t keyset_home(const KArgs& a, uint64_t h1) { return (uint32_t)(h1 >> 32) & a.ks_mask; }
+// issue the home-slot loads of a key (nothing waits here: the caller does other work before keyset_finish; slot and tag
+// are functions of h1 - not kept in registers meanwhile)
 __device__ __forceinline__ KsProbe keyset_probe(const KArgs& a, KeySlot* tab, uint64_t h1) {
     KsProbe p;
-    p.mytag = KS_CLAIMED | (h1 & (KS_READY - 1));
-    p.i = (uint32_t)(h1 >> 32) & a.ks_mask;
-    p.s = &tab[p.i];
-    p.c01 = *reinterpret_cast<const ulonglong2*>(&p.s->tag);
-    p.chi = p.s->hi;
+    const KeySlot* s = &tab[keyset_home(a, h1)];
+    p.c01 = *reinterpret_cast<const ulonglong2*>(&s->tag);
+    p.chi = s->hi;
     return p;
 }
 // One step of the probing path: looks at slots i and i + 1 (one 64-byte line when i is even; both plain loads are in
@@ -509,11 +507,18 @@ __device__ __forceinline__ KsProbe keyset_probe(const KArgs& a, KeySlot* tab, ui
 // another tag (a displaced key walks over those: ~12 % of the probes at a quarter load) or the same tag with another
 // key is skipped without consulting the memory side.  Only EMPTY or claimed-but-not-ready views go to the memory side
 // (system-scope loads and atomics are served past the incoherent per-XCD L2s).
-__device__ __forceinline__ bool keyset_step(const KArgs& a, KeySlot* tab, unsigned long long lo, unsigned long long hi, unsigned long long mytag, uint32_t& i) {
+// (pre: the caller already holds a plain view of slot i - the home slot's, from keyset_probe)
+__device__ __forceinline__ bool keyset_step(const KArgs& a, KeySlot* tab, unsigned long long lo, unsigned long long hi, unsigned long long mytag, uint32_t& i,
+                                            bool pre = false, ulonglong2 pre01 = make_ulonglong2(0, 0), unsigned long long prehi = 0) {
     const uint32_t i1 = (i + 1) & a.ks_mask;
-    const ulonglong2 c0 = *reinterpret_cast<const ulonglong2*>(&tab[i].tag);  // tag, lo
+    ulonglong2 c0 = pre01;
+    unsigned long long h0 = prehi;
+    if (!pre) {
+        c0 = *reinterpret_cast<const ulonglong2*>(&tab[i].tag);  // tag, lo
+        h0 = tab[i].hi;
+    }
     const ulonglong2 c1 = *reinterpret_cast<const ulonglong2*>(&tab[i1].tag);
-    const unsigned long long h0 = tab[i].hi, h1 = tab[i1].hi;
+    const unsigned long long h1 = tab[i1].hi;
     KeySlot* s = &tab[i];
     if (c0.x & KS_READY) {
         if (c0.x == (mytag | KS_READY) && c0.y == lo && h0 == hi) return true;
@@ -526,7 +531,16 @@ __device__ __forceinline__ bool keyset_step(const KArgs& a, KeySlot* tab, unsign
         i = i1;
     }
     i = (i + 1) & a.ks_mask;  // (where the walk goes on if slot s is not the one)
-    unsigned long long t = __hip_atomic_load(&s->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // a slot the plain view shows EMPTY: straight to the claim (the CAS answers with the slot's real tag either way - a
+    // memory-side load in front of it was one more round trip in the chain every NEW key pays, and a streaming batch has
+    // a new key in nearly every tile); a claimed-not-ready view: ask the memory side first
+    const unsigned long long seen = s == &tab[i1] && (c0.x & KS_READY) ? c1.x : c0.x;
+    unsigned long long t = seen == 0ull ? atomicCAS(&s->tag, 0ull, mytag) : __hip_atomic_load(&s->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (seen == 0ull && t == 0ull) {  // claimed: publish the key, then mark it readable
+        const unsigned long long o1 = atomicExch(&s->lo, lo), o2 = atomicExch(&s->hi, hi);
+        if ((o1 & o2) != ~0ull) atomicOr(&s->tag, KS_READY);  // (always true: orders the OR behind both writes)
+        return true;
+    }
     if (t == (mytag | KS_READY)) {
         const unsigned long long l = __hip_atomic_load(&s->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long q = __hip_atomic_load(&s->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -558,30 +572,33 @@ __device__ __forceinline__ void keyset_insert_slow(const KArgs& a, KeySlot* tab,
 }
 // the common case - the key sits in its home slot - costs the two loads keyset_probe issued; everything else
 // (other slot, first occurrence) takes the probing path
-__device__ __forceinline__ bool keyset_at_home(const KsProbe& p, unsigned long long lo, unsigned long long hi) {
-    return p.c01.x == (p.mytag | KS_READY) && p.c01.y == lo && p.chi == hi;
+__device__ __forceinline__ bool keyset_at_home(const KsProbe& p, uint64_t h1, unsigned long long lo, unsigned long long hi) {
+    return p.c01.x == (keyset_tag(h1) | KS_READY) && p.c01.y == lo && p.chi == hi;
 }
-__device__ __forceinline__ void keyset_finish(const KArgs& a, KeySlot* tab, const KsProbe& p, unsigned long long lo, unsigned long long hi) {
-    if (keyset_at_home(p, lo, hi)) return;
-    keyset_insert_slow(a, tab, lo, hi, p.mytag, p.i);
+__device__ __forceinline__ void keyset_finish(const KArgs& a, KeySlot* tab, const KsProbe& p, uint64_t h1, unsigned long long lo, unsigned long long hi) {
+    if (keyset_at_home(p, h1, lo, hi)) return;
+    keyset_insert_slow(a, tab, lo, hi, keyset_tag(h1), keyset_home(a, h1));
 }
 // Both addresses of a record (the ingest kernel's form): ONE probing loop for what is left of the two sets.  A wave almost
 // always has a lane whose key is not in its home slot (12 % of the keys at a quarter load), every step of the probing
 // path is a round trip to memory with the whole wave waiting, and two loops in a row - source set, then destination set
 // - were two such chains per tile; a lane with both takes them one after the other, different lanes side by side.
-__device__ __forceinline__ void keyset_finish2(const KArgs& a, bool vs, const KsProbe& ps, unsigned long long slo, unsigned long long shi, bool vd,
-                                               const KsProbe& pd, unsigned long long dlo, unsigned long long dhi) {
-    const bool ns = vs && !keyset_at_home(ps, slo, shi);
-    bool nd = vd && !keyset_at_home(pd, dlo, dhi);
+__device__ __forceinline__ void keyset_finish2(const KArgs& a, bool vs, const KsProbe& ps, uint64_t sh1, unsigned long long slo, unsigned long long shi, bool vd,
+                                               const KsProbe& pd, uint64_t dh1, unsigned long long dlo, unsigned long long dhi) {
+    const bool ns = vs && !keyset_at_home(ps, sh1, slo, shi);
+    bool nd = vd && !keyset_at_home(pd, dh1, dlo, dhi);
     if (__builtin_amdgcn_ballot_w64(ns || nd) == 0ull) return;
     KeySlot* tab = ns ? a.ks_src : a.ks_dst;
-    unsigned long long lo = ns ? slo : dlo, hi = ns ? shi : dhi, mytag = ns ? ps.mytag : pd.mytag;
-    uint32_t i = ns ? ps.i : pd.i, steps = 0;
-    bool active = ns || nd;
+    unsigned long long lo = ns ? slo : dlo, hi = ns ? shi : dhi, mytag = keyset_tag(ns ? sh1 : dh1);
+    uint32_t i = keyset_home(a, ns ? sh1 : dh1), steps = 0;
+    ulonglong2 pre01 = ns ? ps.c01 : pd.c01;  // the home slot as keyset_probe saw it: the first step does not load it again
+    unsigned long long prehi = ns ? ps.chi : pd.chi;
+    bool active = ns || nd, pre = true;
     nd = nd && ns;  // (from here on: the destination address still waits behind the source address)
     while (__builtin_amdgcn_ballot_w64(active) != 0ull) {
         if (active) {
-            bool done = keyset_step(a, tab, lo, hi, mytag, i);
+            bool done = keyset_step(a, tab, lo, hi, mytag, i, pre, pre01, prehi);
+            pre = false;
             if (!done && ++steps >= 256u) {
                 atomicAdd(&a.ctr->ks_overflow, 1u);
                 done = true;
@@ -592,8 +609,11 @@ __device__ __forceinline__ void keyset_finish2(const KArgs& a, bool vs, const Ks
                     tab = a.ks_dst;
                     lo = dlo;
                     hi = dhi;
-                    mytag = pd.mytag;
-                    i = pd.i;
+                    mytag = keyset_tag(dh1);
+                    i = keyset_home(a, dh1);
+                    pre01 = pd.c01;
+                    prehi = pd.chi;
+                    pre = true;
                     steps = 0;
                     nd = false;
                 }
@@ -606,7 +626,7 @@ __device__ __forceinline__ void keyset_insert(const KArgs& a, KeySlot* tab, cons
     uint64_t h1, h2;
     cms_hash2(lo, hi, a.cms_seed, h1, h2);
     const KsProbe p = keyset_probe(a, tab, h1);
-    keyset_finish(a, tab, p, lo, hi);
+    keyset_finish(a, tab, p, h1, lo, hi);
 }
 
 __device__ __forceinline__ void store_columns(const ColumnPtrs& c, uint32_t idx, const Rec& r,
