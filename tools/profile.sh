@@ -4,7 +4,7 @@
 # PMC passes never carry sys/hip/hsa trace options).  Output: gpurun_out/prof/<tag>/...
 TAG=${1:-r03}
 shift
-ARGS=${@:---steps 3 --warmup 1 --cpu-sample 0 --no-verify --no-host-fed}
+ARGS=${@:---steps 12 --warmup 3 --cpu-sample 0 --no-verify --no-host-fed}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof/$TAG
 mkdir -p $OUT
