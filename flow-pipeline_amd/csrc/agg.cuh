@@ -536,6 +536,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
     __shared__ uint16_t flv[NFG], blv[NBG];  // levels each group of segments needs (so that a wave never walks empty levels)
     __shared__ uint2 queues[WAVES * 64];
     const uint32_t part = blockIdx.x;
+    const unsigned long long tk_start = FA_DBG(a, DBG_AGG8_TIMING) ? wall_clock64() : 0ull;
     for (int i = threadIdx.x; i < AGG8_ALL; i += AGG_BLOCK) {
         lt.key[i] = 0;
         lt.s1[i] = 0;
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
     uint32_t my_groups = 0, my_created = 0;
 #pragma unroll 1
     for (uint32_t pass = 0; pass < npass; pass++) {
-    const unsigned long long tm0 = (FA_DBG(a, DBG_TIMING)) ? clock64() : 0ull;
+    const unsigned long long tm0 = (FA_DBG(a, DBG_TIMING | DBG_AGG8_TIMING)) ? (FA_DBG(a, DBG_AGG8_TIMING) ? wall_clock64() : clock64()) : 0ull;
     uint32_t qn = 0;
     unsigned long long hk = 0ull;  // this wave's heavy key, once it has met one (agg8_consume)
     // Work items of a wave: (group g, level j), g = wave, wave + WAVES, ...; j < levels(g).  The loads of the next item
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
 #undef FA_AGG8_PASS
     agg8_drain(a, lt, tb_base, part, lane, queue, qn);
     __syncthreads();
-    const unsigned long long tm1 = (FA_DBG(a, DBG_TIMING)) ? clock64() : 0ull;
+    const unsigned long long tm1 = (FA_DBG(a, DBG_TIMING | DBG_AGG8_TIMING)) ? (FA_DBG(a, DBG_AGG8_TIMING) ? wall_clock64() : clock64()) : 0ull;
     if (FA_DBG(a, DBG_AGG_NO_FLUSH)) return;
     // every group of this partition goes to the device-wide table once (quad-grouped: one atomic line transaction per
     // group; uniform trip count: the whole wave takes part in the quad rounds)
@@ -717,6 +718,13 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
             quad_atomic_update(sp, b, p, c);
         }
     }
+    }
+    if (FA_DBG(a, DBG_AGG8_TIMING) && threadIdx.x == 0) {  // (FA_DEBUG_FLAGS=8388608: 100 MHz ticks per workgroup - set-up / segment walk / flush)
+        __builtin_amdgcn_s_waitcnt(0);
+        atomicAdd(&a.ctr->t_total, tm0 - tk_start);
+        atomicAdd(&a.ctr->t_wait, tm1 - tm0);
+        atomicAdd(&a.ctr->t_work, wall_clock64() - tm1);
+        atomicAdd(&a.ctr->t_tiles, 1ull);
     }
     if ((FA_DBG(a, DBG_TIMING)) && threadIdx.x == 0) {  // (FA_DEBUG_FLAGS=1024: core clocks per workgroup and pass - fold / add to the device table)
         __builtin_amdgcn_s_waitcnt(0);

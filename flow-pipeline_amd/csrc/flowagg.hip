@@ -398,6 +398,11 @@ extern "C" void fa_destroy(fa_ctx* c) {
         fprintf(stderr, "[flowagg timing] per tile (wave 0 of every workgroup, core clocks): wait %.0f  work %.0f  | tiles %llu  total/wg-launch %.0f\n",
                 (double)c->h_ctr->t_wait / (double)c->h_ctr->t_tiles, (double)c->h_ctr->t_work / (double)c->h_ctr->t_tiles,
                 (unsigned long long)c->h_ctr->t_tiles, (double)c->h_ctr->t_total);
+    if ((c->dbg & DBG_AGG8_TIMING) && c->d_ctr && c->h_ctr && hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost) == hipSuccess &&
+        c->h_ctr->t_tiles)
+        fprintf(stderr, "[flowagg timing] agg8_kernel per workgroup and pass (us): set-up %.2f  segment walk %.2f  flush %.2f  | %llu\n",
+                (double)c->h_ctr->t_total / (double)c->h_ctr->t_tiles * 0.01, (double)c->h_ctr->t_wait / (double)c->h_ctr->t_tiles * 0.01,
+                (double)c->h_ctr->t_work / (double)c->h_ctr->t_tiles * 0.01, (unsigned long long)c->h_ctr->t_tiles);
     if ((c->dbg & DBG_CMS_TIMING) && c->d_ctr && c->h_ctr && hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost) == hipSuccess &&
         c->h_ctr->t_tiles)
         fprintf(stderr, "[flowagg timing] cms_agg_kernel per workgroup (us): schedule + counts + flush %.2f  segment walk %.2f  | workgroups %llu  mean wave's walk %.2f\n",
