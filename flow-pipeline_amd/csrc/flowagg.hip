@@ -78,7 +78,32 @@ struct fa_ctx {
     size_t wseg_bytes = 0;
     uint32_t* wseg_counts = nullptr;
     size_t wseg_counts_cap = 0;
-    int wide_mode = 0;         // env FA_WIDE: 0 adaptive, 1 "atomic" (every update through memory-side atomics), 2 "scatter" (always the scatter sink)
+    int wide_mode = 0;         // env FA_WIDE: 0 adaptive, 1 "atomic" (every update through memory-side atomics), 2 "scatter" (always the scatter sink),
+                               // 3 "log": scatter, and the launch's tuples stay in their segments (wlog below) instead of being folded at once
+    // ---- wide log (FA_WIDE=log) ----
+    // A (SrcAddr,DstPort,Proto) stream opens a row for nearly every record: folding a launch's tuples into the hash table is
+    // two random HBM accesses per record that aggregate nothing - and the window close sorts the rows anyway.  In log mode a
+    // launch's segment buffers are simply KEPT (a chunk); reads take the table's rows AND the chunks' tuples through the
+    // same sort + segmented sums; a close moves the chunks' watermark; only when more than wlog_max chunks are pending (or
+    // the table is rebuilt) the oldest is folded into the table after all (wagg_kernel, or the atomic replay when the
+    // table's geometry has changed since).
+    struct WChunk {
+        uint4* seg = nullptr;
+        size_t seg_bytes = 0;
+        uint32_t* counts = nullptr;   // [nparts][nwg] (+ 4 words: [counts_cap] = the launch's time base)
+        size_t counts_cap = 0;
+        uint32_t nwg = 0, wcapq = 0, wplog2 = 0, wmask = 0, wm = 0;  // wm: buckets below it were dropped after this launch
+        size_t wregion = 0;
+        uint64_t n = 0;               // records of the launch (upper bound of its tuples)
+    };
+    std::vector<WChunk> wlog, wlog_free;
+    bool wide_defer = false;       // adaptive (FA_WIDE unset): log mode from the moment more than half of a million records opened new rows - for
+                                   // the rest of the ctx's life (deferred launches tell nothing about new rows; a stream that stops opening
+                                   // rows folds its chunks through wagg_kernel once more than wlog_max are pending: the scatter sink's cost)
+    bool wlog_now = false;         // the launch being prepared runs in log mode
+    size_t wlog_max = 8;
+    uint64_t wlog_rows_bound = 0;  // upper bound of the table's rows: stats.wide_used at the last settle + records of the chunks folded since
+    uint64_t wlog_recorded = 0, wlog_folded = 0, wlog_replayed = 0, wlog_dropped = 0;  // chunks (FA_VERBOSE)
     bool wide_scatter = true;  // adaptive: the scatter sink while a good share of the records open new rows (7 atomics each
                                // on the atomic path); a stream that mostly hits existing rows (one atomic line transaction
                                // each) is cheaper without the detour through the segments
@@ -294,7 +319,8 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_SINK")) c->sink_mode = !strcmp(d, "direct") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
     if (const char* d = getenv("FA_AGG")) c->agg_generic = !strcmp(d, "generic");
     if (const char* d = getenv("FA_CMS")) c->cms_atomic = !strcmp(d, "atomic");
-    if (const char* d = getenv("FA_WIDE")) c->wide_mode = !strcmp(d, "atomic") ? 1 : !strcmp(d, "scatter") ? 2 : 0;
+    if (const char* d = getenv("FA_WIDE")) c->wide_mode = !strcmp(d, "atomic") ? 1 : !strcmp(d, "scatter") ? 2 : !strcmp(d, "log") ? 3 : 0;
+    if (const char* d = getenv("FA_WIDE_LOG_CHUNKS")) c->wlog_max = (size_t)std::max(0, atoi(d));
     if (const char* d = getenv("FA_AGG_PASSES")) {
         const int v = atoi(d);
         c->agg_passes_forced = (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 0u;
@@ -393,6 +419,9 @@ extern "C" void fa_destroy(fa_ctx* c) {
         fprintf(stderr, "[flowagg] agg8: %llu groups added in %llu launches, passes now %u; direct %llu, ok %llu, wide rows %llu\n",
                 (unsigned long long)c->h_ctr->agg_groups, (unsigned long long)c->h_ctr->agg_launches, c->agg_passes,
                 (unsigned long long)c->h_ctr->direct, (unsigned long long)c->h_ctr->ok, (unsigned long long)(c->wused_base + c->h_ctr->wused));
+    if (getenv("FA_VERBOSE") && c->wlog_recorded)
+        fprintf(stderr, "[flowagg] wide log: %llu chunks recorded, %llu folded by wagg_kernel, %llu by the atomic replay, %llu dropped whole, %zu pending\n",
+                (unsigned long long)c->wlog_recorded, (unsigned long long)c->wlog_folded, (unsigned long long)c->wlog_replayed, (unsigned long long)c->wlog_dropped, c->wlog.size());
     if ((c->dbg & DBG_TIMING) && c->d_ctr && c->h_ctr && hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost) == hipSuccess &&
         c->h_ctr->t_tiles)
         fprintf(stderr, "[flowagg timing] per tile (wave 0 of every workgroup, core clocks): wait %.0f  work %.0f  | tiles %llu  total/wg-launch %.0f\n",
@@ -461,6 +490,11 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->hot_seed_tag);
     (void)hipFree(c->wseg);
     (void)hipFree(c->wseg_counts);
+    for (auto* v : {&c->wlog, &c->wlog_free})
+        for (auto& k : *v) {
+            (void)hipFree(k.seg);
+            (void)hipFree(k.counts);
+        }
     for (int i = 0; i < 2; i++) {
         if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
         (void)hipFree(c->d_in[i]);
@@ -600,13 +634,15 @@ static void format_feedback(fa_ctx* c, const Counters& h) {
     if (d_ok && d_mis * 16 > d_ok) c->t8_wide_until = c->stats.batches + 64;
     c->seen_misfit8 = h.misfit8;
     c->seen_ok = h.ok;
-    if (c->wtab) {  // (SrcAddr,DstPort,Proto): scatter sink or atomics, by the share of records that opened a row lately
+    if (c->wtab && !c->wide_defer) {  // (SrcAddr,DstPort,Proto): scatter sink or atomics, by the share of records that opened a row lately
         if (h.wused < c->seen_wused) c->seen_wused = h.wused;  // (table rebuilt: the count starts over)
         if (h.ok < c->seen_ok_w) c->seen_ok_w = h.ok;
         const uint64_t dw = h.wused - c->seen_wused, dn = h.ok - c->seen_ok_w;
         if (dn >= (1u << 20)) {
             if (dw * 5 > dn) c->wide_scatter = true;
             else if (dw * 10 < dn) c->wide_scatter = false;
+            // ... and no table at all for a stream that opens a row for most of its records: the log (fa_ctx::wlog)
+            if (c->wide_mode == 0 && c->wide_scatter && dw * 2 > dn && c->wlog_max > 0) c->wide_defer = true;
             c->seen_wused = h.wused;
             c->seen_ok_w = h.ok;
         }
@@ -700,6 +736,110 @@ static int settle(fa_ctx* c) {
     c->known_records = c->launched_records;
     c->known_seq = c->launch_seq;
     return rc;
+}
+
+// ---- wide log (FA_WIDE=log; fa_ctx::wlog) -----------------------------------------------------------------------------
+static WChunkArgs wchunk_args(const fa_ctx::WChunk& k) {
+    return WChunkArgs{k.seg, k.counts, k.counts + k.counts_cap, 1u << k.wplog2, k.nwg, k.wcapq, k.wm, k.wregion};
+}
+// room in the table for `more` new rows at <= 50 % load (host-side bound first; a settle - and a one-step growth - only when
+// the bound says so)
+static int wlog_make_room(fa_ctx* c, uint64_t more) {
+    if ((c->wlog_rows_bound + more) * 2 <= (1ull << c->wcap_log2)) return FA_OK;
+    int rc = settle(c);
+    if (rc) return rc;
+    c->wlog_rows_bound = c->stats.wide_used;
+    if ((c->wlog_rows_bound + more) * 2 <= (1ull << c->wcap_log2)) return FA_OK;
+    const uint32_t want = log2_ceil(2 * (c->wlog_rows_bound + more));
+    if (want > 30) return fail(c, FA_ERR_TABLE_FULL, "wide-key table cannot grow further");
+    return rebuild_wide(c, want, 0, 0, 0);  // (pending chunks stay pending: they are folded by the atomic replay from now on)
+}
+// one pending chunk into the table: wagg_kernel while the table still has the geometry the tuples were scattered for (its
+// workgroups own "their" regions' tuples), the atomic replay otherwise; the buffers go to the free list
+static int wlog_fold(fa_ctx* c, const fa_ctx::WChunk& k) {
+    KArgs a = make_args(c);
+    if (k.wplog2 == a.wplog2 && k.wmask == a.wmask) {
+        a.wseg = k.seg;
+        a.wseg_counts = k.counts;
+        a.nwg = k.nwg;
+        a.wcapq = k.wcapq;
+        a.wregion = k.wregion;
+        hipLaunchKernelGGL(wagg_kernel, dim3(1u << a.wplog2), dim3(WAGG_BLOCK), 0, c->stream, a, (const uint32_t*)(k.counts + k.counts_cap), k.wm);
+        c->wlog_folded++;
+    } else {
+        hipLaunchKernelGGL(wlog_replay_kernel, dim3(2048), dim3(256), 0, c->stream, wchunk_args(k), a);
+        c->wlog_replayed++;
+    }
+    HIPCHK(c, hipGetLastError());
+    c->wlog_rows_bound += k.n;
+    c->wlog_free.push_back(k);
+    return FA_OK;
+}
+static int wlog_flush_oldest(fa_ctx* c) {
+    const fa_ctx::WChunk k = c->wlog.front();
+    int rc = wlog_make_room(c, k.n);
+    if (rc) return rc;
+    c->wlog.erase(c->wlog.begin());
+    return wlog_fold(c, k);
+}
+static int wlog_flush_all(fa_ctx* c) {
+    while (!c->wlog.empty()) {
+        int rc = wlog_flush_oldest(c);
+        if (rc) return rc;
+    }
+    return FA_OK;
+}
+// behind a log-mode launch: its segment buffers become the newest chunk (the ctx allocates or recycles others for the next
+// launch); more than wlog_max pending: the oldest is folded into the table after all
+static int wlog_record(fa_ctx* c, const KArgs& a, size_t n) {
+    fa_ctx::WChunk k;
+    k.seg = c->wseg;
+    k.seg_bytes = c->wseg_bytes;
+    k.counts = c->wseg_counts;
+    k.counts_cap = c->wseg_counts_cap;
+    k.nwg = a.nwg;
+    k.wcapq = a.wcapq;
+    k.wplog2 = a.wplog2;
+    k.wmask = a.wmask;
+    k.wregion = a.wregion;
+    k.n = n;
+    c->wlog.push_back(k);
+    c->wlog_recorded++;
+    c->wseg = nullptr;
+    c->wseg_bytes = 0;
+    c->wseg_counts = nullptr;
+    c->wseg_counts_cap = 0;
+    while (c->wlog.size() > c->wlog_max) {
+        int rc = wlog_flush_oldest(c);
+        if (rc) return rc;
+    }
+    return FA_OK;
+}
+// a drop of buckets [lo, hi) as far as the pending chunks go: when nothing older is alive in them it is their watermark
+// (tuples below it are skipped by every later read and fold); anything else folds them into the table first, where the
+// caller's rebuild removes the range
+static int wlog_drop(fa_ctx* c, uint32_t lo, uint32_t hi) {
+    if (c->wlog.empty()) return FA_OK;
+    uint32_t oldest = 0xFFFFFFFFu;
+    std::vector<uint32_t> base(c->wlog.size());
+    for (size_t i = 0; i < c->wlog.size(); i++)
+        HIPCHK(c, hipMemcpyAsync(&base[i], c->wlog[i].counts + c->wlog[i].counts_cap, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->wlog.size(); i++) oldest = std::min(oldest, std::max(base[i], c->wlog[i].wm));
+    if (lo > oldest) return wlog_flush_all(c);
+    for (size_t i = 0; i < c->wlog.size();) {
+        fa_ctx::WChunk& k = c->wlog[i];
+        k.wm = std::max(k.wm, hi);
+        if ((uint64_t)base[i] + 256u <= k.wm) {  // (relative buckets are < 256: nothing of this chunk is alive)
+            c->wlog_free.push_back(k);
+            c->wlog_dropped++;
+            c->wlog.erase(c->wlog.begin() + (long)i);
+            base.erase(base.begin() + (long)i);
+        } else {
+            i++;
+        }
+    }
+    return FA_OK;
 }
 
 // ---- counter snapshots: never lose aggregates ------------------------------------------------------------
@@ -826,7 +966,13 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
     }
     // fold the (SrcAddr,DstPort,Proto) tuples: one workgroup per table region, plain loads and stores - behind every
     // dispatch of this launch that updates the wide table with atomics (wagg.cuh)
-    if (MODE == MODE_INGEST && wave_tiles && a.wseg) hipLaunchKernelGGL(wagg_kernel, dim3(1u << a.wplog2), dim3(WAGG_BLOCK), 0, c->stream, a);
+    if (MODE == MODE_INGEST && wave_tiles && a.wseg) {
+        if (c->wlog_now) {  // log mode: the tuples stay where they are (the chunk is taken over behind the launch: wlog_record)
+            HIPCHK(c, hipMemcpyAsync(c->wseg_counts + c->wseg_counts_cap, &c->d_ctr->tb_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            hipLaunchKernelGGL(wagg_kernel, dim3(1u << a.wplog2), dim3(WAGG_BLOCK), 0, c->stream, a, (const uint32_t*)nullptr, 0u);
+        }
+    }
     if (ev) (void)hipEventRecord(ev->e2, c->stream);
     HIPCHK(c, hipGetLastError());
     return FA_OK;
@@ -973,8 +1119,16 @@ static int ensure_wsegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     if (c->seg_cap_limit) capq = std::max<uint32_t>(std::min(capq, c->seg_cap_limit), 4u);  // (tests: force the overflow fallback)
     const size_t region = (size_t)nwg * capq + 6;  // (skew against power-of-two strides)
     const size_t bytes = region * nparts * 2 * sizeof(uint4);
+    if (!c->wseg && !c->wseg_counts && !c->wlog_free.empty()) {  // log mode: the buffers of a chunk that has been folded or dropped
+        const fa_ctx::WChunk k = c->wlog_free.back();
+        c->wlog_free.pop_back();
+        c->wseg = k.seg;
+        c->wseg_bytes = k.seg_bytes;
+        c->wseg_counts = k.counts;
+        c->wseg_counts_cap = k.counts_cap;
+    }
     if (c->wseg_bytes < bytes) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->wseg) HIPCHK(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->wseg);
         c->wseg = nullptr;
         c->wseg_bytes = 0;
@@ -983,11 +1137,11 @@ static int ensure_wsegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     }
     const size_t ncnt = (size_t)nwg * nparts;
     if (c->wseg_counts_cap < ncnt) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->wseg_counts) HIPCHK(c, hipStreamSynchronize(c->stream));
         (void)hipFree(c->wseg_counts);
         c->wseg_counts = nullptr;
         c->wseg_counts_cap = 0;
-        if (hipMalloc(&c->wseg_counts, ncnt * sizeof(uint32_t)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide segment counts) failed");
+        if (hipMalloc(&c->wseg_counts, (ncnt + 4) * sizeof(uint32_t)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide segment counts) failed");  // (+ the time base word of a log chunk)
         c->wseg_counts_cap = ncnt;
     }
     a.wseg = c->wseg;
@@ -1071,9 +1225,12 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         if (rc) return rc;
     }
     if (c->use_wave_tiles && c->wtab && (c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO) && grid <= WAGG_MAX_NWG &&
-        (c->wide_mode == 2 || (c->wide_mode == 0 && c->wide_scatter))) {
+        (c->wide_mode == 2 || c->wide_mode == 3 || (c->wide_mode == 0 && c->wide_scatter))) {
         rc = ensure_wsegments(c, n, (uint32_t)grid, a);
         if (rc) return rc;
+        c->wlog_now = c->wide_mode == 3 || (c->wide_mode == 0 && c->wide_defer);
+    } else {
+        c->wlog_now = false;
     }
     if (c->ev_used == c->ev_pool.size()) {
         if (c->ev_pool.size() >= 4096) {  // bound the pool: fold what is pending
@@ -1090,6 +1247,10 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     fa_ctx::LaunchEvents* evp = &c->ev_pool[c->ev_used++];
     rc = launch_tiles<MODE_INGEST>(c, a, grid, evp);
     if (rc) return rc;
+    if (c->wlog_now && a.wseg) {
+        rc = wlog_record(c, a, n);
+        if (rc) return rc;
+    }
     rc = post_launch_snapshot(c, n);
     if (rc) return rc;
     c->stats.bytes_in += len;

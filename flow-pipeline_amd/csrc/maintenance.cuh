@@ -177,6 +177,61 @@ __global__ __launch_bounds__(256) void wextract_kernel(const WSlot* tab, uint32_
         }
     }
 }
+// ---- wide log (FA_WIDE=log): launches whose (SrcAddr,DstPort,Proto) tuples still sit in their scatter segments ----------
+// One chunk = one launch's segments wseg[region][workgroup][q] + counts, its time base (device word) and a watermark
+// (buckets below it were dropped after the launch).  A wave takes a segment at a time.
+struct WChunkArgs {
+    const uint4* wseg;
+    const uint32_t* counts;
+    const uint32_t* tb_base;
+    uint32_t nparts, nwg, capq, wm;
+    size_t region;
+};
+template <class F>
+__device__ __forceinline__ void wchunk_walk(const WChunkArgs& k, F&& f) {
+    const uint32_t lane = __lane_id(), nwaves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t tb_base = *k.tb_base;
+    const uint32_t nseg = k.nparts * k.nwg;
+    for (uint32_t sgi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); sgi < nseg; sgi += nwaves) {
+        const uint32_t p = sgi / k.nwg, w = sgi % k.nwg;
+        const uint32_t cnt = min(k.counts[(size_t)p * k.nwg + w], k.capq);
+        const uint4* base = k.wseg + 2u * ((size_t)p * k.region + (size_t)w * k.capq);
+        for (uint32_t q0 = 0; q0 < cnt; q0 += 64u) {  // (wave-uniform trip count)
+            const uint32_t q = q0 + lane;
+            const bool valid = q < cnt;
+            const uint4 t0 = base[2u * (valid ? q : 0u)], t1 = base[2u * (valid ? q : 0u) + 1u];
+            WKey key;
+            uint64_t bytes, packets;
+            wtup_unpack(t0, t1, tb_base, key, bytes, packets);
+            const uint32_t tb = tb_base + (t1.w >> 24);
+            f(valid && tb >= k.wm, tb, key, bytes, packets);
+        }
+    }
+}
+// the chunk's live tuples of buckets [tb_lo, tb_hi) as packed-key rows (count() = 1 each), appended behind wextract_kernel's
+__global__ __launch_bounds__(256) void wlog_rows_kernel(WChunkArgs k, uint32_t tb_lo, uint32_t tb_hi, WRow* rows, uint32_t rows_cap, Counters* ctr) {
+    const uint32_t lane = __lane_id();
+    wchunk_walk(k, [&](bool live, uint32_t tb, const WKey& key, uint64_t bytes, uint64_t packets) {
+        const bool sel = live && tb >= tb_lo && tb < tb_hi;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(sel);
+        if (m == 0ull) return;
+        const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(&ctr->wrows_count, (unsigned int)__builtin_popcountll(m));
+        base = (unsigned int)__builtin_amdgcn_readlane((int)base, (int)leader);
+        const unsigned int j = base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (sel && j < rows_cap) rows[j] = WRow{{key.w[0], key.w[1], key.w[2], key.w[3]}, bytes, packets, 1ull};
+    });
+}
+// the chunk folded into the table through the atomic path (the table's geometry changed since the tuples were scattered:
+// their regions are not the table's any more, wagg_kernel's ownership does not hold)
+__global__ __launch_bounds__(256) void wlog_replay_kernel(WChunkArgs k, KArgs a) {
+    const WArgs t = wargs(a);
+    wchunk_walk(k, [&](bool live, uint32_t, const WKey& key, uint64_t bytes, uint64_t packets) {
+        if (live) wagg_global(t, key, bytes, packets, 1);
+    });
+}
+
 // Re-inserts every row that is NOT selected into a fresh table (window removal / reset / growth).
 __global__ void wrebuild_kernel(const WSlot* old_tab, uint32_t old_slots, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, KArgs a) {
     const WArgs t = wargs(a);

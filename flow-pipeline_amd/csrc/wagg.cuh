@@ -86,13 +86,16 @@ __device__ __forceinline__ bool wagg_upsert(const WArgs& t, const WKey& k, uint3
     return false;
 }
 
-__global__ __launch_bounds__(WAGG_BLOCK) void wagg_kernel(KArgs a) {
+// tb_base_ptr / wm: a launch's tuples may be folded LATER (log mode, flowagg.hip "wide log"): the time base their relative
+// buckets count from was saved with them, and tuples of buckets below the chunk's watermark - windows dropped in the
+// meantime - are skipped.  nullptr / 0: the launch that has just scattered them.
+__global__ __launch_bounds__(WAGG_BLOCK) void wagg_kernel(KArgs a, const uint32_t* tb_base_ptr, uint32_t wm) {
     __shared__ WAggLds L;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t part = blockIdx.x;
     const uint32_t nwg = min(a.nwg, (uint32_t)WAGG_MAX_NWG);
     const WArgs t = wargs(a);
-    const uint32_t tb_base = a.ctr->tb_base;
+    const uint32_t tb_base = tb_base_ptr ? *tb_base_ptr : a.ctr->tb_base;
     for (int i = tid; i < WAGG_SLOTS; i += WAGG_BLOCK) L.rep[i] = 0;
     if (tid == 0) L.created = 0;
     if (wave == 0) {  // exclusive prefix sums of the segments' tuple counts
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(WAGG_BLOCK) void wagg_kernel(KArgs a) {
 #pragma unroll
         for (int u = 0; u < WAGG_U; u++) {
             const uint32_t e = (uint32_t)u * WAGG_BLOCK + tid;
-            have[u] = base + e < total;
+            have[u] = base + e < total && tb_base + (n1[u].w >> 24) >= wm;
             wtup_unpack(n0[u], n1[u], tb_base, k[u], b[u], p[u]);
             h[u] = wkey_hash(k[u]);
             L.k[0][e] = k[u].w[0];

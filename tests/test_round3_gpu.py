@@ -422,3 +422,59 @@ def test_one_sketch_alone_through_the_scheduled_fold(gpu_lib, fa, po, key_sets):
             for c in ("bytes", "packets", "count"):
                 want_rows[c] *= np.uint64(3)
             assert agg.read_window().tobytes() == want_rows.tobytes()
+
+
+@pytest.mark.parametrize("chunks,cap_log2,key_sets", [(8, 20, 9), (1, 20, 9), (0, 20, 9), (2, 10, 9), (8, 18, 63)])
+def test_wide_log_mode_equals_the_oracle(gpu_lib, fa, po, monkeypatch, chunks, cap_log2, key_sets):
+    """FA_WIDE=log: a launch's (SrcAddr,DstPort,Proto) tuples stay in their scatter segments (chunks) instead of being folded into
+    the hash table; reads take table rows and chunk tuples through the same device merge; a close of the oldest buckets is the
+    chunks' watermark, any other drop folds them first; more than FA_WIDE_LOG_CHUNKS pending chunks: the oldest is folded
+    (wagg_kernel, or the atomic replay once the table has grown - cap_log2 10).  Whatever the mix: rows == the oracle's."""
+    monkeypatch.setenv("FA_WIDE", "log")
+    monkeypatch.setenv("FA_WIDE_LOG_CHUNKS", str(chunks))
+    n, parts = 240_000, 4
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=77, n_total=n, zipf_log2_universe=12, span_secs=900)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    assert status.sum() == 0
+    sub = 60
+
+    def want(ts, sel=None):
+        r, s = (rows, status) if sel is None else (rows[sel], status[sel])
+        if ts == fa.ALL_TIMESLOTS:
+            return po.rollup_app(r, s, sub).astype(fa.ROW_APP_DTYPE)
+        return po.rollup_app(r, s, sub, window=300, timeslot=ts).astype(fa.ROW_APP_DTYPE)
+
+    with fa.FlowAgg(framed=True, key_sets=key_sets, subwindow_secs=sub, wide_capacity_log2=cap_log2, cms_width_log2=12, topk_capacity_log2=14,
+                    max_batch_records=n // parts) as agg:
+        step = n // parts
+        for i in range(parts):
+            a, b = i * step, (i + 1) * step
+            agg.ingest(buf[int(off[a]):int(off[b])], off[a:b + 1] - off[a])
+        slots = agg.open_timeslots()
+        t0 = int(slots[0])
+        for ts in (fa.ALL_TIMESLOTS, t0, t0 + 60, t0 + 300):
+            assert agg.read_window_app(ts).tobytes() == want(ts).tobytes(), ("read", ts)
+        # flows_5m is untouched by the mode
+        ref = po.Rollup(sub)
+        ref.ingest(buf, off, 1)
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+        # a sliding close removes the oldest sub-bucket only ...
+        t32 = rows["time_received"].astype(np.uint64).astype(np.uint32)
+        assert agg.close_window_app(t0).tobytes() == want(t0).tobytes()
+        alive = t32 >= t0 + 60
+        assert agg.read_window_app(t0 + 60).tobytes() == want(t0 + 60, alive).tobytes()
+        assert agg.read_window_app(fa.ALL_TIMESLOTS).tobytes() == want(fa.ALL_TIMESLOTS, alive).tobytes()
+        # ... more records (a launch behind the drop: its tuples of old buckets are late rows, not dropped ones) ...
+        agg.ingest(buf[: int(off[step])], off[: step + 1])
+        sel2 = np.concatenate([np.nonzero(alive)[0], np.arange(step)])
+        assert agg.read_window_app(fa.ALL_TIMESLOTS).tobytes() == want(fa.ALL_TIMESLOTS, sel2).tobytes()
+        # ... and a drop that is NOT the oldest buckets (the chunks are folded into the table first)
+        mid = t0 + 300
+        got = agg.close_window_app(mid)
+        assert got.tobytes() == want(mid, sel2).tobytes()
+        keep = sel2[~((t32[sel2] >= mid) & (t32[sel2] < mid + 60))]
+        assert agg.read_window_app(fa.ALL_TIMESLOTS).tobytes() == want(fa.ALL_TIMESLOTS, keep).tobytes()
+        st = agg.stats()
+        assert st["records_bad"] == 0 and st["records_ok"] == n + step
+        assert st["wave_tile_launches"] == parts + 1  # (every launch went through the scatter sink: its tuples were a chunk)

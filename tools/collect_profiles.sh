@@ -19,7 +19,7 @@ for v in decode goflow reversed ks7 ks9; do  # projection stage, collector-shape
   [ -s ${P}_$v/summary.txt ] && cp ${P}_$v/summary.txt $D/${TAG}_${v}_rocprof_summary.txt
 done
 [ -s $S/pcie_rate.json ] && cp $S/pcie_rate.json $D/${TAG}_pcie_rate.json
-for f in config3_1B config4_8ranks_1gpu config5_100M config5_8ranks_1gpu; do
+for f in config3_1B config4_8ranks_1gpu config5_100M config5_100M_scatter config5_100M_log config5_8ranks_1gpu; do
   [ -s $S/$f.json ] && grep '^{' $S/$f.json | tail -1 > $D/${TAG}_$f.json
 done
 ls -la $D/${TAG}_*

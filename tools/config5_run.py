@@ -134,12 +134,17 @@ def main():
         # ---- (SrcAddr,DstPort,Proto): totals over all windows
         cnt = by = 0
         nrows = 0
+        app_ms = []
         for ts in aligned:
+            tw = time.perf_counter()
             app = agg.read_window_app(ts)
+            app_ms.append((time.perf_counter() - tw) * 1e3)
             cnt += int(app["count"].sum())
             by += int(app["bytes"].sum(dtype=np.uint64))
             nrows += len(app)
         out["app_rows"] = nrows
+        out["read_app_windows_ms"] = [round(x, 1) for x in app_ms]  # (SrcAddr,DstPort,Proto) rows of one aligned window each: collect + device merge + copy out
+        out["wide_mode"] = os.environ.get("FA_WIDE", "adaptive")
         out["app_count_equals_records"] = bool(cnt == n)
         out["app_sum_bytes_equals_flows_5m"] = bool(by == int(allrows["bytes"].sum(dtype=np.uint64)))
     print(json.dumps(out))
