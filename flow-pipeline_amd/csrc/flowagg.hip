@@ -101,6 +101,7 @@ struct fa_ctx {
                                    // the rest of the ctx's life (deferred launches tell nothing about new rows; a stream that stops opening
                                    // rows folds its chunks through wagg_kernel once more than wlog_max are pending: the scatter sink's cost)
     bool wlog_now = false;         // the launch being prepared runs in log mode
+    uint64_t seen_wfold = 0;       // Counters::wfold_n at the last feedback look
     size_t wlog_max = 8;
     uint64_t wlog_rows_bound = 0;  // upper bound of the table's rows: stats.wide_used at the last settle + records of the chunks folded since
     uint64_t wlog_recorded = 0, wlog_folded = 0, wlog_replayed = 0, wlog_dropped = 0;  // chunks (FA_VERBOSE)
@@ -642,9 +643,28 @@ static void format_feedback(fa_ctx* c, const Counters& h) {
             if (dw * 5 > dn) c->wide_scatter = true;
             else if (dw * 10 < dn) c->wide_scatter = false;
             // ... and no table at all for a stream that opens a row for most of its records: the log (fa_ctx::wlog)
-            if (c->wide_mode == 0 && c->wide_scatter && dw * 2 > dn && c->wlog_max > 0) c->wide_defer = true;
+            if (c->wide_mode == 0 && c->wide_scatter && dw * 2 > dn && c->wlog_max > 0) {
+                c->wide_defer = true;
+                c->seen_wfold = h.wfold_n;
+            }
             c->seen_wused = h.wused;
             c->seen_ok_w = h.ok;
+        }
+    }
+    if (c->wtab && c->wide_defer && c->wide_mode == 0) {  // log mode chosen by the library: do the chunks that ARE folded still open rows?
+        const uint64_t dn = h.wfold_n - c->seen_wfold;
+        if (h.wused < c->seen_wused || h.wfold_n < c->seen_wfold) {  // (table rebuilt / counters restarted: no verdict from this look)
+            c->seen_wused = h.wused;
+            c->seen_wfold = h.wfold_n;
+        } else if (dn >= (1u << 20)) {
+            // fewer than half of the folded tuples opened a row: this stream aggregates - back to the table (scatter sink or
+            // atomics, by the feedback above); the chunks still pending are folded one per launch (fa_ingest_device)
+            if ((h.wused - c->seen_wused) * 2 < dn) {
+                c->wide_defer = false;
+                c->seen_ok_w = h.ok;
+            }
+            c->seen_wused = h.wused;
+            c->seen_wfold = h.wfold_n;
         }
     }
     // passes of agg8_kernel: the groups a launch adds to the device table, per partition and pass, against the LDS table
@@ -1250,6 +1270,14 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     if (c->wlog_now && a.wseg) {
         rc = wlog_record(c, a, n);
         if (rc) return rc;
+    } else if (c->wide_mode == 0 && !c->wide_defer && !c->wlog.empty()) {
+        // the library left the log mode: what is pending drains - a chunk per launch while wagg_kernel can take it (1.2 ms), one
+        // in eight launches when the table has grown since and it is the atomic replay (13 ms for 16.67 M tuples)
+        const fa_ctx::WChunk& k = c->wlog.front();
+        if ((k.wplog2 == a.wplog2 && k.wmask == a.wmask) || c->stats.batches % 8 == 0) {
+            rc = wlog_flush_oldest(c);
+            if (rc) return rc;
+        }
     }
     rc = post_launch_snapshot(c, n);
     if (rc) return rc;

@@ -229,6 +229,8 @@ __global__ __launch_bounds__(256) void wlog_replay_kernel(WChunkArgs k, KArgs a)
     const WArgs t = wargs(a);
     wchunk_walk(k, [&](bool live, uint32_t, const WKey& key, uint64_t bytes, uint64_t packets) {
         if (live) wagg_global(t, key, bytes, packets, 1);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(live);
+        if (m != 0ull && __lane_id() == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&a.ctr->wfold_n, (unsigned long long)__builtin_popcountll(m));
     });
 }
 

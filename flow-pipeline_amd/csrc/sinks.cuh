@@ -105,6 +105,7 @@ struct Counters {
     unsigned int exotic_count[2], retry_count[2];
     unsigned int spill_count, rows_count, tb_base, ks_overflow, ks_rows, pad;
     unsigned long long t_wait, t_work, t_tiles, t_total;  // DBG_TIMING: core-clock cycles of wave 0 of every workgroup
+    unsigned long long wfold_n;  // tuples of wide-log chunks folded into the table so far (beside wused: do folds still open rows?)
     unsigned long long wused, wspill_lost;  // wide table (wide.cuh)
     unsigned int wspill_count, wrows_count;
     unsigned long long agg_groups, agg_launches;  // agg8_kernel: groups it added to the device table, launches (pass-count feedback)

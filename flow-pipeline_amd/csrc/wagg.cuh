@@ -255,6 +255,7 @@ __global__ __launch_bounds__(WAGG_BLOCK) void wagg_kernel(KArgs a, const uint32_
     if (lane == 0 && cw) atomicAdd(&L.created, cw);
     __syncthreads();
     if (tid == 0 && L.created) atomicAdd(t.used, (unsigned long long)L.created);
+    if (tid == 0 && tb_base_ptr && total) atomicAdd(&a.ctr->wfold_n, (unsigned long long)total);  // (a log chunk's fold: feedback for the host)
 }
 
 }  // namespace fa
