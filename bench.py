@@ -106,31 +106,37 @@ def effective_cpus():
     return eff, aff, quota
 
 
-def cpu_baseline(po, gp, sample, n_rec, groups_hint):
+def cpu_baseline(po, gp, per_thread, n_rec, groups_hint, reps=3):
     """The C oracle (decode + 15-column projection + hash rollup, one shard per thread, merge by key partition) on
-    the CPUs this process may really use (affinity mask cut by the cgroup quota).  Thread sweep; the sample grows with
-    the thread count (>= 1 M records per thread, up to the whole step) so that every shard still aggregates - with
-    fewer records per shard than there are groups the job degenerates into a merge; shard tables are sized from the
-    group count, allocated and first-touched before the start barrier, and sit on 2 MiB pages (round 2's sweep got
-    slower past 8 threads: page faults inside the timed region and one TLB miss per record under the hypervisor)."""
+    the CPUs this process may really use (affinity mask cut by the cgroup quota).  Thread sweep with the SAME number of
+    records per thread at every point (`per_thread`, 4 M by default: 64 M records and >= 0.3 s of timed region at 16
+    threads - round 3 timed 0.08 s and the figure moved by 20 % from run to run), every point run `reps` times and
+    reported as the MEDIAN; shard tables are sized from the group count, allocated and first-touched before the start
+    barrier, and sit on 2 MiB pages."""
     cores, aff, quota = effective_cpus()
     sweep, detail = {}, {}
     points = sorted({1, 8, 32, max(1, cores // 2), cores} & set(range(1, cores + 1)) | {1})
-    best = None
     for th in points:
-        n = min(n_rec, max(4_000_000 if th == 1 else sample, 1_000_000 * th))
-        r = po.bench_rollup_ex(gp, 0, n, th, groups_hint)
-        assert r["bad"] == 0
-        rate = n / r["seconds"]
-        sweep[th] = rate
-        detail[th] = {"records": n, "seconds": r["seconds"], "decode_seconds_min": r["decode_seconds_min"],
-                      "decode_seconds_max": r["decode_seconds_max"], "decode_seconds_mean": r["decode_seconds_mean"],
-                      "merge_seconds": r["merge_seconds"], "wire_bytes": r["wire_bytes"]}
-        if best is None or rate > best[1]:
-            best = (th, rate, n, r)
-    th, rate, n_used, r = best
+        n = min(n_rec, per_thread * th)
+        runs = []
+        for _ in range(reps):
+            r = po.bench_rollup_ex(gp, 0, n, th, groups_hint)
+            assert r["bad"] == 0
+            runs.append(r)
+        runs.sort(key=lambda r: r["seconds"])
+        r = runs[len(runs) // 2]
+        sweep[th] = n / r["seconds"]
+        detail[th] = {"records": n, "seconds": r["seconds"], "seconds_all_runs": [x["seconds"] for x in runs],
+                      "decode_seconds_min": r["decode_seconds_min"], "decode_seconds_max": r["decode_seconds_max"],
+                      "decode_seconds_mean": r["decode_seconds_mean"], "merge_seconds": r["merge_seconds"], "wire_bytes": r["wire_bytes"],
+                      "_run": r}
+    th = max(sweep, key=lambda k: sweep[k])
+    rate, n_used, r = sweep[th], detail[th]["records"], detail[th]["_run"]
+    for d in detail.values():
+        d.pop("_run")
     single = sweep[1]
     eff = rate / (th * single) if single > 0 else 0.0
+    spread = max(detail[th]["seconds_all_runs"]) / min(detail[th]["seconds_all_runs"]) - 1.0
     # what bounds the best point: the slowest shard's decode + rollup, or the merge behind it
     limiter = ("per-shard decode + hash rollup (slowest thread %.3f s of %.3f s; the rest is the key-partitioned merge)"
                % (r["decode_seconds_max"], r["seconds"]))
@@ -146,12 +152,14 @@ def cpu_baseline(po, gp, sample, n_rec, groups_hint):
         "cores_affinity": aff,
         "cgroup_cpu_quota": quota,
         "kind": "port",
-        "sample": "first %d records of the same workload (%.2f GB wire), C oracle restatement (generic protobuf walk + "
-                  "15-column projection + open-addressing rollup), one shard per thread, shard tables sized from the group "
-                  "count and first-touched before the start barrier (2 MiB pages), merged by key partition; best of a thread "
-                  "sweep; the Go inserter + ClickHouse cannot run in this image"
-                  % (n_used, r["wire_bytes"] / 1e9),
+        "sample": "first %d records of the same workload (%.2f GB wire; %d per thread at every point of the sweep), C oracle "
+                  "restatement (generic protobuf walk + 15-column projection + open-addressing rollup), one shard per thread, "
+                  "shard tables sized from the group count and first-touched before the start barrier (2 MiB pages), merged by "
+                  "key partition; median of %d runs per point, best point of the sweep; the Go inserter + ClickHouse cannot run "
+                  "in this image" % (n_used, r["wire_bytes"] / 1e9, per_thread, reps),
         "seconds": r["seconds"],
+        "runs_per_point": reps,
+        "run_to_run_spread_at_best_point": spread,
         "thread_sweep_records_per_s": {str(k): v for k, v in sorted(sweep.items())},
         "thread_sweep_detail": {str(k): v for k, v in sorted(detail.items())},
         "single_core_value": single,
@@ -196,7 +204,7 @@ def main():
     ap.add_argument("--mode", default="aspairs", choices=["mocker", "aspairs", "zipf", "goflow", "reversed", "distinct"])
     ap.add_argument("--stage", default="ingest", choices=["ingest", "decode"],
                     help="decode: the projection stage alone (wire bytes -> 15 SoA columns in HBM, fa_decode_device)")
-    ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="records timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="records PER THREAD timed on the CPU oracle at every point of the thread sweep (0 = skip)")
     ap.add_argument("--key-sets", type=int, default=1, help="fa key_sets mask (must include 1 = flows_5m rollup); 9 = config 5's "
                     "two concurrent key sets; side measurements only - the default is the BASELINE metric")
     ap.add_argument("--zipf-s", type=int, default=110, help="zipf exponent x100 for --mode zipf")
