@@ -63,7 +63,9 @@ class Stats(C.Structure):
         "records_ok", "records_bad", "records_slow", "bytes_in", "batches", "table_used",
         "table_capacity", "kernel_ns", "kernel_ns_total", "kernel_launches", "batch_ns_total",
         "records_direct", "records_retried", "wide_used", "wide_capacity", "wave_tile_launches",
-        "compact_tuple_launches", "records_misfit_compact", "decode_ns_total", "decode_launches")]
+        "compact_tuple_launches", "records_misfit_compact", "decode_ns_total", "decode_launches",
+        "records_late", "wide_log_chunks", "wide_log_bytes", "wide_log_records", "wide_log_recorded", "wide_log_folded",
+        "wide_log_replayed", "wide_log_dropped", "wide_log_watermark_moves", "wide_log_nomem_folds", "wide_log_mode")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -121,7 +123,7 @@ EXPORTS = [
     "fa_mock_generate_device", "fa_mock_generate_host",
     "fa_read_window_app", "fa_close_window_app", "fa_merge_rows_app", "fa_top_ports", "fa_merge_ports",
     "fa_minute_series", "fa_merge_minutes", "fa_dashboard_reset", "fa_rows_to_rowbinary", "fa_format_addr",
-    "fa_row_bytes", "fa_rows_device", "fa_rows_merge_device", "fa_rows_fetch", "fa_drop_window",
+    "fa_row_bytes", "fa_rows_device", "fa_rows_merge_device", "fa_rows_fetch", "fa_drop_window", "fa_rows_partition_device",
 ]
 # row kinds of the device-resident window close (include/flowagg.h, ABI 5)
 ROWS_5M, ROWS_APP, ROWS_PORT_SRC, ROWS_PORT_DST, ROWS_MINUTE, ROWS_TOPK_SRC, ROWS_TOPK_DST = range(7)
@@ -233,6 +235,7 @@ def lib():
     L.fa_rows_device.argtypes = [vp, C.c_int, u32, sz, C.POINTER(vp), szp]
     L.fa_rows_merge_device.argtypes = [vp, C.c_int, vp, sz, sz, C.POINTER(vp), szp]
     L.fa_rows_fetch.argtypes = [vp, C.c_int, vp, sz, vp, sz]
+    L.fa_rows_partition_device.argtypes = [vp, C.c_int, vp, sz, u32, C.POINTER(vp), szp]
     L.fa_drop_window.argtypes = [vp, C.c_int, u32]
     _LIB = L
     return L
@@ -418,11 +421,21 @@ class FlowAgg:
         self._chk(self._L.fa_rows_merge_device(self._h, kind, d_rows_ptr, n, k, C.byref(p), C.byref(m)))
         return p.value or 0, m.value
 
-    def rows_fetch(self, kind: int, d_rows_ptr: int, n: int) -> np.ndarray:
-        out = np.empty(n, dtype=ROW_DTYPES[kind])
+    def rows_fetch(self, kind: int, d_rows_ptr: int, n: int, out: np.ndarray | None = None) -> np.ndarray:
+        """n rows of `kind` from HBM to the host (large results leave through the ctx's pinned buffer in pieces).  out: a
+        buffer of the kind's dtype to reuse (a consumer keeps one per row kind: fresh pages cost more than the copy)."""
+        if out is None or len(out) < n or out.dtype != ROW_DTYPES[kind]:
+            out = np.empty(n, dtype=ROW_DTYPES[kind])
         if n:
-            self._chk(self._L.fa_rows_fetch(self._h, kind, d_rows_ptr, n, out.ctypes.data, n))
-        return out
+            self._chk(self._L.fa_rows_fetch(self._h, kind, d_rows_ptr, n, out.ctypes.data, len(out)))
+        return out[:n]
+
+    def rows_partition_device(self, kind: int, d_rows_ptr: int, n: int, world: int):
+        """n rows in HBM regrouped by owning rank (hash of the key) -> (device pointer, counts per rank)."""
+        p = C.c_void_p()
+        counts = (C.c_size_t * world)()
+        self._chk(self._L.fa_rows_partition_device(self._h, kind, d_rows_ptr, n, world, C.byref(p), counts))
+        return p.value or 0, [int(x) for x in counts]
 
     def drop_window(self, kind: int, timeslot=ALL_TIMESLOTS):
         """Removes what close_window / close_window_app would remove after emitting `timeslot`."""
@@ -445,11 +458,20 @@ class FlowAgg:
         self._chk(self._L.fa_merge_rows(self._h, r.ctypes.data, len(r)))
 
     # -- second exact key set: (SrcAddr, DstPort, Proto) -------------------------------
-    def read_window_app(self, timeslot=ALL_TIMESLOTS) -> np.ndarray:
-        return self._rows_call(self._L.fa_read_window_app, timeslot, ROW_APP_DTYPE)
+    def read_window_app(self, timeslot=ALL_TIMESLOTS, out: np.ndarray | None = None) -> np.ndarray:
+        # With pending log chunks the table's row count says nothing about the size of a window (and a too small buffer
+        # makes the library collect and sort the window twice): the result is left in HBM first, then fetched.
+        if out is None and self.stats()["wide_log_chunks"] == 0:
+            return self._rows_call(self._L.fa_read_window_app, timeslot, ROW_APP_DTYPE)
+        ptr, n = self.rows_device(ROWS_APP, timeslot)
+        return self.rows_fetch(ROWS_APP, ptr, n, out=out)
 
-    def close_window_app(self, timeslot=ALL_TIMESLOTS) -> np.ndarray:
-        return self._rows_call(self._L.fa_close_window_app, timeslot, ROW_APP_DTYPE)
+    def close_window_app(self, timeslot=ALL_TIMESLOTS, out: np.ndarray | None = None) -> np.ndarray:
+        if out is None and self.stats()["wide_log_chunks"] == 0:
+            return self._rows_call(self._L.fa_close_window_app, timeslot, ROW_APP_DTYPE)
+        rows = self.read_window_app(timeslot, out=out)
+        self.drop_window(ROWS_APP, timeslot)
+        return rows
 
     def merge_rows_app(self, rows: np.ndarray):
         r = np.ascontiguousarray(rows, dtype=ROW_APP_DTYPE)

@@ -95,6 +95,8 @@ struct fa_ctx {
         uint32_t nwg = 0, wcapq = 0, wplog2 = 0, wmask = 0, wm = 0;  // wm: buckets below it were dropped after this launch
         size_t wregion = 0;
         uint64_t n = 0;               // records of the launch (upper bound of its tuples)
+        uint32_t minb = 0;            // smallest bucket among the chunk's live tuples when it was last looked for (wlog_drop; valid: minb_known)
+        bool minb_known = false;
     };
     std::vector<WChunk> wlog, wlog_free;
     bool wide_defer = false;       // adaptive (FA_WIDE unset): log mode from the moment more than half of a million records opened new rows - for
@@ -103,8 +105,15 @@ struct fa_ctx {
     bool wlog_now = false;         // the launch being prepared runs in log mode
     uint64_t seen_wfold = 0;       // Counters::wfold_n at the last feedback look
     size_t wlog_max = 8;
-    uint64_t wlog_rows_bound = 0;  // upper bound of the table's rows: stats.wide_used at the last settle + records of the chunks folded since
-    uint64_t wlog_recorded = 0, wlog_folded = 0, wlog_replayed = 0, wlog_dropped = 0;  // chunks (FA_VERBOSE)
+    // Upper bound of the wide table's rows at any moment (wide_rows_bound): what the newest counter snapshot the host has
+    // seen counted, plus every row that whatever was queued BEHIND that snapshot could still open - ingest launches
+    // (a record opens at most wide_per_record rows, through the scatter sink's fold or the atomic paths) and folds of log
+    // chunks (one row per tuple).  wpot_total only grows; every snapshot remembers its value (snap_wpot).
+    uint64_t wpot_total = 0, known_wpot = 0;
+    uint64_t snap_wpot[NSNAP] = {};
+    uint32_t wseg_budget = 0;      // env FA_WSEG_BUDGET (tests only): segment buffers the ctx may hold at a time - the next allocation "fails"
+    uint32_t late_below = 0;       // time buckets below it belong to flows_5m windows that were closed: records that still arrive for them are counted (stats.records_late)
+    uint64_t wlog_recorded = 0, wlog_folded = 0, wlog_replayed = 0, wlog_dropped = 0, wlog_wm_moves = 0, wlog_nomem_folds = 0;  // chunks (fa_stats, FA_VERBOSE)
     bool wide_scatter = true;  // adaptive: the scatter sink while a good share of the records open new rows (7 atomics each
                                // on the atomic path); a stream that mostly hits existing rows (one atomic line transaction
                                // each) is cheaper without the detour through the segments
@@ -157,8 +166,12 @@ struct fa_ctx {
     size_t m_scratch_cap = 0;
     void* m_out[2] = {nullptr, nullptr};  // merged rows; rows in emit order
     size_t m_out_cap[2] = {0, 0};
+    void* part_buf = nullptr;        // fa_rows_partition_device: the rows grouped by destination rank
+    size_t part_cap = 0;
+    unsigned int* part_cnt = nullptr;  // [3][RPART_MAX_WORLD]: counts, starts, cursors
     void* h_rows = nullptr;          // pinned: rows on their way to the caller
     size_t h_rows_cap = 0;
+    hipEvent_t copy_ev[2] = {nullptr, nullptr};  // the two halves of h_rows while a large result leaves in pieces (rows_host.inc)
 
     unsigned long long* cms_src = nullptr;
     unsigned long long* cms_dst = nullptr;
@@ -250,6 +263,7 @@ static KArgs make_args(fa_ctx* c) {
     a.gran_recip = (1.0 / (double)c->gran) * (1.0 + 1.0 / 1099511627776.0);
     a.par = c->par;
     a.agg_passes = c->agg_passes_forced ? c->agg_passes_forced : c->agg_passes;
+    a.late_below = c->late_below;
     return a;
 }
 
@@ -322,6 +336,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_CMS")) c->cms_atomic = !strcmp(d, "atomic");
     if (const char* d = getenv("FA_WIDE")) c->wide_mode = !strcmp(d, "atomic") ? 1 : !strcmp(d, "scatter") ? 2 : !strcmp(d, "log") ? 3 : 0;
     if (const char* d = getenv("FA_WIDE_LOG_CHUNKS")) c->wlog_max = (size_t)std::max(0, atoi(d));
+    if (const char* d = getenv("FA_WSEG_BUDGET")) c->wseg_budget = (uint32_t)std::max(1, atoi(d));
     if (const char* d = getenv("FA_AGG_PASSES")) {
         const int v = atoi(d);
         c->agg_passes_forced = (v == 1 || v == 2 || v == 4 || v == 8) ? (uint32_t)v : 0u;
@@ -345,7 +360,8 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
     for (int i = 0; i < 2; i++)
-        if ((e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming)) != hipSuccess)
+        if ((e = hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&c->copy_ev[i], hipEventDisableTiming)) != hipSuccess)
             return bail("hipEventCreate", e);
     for (int i = 0; i < fa_ctx::NSNAP; i++)
         if ((e = hipEventCreateWithFlags(&c->snap_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -500,6 +516,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
         if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
         (void)hipFree(c->d_in[i]);
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
+        if (c->copy_ev[i]) (void)hipEventDestroy(c->copy_ev[i]);
     }
     (void)hipFree(c->col_block);
     (void)hipFree(c->rc_buf);
@@ -507,6 +524,8 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->m_scratch);
     (void)hipFree(c->m_out[0]);
     (void)hipFree(c->m_out[1]);
+    (void)hipFree(c->part_buf);
+    (void)hipFree(c->part_cnt);
     if (c->h_rows) (void)hipHostFree(c->h_rows);
     (void)hipFree(c->cms_src);
     (void)hipFree(c->cms_dst);
@@ -716,6 +735,7 @@ static int settle(fa_ctx* c) {
     c->stats.records_direct = h.direct;
     c->stats.records_retried = h.retried;
     c->stats.records_misfit_compact = h.misfit8;
+    c->stats.records_late = h.late;
     c->stats.table_used = c->used_base + h.used;
     format_feedback(c, h);
     if (h.spill_lost) {
@@ -755,6 +775,7 @@ static int settle(fa_ctx* c) {
     c->known = h;
     c->known_records = c->launched_records;
     c->known_seq = c->launch_seq;
+    c->known_wpot = c->wpot_total;
     return rc;
 }
 
@@ -764,13 +785,13 @@ static WChunkArgs wchunk_args(const fa_ctx::WChunk& k) {
 }
 // room in the table for `more` new rows at <= 50 % load (host-side bound first; a settle - and a one-step growth - only when
 // the bound says so)
+static uint64_t wide_rows_bound(const fa_ctx* c) { return c->wused_base + c->known.wused + (c->wpot_total - c->known_wpot); }
 static int wlog_make_room(fa_ctx* c, uint64_t more) {
-    if ((c->wlog_rows_bound + more) * 2 <= (1ull << c->wcap_log2)) return FA_OK;
-    int rc = settle(c);
+    if ((wide_rows_bound(c) + more) * 2 <= (1ull << c->wcap_log2)) return FA_OK;
+    int rc = settle(c);  // (exact count; grows the table by itself when it is above 50 % already)
     if (rc) return rc;
-    c->wlog_rows_bound = c->stats.wide_used;
-    if ((c->wlog_rows_bound + more) * 2 <= (1ull << c->wcap_log2)) return FA_OK;
-    const uint32_t want = log2_ceil(2 * (c->wlog_rows_bound + more));
+    if ((c->stats.wide_used + more) * 2 <= (1ull << c->wcap_log2)) return FA_OK;
+    const uint32_t want = log2_ceil(2 * (c->stats.wide_used + more));
     if (want > 30) return fail(c, FA_ERR_TABLE_FULL, "wide-key table cannot grow further");
     return rebuild_wide(c, want, 0, 0, 0);  // (pending chunks stay pending: they are folded by the atomic replay from now on)
 }
@@ -791,7 +812,7 @@ static int wlog_fold(fa_ctx* c, const fa_ctx::WChunk& k) {
         c->wlog_replayed++;
     }
     HIPCHK(c, hipGetLastError());
-    c->wlog_rows_bound += k.n;
+    c->wpot_total += k.n;
     c->wlog_free.push_back(k);
     return FA_OK;
 }
@@ -837,20 +858,41 @@ static int wlog_record(fa_ctx* c, const KArgs& a, size_t n) {
 }
 // a drop of buckets [lo, hi) as far as the pending chunks go: when nothing older is alive in them it is their watermark
 // (tuples below it are skipped by every later read and fold); anything else folds them into the table first, where the
-// caller's rebuild removes the range
+// caller's rebuild removes the range.  "Older" is judged by the smallest bucket among a chunk's live tuples - looked for
+// once per chunk (a scan of its segments, the word behind the time base) and kept: with the launch's time base instead
+// (the smallest SAMPLED bucket - 2) every close of a real timeslot found "something older" and folded all chunks.
 static int wlog_drop(fa_ctx* c, uint32_t lo, uint32_t hi) {
     if (c->wlog.empty()) return FA_OK;
-    uint32_t oldest = 0xFFFFFFFFu;
-    std::vector<uint32_t> base(c->wlog.size());
-    for (size_t i = 0; i < c->wlog.size(); i++)
+    for (auto& k : c->wlog)
+        if (!k.minb_known) {
+            uint32_t* word = k.counts + k.counts_cap + 1;
+            HIPCHK(c, hipMemsetAsync(word, 0xff, sizeof(uint32_t), c->stream));
+            hipLaunchKernelGGL(wlog_minbucket_kernel, dim3(2048), dim3(256), 0, c->stream, wchunk_args(k), word);
+            HIPCHK(c, hipGetLastError());
+        }
+    std::vector<uint32_t> base(c->wlog.size()), minb(c->wlog.size());
+    for (size_t i = 0; i < c->wlog.size(); i++) {
         HIPCHK(c, hipMemcpyAsync(&base[i], c->wlog[i].counts + c->wlog[i].counts_cap, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        if (!c->wlog[i].minb_known) HIPCHK(c, hipMemcpyAsync(&minb[i], c->wlog[i].counts + c->wlog[i].counts_cap + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < c->wlog.size(); i++) oldest = std::min(oldest, std::max(base[i], c->wlog[i].wm));
-    if (lo > oldest) return wlog_flush_all(c);
+    uint32_t oldest = 0xFFFFFFFFu;  // smallest bucket any pending chunk still holds
+    for (size_t i = 0; i < c->wlog.size(); i++) {
+        fa_ctx::WChunk& k = c->wlog[i];
+        if (!k.minb_known) {
+            k.minb = minb[i];  // (~0: no live tuple at all)
+            k.minb_known = true;
+        }
+        if (k.minb != 0xFFFFFFFFu) oldest = std::min(oldest, std::max(k.minb, k.wm));
+    }
+    if (lo > oldest) return wlog_flush_all(c);  // (a range that is not the oldest: the table's rebuild has to remove it)
     for (size_t i = 0; i < c->wlog.size();) {
         fa_ctx::WChunk& k = c->wlog[i];
-        k.wm = std::max(k.wm, hi);
-        if ((uint64_t)base[i] + 256u <= k.wm) {  // (relative buckets are < 256: nothing of this chunk is alive)
+        if (hi > k.wm) {
+            k.wm = hi;
+            c->wlog_wm_moves++;
+        }
+        if (k.minb == 0xFFFFFFFFu || (uint64_t)base[i] + 256u <= k.wm) {  // (relative buckets are < 256: nothing of this chunk is alive)
             c->wlog_free.push_back(k);
             c->wlog_dropped++;
             c->wlog.erase(c->wlog.begin() + (long)i);
@@ -878,6 +920,7 @@ static void poll_snapshots(fa_ctx* c, bool wait_newest) {
             c->known = c->h_snap[k];
             c->known_records = c->snap_records[k];
             c->known_seq = q;
+            c->known_wpot = c->snap_wpot[k];
             format_feedback(c, c->known);
             return;
         }
@@ -910,6 +953,7 @@ static int post_launch_snapshot(fa_ctx* c, size_t n) {
     HIPCHK(c, hipEventRecord(c->snap_ev[k], c->stream));
     c->snap_records[k] = c->launched_records;
     c->snap_seq[k] = c->launch_seq;
+    c->snap_wpot[k] = c->wpot_total;
     return FA_OK;
 }
 
@@ -1139,30 +1183,48 @@ static int ensure_wsegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     if (c->seg_cap_limit) capq = std::max<uint32_t>(std::min(capq, c->seg_cap_limit), 4u);  // (tests: force the overflow fallback)
     const size_t region = (size_t)nwg * capq + 6;  // (skew against power-of-two strides)
     const size_t bytes = region * nparts * 2 * sizeof(uint4);
-    if (!c->wseg && !c->wseg_counts && !c->wlog_free.empty()) {  // log mode: the buffers of a chunk that has been folded or dropped
-        const fa_ctx::WChunk k = c->wlog_free.back();
-        c->wlog_free.pop_back();
-        c->wseg = k.seg;
-        c->wseg_bytes = k.seg_bytes;
-        c->wseg_counts = k.counts;
-        c->wseg_counts_cap = k.counts_cap;
-    }
-    if (c->wseg_bytes < bytes) {
-        if (c->wseg) HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->wseg);
-        c->wseg = nullptr;
-        c->wseg_bytes = 0;
-        if (hipMalloc(&c->wseg, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide tuple segments) failed");
-        c->wseg_bytes = bytes;
-    }
     const size_t ncnt = (size_t)nwg * nparts;
-    if (c->wseg_counts_cap < ncnt) {
-        if (c->wseg_counts) HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->wseg_counts);
-        c->wseg_counts = nullptr;
-        c->wseg_counts_cap = 0;
-        if (hipMalloc(&c->wseg_counts, (ncnt + 4) * sizeof(uint32_t)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide segment counts) failed");  // (+ the time base word of a log chunk)
-        c->wseg_counts_cap = ncnt;
+    // Log mode keeps up to wlog_max + 1 pairs of buffers alive (the pending chunks and the one being filled; recycled through
+    // wlog_free).  When another pair cannot be had - hipMalloc fails (FA_WSEG_BUDGET: the tests' stand-in for that) - the
+    // ingest does not fail: buffers on the free list that are too small are released, then the OLDEST pending chunk is folded
+    // into the table after all and its buffers are taken over; only a ctx that holds no chunk at all reports FA_ERR_NOMEM.
+    auto held = [&]() { return (uint32_t)((c->wseg || c->wseg_counts ? 1 : 0) + c->wlog.size() + c->wlog_free.size()); };
+    for (;;) {
+        if (!c->wseg && !c->wseg_counts && !c->wlog_free.empty()) {  // the buffers of a chunk that has been folded or dropped
+            const fa_ctx::WChunk k = c->wlog_free.back();
+            c->wlog_free.pop_back();
+            c->wseg = k.seg;
+            c->wseg_bytes = k.seg_bytes;
+            c->wseg_counts = k.counts;
+            c->wseg_counts_cap = k.counts_cap;
+        }
+        bool ok = true;
+        if (c->wseg_bytes < bytes || c->wseg_counts_cap < ncnt) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));  // (a recycled pair may still be read by its chunk's fold)
+            (void)hipFree(c->wseg);
+            (void)hipFree(c->wseg_counts);
+            c->wseg = nullptr;
+            c->wseg_counts = nullptr;
+            c->wseg_bytes = c->wseg_counts_cap = 0;
+            ok = !(c->wseg_budget && held() + 1u > c->wseg_budget) && hipMalloc(&c->wseg, bytes) == hipSuccess;
+            if (ok) {
+                c->wseg_bytes = bytes;
+                ok = hipMalloc(&c->wseg_counts, (ncnt + 4) * sizeof(uint32_t)) == hipSuccess;  // (+ the time base and minimum bucket words of a log chunk)
+                if (ok) c->wseg_counts_cap = ncnt;
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                (void)hipFree(c->wseg);
+                c->wseg = nullptr;
+                c->wseg_bytes = 0;
+            }
+        }
+        if (ok) break;
+        if (!c->wlog_free.empty()) continue;  // (the next pair of the free list - released if it is too small as well)
+        if (c->wlog.empty()) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide tuple segments) failed");
+        int rc = wlog_flush_oldest(c);  // its buffers land on the free list
+        if (rc) return rc;
+        c->wlog_nomem_folds++;
     }
     a.wseg = c->wseg;
     a.wseg_counts = c->wseg_counts;
@@ -1265,6 +1327,7 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         }
     }
     fa_ctx::LaunchEvents* evp = &c->ev_pool[c->ev_used++];
+    if (c->wtab) c->wpot_total += (uint64_t)n * c->wide_per_record;  // (rows this launch may open in the wide table: wide_rows_bound)
     rc = launch_tiles<MODE_INGEST>(c, a, grid, evp);
     if (rc) return rc;
     if (c->wlog_now && a.wseg) {
@@ -1964,6 +2027,22 @@ extern "C" int fa_stats(fa_ctx* c, fa_stats_t* out) {
     FA_ON_DEVICE(c);
     if (!c || !out) return FA_ERR_ARG;
     int rc = settle(c);
+    c->stats.wide_log_chunks = c->wlog.size();
+    uint64_t lb = 0, lr = 0;
+    for (const auto& k : c->wlog) {
+        lb += k.seg_bytes + (k.counts_cap + 4) * sizeof(uint32_t);
+        lr += k.n;
+    }
+    for (const auto& k : c->wlog_free) lb += k.seg_bytes + (k.counts_cap + 4) * sizeof(uint32_t);
+    c->stats.wide_log_bytes = lb;
+    c->stats.wide_log_records = lr;
+    c->stats.wide_log_recorded = c->wlog_recorded;
+    c->stats.wide_log_folded = c->wlog_folded;
+    c->stats.wide_log_replayed = c->wlog_replayed;
+    c->stats.wide_log_dropped = c->wlog_dropped;
+    c->stats.wide_log_watermark_moves = c->wlog_wm_moves;
+    c->stats.wide_log_nomem_folds = c->wlog_nomem_folds;
+    c->stats.wide_log_mode = (c->wide_mode == 3 || (c->wide_mode == 0 && c->wide_defer)) ? 1 : 0;
     *out = c->stats;
     return rc;
 }

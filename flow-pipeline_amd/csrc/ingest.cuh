@@ -22,7 +22,7 @@ struct NoHook {
 // unless the sketches use it as scratch)
 // Per-wave tallies that reach the device counters once per workgroup (block_counters_add).
 struct LaneTally {
-    uint32_t ok = 0, direct = 0, second = 0, misfit8 = 0;
+    uint32_t ok = 0, direct = 0, second = 0, misfit8 = 0, late = 0;
     uint32_t tick = 0;  // tiles this wave has taken through the sketch path (wave-uniform)
 };
 // T8: this launch writes compact 8-byte tuples (wave-tile kernel only; table.cuh)
@@ -113,6 +113,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     }
     const uint32_t t32 = (uint32_t)r.time_received;  // UInt64 -> DateTime (create.sh:39)
     const uint32_t tb = time_bucket(a, t32);
+    tally.late += (sure && tb < a.late_below) ? 1u : 0u;  // (its flows_5m window was closed before it arrived; aggregated all the same)
     // state of the sketch path between its two halves (below: in front of and behind the flows_5m sink)
     uint64_t cw = 0, ws = 0, wd = 0, slo = 0, shi = 0, dlo = 0, dhi = 0, sh1 = 0, sh2 = 0, dh1 = 0, dh2 = 0;
     bool on_s = false, on_d = false, vs = false, vd = false;
@@ -270,15 +271,17 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
 // time, and same-address atomics serialize at the memory side: one atomic per wave (8192 of them) was a
 // ~30 us tail on a 0.4 ms launch.
 __device__ __forceinline__ void block_counters_add(uint32_t* lds4, Counters* ctr, const LaneTally& t) {
-    if (threadIdx.x < 4) lds4[threadIdx.x] = 0;
+    if (threadIdx.x < 5) lds4[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t ok = (uint32_t)wave_sum_u64(t.ok), direct = (uint32_t)wave_sum_u64(t.direct);
     const uint32_t second = (uint32_t)wave_sum_u64(t.second), mis = (uint32_t)wave_sum_u64(t.misfit8);
+    const uint32_t late = __builtin_amdgcn_ballot_w64(t.late != 0u) != 0ull ? (uint32_t)wave_sum_u64(t.late) : 0u;
     if (__lane_id() == 0) {
         if (ok) atomicAdd(&lds4[0], ok);
         if (direct) atomicAdd(&lds4[1], direct);
         if (second) atomicAdd(&lds4[2], second);
         if (mis) atomicAdd(&lds4[3], mis);
+        if (late) atomicAdd(&lds4[4], late);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -286,6 +289,7 @@ __device__ __forceinline__ void block_counters_add(uint32_t* lds4, Counters* ctr
         if (lds4[1]) atomicAdd(&ctr->direct, (unsigned long long)lds4[1]);
         if (lds4[2]) atomicAdd(&ctr->retried, (unsigned long long)lds4[2]);
         if (lds4[3]) atomicAdd(&ctr->misfit8, (unsigned long long)lds4[3]);
+        if (lds4[4]) atomicAdd(&ctr->late, (unsigned long long)lds4[4]);
     }
 }
 
@@ -897,6 +901,7 @@ __device__ __forceinline__ void exotic_pass(const KArgs& a) {
         }
         atomicAdd(&a.ctr->ok, 1ull);
         const uint32_t tb = (uint32_t)r.time_received / a.gran;
+        if (tb < a.late_below) atomicAdd(&a.ctr->late, 1ull);
         if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
             uint64_t k0, k1;
             pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
@@ -963,6 +968,7 @@ __global__ __launch_bounds__(BLOCK) void deferred_kernel(KArgs a) {
         }
         n_ok += sure ? 1 : 0;
         const uint32_t tb = time_bucket(a, (uint32_t)r.time_received);
+        if (sure && tb < a.late_below) atomicAdd(&a.ctr->late, 1ull);  // (rare path, rare event)
         if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
             uint64_t k0, k1;
             pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);

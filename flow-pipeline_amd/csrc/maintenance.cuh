@@ -223,6 +223,14 @@ __global__ __launch_bounds__(256) void wlog_rows_kernel(WChunkArgs k, uint32_t t
         if (sel && j < rows_cap) rows[j] = WRow{{key.w[0], key.w[1], key.w[2], key.w[3]}, bytes, packets, 1ull};
     });
 }
+// the smallest bucket among the chunk's live tuples (*out starts at ~0): what a window close compares its range with
+__global__ __launch_bounds__(256) void wlog_minbucket_kernel(WChunkArgs k, uint32_t* out) {
+    uint32_t m = 0xffffffffu;
+    wchunk_walk(k, [&](bool live, uint32_t tb, const WKey&, uint64_t, uint64_t) { m = live ? min(m, tb) : m; });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
+    if (__lane_id() == 0 && m != 0xffffffffu) atomicMin(out, m);
+}
 // the chunk folded into the table through the atomic path (the table's geometry changed since the tuples were scattered:
 // their regions are not the table's any more, wagg_kernel's ownership does not hold)
 __global__ __launch_bounds__(256) void wlog_replay_kernel(WChunkArgs k, KArgs a) {

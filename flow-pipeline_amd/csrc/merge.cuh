@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "maintenance.cuh"
+#include "rowplan.cuh"
 
 namespace fa {
 
@@ -152,16 +153,70 @@ struct RowOps<RK_TOPK_SRC> : RowOpsTopk {};
 template <>
 struct RowOps<RK_TOPK_DST> : RowOpsTopk {};
 
-// key word w of every row, in the order idx gives (idx == nullptr: identity, which also initialises idx_out)
+// ---- sort keys: only the bits that differ ----------------------------------------------------------------------------
+// A row kind's order is up to four 64-bit words (224 bits for (SrcAddr,DstPort,Proto) rows) - but inside ONE row set most of
+// those bits are the same in every row: one or a few timeslots, IPv4 addresses in a FixedString(16), ports below 2^16,
+// two or three protocol numbers.  A first pass takes the OR and the AND of every key word over the rows; a bit that is
+// equal in both is the same everywhere and cannot decide a comparison.  The bits that do vary are packed - in their order of
+// significance - into as few 64-bit words as they need (usually one), and the LSD radix sort runs over those, with
+// end_bit = the bits in use: config 5's 16.6 M-row window sorts 45 bits in ONE pass of SortPairs instead of 224 bits in four
+// passes with gathers through the permutation in between.  Exact for every input: rows compare on the packed bits as they
+// do on the full key (the first bit in which two keys differ is a varying bit, and packing keeps the order of bits).
 template <int KIND, bool EMIT>
-__global__ void row_word_kernel(const typename RowOps<KIND>::Row* rows, const uint32_t* idx, uint32_t n, int w, uint32_t fold,
+__device__ __forceinline__ unsigned long long row_key_word(const typename RowOps<KIND>::Row& r, int w, uint32_t fold) {
+    if constexpr (EMIT) return RowOps<KIND>::key2(r, w);
+    else return RowOps<KIND>::key(r, w, fold);
+}
+// bits[w] |= every row's key word w;  bits[NW + w] &= it   (bits: NW zeros, then NW times ~0)
+template <int KIND, bool EMIT>
+__global__ void row_bits_kernel(const typename RowOps<KIND>::Row* rows, uint32_t n, uint32_t fold, unsigned long long* bits) {
+    constexpr int NW = EMIT ? RowOps<KIND>::NK2 : RowOps<KIND>::NK;
+    unsigned long long o[NW > 0 ? NW : 1], a[NW > 0 ? NW : 1];
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        o[w] = 0ull;
+        a[w] = ~0ull;
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const typename RowOps<KIND>::Row r = rows[i];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const unsigned long long k = row_key_word<KIND, EMIT>(r, w, fold);
+            o[w] |= k;
+            a[w] &= k;
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            o[w] |= (unsigned long long)__shfl_xor((long long)o[w], d);
+            a[w] &= (unsigned long long)__shfl_xor((long long)a[w], d);
+        }
+        if (__lane_id() == 0) {
+            atomicOr(&bits[w], o[w]);
+            atomicAnd(&bits[NW + w], a[w]);
+        }
+    }
+}
+// packed word p of every row, in the order idx gives (idx == nullptr: identity, which also initialises idx_out)
+template <int KIND, bool EMIT>
+__global__ void row_pack_kernel(const typename RowOps<KIND>::Row* rows, const uint32_t* idx, uint32_t n, uint32_t fold, RowPlan plan, uint32_t p,
                                 unsigned long long* out, uint32_t* idx_out) {
+    constexpr int NW = EMIT ? RowOps<KIND>::NK2 : RowOps<KIND>::NK;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t j = idx ? idx[i] : i;
-        if constexpr (EMIT) out[i] = RowOps<KIND>::key2(rows[j], w);
-        else out[i] = RowOps<KIND>::key(rows[j], w, fold);
+        const typename RowOps<KIND>::Row r = rows[j];
+        unsigned long long kw[NW > 0 ? NW : 1];
+#pragma unroll
+        for (int w = 0; w < NW; w++) kw[w] = row_key_word<KIND, EMIT>(r, w, fold);
+        const unsigned long long v = rowplan_pack(plan, kw, NW, p);
+        out[i] = v;
         if (!idx) idx_out[i] = i;
     }
+}
+__global__ void iota_kernel(uint32_t* idx, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) idx[i] = i;
 }
 // head flags of the sorted sequence
 template <int KIND>
@@ -202,6 +257,57 @@ __global__ void row_tail_kernel(const typename RowOps<KIND>::Row* rows, const ui
 template <class Row>
 __global__ void row_gather_kernel(const Row* src, const uint32_t* idx, uint32_t n, Row* dst) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+
+// ---- hash partition of a row set (multi-GPU window close of large sparse sets) -----------------------------------------
+// Rank r of `world` merges the keys with row_dest == r: every rank cuts ITS rows into `world` groups with the same function
+// of the key alone, the groups travel with one all-to-all, and each rank sorts and sums 1 / world of the keys - instead of
+// every rank receiving and sorting every rank's rows (SURVEY.md 8(e) option (ii); flow-pipeline_amd/dist.py).
+// dest = high half of a mix64 chain over the kind's merge-order key words (no fold: fa_rows_device has applied it), scaled
+// to [0, world) by multiply-shift.  Restated in numpy by dist.partition_rows_host (the CPU tests compare the two).
+constexpr uint32_t RPART_MAX_WORLD = 1024, RPART_BLOCK = 256, RPART_U = 16;
+template <int KIND>
+__device__ __forceinline__ uint32_t row_dest(const typename RowOps<KIND>::Row& r, uint32_t world) {
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int w = 0; w < RowOps<KIND>::NK; w++) h = mix64(h ^ RowOps<KIND>::key(r, w, 0xffffffffu));
+    return (uint32_t)(((h >> 32) * (unsigned long long)world) >> 32);
+}
+// SCATTER = false: counts[d] += rows of group d.  SCATTER = true: rows to out[starts[d] + ...] (cursor[d]: rows of group d
+// placed so far; the order inside a group is arbitrary - the merge behind the exchange sorts).
+template <int KIND, bool SCATTER>
+__global__ __launch_bounds__(RPART_BLOCK) void row_partition_kernel(const typename RowOps<KIND>::Row* rows, uint32_t n, uint32_t world, unsigned int* counts,
+                                                                    const unsigned int* starts, unsigned int* cursor, typename RowOps<KIND>::Row* out) {
+    __shared__ unsigned int hist[RPART_MAX_WORLD], base[RPART_MAX_WORLD];
+    constexpr uint32_t PER = RPART_BLOCK * RPART_U;
+    for (uint32_t b0 = blockIdx.x * PER; b0 < n; b0 += gridDim.x * PER) {  // (n < 2^31: no wrap)
+        for (uint32_t d = threadIdx.x; d < world; d += RPART_BLOCK) hist[d] = 0;
+        __syncthreads();
+        uint32_t dest[RPART_U], lrank[RPART_U];
+#pragma unroll
+        for (uint32_t q = 0; q < RPART_U; q++) {
+            const uint32_t i = b0 + q * RPART_BLOCK + threadIdx.x;
+            dest[q] = lrank[q] = 0;
+            if (i < n) {
+                dest[q] = row_dest<KIND>(rows[i], world);
+                lrank[q] = atomicAdd(&hist[dest[q]], 1u);
+            }
+        }
+        __syncthreads();
+        if (!SCATTER) {
+            for (uint32_t d = threadIdx.x; d < world; d += RPART_BLOCK)
+                if (hist[d]) atomicAdd(&counts[d], hist[d]);
+        } else {
+            for (uint32_t d = threadIdx.x; d < world; d += RPART_BLOCK) base[d] = hist[d] ? atomicAdd(&cursor[d], hist[d]) : 0u;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t q = 0; q < RPART_U; q++) {
+                const uint32_t i = b0 + q * RPART_BLOCK + threadIdx.x;
+                if (i < n) out[(size_t)starts[dest[q]] + base[dest[q]] + lrank[q]] = rows[i];
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // ---- public-format rows out of the device state ------------------------------------------------------------------

@@ -109,6 +109,7 @@ struct Counters {
     unsigned long long wused, wspill_lost;  // wide table (wide.cuh)
     unsigned int wspill_count, wrows_count;
     unsigned long long agg_groups, agg_launches;  // agg8_kernel: groups it added to the device table, launches (pass-count feedback)
+    unsigned long long late;  // records below KArgs::late_below (flows_5m windows that were closed before they arrived)
 };
 
 // Distinct-address set behind fa_topk (the dashboards rank EVERY address,
@@ -189,6 +190,7 @@ struct KArgs {
     uint32_t wplog2;         // log2(regions of the wide table) = wide_plog2(log2 slots)
     unsigned long long wregion;
     ulonglong2* port_hist;  // [2][PORT_DENSE] {sum(Bytes*SamplingRate), count()}: SrcPort, then DstPort
+    uint32_t late_below;    // time buckets below it were closed (flows_5m): records that still arrive for them are counted
 };
 
 __device__ __forceinline__ WArgs wargs(const KArgs& a) {

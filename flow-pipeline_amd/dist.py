@@ -10,11 +10,14 @@ exchange is at window close:
 * dense Count-Min sketches -> ``all_reduce(SUM)`` of the library's device buffers into
   the ctx's merged view (out of place, idempotent; RCCL over xGMI when the backend is
   ``nccl``; u64 wrap-around sum == int64 sum bit for bit);
-* sparse flows_5m rows -> ``all_gather`` of each rank's compacted rows, then a
-  local re-aggregation (sum is a commutative monoid, so the merged table equals
-  the single-shard table exactly).  Row sets are tens of MB at most (393 k rows x
-  48 B for BASELINE config 2), far below the point where a hash-partitioned
-  all-to-all would pay off on 153 GB/s xGMI links.
+* sparse rows, small sets (flows_5m: 393 k rows x 48 B for BASELINE config 2; ports, minutes, top-k candidates) ->
+  ``all_gather`` of each rank's compacted rows, then a local re-aggregation (sum is a commutative monoid, so the
+  merged table equals the single-shard table exactly) - every rank ends up with the whole result;
+* sparse rows, LARGE sets ((SrcAddr,DstPort,Proto): a window of BASELINE config 5 is 16.6 M rows x 56 B = 930 MB per
+  rank) -> hash-partitioned exchange (``rows_merged_partitioned``): every rank cuts its rows by ``hash(key) * world >> 64``
+  on the device, ONE ``all_to_all_single`` moves each group to its owner (xGMI is point to point: every link carries
+  1 / world of a rank's rows instead of every rank receiving everything), and each rank sorts and sums 1 / world of the
+  keys - and emits that share (SURVEY.md 8(e) option (ii)).
 
 Works with ``gloo`` on CPU tensors (host logic tests) and ``nccl`` on the GPUs.
 """
@@ -118,12 +121,88 @@ def allgather_struct(rows: np.ndarray, dtype, group=None, device=None):
     return [b.view(dtype).copy() for b in allgather_bytes(rows.view(np.uint8).reshape(-1), group=group, device=device)]
 
 
+def alltoall_struct(rows: np.ndarray, dest: np.ndarray, dtype, group=None):
+    """Host rows to their owners: rank r receives every rank's rows with dest == r (one array, senders in rank order).
+    The host twin of fa_rows_partition_device + alltoall_device_rows (CPU tests; oracle rows in the tools)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rows = np.ascontiguousarray(rows, dtype=dtype)
+    order = np.argsort(dest, kind="stable")
+    counts = np.bincount(dest, minlength=world).astype(np.int64)
+    sc = torch.from_numpy(counts.copy())
+    rc = torch.zeros(world, dtype=torch.int64)
+    dist.all_to_all_single(rc, sc, group=group)
+    payload = torch.from_numpy(np.ascontiguousarray(rows[order]).view(np.uint8).reshape(-1).copy())
+    out = torch.empty(int(rc.sum()) * dtype.itemsize, dtype=torch.uint8)
+    dist.all_to_all_single(out, payload, output_split_sizes=[int(v) * dtype.itemsize for v in rc.tolist()],
+                           input_split_sizes=[int(v) * dtype.itemsize for v in counts.tolist()], group=group)
+    return out.numpy().view(dtype).copy()
+
+
 class _DevArray:
     """Minimal __cuda_array_interface__ view of library-owned HBM."""
 
     def __init__(self, ptr: int, n: int, typestr: str = "<i8"):
         self.__cuda_array_interface__ = {
             "shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
+
+
+def _mix64(z: np.ndarray) -> np.ndarray:
+    z = z.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xbf58476d1ce4e5b9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94d049bb133111eb)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+def _key_words(rows: np.ndarray, kind: int):
+    """The merge-order key words of a row kind, least significant first (merge.cuh, RowOps<KIND>::key)."""
+    from . import ROWS_5M, ROWS_APP, ROWS_MINUTE, ROWS_PORT_DST, ROWS_PORT_SRC
+    u64 = np.uint64
+    if kind == ROWS_5M:
+        return [(rows["dst_as"].astype(u64) << u64(32)) | rows["etype"].astype(u64),
+                (rows["timeslot"].astype(u64) << u64(32)) | rows["src_as"].astype(u64)]
+    if kind == ROWS_APP:
+        addr = np.ascontiguousarray(rows["src_addr"])
+        return [(rows["dst_port"].astype(u64) << u64(32)) | rows["proto"].astype(u64),
+                addr[:, 8:].copy().view(">u8").reshape(-1).astype(u64), addr[:, :8].copy().view(">u8").reshape(-1).astype(u64),
+                rows["timeslot"].astype(u64)]
+    if kind in (ROWS_PORT_SRC, ROWS_PORT_DST):
+        return [rows["port"].astype(u64)]
+    if kind == ROWS_MINUTE:
+        return [rows["minute"].astype(u64)]
+    key = np.ascontiguousarray(rows["key"])  # top-k rows
+    return [key[:, 8:].copy().view(">u8").reshape(-1).astype(u64), key[:, :8].copy().view(">u8").reshape(-1).astype(u64)]
+
+
+def partition_rows_host(rows: np.ndarray, kind: int, world: int) -> np.ndarray:
+    """Owner rank of every row: numpy restatement of merge.cuh row_dest (fa_rows_partition_device)."""
+    h = np.full(len(rows), 0x9E3779B97F4A7C15, dtype=np.uint64)
+    for w in _key_words(rows, kind):
+        h = _mix64(h ^ w)
+    return (((h >> np.uint64(32)) * np.uint64(world)) >> np.uint64(32)).astype(np.int64)
+
+
+class RankFailed(RuntimeError):
+    """Another rank could not produce its part of a window close: every rank raises instead of waiting in a collective."""
+
+
+def _all_ok(ok: bool, what: str, group=None, own_error=None):
+    """One small all-reduce: either every rank goes on or every rank raises (a rank that failed BEFORE a collective would
+    leave the others waiting in it forever; one that failed behind it would let them drop a window it still holds)."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    if own_error is not None:
+        raise own_error
+    if int(t.item()) == 0:
+        raise RankFailed("window close: a rank failed in %s" % what)
 
 
 def allgather_device_rows(ptr: int, n: int, row_bytes: int, group=None):
@@ -142,6 +221,8 @@ def allgather_device_rows(ptr: int, n: int, row_bytes: int, group=None):
     counts = [torch.zeros(1, dtype=torch.int64, device=xdev) for _ in range(world)]
     dist.all_gather(counts, cnt, group=group)
     counts = [int(c.item()) for c in counts]
+    if min(counts) < 0:  # (n = -1: that rank's fa_rows_device failed - rows_merged)
+        raise RankFailed("window close: rank(s) %s could not produce their rows" % [r for r, v in enumerate(counts) if v < 0])
     total = sum(counts)
     out = torch.empty(max(total, 1) * row_bytes, dtype=torch.uint8, device=dev)
     mine = (torch.as_tensor(_DevArray(ptr, n * row_bytes, "|u1"), device=dev) if n
@@ -182,11 +263,99 @@ def rows_merged(agg, kind, timeslot=0xFFFFFFFF, k_local=0, k=0, group=None) -> n
     """One kind of rows merged across ranks at window close, identical on every rank: fa_rows_device (this rank's
     result in HBM: extracted, sub-buckets folded, sorted) -> all-gather of the device buffers -> fa_rows_merge_device
     (radix sort + segmented sums in HBM, emit order) -> one copy of the result to the host."""
-    from . import ROW_DTYPES
-    ptr, n = agg.rows_device(kind, timeslot, k_local)
-    buf, total = allgather_device_rows(ptr, n, ROW_DTYPES[kind].itemsize, group=group)
-    mptr, m = agg.rows_merge_device(kind, buf.data_ptr(), total, k)
-    return agg.rows_fetch(kind, mptr, m)
+    from . import ROW_DTYPES, FlowAggError
+    err = None
+    try:
+        ptr, n = agg.rows_device(kind, timeslot, k_local)
+    except FlowAggError as e:  # (the others must not wait for this rank in the collective: it takes part with count -1)
+        err, ptr, n = e, 0, -1
+    try:
+        buf, total = allgather_device_rows(ptr, n, ROW_DTYPES[kind].itemsize, group=group)
+    except RankFailed:
+        if err is not None:
+            raise err
+        raise
+    rows = None
+    try:
+        mptr, m = agg.rows_merge_device(kind, buf.data_ptr(), total, k)
+        rows = agg.rows_fetch(kind, mptr, m)
+    except FlowAggError as e:
+        err = e
+    _all_ok(err is None, "the merge of the gathered rows", group=group, own_error=err)
+    return rows
+
+
+def alltoall_device_rows(ptr: int, counts, row_bytes: int, group=None):
+    """The partitioned rows of this rank (HBM at ptr, group r = counts[r] rows, back to back) -> the groups every rank
+    holds for THIS rank, back to back in one device buffer.  -> (uint8 cuda tensor, rows received).  `nccl`: one
+    all_to_all_single over RCCL, HBM to HBM; other backends (gloo on a shared test GPU) stage through host memory."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    on_device = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xdev = dev if on_device else torch.device("cpu")
+    sc = torch.tensor([int(v) for v in counts], dtype=torch.int64, device=xdev)
+    rc = torch.zeros(world, dtype=torch.int64, device=xdev)
+    dist.all_to_all_single(rc, sc, group=group)
+    rcounts = [int(v) for v in rc.tolist()]
+    if min(rcounts) < 0 or min(int(v) for v in counts) < 0:  # (counts of -1: this rank's own failure - it must not go on either)
+        raise RankFailed("window close: rank(s) %s could not produce their rows" % ([r for r, v in enumerate(rcounts) if v < 0] or "this one"))
+    n = sum(int(v) for v in counts if v > 0)
+    total = sum(rcounts)
+    mine = (torch.as_tensor(_DevArray(ptr, n * row_bytes, "|u1"), device=dev) if n else torch.empty(0, dtype=torch.uint8, device=dev))
+    insp = [max(int(v), 0) * row_bytes for v in counts]
+    outsp = [v * row_bytes for v in rcounts]
+    if on_device:
+        out = torch.empty(max(total, 1) * row_bytes, dtype=torch.uint8, device=dev)
+        dist.all_to_all_single(out[:total * row_bytes], mine, output_split_sizes=outsp, input_split_sizes=insp, group=group)
+    else:
+        h_out = torch.empty(total * row_bytes, dtype=torch.uint8)
+        dist.all_to_all_single(h_out, mine.cpu(), output_split_sizes=outsp, input_split_sizes=insp, group=group)
+        out = torch.empty(max(total, 1) * row_bytes, dtype=torch.uint8, device=dev)
+        out[:total * row_bytes].copy_(h_out)
+    torch.cuda.synchronize()
+    return out[:total * row_bytes], total
+
+
+def rows_merged_partitioned(agg, kind, timeslot=0xFFFFFFFF, group=None) -> np.ndarray:
+    """THIS rank's share of one kind of rows merged across ranks: the keys with partition_rows_host(...) == rank, complete
+    (every rank's rows of those keys, summed) and in the kind's merge order.  fa_rows_device -> fa_rows_partition_device
+    (groups by owner, in HBM) -> one all-to-all -> fa_rows_merge_device on 1 / world of the keys -> copy out.  The union
+    of the ranks' shares is what rows_merged returns on every rank - without any rank receiving or sorting all of it."""
+    import torch.distributed as dist
+    from . import ROW_DTYPES, FlowAggError
+    world = dist.get_world_size(group)
+    err = None
+    try:
+        ptr, n = agg.rows_device(kind, timeslot)
+        pptr, counts = agg.rows_partition_device(kind, ptr, n, world)
+    except FlowAggError as e:
+        err, pptr, counts = e, 0, [-1] * world
+    try:
+        buf, total = alltoall_device_rows(pptr, counts, ROW_DTYPES[kind].itemsize, group=group)
+    except RankFailed:
+        if err is not None:
+            raise err
+        raise
+    rows = None
+    try:
+        mptr, m = agg.rows_merge_device(kind, buf.data_ptr(), total, 0)
+        rows = agg.rows_fetch(kind, mptr, m)
+    except FlowAggError as e:
+        err = e
+    _all_ok(err is None, "the merge of its share", group=group, own_error=err)
+    return rows
+
+
+def close_window_app_partitioned(agg, timeslot, group=None) -> np.ndarray:
+    """Window close of the (SrcAddr,DstPort,Proto) key set across ranks, hash-partitioned: every rank returns ITS share of
+    the merged rows (sorted; a key appears on exactly one rank) and drops the window.  What a sharded sink wants - each
+    rank inserts its rows - and what keeps a 16.6 M-row window from being received and sorted `world` times."""
+    from . import ROWS_APP
+    rows = rows_merged_partitioned(agg, ROWS_APP, timeslot, group=group)
+    agg.drop_window(ROWS_APP, timeslot)
+    return rows
 
 
 def close_window_merged(agg, timeslot, group=None, device=None) -> np.ndarray:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 5
+#define FA_ABI_VERSION 6
 
 typedef struct fa_ctx fa_ctx;
 
@@ -156,6 +156,28 @@ typedef struct {
     uint64_t records_misfit_compact; /* records of compact-tuple launches whose values only a wide tuple holds */
     uint64_t decode_ns_total;        /* fa_decode_device: device time, summed over its launches (hipEvent) */
     uint64_t decode_launches;
+    /* ABI 6 */
+    uint64_t records_late;           /* records whose time bucket lies below a flows_5m window that fa_close_window /
+                                        fa_drop_window(FA_ROWS_5M, timeslot) had already closed when they arrived.  They are
+                                        aggregated like any other record (a later read of that timeslot shows them - what a
+                                        late INSERT into flows_5m does, create.sh:70-90); the count tells the consumer that a
+                                        closed window has been re-opened. */
+    /* the wide log (FA_KEYS_ADDR_PORT_PROTO on a stream that opens a row for most of its records: a launch's 32-byte
+     * tuples stay in their scatter segments - a "chunk" - and are folded into the hash table only when more than
+     * FA_WIDE_LOG_CHUNKS (default 8) are pending; window reads sort them together with the table's rows).  Memory bound:
+     * at most FA_WIDE_LOG_CHUNKS + 1 pairs of segment buffers of 2 x 32 B x (records of the largest launch) + 6 %, i.e.
+     * 9 x 1.14 GiB at max_batch_records = 2^24 - held until fa_destroy.  A pair that cannot be allocated is not an
+     * error: the oldest pending chunk is folded early and its buffers are taken over (wide_log_nomem_folds). */
+    uint64_t wide_log_chunks;        /* chunks pending right now */
+    uint64_t wide_log_bytes;         /* device bytes of every segment buffer the log holds (pending + recycled) */
+    uint64_t wide_log_records;       /* records of the pending chunks (upper bound of their live tuples) */
+    uint64_t wide_log_recorded;      /* chunks recorded so far */
+    uint64_t wide_log_folded;        /* ... folded into the table by the region-owned kernel */
+    uint64_t wide_log_replayed;      /* ... folded through the atomic replay (the table had grown since they were scattered) */
+    uint64_t wide_log_dropped;       /* ... dropped whole by a window close (nothing alive above the watermark) */
+    uint64_t wide_log_watermark_moves; /* times a close moved a pending chunk's watermark instead of folding it */
+    uint64_t wide_log_nomem_folds;   /* chunks folded early because another pair of segment buffers could not be allocated */
+    uint64_t wide_log_mode;          /* 1: the next launch keeps its (SrcAddr,DstPort,Proto) tuples in the log */
 } fa_stats_t;
 
 typedef struct {
@@ -235,6 +257,15 @@ int fa_rows_device(fa_ctx*, int kind, uint32_t timeslot, size_t k, const void** 
  * touched.  FA_ROWS_5M rows must lie on this ctx's bucket grid (FA_ERR_ARG otherwise).  The ctx reads d_rows on its own
  * stream: whatever wrote them (a collective, a copy on another stream) must have completed when the call is made. */
 int fa_rows_merge_device(fa_ctx*, int kind, const void* d_rows, size_t n, size_t k, const void** d_out, size_t* n_out);
+/* ABI 6 - hash-partitioned window close, for row sets too large to gather on every rank ((SrcAddr,DstPort,Proto): a
+ * window of BASELINE config 5 is 16.6 M rows x 56 B PER RANK).  The n rows of `kind` at d_rows (DEVICE; a fa_rows_device
+ * result) are regrouped by owner: rank r of `world` owns the keys with hash(key) * world >> 64 == r (the same function of
+ * the key on every rank, independent of the row's sums).  *d_out: DEVICE pointer to the n rows, group 0 first (order
+ * inside a group unspecified), owned by the ctx, valid until its next fa_rows_partition_device; counts[r] (HOST array of
+ * `world` entries) = rows of group r.  The ranks then exchange the groups with ONE all-to-all (RCCL: all_to_all_single
+ * with these counts), every rank calls fa_rows_merge_device on what it received - 1 / world of the keys, complete - and
+ * emits or gathers only that share; fa_drop_window as usual.  world <= 1024. */
+int fa_rows_partition_device(fa_ctx*, int kind, const void* d_rows, size_t n, uint32_t world, const void** d_out, size_t* counts);
 /* Copies n rows of `kind` from HBM into the caller's host buffer (cap in rows). */
 int fa_rows_fetch(fa_ctx*, int kind, const void* d_rows, size_t n, void* out, size_t cap);
 /* Removes what fa_close_window / fa_close_window_app would remove after emitting `timeslot` (kind FA_ROWS_5M or

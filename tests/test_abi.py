@@ -24,12 +24,12 @@ def test_library_exports_every_declared_symbol(fa):
     for n in names:
         assert hasattr(L, n), "libflowagg.so does not export %s" % n
     assert sorted(fa.EXPORTS) == names, "python binding and header disagree"
-    assert fa.lib().fa_abi_version() == 5
+    assert fa.lib().fa_abi_version() == 6
 
 
 def test_struct_layouts_match_header(fa):
     assert C.sizeof(fa.Config) == 64
-    assert C.sizeof(fa.Stats) == 160
+    assert C.sizeof(fa.Stats) == 248
     assert C.sizeof(fa.MockParams) == 48
     assert fa.ROW5M_DTYPE.itemsize == 48 and fa.FLOW_ROW_DTYPE.itemsize == 120
 

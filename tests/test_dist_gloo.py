@@ -60,6 +60,25 @@ def _worker(rank, world, port, q):
     d = fa.dist
     app = d.merge_rows_app_host(d.allgather_struct(po.rollup_app(rows[sel], status[sel], 300), d.ROW_APP_DTYPE, device="cpu"))
     ok = ok and app.tobytes() == po.rollup_app(rows, status, 300).astype(d.ROW_APP_DTYPE).tobytes()
+    # ... and the hash-partitioned exchange of the same rows (large sets): every rank ends up with the keys it owns, complete;
+    # the union of the shares is the all-gathered result
+    from types import SimpleNamespace
+    kinds = SimpleNamespace(APP=1, R5M=0)
+    my_app = po.rollup_app(rows[sel], status[sel], 300).astype(d.ROW_APP_DTYPE)
+    share = d.merge_rows_app_host([d.alltoall_struct(my_app, d.partition_rows_host(my_app, kinds.APP, world), d.ROW_APP_DTYPE)])
+    ok = ok and bool((d.partition_rows_host(share, kinds.APP, world) == rank).all()) and 0 < len(share) < len(app)
+    ok = ok and d.merge_rows_app_host(d.allgather_struct(share, d.ROW_APP_DTYPE, device="cpu")).tobytes() == app.tobytes()
+    my5 = shard.rows().astype(d.ROW5M_DTYPE)
+    share5 = d.merge_rows_host([d.alltoall_struct(my5, d.partition_rows_host(my5, kinds.R5M, world), d.ROW5M_DTYPE)])
+    ok = ok and d.merge_rows_host(d.allgather_struct(share5, d.ROW5M_DTYPE, device="cpu")).tobytes() == merged.tobytes()
+    # a rank that fails before / behind a collective of the close: every rank raises, nobody waits (dist._all_ok)
+    try:
+        d._all_ok(rank != 1, "a test", own_error=ValueError("rank 1's own error") if rank == 1 else None)
+        ok = False
+    except ValueError:
+        ok = ok and rank == 1
+    except d.RankFailed:
+        ok = ok and rank != 1
     for dst in (0, 1):
         ports = d.merge_ports_host(d.allgather_struct(po.top_ports(rows[sel], status[sel], dst), d.PORT_ROW_DTYPE, device="cpu"))
         ok = ok and ports.tobytes() == po.top_ports(rows, status, dst).tobytes()

@@ -54,6 +54,20 @@ def test_tuple_formats_round_trip_and_balance():
     assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
 
 
+def test_packed_sort_keys_keep_the_order():
+    """rowplan.cuh (window close: the radix sort runs over the bits that differ inside the row set only): ordering by the
+    packed words == ordering by the full key, for random masks, widths and duplicates (tests/host_rowplan.hip)."""
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "host_rowplan")
+    src = os.path.join(ROOT, "tests", "host_rowplan.hip")
+    deps = [src, os.path.join(ROOT, "flow-pipeline_amd", "csrc", "rowplan.cuh")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-o", exe, src])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
+
+
 def test_sketch_definition_kernel_headers_equal_oracle(po):
     """sinks.cuh's sketch definition (cms_hash2 / cms_key / cms_column / cms_low, host-compiled) == oracle/flow_oracle.c
     fo_cms_column for every width, and the partition invariants of the scatter sink (tests/host_sketch.hip)."""

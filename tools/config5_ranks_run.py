@@ -2,8 +2,10 @@
 """BASELINE config 5 (configs[4]) on ONE GPU: "8xMI355X: concurrent multi-key rollup (SrcAS,DstAS)+(SrcAddr,DstPort,Proto)
 with 1-min sliding windows, Zipf-0.8".  Only one MI355X is reachable from the build environment, so the 8 ranks share it:
 eight processes (torch.distributed.run), one context each, exchange over gloo - the per-rank kernels, the device-side
-window-close merge (fa_rows_device -> gathered device buffers -> fa_rows_merge_device, flow-pipeline_amd/dist.py) and
-the checks are the ones an 8-GPU node runs; what this run canNOT show is xGMI bandwidth or scaling.
+window-close merges - flows_5m rows all-gathered (fa_rows_device -> gathered device buffers -> fa_rows_merge_device), the
+(SrcAddr,DstPort,Proto) rows HASH-PARTITIONED (fa_rows_partition_device -> one all-to-all -> every rank merges and keeps 1 / ranks
+of the keys; flow-pipeline_amd/dist.py) - and the checks are the ones an 8-GPU node runs; what this run canNOT show is xGMI
+bandwidth or scaling.
 Partition p = the chunks c of the stream with c % ranks == p (every partition spans the whole time range).
 Checks (CPU side = oracle/, rank 0):
   * flows_5m, every 5-minute-aligned window closed across ranks: rows == the C oracle's rollup of the whole stream
@@ -12,7 +14,7 @@ Checks (CPU side = oracle/, rank 0):
     flows_5m rows byte-identical to the oracle rollup of exactly the records inside [start, start + 300), folded;
     (SrcAddr,DstPort,Proto) rows byte-identical to the numpy restatement over the same records;
   * (SrcAddr,DstPort,Proto) over all aligned windows: count() == records, sum(Bytes) == flows_5m's;
-  * every rank holds byte-identical merged results.
+  * every rank holds byte-identical merged flows_5m results, and of the partitioned (SrcAddr,DstPort,Proto) rows exactly the keys it owns.
 Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P tools/config5_ranks_run.py
 Prints one JSON line on rank 0 (commit it under profiles/)."""
 import argparse
@@ -86,7 +88,7 @@ def main():
         start = t0 + 420
         tw = time.perf_counter()
         slide5m = fa.dist.rows_merged(agg, fa.ROWS_5M, start)
-        slide_app = fa.dist.rows_merged(agg, fa.ROWS_APP, start)
+        slide_app = fa.dist.rows_merged_partitioned(agg, fa.ROWS_APP, start)  # (this rank's share)
         t_slide = time.perf_counter() - tw
         # ---- then every aligned window, closed across ranks (sliding semantics: a close drops the oldest sub-bucket only)
         tw = time.perf_counter()
@@ -94,22 +96,30 @@ def main():
         t_aligned = time.perf_counter() - tw
         tw = time.perf_counter()
         cnt = by = nrows = 0
+        owned_ok = True
         for ts in aligned:
-            app = fa.dist.rows_merged(agg, fa.ROWS_APP, ts)
+            app = fa.dist.rows_merged_partitioned(agg, fa.ROWS_APP, ts)  # this rank's 1 / ranks of the window's keys
             cnt += int(app["count"].sum())
             by += int(app["bytes"].sum(dtype=np.uint64))
             nrows += len(app)
+            owned_ok = owned_ok and bool((fa.dist.partition_rows_host(app[::97], fa.ROWS_APP, world) == rank).all())
         t_app = time.perf_counter() - tw
         tw = time.perf_counter()
         closed = fa.dist.close_window_merged(agg, aligned[0])       # a real close: removes the oldest sub-bucket on every rank
-        closed_app = fa.dist.close_window_app_merged(agg, aligned[0])
+        closed_app = fa.dist.close_window_app_partitioned(agg, aligned[0])
         after = fa.dist.rows_merged(agg, fa.ROWS_5M, aligned[0] + 60)   # the next sliding window still reads complete
         t_close = time.perf_counter() - tw
     allrows = np.concatenate(wins)
     h = hashlib.sha256()
-    for a in (slide5m, slide_app, allrows, closed, closed_app, after):
+    for a in (slide5m, allrows, closed, after):  # (what every rank holds whole: the all-gathered kinds)
         h.update(np.ascontiguousarray(a).tobytes())
-    h.update(np.array([cnt, by, nrows], dtype=np.uint64).tobytes())
+    tot = torch.tensor([cnt, by, nrows, len(closed_app), 0 if owned_ok else 1], dtype=torch.int64)
+    dist.all_reduce(tot)
+    cnt, by, nrows, closed_app_rows, not_owned = (int(v) for v in tot.tolist())
+    # the sliding window's shares go to rank 0 for the byte-for-byte check (the sink of a sharded close would not gather them)
+    slide_parts = fa.dist.allgather_struct(slide_app, fa.ROW_APP_DTYPE, device="cpu")
+    slide_app = fa.dist.merge_rows_app_host(slide_parts) if rank == 0 else slide_app
+    del slide_parts
     digest = np.frombuffer(h.digest(), dtype=np.uint8).copy()
     digests = fa.dist.allgather_bytes(digest, device="cpu")
     per_rank = torch.tensor([float(mine), float(wire), path_s, t_ingest, t_slide, t_aligned, t_app, t_close], dtype=torch.float64)
@@ -127,6 +137,8 @@ def main():
             "merge_aligned_windows_app_s": float(g[:, 6].max()), "close_and_reread_s": float(g[:, 7].max()),
             "all_ranks_hold_identical_merged_results": bool(all(bytes(d) == bytes(digests[0]) for d in digests)),
             "flows_5m_rows": int(len(allrows)), "app_rows": int(nrows), "sliding_window_rows": int(len(slide5m)), "sliding_window_app_rows": int(len(slide_app)),
+            "app_exchange": "hash-partitioned all-to-all: every rank merges and keeps the keys it owns", "app_rows_all_on_their_owner": not_owned == 0,
+            "closed_app_rows": closed_app_rows,
         })
         assert out["records"] == n
         threads = min(64, effective_cpus()[0])
@@ -166,7 +178,8 @@ def main():
         out["cpu_oracle_seconds"] = time.perf_counter() - t0c
         print(json.dumps(out), flush=True)
         ok = all(out[k] for k in ("flows_5m_aligned_windows_bit_exact", "sliding_window_bit_exact", "sliding_window_app_bit_exact", "app_count_equals_records",
-                                  "app_sum_bytes_equals_flows_5m", "all_ranks_hold_identical_merged_results", "closed_window_equals_first_aligned_window"))
+                                  "app_sum_bytes_equals_flows_5m", "all_ranks_hold_identical_merged_results", "closed_window_equals_first_aligned_window",
+                                  "app_rows_all_on_their_owner"))
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
