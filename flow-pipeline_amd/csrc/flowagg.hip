@@ -95,7 +95,7 @@ struct fa_ctx {
         uint32_t nwg = 0, wcapq = 0, wplog2 = 0, wmask = 0, wm = 0;  // wm: buckets below it were dropped after this launch
         size_t wregion = 0;
         uint64_t n = 0;               // records of the launch (upper bound of its tuples)
-        uint32_t minb = 0;            // smallest bucket among the chunk's live tuples when it was last looked for (wlog_drop; valid: minb_known)
+        uint32_t minb = 0, maxb = 0;  // smallest / largest bucket among the chunk's live tuples when they were looked for (wlog_drop; valid: minb_known)
         bool minb_known = false;
     };
     std::vector<WChunk> wlog, wlog_free;
@@ -193,6 +193,7 @@ struct fa_ctx {
     uint32_t wspill_cap = 0;      // (updates a record can park in the wide table) x 2 x max_batch_records + slack
     uint32_t wide_per_record = 0;  // wide-table updates one record can cause (enabled wide key sets)
     uint64_t wused_base = 0;
+    uint64_t wide_dead = 0;       // slots of the wide table whose rows a window close zeroed (wdrop_kernel): occupied, but no rows - purged by the next rebuild
     ulonglong2* port_hist = nullptr;  // [2][PORT_DENSE]
 
     fa_stats_t stats{};
@@ -596,6 +597,7 @@ static int rebuild_wide(fa_ctx* c, uint32_t new_log2, uint32_t kind_mask, uint32
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipFree(old));
     c->wused_base = 0;
+    c->wide_dead = 0;  // (slots without rows were not carried over)
     c->stats.wide_capacity = 1ull << c->wcap_log2;
     return FA_OK;
 }
@@ -616,8 +618,11 @@ static int settle_wide(fa_ctx* c, Counters& h) {
     }
     int guard = 0;
     while (h.wspill_count || c->stats.wide_used * 2 > (1ull << c->wcap_log2)) {
-        // room for every group that exists plus every parked update, at <= 50 % load, in ONE step
-        const uint32_t want = std::max(c->wcap_log2 + 1, log2_ceil(2 * (c->stats.wide_used + h.wspill_count)));
+        // room for every group that exists plus every parked update, at <= 50 % load, in ONE step - at the SAME size when
+        // the slots that closed windows left dead (wdrop_kernel) are what fills the table
+        const uint64_t live = c->stats.wide_used - std::min(c->wide_dead, c->stats.wide_used);
+        const uint32_t want = c->wide_dead ? std::max(c->wcap_log2, log2_ceil(2 * (live + h.wspill_count))) :
+                                             std::max(c->wcap_log2 + 1, log2_ceil(2 * (c->stats.wide_used + h.wspill_count)));
         if (want > 30 || ++guard > 8) return fail(c, FA_ERR_TABLE_FULL, "wide-key table cannot grow further");
         const uint32_t nspill = h.wspill_count;
         // the parked updates move to a private copy and the buffer is emptied BEFORE the rebuild, so that anything the
@@ -865,25 +870,25 @@ static int wlog_drop(fa_ctx* c, uint32_t lo, uint32_t hi) {
     if (c->wlog.empty()) return FA_OK;
     for (auto& k : c->wlog)
         if (!k.minb_known) {
-            uint32_t* word = k.counts + k.counts_cap + 1;
+            uint32_t* word = k.counts + k.counts_cap + 1;  // (the words behind the time base: min, max)
             HIPCHK(c, hipMemsetAsync(word, 0xff, sizeof(uint32_t), c->stream));
+            HIPCHK(c, hipMemsetAsync(word + 1, 0, sizeof(uint32_t), c->stream));
             hipLaunchKernelGGL(wlog_minbucket_kernel, dim3(2048), dim3(256), 0, c->stream, wchunk_args(k), word);
             HIPCHK(c, hipGetLastError());
         }
-    std::vector<uint32_t> base(c->wlog.size()), minb(c->wlog.size());
-    for (size_t i = 0; i < c->wlog.size(); i++) {
-        HIPCHK(c, hipMemcpyAsync(&base[i], c->wlog[i].counts + c->wlog[i].counts_cap, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        if (!c->wlog[i].minb_known) HIPCHK(c, hipMemcpyAsync(&minb[i], c->wlog[i].counts + c->wlog[i].counts_cap + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    }
+    std::vector<uint32_t> mm(2 * c->wlog.size());
+    for (size_t i = 0; i < c->wlog.size(); i++)
+        if (!c->wlog[i].minb_known) HIPCHK(c, hipMemcpyAsync(&mm[2 * i], c->wlog[i].counts + c->wlog[i].counts_cap + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint32_t oldest = 0xFFFFFFFFu;  // smallest bucket any pending chunk still holds
     for (size_t i = 0; i < c->wlog.size(); i++) {
         fa_ctx::WChunk& k = c->wlog[i];
         if (!k.minb_known) {
-            k.minb = minb[i];  // (~0: no live tuple at all)
+            k.minb = mm[2 * i];  // (~0: no live tuple at all)
+            k.maxb = mm[2 * i + 1];
             k.minb_known = true;
         }
-        if (k.minb != 0xFFFFFFFFu) oldest = std::min(oldest, std::max(k.minb, k.wm));
+        if (k.minb != 0xFFFFFFFFu && k.maxb >= k.wm) oldest = std::min(oldest, std::max(k.minb, k.wm));
     }
     if (lo > oldest) return wlog_flush_all(c);  // (a range that is not the oldest: the table's rebuild has to remove it)
     for (size_t i = 0; i < c->wlog.size();) {
@@ -892,11 +897,10 @@ static int wlog_drop(fa_ctx* c, uint32_t lo, uint32_t hi) {
             k.wm = hi;
             c->wlog_wm_moves++;
         }
-        if (k.minb == 0xFFFFFFFFu || (uint64_t)base[i] + 256u <= k.wm) {  // (relative buckets are < 256: nothing of this chunk is alive)
+        if (k.minb == 0xFFFFFFFFu || k.maxb < k.wm) {  // nothing of this chunk is alive
             c->wlog_free.push_back(k);
             c->wlog_dropped++;
             c->wlog.erase(c->wlog.begin() + (long)i);
-            base.erase(base.begin() + (long)i);
         } else {
             i++;
         }

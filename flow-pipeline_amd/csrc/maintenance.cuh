@@ -223,13 +223,23 @@ __global__ __launch_bounds__(256) void wlog_rows_kernel(WChunkArgs k, uint32_t t
         if (sel && j < rows_cap) rows[j] = WRow{{key.w[0], key.w[1], key.w[2], key.w[3]}, bytes, packets, 1ull};
     });
 }
-// the smallest bucket among the chunk's live tuples (*out starts at ~0): what a window close compares its range with
+// the smallest and the largest bucket among the chunk's live tuples (out[0] starts at ~0, out[1] at 0): what a window
+// close compares its range with, and how it knows that nothing of a chunk is left
 __global__ __launch_bounds__(256) void wlog_minbucket_kernel(WChunkArgs k, uint32_t* out) {
-    uint32_t m = 0xffffffffu;
-    wchunk_walk(k, [&](bool live, uint32_t tb, const WKey&, uint64_t, uint64_t) { m = live ? min(m, tb) : m; });
+    uint32_t m = 0xffffffffu, x = 0u;
+    wchunk_walk(k, [&](bool live, uint32_t tb, const WKey&, uint64_t, uint64_t) {
+        m = live ? min(m, tb) : m;
+        x = live ? max(x, tb) : x;
+    });
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o));
-    if (__lane_id() == 0 && m != 0xffffffffu) atomicMin(out, m);
+    for (int o = 32; o > 0; o >>= 1) {
+        m = min(m, (uint32_t)__shfl_xor((int)m, o));
+        x = max(x, (uint32_t)__shfl_xor((int)x, o));
+    }
+    if (__lane_id() == 0 && m != 0xffffffffu) {
+        atomicMin(&out[0], m);
+        atomicMax(&out[1], x);
+    }
 }
 // the chunk folded into the table through the atomic path (the table's geometry changed since the tuples were scattered:
 // their regions are not the table's any more, wagg_kernel's ownership does not hold)
@@ -240,6 +250,27 @@ __global__ __launch_bounds__(256) void wlog_replay_kernel(WChunkArgs k, KArgs a)
         const unsigned long long m = __builtin_amdgcn_ballot_w64(live);
         if (m != 0ull && __lane_id() == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) atomicAdd(&a.ctr->wfold_n, (unsigned long long)__builtin_popcountll(m));
     });
+}
+
+// Window close without a rebuild: the selected rows' sums are zeroed in place.  A slot whose count() is 0 is no row (every
+// reader and the rebuild skip it) but keeps its key, so probe sequences stay intact; the same key arriving again simply
+// adds to the zeros.  The dead slots go when the table is rebuilt for growth (or, when half of a full table is dead, at
+// the same size: settle_wide).  One scan of the table instead of a scan plus the re-insertion of every surviving row
+// into a second table of the same size (16 GiB for BASELINE config 5: 54 ms per close in round 3).
+__global__ __launch_bounds__(256) void wdrop_kernel(WSlot* tab, uint32_t nslots, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, unsigned int* dropped) {
+    uint32_t mine = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) {
+        const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&tab[i].w[0]);
+        const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&tab[i].w[2]);
+        if (k01.x == 0 || k01.y == 0 || k23.x == 0 || k23.y == 0) continue;
+        const unsigned long long w[4] = {k01.x, k01.y, k23.x, k23.y};
+        if (!wrow_selected(w, kind_mask, tb_lo, tb_hi) || tab[i].v2 == 0) continue;
+        *reinterpret_cast<ulonglong2*>(&tab[i].v0) = make_ulonglong2(0ull, 0ull);
+        tab[i].v2 = 0ull;
+        mine++;
+    }
+    const uint32_t tot = wave_sum_u32(mine);
+    if (__lane_id() == 0 && tot) atomicAdd(dropped, tot);
 }
 
 // Re-inserts every row that is NOT selected into a fresh table (window removal / reset / growth).

@@ -1,0 +1,299 @@
+"""Round-4 GPU tests: the adaptive wide log end to end (enter - leave - drain through both folds), its behaviour when
+segment buffers run out, watermark closes of real timeslots, late records, the hash-partitioned window close (device
+partition == numpy restatement; two ranks on the one GPU), and window reads that leave through the pinned buffer in
+pieces.  All through the C-ABI, bit-exact against the oracle restatements."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stream(po, n, seed, universe_log2=22, zs=80, span=900):
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=seed, n_total=n, zipf_log2_universe=universe_log2, zipf_s_x100=zs, span_secs=span)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    assert status.sum() == 0
+    return buf, off, rows, status
+
+
+def _ingest(agg, buf, off, n, step, sync=True):
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        agg.ingest(buf[int(off[a]):int(off[b])], off[a:b + 1] - off[a])
+        if sync:
+            agg.sync()  # (the counter feedback then sees exactly this launch: the state machine's moves are deterministic)
+
+
+def _scaled(rows, k):
+    out = rows.copy()
+    with np.errstate(over="ignore"):
+        for c in ("bytes", "packets", "count"):
+            out[c] = out[c] * np.uint64(k)
+    return out
+
+
+def test_adaptive_wide_log_enters_leaves_and_drains_both_ways(gpu_lib, fa, po, monkeypatch):
+    """The library's own choices (FA_WIDE unset) on 400 k-record launches, the log bounded at two pending chunks:
+    A  a stream that opens a (SrcAddr,DstPort,Proto) row per record -> the counter feedback switches to the log;
+    B  the same records again and again: chunks are recorded, the folds of the oldest ones stop opening rows -> back to the table;
+    C  more of it: what is still pending drains through the region-owned fold, one chunk per launch;
+    D  NEW keys: log mode again, and now the folds make the table grow - chunks scattered for the old geometry go through the
+       atomic replay.
+    After every phase the rows are the oracle's."""
+    monkeypatch.delenv("FA_WIDE", raising=False)
+    monkeypatch.setenv("FA_WIDE_LOG_CHUNKS", "2")
+    step = 400_000
+    b1, o1, r1, s1 = _stream(po, 3 * step, seed=401)
+    b2, o2, r2, s2 = _stream(po, 20 * step, seed=402)
+    parts1 = [po.rollup_app(r1[i * step:(i + 1) * step], s1[i * step:(i + 1) * step], 300).astype(fa.ROW_APP_DTYPE) for i in range(3)]
+    assert sum(len(p) for p in parts1) > 0.9 * 3 * step  # (random ports: a row per record)
+    times1 = [0, 0, 0]
+    new_parts = []
+    launches = [0]
+
+    def old(agg):  # the next third of stream 1 (keys the table knows after phase A)
+        i = launches[0] % 3
+        _ingest(agg, b1[int(o1[i * step]):int(o1[(i + 1) * step])], o1[i * step:(i + 1) * step + 1] - o1[i * step], step, step)
+        times1[i] += 1
+        launches[0] += 1
+
+    def new(agg):  # the next 400 k records of stream 2: keys nobody has seen
+        i = len(new_parts)
+        _ingest(agg, b2[int(o2[i * step]):int(o2[(i + 1) * step])], o2[i * step:(i + 1) * step + 1] - o2[i * step], step, step)
+        new_parts.append(po.rollup_app(r2[i * step:(i + 1) * step], s2[i * step:(i + 1) * step], 300).astype(fa.ROW_APP_DTYPE))
+
+    def check(agg):
+        want = fa.dist.merge_rows_app_host([_scaled(parts1[i], times1[i]) for i in range(3) if times1[i]] + new_parts)
+        assert agg.read_window_app().tobytes() == want.tobytes()
+
+    with fa.FlowAgg(framed=True, key_sets=9, wide_capacity_log2=16, table_capacity_log2=20, max_batch_records=step) as agg:
+        # A: three launches = 1.2 M records > the 2^20 the feedback wants to see
+        for _ in range(3):
+            old(agg)
+        st = agg.stats()
+        assert st["wide_log_mode"] == 1 and st["wide_log_recorded"] == 0, st
+        check(agg)
+        # B: log mode - chunks recorded, the third one pushes the oldest into the table
+        for _ in range(3):
+            old(agg)
+        st = agg.stats()
+        assert st["wide_log_recorded"] == 3 and st["wide_log_chunks"] == 2 and st["wide_log_folded"] + st["wide_log_replayed"] == 1, st
+        assert st["wide_log_bytes"] > 0 and st["wide_log_records"] == 2 * step
+        check(agg)
+        for _ in range(8):  # ... until more than 2^20 folded tuples have opened no row
+            old(agg)
+            if agg.stats()["wide_log_mode"] == 0:
+                break
+        st = agg.stats()
+        assert st["wide_log_mode"] == 0 and st["wide_log_chunks"] >= 1, st
+        check(agg)
+        # C: the pending chunks drain, one per launch, through the region-owned fold (the table has not grown since)
+        pending, folded = st["wide_log_chunks"], st["wide_log_folded"]
+        for k in range(pending):
+            old(agg)
+            st = agg.stats()
+            assert st["wide_log_chunks"] == pending - k - 1 and st["wide_log_folded"] == folded + k + 1 and st["wide_log_mode"] == 0, st
+        check(agg)
+        # D: new keys - the log again; its folds now grow the table, and chunks scattered before that take the atomic replay
+        for _ in range(8):
+            new(agg)
+            if agg.stats()["wide_log_mode"] == 1:
+                break
+        st = agg.stats()
+        assert st["wide_log_mode"] == 1, st
+        check(agg)
+        replayed = st["wide_log_replayed"]
+        while len(new_parts) < 20:
+            new(agg)
+            if agg.stats()["wide_log_replayed"] > replayed:
+                break
+        st = agg.stats()
+        assert st["wide_log_replayed"] > replayed, st
+        check(agg)
+        assert st["records_ok"] == (launches[0] + len(new_parts)) * step and st["records_bad"] == 0
+        # flows_5m never noticed any of it
+        ref = po.Rollup(300)
+        for i in range(3):
+            for _ in range(times1[i]):
+                ref.ingest(b1[int(o1[i * step]):int(o1[(i + 1) * step])], o1[i * step:(i + 1) * step + 1] - o1[i * step], 1)
+        nn = len(new_parts) * step
+        ref.ingest(b2[:int(o2[nn])], o2[:nn + 1], 1)
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+
+
+def test_wide_log_folds_early_when_segment_buffers_run_out(gpu_lib, fa, po, monkeypatch):
+    """FA_WSEG_BUDGET stands in for a failing hipMalloc: with room for three pairs of segment buffers and eight chunks
+    allowed, the fourth launch cannot get a pair - the oldest chunk is folded and its buffers are taken over; no error."""
+    monkeypatch.setenv("FA_WIDE", "log")
+    monkeypatch.setenv("FA_WIDE_LOG_CHUNKS", "8")
+    monkeypatch.setenv("FA_WSEG_BUDGET", "3")
+    n, step = 600_000, 100_000
+    buf, off, rows, status = _stream(po, n, seed=411, universe_log2=16)
+    with fa.FlowAgg(framed=True, key_sets=9, wide_capacity_log2=20, max_batch_records=step) as agg:
+        _ingest(agg, buf, off, n, step, sync=False)
+        st = agg.stats()
+        assert st["wide_log_nomem_folds"] == 3 and st["wide_log_chunks"] == 3 and st["wide_log_recorded"] == 6, st  # (3 pairs of buffers: 3 chunks)
+        assert agg.read_window_app().tobytes() == po.rollup_app(rows, status, 300).astype(fa.ROW_APP_DTYPE).tobytes()
+
+
+def test_timeslot_closes_move_the_watermark_of_pending_chunks(gpu_lib, fa, po, monkeypatch):
+    """A close of the OLDEST buckets must not fold the log: the chunks' watermark moves (and a chunk with nothing left is
+    dropped whole).  Round 3 compared the window with the launch's time base - two buckets below its smallest sampled one -
+    and every close of a real timeslot folded all chunks."""
+    monkeypatch.setenv("FA_WIDE", "log")
+    monkeypatch.setenv("FA_WIDE_LOG_CHUNKS", "8")
+    n, step, sub = 400_000, 100_000, 60
+    buf, off, rows, status = _stream(po, n, seed=421, universe_log2=14, span=600)
+    t32 = rows["time_received"].astype(np.uint64).astype(np.uint32)
+    with fa.FlowAgg(framed=True, key_sets=9, subwindow_secs=sub, wide_capacity_log2=20, max_batch_records=step) as agg:
+        _ingest(agg, buf, off, n, step, sync=False)
+        t0 = int(agg.open_timeslots()[0])
+        st0 = agg.stats()
+        assert st0["wide_log_chunks"] == 4 and st0["wide_used"] == 0
+        alive = np.ones(n, dtype=bool)
+        for k in range(6):  # six closes, each removes the oldest sub-bucket
+            ts = t0 + k * sub
+            got = agg.close_window_app(ts)
+            want = po.rollup_app(rows[alive], status[alive], sub, window=300, timeslot=ts).astype(fa.ROW_APP_DTYPE)
+            assert got.tobytes() == want.tobytes(), k
+            alive &= ~((t32 >= ts) & (t32 < ts + sub))
+        st = agg.stats()
+        assert st["wide_log_folded"] == 0 and st["wide_log_replayed"] == 0 and st["wide_used"] == 0, st  # nothing was folded
+        assert st["wide_log_watermark_moves"] >= 6 and st["wide_log_dropped"] == 2, st                     # (600 s in 4 launches, 360 s closed: two chunks are gone whole)
+        assert agg.read_window_app().tobytes() == po.rollup_app(rows[alive], status[alive], sub).astype(fa.ROW_APP_DTYPE).tobytes()
+        # a drop that is not the oldest range still folds first (and stays exact)
+        mid = t0 + 8 * sub
+        got = agg.close_window_app(mid)
+        assert got.tobytes() == po.rollup_app(rows[alive], status[alive], sub, window=300, timeslot=mid).astype(fa.ROW_APP_DTYPE).tobytes()
+        assert agg.stats()["wide_log_chunks"] == 0
+
+
+def test_late_records_are_counted_and_still_aggregated(gpu_lib, fa, po):
+    n = 300_000
+    gp = po.gen_params(mode=po.GEN_ASPAIRS, framed=1, seed=431, n_total=n, span_secs=900)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    t32 = rows["time_received"].astype(np.uint64).astype(np.uint32)
+    with fa.FlowAgg(framed=True) as agg:
+        agg.ingest(buf, off)
+        t0 = int(agg.open_timeslots()[0])
+        assert agg.stats()["records_late"] == 0
+        first = agg.close_window(t0)
+        assert int(first["count"].sum()) == int((t32 < t0 + 300).sum())
+        agg.ingest(buf, off)  # the same stream again: what falls into the closed window is late
+        st = agg.stats()
+        assert st["records_late"] == int((t32 < t0 + 300).sum()), st
+        again = agg.read_window(t0)  # ... and visible to a later read of that timeslot, like a late INSERT into flows_5m
+        assert again.tobytes() == first.tobytes()
+        agg.close_window()  # close-all is not a time watermark
+        agg.ingest(buf, off)
+        assert agg.stats()["records_late"] == 2 * int((t32 < t0 + 300).sum())
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_device_partition_equals_the_numpy_restatement(gpu_lib, fa, po, world):
+    n = 300_000
+    buf, off, rows, status = _stream(po, n, seed=441, universe_log2=14)
+    with fa.FlowAgg(framed=True, key_sets=63, cms_width_log2=14, topk_capacity_log2=16, subwindow_secs=60) as agg:
+        agg.ingest(buf, off)
+        t0 = int(agg.open_timeslots()[0])
+        for kind, ts, k in ((fa.ROWS_APP, fa.ALL_TIMESLOTS, 0), (fa.ROWS_APP, t0 + 60, 0), (fa.ROWS_5M, fa.ALL_TIMESLOTS, 0),
+                            (fa.ROWS_PORT_DST, 0, 0), (fa.ROWS_MINUTE, 0, 0), (fa.ROWS_TOPK_SRC, 0, 5000)):
+            ptr, m = agg.rows_device(kind, ts, k)
+            whole = agg.rows_fetch(kind, ptr, m)
+            pptr, counts = agg.rows_partition_device(kind, ptr, m, world)
+            assert sum(counts) == m and m > 0
+            parts = agg.rows_fetch(kind, pptr, m)
+            dest = fa.dist.partition_rows_host(parts, kind, world)
+            assert np.array_equal(dest, np.repeat(np.arange(world), counts)), kind     # grouped by owner, owners as numpy says
+            assert np.array_equal(np.bincount(fa.dist.partition_rows_host(whole, kind, world), minlength=world), counts)
+            def canon(a):  # rows as u64 columns, sorted: the same multiset of rows
+                mtx = np.ascontiguousarray(a).view(np.uint8).reshape(m, -1).view("<u8")
+                return mtx[np.lexsort(mtx.T[::-1])]
+            assert np.array_equal(canon(parts), canon(whole))
+            if kind == fa.ROWS_APP and world > 2:
+                assert min(counts) > 0.5 * m / world  # (a hash partition: balanced)
+
+
+TWO_RANK_PARTITIONED = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+import _pkg
+fa = _pkg.load(); po = _pkg.load_oracle()
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+n, nparts = 300000, 8
+gp = po.gen_params(mode=2, framed=1, seed=451, n_total=n, zipf_log2_universe=20, zipf_s_x100=80)
+buf, off = po.gen_records(gp, 0, n)
+raw = bytes(buf)
+def shard(parts):
+    idx = np.concatenate([np.arange(p, n, nparts) for p in parts]); idx.sort()
+    recs = [raw[int(off[k]):int(off[k + 1])] for k in idx]
+    o = np.zeros(len(recs) + 1, dtype=np.uint64); o[1:] = np.cumsum([len(r) for r in recs])
+    return np.frombuffer(b"".join(recs), dtype=np.uint8), o
+for mode in ("scatter", "log"):
+    os.environ["FA_WIDE"] = mode
+    kw = dict(framed=True, key_sets=9, subwindow_secs=60, max_batch_records=60000)
+    with fa.FlowAgg(**kw) as agg, fa.FlowAgg(**kw) as whole:
+        b, o = shard(fa.dist.partitions_of(rank, world, nparts))
+        agg.ingest(b, o)
+        whole.ingest(buf, off)
+        ts = int(whole.open_timeslots()[0])
+        for t in (ts, ts + 60, fa.ALL_TIMESLOTS):
+            share = fa.dist.close_window_app_partitioned(agg, t)
+            assert (fa.dist.partition_rows_host(share, fa.ROWS_APP, world) == rank).all() and len(share) > 0
+            allp = fa.dist.allgather_struct(share, fa.dist.ROW_APP_DTYPE, device="cpu")
+            assert sum(len(p) for p in allp) == len(fa.dist.merge_rows_app_host(allp))        # a key lives on ONE rank
+            assert fa.dist.merge_rows_app_host(allp).tobytes() == whole.close_window_app(t).tobytes(), (mode, t)
+        # the flows_5m rows through the same exchange
+        s5 = fa.dist.rows_merged_partitioned(agg, fa.ROWS_5M)
+        assert fa.dist.merge_rows_host(fa.dist.allgather_struct(s5, fa.dist.ROW5M_DTYPE, device="cpu")).tobytes() == whole.read_window().tobytes()
+dist.destroy_process_group()
+print("TWO_RANK_PARTITIONED_OK", rank)
+'''
+
+
+def test_two_ranks_partitioned_window_close(gpu_lib, tmp_path):
+    import socket
+    script = tmp_path / "two_rank_partitioned.py"
+    script.write_text(TWO_RANK_PARTITIONED % {"root": ROOT})
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("FA_WIDE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.count("TWO_RANK_PARTITIONED_OK") == 2, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_large_window_leaves_through_the_pinned_buffer_in_pieces(gpu_lib, fa, po, monkeypatch):
+    """34 MB of (SrcAddr,DstPort,Proto) rows: more than half of the ctx's pinned buffer, so the copy-out runs in pieces
+    (copy engine and host threads alternating on the two halves) - from the table and from the log, through the read call
+    and through fa_rows_device + fa_rows_fetch, into a fresh and into a reused buffer."""
+    n, step = 640_000, 160_000
+    buf, off, rows, status = _stream(po, n, seed=461)
+    want = po.rollup_app(rows, status, 300).astype(fa.ROW_APP_DTYPE)
+    assert want.nbytes > 32 << 20
+    for mode in ("scatter", "log"):
+        monkeypatch.setenv("FA_WIDE", mode)
+        with fa.FlowAgg(framed=True, key_sets=9, table_capacity_log2=16, wide_capacity_log2=21, max_batch_records=step) as agg:
+            _ingest(agg, buf, off, n, step, sync=False)
+            assert agg.read_window_app().tobytes() == want.tobytes(), mode
+            reuse = np.empty(len(want) + 1000, dtype=fa.ROW_APP_DTYPE)
+            got = agg.read_window_app(out=reuse)
+            assert got.tobytes() == want.tobytes() and got.base is reuse, mode
+            n_out = fa.C.c_size_t()
+            small = np.empty(1000, dtype=fa.ROW_APP_DTYPE)  # the C contract: too small a buffer -> FA_ERR_CAPACITY and the size
+            assert agg._L.fa_read_window_app(agg._h, fa.ALL_TIMESLOTS, small.ctypes.data, len(small), fa.C.byref(n_out)) == -6
+            assert n_out.value == len(want)
