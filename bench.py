@@ -109,7 +109,7 @@ def effective_cpus():
 def cpu_baseline(po, gp, per_thread, n_rec, groups_hint, reps=3):
     """The C oracle (decode + 15-column projection + hash rollup, one shard per thread, merge by key partition) on
     the CPUs this process may really use (affinity mask cut by the cgroup quota).  Thread sweep with the SAME number of
-    records per thread at every point (`per_thread`, 4 M by default: 64 M records and >= 0.3 s of timed region at 16
+    records per thread at every point (`per_thread`, 6 M by default: 96 M records and >= 0.3 s of timed region at 16
     threads - round 3 timed 0.08 s and the figure moved by 20 % from run to run), every point run `reps` times and
     reported as the MEDIAN; shard tables are sized from the group count, allocated and first-touched before the start
     barrier, and sit on 2 MiB pages."""
@@ -204,7 +204,7 @@ def main():
     ap.add_argument("--mode", default="aspairs", choices=["mocker", "aspairs", "zipf", "goflow", "reversed", "distinct"])
     ap.add_argument("--stage", default="ingest", choices=["ingest", "decode"],
                     help="decode: the projection stage alone (wire bytes -> 15 SoA columns in HBM, fa_decode_device)")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="records PER THREAD timed on the CPU oracle at every point of the thread sweep (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=6_000_000, help="records PER THREAD timed on the CPU oracle at every point of the thread sweep (0 = skip)")
     ap.add_argument("--key-sets", type=int, default=1, help="fa key_sets mask (must include 1 = flows_5m rollup); 9 = config 5's "
                     "two concurrent key sets; side measurements only - the default is the BASELINE metric")
     ap.add_argument("--zipf-s", type=int, default=110, help="zipf exponent x100 for --mode zipf")

@@ -123,7 +123,7 @@ EXPORTS = [
     "fa_mock_generate_device", "fa_mock_generate_host",
     "fa_read_window_app", "fa_close_window_app", "fa_merge_rows_app", "fa_top_ports", "fa_merge_ports",
     "fa_minute_series", "fa_merge_minutes", "fa_dashboard_reset", "fa_rows_to_rowbinary", "fa_format_addr",
-    "fa_row_bytes", "fa_rows_device", "fa_rows_merge_device", "fa_rows_fetch", "fa_drop_window", "fa_rows_partition_device",
+    "fa_row_bytes", "fa_rows_device", "fa_rows_merge_device", "fa_rows_fetch", "fa_drop_window", "fa_rows_partition_device", "fa_drop_range",
 ]
 # row kinds of the device-resident window close (include/flowagg.h, ABI 5)
 ROWS_5M, ROWS_APP, ROWS_PORT_SRC, ROWS_PORT_DST, ROWS_MINUTE, ROWS_TOPK_SRC, ROWS_TOPK_DST = range(7)
@@ -237,6 +237,7 @@ def lib():
     L.fa_rows_fetch.argtypes = [vp, C.c_int, vp, sz, vp, sz]
     L.fa_rows_partition_device.argtypes = [vp, C.c_int, vp, sz, u32, C.POINTER(vp), szp]
     L.fa_drop_window.argtypes = [vp, C.c_int, u32]
+    L.fa_drop_range.argtypes = [vp, C.c_int, u32, u32]
     _LIB = L
     return L
 
@@ -440,6 +441,10 @@ class FlowAgg:
     def drop_window(self, kind: int, timeslot=ALL_TIMESLOTS):
         """Removes what close_window / close_window_app would remove after emitting `timeslot`."""
         self._chk(self._L.fa_drop_window(self._h, kind, timeslot))
+
+    def drop_range(self, kind: int, timeslot_lo: int, timeslot_hi: int):
+        """Removes every (sub-)bucket whose start lies in [timeslot_lo, timeslot_hi) in one pass (tumbling closes over sub-buckets)."""
+        self._chk(self._L.fa_drop_range(self._h, kind, timeslot_lo, timeslot_hi))
 
     def open_timeslots(self) -> np.ndarray:
         n = C.c_size_t()

@@ -866,8 +866,9 @@ static int wlog_record(fa_ctx* c, const KArgs& a, size_t n) {
 // caller's rebuild removes the range.  "Older" is judged by the smallest bucket among a chunk's live tuples - looked for
 // once per chunk (a scan of its segments, the word behind the time base) and kept: with the launch's time base instead
 // (the smallest SAMPLED bucket - 2) every close of a real timeslot found "something older" and folded all chunks.
-static int wlog_drop(fa_ctx* c, uint32_t lo, uint32_t hi) {
-    if (c->wlog.empty()) return FA_OK;
+// every pending chunk's bucket range [minb, maxb] (live tuples; one scan per chunk, kept)
+static int wlog_bucket_ranges(fa_ctx* c) {
+    bool any = false;
     for (auto& k : c->wlog)
         if (!k.minb_known) {
             uint32_t* word = k.counts + k.counts_cap + 1;  // (the words behind the time base: min, max)
@@ -875,12 +876,13 @@ static int wlog_drop(fa_ctx* c, uint32_t lo, uint32_t hi) {
             HIPCHK(c, hipMemsetAsync(word + 1, 0, sizeof(uint32_t), c->stream));
             hipLaunchKernelGGL(wlog_minbucket_kernel, dim3(2048), dim3(256), 0, c->stream, wchunk_args(k), word);
             HIPCHK(c, hipGetLastError());
+            any = true;
         }
+    if (!any) return FA_OK;
     std::vector<uint32_t> mm(2 * c->wlog.size());
     for (size_t i = 0; i < c->wlog.size(); i++)
         if (!c->wlog[i].minb_known) HIPCHK(c, hipMemcpyAsync(&mm[2 * i], c->wlog[i].counts + c->wlog[i].counts_cap + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint32_t oldest = 0xFFFFFFFFu;  // smallest bucket any pending chunk still holds
     for (size_t i = 0; i < c->wlog.size(); i++) {
         fa_ctx::WChunk& k = c->wlog[i];
         if (!k.minb_known) {
@@ -888,6 +890,16 @@ static int wlog_drop(fa_ctx* c, uint32_t lo, uint32_t hi) {
             k.maxb = mm[2 * i + 1];
             k.minb_known = true;
         }
+    }
+    return FA_OK;
+}
+static int wlog_drop(fa_ctx* c, uint32_t lo, uint32_t hi) {
+    if (c->wlog.empty()) return FA_OK;
+    int rc0 = wlog_bucket_ranges(c);
+    if (rc0) return rc0;
+    uint32_t oldest = 0xFFFFFFFFu;  // smallest bucket any pending chunk still holds
+    for (size_t i = 0; i < c->wlog.size(); i++) {
+        fa_ctx::WChunk& k = c->wlog[i];
         if (k.minb != 0xFFFFFFFFu && k.maxb >= k.wm) oldest = std::min(oldest, std::max(k.minb, k.wm));
     }
     if (lo > oldest) return wlog_flush_all(c);  // (a range that is not the oldest: the table's rebuild has to remove it)

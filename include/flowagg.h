@@ -271,6 +271,10 @@ int fa_rows_fetch(fa_ctx*, int kind, const void* d_rows, size_t n, void* out, si
 /* Removes what fa_close_window / fa_close_window_app would remove after emitting `timeslot` (kind FA_ROWS_5M or
  * FA_ROWS_APP): the whole window for tumbling windows and close-all, the oldest sub-bucket when windows slide. */
 int fa_drop_window(fa_ctx*, int kind, uint32_t timeslot);
+/* ABI 6: removes every (sub-)bucket whose start lies in [timeslot_lo, timeslot_hi) - both on the bucket grid - in one pass:
+ * a consumer of TUMBLING windows over sub-buckets closes a whole window with it (fa_drop_window removes one sub-bucket
+ * per call, what a sliding consumer wants). */
+int fa_drop_range(fa_ctx*, int kind, uint32_t timeslot_lo, uint32_t timeslot_hi);
 
 /* ---- bulk-load sink: flows_5m rows as ClickHouse RowBinary ------------------- */
 /* Serialises rows for `INSERT INTO flows_5m FORMAT RowBinary` with the column list of

@@ -297,3 +297,33 @@ def test_large_window_leaves_through_the_pinned_buffer_in_pieces(gpu_lib, fa, po
             small = np.empty(1000, dtype=fa.ROW_APP_DTYPE)  # the C contract: too small a buffer -> FA_ERR_CAPACITY and the size
             assert agg._L.fa_read_window_app(agg._h, fa.ALL_TIMESLOTS, small.ctypes.data, len(small), fa.C.byref(n_out)) == -6
             assert n_out.value == len(want)
+
+
+@pytest.mark.parametrize("mode", ["scatter", "log"])
+def test_drop_range_closes_a_tumbling_window_over_sub_buckets(gpu_lib, fa, po, monkeypatch, mode):
+    """fa_drop_range: the five 60-s sub-buckets of a 5-minute window leave in one pass - both key sets, table and log."""
+    monkeypatch.setenv("FA_WIDE", mode)
+    n, step, sub = 300_000, 100_000, 60
+    buf, off, rows, status = _stream(po, n, seed=471, universe_log2=14, span=900)
+    t32 = rows["time_received"].astype(np.uint64).astype(np.uint32)
+    with fa.FlowAgg(framed=True, key_sets=9, subwindow_secs=sub, max_batch_records=step) as agg:
+        _ingest(agg, buf, off, n, step, sync=False)
+        t0 = int(agg.open_timeslots()[0])
+        t0 -= t0 % 300
+        alive = np.ones(n, dtype=bool)
+        for w in (t0, t0 + 300):
+            assert agg.read_window_app(w).tobytes() == po.rollup_app(rows[alive], status[alive], sub, window=300, timeslot=w).astype(fa.ROW_APP_DTYPE).tobytes()
+            agg.drop_range(fa.ROWS_APP, w, w + 300)
+            agg.drop_range(fa.ROWS_5M, w, w + 300)
+            alive &= ~((t32 >= w) & (t32 < w + 300))
+            assert agg.read_window_app().tobytes() == po.rollup_app(rows[alive], status[alive], sub).astype(fa.ROW_APP_DTYPE).tobytes()
+            ref = po.Rollup(sub)
+            idx = np.nonzero(alive)[0]
+            if len(idx):
+                a, b = int(idx[0]), int(idx[-1]) + 1  # (the stream is time-ordered: the live records are a suffix)
+                assert alive[a:b].all()
+                ref.ingest(buf[int(off[a]):int(off[b])], off[a:b + 1] - off[a], 1)
+            assert agg.read_window().tobytes() == ref.rows().tobytes()
+        with pytest.raises(fa.FlowAggError):
+            agg.drop_range(fa.ROWS_APP, t0 + 7, t0 + 300)
+        assert agg.stats()["records_late"] == 0

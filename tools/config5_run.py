@@ -149,14 +149,13 @@ def main():
             nrows += len(app)
         out["app_rows"] = nrows
         out["read_app_windows_ms"] = [round(x, 1) for x in app_ms]  # (SrcAddr,DstPort,Proto) rows of one aligned window each: collect + device merge + copy out (reused host buffer)
-        # ---- real closes, oldest window first: read + drop of its five 60-s sub-buckets (the log's watermark moves; the table's
-        # rows of the window are zeroed in place)
+        # ---- real closes, oldest window first: read + drop of its five 60-s sub-buckets in one pass (the log's watermark moves;
+        # the table's rows of the window are zeroed in place)
         close_ms, closes_ok = [], True
         for i, ts in enumerate(aligned):
             tw = time.perf_counter()
-            app = agg.close_window_app(ts, out=reuse)
-            for k in range(1, 5):
-                agg.drop_window(fa.ROWS_APP, ts + 60 * k)
+            app = agg.read_window_app(ts, out=reuse)
+            agg.drop_range(fa.ROWS_APP, ts, ts + 300)  # (a tumbling consumer: the window's five sub-buckets in one pass)
             close_ms.append((time.perf_counter() - tw) * 1e3)
             closes_ok = closes_ok and (int(app["count"].sum()), int(app["bytes"].sum(dtype=np.uint64)), len(app)) == sums[i]
         stc = agg.stats()
