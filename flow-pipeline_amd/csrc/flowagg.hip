@@ -123,6 +123,8 @@ struct fa_ctx {
     int sink_mode = 0;  // 0 auto, 1 direct, 2 scatter (env FA_SINK)
     bool use_wave_tiles = false;  // decision for the batch being launched
     bool use_t8 = false;          // ... compact 8-byte tuples (table.cuh) for it
+    bool use_long = false;        // ... the long-record geometry of the lean kernel variants (sinks.cuh, WBLOCK_LONG)
+    int long_mode = 0;            // env FA_LONG_TILES: 0 by record size, 1 always, 2 never (A/B, tests)
     // tuple format feedback: compact tuples while (almost) every record fits them.  A launch whose misfits (records
     // that only a wide tuple holds - they took the direct path) exceed 1/16 of its records switches the ctx to wide
     // tuples for the next 64 launches, then compact is tried again.  Only speed depends on this, never results.
@@ -346,6 +348,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_STAGE_THREADS")) c->stage_threads = (unsigned)std::min(64, std::max(1, atoi(d)));
     c->stage_threads = std::min(c->stage_threads, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* d = getenv("FA_TUPLE")) c->t8_mode = !strcmp(d, "8") ? 1 : !strcmp(d, "16") ? 2 : 0;
+    if (const char* d = getenv("FA_LONG_TILES")) c->long_mode = !strcmp(d, "1") ? 1 : !strcmp(d, "0") ? 2 : 0;
     auto bail = [&](const char* what, hipError_t e) {
         g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
         fa_destroy(c);
@@ -1002,6 +1005,13 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
     if (t8) c->stats.compact_tuple_launches += 1;
 #define FA_LAUNCH_W(KS)                                                                         \
     do {                                                                                        \
+        if constexpr (wt_lean(KS)) {                                                            \
+            if (c->use_long) {                                                                  \
+                if (t8) hipLaunchKernelGGL((wtile_kernel<KS, true, 1>), g, dim3(wtile_block<KS, 1>()), 0, c->stream, a); \
+                else hipLaunchKernelGGL((wtile_kernel<KS, false, 1>), g, dim3(wtile_block<KS, 1>()), 0, c->stream, a);   \
+                break;                                                                          \
+            }                                                                                   \
+        }                                                                                       \
         if (t8) hipLaunchKernelGGL((wtile_kernel<KS, true>), g, dim3(wtile_block<KS>()), 0, c->stream, a); \
         else hipLaunchKernelGGL((wtile_kernel<KS, false>), g, dim3(wtile_block<KS>()), 0, c->stream, a);   \
     } while (0)
@@ -1304,12 +1314,18 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         // slightly shorter tile buffers: wtile_block, wtile_stride)
         const bool big_wg = !wt_lean(c->cfg.key_sets);
         const uint32_t ks = c->cfg.key_sets;
+        auto recs_for = [&](double cap) {
+            double r = cap / avg;
+            r = (cap - 2.0 * 12.0 * std::sqrt(std::min(r, (double)WT_RECS))) / avg;
+            return r >= (double)WT_RECS ? (uint32_t)WT_RECS : r < 1.0 ? 1u : (uint32_t)r;
+        };
         const double cap = (double)wt_stride((ks >= 1u && ks <= 7u) || ks == 9u ? ks : KS_ALL) - 16.0 - 15.0;  // (the instantiation launch_tiles picks)
-        double r = cap / avg;
-        r = (cap - 2.0 * 12.0 * std::sqrt(std::min(r, (double)WT_RECS))) / avg;
-        a.tile_recs = r >= (double)WT_RECS ? WT_RECS : r < 1.0 ? 1u : (uint32_t)r;
+        a.tile_recs = recs_for(cap);
+        // long records (GoFlow-shaped, ~156 B): half the waves, tile buffers twice as long - every lane of a wave has a record
+        c->use_long = !big_wg && c->long_mode != 2 && (c->long_mode == 1 || a.tile_recs < WT_LONG_BELOW);
+        if (c->use_long) a.tile_recs = recs_for(cap + (double)(WT_STRIDE_LONG - WT_STRIDE));
         const uint32_t wtiles = (a.n + a.tile_recs - 1) / a.tile_recs;
-        const uint32_t waves = (uint32_t)(big_wg ? WBLOCK_CMS : WBLOCK) / 64u;
+        const uint32_t waves = (uint32_t)(big_wg ? WBLOCK_CMS : c->use_long ? WBLOCK_LONG : WBLOCK) / 64u;
         const uint32_t wgs = (wtiles + waves - 1) / waves;
         grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * (uint32_t)(big_wg ? 1 : WT_WG_PER_CU)));
         if (a.tile_recs > (uint32_t)WT_RECS) c->use_t8 = false;

@@ -565,12 +565,12 @@ struct CmsLdsOpt<false> {
 };
 // workgroup size of a variant: the sketch variants need 32 KiB of LDS more per workgroup (CmsLds) than two
 // workgroups per CU leave - they run ONE workgroup of 16 waves per CU (the same 16 waves per CU)
-template <uint32_t KEYSETS>
-constexpr int wtile_block() { return wt_lean(KEYSETS) ? WBLOCK : WBLOCK_CMS; }
+template <uint32_t KEYSETS, int LONGT = 0>
+constexpr int wtile_block() { return LONGT ? WBLOCK_LONG : wt_lean(KEYSETS) ? WBLOCK : WBLOCK_CMS; }
 // ... and their tile buffers are 256 bytes shorter (62 instead of 64 mocker-sized records; the LDS goes to the sketch
 // bins and the hot-address cache - the whole 160 KiB of the CU are spoken for)
-template <uint32_t KEYSETS>
-constexpr int wtile_stride() { return wt_stride(KEYSETS); }
+template <uint32_t KEYSETS, int LONGT = 0>
+constexpr int wtile_stride() { return LONGT ? wt_stride(KEYSETS) - WT_STRIDE + WT_STRIDE_LONG : wt_stride(KEYSETS); }
 template <bool ON>
 struct HotAddrsOpt {
     HotAddrs v;
@@ -581,15 +581,17 @@ struct HotAddrsOpt<false> {
     __device__ __forceinline__ HotAddrs* get() { return nullptr; }
 };
 
-template <uint32_t KEYSETS, bool T8>
-__global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) void wtile_kernel(KArgs a) {
+// LONGT: the long-record geometry (sinks.cuh, WBLOCK_LONG) - lean variants only
+template <uint32_t KEYSETS, bool T8, int LONGT = 0>
+__global__ __launch_bounds__((wtile_block<KEYSETS, LONGT>()), LONGT ? 3 : wt_lean(KEYSETS) ? 6 : 4) void wtile_kernel(KArgs a) {
+    static_assert(!LONGT || wt_lean(KEYSETS), "long-record geometry: lean variants");
     constexpr uint32_t BL = bin_line(KEYSETS);
     constexpr uint32_t TB = bin_cap<T8, BL>();
     constexpr uint32_t COLS = cols_for_keysets<KEYSETS>();
-    constexpr int WBLOCK = wtile_block<KEYSETS>();  // (shadows the namespace constant inside this kernel)
+    constexpr int WBLOCK = wtile_block<KEYSETS, LONGT>();  // (shadows the namespace constant inside this kernel)
     constexpr bool HAS_CMS = (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) != 0;
     constexpr int WAVES = WBLOCK / 64;
-    constexpr int WT_STRIDE = wtile_stride<KEYSETS>();  // (shadows the namespace constant inside this kernel)
+    constexpr int WT_STRIDE = wtile_stride<KEYSETS, LONGT>();  // (shadows the namespace constant inside this kernel)
     __shared__ CmsLdsOpt<HAS_CMS> cms_lds;
     __shared__ HotAddrsOpt<HAS_CMS> hot_lds;
     __shared__ uint32_t cms_scratch_all[HAS_CMS ? WAVES * 16 : 1];
