@@ -32,7 +32,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                                           LaneTally& tally, uint32_t& pmode, uint32_t& lt_seen, uint32_t& lt_hits,
                                           uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook(),
                                           CmsLds* cl = nullptr, uint32_t* cms_scratch = nullptr, HotAddrs* hot = nullptr,
-                                          uint32_t* wpart_cnt = nullptr) {
+                                          uint32_t* wpart_cnt = nullptr, uint32_t* ks_cnt = nullptr) {
     constexpr uint32_t TB = bin_cap<T8, bin_line(KEYSETS)>();
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false, framed_ok = false;
@@ -262,7 +262,14 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 if (vd) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, wd);
             }
         }
-        if (keys_on) keyset_finish2(a, vs, ps, sh1, slo, shi, vd, pd, dh1, dlo, dhi);
+        if (keys_on) {
+            if (ks_cnt && a.ks_list) {  // (wave-tile kernel: what is not at home goes to the list - sinks.cuh, keyset_defer)
+                keyset_defer(a, ks_cnt, 0u, vs && !keyset_at_home(ps, sh1, slo, shi), slo, shi, sh1);
+                keyset_defer(a, ks_cnt, 1u, vd && !keyset_at_home(pd, dh1, dlo, dhi), dlo, dhi, dh1);
+            } else {
+                keyset_finish2(a, vs, ps, sh1, slo, shi, vd, pd, dh1, dlo, dhi);
+            }
+        }
     }
     if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb, tb_base, wpart_cnt);
 }
@@ -595,6 +602,7 @@ __global__ __launch_bounds__((wtile_block<KEYSETS, LONGT>()), LONGT ? 3 : wt_lea
     __shared__ CmsLdsOpt<HAS_CMS> cms_lds;
     __shared__ HotAddrsOpt<HAS_CMS> hot_lds;
     __shared__ uint32_t cms_scratch_all[HAS_CMS ? WAVES * 16 : 1];
+    __shared__ uint32_t ks_cnt[2];  // keys this workgroup has put on the distinct sets' lists (keyset_defer)
     __shared__ __attribute__((aligned(16))) uint32_t tiles[WAVES * WT_STRIDE / 4];
     __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BL];  // 256 x one store unit (sinks.cuh, bin_line)
     __shared__ uint32_t bin_cnt[NPART_MAX];
@@ -615,6 +623,7 @@ __global__ __launch_bounds__((wtile_block<KEYSETS, LONGT>()), LONGT ? 3 : wt_lea
         }
     }
     if (KEYSETS & FA_KEYS_MINUTE_SERIES) lds_minutes_clear(lm);
+    if (HAS_CMS && tid < 2) ks_cnt[tid] = 0;
     if (HAS_APP)
         for (int i = tid; i < (1 << WIDE_PLOG2_MAX); i += WBLOCK) wpart_cnt[i] = 0;
     CmsLds* const cl = (HAS_CMS && a.cseg) ? cms_lds.get() : nullptr;
@@ -726,7 +735,7 @@ __global__ __launch_bounds__((wtile_block<KEYSETS, LONGT>()), LONGT ? 3 : wt_lea
         uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
         lane_work<MODE_INGEST, KEYSETS, COLS, T8>(a, lt, lm, part_cnt, tile, staged, cur.q0 - cbase, cur.q1 - cbase, cur.r0 + lane, tb_base, tally,
                                                   pmode, lt_seen, lt_hits, bins, bin_cnt, fill, NoHook(), cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0), hot,
-                                                  (HAS_APP && a.wseg) ? wpart_cnt : nullptr);
+                                                  (HAS_APP && a.wseg) ? wpart_cnt : nullptr, HAS_CMS ? ks_cnt : nullptr);
         // (sketch variants, round 3: starting the next tile's DMA right behind the parse - the sink is long there and does
         // not look at the tile's bytes - measured +1.8 %, like the following for the lean variants)
         // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
@@ -815,6 +824,13 @@ __global__ __launch_bounds__((wtile_block<KEYSETS, LONGT>()), LONGT ? 3 : wt_lea
                 a.hot_seed_tag[at] = keep ? tg : 0u;
                 if (keep) a.hot_seed[at] = HotSeed{lo, hi};
             }
+        }
+    }
+    if (HAS_CMS && a.ks_list) {  // how many keys this workgroup left on each set's list
+        __syncthreads();
+        if (tid < 2) {
+            a.ks_list_counts[(size_t)tid * a.nwg + blockIdx.x] = min(ks_cnt[tid], a.ks_list_capw);
+            if (ks_cnt[tid]) atomicAdd(&a.ctr->ks_listed, (unsigned long long)min(ks_cnt[tid], a.ks_list_capw));
         }
     }
     if (HAS_CMS && cl) {  // what is left in the sketch bins (fewer than a chunk each) goes to the back part of the segments
@@ -919,6 +935,26 @@ __device__ __forceinline__ void exotic_pass(const KArgs& a) {
             keyset_insert(a, a.ks_dst, r.dst);
         }
         if (KEYSETS & FA_KEYS_WIDE) wide_sink_slow<KEYSETS>(a, r, tb);
+    }
+}
+
+// ---- the distinct sets' lists: keys the wave-tile kernel did not find in their home slot (sinks.cuh, keyset_defer) ---------
+// One workgroup per (set, ingest workgroup) part, a key per lane: the full probing / claiming path, every lane on its own
+// chain - thousands of them in flight instead of one per wave tile.
+__global__ __launch_bounds__(256) void keyset_list_kernel(KArgs a) {
+    for (uint32_t part = blockIdx.x; part < CMS_SETS * a.nwg; part += gridDim.x) {
+        const uint32_t set = part / a.nwg;
+        KeySlot* tab = set ? a.ks_dst : a.ks_src;
+        if (!tab) continue;
+        const uint32_t cnt = min(a.ks_list_counts[part], a.ks_list_capw);
+        const uint4* list = a.ks_list + (size_t)part * a.ks_list_capw;
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const uint4 e = list[i];
+            const unsigned long long lo = (unsigned long long)e.y << 32 | e.x, hi = (unsigned long long)e.w << 32 | e.z;
+            uint64_t h1, h2;
+            cms_hash2(lo, hi, a.cms_seed, h1, h2);
+            keyset_insert_slow(a, tab, lo, hi, keyset_tag(h1), keyset_home(a, h1));
+        }
     }
 }
 

@@ -119,6 +119,7 @@ struct Counters {
     unsigned int wspill_count, wrows_count;
     unsigned long long agg_groups, agg_launches;  // agg8_kernel: groups it added to the device table, launches (pass-count feedback)
     unsigned long long late;  // records below KArgs::late_below (flows_5m windows that were closed before they arrived)
+    unsigned long long ks_listed;  // distinct-set keys that took the list (keyset_list_kernel) instead of probing inside the ingest kernel
 };
 
 // Distinct-address set behind fa_topk (the dashboards rank EVERY address,
@@ -200,6 +201,11 @@ struct KArgs {
     unsigned long long wregion;
     ulonglong2* port_hist;  // [2][PORT_DENSE] {sum(Bytes*SamplingRate), count()}: SrcPort, then DstPort
     uint32_t late_below;    // time buckets below it were closed (flows_5m): records that still arrive for them are counted
+    // distinct-address sets: keys that are not in their home slot (displaced by an older key, or new) leave the wave-tile
+    // kernel as 16-byte entries in the workgroup's private part of a list and are inserted by keyset_list_kernel behind it
+    uint4* ks_list;            // [CMS_SETS][nwg][ks_list_capw] (nullptr: the probing path runs inside the ingest kernel)
+    uint32_t* ks_list_counts;  // [CMS_SETS][nwg]
+    uint32_t ks_list_capw;
 };
 
 __device__ __forceinline__ WArgs wargs(const KArgs& a) {
@@ -632,6 +638,27 @@ __device__ __forceinline__ void keyset_finish2(const KArgs& a, bool vs, const Ks
                 }
             }
         }
+    }
+}
+// The probing path OUT of the ingest kernel.  What is left of a tile's keys after the home-slot look (12 % of the known
+// keys sit elsewhere at a quarter load; every new key) used to walk the set right there - a chain of round trips to memory
+// with the whole wave waiting, once per tile (round 3: 166 us of a 760 us launch re-ingesting, more when streaming).  Now
+// such a key is appended to the workgroup's private part of a list (position from an LDS counter: no global atomic, no
+// round trip) and keyset_list_kernel inserts the lists behind the ingest kernel, one key per lane, thousands of
+// independent probe chains in flight.  A full list part: the key is inserted on the spot (exact either way).
+__device__ __forceinline__ void keyset_defer(const KArgs& a, uint32_t* ks_cnt, uint32_t set, bool need, unsigned long long lo, unsigned long long hi, uint64_t h1) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+    if (m == 0ull) return;
+    const uint32_t ln = __lane_id(), leader = (uint32_t)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (ln == leader) base = lds_add_rtn_u32(&ks_cnt[set], (uint32_t)__builtin_popcountll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+    const uint32_t pos = base + (uint32_t)__builtin_popcountll(m & ((1ull << ln) - 1ull));
+    if (!need) return;
+    if (pos < a.ks_list_capw) {
+        a.ks_list[((size_t)set * a.nwg + blockIdx.x) * a.ks_list_capw + pos] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    } else {
+        keyset_insert_slow(a, set ? a.ks_dst : a.ks_src, lo, hi, keyset_tag(h1), keyset_home(a, h1));
     }
 }
 __device__ __forceinline__ void keyset_insert(const KArgs& a, KeySlot* tab, const uint32_t key[4]) {

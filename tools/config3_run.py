@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--universe-log2", type=int, default=24)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--topk-log2", type=int, default=0, help="slots of each distinct-address set (default: universe + 2)")
+    ap.add_argument("--timing-only", action="store_true", help="A/B runs: ingest and print the path numbers, skip the CPU-side checks")
     args = ap.parse_args()
     import torch
     fa = _pkg.load()
@@ -128,6 +129,11 @@ def main():
         "ingest_wall_s_with_sync_per_chunk": t_ing, "generator_wall_s": t_gen,
         "records_direct_path": int(st1["records_direct"]), "flows_5m_rows": int(len(rows)),
     })
+    out["distinct_set_keys_listed"] = int(st1.get("ks_listed", 0))
+    if args.timing_only:
+        out["checks"] = "skipped (--timing-only)"
+        print(json.dumps(out))
+        return
     # ---- CPU side (oracle): the same stream, sketches + exact weights of the prefix
     t0 = time.perf_counter()
     words = depth << wl2
