@@ -128,8 +128,6 @@ struct fa_ctx {
     int sink_mode = 0;  // 0 auto, 1 direct, 2 scatter (env FA_SINK)
     bool use_wave_tiles = false;  // decision for the batch being launched
     bool use_t8 = false;          // ... compact 8-byte tuples (table.cuh) for it
-    bool use_long = false;        // ... the long-record geometry of the lean kernel variants (sinks.cuh, WBLOCK_LONG)
-    int long_mode = 0;            // env FA_LONG_TILES: 0 by record size, 1 always, 2 never (A/B, tests)
     // tuple format feedback: compact tuples while (almost) every record fits them.  A launch whose misfits (records
     // that only a wide tuple holds - they took the direct path) exceed 1/16 of its records switches the ctx to wide
     // tuples for the next 64 launches, then compact is tried again.  Only speed depends on this, never results.
@@ -173,6 +171,8 @@ struct fa_ctx {
     size_t m_scratch_cap = 0;
     void* m_out[2] = {nullptr, nullptr};  // merged rows; rows in emit order
     size_t m_out_cap[2] = {0, 0};
+    void* wl_scratch = nullptr;      // window reads of log chunks: per-segment counts, their scan, hipcub storage
+    size_t wl_scratch_cap = 0;
     void* part_buf = nullptr;        // fa_rows_partition_device: the rows grouped by destination rank
     size_t part_cap = 0;
     unsigned int* part_cnt = nullptr;  // [3][RPART_MAX_WORLD]: counts, starts, cursors
@@ -354,7 +354,6 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     c->stage_threads = std::min(c->stage_threads, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* d = getenv("FA_TUPLE")) c->t8_mode = !strcmp(d, "8") ? 1 : !strcmp(d, "16") ? 2 : 0;
     if (const char* d = getenv("FA_KS_DEFER")) c->ks_defer = strcmp(d, "0") != 0;
-    if (const char* d = getenv("FA_LONG_TILES")) c->long_mode = !strcmp(d, "1") ? 1 : !strcmp(d, "0") ? 2 : 0;
     auto bail = [&](const char* what, hipError_t e) {
         g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
         fa_destroy(c);
@@ -536,6 +535,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->m_scratch);
     (void)hipFree(c->m_out[0]);
     (void)hipFree(c->m_out[1]);
+    (void)hipFree(c->wl_scratch);
     (void)hipFree(c->part_buf);
     (void)hipFree(c->part_cnt);
     if (c->h_rows) (void)hipHostFree(c->h_rows);
@@ -1014,13 +1014,6 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
     if (t8) c->stats.compact_tuple_launches += 1;
 #define FA_LAUNCH_W(KS)                                                                         \
     do {                                                                                        \
-        if constexpr (wt_lean(KS)) {                                                            \
-            if (c->use_long) {                                                                  \
-                if (t8) hipLaunchKernelGGL((wtile_kernel<KS, true, 1>), g, dim3(wtile_block<KS, 1>()), 0, c->stream, a); \
-                else hipLaunchKernelGGL((wtile_kernel<KS, false, 1>), g, dim3(wtile_block<KS, 1>()), 0, c->stream, a);   \
-                break;                                                                          \
-            }                                                                                   \
-        }                                                                                       \
         if (t8) hipLaunchKernelGGL((wtile_kernel<KS, true>), g, dim3(wtile_block<KS>()), 0, c->stream, a); \
         else hipLaunchKernelGGL((wtile_kernel<KS, false>), g, dim3(wtile_block<KS>()), 0, c->stream, a);   \
     } while (0)
@@ -1052,7 +1045,7 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
 #undef FA_LAUNCH
 #undef FA_LAUNCH_W
     if (MODE == MODE_INGEST && wave_tiles && a.ks_list)  // the keys that were not in their home slots: probing path, a key per lane
-        hipLaunchKernelGGL(keyset_list_kernel, dim3(std::min<uint32_t>(CMS_SETS * a.nwg, 2048u)), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(keyset_list_kernel, dim3(std::min<uint32_t>(CMS_SETS * a.nwg, 2048u), 16), dim3(256), 0, c->stream, a);
     if (MODE == MODE_INGEST && a.seg) {
         const dim3 ga((1u << a.plog2) * AGG_SPLIT);
         if (t8 && AGG_SPLIT == 1 && !c->agg_generic) hipLaunchKernelGGL(agg8_kernel, ga, dim3(AGG_BLOCK), 0, c->stream, a);
@@ -1362,11 +1355,8 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         };
         const double cap = (double)wt_stride((ks >= 1u && ks <= 7u) || ks == 9u ? ks : KS_ALL) - 16.0 - 15.0;  // (the instantiation launch_tiles picks)
         a.tile_recs = recs_for(cap);
-        // long records (GoFlow-shaped, ~156 B): half the waves, tile buffers twice as long - every lane of a wave has a record
-        c->use_long = !big_wg && c->long_mode != 2 && (c->long_mode == 1 || a.tile_recs < WT_LONG_BELOW);
-        if (c->use_long) a.tile_recs = recs_for(cap + (double)(WT_STRIDE_LONG - WT_STRIDE));
         const uint32_t wtiles = (a.n + a.tile_recs - 1) / a.tile_recs;
-        const uint32_t waves = (uint32_t)(big_wg ? WBLOCK_CMS : c->use_long ? WBLOCK_LONG : WBLOCK) / 64u;
+        const uint32_t waves = (uint32_t)(big_wg ? WBLOCK_CMS : WBLOCK) / 64u;
         const uint32_t wgs = (wtiles + waves - 1) / waves;
         grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * (uint32_t)(big_wg ? 1 : WT_WG_PER_CU)));
         if (a.tile_recs > (uint32_t)WT_RECS) c->use_t8 = false;

@@ -572,12 +572,12 @@ struct CmsLdsOpt<false> {
 };
 // workgroup size of a variant: the sketch variants need 32 KiB of LDS more per workgroup (CmsLds) than two
 // workgroups per CU leave - they run ONE workgroup of 16 waves per CU (the same 16 waves per CU)
-template <uint32_t KEYSETS, int LONGT = 0>
-constexpr int wtile_block() { return LONGT ? WBLOCK_LONG : wt_lean(KEYSETS) ? WBLOCK : WBLOCK_CMS; }
+template <uint32_t KEYSETS>
+constexpr int wtile_block() { return wt_lean(KEYSETS) ? WBLOCK : WBLOCK_CMS; }
 // ... and their tile buffers are 256 bytes shorter (62 instead of 64 mocker-sized records; the LDS goes to the sketch
 // bins and the hot-address cache - the whole 160 KiB of the CU are spoken for)
-template <uint32_t KEYSETS, int LONGT = 0>
-constexpr int wtile_stride() { return LONGT ? wt_stride(KEYSETS) - WT_STRIDE + WT_STRIDE_LONG : wt_stride(KEYSETS); }
+template <uint32_t KEYSETS>
+constexpr int wtile_stride() { return wt_stride(KEYSETS); }
 template <bool ON>
 struct HotAddrsOpt {
     HotAddrs v;
@@ -588,17 +588,15 @@ struct HotAddrsOpt<false> {
     __device__ __forceinline__ HotAddrs* get() { return nullptr; }
 };
 
-// LONGT: the long-record geometry (sinks.cuh, WBLOCK_LONG) - lean variants only
-template <uint32_t KEYSETS, bool T8, int LONGT = 0>
-__global__ __launch_bounds__((wtile_block<KEYSETS, LONGT>()), LONGT ? 3 : wt_lean(KEYSETS) ? 6 : 4) void wtile_kernel(KArgs a) {
-    static_assert(!LONGT || wt_lean(KEYSETS), "long-record geometry: lean variants");
+template <uint32_t KEYSETS, bool T8>
+__global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) void wtile_kernel(KArgs a) {
     constexpr uint32_t BL = bin_line(KEYSETS);
     constexpr uint32_t TB = bin_cap<T8, BL>();
     constexpr uint32_t COLS = cols_for_keysets<KEYSETS>();
-    constexpr int WBLOCK = wtile_block<KEYSETS, LONGT>();  // (shadows the namespace constant inside this kernel)
+    constexpr int WBLOCK = wtile_block<KEYSETS>();  // (shadows the namespace constant inside this kernel)
     constexpr bool HAS_CMS = (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) != 0;
     constexpr int WAVES = WBLOCK / 64;
-    constexpr int WT_STRIDE = wtile_stride<KEYSETS, LONGT>();  // (shadows the namespace constant inside this kernel)
+    constexpr int WT_STRIDE = wtile_stride<KEYSETS>();  // (shadows the namespace constant inside this kernel)
     __shared__ CmsLdsOpt<HAS_CMS> cms_lds;
     __shared__ HotAddrsOpt<HAS_CMS> hot_lds;
     __shared__ uint32_t cms_scratch_all[HAS_CMS ? WAVES * 16 : 1];
@@ -941,6 +939,8 @@ __device__ __forceinline__ void exotic_pass(const KArgs& a) {
 // ---- the distinct sets' lists: keys the wave-tile kernel did not find in their home slot (sinks.cuh, keyset_defer) ---------
 // One workgroup per (set, ingest workgroup) part, a key per lane: the full probing / claiming path, every lane on its own
 // chain - thousands of them in flight instead of one per wave tile.
+// (grid: x = part, y = slices of a part - a part holds thousands of keys and a lane's keys are chains of round trips one
+// after the other: 16 slices keep a lane at one or two keys)
 __global__ __launch_bounds__(256) void keyset_list_kernel(KArgs a) {
     for (uint32_t part = blockIdx.x; part < CMS_SETS * a.nwg; part += gridDim.x) {
         const uint32_t set = part / a.nwg;
@@ -948,7 +948,7 @@ __global__ __launch_bounds__(256) void keyset_list_kernel(KArgs a) {
         if (!tab) continue;
         const uint32_t cnt = min(a.ks_list_counts[part], a.ks_list_capw);
         const uint4* list = a.ks_list + (size_t)part * a.ks_list_capw;
-        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < cnt; i += gridDim.y * blockDim.x) {
             const uint4 e = list[i];
             const unsigned long long lo = (unsigned long long)e.y << 32 | e.x, hi = (unsigned long long)e.w << 32 | e.z;
             uint64_t h1, h2;

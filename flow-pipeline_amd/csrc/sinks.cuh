@@ -59,15 +59,10 @@ __host__ __device__ constexpr uint32_t bin_line(uint32_t key_sets) { return wt_l
 // tuples per bin: wide (16-byte) or compact (8-byte) tuples
 template <bool T8, uint32_t BL>
 constexpr uint32_t bin_cap() { return (T8 ? 2u : 1u) * BL; }
-// Long records (GoFlow's sFlow samples: 33 fields, ~156 bytes): a 4864-byte tile buffer holds 30 of them - 30 of a wave's 64
-// lanes parse, the other 34 idle through every instruction of the walk.  The lean kernel variants therefore come in a second
-// geometry with HALF the waves per workgroup and tile buffers TWICE as long (the same LDS: two workgroups per CU): a wave
-// takes ~60 records per round, the same records are in flight per CU, and every parse instruction works for twice as many
-// of them.  The host picks it when a normal tile would hold fewer than WT_LONG_BELOW records (fa_ingest_device).
-constexpr int WBLOCK_LONG = FA_WBLOCK / 2;
-constexpr int WT_STRIDE_LONG = 2 * FA_WT_STRIDE;
-constexpr uint32_t WT_LONG_BELOW = 44;
-static_assert(WBLOCK_LONG % 64 == 0 && WBLOCK_LONG >= 256, "long-record geometry");
+// (Round 4 measured a second geometry for long records - GoFlow's 156-byte sFlow samples fill 30 of a wave's 64 lanes -: half
+// the waves per workgroup, tile buffers twice as long, ~60 records per wave and round in the same LDS.  1.08 ms per launch
+// against 0.75 ms: the walk is a chain of dependent LDS reads per record, what hides it is the number of waves, not the
+// number of busy lanes.  profiles/r04_goflow_long_geometry.json; the variant is gone.)
 constexpr int AGG_BLOCK = 1024;    // agg_kernel: 16 waves share one LDS table
 #ifndef FA_AGG_SLOTS
 #define FA_AGG_SLOTS 4096

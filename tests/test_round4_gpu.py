@@ -327,24 +327,3 @@ def test_drop_range_closes_a_tumbling_window_over_sub_buckets(gpu_lib, fa, po, m
         with pytest.raises(fa.FlowAggError):
             agg.drop_range(fa.ROWS_APP, t0 + 7, t0 + 300)
         assert agg.stats()["records_late"] == 0
-
-
-@pytest.mark.parametrize("mode,key_sets,long_tiles", [(3, 1, ""), (3, 1, "0"), (1, 1, "1"), (3, 9, ""), (2, 9, "1"), (0, 1, "1")])
-def test_long_record_geometry_is_only_a_geometry(gpu_lib, fa, po, monkeypatch, mode, key_sets, long_tiles):
-    """The lean ingest kernels in their long-record geometry (6 waves x 9.5 KiB tiles instead of 12 x 4.75 KiB): chosen for
-    GoFlow-shaped records, forced on short ones and forced off on long ones (FA_LONG_TILES) - the rows are the oracle's."""
-    if long_tiles:
-        monkeypatch.setenv("FA_LONG_TILES", long_tiles)
-    n = 300_000
-    gp = po.gen_params(mode=mode, framed=1, seed=481, n_total=n, span_secs=900, zipf_log2_universe=14)
-    buf, off = po.gen_records(gp, 0, n)
-    ref = po.Rollup(300)
-    assert ref.ingest(buf, off, 1) == 0
-    with fa.FlowAgg(framed=True, key_sets=key_sets, max_batch_records=100_000) as agg:
-        agg.ingest(buf, off)
-        assert agg.read_window().tobytes() == ref.rows().tobytes()
-        st = agg.stats()
-        assert st["records_ok"] == n and st["records_bad"] == 0 and st["records_slow"] == 0 and st["wave_tile_launches"] == 3
-        if key_sets & 8:
-            rows, status = po.decode_batch(buf, off, 1)
-            assert agg.read_window_app().tobytes() == po.rollup_app(rows, status, 300).astype(fa.ROW_APP_DTYPE).tobytes()
