@@ -71,6 +71,8 @@ struct fa_ctx {
     HotSeed* hot_seed = nullptr;   // [hot_seed_wgs][CMS_SETS][HOT_SLOTS] entries of the hot-address caches that survive a launch
     uint32_t* hot_seed_tag = nullptr;
     uint32_t hot_seed_wgs = 0, hot_epoch = 0;
+    HeavyKey* heavy = nullptr;     // [NPART_MAX] heavy (SrcAS,DstAS,EType) groups as agg8_kernel reports them (table.cuh); forgotten every 16 launches
+    bool heavy_on = true;          // env FA_HEAVY=0 (A/B)
     uint4* ks_list = nullptr;      // the distinct sets' lists (sinks.cuh, keyset_defer): [CMS_SETS][nwg][capw]
     size_t ks_list_bytes = 0;
     uint32_t* ks_list_counts = nullptr;
@@ -354,6 +356,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     c->stage_threads = std::min(c->stage_threads, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* d = getenv("FA_TUPLE")) c->t8_mode = !strcmp(d, "8") ? 1 : !strcmp(d, "16") ? 2 : 0;
     if (const char* d = getenv("FA_KS_DEFER")) c->ks_defer = strcmp(d, "0") != 0;
+    if (const char* d = getenv("FA_HEAVY")) c->heavy_on = strcmp(d, "0") != 0;
     auto bail = [&](const char* what, hipError_t e) {
         g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
         fa_destroy(c);
@@ -385,6 +388,8 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if ((e = hipMemsetAsync(c->tab, 0, tab_bytes, c->stream)) != hipSuccess) return bail("memset", e);
     if ((e = hipMalloc(&c->spill, sizeof(SpillEntry) * c->spill_cap)) != hipSuccess)
         return bail("hipMalloc(spill)", e);
+    if ((e = hipMalloc(&c->heavy, sizeof(HeavyKey) * NPART_MAX)) != hipSuccess) return bail("hipMalloc(heavy groups)", e);
+    if ((e = hipMemsetAsync(c->heavy, 0, sizeof(HeavyKey) * NPART_MAX, c->stream)) != hipSuccess) return bail("memset", e);
     if ((e = hipMalloc(&c->d_ctr, sizeof(Counters))) != hipSuccess) return bail("hipMalloc(ctr)", e);
     if ((e = hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream)) != hipSuccess)
         return bail("memset", e);
@@ -512,6 +517,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->cseg);
     (void)hipFree(c->cseg_counts);
     (void)hipFree(c->cms_psize);
+    (void)hipFree(c->heavy);
     (void)hipFree(c->ks_list);
     (void)hipFree(c->ks_list_counts);
     (void)hipFree(c->hot_seed);
@@ -1364,6 +1370,11 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     if (scatter) {
         rc = ensure_segments(c, n, (uint32_t)grid, c->use_t8, a);
         if (rc) return rc;
+        // heavy groups (table.cuh, HeavyKey): reported by agg8_kernel, pinned by the next launches' ingest workgroups
+        if (c->use_t8 && c->heavy_on && !c->agg_generic && c->plog2 == PART_LOG2_MAX) {
+            if (c->stats.batches % 16 == 0) HIPCHK(c, hipMemsetAsync(c->heavy, 0, sizeof(HeavyKey) * NPART_MAX, c->stream));
+            a.heavy = c->heavy;
+        }
     }
     if (c->use_wave_tiles && (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) && !c->cms_atomic && c->cms_scatter_ok) {
         rc = ensure_csegments(c, n, (uint32_t)grid, a);

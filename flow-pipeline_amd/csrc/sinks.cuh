@@ -198,6 +198,7 @@ struct KArgs {
     uint32_t late_below;    // time buckets below it were closed (flows_5m): records that still arrive for them are counted
     // distinct-address sets: keys that are not in their home slot (displaced by an older key, or new) leave the wave-tile
     // kernel as 16-byte entries in the workgroup's private part of a list and are inserted by keyset_list_kernel behind it
+    HeavyKey* heavy;           // [NPART_MAX] the heavy group of every key partition as the previous launch's agg8_kernel saw it (table.cuh)
     uint4* ks_list;            // [CMS_SETS][nwg][ks_list_capw] (nullptr: the probing path runs inside the ingest kernel)
     uint32_t* ks_list_counts;  // [CMS_SETS][nwg]
     uint32_t ks_list_capw;
@@ -571,7 +572,9 @@ __device__ __forceinline__ bool keyset_step(const KArgs& a, KeySlot* tab, unsign
     }
     // (claimers of this wave have published by now; owners in other waves are a few instructions away)
     if ((t | KS_READY) == (mytag | KS_READY)) {
-        for (int spin = 0; spin < 4096 && !(t & KS_READY); spin++) t = atomicOr(&s->tag, 0ull);
+        // (system-scope loads are served past the per-XCD L2s like the atomics, without queueing up behind each other on the
+        // one address as read-modify-writes do when many lanes wait for the same new key)
+        for (int spin = 0; spin < 4096 && !(t & KS_READY); spin++) t = __hip_atomic_load(&s->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (t & KS_READY) {
             const unsigned long long l = atomicAdd(&s->lo, 0ull), q = atomicAdd(&s->hi, 0ull);  // memory-side reads
             return l == lo && q == hi;
@@ -641,7 +644,23 @@ __device__ __forceinline__ void keyset_finish2(const KArgs& a, bool vs, const Ks
 // such a key is appended to the workgroup's private part of a list (position from an LDS counter: no global atomic, no
 // round trip) and keyset_list_kernel inserts the lists behind the ingest kernel, one key per lane, thousands of
 // independent probe chains in flight.  A full list part: the key is inserted on the spot (exact either way).
-__device__ __forceinline__ void keyset_defer(const KArgs& a, uint32_t* ks_cnt, uint32_t set, bool need, unsigned long long lo, unsigned long long hi, uint64_t h1) {
+// A key whose home slot the plain view shows EMPTY is claimed right here (one returning CAS, the key published behind it):
+// the first occurrence of a new key inserts it and every later one finds it at home - put on the list instead, a new heavy
+// key would be listed once per occurrence of the launch and the list kernel's lanes would fight over its slot (first cut:
+// 863 us of keyset_list_kernel per launch while the sets fill up).  What goes to the list is a key whose home slot holds
+// ANOTHER key (or that lost the claim).
+__device__ __forceinline__ void keyset_defer(const KArgs& a, uint32_t* ks_cnt, uint32_t set, bool need, unsigned long long lo, unsigned long long hi, uint64_t h1,
+                                             unsigned long long home_tag) {
+    if (__builtin_amdgcn_ballot_w64(need && home_tag == 0ull) != 0ull) {
+        if (need && home_tag == 0ull) {
+            KeySlot* s = &(set ? a.ks_dst : a.ks_src)[keyset_home(a, h1)];
+            if (atomicCAS(&s->tag, 0ull, keyset_tag(h1)) == 0ull) {  // claimed: publish the key, then mark it readable
+                const unsigned long long o1 = atomicExch(&s->lo, lo), o2 = atomicExch(&s->hi, hi);
+                if ((o1 & o2) != ~0ull) atomicOr(&s->tag, KS_READY);  // (always true: orders the OR behind both writes)
+                need = false;
+            }
+        }
+    }
     const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
     if (m == 0ull) return;
     const uint32_t ln = __lane_id(), leader = (uint32_t)__builtin_ctzll(m);

@@ -100,6 +100,7 @@ def main():
         t_gen = t_ing = 0.0
         i0 = 0
         st0 = agg.stats()
+        series, prev_ns = [], st0["batch_ns_total"]
         while i0 < n:
             m = min(args.chunk, n - i0)
             if prefix_sk is None and i0 >= args.prefix:
@@ -112,6 +113,10 @@ def main():
             agg.sync()
             t_gen += t1 - t0
             t_ing += time.perf_counter() - t1
+            if args.timing_only:  # (per launch: device-path time of this chunk - the sets fill up during the first launches)
+                ns = agg.stats()["batch_ns_total"]
+                series.append(round((ns - prev_ns) * 1e-6, 4))
+                prev_ns = ns
             wire += w
             i0 += m
         st1 = agg.stats()
@@ -130,6 +135,9 @@ def main():
         "records_direct_path": int(st1["records_direct"]), "flows_5m_rows": int(len(rows)),
     })
     out["distinct_set_keys_listed"] = int(st1.get("ks_listed", 0))
+    if series:
+        out["path_ms_series"] = series
+        out["path_ms_last_third_mean"] = float(np.mean(series[-max(len(series) // 3, 1):]))
     if args.timing_only:
         out["checks"] = "skipped (--timing-only)"
         print(json.dumps(out))
