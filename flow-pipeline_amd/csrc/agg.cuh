@@ -427,6 +427,10 @@ __device__ __forceinline__ void agg8_drain(const KArgs& a, Agg8Table& lt, uint32
 // of the kernel (1.85x the mean tuples, and its LDS adds queue up on ONE slot: 147 us against 100 us for twice the
 // tuples spread evenly).  So a wave looks for a key that holds an eighth of a row (agg8_find_heavy, until it has one) and
 // from then on adds that key's tuples of a row up first (two 32-bit wave sums): one pair of LDS adds per row.
+// (Round 4 tried the step before this kernel: the heavy group of a partition reported to the NEXT launches' ingest workgroups,
+// which pinned it in their LDS hot-key tables so that its records never became tuples.  Zipf-1.1 AS pairs: aggregation +
+// second-chance kernels 122 -> 108 us, the ingest kernel 311 -> 340 us - every tile pays the mask test and a key hash for the
+// mask's false positives.  profiles/r04_exp_bench_zipf_ks1_heavy{0,1}.json; dropped.)
 __device__ __forceinline__ unsigned long long agg8_find_heavy(unsigned long long key, bool valid) {
     unsigned long long rest = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll 1
@@ -535,8 +539,6 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
     __shared__ uint32_t pc[AGG_MAX_NWG + AGG_PAD], pcb[AGG_MAX_NWG + AGG_PAD];  // front / back counts of this partition's segments, zero padded
     __shared__ uint16_t flv[NFG], blv[NBG];  // levels each group of segments needs (so that a wave never walks empty levels)
     __shared__ uint2 queues[WAVES * 64];
-    __shared__ unsigned long long hv_best;
-    __shared__ uint32_t hv_total;
     const uint32_t part = blockIdx.x;
     const unsigned long long tk_start = FA_DBG(a, DBG_AGG8_TIMING) ? wall_clock64() : 0ull;
     for (int i = threadIdx.x; i < AGG8_ALL; i += AGG_BLOCK) {
@@ -609,41 +611,6 @@ __global__ __launch_bounds__(AGG_BLOCK) void agg8_kernel(KArgs a) {
 #undef FA_AGG8_PASS
     agg8_drain(a, lt, tb_base, part, lane, queue, qn);
     __syncthreads();
-    // The partition's heavy group, for the next launches' ingest workgroups (table.cuh, HeavyKey): the group that holds more
-    // than a quarter of the partition's tuples.  Written when there is one, never cleared here (a pinned group does not show up
-    // as tuples any more): the host forgets the whole list every 16 launches and the groups that still are heavy come back.
-    if (a.heavy && npass == 1u) {
-        if (threadIdx.x == 0) {
-            hv_best = 0ull;
-            hv_total = 0u;
-        }
-        __syncthreads();
-        uint32_t mysum = 0;
-        unsigned long long mybest = 0ull;
-        for (int i = threadIdx.x; i < AGG8_ALL; i += AGG_BLOCK) {
-            const unsigned long long cnt = lt.s2[i] & 0x1ffffffull;
-            if (lt.key[i] != 0ull && cnt != 0ull) {
-                mysum += (uint32_t)cnt;
-                mybest = max(mybest, (cnt << 32) | (unsigned long long)i);
-            }
-        }
-        mysum = wave_sum_u32(mysum);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mybest = max(mybest, (unsigned long long)__shfl_xor((long long)mybest, o));
-        if (lane == 0) {
-            if (mysum) atomicAdd(&hv_total, mysum);
-            if (mybest) atomicMax(&hv_best, mybest);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0 && (hv_best >> 32) * 4ull > (unsigned long long)hv_total) {
-            const unsigned long long key = lt.key[(uint32_t)hv_best];
-            TupleVals v;
-            t8_unpack(make_uint2((uint32_t)key, (uint32_t)(key >> 32) << 26), part, tb_base, v);
-            uint64_t k0, k1;
-            pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);
-            a.heavy[part] = HeavyKey{k0, k1};
-        }
-    }
     const unsigned long long tm1 = (FA_DBG(a, DBG_TIMING | DBG_AGG8_TIMING)) ? (FA_DBG(a, DBG_AGG8_TIMING) ? wall_clock64() : clock64()) : 0ull;
     if (FA_DBG(a, DBG_AGG_NO_FLUSH)) return;
     // every group of this partition goes to the device-wide table once (quad-grouped: one atomic line transaction per

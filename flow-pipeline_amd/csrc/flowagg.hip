@@ -71,13 +71,6 @@ struct fa_ctx {
     HotSeed* hot_seed = nullptr;   // [hot_seed_wgs][CMS_SETS][HOT_SLOTS] entries of the hot-address caches that survive a launch
     uint32_t* hot_seed_tag = nullptr;
     uint32_t hot_seed_wgs = 0, hot_epoch = 0;
-    HeavyKey* heavy = nullptr;     // [NPART_MAX] heavy (SrcAS,DstAS,EType) groups as agg8_kernel reports them (table.cuh); forgotten every 16 launches
-    bool heavy_on = true;          // env FA_HEAVY=0 (A/B)
-    uint4* ks_list = nullptr;      // the distinct sets' lists (sinks.cuh, keyset_defer): [CMS_SETS][nwg][capw]
-    size_t ks_list_bytes = 0;
-    uint32_t* ks_list_counts = nullptr;
-    size_t ks_list_counts_cap = 0;
-    bool ks_defer = true;          // env FA_KS_DEFER=0: the probing path stays inside the ingest kernel (A/B)
     uint32_t cms_par = 0;          // parity of the next cms_agg_kernel launch (its size copies and unit counters)
     uint32_t* cms_psize = nullptr;  // [2][CMS_SETS * CMS_NPART] tuples per sketch partition, last launch / this launch (cms_agg_kernel: heaviest first)
     // scatter sink of the (SrcAddr,DstPort,Proto) key set (wagg.cuh)
@@ -355,8 +348,6 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_STAGE_THREADS")) c->stage_threads = (unsigned)std::min(64, std::max(1, atoi(d)));
     c->stage_threads = std::min(c->stage_threads, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* d = getenv("FA_TUPLE")) c->t8_mode = !strcmp(d, "8") ? 1 : !strcmp(d, "16") ? 2 : 0;
-    if (const char* d = getenv("FA_KS_DEFER")) c->ks_defer = strcmp(d, "0") != 0;
-    if (const char* d = getenv("FA_HEAVY")) c->heavy_on = strcmp(d, "0") != 0;
     auto bail = [&](const char* what, hipError_t e) {
         g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
         fa_destroy(c);
@@ -388,8 +379,6 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if ((e = hipMemsetAsync(c->tab, 0, tab_bytes, c->stream)) != hipSuccess) return bail("memset", e);
     if ((e = hipMalloc(&c->spill, sizeof(SpillEntry) * c->spill_cap)) != hipSuccess)
         return bail("hipMalloc(spill)", e);
-    if ((e = hipMalloc(&c->heavy, sizeof(HeavyKey) * NPART_MAX)) != hipSuccess) return bail("hipMalloc(heavy groups)", e);
-    if ((e = hipMemsetAsync(c->heavy, 0, sizeof(HeavyKey) * NPART_MAX, c->stream)) != hipSuccess) return bail("memset", e);
     if ((e = hipMalloc(&c->d_ctr, sizeof(Counters))) != hipSuccess) return bail("hipMalloc(ctr)", e);
     if ((e = hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream)) != hipSuccess)
         return bail("memset", e);
@@ -517,9 +506,6 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->cseg);
     (void)hipFree(c->cseg_counts);
     (void)hipFree(c->cms_psize);
-    (void)hipFree(c->heavy);
-    (void)hipFree(c->ks_list);
-    (void)hipFree(c->ks_list_counts);
     (void)hipFree(c->hot_seed);
     (void)hipFree(c->hot_seed_tag);
     (void)hipFree(c->wseg);
@@ -758,7 +744,6 @@ static int settle(fa_ctx* c) {
     c->stats.records_retried = h.retried;
     c->stats.records_misfit_compact = h.misfit8;
     c->stats.records_late = h.late;
-    c->stats.ks_listed = h.ks_listed;
     c->stats.table_used = c->used_base + h.used;
     format_feedback(c, h);
     if (h.spill_lost) {
@@ -1050,8 +1035,6 @@ static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev 
     }
 #undef FA_LAUNCH
 #undef FA_LAUNCH_W
-    if (MODE == MODE_INGEST && wave_tiles && a.ks_list)  // the keys that were not in their home slots: probing path, a key per lane
-        hipLaunchKernelGGL(keyset_list_kernel, dim3(std::min<uint32_t>(CMS_SETS * a.nwg, 2048u), 16), dim3(256), 0, c->stream, a);
     if (MODE == MODE_INGEST && a.seg) {
         const dim3 ga((1u << a.plog2) * AGG_SPLIT);
         if (t8 && AGG_SPLIT == 1 && !c->agg_generic) hipLaunchKernelGGL(agg8_kernel, ga, dim3(AGG_BLOCK), 0, c->stream, a);
@@ -1210,36 +1193,6 @@ static int ensure_csegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     return FA_OK;
 }
 
-// Lists of the distinct-address sets for a batch of n records processed by nwg workgroups: per (set, workgroup) room for
-// half of the workgroup's records (about one key in seven of a steady stream leaves its home-slot look unsettled; a
-// workgroup whose part is full inserts on the spot).
-static int ensure_kslist(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
-    const uint32_t capw = (uint32_t)std::max<size_t>(64, (n / nwg / 2 + 15) & ~(size_t)15);
-    const size_t bytes = (size_t)CMS_SETS * nwg * capw * sizeof(uint4);
-    if (c->ks_list_bytes < bytes) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->ks_list);
-        c->ks_list = nullptr;
-        c->ks_list_bytes = 0;
-        if (hipMalloc(&c->ks_list, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(distinct-set lists) failed");
-        c->ks_list_bytes = bytes;
-    }
-    const size_t ncnt = (size_t)CMS_SETS * nwg;
-    if (c->ks_list_counts_cap < ncnt) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->ks_list_counts);
-        c->ks_list_counts = nullptr;
-        c->ks_list_counts_cap = 0;
-        if (hipMalloc(&c->ks_list_counts, ncnt * sizeof(uint32_t)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(distinct-set list counts) failed");
-        c->ks_list_counts_cap = ncnt;
-    }
-    a.ks_list = c->ks_list;
-    a.ks_list_counts = c->ks_list_counts;
-    a.ks_list_capw = capw;
-    a.nwg = nwg;
-    return FA_OK;
-}
-
 // Segments of the wide scatter sink for a batch of n records processed by nwg workgroups: per (table region, workgroup)
 // 2x the mean + 32 tuples of 32 bytes (what overflows - a heavy key's region - takes the atomic path).
 static int ensure_wsegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
@@ -1370,18 +1323,9 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     if (scatter) {
         rc = ensure_segments(c, n, (uint32_t)grid, c->use_t8, a);
         if (rc) return rc;
-        // heavy groups (table.cuh, HeavyKey): reported by agg8_kernel, pinned by the next launches' ingest workgroups
-        if (c->use_t8 && c->heavy_on && !c->agg_generic && c->plog2 == PART_LOG2_MAX) {
-            if (c->stats.batches % 16 == 0) HIPCHK(c, hipMemsetAsync(c->heavy, 0, sizeof(HeavyKey) * NPART_MAX, c->stream));
-            a.heavy = c->heavy;
-        }
     }
     if (c->use_wave_tiles && (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) && !c->cms_atomic && c->cms_scatter_ok) {
         rc = ensure_csegments(c, n, (uint32_t)grid, a);
-        if (rc) return rc;
-    }
-    if (c->use_wave_tiles && (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) && c->ks_defer) {
-        rc = ensure_kslist(c, n, (uint32_t)grid, a);
         if (rc) return rc;
     }
     if (c->use_wave_tiles && c->wtab && (c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO) && grid <= WAGG_MAX_NWG &&

@@ -32,7 +32,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                                           LaneTally& tally, uint32_t& pmode, uint32_t& lt_seen, uint32_t& lt_hits,
                                           uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook(),
                                           CmsLds* cl = nullptr, uint32_t* cms_scratch = nullptr, HotAddrs* hot = nullptr,
-                                          uint32_t* wpart_cnt = nullptr, uint32_t* ks_cnt = nullptr, unsigned long long pin_mask = 0ull) {
+                                          uint32_t* wpart_cnt = nullptr) {
     constexpr uint32_t TB = bin_cap<T8, bin_line(KEYSETS)>();
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false, framed_ok = false;
@@ -174,11 +174,6 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 if (lt_hits * FA_LT_KEEP < lt_seen) lt_seen = 0xffffffffu;
                 else lt_seen = lt_hits = 0;
             }
-        } else if (pin_mask != 0ull) {  // (wave-uniform) the table is off for this stream - but it holds the pinned heavy groups (table.cuh, HeavyKey)
-            const bool maybe = pending && ((pin_mask >> heavy_pin_bit(r.src_as, r.dst_as)) & 1ull) != 0ull;
-            if (FA_ANY(maybe)) {
-                if (maybe) pending = !lds_table_lookup_add<LDS_SLOTS, LDS_PROBES>(lt, k0, k1, key_hash(k0, k1), b, p, c);
-            }
         }
         // tuple path: one tuple to this workgroup's private segment of the key's partition
         uint32_t fill_part = 0xffffffffu;  // wave-tile kernel: the bin this lane has just filled
@@ -267,14 +262,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 if (vd) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, wd);
             }
         }
-        if (keys_on) {
-            if (ks_cnt && a.ks_list) {  // (wave-tile kernel: what is not at home goes to the list - sinks.cuh, keyset_defer)
-                keyset_defer(a, ks_cnt, 0u, vs && !keyset_at_home(ps, sh1, slo, shi), slo, shi, sh1, ps.c01.x);
-                keyset_defer(a, ks_cnt, 1u, vd && !keyset_at_home(pd, dh1, dlo, dhi), dlo, dhi, dh1, pd.c01.x);
-            } else {
-                keyset_finish2(a, vs, ps, sh1, slo, shi, vd, pd, dh1, dlo, dhi);
-            }
-        }
+        if (keys_on) keyset_finish2(a, vs, ps, sh1, slo, shi, vd, pd, dh1, dlo, dhi);
     }
     if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb, tb_base, wpart_cnt);
 }
@@ -605,9 +593,6 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
     __shared__ CmsLdsOpt<HAS_CMS> cms_lds;
     __shared__ HotAddrsOpt<HAS_CMS> hot_lds;
     __shared__ uint32_t cms_scratch_all[HAS_CMS ? WAVES * 16 : 1];
-    __shared__ uint32_t ks_cnt[2];  // keys this workgroup has put on the distinct sets' lists (keyset_defer)
-    __shared__ unsigned long long pin_mask_s;  // heavy_pin_bit of every pinned heavy group
-    __shared__ uint32_t pin_n;
     __shared__ __attribute__((aligned(16))) uint32_t tiles[WAVES * WT_STRIDE / 4];
     __shared__ __attribute__((aligned(16))) uint4 bins[NPART_MAX * BL];  // 256 x one store unit (sinks.cuh, bin_line)
     __shared__ uint32_t bin_cnt[NPART_MAX];
@@ -628,11 +613,6 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
         }
     }
     if (KEYSETS & FA_KEYS_MINUTE_SERIES) lds_minutes_clear(lm);
-    if (HAS_CMS && tid < 2) ks_cnt[tid] = 0;
-    if (tid == 0) {
-        pin_mask_s = 0ull;
-        pin_n = 0;
-    }
     if (HAS_APP)
         for (int i = tid; i < (1 << WIDE_PLOG2_MAX); i += WBLOCK) wpart_cnt[i] = 0;
     CmsLds* const cl = (HAS_CMS && a.cseg) ? cms_lds.get() : nullptr;
@@ -722,25 +702,6 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
     // (no probe dispatch, no cross-workgroup hand-over: the answer is identical all over the grid)
     tb_base = probe_tb_base(a);
     if (blockIdx.x == 0 && tid == 0) a.ctr->tb_base = tb_base;  // (for agg_kernel)
-    unsigned long long pin_mask = 0ull;
-    if ((KEYSETS & FA_KEYS_AS_PAIR) && T8 && a.heavy) {  // pin the heavy groups the previous launch's aggregation reported (table.cuh, HeavyKey)
-        if (tid < NPART_MAX) {
-            const HeavyKey hk = a.heavy[tid];
-            if (hk.k0 != 0ull && hk.k1 != 0ull && atomicAdd(&pin_n, 1u) < HEAVY_PIN_MAX) {
-                uint32_t tb, sa, da, et;
-                unpack_key(hk.k0, hk.k1, tb, sa, da, et);
-                bool in = false;
-                for (uint32_t d = 2; d < 4; d++) {  // (tb_base = the smallest sampled bucket - 2)
-                    uint64_t k0, k1;
-                    pack_key(tb_base + d, sa, da, et, k0, k1);
-                    in = lds_table_add<LDS_SLOTS, LDS_PROBES>(lt, k0, k1, key_hash(k0, k1), 0, 0, 0) || in;
-                }
-                if (in) atomicOr(&pin_mask_s, 1ull << heavy_pin_bit(sa, da));
-            }
-        }
-        __syncthreads();  // (the waves' first tiles are on their way meanwhile)
-        pin_mask = readlane_u64(pin_mask_s, 0);
-    }
     while (cur.nrec != 0) {
         dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
         const uint32_t cbase = cur_lo & ~15u;
@@ -763,7 +724,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
         uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
         lane_work<MODE_INGEST, KEYSETS, COLS, T8>(a, lt, lm, part_cnt, tile, staged, cur.q0 - cbase, cur.q1 - cbase, cur.r0 + lane, tb_base, tally,
                                                   pmode, lt_seen, lt_hits, bins, bin_cnt, fill, NoHook(), cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0), hot,
-                                                  (HAS_APP && a.wseg) ? wpart_cnt : nullptr, HAS_CMS ? ks_cnt : nullptr, pin_mask);
+                                                  (HAS_APP && a.wseg) ? wpart_cnt : nullptr);
         // (sketch variants, round 3: starting the next tile's DMA right behind the parse - the sink is long there and does
         // not look at the tile's bytes - measured +1.8 %, like the following for the lean variants)
         // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
@@ -852,13 +813,6 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
                 a.hot_seed_tag[at] = keep ? tg : 0u;
                 if (keep) a.hot_seed[at] = HotSeed{lo, hi};
             }
-        }
-    }
-    if (HAS_CMS && a.ks_list) {  // how many keys this workgroup left on each set's list
-        __syncthreads();
-        if (tid < 2) {
-            a.ks_list_counts[(size_t)tid * a.nwg + blockIdx.x] = min(ks_cnt[tid], a.ks_list_capw);
-            if (ks_cnt[tid]) atomicAdd(&a.ctr->ks_listed, (unsigned long long)min(ks_cnt[tid], a.ks_list_capw));
         }
     }
     if (HAS_CMS && cl) {  // what is left in the sketch bins (fewer than a chunk each) goes to the back part of the segments
@@ -963,28 +917,6 @@ __device__ __forceinline__ void exotic_pass(const KArgs& a) {
             keyset_insert(a, a.ks_dst, r.dst);
         }
         if (KEYSETS & FA_KEYS_WIDE) wide_sink_slow<KEYSETS>(a, r, tb);
-    }
-}
-
-// ---- the distinct sets' lists: keys the wave-tile kernel did not find in their home slot (sinks.cuh, keyset_defer) ---------
-// One workgroup per (set, ingest workgroup) part, a key per lane: the full probing / claiming path, every lane on its own
-// chain - thousands of them in flight instead of one per wave tile.
-// (grid: x = part, y = slices of a part - a part holds thousands of keys and a lane's keys are chains of round trips one
-// after the other: 16 slices keep a lane at one or two keys)
-__global__ __launch_bounds__(256) void keyset_list_kernel(KArgs a) {
-    for (uint32_t part = blockIdx.x; part < CMS_SETS * a.nwg; part += gridDim.x) {
-        const uint32_t set = part / a.nwg;
-        KeySlot* tab = set ? a.ks_dst : a.ks_src;
-        if (!tab) continue;
-        const uint32_t cnt = min(a.ks_list_counts[part], a.ks_list_capw);
-        const uint4* list = a.ks_list + (size_t)part * a.ks_list_capw;
-        for (uint32_t i = blockIdx.y * blockDim.x + threadIdx.x; i < cnt; i += gridDim.y * blockDim.x) {
-            const uint4 e = list[i];
-            const unsigned long long lo = (unsigned long long)e.y << 32 | e.x, hi = (unsigned long long)e.w << 32 | e.z;
-            uint64_t h1, h2;
-            cms_hash2(lo, hi, a.cms_seed, h1, h2);
-            keyset_insert_slow(a, tab, lo, hi, keyset_tag(h1), keyset_home(a, h1));
-        }
     }
 }
 

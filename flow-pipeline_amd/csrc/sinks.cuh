@@ -114,7 +114,6 @@ struct Counters {
     unsigned int wspill_count, wrows_count;
     unsigned long long agg_groups, agg_launches;  // agg8_kernel: groups it added to the device table, launches (pass-count feedback)
     unsigned long long late;  // records below KArgs::late_below (flows_5m windows that were closed before they arrived)
-    unsigned long long ks_listed;  // distinct-set keys that took the list (keyset_list_kernel) instead of probing inside the ingest kernel
 };
 
 // Distinct-address set behind fa_topk (the dashboards rank EVERY address,
@@ -196,12 +195,6 @@ struct KArgs {
     unsigned long long wregion;
     ulonglong2* port_hist;  // [2][PORT_DENSE] {sum(Bytes*SamplingRate), count()}: SrcPort, then DstPort
     uint32_t late_below;    // time buckets below it were closed (flows_5m): records that still arrive for them are counted
-    // distinct-address sets: keys that are not in their home slot (displaced by an older key, or new) leave the wave-tile
-    // kernel as 16-byte entries in the workgroup's private part of a list and are inserted by keyset_list_kernel behind it
-    HeavyKey* heavy;           // [NPART_MAX] the heavy group of every key partition as the previous launch's agg8_kernel saw it (table.cuh)
-    uint4* ks_list;            // [CMS_SETS][nwg][ks_list_capw] (nullptr: the probing path runs inside the ingest kernel)
-    uint32_t* ks_list_counts;  // [CMS_SETS][nwg]
-    uint32_t ks_list_capw;
 };
 
 __device__ __forceinline__ WArgs wargs(const KArgs& a) {
@@ -572,9 +565,7 @@ __device__ __forceinline__ bool keyset_step(const KArgs& a, KeySlot* tab, unsign
     }
     // (claimers of this wave have published by now; owners in other waves are a few instructions away)
     if ((t | KS_READY) == (mytag | KS_READY)) {
-        // (system-scope loads are served past the per-XCD L2s like the atomics, without queueing up behind each other on the
-        // one address as read-modify-writes do when many lanes wait for the same new key)
-        for (int spin = 0; spin < 4096 && !(t & KS_READY); spin++) t = __hip_atomic_load(&s->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int spin = 0; spin < 4096 && !(t & KS_READY); spin++) t = atomicOr(&s->tag, 0ull);
         if (t & KS_READY) {
             const unsigned long long l = atomicAdd(&s->lo, 0ull), q = atomicAdd(&s->hi, 0ull);  // memory-side reads
             return l == lo && q == hi;
@@ -596,6 +587,10 @@ __device__ __forceinline__ void keyset_finish(const KArgs& a, KeySlot* tab, cons
     if (keyset_at_home(p, h1, lo, hi)) return;
     keyset_insert_slow(a, tab, lo, hi, keyset_tag(h1), keyset_home(a, h1));
 }
+// (Round 4 measured the probing path OUT of the ingest kernel: keys not found in their home slot appended to per-workgroup
+// lists and inserted by a kernel behind it, a key per lane.  While the sets fill up the ingest kernel gained a third (994 vs
+// 1455 us) and the list kernel cost 863 us; in the steady state of the 1 B-record stream both forms take 1.16 ms per launch
+// and the lists add launches of 1.63 ms.  profiles/r04_exp_config3_400M_defer{0,1}.json; the lists are gone.)
 // Both addresses of a record (the ingest kernel's form): ONE probing loop for what is left of the two sets.  A wave almost
 // always has a lane whose key is not in its home slot (12 % of the keys at a quarter load), every step of the probing
 // path is a round trip to memory with the whole wave waiting, and two loops in a row - source set, then destination set
@@ -636,43 +631,6 @@ __device__ __forceinline__ void keyset_finish2(const KArgs& a, bool vs, const Ks
                 }
             }
         }
-    }
-}
-// The probing path OUT of the ingest kernel.  What is left of a tile's keys after the home-slot look (12 % of the known
-// keys sit elsewhere at a quarter load; every new key) used to walk the set right there - a chain of round trips to memory
-// with the whole wave waiting, once per tile (round 3: 166 us of a 760 us launch re-ingesting, more when streaming).  Now
-// such a key is appended to the workgroup's private part of a list (position from an LDS counter: no global atomic, no
-// round trip) and keyset_list_kernel inserts the lists behind the ingest kernel, one key per lane, thousands of
-// independent probe chains in flight.  A full list part: the key is inserted on the spot (exact either way).
-// A key whose home slot the plain view shows EMPTY is claimed right here (one returning CAS, the key published behind it):
-// the first occurrence of a new key inserts it and every later one finds it at home - put on the list instead, a new heavy
-// key would be listed once per occurrence of the launch and the list kernel's lanes would fight over its slot (first cut:
-// 863 us of keyset_list_kernel per launch while the sets fill up).  What goes to the list is a key whose home slot holds
-// ANOTHER key (or that lost the claim).
-__device__ __forceinline__ void keyset_defer(const KArgs& a, uint32_t* ks_cnt, uint32_t set, bool need, unsigned long long lo, unsigned long long hi, uint64_t h1,
-                                             unsigned long long home_tag) {
-    if (__builtin_amdgcn_ballot_w64(need && home_tag == 0ull) != 0ull) {
-        if (need && home_tag == 0ull) {
-            KeySlot* s = &(set ? a.ks_dst : a.ks_src)[keyset_home(a, h1)];
-            if (atomicCAS(&s->tag, 0ull, keyset_tag(h1)) == 0ull) {  // claimed: publish the key, then mark it readable
-                const unsigned long long o1 = atomicExch(&s->lo, lo), o2 = atomicExch(&s->hi, hi);
-                if ((o1 & o2) != ~0ull) atomicOr(&s->tag, KS_READY);  // (always true: orders the OR behind both writes)
-                need = false;
-            }
-        }
-    }
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
-    if (m == 0ull) return;
-    const uint32_t ln = __lane_id(), leader = (uint32_t)__builtin_ctzll(m);
-    uint32_t base = 0;
-    if (ln == leader) base = lds_add_rtn_u32(&ks_cnt[set], (uint32_t)__builtin_popcountll(m));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
-    const uint32_t pos = base + (uint32_t)__builtin_popcountll(m & ((1ull << ln) - 1ull));
-    if (!need) return;
-    if (pos < a.ks_list_capw) {
-        a.ks_list[((size_t)set * a.nwg + blockIdx.x) * a.ks_list_capw + pos] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-    } else {
-        keyset_insert_slow(a, set ? a.ks_dst : a.ks_src, lo, hi, keyset_tag(h1), keyset_home(a, h1));
     }
 }
 __device__ __forceinline__ void keyset_insert(const KArgs& a, KeySlot* tab, const uint32_t key[4]) {

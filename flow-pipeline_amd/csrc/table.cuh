@@ -226,35 +226,6 @@ __device__ __forceinline__ bool lds_table_add(LdsTable<SLOTS>& t, uint64_t k0, u
 }
 
 
-// Lookup-only form (pinned heavy keys, ingest.cuh): adds to the key's slot when the table holds it, never claims one.
-template <int SLOTS, int PROBES>
-__device__ __forceinline__ bool lds_table_lookup_add(LdsTable<SLOTS>& t, uint64_t k0, uint64_t k1, uint32_t h, uint64_t bytes, uint64_t packets, uint64_t count) {
-    uint32_t i = (h >> 8) & (SLOTS - 1);
-#pragma unroll 1
-    for (int probe = 0; probe < PROBES; probe++, i = (i + 1) & (SLOTS - 1)) {
-        const unsigned long long c0 = t.k0[i];
-        if (c0 == 0) return false;
-        if (c0 != k0 || t.k1[i] != k1) continue;
-        if (bytes) lds_add_u64(&t.bytes[i], (unsigned long long)bytes);
-        if (packets) lds_add_u64(&t.packets[i], (unsigned long long)packets);
-        lds_add_u64(&t.count[i], (unsigned long long)count);
-        return true;
-    }
-    return false;
-}
-// Heavy (SrcAS, DstAS) groups.  A skewed stream (Zipf-1.1 addresses: the top AS pair is 0.6 % of the records) sends half of
-// one partition's tuples to ONE group: that partition's aggregation workgroup is the last of its kernel (1.85x the mean) and
-// the launch waits for it.  agg8_kernel therefore reports, per partition, the group that held more than a quarter of the
-// partition's tuples (HeavyKey, 0 = none); the NEXT launch's ingest workgroups pin those keys in their LDS hot-key tables
-// and absorb their records there - they never become tuples.  A 64-bit mask over a cheap function of the AS pair keeps
-// the lookup away from the records of every other group.  What is heavy is (SrcAS, DstAS, EType), whatever the window: a
-// reported key is pinned for the two time buckets the launch's samples say it sits in (a launch rarely spans more).
-struct HeavyKey {
-    unsigned long long k0, k1;
-};
-constexpr uint32_t HEAVY_PIN_MAX = 24;  // heavy groups pinned per workgroup (x 2 buckets; the hot-key table has 64 slots)
-__host__ __device__ __forceinline__ uint32_t heavy_pin_bit(uint32_t src_as, uint32_t dst_as) { return (src_as * 5u + dst_as) & 63u; }
-
 // ---- wavefront helpers -------------------------------------------------------
 // 64-lane sum of a u64 with DPP row shifts inside each 16-lane row and scalar
 // readlane across the four rows (wave64; no LDS traffic).

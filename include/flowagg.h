@@ -178,8 +178,6 @@ typedef struct {
     uint64_t wide_log_watermark_moves; /* times a close moved a pending chunk's watermark instead of folding it */
     uint64_t wide_log_nomem_folds;   /* chunks folded early because another pair of segment buffers could not be allocated */
     uint64_t wide_log_mode;          /* 1: the next launch keeps its (SrcAddr,DstPort,Proto) tuples in the log */
-    uint64_t ks_listed;              /* distinct-address-set keys that were not found in their home slot by the ingest kernel and
-                                        were inserted from the lists behind it (keyset_list_kernel) */
 } fa_stats_t;
 
 typedef struct {

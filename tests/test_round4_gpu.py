@@ -327,22 +327,3 @@ def test_drop_range_closes_a_tumbling_window_over_sub_buckets(gpu_lib, fa, po, m
         with pytest.raises(fa.FlowAggError):
             agg.drop_range(fa.ROWS_APP, t0 + 7, t0 + 300)
         assert agg.stats()["records_late"] == 0
-
-
-@pytest.mark.parametrize("heavy", ["", "0"])
-def test_pinned_heavy_groups_change_nothing_but_speed(gpu_lib, fa, po, monkeypatch, heavy):
-    """Zipf-1.1 AS pairs: agg8_kernel reports the group that fills a quarter of its partition, the following launches' ingest
-    workgroups pin it in their LDS hot-key tables (two time buckets), the list is forgotten every 16 launches - 20 launches
-    across three windows: rows == the oracle's, with the mechanism on and off (FA_HEAVY=0)."""
-    if heavy:
-        monkeypatch.setenv("FA_HEAVY", heavy)
-    n, step = 2_000_000, 100_000
-    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=491, n_total=n, span_secs=900, zipf_log2_universe=16, zipf_s_x100=110)
-    buf, off = po.gen_records(gp, 0, n)
-    ref = po.Rollup(300)
-    assert ref.ingest(buf, off, 1) == 0
-    with fa.FlowAgg(framed=True, max_batch_records=step) as agg:
-        _ingest(agg, buf, off, n, step, sync=False)
-        assert agg.read_window().tobytes() == ref.rows().tobytes()
-        st = agg.stats()
-        assert st["records_ok"] == n and st["compact_tuple_launches"] == n // step

@@ -134,7 +134,6 @@ def main():
         "ingest_wall_s_with_sync_per_chunk": t_ing, "generator_wall_s": t_gen,
         "records_direct_path": int(st1["records_direct"]), "flows_5m_rows": int(len(rows)),
     })
-    out["distinct_set_keys_listed"] = int(st1.get("ks_listed", 0))
     if series:
         out["path_ms_series"] = series
         out["path_ms_last_third_mean"] = float(np.mean(series[-max(len(series) // 3, 1):]))
