@@ -166,6 +166,10 @@ struct fa_ctx {
     size_t m_scratch_cap = 0;
     void* m_out[2] = {nullptr, nullptr};  // merged rows; rows in emit order
     size_t m_out_cap[2] = {0, 0};
+    void* fs_scratch = nullptr;      // device-side framing (framing.cuh): block starts (two copies), counts, bases, error flags, counters
+    size_t fs_scratch_cap = 0;
+    void* fs_off = nullptr;          // ... the offsets it produces
+    size_t fs_off_cap = 0;
     void* wl_scratch = nullptr;      // window reads of log chunks: per-segment counts, their scan, hipcub storage
     size_t wl_scratch_cap = 0;
     void* part_buf = nullptr;        // fa_rows_partition_device: the rows grouped by destination rank
@@ -527,6 +531,8 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->m_scratch);
     (void)hipFree(c->m_out[0]);
     (void)hipFree(c->m_out[1]);
+    (void)hipFree(c->fs_scratch);
+    (void)hipFree(c->fs_off);
     (void)hipFree(c->wl_scratch);
     (void)hipFree(c->part_buf);
     (void)hipFree(c->part_cnt);
@@ -1253,21 +1259,119 @@ static int ensure_wsegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
     return FA_OK;
 }
 
+static int ensure_dev(fa_ctx* c, void** p, size_t* cap, size_t bytes, const char* what);
+static int frame_split_host(const uint8_t* buf, size_t len, std::vector<uint64_t>& off);
+// Device-side framing (framing.cuh): d_buf[0, len) is a chain of varint(len)-framed records -> *d_off = n + 1 offsets in HBM
+// (owned by the ctx, valid until the next split), *n_out = records.  FA_ERR_FRAMING when it is not such a chain.
+static int frame_split_device(fa_ctx* c, const uint8_t* d_buf, size_t len, const uint32_t** d_off, size_t* n_out) {
+    *d_off = nullptr;
+    *n_out = 0;
+    if (len == 0) return FA_OK;
+    const uint32_t nb = (uint32_t)((len + FS_BLOCK - 1) / FS_BLOCK);
+    size_t tmp_scan = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)nb, c->stream);
+    const size_t arr = ((size_t)nb * 4 + 255) & ~(size_t)255;
+    int rc = ensure_dev(c, &c->fs_scratch, &c->fs_scratch_cap, 5 * arr + tmp_scan + 512, "framing scratch");
+    if (rc) return rc;
+    uint8_t* base = (uint8_t*)c->fs_scratch;
+    uint32_t* start = (uint32_t*)base;
+    uint32_t* next = (uint32_t*)(base + arr);
+    uint32_t* cnt = (uint32_t*)(base + 2 * arr);
+    uint32_t* bases = (uint32_t*)(base + 3 * arr);
+    uint8_t* err = base + 4 * arr;
+    unsigned int* flag = (unsigned int*)(base + 5 * arr);
+    void* tmp = base + 5 * arr + 256;
+    HIPCHK(c, hipMemsetAsync(start, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(fs_guess_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, d_buf, (uint32_t)len, nb, start);
+    HIPCHK(c, hipGetLastError());
+    bool settled = false;
+    for (int round = 0; round < FS_MAX_ROUNDS && !settled; round++) {
+        HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(unsigned int), c->stream));
+        hipLaunchKernelGGL(fs_walk_kernel, dim3((nb + 255) / 256), dim3(256), 0, c->stream, d_buf, (uint32_t)len, nb, (const uint32_t*)start, next, cnt, err, flag);
+        HIPCHK(c, hipGetLastError());
+        unsigned int changed = 0;
+        HIPCHK(c, hipMemcpyAsync(&changed, flag, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::swap(start, next);
+        settled = changed == 0;
+    }
+    std::vector<uint32_t> h_off;
+    if (settled) {
+        HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(unsigned int), c->stream));
+        hipLaunchKernelGGL(fs_err_kernel, dim3(64), dim3(256), 0, c->stream, (const uint8_t*)err, nb, flag);
+        size_t tb = tmp_scan;
+        if (hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, bases, (int)nb, c->stream) != hipSuccess) return fail(c, FA_ERR_HIP, "scan failed");
+        unsigned int bad = 0;
+        uint32_t last[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(&bad, flag, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&last[0], bases + (nb - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&last[1], cnt + (nb - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (bad) return fail(c, FA_ERR_FRAMING, "stream is not a chain of varint-framed records");
+        const size_t n = (size_t)last[0] + last[1];
+        rc = ensure_dev(c, &c->fs_off, &c->fs_off_cap, (n + 1) * sizeof(uint32_t), "frame offsets");
+        if (rc) return rc;
+        hipLaunchKernelGGL(fs_emit_kernel, dim3((nb + 255) / 256), dim3(256), 0, c->stream, d_buf, (uint32_t)len, nb, (const uint32_t*)start, (const uint32_t*)bases,
+                           (uint32_t*)c->fs_off, (uint32_t)n);
+        HIPCHK(c, hipGetLastError());
+        *d_off = (const uint32_t*)c->fs_off;
+        *n_out = n;
+        return FA_OK;
+    }
+    // the guesses did not settle (records longer than several blocks, adversarial bytes): the host walks the stream
+    std::vector<uint8_t> h(len);
+    HIPCHK(c, hipMemcpy(h.data(), d_buf, len, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> off64;
+    rc = frame_split_host(h.data(), len, off64);
+    if (rc) return fail(c, rc, "stream is not a chain of varint-framed records");
+    h_off.assign(off64.begin(), off64.end());
+    rc = ensure_dev(c, &c->fs_off, &c->fs_off_cap, h_off.size() * sizeof(uint32_t), "frame offsets");
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(c->fs_off, h_off.data(), h_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    *d_off = (const uint32_t*)c->fs_off;
+    *n_out = h_off.size() - 1;
+    return FA_OK;
+}
+
+// One call's records -> launches.  len = bytes of the whole buffer the offsets point into (the bound the kernels clamp
+// to); bytes = wire bytes of THESE n records (exact or estimated: tile sizing and the bytes_in statistic).
+static int ingest_device_records(fa_ctx* c, const void* d_buf, size_t len, size_t bytes, const void* d_off, size_t n);
+
 extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const void* d_off, size_t n) {
     FA_ON_DEVICE(c);
     if (!c) return FA_ERR_ARG;
     if (c->sticky) return c->sticky;
+    if (!d_off) {  // offsets == NULL: the stream is split on the device (framing.cuh); n is ignored
+        if (!c->cfg.framed) return fail(c, FA_ERR_ARG, "fa_ingest_device: offsets are required for bare (unframed) records");
+        if (len == 0) return FA_OK;
+        if (!d_buf || len >= (1ull << 32) || ((uintptr_t)d_buf & 15)) return fail(c, FA_ERR_ARG, "fa_ingest_device: bad buffer (16-byte aligned, < 4 GiB)");
+        const uint32_t* off = nullptr;
+        size_t total = 0;
+        int rc = frame_split_device(c, (const uint8_t*)d_buf, len, &off, &total);
+        if (rc) return rc;
+        for (size_t i = 0; i < total;) {
+            const size_t m = std::min<size_t>(c->cfg.max_batch_records, total - i);
+            rc = ingest_device_records(c, d_buf, len, (size_t)((double)len * (double)m / (double)total), off + i, m);
+            if (rc) return rc;
+            i += m;
+        }
+        return FA_OK;
+    }
     if (n == 0) return FA_OK;
-    if (!d_buf || !d_off || len >= (1ull << 32) || n > c->cfg.max_batch_records ||
-        ((uintptr_t)d_buf & 15) || ((uintptr_t)d_off & 3))
+    if (!d_buf || len >= (1ull << 32) || n > c->cfg.max_batch_records || ((uintptr_t)d_buf & 15) || ((uintptr_t)d_off & 3))
         return fail(c, FA_ERR_ARG, "fa_ingest_device: bad buffer (16-byte aligned, < 4 GiB, n <= max_batch_records)");
+    return ingest_device_records(c, d_buf, len, len, d_off, n);
+}
+
+static int ingest_device_records(fa_ctx* c, const void* d_buf, size_t len, size_t bytes, const void* d_off, size_t n) {
+    if (n == 0) return FA_OK;
     if (c->wide_per_record) {
         // a launch may not be able to park more wide-table updates than the spill buffer holds: split it
         const size_t lim = (c->wspill_cap - (1u << 20)) / c->wide_per_record;
         if (n > lim) {
             for (size_t i = 0; i < n; i += lim) {
                 const size_t m = std::min(lim, n - i);
-                int rc1 = fa_ingest_device(c, d_buf, (size_t)((double)len * (double)m / (double)n), (const uint32_t*)d_off + i, m);
+                int rc1 = ingest_device_records(c, d_buf, len, (size_t)((double)bytes * (double)m / (double)n), (const uint32_t*)d_off + i, m);
                 if (rc1) return rc1;
             }
             return FA_OK;
@@ -1281,9 +1385,9 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     c->use_t8 = c->use_wave_tiles && c->plog2 == 8 && c->t8_mode != 2 && (c->t8_mode == 1 || c->stats.batches >= c->t8_wide_until);
     if (n > AGG_MAX_BATCH && !c->use_t8) {  // the packed LDS sums of the wide-tuple aggregation hold 2^24 records per launch
         const size_t h = n / 2;
-        int rc1 = fa_ingest_device(c, d_buf, len / 2, d_off, h);
+        int rc1 = ingest_device_records(c, d_buf, len, bytes / 2, d_off, h);
         if (rc1) return rc1;
-        return fa_ingest_device(c, d_buf, len - len / 2, (const uint32_t*)d_off + h, n - h);
+        return ingest_device_records(c, d_buf, len, bytes - bytes / 2, (const uint32_t*)d_off + h, n - h);
     }
     int rc = pre_launch_guard(c, n);
     if (rc) return rc;
@@ -1294,10 +1398,10 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     a.off = (const uint32_t*)d_off;
     a.n = (uint32_t)n;
     a.len = (uint32_t)len;
-    a.tile_recs = tile_recs_for(len, n);
+    a.tile_recs = tile_recs_for(bytes, n);
     int grid = tile_grid<MODE_INGEST>(c, a.n, a.tile_recs);
     if (c->use_wave_tiles) {  // wave-private tiles: <= 64 records per wave, WBLOCK / 64 waves per workgroup, WT_WG_PER_CU workgroups per CU
-        const double avg = (double)len / (double)n;
+        const double avg = (double)bytes / (double)n;
         // Tiles are sized by RECORDS: 64 (one per lane) whenever the mean record allows, otherwise as many as fit the
         // buffer with about two sigma of byte headroom (sigma of a tile ~ 12 B x sqrt(records): a mix of 60- and 84-byte
         // records).  A tile whose bytes still exceed the buffer is not lost to the slow path any more: the wave takes
@@ -1366,7 +1470,7 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
     }
     rc = post_launch_snapshot(c, n);
     if (rc) return rc;
-    c->stats.bytes_in += len;
+    c->stats.bytes_in += bytes;
     c->stats.batches += 1;
     if (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
         c->cms_dirty = true;
@@ -1476,6 +1580,19 @@ extern "C" int fa_ingest(fa_ctx* c, const uint8_t* buf, size_t len, const uint64
     if (c->sticky) return c->sticky;
     if (!buf && len) return fail(c, FA_ERR_ARG, "fa_ingest: null buffer");
     std::vector<uint64_t> split;
+    if (!offsets && c->cfg.framed && len && len <= (1ull << 30)) {
+        // a framed stream without offsets: the bytes are uploaded as they are and cut into records on the device (framing.cuh);
+        // the host walk below - 1 GB/s - only serves streams beyond one staging buffer
+        const uint64_t whole[2] = {0, len};
+        const uint8_t* d_buf;
+        const uint32_t* d_off;
+        int slot = 0;
+        int rc = stage_and_upload(c, buf, len, whole, 1, &d_buf, &d_off, &slot);
+        if (rc) return rc;
+        rc = fa_ingest_device(c, d_buf, len, nullptr, 0);
+        HIPCHK(c, hipEventRecord(c->stage_ev[slot], c->stream));
+        return rc;
+    }
     if (!offsets) {
         if (!c->cfg.framed) return fail(c, FA_ERR_ARG, "fa_ingest: offsets are required for bare (unframed) records");
         int rc = frame_split_host(buf, len, split);

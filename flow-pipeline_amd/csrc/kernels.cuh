@@ -26,3 +26,4 @@
 #include "wagg.cuh"
 #include "maintenance.cuh"
 #include "merge.cuh"
+#include "framing.cuh"

@@ -201,7 +201,12 @@ int fa_ingest(fa_ctx*, const uint8_t* buf, size_t len, const uint64_t* offsets, 
 /* Device-resident buffers (inputs already in HBM).  d_buf: DEVICE pointer to
  * len bytes, 16-byte aligned, followed by >= 32 readable slack bytes; d_offsets: DEVICE pointer to
  * n+1 uint32 offsets relative to d_buf (so len < 4 GiB per call).  Asynchronous
- * on the ctx stream; fa_sync() or any result call waits. */
+ * on the ctx stream; fa_sync() or any result call waits.
+ * ABI 6: d_offsets may be NULL when cfg.framed - the chain of varint(len)-framed records is then cut into records ON THE
+ * DEVICE (block starts guessed by 64 walks per 16 KiB block, proven by a fixed-point pass, offsets emitted; n is ignored,
+ * the call may become several launches).  FA_ERR_FRAMING when the bytes are not such a chain ending at len.  Three extra
+ * passes over the bytes: about a third of the rate of a call WITH offsets (which a Kafka consumer has for free: one
+ * message = one record) - the path for framed dumps.  fa_ingest (host buffers, offsets == NULL, len <= 1 GiB) uses it too. */
 int fa_ingest_device(fa_ctx*, const void* d_buf, size_t len, const void* d_offsets, size_t n);
 
 int fa_sync(fa_ctx*);

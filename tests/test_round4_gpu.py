@@ -327,3 +327,94 @@ def test_drop_range_closes_a_tumbling_window_over_sub_buckets(gpu_lib, fa, po, m
         with pytest.raises(fa.FlowAggError):
             agg.drop_range(fa.ROWS_APP, t0 + 7, t0 + 300)
         assert agg.stats()["records_late"] == 0
+
+
+def _varint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_device_side_framing_equals_the_offsets_path(gpu_lib, fa, po, mode):
+    """offsets == NULL on the device path: the framed chain is cut into records on the GPU (framing.cuh) - the rows, every
+    counter and every other key set's result equal the call with offsets; several launches per call (max_batch_records)."""
+    import torch
+    n = 700_000
+    gp = po.gen_params(mode=mode, framed=1, seed=501, n_total=n, span_secs=900, zipf_log2_universe=14)
+    buf, off = po.gen_records(gp, 0, n)
+    ref = po.Rollup(300)
+    assert ref.ingest(buf, off, 1) == 0
+    d = torch.zeros(len(buf) + 64, dtype=torch.uint8, device="cuda")
+    d[:len(buf)] = torch.from_numpy(np.ascontiguousarray(buf))
+    torch.cuda.synchronize()
+    with fa.FlowAgg(framed=True, key_sets=9, max_batch_records=250_000) as agg, fa.FlowAgg(framed=True, key_sets=9, max_batch_records=250_000) as want:
+        agg.ingest_device(d.data_ptr(), len(buf), 0, 0)
+        want.ingest(buf, off)
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+        assert agg.read_window_app().tobytes() == want.read_window_app().tobytes()
+        st, sw = agg.stats(), want.stats()
+        assert st["records_ok"] == n and st["records_bad"] == 0 and st["bytes_in"] == sw["bytes_in"] == len(buf) and st["batches"] == 3
+    # the host entry point without offsets takes the same road (bytes uploaded as they are, cut on the device)
+    with fa.FlowAgg(framed=True) as agg:
+        agg.ingest(buf)
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+    with fa.FlowAgg(framed=False) as agg, pytest.raises(fa.FlowAggError):
+        agg.ingest_device(d.data_ptr(), len(buf), 0, 0)  # bare records need offsets
+
+
+def test_device_side_framing_refuses_what_is_not_a_chain_and_survives_odd_ones(gpu_lib, fa, po):
+    import torch
+    n = 120_000
+    gp = po.gen_params(mode=1, framed=1, seed=511, n_total=n, span_secs=900)
+    buf, off = po.gen_records(gp, 0, n)
+    raw = bytes(buf)
+
+    def run(stream, **kw):
+        d = torch.zeros(len(stream) + 64, dtype=torch.uint8, device="cuda")
+        if len(stream):
+            d[:len(stream)] = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy())
+        torch.cuda.synchronize()
+        with fa.FlowAgg(framed=True, **kw) as agg:
+            agg.ingest_device(d.data_ptr(), len(stream), 0, 0)
+            return agg.read_window(), agg.stats()
+
+    def host(stream):  # the host walk + the offsets path: what the device split has to equal
+        o = [0]
+        p = 0
+        while p < len(stream):
+            v = s = 0
+            while True:
+                b = stream[p]
+                p += 1
+                v |= (b & 0x7F) << s
+                s += 7
+                if not b & 0x80:
+                    break
+            p += v
+            o.append(p)
+        assert p == len(stream)
+        with fa.FlowAgg(framed=True) as agg:
+            agg.ingest(stream, np.array(o, dtype=np.uint64))
+            return agg.read_window(), agg.stats()
+
+    # 1. a stream whose last frame is cut short / whose first length runs past the end: FA_ERR_FRAMING, nothing ingested
+    for broken in (raw[:-1], _varint(len(raw) + 5) + raw, raw + b"\xff\xff\xff\xff\xff\xff\xff\xff\xff\xff\xff"):
+        with pytest.raises(fa.FlowAggError) as ei:
+            run(broken)
+        assert ei.value.code == -7
+    # 2. odd but valid chains equal the host walk: empty frames, a record of 40 KB (three blocks: settles by rounds), one of
+    #    300 KB (19 blocks: more rounds than the device takes - the host walks), single-record and empty streams
+    junk40 = _varint(40_000) + bytes(40_000)
+    junk300 = _varint(300_000) + bytes([0x08, 0x01] * 150_000)
+    for stream in (raw[:int(off[1000])] + b"\x00" * 5000 + raw[int(off[1000]):int(off[5000])],
+                   raw[:int(off[70000])] + junk40 + raw[int(off[70000]):],
+                   raw[:int(off[300])] + junk300 + raw[int(off[300]):int(off[90000])],
+                   raw[:int(off[1])], b""):
+        got, st = run(stream)
+        want, sw = host(stream)
+        assert got.tobytes() == want.tobytes()
+        assert (st["records_ok"], st["records_bad"], st["bytes_in"]) == (sw["records_ok"], sw["records_bad"], sw["bytes_in"])
