@@ -1349,10 +1349,13 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
         size_t total = 0;
         int rc = frame_split_device(c, (const uint8_t*)d_buf, len, &off, &total);
         if (rc) return rc;
+        size_t used = 0;
         for (size_t i = 0; i < total;) {
             const size_t m = std::min<size_t>(c->cfg.max_batch_records, total - i);
-            rc = ingest_device_records(c, d_buf, len, (size_t)((double)len * (double)m / (double)total), off + i, m);
+            const size_t bytes = i + m == total ? len - used : (size_t)((double)len * (double)m / (double)total);  // (an estimate per launch; exact in sum)
+            rc = ingest_device_records(c, d_buf, len, bytes, off + i, m);
             if (rc) return rc;
+            used += bytes;
             i += m;
         }
         return FA_OK;
