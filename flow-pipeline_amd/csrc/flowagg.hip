@@ -1271,30 +1271,35 @@ static int frame_split_device(fa_ctx* c, const uint8_t* d_buf, size_t len, const
     size_t tmp_scan = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)nb, c->stream);
     const size_t arr = ((size_t)nb * 4 + 255) & ~(size_t)255;
-    int rc = ensure_dev(c, &c->fs_scratch, &c->fs_scratch_cap, 5 * arr + tmp_scan + 512, "framing scratch");
+    int rc = ensure_dev(c, &c->fs_scratch, &c->fs_scratch_cap, 7 * arr + tmp_scan + 512, "framing scratch");
     if (rc) return rc;
     uint8_t* base = (uint8_t*)c->fs_scratch;
     uint32_t* start = (uint32_t*)base;
-    uint32_t* next = (uint32_t*)(base + arr);
+    uint32_t* exits = (uint32_t*)(base + arr);
     uint32_t* cnt = (uint32_t*)(base + 2 * arr);
     uint32_t* bases = (uint32_t*)(base + 3 * arr);
-    uint8_t* err = base + 4 * arr;
-    unsigned int* flag = (unsigned int*)(base + 5 * arr);
-    void* tmp = base + 5 * arr + 256;
+    uint8_t* err = base + 4 * arr;             // (nb bytes)
+    uint8_t* trust[2] = {base + 5 * arr, base + 6 * arr};  // (nb bytes each)
+    unsigned int* flag = (unsigned int*)(base + 7 * arr);
+    void* tmp = base + 7 * arr + 256;
+    const dim3 gl((nb + 255) / 256), bl(256);
     HIPCHK(c, hipMemsetAsync(start, 0, sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(fs_guess_kernel, dim3((nb + 3) / 4), dim3(256), 0, c->stream, d_buf, (uint32_t)len, nb, start);
+    hipLaunchKernelGGL(fs_guess_kernel, dim3((nb + 3) / 4), bl, 0, c->stream, d_buf, (uint32_t)len, nb, start);
     HIPCHK(c, hipGetLastError());
     bool settled = false;
-    for (int round = 0; round < FS_MAX_ROUNDS && !settled; round++) {
+    int rounds = 0;
+    for (int round = 0; round < FS_MAX_ROUNDS && !settled; round++, rounds++) {
+        const uint8_t* tin = round ? trust[(round - 1) & 1] : nullptr;
+        if (round) hipLaunchKernelGGL(fs_apply_kernel, gl, bl, 0, c->stream, nb, start, (const uint32_t*)exits, tin);
         HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(unsigned int), c->stream));
-        hipLaunchKernelGGL(fs_walk_kernel, dim3((nb + 255) / 256), dim3(256), 0, c->stream, d_buf, (uint32_t)len, nb, (const uint32_t*)start, next, cnt, err, flag);
+        hipLaunchKernelGGL(fs_walk_kernel, gl, bl, 0, c->stream, d_buf, (uint32_t)len, nb, start, cnt, err, tin, trust[round & 1], exits, flag);
         HIPCHK(c, hipGetLastError());
-        unsigned int changed = 0;
-        HIPCHK(c, hipMemcpyAsync(&changed, flag, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        unsigned int differ = 0;
+        HIPCHK(c, hipMemcpyAsync(&differ, flag, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        std::swap(start, next);
-        settled = changed == 0;
+        settled = differ == 0;
     }
+    if (getenv("FA_VERBOSE")) fprintf(stderr, "[flowagg framing] %zu bytes, %u blocks: %s after %d round(s)\n", len, nb, settled ? "settled" : "NOT settled (host walk)", rounds);
     std::vector<uint32_t> h_off;
     if (settled) {
         HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(unsigned int), c->stream));
