@@ -61,6 +61,36 @@ __global__ __launch_bounds__(256) void extract_kernel(const Slot* tab, uint32_t 
     }
 }
 
+// ---- which time buckets does the table hold?  (fa_open_timeslots: a consumer asks before every flush) -----------------
+// Pass 1 (bits == nullptr): range[0] = min, range[1] = max bucket of the live groups.  Pass 2: bit (tb - lo) of `bits`.
+// Two scans of the table and a few hundred bytes to the host, instead of every row copied out and sorted there.
+__global__ __launch_bounds__(256) void timeslots_kernel(const Slot* tab, uint32_t nslots, uint32_t lo, uint32_t nbits, unsigned int* bits, unsigned int* range) {
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) {
+        const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(&tab[i].k0);
+        if (k.x == 0 || k.y == 0 || tab[i].count == 0) continue;
+        uint32_t tb, sa, da, et;
+        unpack_key(k.x, k.y, tb, sa, da, et);
+        if (bits) {
+            if (tb - lo < nbits) atomicOr(&bits[(tb - lo) >> 5], 1u << ((tb - lo) & 31u));
+        } else {
+            mn = min(mn, tb);
+            mx = max(mx, tb);
+        }
+    }
+    if (!bits) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+        }
+        if (__lane_id() == 0 && mn != 0xffffffffu) {
+            atomicMin(&range[0], mn);
+            atomicMax(&range[1], mx);
+        }
+    }
+}
+
 // ---- window close, device side: sort the extracted rows by (date, timeslot, src_as, dst_as, etype) ---------
 // Two stable radix-sort passes over 64-bit keys (hipcub, flowagg.hip): low key (DstAS, EType) first, then high key
 // (Timeslot, SrcAS); Date is a function of Timeslot.  fold_ts != ~0: the rows of a sliding window get the window's

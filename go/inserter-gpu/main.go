@@ -13,8 +13,15 @@
 //     5-minute window closes, so "the sink accepted it" has two meanings, chosen by
 //     -mark.after.close:
 //       true  (default): a flush batch is marked only once EVERY window that was open
-//              when it was ingested has been emitted (closeWindows) - a crash replays
-//              at most the batches whose windows had not reached the sink;
+//              when it was ingested has been emitted (closeWindows).  AT-LEAST-ONCE: a
+//              batch that spans a window already emitted and one still open stays
+//              unmarked, so a crash (or a rebalance that emits partial windows) replays
+//              records whose window the sink has seen - SummingMergeTree then counts
+//              them twice.  The sink has to be idempotent per (partition, timeslot)
+//              for exactly-once (e.g. ReplacingMergeTree keyed by it, or a dedup on
+//              insert); libflowagg reports such records when they come back
+//              (fa_stats_t.records_late, ABI 6).  fa_open_timeslots, asked before every
+//              flush here, is two scans of the device table (ABI 6), not a copy of it;
 //       false: marked as soon as fa_ingest returns (the reference's timing: what the
 //              GPU holds and has not emitted is lost with the process);
 //     a fatal sink error closes every partition's windows (best effort) before exit,
