@@ -16,6 +16,11 @@
 //   wagg_kernel: (SrcAddr,DstPort,Proto) tuples per region of the wide table, LDS dedup, plain loads and stores.
 //   Records the in-place parsers are not sure about go to deferred_kernel (parse_generic, complete semantics); values
 //   that do not fit a tuple take the direct device-wide-table path (64-bit atomics).
+// Around the hot path:
+//   framing.cuh   offsets == NULL: the framed chain cut into records on the device (guess, fixed-point proof, emit);
+//   merge.cuh     window close in HBM: rows collected, sorted over the key bits that differ (rowplan.cuh), equal keys summed,
+//                 emit order; hash partition of a row set for the multi-GPU close (row_partition_kernel);
+//   maintenance.cuh  table scans, rebuilds, the wide log's reads / folds / drops (wdrop_kernel: a close zeroes sums in place).
 //
 // Roofline: HBM-bound integer/byte work; algorithmic bytes = wire bytes, read
 // once (DESIGN.md "Roofline").  No MFMA anywhere - nothing here is a contraction.
