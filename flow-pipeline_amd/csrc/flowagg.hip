@@ -99,6 +99,7 @@ struct fa_ctx {
         bool minb_known = false;
     };
     std::vector<WChunk> wlog, wlog_free;
+    bool wide_probed = false;      // the ctx has seen its first launch (ingest_device_records: a first big launch is probed with its first 2^20 records)
     bool wide_defer = false;       // adaptive (FA_WIDE unset): log mode from the moment more than half of a million records opened new rows - for
                                    // the rest of the ctx's life (deferred launches tell nothing about new rows; a stream that stops opening
                                    // rows folds its chunks through wagg_kernel once more than wlog_max are pending: the scatter sink's cost)
@@ -1373,6 +1374,21 @@ extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const 
 
 static int ingest_device_records(fa_ctx* c, const void* d_buf, size_t len, size_t bytes, const void* d_off, size_t n) {
     if (n == 0) return FA_OK;
+    // The first big launch of a ctx with the (SrcAddr,DstPort,Proto) key set teaches it what the stream looks like: its first 2^20 (and
+    // a margin) records go ahead as a launch of their own and the host looks at the counters before the rest follows - a stream that
+    // opens a row per record (BASELINE config 5) keeps the rest of that launch in the log instead of folding 16 M rows into the
+    // hash table first (one extra launch and one synchronisation in a ctx's life).
+    if (c->wtab && (c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO) && c->wide_mode == 0 && !c->wide_defer && !c->wide_probed && n >= (1u << 22)) {
+        c->wide_probed = true;
+        const size_t m = ((size_t)1 << 20) + ((size_t)1 << 17);  // (format_feedback wants 2^20 decoded records; some may be refused)
+        const size_t b0 = (size_t)((double)bytes * (double)m / (double)n);
+        int rc0 = ingest_device_records(c, d_buf, len, b0, d_off, m);
+        if (rc0) return rc0;
+        rc0 = settle(c);  // (the counters of those records: format_feedback decides between table, scatter sink and log)
+        if (rc0) return rc0;
+        return ingest_device_records(c, d_buf, len, bytes - b0, (const uint32_t*)d_off + m, n - m);
+    }
+    c->wide_probed = true;
     if (c->wide_per_record) {
         // a launch may not be able to park more wide-table updates than the spill buffer holds: split it
         const size_t lim = (c->wspill_cap - (1u << 20)) / c->wide_per_record;

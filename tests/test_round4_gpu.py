@@ -418,3 +418,51 @@ def test_device_side_framing_refuses_what_is_not_a_chain_and_survives_odd_ones(g
         want, sw = host(stream)
         assert got.tobytes() == want.tobytes()
         assert (st["records_ok"], st["records_bad"], st["bytes_in"]) == (sw["records_ok"], sw["records_bad"], sw["bytes_in"])
+
+
+def test_first_big_launch_is_probed_before_the_rest_follows(gpu_lib, fa, po, monkeypatch):
+    """A ctx whose FIRST launch is big (>= 2^22 records) and carries the (SrcAddr,DstPort,Proto) key set: its first 2^20 + 2^17
+    records go ahead as a launch of their own, the counter feedback reads them, and a stream that opens a row per record has the
+    rest of that launch recorded in the wide log instead of folded into the hash table.  Rows are the oracle's either way; a
+    second ctx with the sink pinned (FA_WIDE=scatter: no probe) has the same rows and no log."""
+    import torch
+    monkeypatch.delenv("FA_WIDE", raising=False)
+    n = 4_400_000
+    probe = (1 << 20) + (1 << 17)
+    kw = dict(mode=2, framed=1, seed=77, n_total=n, span_secs=600, zipf_log2_universe=22, zipf_s_x100=80)
+    gp = po.gen_params(**kw)
+    mp = fa.mock_params(**kw)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    want = po.rollup_app(rows, status, 300).astype(fa.ROW_APP_DTYPE)
+    assert len(want) > 0.9 * n
+    ref = po.Rollup(300)
+    ref.ingest(buf, off, 1)
+    ks = fa.FA_KEYS_AS_PAIR | fa.FA_KEYS_ADDR_PORT_PROTO
+    dev = torch.device("cuda", 0)
+    d_buf = torch.empty(n * 96 + 4096, dtype=torch.uint8, device=dev)
+    d_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    for pinned in (False, True):
+        if pinned:
+            monkeypatch.setenv("FA_WIDE", "scatter")
+        with fa.FlowAgg(framed=True, key_sets=ks, max_batch_records=n) as agg:
+            wbytes = agg.mock_generate_device(mp, 0, n, d_buf.data_ptr(), d_buf.numel(), d_off.data_ptr())
+            assert wbytes == len(buf)
+            agg.ingest_device(d_buf.data_ptr(), wbytes, d_off.data_ptr(), n)
+            agg.sync()
+            st = agg.stats()
+            assert st["records_ok"] == n and st["bytes_in"] == wbytes
+            first = st["wave_tile_launches"]
+            if pinned:
+                assert st["wide_log_recorded"] == 0 and st["wide_log_mode"] == 0
+            else:
+                assert first >= 2
+                assert st["wide_log_mode"] == 1 and st["wide_log_recorded"] >= 1 and st["wide_log_records"] == n - probe
+            got = agg.read_window_app()
+            assert got.tobytes() == want.tobytes()
+            assert agg.read_window().tobytes() == ref.rows().tobytes()
+            # the next launch of the same ctx is not probed again
+            agg.ingest_device(d_buf.data_ptr(), wbytes, d_off.data_ptr(), n)
+            agg.sync()
+            assert agg.stats()["wave_tile_launches"] == (2 * first if pinned else 2 * first - 1)
+            assert agg.read_window_app().tobytes() == _scaled(want, 2).tobytes()
