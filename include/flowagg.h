@@ -271,7 +271,10 @@ int fa_rows_merge_device(fa_ctx*, int kind, const void* d_rows, size_t n, size_t
  * with these counts), every rank calls fa_rows_merge_device on what it received - 1 / world of the keys, complete - and
  * emits or gathers only that share; fa_drop_window as usual.  world <= 1024. */
 int fa_rows_partition_device(fa_ctx*, int kind, const void* d_rows, size_t n, uint32_t world, const void** d_out, size_t* counts);
-/* Copies n rows of `kind` from HBM into the caller's host buffer (cap in rows). */
+/* Copies n rows of `kind` from HBM into the caller's host buffer (cap in rows).  This call and every window read: when `out` is
+ * page-locked host memory (hipHostMalloc, or hipHostRegister'ed by the caller - both ends of the buffer are looked at), a
+ * result of 1 MiB or more is ONE copy-engine transfer into it (the link's 57 GB/s on MI355X, no host thread involved); into
+ * pageable memory the rows are relayed through the ctx's two pinned slots by host threads (54 GB/s). */
 int fa_rows_fetch(fa_ctx*, int kind, const void* d_rows, size_t n, void* out, size_t cap);
 /* Removes what fa_close_window / fa_close_window_app would remove after emitting `timeslot` (kind FA_ROWS_5M or
  * FA_ROWS_APP): the whole window for tumbling windows and close-all, the oldest sub-bucket when windows slide. */

@@ -293,6 +293,12 @@ def test_large_window_leaves_through_the_pinned_buffer_in_pieces(gpu_lib, fa, po
             reuse = np.empty(len(want) + 1000, dtype=fa.ROW_APP_DTYPE)
             got = agg.read_window_app(out=reuse)
             assert got.tobytes() == want.tobytes() and got.base is reuse, mode
+            # a page-locked buffer of the caller's: one copy-engine transfer, no relay (also at an odd offset into it)
+            pinned = fa.FlowAgg.pinned_rows(fa.ROWS_APP, len(want) + 7)
+            got = agg.read_window_app(out=pinned)
+            assert got.tobytes() == want.tobytes() and np.shares_memory(got, pinned), mode
+            got = agg.read_window_app(out=pinned[3:])
+            assert got.tobytes() == want.tobytes(), mode
             n_out = fa.C.c_size_t()
             small = np.empty(1000, dtype=fa.ROW_APP_DTYPE)  # the C contract: too small a buffer -> FA_ERR_CAPACITY and the size
             assert agg._L.fa_read_window_app(agg._h, fa.ALL_TIMESLOTS, small.ctypes.data, len(small), fa.C.byref(n_out)) == -6

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--span", type=int, default=1800, help="seconds of event time the stream covers (6 windows)")
     ap.add_argument("--wide-log2", type=int, default=26, help="slots of the (SrcAddr,DstPort,Proto) table, log2 (round 3 ran 2^28 for the scatter sink; with the log only the first launch's 16.6 M rows ever reach the table)")
     ap.add_argument("--universe-log2", type=int, default=24)
+    ap.add_argument("--pinned-out", action="store_true", help="the consumer's row buffer is page-locked: window reads are one copy-engine transfer")
     ap.add_argument("--table-log2", type=int, default=24, help="slots of the flows_5m table, log2 (3.9 M groups at the default span)")
     args = ap.parse_args()
     import torch
@@ -136,8 +137,10 @@ def main():
         nrows = 0
         app_ms = []
         # (a consumer keeps ONE row buffer per kind: fresh pages - 930 MB per window - cost more than the copy into them)
-        reuse = np.empty(int(st1["wide_used"] + st1["wide_log_records"]) // max(len(aligned) - 1, 1) + (1 << 20), dtype=fa.ROW_APP_DTYPE)
+        nreuse = int(st1["wide_used"] + st1["wide_log_records"]) // max(len(aligned) - 1, 1) + (1 << 20)
+        reuse = fa.FlowAgg.pinned_rows(fa.ROWS_APP, nreuse) if args.pinned_out else np.empty(nreuse, dtype=fa.ROW_APP_DTYPE)
         reuse.view(np.uint8)[::4096] = 0
+        out["row_buffer"] = "page-locked (one copy-engine transfer per read)" if args.pinned_out else "pageable (relayed through the ctx's pinned slots)"
         sums = []
         for ts in aligned:
             tw = time.perf_counter()
