@@ -62,7 +62,11 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     // ballot per tile for the tiers it never needs); a wave moves its starting tier up when more than half of a tile
     // needed the next one.
     if (!FA_DBG(a, DBG_NO_PARSE)) {
-        LdsSrc src{tile};
+        // (the walks run on absolute LDS addresses: wire.cuh, LdsAbsSrc)
+        LdsAbsSrc src;
+        const uint32_t tile_at = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)tile;
+        pos += tile_at;
+        end += tile_at;
         const uint32_t n_mine = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(framed_ok));
         auto most = [&](bool c) { return 2u * (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c)) > n_mine; };
         if (pmode == 0u && !FA_DBG(a, DBG_LOOP_PARSER)) {

@@ -99,6 +99,19 @@ struct LdsSrc {
     const uint32_t* base;  // LDS, dword aligned
     FA_HD uint32_t dw(uint32_t i) const { return base[i]; }
 };
+// LDS by ABSOLUTE byte address: dword i = the four bytes at LDS address 4 i.  The cursors of a walk then ARE LDS addresses
+// (tile base folded in once per record) and a window load is "and -4, ds_read2, ds_read" - the add of the tile's base that
+// every field step of LdsSrc pays is gone (one VALU instruction per step: 14 of a mocker-shaped record's ~420, 33 of GoFlow's).
+struct LdsAbsSrc {
+    FA_HD uint32_t dw(uint32_t i) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const __attribute__((address_space(3))) uint32_t* lds_p;
+        return *(lds_p)(i << 2);
+#else
+        return 0u * i;
+#endif
+    }
+};
 struct GlobalSrc {
     const uint32_t* base;  // global, dword aligned
     FA_HD uint32_t dw(uint32_t i) const { return base[i]; }
