@@ -119,11 +119,17 @@ __host__ __device__ __forceinline__ void tup16_unpack(const uint4& t, TupleVals&
     v.etype = t.w >> 15;
 }
 // 2-bit EType dictionary of the compact format: 0 -> 0 (absent), 1 -> 0x0800, 2 -> 0x86dd, 3 -> 0x0806
+// (branch-free: as a chain of compares the compiler built a decision tree with an exec-mask branch per level into the ingest
+// kernel's sink - on a stream that mixes IPv4 and IPv6 every level is taken by some lane.  Bits 2..1 of the three known
+// values are 00, 10, 11: a candidate code without a compare, then ONE compare against the value that code stands for.)
 __host__ __device__ __forceinline__ uint32_t t8_etcode(uint32_t etype) {
-    return etype == 0x0800u ? 1u : etype == 0x86ddu ? 2u : etype == 0x0806u ? 3u : 0u;
+    uint32_t c = (etype >> 1) & 3u;  // 0x0800 -> 0, 0x86dd -> 2, 0x0806 -> 3
+    c = c ? c : 1u;
+    const uint32_t stands_for = (uint32_t)(0x080686dd08000000ull >> (16u * c)) & 0xffffu;
+    return stands_for == etype ? c : 0u;
 }
 __host__ __device__ __forceinline__ uint32_t t8_etype(uint32_t code) {
-    return (code & 2u) ? ((code & 1u) ? 0x0806u : 0x86ddu) : ((code & 1u) ? 0x0800u : 0u);
+    return (uint32_t)(0x080686dd08000000ull >> (16u * (code & 3u))) & 0xffffu;
 }
 // 8 well-mixed bits of the stored part of the key (lo = DstAS | SrcAS[19:8] << 20, kh = (tb & 15) | etcode << 4)
 __host__ __device__ __forceinline__ uint32_t t8_mix8(uint32_t lo, uint32_t kh) {
@@ -132,8 +138,9 @@ __host__ __device__ __forceinline__ uint32_t t8_mix8(uint32_t lo, uint32_t kh) {
     return ((lo ^ (kh << 26)) * 0x9E3779B1u) >> 24;
 }
 __host__ __device__ __forceinline__ bool t8_fits(uint32_t src_as, uint32_t dst_as, uint32_t tbr, uint64_t b, uint64_t p, uint32_t etype) {
-    return tbr < TUPLE_TB_SPAN && (src_as | dst_as) < T8_MAX_AS && b < T8_MAX_BYTES && p < T8_MAX_PACKETS &&
-           (etype == 0u || t8_etcode(etype) != 0u);
+    // (& and |, not && and ||: five tests side by side; as short circuits they were nested exec-mask regions in the ingest kernel)
+    return (tbr < TUPLE_TB_SPAN) & ((src_as | dst_as) < T8_MAX_AS) & (b < T8_MAX_BYTES) & (p < T8_MAX_PACKETS) &
+           ((etype == 0u) | (t8_etcode(etype) != 0u));
 }
 // the partition of a compact-eligible key: a function of the key alone (tb = absolute time bucket)
 __host__ __device__ __forceinline__ uint32_t t8_part(uint32_t src_as, uint32_t dst_as, uint32_t tb, uint32_t etype) {

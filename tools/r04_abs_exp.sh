@@ -1,6 +1,5 @@
 #!/bin/bash
-# Walk cursors as absolute LDS addresses (no add of the tile base per field step): old library against new, alternating on one box;
-# config 2, GoFlow-shaped, Zipf, config 3 shape; hipEvent times of bench.py (no profiler).
+# Old library against new, alternating on one box (hipEvent times of bench.py, no profiler): config 2 five times each, then the side workloads.
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/absexp
 mkdir -p $OUT
@@ -19,13 +18,14 @@ except Exception as e:
     print("ERR", sys.argv[2], e)
 PY
 }
-for rep in 1 2 3; do
+for rep in 1 2 3 4 5; do
 one c2_old_$rep old
 one c2_new_$rep ""
 done
 G="--mode goflow --records 50000000 --chunk 16666667"
 Z="--mode zipf --records 50000000 --chunk 16666667"
 Z7="--mode zipf --key-sets 7 --records 50000000 --chunk 16666667 --no-verify"
+M="--mode mocker"
 for rep in 1 2; do
 one gf_old_$rep old $G
 one gf_new_$rep "" $G
@@ -33,8 +33,6 @@ one z_old_$rep old $Z
 one z_new_$rep "" $Z
 one z7_old_$rep old $Z7
 one z7_new_$rep "" $Z7
+one mk_old_$rep old $M
+one mk_new_$rep "" $M
 done
-one dec_old old --stage decode --records 50000000
-one dec_new "" --stage decode --records 50000000
-one rev_old old --mode reversed --records 50000000
-one rev_new "" --mode reversed --records 50000000
