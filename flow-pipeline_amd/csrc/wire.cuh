@@ -445,7 +445,7 @@ FA_HD bool parse_canon(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
 //   tw_time5   a varint of exactly 5 bytes (a Unix timestamp between 1978 and 3058) - tag and continuation bits checked
 //              with two masked compares;
 //   tw_short   a varint whose value fits 4 bytes (< 2^28);            tw_skip   a varint that ends inside the window;
-//   tw_addr    a bytes field with a one-byte length <= 16;            canon_skip (above) for 7-byte MAC varints.
+//   tw_addr    a bytes field with a one-byte length <= 16;            tw_skip7 for 7-byte MAC varints.
 // Same contract as every tier: a step only moves the cursor over a field it has validated completely, steps come in
 // ascending field order, so "cursor == end" means the record is exactly a sub-sequence of the template's fields - decoded
 // exactly - and anything else (another field, another order, a longer varint, a timestamp outside 1978..3058) is "not
@@ -495,6 +495,26 @@ FA_HD void tw_skip(const Src& s, Cursor& c, uint32_t end) {
     const bool ok = m && pn <= end;
     c.pos = ok ? pn : c.pos;
     if (!LAST) cur_load(s, c);
+}
+// a varint outside the projection of up to 7 bytes behind a 2-byte tag (GoFlow's MAC addresses: uint64 fields holding 48 bits):
+// the stop byte is looked for in the window and in the one byte behind it that the cursor's three dwords always hold
+// (12 - (pos & 3) >= 9 bytes from pos).  Branch-free - the general canon_skip in this place (any wire type, a second window
+// behind a wave-level question) compiled into a decision tree of a dozen exec-mask branches per field.  A longer varint leaves
+// the cursor where it is: not sure, the general tiers take the record.
+template <uint32_t TAG, class Src>
+FA_HD void tw_skip7(const Src& s, Cursor& c, uint32_t end) {
+    static_assert(TAG > 0xffu, "tw_skip7: 2-byte tags");
+    const bool m = (c.x & 0xffffu) == TAG;
+    const uint32_t z = fa_alignbyte(0u, s.dw((c.pos >> 2) + 2u), c.pos);  // byte 8 (.. 11 - (pos & 3)), zero above
+    const uint32_t s0 = fa_ffbl(~c.x & 0x80800000u);
+    const uint32_t s1 = fa_ffbl(~c.y & 0x80808080u) | 32u;  // (stays 0xffffffff when there is no stop)
+    const uint32_t s2 = fa_ffbl(~z & 0x80u) | 64u;
+    const uint32_t s01 = s0 < s1 ? s0 : s1;
+    const uint32_t sb = s01 < s2 ? s01 : s2;
+    const uint32_t pn = c.pos + (sb >> 3) + 1u;
+    const bool ok = m && pn <= end;
+    c.pos = ok ? pn : c.pos;
+    cur_load(s, c);
 }
 // a varint of exactly 5 bytes (value in [2^28, 2^35)): timestamps
 template <uint32_t TAG, bool WANT, bool LAST = false, class Src>
@@ -581,8 +601,8 @@ FA_HD bool parse_tmpl(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
         tw_short<0x01b8u, false>(s, c, end, d32);  // 23 IPTos
         tw_short<0x01c8u, false>(s, c, end, d32);  // 25 IPTTL
         tw_short<0x01d0u, false>(s, c, end, d32);  // 26 TCPFlags
-        canon_skip<true>(s, c, end, (c.x & 0xffffu) == 0x01d8u);                               // 27 SrcMac (7-byte varint)
-        canon_skip<true>(s, c, end, (c.x & 0xffffu) == 0x01e0u);                               // 28 DstMac
+        tw_skip7<0x01d8u>(s, c, end);              // 27 SrcMac (7-byte varint)
+        tw_skip7<0x01e0u>(s, c, end);              // 28 DstMac
         tw_short<0x01e8u, false>(s, c, end, d32);  // 29 VlanId
     }
     tw_short<0x01f0u, (COLS & COL_ETYPE) != 0>(s, c, end, r.etype);                            // 30 Etype
