@@ -386,7 +386,8 @@ __device__ __forceinline__ bool hot_add(HotAddrs& ht, uint32_t set, uint64_t lo,
     }
     if (way < 4u) {
         const uint32_t slot = base + way;
-        if (ht.lo[set][slot] == lo && ht.hi[set][slot] == hi) {
+        const unsigned long long klo = ht.lo[set][slot], khi = ht.hi[set][slot];  // (both halves in flight together: one wait)
+        if ((klo == lo) & (khi == hi)) {
             if (w) atomicAdd(&ht.w[set][slot], (unsigned long long)w);
             ht.touched[set][slot] = 1;
             return true;

@@ -28,3 +28,24 @@ r=d["roofline"]; k=r.get("dominant_kernel") or {}
 print("bench value %.4g  path %.4f ms frac %.4f | kernel %.4f ms frac %.4f | traffic %s" % (d["value"], r["avg_launch_ms"], r["frac"], k.get("avg_launch_ms",0), k.get("frac",0), r.get("traffic")), (d.get("parity") or {}).get("ok"), d["cpu_baseline"]["value"])
 PY
 done
+S="--steps 5 --warmup 2 --cpu-sample 0 --no-host-fed"
+run() { name=$1; shift; timeout 300 python bench.py $S "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; }
+run mocker --mode mocker
+run goflow --mode goflow --records 50000000 --chunk 16666667
+run reversed --mode reversed --records 50000000
+run decode --stage decode --records 50000000
+run zipf_ks1 --mode zipf --records 50000000 --chunk 16666667 --no-verify
+run config3_shape --mode zipf --key-sets 7 --records 50000000 --chunk 16666667 --no-verify
+run config5_pair --mode zipf --zipf-s 80 --key-sets 9 --records 50000000 --chunk 16666667 --no-verify
+FA_TUPLE=16 run wide_tuples --chunk 16666667 --no-verify
+run c16 --chunk 16666667 --no-verify
+for f in $OUT/bench_*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    r=d["roofline"]; k=r.get("dominant_kernel") or {}
+    print(sys.argv[1].split("/")[-1], "value %.4g  path %.4f ms frac %.4f | kernel %.4f ms frac %.4f" % (d["value"], r["avg_launch_ms"], r["frac"], k.get("avg_launch_ms",0), k.get("frac",0)), (d.get("parity") or {}).get("ok"))
+except Exception as e:
+    print("ERR", sys.argv[1], e)
+PY
+done
