@@ -706,8 +706,18 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
     // (no probe dispatch, no cross-workgroup hand-over: the answer is identical all over the grid)
     tb_base = probe_tb_base(a);
     if (blockIdx.x == 0 && tid == 0) a.ctr->tb_base = tb_base;  // (for agg_kernel)
+    uint32_t t2 = 0;       // the tile after the next one (wave-uniform), claimed when a tile's first part starts
+    bool t2_have = false;
     while (cur.nrec != 0) {
         dma_wait_all();  // the wave's own DMA has landed: no workgroup barrier on this path
+        // The claim of the tile after the next one is an LDS atomic, and an LDS instruction behind a path that may have an LDS
+        // DMA in flight makes the compiler wait for EVERYTHING in flight (vmcnt is one in-order counter): at the end of the
+        // round, where it used to stand, that was a wait for the write acknowledgements of the tile's tuple stores - every
+        // tile, in front of the next tile's DMA.  Here nothing is in flight.
+        if (!t2_have) {
+            t2 = tile_after_next();
+            t2_have = true;
+        }
         const uint32_t cbase = cur_lo & ~15u;
         // sane bounds (the offsets come from the caller): inside the tile's byte range, end >= start
         const bool valid = live && cur.q1 >= cur.q0 && cur.q0 >= cur_lo && cur.q1 <= cur_hi;
@@ -741,7 +751,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
             issue_dma(cur_lo, cur_hi);
             continue;
         }
-        const uint32_t t2 = tile_after_next();  // (an LDS atomic - before the DMA, or the compiler drains vmcnt for it)
+        t2_have = false;
         cur = nxt;
         cur_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur.q0);
         cur_hi = cur.nrec ? min((uint32_t)__builtin_amdgcn_readlane((int)cur.q1, (int)(cur.nrec - 1u)), a.len) : 0u;

@@ -341,7 +341,13 @@ FA_HD void canon_skip(const Src& s, Cursor& c, uint32_t end, bool go) {
         vlen = sb == 0xffffffffu ? (ok2 ? (8u - TL) + l2 : NONE) : vlen;
     }
     const uint32_t lb = v0 & 0xffu;  // bytes field: one length byte
-    const uint32_t body = wt == 0u ? vlen : wt == 1u ? 8u : wt == 5u ? 4u : (wt == 2u && lb < 0x80u) ? 1u + lb : NONE;
+    // (selects side by side, & instead of &&: as one chain of ?: with a short circuit in it this compiled into a decision tree
+    // of exec-mask branches, a dozen per call)
+    uint32_t body = NONE;
+    body = wt == 5u ? 4u : body;
+    body = wt == 1u ? 8u : body;
+    body = ((wt == 2u) & (lb < 0x80u)) ? 1u + lb : body;
+    body = wt == 0u ? vlen : body;
     const uint32_t pn = c.pos + TL + body;
     const bool ok = go && pn <= end;
     c.pos = ok ? pn : c.pos;

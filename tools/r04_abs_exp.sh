@@ -1,7 +1,7 @@
 #!/bin/bash
 # Old library against new, alternating on one box (hipEvent times of bench.py, no profiler).
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/absexp2
+OUT=$ROOT/gpurun_out/absexp3
 mkdir -p $OUT
 cd $ROOT
 B="--steps 6 --warmup 3 --cpu-sample 0 --no-host-fed"
@@ -19,10 +19,19 @@ except Exception as e:
 PY
 }
 G="--mode goflow --records 50000000 --chunk 16666667"
-for rep in 1 2 3; do
+Z="--mode zipf --records 50000000 --chunk 16666667"
+Z7="--mode zipf --key-sets 7 --records 50000000 --chunk 16666667 --no-verify"
+for rep in 1 2 3 4; do
+one c2_old_$rep old
+one c2_new_$rep ""
+done
+for rep in 1 2; do
 one gf_old_$rep old $G
 one gf_new_$rep "" $G
+one z_old_$rep old $Z
+one z_new_$rep "" $Z
+one z7_old_$rep old $Z7
+one z7_new_$rep "" $Z7
+one mk_old_$rep old --mode mocker
+one mk_new_$rep "" --mode mocker
 done
-one c2_old old
-one c2_new ""
-timeout 600 python -m pytest tests -m gpu -q -x -k "goflow or GoFlow or template or parser or tier or shapes or producers" 2>&1 | tail -3
