@@ -117,7 +117,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     }
     const uint32_t t32 = (uint32_t)r.time_received;  // UInt64 -> DateTime (create.sh:39)
     const uint32_t tb = time_bucket(a, t32);
-    tally.late += (sure && tb < a.late_below) ? 1u : 0u;  // (its flows_5m window was closed before it arrived; aggregated all the same)
+    if (a.late_below != 0u) tally.late += (sure && tb < a.late_below) ? 1u : 0u;  // (its flows_5m window was closed before it arrived; aggregated all the same.  Nothing closed yet: three instructions a record less)
     // state of the sketch path between its two halves (below: in front of and behind the flows_5m sink)
     uint64_t cw = 0, ws = 0, wd = 0, slo = 0, shi = 0, dlo = 0, dhi = 0, sh1 = 0, sh2 = 0, dh1 = 0, dh2 = 0;
     bool on_s = false, on_d = false, vs = false, vd = false;
@@ -158,13 +158,16 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         if (vd && keys_on) pd = keyset_probe(a, a.ks_dst, dh1);
     }
     if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
-        uint64_t k0, k1;
-        pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
-        // the 32-bit key hash (three quarter-rate multiplies) is only needed by the hot-key table, the wide tuple's
-        // partition and the direct path: a compact-tuple wave that has given the hot-key table up never computes it
+        // the two key words and the 32-bit key hash (three quarter-rate multiplies) are only needed by the hot-key table, the wide
+        // tuple's partition and the direct path: a compact-tuple wave that has given the hot-key table up never computes them
+        // (the key words are packed where they are used: hoisted in front of the branches they were six instructions a record)
+        uint64_t k0 = 0, k1 = 0;
         const bool lt_on = lt_seen != 0xffffffffu && !(FA_DBG(a, DBG_NO_LDS_TABLE));  // wave-uniform
         uint32_t h = 0;
-        if (!T8 || lt_on) h = key_hash(k0, k1);
+        if (!T8 || lt_on) {
+            pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
+            h = key_hash(k0, k1);
+        }
         const uint64_t b = r.bytes, p = r.packets, c = 1;
         bool pending = sure;
         // hot-key table: worth its LDS atomics only while it absorbs records.  Every wave keeps score (ballots:
@@ -247,7 +250,10 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             Slot* sp = nullptr;
             if (pending) {
                 tally.direct++;
-                if (T8 && !lt_on) h = key_hash(k0, k1);
+                if (T8 && !lt_on) {
+                    pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
+                    h = key_hash(k0, k1);
+                }
                 sp = table_find_or_claim(a, k0, k1, h);
                 if (!sp) spill_park(a, k0, k1, b, p, c);
             }

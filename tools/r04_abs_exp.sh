@@ -1,7 +1,7 @@
 #!/bin/bash
 # Old library against new, alternating on one box (hipEvent times of bench.py, no profiler).
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/absexp3
+OUT=$ROOT/gpurun_out/absexp4
 mkdir -p $OUT
 cd $ROOT
 B="--steps 6 --warmup 3 --cpu-sample 0 --no-host-fed"
