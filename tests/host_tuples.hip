@@ -55,6 +55,13 @@ int main() {
             }
         }
     }
+    // 1b. the branch-free EType dictionary, every value of a 17-bit range (and some beyond): code and its inverse
+    for (uint32_t et = 0; et < (1u << 17) + 64; et++) {
+        const uint32_t e = et < (1u << 17) ? et : (uint32_t)rnd();
+        const uint32_t want = e == 0x0800u ? 1u : e == 0x86ddu ? 2u : e == 0x0806u ? 3u : 0u;
+        if (t8_etcode(e) != want) fails++;
+    }
+    if (t8_etype(0) != 0 || t8_etype(1) != 0x0800u || t8_etype(2) != 0x86ddu || t8_etype(3) != 0x0806u) fails++;
     // 2. balance of the partition over key populations: only SrcAS[7:0] varies / only the rest varies / config 2 / mocker
     auto balance = [&](const char* name, auto gen, uint32_t nkeys) {
         std::vector<uint32_t> cnt(256, 0);
