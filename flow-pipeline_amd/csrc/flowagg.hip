@@ -557,1259 +557,11 @@ extern "C" void fa_destroy(fa_ctx* c) {
     delete c;
 }
 
-// ---- table maintenance -------------------------------------------------------------
-// Builds a fresh table of 2^new_log2 slots holding every row outside [tb_lo,tb_hi).
-static int rebuild_table(fa_ctx* c, uint32_t new_log2, uint32_t tb_lo, uint32_t tb_hi) {
-    Slot* nt = nullptr;
-    size_t bytes = sizeof(Slot) << new_log2;
-    hipError_t e = hipMalloc(&nt, bytes);
-    if (e != hipSuccess) return fail(c, FA_ERR_NOMEM, "rebuild_table: hipMalloc failed");
-    if ((e = hipMemsetAsync(nt, 0, bytes, c->stream)) != hipSuccess ||
-        (e = hipMemsetAsync(&c->d_ctr->used, 0, sizeof(unsigned long long), c->stream)) != hipSuccess) {
-        (void)hipFree(nt);  // the old table stays in place
-        c->err = std::string("rebuild_table: ") + hipGetErrorString(e);
-        return FA_ERR_HIP;
-    }
-    Slot* old = c->tab;
-    uint32_t old_slots = 1u << c->cap_log2;
-    c->tab = nt;
-    c->cap_log2 = new_log2;
-    KArgs a = make_args(c);
-    hipLaunchKernelGGL(rebuild_kernel, dim3(1024), dim3(256), 0, c->stream, old, old_slots, tb_lo, tb_hi, a);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(old));
-    c->used_base = 0;
-    c->stats.table_capacity = 1ull << c->cap_log2;
-    return FA_OK;
-}
-
-// Wide table: fresh table of 2^new_log2 slots holding every row that is not selected by
-// (kind_mask, [tb_lo,tb_hi)) - see wrow_selected().
-static int rebuild_wide(fa_ctx* c, uint32_t new_log2, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi) {
-    WSlot* nt = nullptr;
-    size_t bytes = sizeof(WSlot) << new_log2;
-    if (hipMalloc(&nt, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "rebuild_wide: hipMalloc failed");
-    hipError_t e;
-    if ((e = hipMemsetAsync(nt, 0, bytes, c->stream)) != hipSuccess ||
-        (e = hipMemsetAsync(&c->d_ctr->wused, 0, sizeof(unsigned long long), c->stream)) != hipSuccess) {
-        (void)hipFree(nt);  // the old table stays in place
-        c->err = std::string("rebuild_wide: ") + hipGetErrorString(e);
-        return FA_ERR_HIP;
-    }
-    WSlot* old = c->wtab;
-    uint32_t old_slots = 1u << c->wcap_log2;
-    c->wtab = nt;
-    c->wcap_log2 = new_log2;
-    KArgs a = make_args(c);
-    hipLaunchKernelGGL(wrebuild_kernel, dim3(1024), dim3(256), 0, c->stream, old, old_slots, kind_mask, tb_lo, tb_hi, a);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipFree(old));
-    c->wused_base = 0;
-    c->wide_dead = 0;  // (slots without rows were not carried over)
-    c->stats.wide_capacity = 1ull << c->wcap_log2;
-    return FA_OK;
-}
-
-static uint32_t log2_ceil(uint64_t v) {
-    uint32_t l = 0;
-    while ((1ull << l) < v) l++;
-    return l;
-}
-
-// grows the wide table / replays parked updates until nothing is pending (h = fresh copy of the counters)
-static int settle_wide(fa_ctx* c, Counters& h) {
-    if (!c->wtab) return FA_OK;
-    c->stats.wide_used = c->wused_base + h.wused;
-    if (h.wspill_lost) {
-        c->sticky = FA_ERR_TABLE_FULL;
-        return fail(c, FA_ERR_TABLE_FULL, "wide-key table and its spill buffer overflowed; aggregates were lost");
-    }
-    int guard = 0;
-    while (h.wspill_count || c->stats.wide_used * 2 > (1ull << c->wcap_log2)) {
-        // room for every group that exists plus every parked update, at <= 50 % load, in ONE step - at the SAME size when
-        // the slots that closed windows left dead (wdrop_kernel) are what fills the table
-        const uint64_t live = c->stats.wide_used - std::min(c->wide_dead, c->stats.wide_used);
-        const uint32_t want = c->wide_dead ? std::max(c->wcap_log2, log2_ceil(2 * (live + h.wspill_count))) :
-                                             std::max(c->wcap_log2 + 1, log2_ceil(2 * (c->stats.wide_used + h.wspill_count)));
-        if (want > 30 || ++guard > 8) return fail(c, FA_ERR_TABLE_FULL, "wide-key table cannot grow further");
-        const uint32_t nspill = h.wspill_count;
-        // the parked updates move to a private copy and the buffer is emptied BEFORE the rebuild, so that anything the
-        // rebuild or the replay parks again is kept for the next round of this loop
-        WSpillEntry* tmp = nullptr;
-        if (nspill) {
-            if (hipMalloc(&tmp, sizeof(WSpillEntry) * nspill) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide spill copy) failed");
-            hipError_t e = hipMemcpyAsync(tmp, c->wspill, sizeof(WSpillEntry) * nspill, hipMemcpyDeviceToDevice, c->stream);
-            if (e != hipSuccess) { (void)hipFree(tmp); c->err = "settle_wide: copy failed"; return FA_ERR_HIP; }
-        }
-        hipError_t e0 = hipMemsetAsync(&c->d_ctr->wspill_count, 0, sizeof(unsigned int), c->stream);
-        int rc = e0 == hipSuccess ? rebuild_wide(c, want, 0, 0, 0 /* nothing selected: keep everything */) : FA_ERR_HIP;
-        if (rc == FA_OK && nspill) {
-            KArgs a = make_args(c);
-            static_assert(sizeof(WSpillEntry) == sizeof(WRow), "spill entries replay as rows");
-            hipLaunchKernelGGL(wmerge_kernel, dim3(256), dim3(256), 0, c->stream, (const WRow*)tmp, nspill, a);
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = FA_ERR_HIP;
-        }
-        if (tmp) (void)hipFree(tmp);
-        if (rc) return rc == FA_ERR_HIP ? fail(c, FA_ERR_HIP, "settle_wide: replay failed") : rc;
-        HIPCHK(c, hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost));
-        h = *c->h_ctr;
-        c->stats.wide_used = c->wused_base + h.wused;
-        if (h.wspill_lost) return fail(c, FA_ERR_TABLE_FULL, "wide spill buffer overflowed during replay");
-    }
-    return FA_OK;
-}
-
-static int cms_fold(fa_ctx* c);
-
-// tuple-format feedback (fa_ctx::use_t8): h = counters at least as new as the last look
-static void format_feedback(fa_ctx* c, const Counters& h) {
-    const uint64_t d_mis = h.misfit8 - c->seen_misfit8, d_ok = h.ok - c->seen_ok;
-    if (d_ok && d_mis * 16 > d_ok) c->t8_wide_until = c->stats.batches + 64;
-    c->seen_misfit8 = h.misfit8;
-    c->seen_ok = h.ok;
-    if (c->wtab && !c->wide_defer) {  // (SrcAddr,DstPort,Proto): scatter sink or atomics, by the share of records that opened a row lately
-        if (h.wused < c->seen_wused) c->seen_wused = h.wused;  // (table rebuilt: the count starts over)
-        if (h.ok < c->seen_ok_w) c->seen_ok_w = h.ok;
-        const uint64_t dw = h.wused - c->seen_wused, dn = h.ok - c->seen_ok_w;
-        if (dn >= (1u << 20)) {
-            if (dw * 5 > dn) c->wide_scatter = true;
-            else if (dw * 10 < dn) c->wide_scatter = false;
-            // ... and no table at all for a stream that opens a row for most of its records: the log (fa_ctx::wlog)
-            if (c->wide_mode == 0 && c->wide_scatter && dw * 2 > dn && c->wlog_max > 0) {
-                c->wide_defer = true;
-                c->seen_wfold = h.wfold_n;
-            }
-            c->seen_wused = h.wused;
-            c->seen_ok_w = h.ok;
-        }
-    }
-    if (c->wtab && c->wide_defer && c->wide_mode == 0) {  // log mode chosen by the library: do the chunks that ARE folded still open rows?
-        const uint64_t dn = h.wfold_n - c->seen_wfold;
-        if (h.wused < c->seen_wused || h.wfold_n < c->seen_wfold) {  // (table rebuilt / counters restarted: no verdict from this look)
-            c->seen_wused = h.wused;
-            c->seen_wfold = h.wfold_n;
-        } else if (dn >= (1u << 20)) {
-            // fewer than half of the folded tuples opened a row: this stream aggregates - back to the table (scatter sink or
-            // atomics, by the feedback above); the chunks still pending are folded one per launch (fa_ingest_device)
-            if ((h.wused - c->seen_wused) * 2 < dn) {
-                c->wide_defer = false;
-                c->seen_ok_w = h.ok;
-            }
-            c->seen_wused = h.wused;
-            c->seen_wfold = h.wfold_n;
-        }
-    }
-    // passes of agg8_kernel: the groups a launch adds to the device table, per partition and pass, against the LDS table
-    if (h.agg_launches < c->seen_agg_launches || h.agg_groups < c->seen_agg_groups) c->seen_agg_launches = c->seen_agg_groups = 0;
-    const uint64_t d_l = h.agg_launches - c->seen_agg_launches, d_g = h.agg_groups - c->seen_agg_groups;
-    if (d_l) {
-        const uint64_t per_part = d_g / d_l >> c->plog2;
-        uint32_t want = 1;
-        while (want < 8 && per_part > (uint64_t)(AGG8_SLOTS / 2) * want) want *= 2;
-        // (a launch that overflowed its table under-counts: move up one step at a time, down only when clearly below)
-        if (want > c->agg_passes) c->agg_passes = std::min(want, c->agg_passes * 2);
-        else if (want < c->agg_passes && per_part * 3 < (uint64_t)(AGG8_SLOTS / 2) * c->agg_passes) c->agg_passes = std::max(want, c->agg_passes / 2);
-        c->seen_agg_launches = h.agg_launches;
-        c->seen_agg_groups = h.agg_groups;
-    }
-}
-
-// Waits for the stream, folds device counters into stats, replays spills after growing.
-static int settle(fa_ctx* c) {
-    if (c->cms_dirty) {
-        int frc = cms_fold(c);
-        if (frc) return frc;
-    }
-    HIPCHK(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < c->ev_used; i++) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev_pool[i].e0, c->ev_pool[i].e1) == hipSuccess) {
-            c->stats.kernel_ns = (uint64_t)((double)ms * 1e6);
-            c->stats.kernel_ns_total += c->stats.kernel_ns;
-            c->stats.kernel_launches += 1;
-        }
-        if (hipEventElapsedTime(&ms, c->ev_pool[i].e0, c->ev_pool[i].e2) == hipSuccess)
-            c->stats.batch_ns_total += (uint64_t)((double)ms * 1e6);
-    }
-    c->ev_used = 0;
-    for (size_t i = 0; i < c->dev_used; i++) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, c->dev_pool[i].e0, c->dev_pool[i].e2) == hipSuccess) {
-            c->stats.decode_ns_total += (uint64_t)((double)ms * 1e6);
-            c->stats.decode_launches += 1;
-        }
-    }
-    c->dev_used = 0;
-    Counters h = *c->h_ctr;
-    c->stats.records_ok = h.ok;
-    c->stats.records_bad = h.bad;
-    c->stats.records_slow = h.slow;
-    c->stats.records_direct = h.direct;
-    c->stats.records_retried = h.retried;
-    c->stats.records_misfit_compact = h.misfit8;
-    c->stats.records_late = h.late;
-    c->stats.table_used = c->used_base + h.used;
-    format_feedback(c, h);
-    if (h.spill_lost) {
-        c->sticky = FA_ERR_TABLE_FULL;
-        return fail(c, FA_ERR_TABLE_FULL, "group-by table and spill buffer overflowed; aggregates were lost");
-    }
-    int guard = 0;
-    while (h.spill_count || c->stats.table_used * 2 > (1ull << c->cap_log2)) {
-        // room for every group that exists plus every parked update, at <= 50 % load, in ONE step
-        const uint32_t want = std::max(c->cap_log2 + 1, log2_ceil(2 * (c->stats.table_used + h.spill_count)));
-        if (want > 30 || ++guard > 8) return fail(c, FA_ERR_TABLE_FULL, "group-by table cannot grow further");
-        const uint32_t nspill = h.spill_count;
-        // the parked aggregates move to a private copy and the buffer is emptied BEFORE the rebuild, so that anything
-        // the rebuild or the replay parks again is kept for the next round of this loop
-        SpillEntry* tmp = nullptr;
-        if (nspill) {
-            if (hipMalloc(&tmp, sizeof(SpillEntry) * nspill) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(spill copy) failed");
-            hipError_t e = hipMemcpyAsync(tmp, c->spill, sizeof(SpillEntry) * nspill, hipMemcpyDeviceToDevice, c->stream);
-            if (e != hipSuccess) { (void)hipFree(tmp); c->err = "settle: copy failed"; return FA_ERR_HIP; }
-        }
-        hipError_t e0 = hipMemsetAsync(&c->d_ctr->spill_count, 0, sizeof(unsigned int), c->stream);
-        int rc = e0 == hipSuccess ? rebuild_table(c, want, 1, 0 /* empty range: keep everything */) : FA_ERR_HIP;
-        if (rc == FA_OK && nspill) {
-            KArgs a = make_args(c);
-            hipLaunchKernelGGL(replay_spill_kernel, dim3(1024), dim3(256), 0, c->stream, tmp, nspill, a);
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = FA_ERR_HIP;
-        }
-        if (tmp) (void)hipFree(tmp);
-        if (rc) return rc == FA_ERR_HIP ? fail(c, FA_ERR_HIP, "settle: replay failed") : rc;
-        HIPCHK(c, hipMemcpy(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost));
-        h = *c->h_ctr;
-        c->stats.table_used = c->used_base + h.used;
-        if (h.spill_lost) return fail(c, FA_ERR_TABLE_FULL, "spill buffer overflowed during replay");
-    }
-    int rc = settle_wide(c, h);
-    // everything launched so far is accounted for
-    c->known = h;
-    c->known_records = c->launched_records;
-    c->known_seq = c->launch_seq;
-    c->known_wpot = c->wpot_total;
-    return rc;
-}
-
-// ---- wide log (FA_WIDE=log; fa_ctx::wlog) -----------------------------------------------------------------------------
-static WChunkArgs wchunk_args(const fa_ctx::WChunk& k) {
-    return WChunkArgs{k.seg, k.counts, k.counts + k.counts_cap, 1u << k.wplog2, k.nwg, k.wcapq, k.wm, k.wregion};
-}
-// room in the table for `more` new rows at <= 50 % load (host-side bound first; a settle - and a one-step growth - only when
-// the bound says so)
-static uint64_t wide_rows_bound(const fa_ctx* c) { return c->wused_base + c->known.wused + (c->wpot_total - c->known_wpot); }
-static int wlog_make_room(fa_ctx* c, uint64_t more) {
-    if ((wide_rows_bound(c) + more) * 2 <= (1ull << c->wcap_log2)) return FA_OK;
-    int rc = settle(c);  // (exact count; grows the table by itself when it is above 50 % already)
-    if (rc) return rc;
-    if ((c->stats.wide_used + more) * 2 <= (1ull << c->wcap_log2)) return FA_OK;
-    const uint32_t want = log2_ceil(2 * (c->stats.wide_used + more));
-    if (want > 30) return fail(c, FA_ERR_TABLE_FULL, "wide-key table cannot grow further");
-    return rebuild_wide(c, want, 0, 0, 0);  // (pending chunks stay pending: they are folded by the atomic replay from now on)
-}
-// one pending chunk into the table: wagg_kernel while the table still has the geometry the tuples were scattered for (its
-// workgroups own "their" regions' tuples), the atomic replay otherwise; the buffers go to the free list
-static int wlog_fold(fa_ctx* c, const fa_ctx::WChunk& k) {
-    KArgs a = make_args(c);
-    if (k.wplog2 == a.wplog2 && k.wmask == a.wmask) {
-        a.wseg = k.seg;
-        a.wseg_counts = k.counts;
-        a.nwg = k.nwg;
-        a.wcapq = k.wcapq;
-        a.wregion = k.wregion;
-        hipLaunchKernelGGL(wagg_kernel, dim3(1u << a.wplog2), dim3(WAGG_BLOCK), 0, c->stream, a, (const uint32_t*)(k.counts + k.counts_cap), k.wm);
-        c->wlog_folded++;
-    } else {
-        hipLaunchKernelGGL(wlog_replay_kernel, dim3(2048), dim3(256), 0, c->stream, wchunk_args(k), a);
-        c->wlog_replayed++;
-    }
-    HIPCHK(c, hipGetLastError());
-    c->wpot_total += k.n;
-    c->wlog_free.push_back(k);
-    return FA_OK;
-}
-static int wlog_flush_oldest(fa_ctx* c) {
-    const fa_ctx::WChunk k = c->wlog.front();
-    int rc = wlog_make_room(c, k.n);
-    if (rc) return rc;
-    c->wlog.erase(c->wlog.begin());
-    return wlog_fold(c, k);
-}
-static int wlog_flush_all(fa_ctx* c) {
-    while (!c->wlog.empty()) {
-        int rc = wlog_flush_oldest(c);
-        if (rc) return rc;
-    }
-    return FA_OK;
-}
-// behind a log-mode launch: its segment buffers become the newest chunk (the ctx allocates or recycles others for the next
-// launch); more than wlog_max pending: the oldest is folded into the table after all
-static int wlog_record(fa_ctx* c, const KArgs& a, size_t n) {
-    fa_ctx::WChunk k;
-    k.seg = c->wseg;
-    k.seg_bytes = c->wseg_bytes;
-    k.counts = c->wseg_counts;
-    k.counts_cap = c->wseg_counts_cap;
-    k.nwg = a.nwg;
-    k.wcapq = a.wcapq;
-    k.wplog2 = a.wplog2;
-    k.wmask = a.wmask;
-    k.wregion = a.wregion;
-    k.n = n;
-    c->wlog.push_back(k);
-    c->wlog_recorded++;
-    c->wseg = nullptr;
-    c->wseg_bytes = 0;
-    c->wseg_counts = nullptr;
-    c->wseg_counts_cap = 0;
-    while (c->wlog.size() > c->wlog_max) {
-        int rc = wlog_flush_oldest(c);
-        if (rc) return rc;
-    }
-    return FA_OK;
-}
-// a drop of buckets [lo, hi) as far as the pending chunks go: when nothing older is alive in them it is their watermark
-// (tuples below it are skipped by every later read and fold); anything else folds them into the table first, where the
-// caller's rebuild removes the range.  "Older" is judged by the smallest bucket among a chunk's live tuples - looked for
-// once per chunk (a scan of its segments, the word behind the time base) and kept: with the launch's time base instead
-// (the smallest SAMPLED bucket - 2) every close of a real timeslot found "something older" and folded all chunks.
-// every pending chunk's bucket range [minb, maxb] (live tuples; one scan per chunk, kept)
-static int wlog_bucket_ranges(fa_ctx* c) {
-    bool any = false;
-    for (auto& k : c->wlog)
-        if (!k.minb_known) {
-            uint32_t* word = k.counts + k.counts_cap + 1;  // (the words behind the time base: min, max)
-            HIPCHK(c, hipMemsetAsync(word, 0xff, sizeof(uint32_t), c->stream));
-            HIPCHK(c, hipMemsetAsync(word + 1, 0, sizeof(uint32_t), c->stream));
-            hipLaunchKernelGGL(wlog_minbucket_kernel, dim3(2048), dim3(256), 0, c->stream, wchunk_args(k), word);
-            HIPCHK(c, hipGetLastError());
-            any = true;
-        }
-    if (!any) return FA_OK;
-    std::vector<uint32_t> mm(2 * c->wlog.size());
-    for (size_t i = 0; i < c->wlog.size(); i++)
-        if (!c->wlog[i].minb_known) HIPCHK(c, hipMemcpyAsync(&mm[2 * i], c->wlog[i].counts + c->wlog[i].counts_cap + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < c->wlog.size(); i++) {
-        fa_ctx::WChunk& k = c->wlog[i];
-        if (!k.minb_known) {
-            k.minb = mm[2 * i];  // (~0: no live tuple at all)
-            k.maxb = mm[2 * i + 1];
-            k.minb_known = true;
-        }
-    }
-    return FA_OK;
-}
-static int wlog_drop(fa_ctx* c, uint32_t lo, uint32_t hi) {
-    if (c->wlog.empty()) return FA_OK;
-    int rc0 = wlog_bucket_ranges(c);
-    if (rc0) return rc0;
-    uint32_t oldest = 0xFFFFFFFFu;  // smallest bucket any pending chunk still holds
-    for (size_t i = 0; i < c->wlog.size(); i++) {
-        fa_ctx::WChunk& k = c->wlog[i];
-        if (k.minb != 0xFFFFFFFFu && k.maxb >= k.wm) oldest = std::min(oldest, std::max(k.minb, k.wm));
-    }
-    if (lo > oldest) return wlog_flush_all(c);  // (a range that is not the oldest: the table's rebuild has to remove it)
-    for (size_t i = 0; i < c->wlog.size();) {
-        fa_ctx::WChunk& k = c->wlog[i];
-        if (hi > k.wm) {
-            k.wm = hi;
-            c->wlog_wm_moves++;
-        }
-        if (k.minb == 0xFFFFFFFFu || k.maxb < k.wm) {  // nothing of this chunk is alive
-            c->wlog_free.push_back(k);
-            c->wlog_dropped++;
-            c->wlog.erase(c->wlog.begin() + (long)i);
-        } else {
-            i++;
-        }
-    }
-    return FA_OK;
-}
-
-// ---- counter snapshots: never lose aggregates ------------------------------------------------------------
-// Every ingest launch is followed by an asynchronous copy of the device counters into a pinned ring slot.  Before
-// the next launch the host looks at the newest snapshot that has landed (no waiting): a table above 50 % load or
-// parked updates are settled (grow + replay) right away, and a launch is only queued while the updates that could
-// be parked by everything in flight still fit the spill buffers - otherwise the host first waits for the newest
-// snapshot.  Steady state costs one 300-byte copy per launch and no synchronisation.
-static void poll_snapshots(fa_ctx* c, bool wait_newest) {
-    if (c->launch_seq == c->known_seq) return;
-    if (wait_newest) (void)hipEventSynchronize(c->snap_ev[(c->launch_seq - 1) % fa_ctx::NSNAP]);
-    for (uint64_t q = c->launch_seq; q > c->known_seq; q--) {  // newest first
-        const int k = (int)((q - 1) % fa_ctx::NSNAP);
-        if (c->snap_seq[k] != q) break;  // overwritten: older ones are gone too
-        if (hipEventQuery(c->snap_ev[k]) == hipSuccess) {
-            c->known = c->h_snap[k];
-            c->known_records = c->snap_records[k];
-            c->known_seq = q;
-            c->known_wpot = c->snap_wpot[k];
-            format_feedback(c, c->known);
-            return;
-        }
-    }
-}
-static int pre_launch_guard(fa_ctx* c, size_t n) {
-    auto verdict = [&]() -> int {  // 0 go, 1 look again after waiting, 2 settle
-        const Counters& h = c->known;
-        if (h.spill_count || h.wspill_count || (c->used_base + h.used) * 2 > (1ull << c->cap_log2) ||
-            (c->wtab && (c->wused_base + h.wused) * 2 > (1ull << c->wcap_log2)))
-            return 2;
-        const uint64_t pot = (c->launched_records - c->known_records) + n;  // records whose updates the host has not seen settle
-        if (pot + (1u << 20) > c->spill_cap || (c->wtab && pot * c->wide_per_record + (1u << 20) > c->wspill_cap)) return 1;
-        return 0;
-    };
-    poll_snapshots(c, false);
-    int v = verdict();
-    if (v == 1) {
-        poll_snapshots(c, true);
-        v = verdict() ? 2 : 0;
-    }
-    return v == 2 ? settle(c) : FA_OK;
-}
-static int post_launch_snapshot(fa_ctx* c, size_t n) {
-    c->launched_records += n;
-    c->launch_seq += 1;
-    const int k = (int)((c->launch_seq - 1) % fa_ctx::NSNAP);
-    HIPCHK(c, hipEventSynchronize(c->snap_ev[k]));  // (the slot's previous copy, NSNAP launches ago)
-    HIPCHK(c, hipMemcpyAsync(&c->h_snap[k], c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipEventRecord(c->snap_ev[k], c->stream));
-    c->snap_records[k] = c->launched_records;
-    c->snap_seq[k] = c->launch_seq;
-    c->snap_wpot[k] = c->wpot_total;
-    return FA_OK;
-}
-
-extern "C" int fa_sync(fa_ctx* c) {
-    FA_ON_DEVICE(c);
-    if (!c) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    return settle(c);
-}
-
-// ---- ingest ---------------------------------------------------------------------------
-// Launch order on the ctx stream: tile -> deferred -> [agg]   (wave-tile kernel: it finds the batch's time base
-// itself; the workgroup-tile kernel with the scatter sink still takes it from probe_kernel).
-template <int MODE>
-static int launch_tiles(fa_ctx* c, KArgs& a, int grid, fa_ctx::LaunchEvents* ev = nullptr) {
-    dim3 b(BLOCK);
-    dim3 g(grid);
-    dim3 ge(std::min(256u, (a.n + BLOCK - 1) / BLOCK));
-    a.par = c->par;
-    c->par ^= 1u;
-    const bool wave_tiles = MODE == MODE_INGEST && a.seg != nullptr && a.tile_recs <= (uint32_t)WT_RECS && c->use_wave_tiles;
-    const bool t8 = wave_tiles && c->use_t8;
-    // (the second-chance kernel runs in line: on a side stream beside the aggregation it cost MORE - 66 vs 58 us for
-    // deferred + aggregation per launch, the cross-stream hand-over being slower than the 4.5 us kernel - and its atomic
-    // upserts would race with the region-owned plain stores of agg8_kernel / cms_agg_kernel; the knob is gone)
-    hipStream_t dstream = c->stream;
-    if (ev) (void)hipEventRecord(ev->e0, c->stream);
-    if (MODE == MODE_INGEST && a.seg && !wave_tiles) hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, c->stream, a);
-    if (wave_tiles) c->stats.wave_tile_launches += 1;
-    if (t8) c->stats.compact_tuple_launches += 1;
-#define FA_LAUNCH_W(KS)                                                                         \
-    do {                                                                                        \
-        if (t8) hipLaunchKernelGGL((wtile_kernel<KS, true>), g, dim3(wtile_block<KS>()), 0, c->stream, a); \
-        else hipLaunchKernelGGL((wtile_kernel<KS, false>), g, dim3(wtile_block<KS>()), 0, c->stream, a);   \
-    } while (0)
-#define FA_LAUNCH(KS)                                                                           \
-    case KS: {                                                                                  \
-        if constexpr (MODE == MODE_INGEST) {                                                    \
-            if (wave_tiles) FA_LAUNCH_W(KS);                                                    \
-            else hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);            \
-        } else {                                                                                \
-            hipLaunchKernelGGL((tile_kernel<MODE, KS>), g, b, 0, c->stream, a);                 \
-        }                                                                                       \
-        if (ev) (void)hipEventRecord(ev->e1, c->stream);                                        \
-        hipLaunchKernelGGL((deferred_kernel<MODE, KS>), ge, b, 0, dstream, a);                  \
-        break;                                                                                  \
-    }
-    if constexpr (MODE == MODE_DECODE) {
-        switch (1u) { FA_LAUNCH(1u) }
-    } else {
-        switch (c->cfg.key_sets) {
-            FA_LAUNCH(1u) FA_LAUNCH(2u) FA_LAUNCH(3u) FA_LAUNCH(4u) FA_LAUNCH(5u) FA_LAUNCH(6u) FA_LAUNCH(7u) FA_LAUNCH(9u)
-        default:  // any wide key set: the generic variant (runtime mask)
-            if (wave_tiles) FA_LAUNCH_W(KS_ALL);
-            else hipLaunchKernelGGL((tile_kernel<MODE, KS_ALL>), g, b, 0, c->stream, a);
-            if (ev) (void)hipEventRecord(ev->e1, c->stream);
-            hipLaunchKernelGGL((deferred_kernel<MODE, KS_ALL>), ge, b, 0, dstream, a);
-            break;
-        }
-    }
-#undef FA_LAUNCH
-#undef FA_LAUNCH_W
-    if (MODE == MODE_INGEST && a.seg) {
-        const dim3 ga((1u << a.plog2) * AGG_SPLIT);
-        if (t8 && AGG_SPLIT == 1 && !c->agg_generic) hipLaunchKernelGGL(agg8_kernel, ga, dim3(AGG_BLOCK), 0, c->stream, a);
-        else if (t8) hipLaunchKernelGGL(agg_kernel<true>, ga, dim3(AGG_BLOCK), 0, c->stream, a);
-        else hipLaunchKernelGGL(agg_kernel<false>, ga, dim3(AGG_BLOCK), 0, c->stream, a);
-    }
-    if (MODE == MODE_INGEST && wave_tiles && a.cseg) {  // fold the sketch tuples (Count-Min scatter sink)
-        const uint32_t set_mask = (c->cfg.key_sets >> 1) & 3u;
-        const uint32_t nlog = CMS_NPART * (set_mask == 3u ? 2u : 1u);
-        hipLaunchKernelGGL(cms_agg_kernel, dim3(std::min<uint32_t>((uint32_t)c->num_cus, nlog)), dim3(AGG_BLOCK), 0, c->stream, a, set_mask, c->cms_par);  // persistent: one per CU
-        c->cms_par ^= 1u;
-    }
-    // fold the (SrcAddr,DstPort,Proto) tuples: one workgroup per table region, plain loads and stores - behind every
-    // dispatch of this launch that updates the wide table with atomics (wagg.cuh)
-    if (MODE == MODE_INGEST && wave_tiles && a.wseg) {
-        if (c->wlog_now) {  // log mode: the tuples stay where they are (the chunk is taken over behind the launch: wlog_record)
-            HIPCHK(c, hipMemcpyAsync(c->wseg_counts + c->wseg_counts_cap, &c->d_ctr->tb_base, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-        } else {
-            hipLaunchKernelGGL(wagg_kernel, dim3(1u << a.wplog2), dim3(WAGG_BLOCK), 0, c->stream, a, (const uint32_t*)nullptr, 0u);
-        }
-    }
-    if (ev) (void)hipEventRecord(ev->e2, c->stream);
-    HIPCHK(c, hipGetLastError());
-    return FA_OK;
-}
-
-template <int MODE>
-static int tile_grid(fa_ctx* c, uint32_t n, uint32_t tile_recs) {
-    if constexpr (MODE == MODE_DECODE) return grid_for(c, tile_kernel<MODE_DECODE, 1u>, n, tile_recs);
-    switch (c->cfg.key_sets) {
-    case 1u: return grid_for(c, tile_kernel<MODE_INGEST, 1u>, n, tile_recs);
-    case 2u: return grid_for(c, tile_kernel<MODE_INGEST, 2u>, n, tile_recs);
-    case 3u: return grid_for(c, tile_kernel<MODE_INGEST, 3u>, n, tile_recs);
-    case 4u: return grid_for(c, tile_kernel<MODE_INGEST, 4u>, n, tile_recs);
-    case 5u: return grid_for(c, tile_kernel<MODE_INGEST, 5u>, n, tile_recs);
-    case 6u: return grid_for(c, tile_kernel<MODE_INGEST, 6u>, n, tile_recs);
-    case 7u: return grid_for(c, tile_kernel<MODE_INGEST, 7u>, n, tile_recs);
-    case 9u: return grid_for(c, tile_kernel<MODE_INGEST, 9u>, n, tile_recs);
-    default: return grid_for(c, tile_kernel<MODE_INGEST, KS_ALL>, n, tile_recs);
-    }
-}
-
-// deferral lists for n records: exotic [0,cap) and retry [cap,2cap)
-static int ensure_exotic(fa_ctx* c, size_t n) {
-    if (c->exotic_cap >= n) return FA_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(c->d_exotic);
-    c->d_exotic = nullptr;
-    size_t cap = std::max<size_t>(n, 1 << 16);
-    if (hipMalloc(&c->d_exotic, 2 * cap * sizeof(uint32_t)) != hipSuccess)
-        return fail(c, FA_ERR_NOMEM, "hipMalloc(deferral lists) failed");
-    c->exotic_cap = cap;
-    return FA_OK;
-}
-
-// Tuple segments for a batch of n records processed by nwg workgroups: capacity per (partition,
-// workgroup) = 2x the mean + 32 (a Poisson mean of m never reaches 2m+32; skewed batches overflow into
-// the direct path), in whole 128-byte lines (8 wide / 16 compact tuples).  The region stride gets a skew of
-// three lines so that consecutive partitions do not alias in L2.
-static int ensure_segments(fa_ctx* c, size_t n, uint32_t nwg, bool t8, KArgs& a) {
-    const size_t NPART = (size_t)1 << c->plog2;
-    const size_t avg = n / ((size_t)nwg * NPART);
-    const uint32_t tpl = (t8 ? 2u : 1u) * bin_line(c->cfg.key_sets);  // tuples per store unit (a 128-byte line; flows_5m alone: half a line)
-    uint32_t capq = (uint32_t)((2 * avg + 32 + tpl - 1) & ~(size_t)(tpl - 1));
-    if (c->seg_cap_limit) capq = std::max<uint32_t>(std::min(capq, c->seg_cap_limit) & ~(tpl - 1), 2 * tpl);  // (tests: force the segment-overflow fallbacks)
-    const size_t region = (size_t)nwg * capq + 3 * tpl;
-    const size_t bytes = region * NPART * (t8 ? 8 : 16);
-    if (c->seg_bytes < bytes) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->seg);
-        c->seg = nullptr;
-        c->seg_bytes = 0;
-        if (hipMalloc(&c->seg, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(tuple segments) failed");
-        c->seg_bytes = bytes;
-    }
-    const size_t ncnt = (size_t)nwg * NPART_MAX * 2;  // front and back counts
-    if (c->seg_counts_cap < ncnt) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->seg_counts);
-        c->seg_counts = nullptr;
-        c->seg_counts_cap = 0;
-        if (hipMalloc(&c->seg_counts, ncnt * sizeof(uint32_t)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(segment counts) failed");
-        c->seg_counts_cap = ncnt;
-    }
-    a.seg = c->seg;
-    a.seg_counts = c->seg_counts;
-    a.capq = capq;
-    // (the LDS position counters are 16-bit halves of one word: caps leave room for the few increments that are in
-    // flight before a full segment's overflow is taken back - sinks.cuh)
-    a.capb = std::min<uint32_t>(std::max<uint32_t>(2 * tpl, (capq / 4) & ~(tpl - 1)), 0xff00u - tpl);  // back part: single tuples, bin leftovers
-    a.capb = std::min(a.capb, capq - tpl);
-    a.capf = std::min<uint32_t>(capq - a.capb, 0xff00u * tpl);                                           // front part: full lines
-    a.nwg = nwg;
-    a.region = region;
-    a.plog2 = c->plog2;
-    c->last_nwg = nwg;
-    return FA_OK;
-}
-
-// Segments of the Count-Min scatter sink for a batch of n records processed by nwg workgroups: per (sketch partition,
-// workgroup) 3x the mean + 32 tuples of 16 bytes (a heavy hitter adds up to one tuple per wave-tile to its partition after
-// the wave-level fold: about as much again as the partition's mean; what still overflows is added with atomics).
-static int ensure_csegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
-    const size_t nparts = (size_t)CMS_SETS * CMS_NPART;
-    const size_t mean = n / ((size_t)CMS_NPART * nwg);
-    uint32_t capq = (uint32_t)((3 * mean + 32 + 3) & ~(size_t)3);
-    if (c->seg_cap_limit) capq = std::max<uint32_t>(std::min(capq, c->seg_cap_limit) & ~3u, 32u);  // (tests: force the overflow fallbacks)
-    const size_t region = (size_t)nwg * capq + 12;
-    const size_t bytes = region * nparts * sizeof(uint4);
-    if (c->cseg_bytes < bytes) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->cseg);
-        c->cseg = nullptr;
-        c->cseg_bytes = 0;
-        if (hipMalloc(&c->cseg, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(sketch tuple segments) failed");
-        c->cseg_bytes = bytes;
-    }
-    const size_t ncnt = (size_t)nwg * nparts * 2;
-    if (c->cseg_counts_cap < ncnt) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->cseg_counts);
-        c->cseg_counts = nullptr;
-        c->cseg_counts_cap = 0;
-        if (hipMalloc(&c->cseg_counts, ncnt * sizeof(uint32_t)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(sketch segment counts) failed");
-        c->cseg_counts_cap = ncnt;
-    }
-    if (c->hot_seed_wgs < nwg) {  // the hot-address caches' surviving entries, one set per workgroup (sinks.cuh, HotAddrs)
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->hot_seed);
-        (void)hipFree(c->hot_seed_tag);
-        c->hot_seed = nullptr;
-        c->hot_seed_tag = nullptr;
-        c->hot_seed_wgs = 0;
-        const size_t ne = (size_t)nwg * CMS_SETS * HOT_SLOTS;
-        if (hipMalloc(&c->hot_seed, ne * sizeof(HotSeed)) != hipSuccess || hipMalloc(&c->hot_seed_tag, ne * sizeof(uint32_t)) != hipSuccess)
-            return fail(c, FA_ERR_NOMEM, "hipMalloc(hot-address seeds) failed");
-        HIPCHK(c, hipMemsetAsync(c->hot_seed_tag, 0, ne * sizeof(uint32_t), c->stream));
-        c->hot_seed_wgs = nwg;
-    }
-    a.hot_seed = c->hot_seed;
-    a.hot_seed_tag = c->hot_seed_tag;
-    a.hot_epoch = c->hot_epoch++;
-    if (!c->cms_psize) {
-        const size_t bytes = (2 * (size_t)CMS_SETS * CMS_NPART + 2) * sizeof(uint32_t);  // (+ the two unit counters)
-        if (hipMalloc(&c->cms_psize, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(sketch partition sizes) failed");
-        HIPCHK(c, hipMemsetAsync(c->cms_psize, 0, bytes, c->stream));
-    }
-    a.cms_psize = c->cms_psize;
-    a.cseg = c->cseg;
-    a.cseg_counts = c->cseg_counts;
-    a.ccapq = capq;
-    a.ccapb = std::min<uint32_t>(std::max<uint32_t>(8u, (capq / 8) & ~3u), 0xff00u);
-    a.ccapf = std::min<uint32_t>(capq - a.ccapb, 0xff00u * CMS_BIN);
-    a.cregion = region;
-    a.cms_sub = c->cfg.cms_width_log2 - 8u;
-    return FA_OK;
-}
-
-// Segments of the wide scatter sink for a batch of n records processed by nwg workgroups: per (table region, workgroup)
-// 2x the mean + 32 tuples of 32 bytes (what overflows - a heavy key's region - takes the atomic path).
-static int ensure_wsegments(fa_ctx* c, size_t n, uint32_t nwg, KArgs& a) {
-    const size_t nparts = (size_t)1 << a.wplog2;
-    const size_t mean = n / (nparts * nwg);
-    uint32_t capq = (uint32_t)(2 * mean + 32);
-    if (c->seg_cap_limit) capq = std::max<uint32_t>(std::min(capq, c->seg_cap_limit), 4u);  // (tests: force the overflow fallback)
-    const size_t region = (size_t)nwg * capq + 6;  // (skew against power-of-two strides)
-    const size_t bytes = region * nparts * 2 * sizeof(uint4);
-    const size_t ncnt = (size_t)nwg * nparts;
-    // Log mode keeps up to wlog_max + 1 pairs of buffers alive (the pending chunks and the one being filled; recycled through
-    // wlog_free).  When another pair cannot be had - hipMalloc fails (FA_WSEG_BUDGET: the tests' stand-in for that) - the
-    // ingest does not fail: buffers on the free list that are too small are released, then the OLDEST pending chunk is folded
-    // into the table after all and its buffers are taken over; only a ctx that holds no chunk at all reports FA_ERR_NOMEM.
-    auto held = [&]() { return (uint32_t)((c->wseg || c->wseg_counts ? 1 : 0) + c->wlog.size() + c->wlog_free.size()); };
-    for (;;) {
-        if (!c->wseg && !c->wseg_counts && !c->wlog_free.empty()) {  // the buffers of a chunk that has been folded or dropped
-            const fa_ctx::WChunk k = c->wlog_free.back();
-            c->wlog_free.pop_back();
-            c->wseg = k.seg;
-            c->wseg_bytes = k.seg_bytes;
-            c->wseg_counts = k.counts;
-            c->wseg_counts_cap = k.counts_cap;
-        }
-        bool ok = true;
-        if (c->wseg_bytes < bytes || c->wseg_counts_cap < ncnt) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));  // (a recycled pair may still be read by its chunk's fold)
-            (void)hipFree(c->wseg);
-            (void)hipFree(c->wseg_counts);
-            c->wseg = nullptr;
-            c->wseg_counts = nullptr;
-            c->wseg_bytes = c->wseg_counts_cap = 0;
-            ok = !(c->wseg_budget && held() + 1u > c->wseg_budget) && hipMalloc(&c->wseg, bytes) == hipSuccess;
-            if (ok) {
-                c->wseg_bytes = bytes;
-                ok = hipMalloc(&c->wseg_counts, (ncnt + 4) * sizeof(uint32_t)) == hipSuccess;  // (+ the time base and minimum bucket words of a log chunk)
-                if (ok) c->wseg_counts_cap = ncnt;
-            }
-            if (!ok) {
-                (void)hipGetLastError();
-                (void)hipFree(c->wseg);
-                c->wseg = nullptr;
-                c->wseg_bytes = 0;
-            }
-        }
-        if (ok) break;
-        if (!c->wlog_free.empty()) continue;  // (the next pair of the free list - released if it is too small as well)
-        if (c->wlog.empty()) return fail(c, FA_ERR_NOMEM, "hipMalloc(wide tuple segments) failed");
-        int rc = wlog_flush_oldest(c);  // its buffers land on the free list
-        if (rc) return rc;
-        c->wlog_nomem_folds++;
-    }
-    a.wseg = c->wseg;
-    a.wseg_counts = c->wseg_counts;
-    a.wcapq = capq;
-    a.wregion = region;
-    a.nwg = nwg;
-    return FA_OK;
-}
-
-static int ensure_dev(fa_ctx* c, void** p, size_t* cap, size_t bytes, const char* what);
-static int frame_split_host(const uint8_t* buf, size_t len, std::vector<uint64_t>& off);
-// Device-side framing (framing.cuh): d_buf[0, len) is a chain of varint(len)-framed records -> *d_off = n + 1 offsets in HBM
-// (owned by the ctx, valid until the next split), *n_out = records.  FA_ERR_FRAMING when it is not such a chain.
-static int frame_split_device(fa_ctx* c, const uint8_t* d_buf, size_t len, const uint32_t** d_off, size_t* n_out) {
-    *d_off = nullptr;
-    *n_out = 0;
-    if (len == 0) return FA_OK;
-    const uint32_t nb = (uint32_t)((len + FS_BLOCK - 1) / FS_BLOCK);
-    size_t tmp_scan = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)nb, c->stream);
-    const size_t arr = ((size_t)nb * 4 + 255) & ~(size_t)255;
-    int rc = ensure_dev(c, &c->fs_scratch, &c->fs_scratch_cap, 7 * arr + tmp_scan + 512, "framing scratch");
-    if (rc) return rc;
-    uint8_t* base = (uint8_t*)c->fs_scratch;
-    uint32_t* start = (uint32_t*)base;
-    uint32_t* exits = (uint32_t*)(base + arr);
-    uint32_t* cnt = (uint32_t*)(base + 2 * arr);
-    uint32_t* bases = (uint32_t*)(base + 3 * arr);
-    uint8_t* err = base + 4 * arr;             // (nb bytes)
-    uint8_t* trust[2] = {base + 5 * arr, base + 6 * arr};  // (nb bytes each)
-    unsigned int* flag = (unsigned int*)(base + 7 * arr);
-    void* tmp = base + 7 * arr + 256;
-    const dim3 gl((nb + 255) / 256), bl(256);
-    HIPCHK(c, hipMemsetAsync(start, 0, sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(fs_guess_kernel, dim3((nb + 3) / 4), bl, 0, c->stream, d_buf, (uint32_t)len, nb, start);
-    HIPCHK(c, hipGetLastError());
-    bool settled = false;
-    int rounds = 0;
-    for (int round = 0; round < FS_MAX_ROUNDS && !settled; round++, rounds++) {
-        const uint8_t* tin = round ? trust[(round - 1) & 1] : nullptr;
-        if (round) hipLaunchKernelGGL(fs_apply_kernel, gl, bl, 0, c->stream, nb, start, (const uint32_t*)exits, tin);
-        HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(unsigned int), c->stream));
-        hipLaunchKernelGGL(fs_walk_kernel, gl, bl, 0, c->stream, d_buf, (uint32_t)len, nb, start, cnt, err, tin, trust[round & 1], exits, flag);
-        HIPCHK(c, hipGetLastError());
-        unsigned int differ = 0;
-        HIPCHK(c, hipMemcpyAsync(&differ, flag, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        settled = differ == 0;
-    }
-    if (getenv("FA_VERBOSE")) fprintf(stderr, "[flowagg framing] %zu bytes, %u blocks: %s after %d round(s)\n", len, nb, settled ? "settled" : "NOT settled (host walk)", rounds);
-    std::vector<uint32_t> h_off;
-    if (settled) {
-        HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(unsigned int), c->stream));
-        hipLaunchKernelGGL(fs_err_kernel, dim3(64), dim3(256), 0, c->stream, (const uint8_t*)err, nb, flag);
-        size_t tb = tmp_scan;
-        if (hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt, bases, (int)nb, c->stream) != hipSuccess) return fail(c, FA_ERR_HIP, "scan failed");
-        unsigned int bad = 0;
-        uint32_t last[2] = {0, 0};
-        HIPCHK(c, hipMemcpyAsync(&bad, flag, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&last[0], bases + (nb - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&last[1], cnt + (nb - 1), 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (bad) return fail(c, FA_ERR_FRAMING, "stream is not a chain of varint-framed records");
-        const size_t n = (size_t)last[0] + last[1];
-        rc = ensure_dev(c, &c->fs_off, &c->fs_off_cap, (n + 1) * sizeof(uint32_t), "frame offsets");
-        if (rc) return rc;
-        hipLaunchKernelGGL(fs_emit_kernel, dim3((nb + 255) / 256), dim3(256), 0, c->stream, d_buf, (uint32_t)len, nb, (const uint32_t*)start, (const uint32_t*)bases,
-                           (uint32_t*)c->fs_off, (uint32_t)n);
-        HIPCHK(c, hipGetLastError());
-        *d_off = (const uint32_t*)c->fs_off;
-        *n_out = n;
-        return FA_OK;
-    }
-    // the guesses did not settle (records longer than several blocks, adversarial bytes): the host walks the stream
-    std::vector<uint8_t> h(len);
-    HIPCHK(c, hipMemcpy(h.data(), d_buf, len, hipMemcpyDeviceToHost));
-    std::vector<uint64_t> off64;
-    rc = frame_split_host(h.data(), len, off64);
-    if (rc) return fail(c, rc, "stream is not a chain of varint-framed records");
-    h_off.assign(off64.begin(), off64.end());
-    rc = ensure_dev(c, &c->fs_off, &c->fs_off_cap, h_off.size() * sizeof(uint32_t), "frame offsets");
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpy(c->fs_off, h_off.data(), h_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    *d_off = (const uint32_t*)c->fs_off;
-    *n_out = h_off.size() - 1;
-    return FA_OK;
-}
-
-// One call's records -> launches.  len = bytes of the whole buffer the offsets point into (the bound the kernels clamp
-// to); bytes = wire bytes of THESE n records (exact or estimated: tile sizing and the bytes_in statistic).
-static int ingest_device_records(fa_ctx* c, const void* d_buf, size_t len, size_t bytes, const void* d_off, size_t n);
-
-extern "C" int fa_ingest_device(fa_ctx* c, const void* d_buf, size_t len, const void* d_off, size_t n) {
-    FA_ON_DEVICE(c);
-    if (!c) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    if (!d_off) {  // offsets == NULL: the stream is split on the device (framing.cuh); n is ignored
-        if (!c->cfg.framed) return fail(c, FA_ERR_ARG, "fa_ingest_device: offsets are required for bare (unframed) records");
-        if (len == 0) return FA_OK;
-        if (!d_buf || len >= (1ull << 32) || ((uintptr_t)d_buf & 15)) return fail(c, FA_ERR_ARG, "fa_ingest_device: bad buffer (16-byte aligned, < 4 GiB)");
-        const uint32_t* off = nullptr;
-        size_t total = 0;
-        int rc = frame_split_device(c, (const uint8_t*)d_buf, len, &off, &total);
-        if (rc) return rc;
-        size_t used = 0;
-        for (size_t i = 0; i < total;) {
-            const size_t m = std::min<size_t>(c->cfg.max_batch_records, total - i);
-            const size_t bytes = i + m == total ? len - used : (size_t)((double)len * (double)m / (double)total);  // (an estimate per launch; exact in sum)
-            rc = ingest_device_records(c, d_buf, len, bytes, off + i, m);
-            if (rc) return rc;
-            used += bytes;
-            i += m;
-        }
-        return FA_OK;
-    }
-    if (n == 0) return FA_OK;
-    if (!d_buf || len >= (1ull << 32) || n > c->cfg.max_batch_records || ((uintptr_t)d_buf & 15) || ((uintptr_t)d_off & 3))
-        return fail(c, FA_ERR_ARG, "fa_ingest_device: bad buffer (16-byte aligned, < 4 GiB, n <= max_batch_records)");
-    return ingest_device_records(c, d_buf, len, len, d_off, n);
-}
-
-static int ingest_device_records(fa_ctx* c, const void* d_buf, size_t len, size_t bytes, const void* d_off, size_t n) {
-    if (n == 0) return FA_OK;
-    // The first big launch of a ctx with the (SrcAddr,DstPort,Proto) key set teaches it what the stream looks like: its first 2^20 (and
-    // a margin) records go ahead as a launch of their own and the host looks at the counters before the rest follows - a stream that
-    // opens a row per record (BASELINE config 5) keeps the rest of that launch in the log instead of folding 16 M rows into the
-    // hash table first (one extra launch and one synchronisation in a ctx's life).
-    if (c->wtab && (c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO) && c->wide_mode == 0 && !c->wide_defer && !c->wide_probed && n >= (1u << 22)) {
-        c->wide_probed = true;
-        const size_t m = ((size_t)1 << 20) + ((size_t)1 << 17);  // (format_feedback wants 2^20 decoded records; some may be refused)
-        const size_t b0 = (size_t)((double)bytes * (double)m / (double)n);
-        int rc0 = ingest_device_records(c, d_buf, len, b0, d_off, m);
-        if (rc0) return rc0;
-        rc0 = settle(c);  // (the counters of those records: format_feedback decides between table, scatter sink and log)
-        if (rc0) return rc0;
-        return ingest_device_records(c, d_buf, len, bytes - b0, (const uint32_t*)d_off + m, n - m);
-    }
-    c->wide_probed = true;
-    if (c->wide_per_record) {
-        // a launch may not be able to park more wide-table updates than the spill buffer holds: split it
-        const size_t lim = (c->wspill_cap - (1u << 20)) / c->wide_per_record;
-        if (n > lim) {
-            for (size_t i = 0; i < n; i += lim) {
-                const size_t m = std::min(lim, n - i);
-                int rc1 = ingest_device_records(c, d_buf, len, (size_t)((double)bytes * (double)m / (double)n), (const uint32_t*)d_off + i, m);
-                if (rc1) return rc1;
-            }
-            return FA_OK;
-        }
-    }
-    // small batches are not worth a second pass: they go straight to the device-wide table
-    const bool scatter = (c->cfg.key_sets & FA_KEYS_AS_PAIR) && (c->sink_mode == 2 || (c->sink_mode == 0 && n >= (1u << 15)));
-    c->use_wave_tiles = scatter && c->tile_mode != 2;
-    // tuple format of this launch (table.cuh): compact 8-byte tuples on the wave-tile kernel with 256 partitions,
-    // unless recent launches showed that this stream's records do not fit them
-    c->use_t8 = c->use_wave_tiles && c->plog2 == 8 && c->t8_mode != 2 && (c->t8_mode == 1 || c->stats.batches >= c->t8_wide_until);
-    if (n > AGG_MAX_BATCH && !c->use_t8) {  // the packed LDS sums of the wide-tuple aggregation hold 2^24 records per launch
-        const size_t h = n / 2;
-        int rc1 = ingest_device_records(c, d_buf, len, bytes / 2, d_off, h);
-        if (rc1) return rc1;
-        return ingest_device_records(c, d_buf, len, bytes - bytes / 2, (const uint32_t*)d_off + h, n - h);
-    }
-    int rc = pre_launch_guard(c, n);
-    if (rc) return rc;
-    rc = ensure_exotic(c, n);
-    if (rc) return rc;
-    KArgs a = make_args(c);
-    a.buf = (const uint8_t*)d_buf;
-    a.off = (const uint32_t*)d_off;
-    a.n = (uint32_t)n;
-    a.len = (uint32_t)len;
-    a.tile_recs = tile_recs_for(bytes, n);
-    int grid = tile_grid<MODE_INGEST>(c, a.n, a.tile_recs);
-    if (c->use_wave_tiles) {  // wave-private tiles: <= 64 records per wave, WBLOCK / 64 waves per workgroup, WT_WG_PER_CU workgroups per CU
-        const double avg = (double)bytes / (double)n;
-        // Tiles are sized by RECORDS: 64 (one per lane) whenever the mean record allows, otherwise as many as fit the
-        // buffer with about two sigma of byte headroom (sigma of a tile ~ 12 B x sqrt(records): a mix of 60- and 84-byte
-        // records).  A tile whose bytes still exceed the buffer is not lost to the slow path any more: the wave takes
-        // its rest as one more part (ingest.cuh) - about 1 tile in 80 on BASELINE config 2, where this fills all 64
-        // lanes instead of 61.
-        // (the kernel variants that serve a sketch run one 16-wave workgroup per CU instead of two 12-wave ones, with
-        // slightly shorter tile buffers: wtile_block, wtile_stride)
-        const bool big_wg = !wt_lean(c->cfg.key_sets);
-        const uint32_t ks = c->cfg.key_sets;
-        auto recs_for = [&](double cap) {
-            double r = cap / avg;
-            r = (cap - 2.0 * 12.0 * std::sqrt(std::min(r, (double)WT_RECS))) / avg;
-            return r >= (double)WT_RECS ? (uint32_t)WT_RECS : r < 1.0 ? 1u : (uint32_t)r;
-        };
-        const double cap = (double)wt_stride((ks >= 1u && ks <= 7u) || ks == 9u ? ks : KS_ALL) - 16.0 - 15.0;  // (the instantiation launch_tiles picks)
-        a.tile_recs = recs_for(cap);
-        const uint32_t wtiles = (a.n + a.tile_recs - 1) / a.tile_recs;
-        const uint32_t waves = (uint32_t)(big_wg ? WBLOCK_CMS : WBLOCK) / 64u;
-        const uint32_t wgs = (wtiles + waves - 1) / waves;
-        grid = (int)std::max(1u, std::min<uint32_t>(wgs, (uint32_t)c->num_cus * (uint32_t)(big_wg ? 1 : WT_WG_PER_CU)));
-        if (a.tile_recs > (uint32_t)WT_RECS) c->use_t8 = false;
-    }
-    if (scatter) {
-        rc = ensure_segments(c, n, (uint32_t)grid, c->use_t8, a);
-        if (rc) return rc;
-    }
-    if (c->use_wave_tiles && (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) && !c->cms_atomic && c->cms_scatter_ok) {
-        rc = ensure_csegments(c, n, (uint32_t)grid, a);
-        if (rc) return rc;
-    }
-    if (c->use_wave_tiles && c->wtab && (c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO) && grid <= WAGG_MAX_NWG &&
-        (c->wide_mode == 2 || c->wide_mode == 3 || (c->wide_mode == 0 && c->wide_scatter))) {
-        rc = ensure_wsegments(c, n, (uint32_t)grid, a);
-        if (rc) return rc;
-        c->wlog_now = c->wide_mode == 3 || (c->wide_mode == 0 && c->wide_defer);
-    } else {
-        c->wlog_now = false;
-    }
-    if (c->ev_used == c->ev_pool.size()) {
-        if (c->ev_pool.size() >= 4096) {  // bound the pool: fold what is pending
-            rc = settle(c);
-            if (rc) return rc;
-        } else {
-            fa_ctx::LaunchEvents e{};
-            HIPCHK(c, hipEventCreate(&e.e0));
-            HIPCHK(c, hipEventCreate(&e.e1));
-            HIPCHK(c, hipEventCreate(&e.e2));
-            c->ev_pool.push_back(e);
-        }
-    }
-    fa_ctx::LaunchEvents* evp = &c->ev_pool[c->ev_used++];
-    if (c->wtab) c->wpot_total += (uint64_t)n * c->wide_per_record;  // (rows this launch may open in the wide table: wide_rows_bound)
-    rc = launch_tiles<MODE_INGEST>(c, a, grid, evp);
-    if (rc) return rc;
-    if (c->wlog_now && a.wseg) {
-        rc = wlog_record(c, a, n);
-        if (rc) return rc;
-    } else if (c->wide_mode == 0 && !c->wide_defer && !c->wlog.empty()) {
-        // the library left the log mode: what is pending drains - a chunk per launch while wagg_kernel can take it (1.2 ms), one
-        // in eight launches when the table has grown since and it is the atomic replay (13 ms for 16.67 M tuples)
-        const fa_ctx::WChunk& k = c->wlog.front();
-        if ((k.wplog2 == a.wplog2 && k.wmask == a.wmask) || c->stats.batches % 8 == 0) {
-            rc = wlog_flush_oldest(c);
-            if (rc) return rc;
-        }
-    }
-    rc = post_launch_snapshot(c, n);
-    if (rc) return rc;
-    c->stats.bytes_in += bytes;
-    c->stats.batches += 1;
-    if (c->cfg.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
-        c->cms_dirty = true;
-        c->merged_valid = false;
-    }
-    return FA_OK;
-}
-
-// Splits a chain of framed records on the host (offsets == NULL).
-static int frame_split_host(const uint8_t* buf, size_t len, std::vector<uint64_t>& off) {
-    size_t p = 0;
-    off.clear();
-    while (p < len) {
-        off.push_back(p);
-        uint64_t v = 0;
-        int i = 0;
-        for (;; i++) {
-            if (i >= 10 || p >= len) return FA_ERR_FRAMING;
-            uint8_t b = buf[p++];
-            if (i < 9)
-                v |= (uint64_t)(b & 0x7f) << (7 * i);
-            else
-                v |= (uint64_t)(b & 1) << 63;
-            if (!(b & 0x80)) break;
-        }
-        if (v > len - p) return FA_ERR_FRAMING;
-        p += v;
-    }
-    off.push_back(len);
-    return FA_OK;
-}
-
-static int ensure_stage(fa_ctx* c, int s, size_t bytes) {
-    if (c->h_stage_cap[s] < bytes) {
-        if (c->h_stage[s]) (void)hipHostFree(c->h_stage[s]);
-        c->h_stage[s] = nullptr;
-        size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 20);
-        if (hipHostMalloc(&c->h_stage[s], cap) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipHostMalloc(staging) failed");
-        c->h_stage_cap[s] = cap;
-    }
-    if (c->d_in_cap[s] < bytes) {
-        (void)hipFree(c->d_in[s]);
-        c->d_in[s] = nullptr;
-        size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 20);
-        if (hipMalloc(&c->d_in[s], cap) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(input) failed");
-        c->d_in_cap[s] = cap;
-    }
-    return FA_OK;
-}
-
-// Copies [buf,len) + offsets into pinned staging slot and uploads.  On return the
-// caller's memory is no longer referenced.  Layout in the slot: bytes, pad to 16,
-// 32 B slack, then n+1 uint32 offsets.
-static int stage_and_upload(fa_ctx* c, const uint8_t* buf, size_t len, const uint64_t* off, size_t n,
-                            const uint8_t** d_buf, const uint32_t** d_off, int* slot) {
-    if (len >= (1ull << 32) - 64) return fail(c, FA_ERR_ARG, "batch larger than 4 GiB; split it");
-    int s = c->stage_cur;
-    c->stage_cur ^= 1;
-    size_t off_pos = ((len + 15) & ~(size_t)15) + 32;
-    size_t total = off_pos + (n + 1) * sizeof(uint32_t);
-    HIPCHK(c, hipEventSynchronize(c->stage_ev[s]));  // slot free again?
-    int rc = ensure_stage(c, s, total);
-    if (rc) return rc;
-    uint8_t* hs = c->h_stage[s];
-    uint32_t* ho = reinterpret_cast<uint32_t*>(hs + off_pos);
-    // the copy into pinned memory and the u64 -> u32 narrowing of the offsets run on a few host threads: one thread
-    // moves ~10 GB/s, the PCIe Gen5 link behind it 63 GB/s (env FA_STAGE_THREADS, default 8; small batches: inline)
-    unsigned nthr = c->stage_threads;
-    if (len + n * 12 < (8u << 20)) nthr = 1;
-    std::atomic<int> bad{0};
-    auto work = [&](unsigned t) {
-        const size_t b0 = len * t / nthr, b1 = len * (t + 1) / nthr;
-        if (b1 > b0) memcpy(hs + b0, buf + b0, b1 - b0);
-        const size_t i0 = (n + 1) * t / nthr, i1 = (n + 1) * (t + 1) / nthr;
-        uint64_t prev = i0 ? off[i0 - 1] : 0;
-        for (size_t i = i0; i < i1; i++) {
-            const uint64_t o = off[i];
-            if (o < prev || o > len) {
-                bad.store(1);
-                return;
-            }
-            prev = o;
-            ho[i] = (uint32_t)o;
-        }
-    };
-    if (nthr <= 1) {
-        nthr = 1;
-        work(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nthr; t++) pool.emplace_back(work, t);
-        work(0);
-        for (auto& th : pool) th.join();
-    }
-    if (bad.load()) return fail(c, FA_ERR_ARG, "offsets must be non-decreasing and <= len");
-    memset(hs + len, 0, off_pos - len);
-    HIPCHK(c, hipMemcpyAsync(c->d_in[s], hs, total, hipMemcpyHostToDevice, c->stream));
-    *slot = s;  // caller records stage_ev[s] once the kernels reading d_in[s] are enqueued
-    *d_buf = c->d_in[s];
-    *d_off = reinterpret_cast<const uint32_t*>(c->d_in[s] + off_pos);
-    return FA_OK;
-}
-
-extern "C" int fa_ingest(fa_ctx* c, const uint8_t* buf, size_t len, const uint64_t* offsets, size_t n) {
-    FA_ON_DEVICE(c);
-    if (!c) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    if (!buf && len) return fail(c, FA_ERR_ARG, "fa_ingest: null buffer");
-    std::vector<uint64_t> split;
-    if (!offsets && c->cfg.framed && len && len <= (1ull << 30)) {
-        // a framed stream without offsets: the bytes are uploaded as they are and cut into records on the device (framing.cuh);
-        // the host walk below - 1 GB/s - only serves streams beyond one staging buffer
-        const uint64_t whole[2] = {0, len};
-        const uint8_t* d_buf;
-        const uint32_t* d_off;
-        int slot = 0;
-        int rc = stage_and_upload(c, buf, len, whole, 1, &d_buf, &d_off, &slot);
-        if (rc) return rc;
-        rc = fa_ingest_device(c, d_buf, len, nullptr, 0);
-        HIPCHK(c, hipEventRecord(c->stage_ev[slot], c->stream));
-        return rc;
-    }
-    if (!offsets) {
-        if (!c->cfg.framed) return fail(c, FA_ERR_ARG, "fa_ingest: offsets are required for bare (unframed) records");
-        int rc = frame_split_host(buf, len, split);
-        if (rc) return fail(c, rc, "fa_ingest: stream is not a chain of varint-framed records");
-        offsets = split.data();
-        n = split.size() - 1;
-    }
-    if (n == 0) return FA_OK;
-    // chunk so that each launch stays under max_batch_records and 1 GiB of wire bytes
-    size_t i = 0;
-    while (i < n) {
-        size_t j = std::min(n, i + (size_t)c->cfg.max_batch_records);
-        while (j > i + 1 && offsets[j] - offsets[i] > (1ull << 30)) j = i + (j - i) / 2;
-        std::vector<uint64_t> rel;
-        const uint64_t* o = offsets + i;
-        uint64_t base = offsets[i];
-        if (base) {
-            rel.resize(j - i + 1);
-            for (size_t k = 0; k <= j - i; k++) {
-                if (offsets[i + k] < base) return fail(c, FA_ERR_ARG, "offsets must be non-decreasing");
-                rel[k] = offsets[i + k] - base;
-            }
-            o = rel.data();
-        }
-        if (offsets[j] > len || offsets[j] < base) return fail(c, FA_ERR_ARG, "offsets exceed len");
-        const uint8_t* d_buf;
-        const uint32_t* d_off;
-        int slot = 0;
-        int rc = stage_and_upload(c, buf + base, (size_t)(offsets[j] - base), o, j - i, &d_buf, &d_off, &slot);
-        if (rc) return rc;
-        rc = fa_ingest_device(c, d_buf, (size_t)(offsets[j] - base), d_off, j - i);
-        if (rc) return rc;
-        HIPCHK(c, hipEventRecord(c->stage_ev[slot], c->stream));
-        i = j;
-    }
-    return FA_OK;
-}
-
-// ---- decode + project ---------------------------------------------------------------------
-static int ensure_columns(fa_ctx* c, size_t n) {
-    if (c->col_cap >= n) return FA_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(c->col_block);
-    c->col_block = nullptr;
-    size_t cap = std::max<size_t>(n, 1 << 16);
-    cap = (cap + 63) & ~(size_t)63;
-    size_t bytes = cap * (5 * 8 + 7 * 4 + 3 * 16 + 1);
-    if (hipMalloc(&c->col_block, bytes) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(columns) failed");
-    uint8_t* p = (uint8_t*)c->col_block;
-    auto take = [&](size_t elem) {
-        uint8_t* r = p;
-        p += cap * elem;
-        return r;
-    };
-    c->cols.sampler_address = (uint4*)take(16);
-    c->cols.src_addr = (uint4*)take(16);
-    c->cols.dst_addr = (uint4*)take(16);
-    c->cols.time_received = (uint64_t*)take(8);
-    c->cols.time_flow_start = (uint64_t*)take(8);
-    c->cols.sampling_rate = (uint64_t*)take(8);
-    c->cols.bytes = (uint64_t*)take(8);
-    c->cols.packets = (uint64_t*)take(8);
-    c->cols.sequence_num = (uint32_t*)take(4);
-    c->cols.src_as = (uint32_t*)take(4);
-    c->cols.dst_as = (uint32_t*)take(4);
-    c->cols.etype = (uint32_t*)take(4);
-    c->cols.proto = (uint32_t*)take(4);
-    c->cols.src_port = (uint32_t*)take(4);
-    c->cols.dst_port = (uint32_t*)take(4);
-    c->cols.status = (uint8_t*)take(1);
-    c->col_cap = cap;
-    return FA_OK;
-}
-
-extern "C" int fa_decode_device(fa_ctx* c, const void* d_buf, size_t len, const void* d_off, size_t n,
-                                fa_columns* out) {
-    FA_ON_DEVICE(c);
-    FA_ON_DEVICE(c);
-    if (!c || !out) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    if (!d_buf || !d_off || len >= (1ull << 32) || n > c->cfg.max_batch_records || ((uintptr_t)d_buf & 15))
-        return fail(c, FA_ERR_ARG, "fa_decode_device: bad buffer");
-    int rc = ensure_columns(c, std::max<size_t>(n, 1));
-    if (rc) return rc;
-    rc = ensure_exotic(c, std::max<size_t>(n, 1));
-    if (rc) return rc;
-    if (n) {
-        KArgs a = make_args(c);
-        a.buf = (const uint8_t*)d_buf;
-        a.off = (const uint32_t*)d_off;
-        a.n = (uint32_t)n;
-        a.len = (uint32_t)len;
-        a.tile_recs = tile_recs_for(len, n);
-        if (c->dev_used == c->dev_pool.size()) {
-            if (c->dev_pool.size() >= 1024) {  // bound the pool: fold what is pending
-                rc = settle(c);
-                if (rc) return rc;
-            } else {
-                fa_ctx::LaunchEvents e{};
-                HIPCHK(c, hipEventCreate(&e.e0));
-                HIPCHK(c, hipEventCreate(&e.e1));
-                HIPCHK(c, hipEventCreate(&e.e2));
-                c->dev_pool.push_back(e);
-            }
-        }
-        rc = launch_tiles<MODE_DECODE>(c, a, tile_grid<MODE_DECODE>(c, a.n, a.tile_recs), &c->dev_pool[c->dev_used++]);
-        if (rc) return rc;
-    }
-    out->time_received = c->cols.time_received;
-    out->time_flow_start = c->cols.time_flow_start;
-    out->sampling_rate = c->cols.sampling_rate;
-    out->bytes = c->cols.bytes;
-    out->packets = c->cols.packets;
-    out->sequence_num = c->cols.sequence_num;
-    out->src_as = c->cols.src_as;
-    out->dst_as = c->cols.dst_as;
-    out->etype = c->cols.etype;
-    out->proto = c->cols.proto;
-    out->src_port = c->cols.src_port;
-    out->dst_port = c->cols.dst_port;
-    out->sampler_address = (const uint8_t*)c->cols.sampler_address;
-    out->src_addr = (const uint8_t*)c->cols.src_addr;
-    out->dst_addr = (const uint8_t*)c->cols.dst_addr;
-    out->status = c->cols.status;
-    return FA_OK;
-}
-
-extern "C" int fa_decode(fa_ctx* c, const uint8_t* buf, size_t len, const uint64_t* offsets, size_t n,
-                         fa_flow_row* out) {
-    FA_ON_DEVICE(c);
-    FA_ON_DEVICE(c);
-    if (!c || (!out && n)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    if (!offsets) return fail(c, FA_ERR_ARG, "fa_decode: offsets required");
-    size_t done = 0;
-    while (done < n) {
-        size_t j = std::min(n, done + (size_t)std::min<uint32_t>(c->cfg.max_batch_records, 1u << 22));
-        while (j > done + 1 && offsets[j] - offsets[done] > (1ull << 30)) j = done + (j - done) / 2;
-        size_t m = j - done;
-        uint64_t base = offsets[done];
-        std::vector<uint64_t> rel(m + 1);
-        for (size_t k = 0; k <= m; k++) {
-            if (offsets[done + k] < base || offsets[done + k] > len) return fail(c, FA_ERR_ARG, "bad offsets");
-            rel[k] = offsets[done + k] - base;
-        }
-        const uint8_t* d_buf;
-        const uint32_t* d_off;
-        int slot = 0;
-        int rc = stage_and_upload(c, buf + base, (size_t)rel[m], rel.data(), m, &d_buf, &d_off, &slot);
-        if (rc) return rc;
-        fa_columns cols;
-        rc = fa_decode_device(c, d_buf, (size_t)rel[m], d_off, m, &cols);
-        if (rc) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        // gather SoA -> AoS on the host
-        std::vector<uint64_t> u64(m);
-        std::vector<uint32_t> u32(m);
-        std::vector<uint8_t> b16(m * 16), st(m);
-        fa_flow_row* o = out + done;
-        memset(o, 0, m * sizeof(fa_flow_row));
-#define GET64(member, src)                                                                  \
-    HIPCHK(c, hipMemcpy(u64.data(), src, m * 8, hipMemcpyDeviceToHost));                    \
-    for (size_t k = 0; k < m; k++) o[k].member = u64[k];
-#define GET32(member, src)                                                                  \
-    HIPCHK(c, hipMemcpy(u32.data(), src, m * 4, hipMemcpyDeviceToHost));                    \
-    for (size_t k = 0; k < m; k++) o[k].member = u32[k];
-#define GET16(member, src)                                                                  \
-    HIPCHK(c, hipMemcpy(b16.data(), src, m * 16, hipMemcpyDeviceToHost));                   \
-    for (size_t k = 0; k < m; k++) memcpy(o[k].member, &b16[k * 16], 16);
-        GET64(time_received, cols.time_received)
-        GET64(time_flow_start, cols.time_flow_start)
-        GET64(sampling_rate, cols.sampling_rate)
-        GET64(bytes, cols.bytes)
-        GET64(packets, cols.packets)
-        GET32(sequence_num, cols.sequence_num)
-        GET32(src_as, cols.src_as)
-        GET32(dst_as, cols.dst_as)
-        GET32(etype, cols.etype)
-        GET32(proto, cols.proto)
-        GET32(src_port, cols.src_port)
-        GET32(dst_port, cols.dst_port)
-        GET16(sampler_address, cols.sampler_address)
-        GET16(src_addr, cols.src_addr)
-        GET16(dst_addr, cols.dst_addr)
-#undef GET64
-#undef GET32
-#undef GET16
-        HIPCHK(c, hipMemcpy(st.data(), cols.status, m, hipMemcpyDeviceToHost));
-        for (size_t k = 0; k < m; k++) o[k].status = st[k];
-        done = j;
-    }
-    return FA_OK;
-}
+#include "maintain_host.inc"
+#include "ingest_host.inc"
+#include "decode_host.inc"
+#include "format_host.inc"
+#include "state_host.inc"
 
 // ---- window close: see rows_host.inc (included below) ------------------------------------------------
 // timeslot -> bucket range.  With sub-windows a window [timeslot, timeslot+window_secs)
@@ -1827,364 +579,8 @@ static bool bucket_range(const fa_ctx* c, uint32_t timeslot, uint32_t& lo, uint3
 }
 
 
-// ---- RowBinary sink -------------------------------------------------------------------------------
-// ClickHouse RowBinary: fixed-width little-endian integers, arrays as LEB128 length + elements; Nested
-// columns travel as one array per sub-column (format restated from the ClickHouse documentation; no
-// server in this image to load it into).
-extern "C" int fa_rows_to_rowbinary(const fa_row5m* rows, size_t n, uint8_t* out, size_t cap, size_t* bytes_out) {
-    if ((!rows && n) || !bytes_out) return FA_ERR_ARG;
-    const size_t need = n * (size_t)FA_ROWBINARY_ROW5M_BYTES;
-    *bytes_out = need;
-    if (need > cap || (!out && need)) return FA_ERR_CAPACITY;
-    uint8_t* p = out;
-    auto put = [&](uint64_t v, int bytes) {
-        for (int i = 0; i < bytes; i++) *p++ = (uint8_t)(v >> (8 * i));
-    };
-    for (size_t i = 0; i < n; i++) {
-        const fa_row5m& r = rows[i];
-        if (r.date > 0xFFFFu) return FA_ERR_ARG;
-        put(r.date, 2);
-        put(r.timeslot, 4);
-        put(r.src_as, 4);
-        put(r.dst_as, 4);
-        put(1, 1); put(r.etype, 4);    // ETypeMap.EType   [EType]
-        put(1, 1); put(r.bytes, 8);    // ETypeMap.Bytes   [Bytes]
-        put(1, 1); put(r.packets, 8);  // ETypeMap.Packets [Packets]
-        put(1, 1); put(r.count, 8);    // ETypeMap.Count   [Count]
-        put(r.bytes, 8);
-        put(r.packets, 8);
-        put(r.count, 8);
-    }
-    return FA_OK;
-}
-
-// ---- dashboard address rendering (viz-ch.json:233,479) ---------------------------------------------
-// IPv6NumToString is restated from BIND's inet_ntop6 (the algorithm ClickHouse's formatIPv6 follows and glibc
-// ships; the CPU test-suite checks this function against glibc on random and structured addresses).
-extern "C" int fa_format_addr(const uint8_t addr[16], uint32_t etype, char* out, size_t cap) {
-    if (!addr || !out) return FA_ERR_ARG;
-    char tmp[FA_ADDR_STRLEN + 2];
-    char* p = tmp;
-    auto dec = [&](unsigned v) {
-        if (v >= 100) *p++ = (char)('0' + v / 100);
-        if (v >= 10) *p++ = (char)('0' + v / 10 % 10);
-        *p++ = (char)('0' + v % 10);
-    };
-    auto dotted = [&](const uint8_t* b) {
-        for (int i = 0; i < 4; i++) {
-            if (i) *p++ = '.';
-            dec(b[i]);
-        }
-    };
-    if (etype == 0x800) {
-        dotted(addr);
-    } else {
-        unsigned w[8];
-        for (int i = 0; i < 8; i++) w[i] = ((unsigned)addr[2 * i] << 8) | addr[2 * i + 1];
-        int best = -1, best_len = 0, cur = -1, cur_len = 0;
-        for (int i = 0; i < 8; i++) {
-            if (w[i] == 0) {
-                if (cur < 0) cur = i, cur_len = 1;
-                else cur_len++;
-            } else if (cur >= 0) {
-                if (best < 0 || cur_len > best_len) best = cur, best_len = cur_len;
-                cur = -1;
-            }
-        }
-        if (cur >= 0 && (best < 0 || cur_len > best_len)) best = cur, best_len = cur_len;
-        if (best >= 0 && best_len < 2) best = -1;
-        bool done = false;
-        for (int i = 0; i < 8 && !done; i++) {
-            if (best >= 0 && i >= best && i < best + best_len) {
-                if (i == best) *p++ = ':';
-                continue;
-            }
-            if (i) *p++ = ':';
-            if (i == 6 && best == 0 && (best_len == 6 || (best_len == 5 && w[5] == 0xffffu))) {
-                dotted(addr + 12);  // encapsulated IPv4
-                done = true;
-                break;
-            }
-            static const char hex[] = "0123456789abcdef";
-            bool lead = true;
-            for (int s = 12; s >= 0; s -= 4) {
-                unsigned d = (w[i] >> s) & 15u;
-                if (d || !lead || s == 0) *p++ = hex[d], lead = false;
-            }
-        }
-        if (!done && best >= 0 && best + best_len == 8) *p++ = ':';
-    }
-    *p++ = 0;
-    const size_t need = (size_t)(p - tmp);
-    if (need > cap) return FA_ERR_CAPACITY;
-    memcpy(out, tmp, need);
-    return FA_OK;
-}
-
-// ---- wide key sets: window close and dashboard reads -----------------------------------------------
-// rows (already packed keys) -> device -> wmerge_kernel
-static int merge_wide(fa_ctx* c, const std::vector<WRow>& rows) {
-    if (!c->wtab) return fail(c, FA_ERR_ARG, "key set not enabled");
-    if (rows.empty()) return FA_OK;
-    WRow* d = nullptr;
-    if (hipMalloc(&d, rows.size() * sizeof(WRow)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc failed");
-    hipError_t e = hipMemcpyAsync(d, rows.data(), rows.size() * sizeof(WRow), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        KArgs a = make_args(c);
-        hipLaunchKernelGGL(wmerge_kernel, dim3(256), dim3(256), 0, c->stream, d, (uint32_t)rows.size(), a);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    if (e != hipSuccess) {
-        c->err = std::string("merge_wide: ") + hipGetErrorString(e);
-        return FA_ERR_HIP;
-    }
-    return settle(c);
-}
-
-extern "C" int fa_merge_rows_app(fa_ctx* c, const fa_row_app* rows, size_t n) {
-    FA_ON_DEVICE(c);
-    if (!c || (!rows && n)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    if (!(c->cfg.key_sets & FA_KEYS_ADDR_PORT_PROTO)) return fail(c, FA_ERR_ARG, "FA_KEYS_ADDR_PORT_PROTO not enabled");
-    std::vector<WRow> w(n);
-    for (size_t i = 0; i < n; i++) {
-        if (rows[i].timeslot % c->gran) return fail(c, FA_ERR_ARG, "fa_merge_rows_app: timeslot not on this ctx's bucket grid");
-        uint64_t lo, hi;
-        memcpy(&lo, rows[i].src_addr, 8);
-        memcpy(&hi, rows[i].src_addr + 8, 8);
-        WKey k;
-        wkey_pack(WK_APP, rows[i].timeslot / c->gran, lo, hi, rows[i].dst_port, rows[i].proto, k);
-        w[i] = WRow{{k.w[0], k.w[1], k.w[2], k.w[3]}, rows[i].bytes, rows[i].packets, rows[i].count};
-    }
-    return merge_wide(c, w);
-}
-
-__global__ void port_merge_kernel(const fa_port_row* rows, uint32_t n, ulonglong2* hist) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        unsigned long long* e = reinterpret_cast<unsigned long long*>(&hist[rows[i].port]);
-        if (rows[i].weight) atomicAdd(e, (unsigned long long)rows[i].weight);
-        atomicAdd(e + 1, (unsigned long long)rows[i].count);
-    }
-}
-
-extern "C" int fa_merge_ports(fa_ctx* c, int dst, const fa_port_row* rows, size_t n) {
-    FA_ON_DEVICE(c);
-    if (!c || (!rows && n) || (dst != 0 && dst != 1)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    if (!c->port_hist) return fail(c, FA_ERR_ARG, "FA_KEYS_PORT_HIST not enabled");
-    std::vector<fa_port_row> small;
-    std::vector<WRow> big;
-    for (size_t i = 0; i < n; i++) {
-        if (rows[i].port < PORT_DENSE) {
-            small.push_back(rows[i]);
-        } else {
-            WKey k;
-            wkey_pack(dst ? WK_DSTPORT : WK_SRCPORT, 0, 0, 0, rows[i].port, 0, k);
-            big.push_back(WRow{{k.w[0], k.w[1], k.w[2], k.w[3]}, rows[i].weight, 0, rows[i].count});
-        }
-    }
-    if (!small.empty()) {
-        fa_port_row* d = nullptr;
-        if (hipMalloc(&d, small.size() * sizeof(fa_port_row)) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc failed");
-        hipError_t e = hipMemcpyAsync(d, small.data(), small.size() * sizeof(fa_port_row), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(port_merge_kernel, dim3(64), dim3(256), 0, c->stream, d, (uint32_t)small.size(),
-                               c->port_hist + (size_t)dst * PORT_DENSE);
-            e = hipGetLastError();
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        (void)hipFree(d);
-        if (e != hipSuccess) {
-            c->err = std::string("fa_merge_ports: ") + hipGetErrorString(e);
-            return FA_ERR_HIP;
-        }
-    }
-    return merge_wide(c, big);
-}
-
-extern "C" int fa_merge_minutes(fa_ctx* c, const fa_minute_row* rows, size_t n) {
-    FA_ON_DEVICE(c);
-    if (!c || (!rows && n)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    if (!(c->cfg.key_sets & FA_KEYS_MINUTE_SERIES)) return fail(c, FA_ERR_ARG, "FA_KEYS_MINUTE_SERIES not enabled");
-    std::vector<WRow> w(n);
-    for (size_t i = 0; i < n; i++) {
-        if (rows[i].minute % 60u) return fail(c, FA_ERR_ARG, "fa_merge_minutes: not a minute boundary");
-        WKey k;
-        wkey_pack(WK_MINUTE, 0, 0, 0, rows[i].minute / 60u, 0, k);
-        w[i] = WRow{{k.w[0], k.w[1], k.w[2], k.w[3]}, rows[i].weight, 0, rows[i].count};
-    }
-    return merge_wide(c, w);
-}
-
-extern "C" int fa_dashboard_reset(fa_ctx* c) {
-    FA_ON_DEVICE(c);
-    if (!c) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    int rc = settle(c);
-    if (rc) return rc;
-    if (c->port_hist) HIPCHK(c, hipMemsetAsync(c->port_hist, 0, sizeof(ulonglong2) * 2 * PORT_DENSE, c->stream));
-    if (c->wtab && (c->cfg.key_sets & (FA_KEYS_PORT_HIST | FA_KEYS_MINUTE_SERIES)))
-        return rebuild_wide(c, c->wcap_log2, (1u << WK_SRCPORT) | (1u << WK_DSTPORT) | (1u << WK_MINUTE), 0, 0);
-    return FA_OK;
-}
-
-// ---- sketches -----------------------------------------------------------------------------------
-// Sums the sketch copies into copy 0 (sinks.cuh, cms_add).  Every reader of a sketch calls this first.
-static int cms_fold(fa_ctx* c) {
-    if (!c->cms_dirty) return FA_OK;
-    for (unsigned long long* p : {c->cms_src, c->cms_dst})
-        if (p) hipLaunchKernelGGL(cms_fold_kernel, dim3(2048), dim3(256), 0, c->stream, p, c->cms_words);
-    HIPCHK(c, hipGetLastError());
-    c->cms_dirty = false;
-    return FA_OK;
-}
-
-// the sketch readers answer from: the merged (all-rank) view while it is valid, the ctx's own sketch otherwise
-static unsigned long long* cms_of(fa_ctx* c, uint32_t key_set) {
-    if (key_set == FA_KEYS_SRCADDR_CMS) return c->merged_valid && c->cms_src_m ? c->cms_src_m : c->cms_src;
-    if (key_set == FA_KEYS_DSTADDR_CMS) return c->merged_valid && c->cms_dst_m ? c->cms_dst_m : c->cms_dst;
-    return nullptr;
-}
-static int ensure_merged_view(fa_ctx* c) {
-    for (int d = 0; d < 2; d++) {
-        unsigned long long* own = d ? c->cms_dst : c->cms_src;
-        unsigned long long** m = d ? &c->cms_dst_m : &c->cms_src_m;
-        if (own && !*m && hipMalloc(m, c->cms_words * 8) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc(merged sketch view) failed");
-    }
-    return FA_OK;
-}
-
-extern "C" int fa_cms_read(fa_ctx* c, uint32_t key_set, uint64_t* out, size_t cap_words) {
-    FA_ON_DEVICE(c);
-    if (!c || !out) return FA_ERR_ARG;
-    unsigned long long* p = cms_of(c, key_set);
-    if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
-    if (cap_words < c->cms_words) return fail(c, FA_ERR_CAPACITY, "sketch buffer too small");
-    int rc = settle(c);
-    if (rc) return rc;
-    HIPCHK(c, hipMemcpy(out, p, c->cms_words * 8, hipMemcpyDeviceToHost));
-    return FA_OK;
-}
-
-extern "C" int fa_cms_reset(fa_ctx* c, uint32_t key_set) {
-    FA_ON_DEVICE(c);
-    if (!c) return FA_ERR_ARG;
-    unsigned long long* p = key_set == FA_KEYS_SRCADDR_CMS ? c->cms_src : key_set == FA_KEYS_DSTADDR_CMS ? c->cms_dst : nullptr;
-    if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
-    c->merged_valid = false;
-    HIPCHK(c, hipMemsetAsync(p, 0, c->cms_words * 8 * CMS_REPLICAS, c->stream));
-    KeySlot* ks = key_set == FA_KEYS_SRCADDR_CMS ? c->ks_src : c->ks_dst;
-    if (ks) HIPCHK(c, hipMemsetAsync(ks, 0, sizeof(KeySlot) << c->ks_log2, c->stream));
-    return FA_OK;
-}
-
-static uint32_t cms_column_host(const uint8_t key[16], uint64_t seed, uint32_t wl2, uint32_t row) {
-    uint64_t lo, hi, h1, h2;
-    memcpy(&lo, key, 8);
-    memcpy(&hi, key + 8, 8);
-    cms_hash2(lo, hi, seed, h1, h2);  // (sinks.cuh: the one definition, host and device)
-    return cms_column(cms_key(h1, h2, wl2), row, wl2);
-}
-
-extern "C" int fa_cms_query(fa_ctx* c, uint32_t key_set, const uint8_t key[16], uint64_t* weight) {
-    FA_ON_DEVICE(c);
-    if (!c || !key || !weight) return FA_ERR_ARG;
-    unsigned long long* p = cms_of(c, key_set);
-    if (!p) return fail(c, FA_ERR_ARG, "key set not enabled");
-    int rc = settle(c);
-    if (rc) return rc;
-    uint64_t best = ~0ull;
-    for (uint32_t r = 0; r < c->cfg.cms_depth; r++) {
-        size_t idx = ((size_t)r << c->cfg.cms_width_log2) + cms_column_host(key, c->cfg.cms_seed, c->cfg.cms_width_log2, r);
-        unsigned long long v;
-        HIPCHK(c, hipMemcpy(&v, p + idx, 8, hipMemcpyDeviceToHost));
-        best = std::min<uint64_t>(best, v);
-    }
-    *weight = best;
-    return FA_OK;
-}
-
-extern "C" int fa_topk_merge_keys(fa_ctx* c, uint32_t key_set, const uint8_t* keys, size_t n) {
-    FA_ON_DEVICE(c);
-    if (!c || (!keys && n)) return FA_ERR_ARG;
-    if (c->sticky) return c->sticky;
-    KeySlot* ks = key_set == FA_KEYS_SRCADDR_CMS ? c->ks_src : key_set == FA_KEYS_DSTADDR_CMS ? c->ks_dst : nullptr;
-    if (!ks) return fail(c, FA_ERR_ARG, "fa_topk_merge_keys: key set not enabled");
-    if (!n) return FA_OK;
-    uint4* d = nullptr;
-    if (hipMalloc(&d, n * 16) != hipSuccess) return fail(c, FA_ERR_NOMEM, "hipMalloc failed");
-    hipError_t e = hipMemcpyAsync(d, keys, n * 16, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) {
-        KArgs a = make_args(c);
-        hipLaunchKernelGGL(keyset_merge_kernel, dim3(256), dim3(256), 0, c->stream, d, (uint32_t)n, ks, a);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    if (e != hipSuccess) {
-        c->err = std::string("fa_topk_merge_keys: ") + hipGetErrorString(e);
-        return FA_ERR_HIP;
-    }
-    return FA_OK;
-}
-
 #include "rows_host.inc"
-
-extern "C" int fa_device_state_get(fa_ctx* c, fa_device_state* out) {
-    FA_ON_DEVICE(c);
-    if (!c || !out) return FA_ERR_ARG;
-    int rc = settle(c);
-    if (rc) return rc;
-    out->cms_src = c->cms_src;
-    out->cms_dst = c->cms_dst;
-    out->cms_words = c->cms_words;
-    out->port_hist = c->port_hist;
-    out->port_hist_words = c->port_hist ? (size_t)4 * PORT_DENSE : 0;
-    rc = ensure_merged_view(c);
-    if (rc) return rc;
-    out->cms_src_merged = c->cms_src_m;
-    out->cms_dst_merged = c->cms_dst_m;
-    return FA_OK;
-}
-
-extern "C" int fa_merged_view_set(fa_ctx* c, int valid) {
-    FA_ON_DEVICE(c);
-    if (!c) return FA_ERR_ARG;
-    if (valid && ((c->cms_src && !c->cms_src_m) || (c->cms_dst && !c->cms_dst_m))) return fail(c, FA_ERR_ARG, "fa_merged_view_set: no merged view (call fa_device_state_get first)");
-    c->merged_valid = valid != 0;
-    return FA_OK;
-}
-
-// RCCL is bound lazily so that libflowagg.so loads on hosts without librccl.
-#include <dlfcn.h>
-extern "C" int fa_merge_allreduce(fa_ctx* c, void* comm) {
-    FA_ON_DEVICE(c);
-    if (!c || !comm) return FA_ERR_ARG;
-    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
-    static allreduce_fn fn = nullptr;
-    if (!fn) {
-        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (h) fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
-        if (!fn) return fail(c, FA_ERR_UNSUPPORTED, "librccl.so / ncclAllReduce not found");
-    }
-    int rc = settle(c);  // (folds the sketch copies into copy 0)
-    if (rc) return rc;
-    rc = ensure_merged_view(c);
-    if (rc) return rc;
-    const int ncclUint64 = 5, ncclSum = 0;  // rccl.h: ncclDataType_t / ncclRedOp_t
-    c->merged_valid = false;
-    if (c->cms_src && fn(c->cms_src, c->cms_src_m, c->cms_words, ncclUint64, ncclSum, comm, c->stream) != 0)
-        return fail(c, FA_ERR_HIP, "ncclAllReduce(cms_src) failed");
-    if (c->cms_dst && fn(c->cms_dst, c->cms_dst_m, c->cms_words, ncclUint64, ncclSum, comm, c->stream) != 0)
-        return fail(c, FA_ERR_HIP, "ncclAllReduce(cms_dst) failed");
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->merged_valid = true;
-    return FA_OK;
-}
+#include "group_host.inc"
 
 extern "C" int fa_stats(fa_ctx* c, fa_stats_t* out) {
     FA_ON_DEVICE(c);

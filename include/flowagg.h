@@ -203,10 +203,14 @@ int fa_ingest(fa_ctx*, const uint8_t* buf, size_t len, const uint64_t* offsets, 
  * n+1 uint32 offsets relative to d_buf (so len < 4 GiB per call).  Asynchronous
  * on the ctx stream; fa_sync() or any result call waits.
  * ABI 6: d_offsets may be NULL when cfg.framed - the chain of varint(len)-framed records is then cut into records ON THE
- * DEVICE (block starts guessed by 64 walks per 16 KiB block, proven by a fixed-point pass, offsets emitted; n is ignored,
- * the call may become several launches).  FA_ERR_FRAMING when the bytes are not such a chain ending at len.  Three extra
- * passes over the bytes: about a third of the rate of a call WITH offsets (which a Kafka consumer has for free: one
- * message = one record) - the path for framed dumps.  fa_ingest (host buffers, offsets == NULL, len <= 1 GiB) uses it too. */
+ * DEVICE (per 16 KiB block the first frame start is guessed - the first of the block's 256 leading byte positions from which two
+ * consecutive frames are non-empty protobuf messages with ascending field numbers that end where their length prefix says -
+ * then proven by a fixed-point pass over all blocks, offsets emitted; n is ignored, the call may become several launches).
+ * FA_ERR_FRAMING when the bytes are not such a chain ending at len.  A chain whose guesses do not settle in 12 rounds (records
+ * longer than several blocks, producers that do not marshal in field order) is copied back and walked on the host - same
+ * result, slower.  Several passes over the bytes: a sixth to a third of the rate of a call WITH offsets (which a Kafka consumer
+ * has for free: one message = one record) - the path for framed dumps.  fa_ingest (host buffers, offsets == NULL, 1 MiB <= len
+ * <= 1 GiB) uses it too; smaller host buffers are walked on the host. */
 int fa_ingest_device(fa_ctx*, const void* d_buf, size_t len, const void* d_offsets, size_t n);
 
 int fa_sync(fa_ctx*);
@@ -264,7 +268,7 @@ int fa_rows_device(fa_ctx*, int kind, uint32_t timeslot, size_t k, const void** 
 int fa_rows_merge_device(fa_ctx*, int kind, const void* d_rows, size_t n, size_t k, const void** d_out, size_t* n_out);
 /* ABI 6 - hash-partitioned window close, for row sets too large to gather on every rank ((SrcAddr,DstPort,Proto): a
  * window of BASELINE config 5 is 16.6 M rows x 56 B PER RANK).  The n rows of `kind` at d_rows (DEVICE; a fa_rows_device
- * result) are regrouped by owner: rank r of `world` owns the keys with hash(key) * world >> 64 == r (the same function of
+ * result) are regrouped by owner: rank r of `world` owns the keys with (hash(key) >> 32) * world >> 32 == r (the same function of
  * the key on every rank, independent of the row's sums).  *d_out: DEVICE pointer to the n rows, group 0 first (order
  * inside a group unspecified), owned by the ctx, valid until its next fa_rows_partition_device; counts[r] (HOST array of
  * `world` entries) = rows of group r.  The ranks then exchange the groups with ONE all-to-all (RCCL: all_to_all_single
