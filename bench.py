@@ -169,6 +169,130 @@ def cpu_baseline(po, gp, per_thread, n_rec, groups_hint, reps=3):
     return out
 
 
+def gpu_clocks(device):
+    """sclk / mclk of `device` as rocm-smi reports them right now (MHz; None when rocm-smi is missing or says nothing): the
+    ingest kernel follows the core clock (same box, a minute apart: 7 %), so the line records what it ran at."""
+    import re
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        js = json.loads(r.stdout[r.stdout.index("{"):]) if "{" in r.stdout else {}
+    except (OSError, ValueError, subprocess.TimeoutExpired):
+        return None
+    out = {}
+    for card in js.values():
+        if not isinstance(card, dict):
+            continue
+        for k, v in card.items():
+            m = re.search(r"(\d+)\s*Mhz", str(v), re.I)
+            for name in ("sclk", "mclk", "fclk", "socclk"):
+                if name in k.lower() and m:
+                    out[name + "_mhz"] = int(m.group(1))
+    return out or None
+
+
+def preflight(fa, torch, dist, rank, world, local_rank, backend, xdev):
+    """world > 1, before anything is timed: the three exchanges of a window close on tiny KNOWN data - the uneven all-gather of
+    device row buffers, the all-to-all with split sizes, the in-library ncclAllReduce through a communicator made here with
+    ncclCommInitRank - each checked against numpy.  The first run on an 8-GPU node can then tell a failing collective from a
+    failing kernel: a mismatch or an exception here names the exchange, with the tail of this rank's NCCL_DEBUG=WARN log."""
+    import ctypes as C
+    t0 = time.perf_counter()
+    res = {"ok": False}
+    import socket
+    dbg = os.environ.get("NCCL_DEBUG_FILE", "").replace("%h", socket.gethostname()).replace("%p", str(os.getpid()))
+    try:
+        dev = torch.device("cuda", local_rank)
+        ids = [torch.zeros(2, dtype=torch.int64, device=xdev) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([local_rank, rank], dtype=torch.int64, device=xdev))
+        res["device_ids"] = [int(t[0].item()) for t in ids]
+        res["rccl_ranks_seen"] = len({int(t[1].item()) for t in ids})
+        res["backend"] = backend
+        rb = fa.ROW5M_DTYPE.itemsize
+
+        def rows_for(src, n, dst_as):
+            r = np.zeros(n, dtype=fa.ROW5M_DTYPE)
+            r["date"], r["timeslot"] = fa.T0 // 86400, fa.T0
+            r["src_as"], r["dst_as"], r["etype"] = np.arange(n), dst_as, 0x800
+            r["bytes"], r["packets"], r["count"] = src + 1, 2 * (src + 1), 1
+            return r
+
+        with fa.FlowAgg(device=local_rank, framed=True, key_sets=7, cms_width_log2=12, topk_capacity_log2=12) as pf:
+            # 1. uneven all-gather: rank r brings r + 1 rows (keys 0..r) -> key i is held by the ranks r >= i
+            mine = torch.from_numpy(rows_for(rank, rank + 1, 7).view(np.uint8).copy()).to(dev)
+            buf, total = fa.dist.allgather_device_rows(mine.data_ptr(), rank + 1, rb)
+            ptr, m = pf.rows_merge_device(fa.ROWS_5M, buf.data_ptr(), total)
+            got = pf.rows_fetch(fa.ROWS_5M, ptr, m)
+            want = rows_for(0, world, 7)
+            for i in range(world):
+                held = np.arange(i, world)
+                want["bytes"][i], want["packets"][i], want["count"][i] = (held + 1).sum(), 2 * (held + 1).sum(), len(held)
+            res["allgather_uneven"] = bool(total == world * (world + 1) // 2 and got.tobytes() == want.tobytes())
+            # 2. all-to-all with split sizes: rank s sends s + d + 1 rows to rank d (dst_as = d names the receiver)
+            counts = [rank + d + 1 for d in range(world)]
+            send = np.concatenate([rows_for(rank, rank + d + 1, d) for d in range(world)])
+            sbuf = torch.from_numpy(send.view(np.uint8).copy()).to(dev)
+            rbuf, rtot = fa.dist.alltoall_device_rows(sbuf.data_ptr(), counts, rb)
+            recv = np.frombuffer(rbuf.cpu().numpy().tobytes(), dtype=fa.ROW5M_DTYPE)
+            res["all_to_all_split"] = bool(rtot == sum(s + rank + 1 for s in range(world)) and
+                                           recv.tobytes() == np.concatenate([rows_for(s, s + rank + 1, rank) for s in range(world)]).tobytes())
+            # 3. fa_merge_allreduce (ncclAllReduce inside libflowagg) through a communicator of our own: every rank's sketch of its
+            #    own tiny stream -> merged view == the sum of all ranks' sketches (gathered over torch.distributed, summed in numpy)
+            mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=900 + rank, n_total=4096, zipf_log2_universe=10)
+            hb, ho = fa.mock_generate_host(mp, 0, 4096)
+            pf.ingest(hb, ho)
+            own = pf.cms_read(fa.FA_KEYS_SRCADDR_CMS).reshape(-1).astype(np.int64)
+            parts = [torch.zeros(own.size, dtype=torch.int64, device=xdev) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(own).to(xdev))
+            want_sk = sum(p.cpu().numpy().astype(np.uint64) for p in parts)
+            if backend == "nccl":
+                rccl = None
+                for name in ("librccl.so", "librccl.so.1", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), "/opt/rocm/lib/librccl.so"):
+                    try:
+                        rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+                        break
+                    except OSError:
+                        pass
+                assert rccl is not None, "librccl.so not found"
+
+                class UniqueId(C.Structure):
+                    _fields_ = [("internal", C.c_char * 128)]
+                uid = UniqueId()
+                if rank == 0:
+                    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0, "ncclGetUniqueId failed"
+                t = torch.from_numpy(np.frombuffer(bytes(uid), dtype=np.uint8).copy()).to(xdev)
+                dist.broadcast(t, src=0)
+                C.memmove(C.byref(uid), t.cpu().numpy().tobytes(), 128)
+                comm = C.c_void_p()
+                rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+                assert rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0, "ncclCommInitRank failed"
+                pf.merge_allreduce(comm.value)
+                got_sk = pf.cms_read(fa.FA_KEYS_SRCADDR_CMS).reshape(-1)
+                rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+                rccl.ncclCommDestroy(comm)
+                res["in_library_allreduce"] = bool(np.array_equal(got_sk, want_sk))
+            else:
+                fa.dist.allreduce_sketches(pf)  # (ranks share a GPU: RCCL cannot put two ranks on one device - the gloo twin)
+                res["in_library_allreduce"] = "skipped (backend %s: ranks share a GPU); torch.distributed twin: %s" % (
+                    backend, bool(np.array_equal(pf.cms_read(fa.FA_KEYS_SRCADDR_CMS).reshape(-1), want_sk)))
+        flags = [res["allgather_uneven"], res["all_to_all_split"], res["in_library_allreduce"] is True or
+                 (isinstance(res["in_library_allreduce"], str) and res["in_library_allreduce"].endswith("True"))]
+        t = torch.tensor([1 if all(flags) else 0], dtype=torch.int64, device=xdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        res["ok"] = bool(int(t.item()))
+    except Exception as e:  # noqa: BLE001 - whatever failed, say which exchange and show the RCCL log
+        res["error"] = "%s: %s" % (type(e).__name__, e)
+    res["seconds"] = time.perf_counter() - t0
+    if not res["ok"]:
+        tail = ""
+        if dbg and os.path.exists(dbg):
+            with open(dbg, errors="replace") as f:
+                tail = "".join(f.readlines()[-40:])
+        sys.stderr.write("bench.py preflight FAILED on rank %d: %s\n--- NCCL_DEBUG=WARN tail (%s) ---\n%s\n" % (rank, json.dumps(res), dbg or "stderr", tail))
+        raise SystemExit(3)
+    return res
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (the driver's N=1
     command shape with another N must not die at argument parsing).  One rank per GPU over RCCL; on a box with fewer
@@ -212,6 +336,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the full-step parity check against the oracle")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the PCIe-inclusive fa_ingest measurement")
     ap.add_argument("--no-assert", action="store_true", help="ablation runs (FA_DEBUG_FLAGS): skip result checks")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --records is the WHOLE job's step, split evenly over the ranks "
+                    "(default: weak - every rank is a Kafka partition with --records of its own)")
+    ap.add_argument("--no-preflight", action="store_true", help="world > 1: skip the check of the three window-close exchanges on known data")
     args = ap.parse_args()
 
     import torch
@@ -234,6 +361,8 @@ def main():
     xdev = dev if backend == "nccl" else torch.device("cpu")  # where the window-close exchange tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")  # (quiet unless something is wrong; the preflight shows its tail on failure)
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/fa_bench_rccl.%h.%p.log")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -243,7 +372,11 @@ def main():
     fa.build()
     mode = {"mocker": fa.MOCK_MOCKER, "aspairs": fa.MOCK_ASPAIRS, "zipf": fa.MOCK_ZIPF, "goflow": fa.MOCK_GOFLOW,
             "reversed": fa.MOCK_REVERSED, "distinct": fa.MOCK_DISTINCT}[args.mode]
-    n_rec = args.records
+    n_rec = args.records // world if args.strong else args.records
+    clocks = {"start": gpu_clocks(local_rank)} if rank == 0 else None
+    pre = None
+    if world > 1 and not args.no_preflight:
+        pre = preflight(fa, torch, dist, rank, world, local_rank, backend, xdev)
     # every rank = one Kafka partition with its own stream (seed 2 = config 2, + rank)
     mp = fa.mock_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000,
                         zipf_s_x100=args.zipf_s, zipf_log2_universe=args.zipf_universe_log2)
@@ -294,6 +427,8 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     st1 = agg.stats()
+    if clocks is not None:
+        clocks["end"] = gpu_clocks(local_rank)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -310,7 +445,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic",
@@ -382,6 +517,10 @@ def main():
     fmt = "compact8" if compact == launches else "wide16" if compact == 0 else "mixed (%d of %d launches compact)" % (compact, launches)
     ks_name = "AS_PAIR" if args.key_sets == 1 else "KS_ALL" if args.key_sets > 7 else str(args.key_sets)
     out = dict(common)
+    if clocks is not None:
+        out["clocks"] = clocks
+    if pre is not None:
+        out["preflight"] = pre
     out["config"] = {
         "workload": ("BASELINE configs[1]: 1xMI355X per rank, %d mocker-shaped framed FlowMessages, "
                      "64k SrcAS/DstAS pairs x 2 ETypes x 3 five-minute windows, sum(Bytes,Packets)+count() group-by" % n_rec)
@@ -460,17 +599,26 @@ def main():
             rows = check.read_window()
             cst = check.stats()
             check.close()
-            ref = po.bench_rollup_ex(gp, first, m, threads, groups_hint=len(rows), want_rows=world > 1)
+            ref = po.bench_rollup_ex(gp, first, m, threads, groups_hint=len(rows), want_rows=True)
             ok = ok and rows_checksum(rows) == ref["checksum"] and ref["bad"] == 0 and cst["records_bad"] == 0 \
                 and ref["wire_bytes"] == w and ref["groups"] == len(rows)
-            if world > 1:
-                oracle_parts.append(ref["rows"])
+            oracle_parts.append(ref["rows"])
             verified += m
         parity = {"ok": bool(ok), "records_verified": int(verified), "of_records_per_step": n_rec,
                   "how": "per launch: GPU flows_5m rows vs C-oracle rows of the same records (row count, wire bytes, "
                          "order-independent checksum over keys and sums)"}
+        mine = fa.dist.merge_rows_host(oracle_parts)
+        if world == 1:
+            # the TIMED ctx itself: the rows it handed out at window close == the oracle's rollup of the step, sums x the steps
+            # it ingested (warm-up included) - byte for byte (the per-launch check above runs through fresh contexts)
+            want = mine.copy()
+            with np.errstate(over="ignore"):
+                for f in ("bytes", "packets", "count"):
+                    want[f] = want[f] * np.uint64(total_steps)
+            parity["timed_ctx_rows_equal_oracle"] = bool(want.tobytes() == np.ascontiguousarray(merged).tobytes())
+            parity["ok"] = parity["ok"] and parity["timed_ctx_rows_equal_oracle"]
+            parity["how"] += "; the timed context's own window-close rows vs the oracle's rollup x %d steps (byte-identical)" % total_steps
         if world > 1:
-            mine = fa.dist.merge_rows_host(oracle_parts)
             want = fa.dist.merge_rows_host(fa.dist.allgather_struct(mine, fa.dist.ROW5M_DTYPE, device=xdev))
             with np.errstate(over="ignore"):
                 for f in ("bytes", "packets", "count"):

@@ -124,7 +124,11 @@ EXPORTS = [
     "fa_read_window_app", "fa_close_window_app", "fa_merge_rows_app", "fa_top_ports", "fa_merge_ports",
     "fa_minute_series", "fa_merge_minutes", "fa_dashboard_reset", "fa_rows_to_rowbinary", "fa_format_addr",
     "fa_row_bytes", "fa_rows_device", "fa_rows_merge_device", "fa_rows_fetch", "fa_drop_window", "fa_rows_partition_device", "fa_drop_range",
+    "fa_group_create", "fa_group_destroy", "fa_group_last_error", "fa_group_size", "fa_group_transport", "fa_group_open_timeslots",
+    "fa_group_read_window", "fa_group_close_window", "fa_group_read_window_partitioned", "fa_group_close_window_partitioned",
+    "fa_group_allreduce_sketches", "fa_group_topk", "fa_group_stats",
 ]
+GROUP_PEER, GROUP_RCCL = 0, 1
 # row kinds of the device-resident window close (include/flowagg.h, ABI 5)
 ROWS_5M, ROWS_APP, ROWS_PORT_SRC, ROWS_PORT_DST, ROWS_MINUTE, ROWS_TOPK_SRC, ROWS_TOPK_DST = range(7)
 
@@ -238,6 +242,22 @@ def lib():
     L.fa_rows_partition_device.argtypes = [vp, C.c_int, vp, sz, u32, C.POINTER(vp), szp]
     L.fa_drop_window.argtypes = [vp, C.c_int, u32]
     L.fa_drop_range.argtypes = [vp, C.c_int, u32, u32]
+    L.fa_group_create.argtypes = [C.POINTER(vp), sz, u32, C.POINTER(vp)]
+    L.fa_group_destroy.argtypes = [vp]
+    L.fa_group_destroy.restype = None
+    L.fa_group_last_error.argtypes = [vp]
+    L.fa_group_last_error.restype = C.c_char_p
+    L.fa_group_size.argtypes = [vp]
+    L.fa_group_size.restype = sz
+    L.fa_group_transport.argtypes = [vp]
+    L.fa_group_open_timeslots.argtypes = [vp, vp, sz, szp]
+    L.fa_group_read_window.argtypes = [vp, C.c_int, u32, sz, vp, sz, szp]
+    L.fa_group_close_window.argtypes = [vp, C.c_int, u32, vp, sz, szp]
+    L.fa_group_read_window_partitioned.argtypes = [vp, C.c_int, u32, vp, sz, szp, szp]
+    L.fa_group_close_window_partitioned.argtypes = [vp, C.c_int, u32, vp, sz, szp, szp]
+    L.fa_group_allreduce_sketches.argtypes = [vp]
+    L.fa_group_topk.argtypes = [vp, u32, sz, vp, sz, szp]
+    L.fa_group_stats.argtypes = [vp, C.POINTER(Stats)]
     _LIB = L
     return L
 
@@ -582,3 +602,94 @@ class FlowAgg:
         self._chk(self._L.fa_mock_generate_device(self._h, C.byref(mp), i0, n, d_buf_ptr, cap,
                                                   d_off_ptr, C.byref(w)))
         return w.value
+
+
+class FlowGroup:
+    """The window close of several contexts inside ONE process (ABI 7, fa_group_*): one FlowAgg per (Kafka partition, GPU),
+    results merged in HBM.  The multi-process twin is flow-pipeline_amd.dist (one rank per GPU under torchrun)."""
+
+    def __init__(self, members, transport=GROUP_PEER):
+        self._L = lib()
+        self.members = list(members)
+        arr = (C.c_void_p * len(self.members))(*[m._h for m in self.members])
+        h = C.c_void_p()
+        rc = self._L.fa_group_create(arr, len(self.members), transport, C.byref(h))
+        if rc:
+            raise FlowAggError(rc, (self._L.fa_group_last_error(None) or b"").decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fa_group_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc:
+            raise FlowAggError(rc, (self._L.fa_group_last_error(self._h) or b"").decode())
+
+    @property
+    def transport(self) -> int:
+        return self._L.fa_group_transport(self._h)
+
+    def _rows(self, call, kind, cap=1 << 12):
+        n = C.c_size_t()
+        while True:
+            out = np.empty(cap, dtype=ROW_DTYPES[kind])
+            rc = call(out, cap, n)
+            if rc == -6:
+                cap = n.value
+                continue
+            self._chk(rc)
+            return out[:n.value]
+
+    def open_timeslots(self) -> np.ndarray:
+        n = C.c_size_t()
+        cap = 1 << 10
+        while True:
+            out = np.zeros(cap, dtype=np.uint32)
+            rc = self._L.fa_group_open_timeslots(self._h, out.ctypes.data, cap, C.byref(n))
+            if rc == -6:
+                cap = n.value
+                continue
+            self._chk(rc)
+            return out[:n.value].copy()
+
+    def read_window(self, kind=ROWS_5M, timeslot=ALL_TIMESLOTS, k=0, cap=1 << 12) -> np.ndarray:
+        return self._rows(lambda out, c, n: self._L.fa_group_read_window(self._h, kind, timeslot, k, out.ctypes.data, c, C.byref(n)), kind, cap)
+
+    def close_window(self, kind=ROWS_5M, timeslot=ALL_TIMESLOTS, cap=1 << 12) -> np.ndarray:
+        return self._rows(lambda out, c, n: self._L.fa_group_close_window(self._h, kind, timeslot, out.ctypes.data, c, C.byref(n)), kind, cap)
+
+    def _part(self, fn, kind, timeslot, cap):
+        shares = (C.c_size_t * len(self.members))()
+        rows = self._rows(lambda out, c, n: fn(self._h, kind, timeslot, out.ctypes.data, c, shares, C.byref(n)), kind, cap)
+        return rows, [int(v) for v in shares]
+
+    def read_window_partitioned(self, kind=ROWS_APP, timeslot=ALL_TIMESLOTS, cap=1 << 12):
+        """-> (rows, share sizes): the members' shares back to back, share 0 first; a key lives in exactly one share."""
+        return self._part(self._L.fa_group_read_window_partitioned, kind, timeslot, cap)
+
+    def close_window_partitioned(self, kind=ROWS_APP, timeslot=ALL_TIMESLOTS, cap=1 << 12):
+        return self._part(self._L.fa_group_close_window_partitioned, kind, timeslot, cap)
+
+    def allreduce_sketches(self):
+        self._chk(self._L.fa_group_allreduce_sketches(self._h))
+
+    def topk(self, key_set, k) -> np.ndarray:
+        out = np.zeros(max(int(k), 1), dtype=TOPK_DTYPE)
+        n = C.c_size_t()
+        self._chk(self._L.fa_group_topk(self._h, key_set, int(k), out.ctypes.data, len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._chk(self._L.fa_group_stats(self._h, C.byref(s)))
+        return s.as_dict()

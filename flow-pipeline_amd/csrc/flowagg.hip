@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 

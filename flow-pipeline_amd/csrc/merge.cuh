@@ -357,4 +357,27 @@ __global__ void rows5m_check_kernel(const Row5m* rows, uint32_t n, uint32_t gran
         if (rows[i].timeslot % gran) atomicAdd(bad, 1u);
 }
 
+// window close of a group of contexts (group_host.inc): member r's slice of a sketch = its own slice + the same slice of every
+// other member, staged back to back (stride words apart) in the member's exchange buffer.  Plain 16-byte loads and stores,
+// every word read once: n x slice bytes at the copy rate.  own / stage / out are 16-byte aligned, w is even or the tail is
+// taken by the last thread.
+__global__ __launch_bounds__(256) void group_sum_kernel(const unsigned long long* own, const unsigned long long* stage, uint32_t nstage, size_t stride, size_t w,
+                                                        unsigned long long* out) {
+    const size_t pairs = w / 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+        ulonglong2 s = reinterpret_cast<const ulonglong2*>(own)[i];
+        for (uint32_t q = 0; q < nstage; q++) {
+            const ulonglong2 v = reinterpret_cast<const ulonglong2*>(stage + (size_t)q * stride)[i];
+            s.x += v.x;
+            s.y += v.y;
+        }
+        reinterpret_cast<ulonglong2*>(out)[i] = s;
+    }
+    if ((w & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long s = own[w - 1];
+        for (uint32_t q = 0; q < nstage; q++) s += stage[(size_t)q * stride + w - 1];
+        out[w - 1] = s;
+    }
+}
+
 }  // namespace fa

@@ -18,7 +18,11 @@
 //
 // Differences from the reference, on purpose (same as the Go shim):
 //   - messages are marked AFTER the sink accepted the batch (the reference marks first, inserter.go:188);
-//   - one aggregation context per claimed partition, no global mutex (inserter.go:84,115);
+//   - one aggregation context per claimed partition, no global mutex (inserter.go:84,115): partition p lives on GPU
+//     p % -gpu.devices; the contexts form ONE group (fa_group_*, include/flowagg.h ABI 7) and windows are closed for the
+//     whole topic - flows_5m rows merged over the partitions in HBM, (SrcAddr,DstPort,Proto) rows hash-partitioned over
+//     the GPUs, sketches all-reduced, top-k of the merged sketch.  Flushes (fa_ingest, one goroutine's ctx) hold a read
+//     lock, a close the write lock: a group call uses every member;
 //   - insert_count is actually incremented.
 #include <atomic>
 #include <chrono>
@@ -30,6 +34,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -53,6 +58,8 @@ struct Flags {
     long KeySets = FA_KEYS_AS_PAIR;
     std::string InputFiles, InputFormat = "framed";
     std::string OutRowBinary, OutTsv, OffsetsOut, MetricsDump;
+    std::string OutApp, OutTopk, GpuTransport = "peer";  // raw fa_row_app records / "src|dst <hex key> <weight>" lines; peer | rccl
+    long TopkK = 100;
     bool DryRun = false;  // test double for the host logic: batches are logged, nothing is computed
     bool CloseAllAtEnd = true;
 };
@@ -122,11 +129,12 @@ static Flags parse_flags(int argc, char** argv) {
         {"kafka.group", &f.KafkaGroup}, {"postgres.user", &f.PostgresUser}, {"postgres.pass", &f.PostgresPass},
         {"postgres.host", &f.PostgresHost}, {"postgres.dbname", &f.PostgresDbName}, {"input.files", &f.InputFiles},
         {"input.format", &f.InputFormat}, {"out.rowbinary", &f.OutRowBinary}, {"out.tsv", &f.OutTsv},
-        {"offsets.out", &f.OffsetsOut}, {"metrics.dump", &f.MetricsDump}};
+        {"offsets.out", &f.OffsetsOut}, {"metrics.dump", &f.MetricsDump}, {"out.app", &f.OutApp}, {"out.topk", &f.OutTopk},
+        {"gpu.transport", &f.GpuTransport}};
     std::map<std::string, long*> ints = {
         {"flush.count", &f.FlushCount}, {"postgres.port", &f.PostgresPort}, {"gpu.devices", &f.GpuDevices},
         {"window.secs", &f.WindowSecs}, {"window.lag", &f.CloseLagSec},
-        {"key.sets", &f.KeySets}};
+        {"key.sets", &f.KeySets}, {"topk.k", &f.TopkK}};
     std::map<std::string, bool*> bools = {{"proto.fixedlen", &f.ProtoFixed}, {"sink.dryrun", &f.DryRun},
                                           {"window.closeall", &f.CloseAllAtEnd}};
     for (int i = 1; i < argc; i++) {
@@ -167,6 +175,7 @@ struct ConsumerMessage {
 };
 
 struct ConsumerGroupSession {
+    std::vector<int32_t> claims;  // sarama: session.Claims()[topic] - the partitions this member of the consumer group owns
     std::mutex mu;
     std::map<int32_t, int64_t> marked;  // partition -> next offset to consume (sarama: offset+1 is committed)
     void MarkMessage(const ConsumerMessage& m, const char* /*metadata*/) {
@@ -231,6 +240,25 @@ public:
     void open(const Flags& f) {
         if (!f.OutRowBinary.empty() && !(rb_ = fopen(f.OutRowBinary.c_str(), "wb"))) fatal("cannot open %s", f.OutRowBinary.c_str());
         if (!f.OutTsv.empty() && !(tsv_ = fopen(f.OutTsv.c_str(), "w"))) fatal("cannot open %s", f.OutTsv.c_str());
+        if (!f.OutApp.empty() && !(app_ = fopen(f.OutApp.c_str(), "wb"))) fatal("cannot open %s", f.OutApp.c_str());
+        if (!f.OutTopk.empty() && !(topk_ = fopen(f.OutTopk.c_str(), "w"))) fatal("cannot open %s", f.OutTopk.c_str());
+    }
+    bool wantsApp() const { return app_ != nullptr; }
+    bool wantsTopk() const { return topk_ != nullptr; }
+    void writeApp(const std::vector<fa_row_app>& rows) {  // (SrcAddr,DstPort,Proto) rows of a closed window, as they are
+        if (rows.empty() || !app_) return;
+        std::lock_guard<std::mutex> g(mu_);
+        if (fwrite(rows.data(), sizeof(fa_row_app), rows.size(), app_) != rows.size()) fatal("short write on the app-rows sink");
+        RowsOut += rows.size();
+    }
+    void writeTopk(const char* which, const std::vector<fa_topk_row>& rows) {
+        if (!topk_) return;
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto& r : rows) {
+            fprintf(topk_, "%s\t", which);
+            for (int i = 0; i < 16; i++) fprintf(topk_, "%02x", r.key[i]);
+            fprintf(topk_, "\t%llu\n", (unsigned long long)r.weight);
+        }
     }
     void write(const std::vector<fa_row5m>& rows) {
         if (rows.empty()) return;
@@ -250,13 +278,17 @@ public:
     void close() {
         if (rb_) fclose(rb_);
         if (tsv_) fclose(tsv_);
-        rb_ = tsv_ = nullptr;
+        if (app_) fclose(app_);
+        if (topk_) fclose(topk_);
+        rb_ = tsv_ = app_ = topk_ = nullptr;
     }
 
 private:
     std::mutex mu_;
     FILE* rb_ = nullptr;
     FILE* tsv_ = nullptr;
+    FILE* app_ = nullptr;
+    FILE* topk_ = nullptr;
 };
 
 // one aggregation context per claimed partition (fa_ctx is not thread-safe; distinct ctxs are independent)
@@ -271,7 +303,36 @@ class State : public ConsumerGroupHandler {
 public:
     State(const Flags& f, RowWriter& w) : f_(f), out_(w) {}
 
-    int Setup(ConsumerGroupSession&) override { return 0; }
+    // Setup: the session knows its claims (sarama: session.Claims()) - one ctx per claimed partition, partition p on GPU
+    // p % -gpu.devices (north star: 8 partitions, one per GPU), and ONE group over them for the window close
+    int Setup(ConsumerGroupSession& session) override {
+        std::vector<fa_ctx*> ctxs;
+        for (int32_t part : session.claims) {
+            auto p = std::make_unique<PartitionState>();
+            p->offsets.assign(1, 0);
+            if (!f_.DryRun) {
+                fa_config cfg;
+                memset(&cfg, 0, sizeof cfg);
+                cfg.device = (int32_t)(part % (f_.GpuDevices > 0 ? f_.GpuDevices : 1));
+                cfg.window_secs = (uint32_t)f_.WindowSecs;
+                cfg.subwindow_secs = 0;  // the sink stores tumbling windows (what flows_5m holds, create.sh:96)
+                cfg.key_sets = (uint32_t)f_.KeySets;
+                cfg.framed = f_.ProtoFixed ? 1 : 0;
+                int rc = fa_create(&cfg, &p->ctx);
+                if (rc != 0) fatal("fa_create: %d %s", rc, fa_last_error(nullptr));
+                ctxs.push_back(p->ctx);
+            }
+            parts_[part] = std::move(p);
+        }
+        if (!ctxs.empty()) {
+            const uint32_t flags = f_.GpuTransport == "rccl" ? FA_GROUP_RCCL : FA_GROUP_PEER;
+            int rc = fa_group_create(ctxs.data(), ctxs.size(), flags, &group_);
+            if (rc != 0) fatal("fa_group_create: %d %s", rc, fa_group_last_error(nullptr));
+            logf(2, "window close: group of %zu context(s) over %ld GPU(s), transport %s", ctxs.size(), f_.GpuDevices,
+                 fa_group_transport(group_) == FA_GROUP_RCCL ? "rccl" : "peer copies");
+        }
+        return 0;
+    }
     int Cleanup(ConsumerGroupSession&) override { return 0; }
 
     // ConsumeClaim: the consumer group runs one of these per claimed partition, concurrently (inserter.go:176)
@@ -286,7 +347,7 @@ public:
             if ((long)p->pending.size() >= f_.FlushCount) flush(*p, session);  // inserter.go:118-120
             if (std::chrono::steady_clock::now() >= deadline) {                // inserter.go:189-191
                 flush(*p, session);
-                closeWindows(*p, (int64_t)time(nullptr), false);
+                closeWindows((int64_t)time(nullptr), false);
                 deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(f_.FlushTime);
             }
         }
@@ -302,6 +363,7 @@ public:
         if (f_.DryRun) {
             logf(2, "dryrun flush partition=%d records=%zu bytes=%zu", p.pending.front().Partition, n, p.buf.size());
         } else {
+            std::shared_lock<std::shared_mutex> rd(close_mu_);  // (not while the group closes a window: that uses every ctx)
             // fa_ingest copies into library-owned pinned memory before returning
             int rc = fa_ingest(p.ctx, p.buf.data(), p.buf.size(), p.offsets.data(), n);
             if (rc != 0) fatal("fa_ingest: %d %s", rc, fa_last_error(p.ctx));  // sink error is fatal, inserter.go:102-105
@@ -314,25 +376,45 @@ public:
         p.pending.clear();
     }
 
-    // emits finished flows_5m rows (create.sh:70-90) to the bulk-load sink
-    void closeWindows(PartitionState& p, int64_t now, bool all) {
-        if (f_.DryRun) return;
+    // emits the finished windows of the WHOLE topic to the bulk-load sinks: flows_5m rows (create.sh:70-90) merged over the
+    // partitions (one row per key - what flows_5m holds after its SummingMergeTree has merged the per-partition inserts, and
+    // an eighth of the rows to insert), (SrcAddr,DstPort,Proto) rows hash-partitioned over the GPUs (-out.app)
+    void closeWindows(int64_t now, bool all) {
+        if (f_.DryRun || !group_) return;
+        std::unique_lock<std::shared_mutex> wr(close_mu_);
         std::vector<uint32_t> slots(64);
         size_t ns = 0;
-        int rc = fa_open_timeslots(p.ctx, slots.data(), slots.size(), &ns);
+        int rc = fa_group_open_timeslots(group_, slots.data(), slots.size(), &ns);
         if (rc == FA_ERR_CAPACITY) {
             slots.resize(ns);
-            rc = fa_open_timeslots(p.ctx, slots.data(), slots.size(), &ns);
+            rc = fa_group_open_timeslots(group_, slots.data(), slots.size(), &ns);
         }
-        if (rc != 0) fatal("fa_open_timeslots: %d %s", rc, fa_last_error(p.ctx));
+        if (rc != 0) fatal("fa_group_open_timeslots: %d %s", rc, fa_group_last_error(group_));
         const uint32_t gran = (uint32_t)f_.WindowSecs;
         for (size_t i = 0; i < ns; i++) {
             const uint32_t ts = slots[i];
             if (!all && (int64_t)ts + gran + f_.CloseLagSec > now) continue;
+            if (out_.wantsApp() && ((uint32_t)f_.KeySets & FA_KEYS_ADDR_PORT_PROTO)) {
+                std::vector<fa_row_app> app(1 << 16);
+                size_t na = 0;
+                rc = fa_group_close_window_partitioned(group_, FA_ROWS_APP, ts, app.data(), app.size(), nullptr, &na);
+                if (rc == FA_ERR_CAPACITY) {
+                    app.resize(na);
+                    rc = fa_group_close_window_partitioned(group_, FA_ROWS_APP, ts, app.data(), app.size(), nullptr, &na);
+                }
+                if (rc != 0) fatal("fa_group_close_window_partitioned: %d %s", rc, fa_group_last_error(group_));
+                app.resize(na);
+                logf(2, "(SrcAddr,DstPort,Proto) timeslot %u: %zu rows", ts, na);
+                out_.writeApp(app);
+            }
             std::vector<fa_row5m> rows(1 << 16);
             size_t nr = 0;
-            rc = closeOne(p, ts, rows, nr);
-            if (rc != 0) fatal("fa_close_window: %d %s", rc, fa_last_error(p.ctx));
+            rc = fa_group_close_window(group_, FA_ROWS_5M, ts, rows.data(), rows.size(), &nr);
+            if (rc == FA_ERR_CAPACITY) {
+                rows.resize(nr);
+                rc = fa_group_close_window(group_, FA_ROWS_5M, ts, rows.data(), rows.size(), &nr);
+            }
+            if (rc != 0) fatal("fa_group_close_window: %d %s", rc, fa_group_last_error(group_));
             rows.resize(nr);
             logf(2, "flows_5m timeslot %u: %zu rows", ts, nr);
             out_.write(rows);
@@ -340,57 +422,47 @@ public:
     }
 
     void finish(ConsumerGroupSession&) {
+        if (f_.CloseAllAtEnd) closeWindows(0, true);
         std::lock_guard<std::mutex> g(mu_);
-        for (auto& kv : parts_) {
-            if (f_.CloseAllAtEnd) closeWindows(*kv.second, 0, true);
-            if (!f_.DryRun) {
-                fa_stats_t st;
-                if (fa_stats(kv.second->ctx, &st) == 0)
-                    logf(2, "partition %d: records_ok=%llu records_bad=%llu", kv.first, (unsigned long long)st.records_ok,
-                         (unsigned long long)st.records_bad);
+        if (group_ && !f_.DryRun) {
+            // the heavy hitters of the whole topic (viz-ch.json:233,479): sketches all-reduced over the GPUs, top k of the merged sketch
+            if (out_.wantsTopk())
+                for (uint32_t ks : {(uint32_t)FA_KEYS_SRCADDR_CMS, (uint32_t)FA_KEYS_DSTADDR_CMS}) {
+                    if (!((uint32_t)f_.KeySets & ks)) continue;
+                    std::vector<fa_topk_row> top((size_t)std::max(1L, f_.TopkK));
+                    size_t nt = 0;
+                    int rc = fa_group_topk(group_, ks, top.size(), top.data(), top.size(), &nt);
+                    if (rc != 0) fatal("fa_group_topk: %d %s", rc, fa_group_last_error(group_));
+                    top.resize(nt);
+                    out_.writeTopk(ks == FA_KEYS_SRCADDR_CMS ? "src" : "dst", top);
+                }
+            fa_stats_t st;
+            if (fa_group_stats(group_, &st) == 0) {
+                logf(2, "topic: records_ok=%llu records_bad=%llu", (unsigned long long)st.records_ok, (unsigned long long)st.records_bad);
                 bad_ += st.records_bad;
-                fa_destroy(kv.second->ctx);
             }
+            fa_group_destroy(group_);
+            group_ = nullptr;
         }
+        for (auto& kv : parts_)
+            if (kv.second->ctx) fa_destroy(kv.second->ctx);
     }
     uint64_t bad() const { return bad_; }
 
 private:
-    int closeOne(PartitionState& p, uint32_t ts, std::vector<fa_row5m>& rows, size_t& nr) {
-        int rc = fa_close_window(p.ctx, ts, rows.data(), rows.size(), &nr);
-        if (rc == FA_ERR_CAPACITY) {
-            rows.resize(nr);
-            rc = fa_close_window(p.ctx, ts, rows.data(), rows.size(), &nr);
-        }
-        return rc;
-    }
-
     PartitionState* partition(int32_t part) {
         std::lock_guard<std::mutex> g(mu_);
         auto it = parts_.find(part);
-        if (it != parts_.end()) return it->second.get();
-        auto p = std::make_unique<PartitionState>();
-        p->offsets.assign(1, 0);
-        if (!f_.DryRun) {
-            fa_config cfg;
-            memset(&cfg, 0, sizeof cfg);
-            cfg.device = (int32_t)(part % (f_.GpuDevices > 0 ? f_.GpuDevices : 1));
-            cfg.window_secs = (uint32_t)f_.WindowSecs;
-            cfg.subwindow_secs = 0;  // the sink stores tumbling windows (what flows_5m holds, create.sh:96)
-            cfg.key_sets = (uint32_t)f_.KeySets;
-            cfg.framed = f_.ProtoFixed ? 1 : 0;
-            int rc = fa_create(&cfg, &p->ctx);
-            if (rc != 0) fatal("fa_create: %d %s", rc, fa_last_error(nullptr));
-        }
-        PartitionState* raw = p.get();
-        parts_[part] = std::move(p);
-        return raw;
+        if (it == parts_.end()) fatal("partition %d was not claimed in Setup", part);
+        return it->second.get();
     }
 
     const Flags& f_;
     RowWriter& out_;
     std::mutex mu_;
+    std::shared_mutex close_mu_;  // flushes: shared; a window close (every member ctx of the group): exclusive
     std::map<int32_t, std::unique_ptr<PartitionState>> parts_;
+    fa_group* group_ = nullptr;
     uint64_t bad_ = 0;
 };
 
@@ -413,6 +485,7 @@ int main(int argc, char** argv) {
     if (f.InputFormat != "framed" && f.InputFormat != "len32") fatal("-input.format must be framed or len32");
     if (f.InputFormat == "framed" && !f.ProtoFixed) fatal("-input.format=framed needs -proto.fixedlen=true (bare values are not self-delimiting)");
     if (f.FlushCount < 1) fatal("-flush.count must be >= 1");
+    if (f.GpuTransport != "peer" && f.GpuTransport != "rccl") fatal("-gpu.transport must be peer or rccl");
 
     RowWriter out;
     out.open(f);
@@ -428,6 +501,7 @@ int main(int argc, char** argv) {
         if (j > i) claims.push_back(std::make_unique<ConsumerGroupClaim>(part++, read_file(f.InputFiles.substr(i, j - i)), f.InputFormat == "len32"));
         i = j + 1;
     }
+    for (auto& c : claims) session.claims.push_back(c->Partition());
     if (s.Setup(session) != 0) fatal("Setup failed");
     logf(2, "inserter-gpu up and running: %zu partition(s), flush.count=%ld flush.dur=%gs", claims.size(), f.FlushCount, f.FlushTime);
     std::vector<std::thread> workers;

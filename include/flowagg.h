@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 6
+#define FA_ABI_VERSION 7
 
 typedef struct fa_ctx fa_ctx;
 
@@ -375,6 +375,59 @@ int fa_merge_rows(fa_ctx*, const fa_row5m* rows, size_t n);
 int fa_merge_allreduce(fa_ctx*, void* rccl_comm);
 
 int fa_stats(fa_ctx*, fa_stats_t* out);
+
+/* ---- ABI 7: window close of a GROUP of contexts inside one process ----------------------------------------------------
+ * The reference's consumer is one process with one goroutine per claimed Kafka partition (inserter.go:167-196, :176); the
+ * GPU stage keeps one ctx per (partition, GPU) and ingests without any exchange.  What needs every partition is the window
+ * close: the sketches, the top-k, the (SrcAddr,DstPort,Proto) rows have no SummingMergeTree behind them that would sum
+ * partial results (flows_5m has: create.sh:70-90 - its rows MAY leave per partition; merged they are fewer and final).
+ * A group is that close: the members' results are produced, exchanged and merged in HBM - peer copies between the GPUs
+ * (hipMemcpyPeerAsync over xGMI; members on one GPU: device copies), or RCCL for the dense sketches - and one result
+ * leaves.  Every result equals, bit for bit, what ONE ctx that ingested all partitions returns from the matching call.
+ * The multi-PROCESS twin (one rank per GPU under torchrun) is flow-pipeline_amd/dist.py over the same ABI 5/6 steps.
+ * Threading: a group call uses every member ctx (on host threads of its own, one per member); the caller must not run any
+ * other call on a member at the same time (ingest goroutines take a read lock, the closing goroutine the write lock).
+ * Errors: a member's failure fails the call, nothing is dropped, and fa_last_error of EVERY member - and
+ * fa_group_last_error - name the member and its error. */
+typedef struct fa_group fa_group;
+enum {
+    FA_GROUP_PEER = 0, /* exchange by peer copies; sketches: reduce-scatter + all-gather by peer copies and an add kernel */
+    FA_GROUP_RCCL = 1  /* sketches by ncclAllReduce over communicators made with ncclCommInitAll (librccl.so is bound
+                          lazily; needs every member on its own GPU - FA_ERR_UNSUPPORTED otherwise); rows still by peer copies */
+};
+/* ctxs: n contexts (1 <= n <= 1024) with the same window / key-set / sketch configuration, any placement over the GPUs.
+ * The contexts stay the caller's: destroy the group first, then them. */
+int fa_group_create(fa_ctx* const* ctxs, size_t n, uint32_t flags, fa_group** out);
+void fa_group_destroy(fa_group*);
+const char* fa_group_last_error(const fa_group*); /* group may be NULL: last create error */
+size_t fa_group_size(const fa_group*);
+int fa_group_transport(const fa_group*); /* FA_GROUP_PEER or FA_GROUP_RCCL */
+/* The union of the members' open flows_5m timeslots, ascending (fa_open_timeslots). */
+int fa_group_open_timeslots(fa_group*, uint32_t* out, size_t cap, size_t* n_out);
+/* Rows of `kind` (FA_ROWS_*) for `timeslot`, merged over the members, in the kind's emit order, cut after k rows (0: all)
+ * - fa_read_window / fa_read_window_app / fa_top_ports / fa_minute_series / fa_topk of the whole topic.  `out`: host
+ * buffer of cap rows of fa_row_bytes(kind).  Small row sets: every member's result is gathered on one member (they take
+ * turns) and merged there.  FA_ROWS_TOPK_*: the sketches are all-reduced first (fa_group_allreduce_sketches), every member
+ * ranks its distinct addresses by the MERGED estimate and hands over k rows - exact with respect to the merged sketch.
+ * FA_ERR_CAPACITY: *n_out = rows needed. */
+int fa_group_read_window(fa_group*, int kind, uint32_t timeslot, size_t k, void* out, size_t cap, size_t* n_out);
+/* ... and removes from every member what fa_close_window / fa_close_window_app remove (kind FA_ROWS_5M or FA_ROWS_APP). */
+int fa_group_close_window(fa_group*, int kind, uint32_t timeslot, void* out, size_t cap, size_t* n_out);
+/* Hash-partitioned form for LARGE row sets ((SrcAddr,DstPort,Proto): 16.6 M rows x 56 B per member and window in BASELINE
+ * config 5): every member regroups its rows by owner (fa_rows_partition_device with world = group size), member r receives
+ * group r of every member - one peer copy per pair, every xGMI link carries 1 / n of a member's rows -, merges its share
+ * (1 / n of the keys, complete) and copies it out over ITS PCIe link while the others do the same.  out receives the shares
+ * back to back, share 0 first (share_rows[r] rows each - host array of fa_group_size entries, may be NULL); inside a share
+ * the rows are in the kind's emit order; a key appears in exactly one share.  The union equals fa_group_read_window's rows. */
+int fa_group_read_window_partitioned(fa_group*, int kind, uint32_t timeslot, void* out, size_t cap, size_t* share_rows, size_t* n_out);
+int fa_group_close_window_partitioned(fa_group*, int kind, uint32_t timeslot, void* out, size_t cap, size_t* share_rows, size_t* n_out);
+/* Every member's merged sketch view = the sum of all members' sketches (out of place, repeatable: fa_merge_allreduce's
+ * contract); fa_topk / fa_cms_read / fa_cms_query of ANY member then answer for the whole topic until it ingests again. */
+int fa_group_allreduce_sketches(fa_group*);
+/* fa_topk over the whole topic (= fa_group_read_window(FA_ROWS_TOPK_SRC / _DST, 0, k, ...)). */
+int fa_group_topk(fa_group*, uint32_t key_set, size_t k, fa_topk_row* out, size_t cap, size_t* n_out);
+/* fa_stats summed over the members (kernel_ns: the slowest member's last launch). */
+int fa_group_stats(fa_group*, fa_stats_t* out);
 
 /* ---- synthetic producer (mocker/mocker.go:57-106 distribution) ------------ */
 enum {

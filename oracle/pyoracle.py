@@ -368,6 +368,32 @@ def cms_sketch_numpy(keys16: np.ndarray, weights: np.ndarray, depth: int, width_
     return out
 
 
+def cms_estimates_numpy(sketch: np.ndarray, keys16: np.ndarray, depth: int, width_log2: int, seed: int) -> np.ndarray:
+    """Count-Min estimates (minimum over the rows) of uint8[n,16] keys in a sketch laid out like cms_sketch_numpy's - the ranking
+    weight of fa_topk (viz-ch.json:233,479 rank by sum(Bytes*SamplingRate); the sketch over-estimates it)."""
+    def mix64(z):
+        z = z.astype(np.uint64)
+        with np.errstate(over="ignore"):
+            z ^= z >> np.uint64(30)
+            z *= np.uint64(0xbf58476d1ce4e5b9)
+            z ^= z >> np.uint64(27)
+            z *= np.uint64(0x94d049bb133111eb)
+            z ^= z >> np.uint64(31)
+        return z
+    k = np.ascontiguousarray(keys16, dtype=np.uint8).reshape(-1, 16)
+    lo = k[:, :8].copy().view("<u8").reshape(-1)
+    hi = k[:, 8:].copy().view("<u8").reshape(-1)
+    sk = np.ascontiguousarray(sketch, dtype=np.uint64).reshape(-1)
+    with np.errstate(over="ignore"):
+        s0 = mix64(np.array([(seed + 0x9E3779B97F4A7C15) & (2**64 - 1)], dtype=np.uint64))[0]
+        a = mix64(lo ^ s0)
+        h1 = mix64(a ^ hi)
+    est = np.full(len(k), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    for r in range(depth):
+        est = np.minimum(est, sk[cms_columns(a, h1, width_log2, r) + (r << width_log2)])
+    return est
+
+
 def cms_columns(a, h1, width_log2: int, row: int):
     """Columns of row `row` for keys given by their two hashes (a = mix64(lo ^ mix64(seed + phi)), h1 = mix64(a ^ hi)):
     the prefix-partitioned sketch of flow_oracle.c (fo_cms_column), vectorised.  -> int64 array."""

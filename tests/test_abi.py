@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(fa):
     for n in names:
         assert hasattr(L, n), "libflowagg.so does not export %s" % n
     assert sorted(fa.EXPORTS) == names, "python binding and header disagree"
-    assert fa.lib().fa_abi_version() == 6
+    assert fa.lib().fa_abi_version() == 7
 
 
 def test_struct_layouts_match_header(fa):

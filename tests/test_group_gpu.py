@@ -1,0 +1,184 @@
+"""The window close of a GROUP of contexts inside one process (ABI 7, fa_group_*; csrc/group_host.inc).
+
+The reference's consumer is one process with a goroutine per claimed partition (inserter/inserter.go:167-196).  Here every
+partition has its own ctx - all of them on the one GPU of the test box, which exercises everything but the xGMI hop: the
+peer-copy transport degrades to device copies - and the group's results are compared, byte for byte, with ONE ctx that
+ingested every partition, with the oracle's rollup of the whole stream, and with the host-side merges dist.py's tests use."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _partitions(po, n, seed, nparts, zipf_log2=14, span_secs=900):
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=seed, n_total=n, zipf_log2_universe=zipf_log2, span_secs=span_secs)
+    buf, off = po.gen_records(gp, 0, n)
+    raw = bytes(buf)
+    parts = []
+    for p in range(nparts):  # record i belongs to Kafka partition i % nparts
+        recs = [raw[int(off[k]):int(off[k + 1])] for k in range(p, n, nparts)]
+        o = np.zeros(len(recs) + 1, dtype=np.uint64)
+        o[1:] = np.cumsum([len(r) for r in recs])
+        parts.append((np.frombuffer(b"".join(recs), dtype=np.uint8), o))
+    return buf, off, parts
+
+
+def _sorted_app(rows):
+    addr = np.ascontiguousarray(rows["src_addr"])
+    hi = addr[:, :8].copy().view(">u8").reshape(-1)
+    lo = addr[:, 8:].copy().view(">u8").reshape(-1)
+    return rows[np.lexsort((rows["proto"], rows["dst_port"], lo, hi, rows["timeslot"], rows["date"]))]
+
+
+@pytest.mark.parametrize("nparts,sub", [(2, 0), (2, 60), (8, 0), (8, 60), (3, 0)])
+def test_group_close_equals_one_ctx_that_ingested_everything(gpu_lib, fa, po, nparts, sub):
+    n = 240_000
+    buf, off, parts = _partitions(po, n, seed=700 + nparts, nparts=nparts)
+    kw = dict(framed=True, key_sets=63, cms_width_log2=14, topk_capacity_log2=16, subwindow_secs=sub)
+    ref = po.Rollup(sub or 300)
+    assert ref.ingest(buf, off, 1) == 0
+    members = [fa.FlowAgg(**kw) for _ in range(nparts)]
+    whole = fa.FlowAgg(**kw)
+    try:
+        for m, (b, o) in zip(members, parts):
+            m.ingest(b, o)
+        whole.ingest(buf, off)
+        with fa.FlowGroup(members) as g:
+            assert g.transport == fa.GROUP_PEER
+            slots = whole.open_timeslots()
+            assert g.open_timeslots().tobytes() == slots.tobytes()
+            st = g.stats()
+            assert st["records_ok"] == n and st["records_bad"] == 0 and st["bytes_in"] == len(buf) and st["batches"] == nparts
+            # flows_5m: the whole table == the oracle's rollup of ALL partitions; windows (tumbling / sliding) == the single ctx
+            assert g.read_window(fa.ROWS_5M).tobytes() == ref.rows().tobytes()
+            t0 = int(slots[0])
+            windows = [fa.ALL_TIMESLOTS, t0] + ([t0 + 60, t0 + 240] if sub else [t0 + 300])
+            for ts in windows:
+                want = whole.read_window(ts)
+                got = g.read_window(fa.ROWS_5M, ts)
+                assert got.tobytes() == want.tobytes() and (len(want) or ts != t0)
+                # ... and == the host-side merge of the members' own windows (what dist.py's CPU tests use)
+                assert fa.dist.merge_rows_host([m.read_window(ts) for m in members]).tobytes() == want.tobytes()
+                want = whole.read_window_app(ts)
+                assert g.read_window(fa.ROWS_APP, ts).tobytes() == want.tobytes()
+                # hash-partitioned: the shares back to back, every key in exactly one share - the share of its owner
+                rows, shares = g.read_window_partitioned(fa.ROWS_APP, ts)
+                assert sum(shares) == len(rows) == len(want) and len(shares) == nparts
+                owner = fa.dist.partition_rows_host(rows, fa.ROWS_APP, nparts)
+                assert owner.tolist() == np.repeat(np.arange(nparts), shares).tolist()
+                at = 0
+                for s in shares:  # inside a share: emit order
+                    assert rows[at:at + s].tobytes() == _sorted_app(rows[at:at + s]).tobytes()
+                    at += s
+                assert _sorted_app(rows).tobytes() == want.tobytes()
+                rows5, shares5 = g.read_window_partitioned(fa.ROWS_5M, ts)
+                assert fa.dist.merge_rows_host([rows5]).tobytes() == whole.read_window(ts).tobytes() and sum(shares5) == len(rows5)
+            # dashboards: ports (cut at k AFTER the merge), minutes
+            for dst, kind in ((0, fa.ROWS_PORT_SRC), (1, fa.ROWS_PORT_DST)):
+                assert g.read_window(kind, k=50).tobytes() == whole.top_ports(dst, 50).tobytes()
+                assert g.read_window(kind).tobytes() == whole.top_ports(dst).tobytes()
+            assert g.read_window(fa.ROWS_MINUTE).tobytes() == whole.minute_series().tobytes()
+            # sketches + top-k: every member's merged view == the single ctx's sketch; the group's top-k == its top-k
+            for key_set in (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS):
+                assert g.topk(key_set, 100).tobytes() == whole.topk(key_set, 100).tobytes()
+                sk = whole.cms_read(key_set)
+                for m in members:
+                    assert m.cms_read(key_set).tobytes() == sk.tobytes()
+            g.allreduce_sketches()  # again: out of place, nothing is counted twice
+            assert members[-1].cms_read(fa.FA_KEYS_SRCADDR_CMS).tobytes() == whole.cms_read(fa.FA_KEYS_SRCADDR_CMS).tobytes()
+            # closes remove from every member what the single ctx's close removes
+            assert g.close_window(fa.ROWS_5M, t0).tobytes() == whole.close_window(t0).tobytes()
+            assert g.read_window(fa.ROWS_5M).tobytes() == whole.read_window().tobytes()
+            rows, shares = g.close_window_partitioned(fa.ROWS_APP, t0)
+            assert _sorted_app(rows).tobytes() == whole.close_window_app(t0).tobytes()
+            assert g.read_window(fa.ROWS_APP).tobytes() == whole.read_window_app().tobytes()
+            assert g.close_window(fa.ROWS_APP).tobytes() == whole.close_window_app().tobytes()
+            assert len(g.read_window(fa.ROWS_APP)) == 0 and len(g.read_window_partitioned(fa.ROWS_APP)[0]) == 0
+            # ingest goes on behind a close; the merged view is stale then and the next top-k recomputes it
+            members[0].ingest(*parts[0])
+            whole.ingest(*parts[0])
+            assert g.topk(fa.FA_KEYS_SRCADDR_CMS, 20).tobytes() == whole.topk(fa.FA_KEYS_SRCADDR_CMS, 20).tobytes()
+            assert g.read_window(fa.ROWS_5M).tobytes() == whole.read_window().tobytes()
+    finally:
+        for m in members + [whole]:
+            m.close()
+
+
+def test_group_of_one_and_small_buffers(gpu_lib, fa, po):
+    """n = 1 is the single ctx; FA_ERR_CAPACITY reports the rows needed and removes nothing."""
+    import ctypes as C
+    n = 60_000
+    buf, off, parts = _partitions(po, n, seed=811, nparts=2)
+    kw = dict(framed=True, key_sets=9)
+    with fa.FlowAgg(**kw) as a, fa.FlowAgg(**kw) as b, fa.FlowAgg(**kw) as whole:
+        a.ingest(*parts[0])
+        b.ingest(*parts[1])
+        whole.ingest(buf, off)
+        with fa.FlowGroup([a]) as g1:
+            assert g1.read_window(fa.ROWS_5M).tobytes() == a.read_window().tobytes()
+            assert g1.read_window_partitioned(fa.ROWS_APP)[0].tobytes() == a.read_window_app().tobytes()
+        with fa.FlowGroup([a, b]) as g:
+            want = whole.read_window()
+            out = np.empty(4, dtype=fa.ROW5M_DTYPE)
+            need = C.c_size_t()
+            L = fa.lib()
+            for fn in (lambda: L.fa_group_close_window(g._h, fa.ROWS_5M, fa.ALL_TIMESLOTS, out.ctypes.data, 4, C.byref(need)),
+                       lambda: L.fa_group_close_window_partitioned(g._h, fa.ROWS_5M, fa.ALL_TIMESLOTS, out.ctypes.data, 4, None, C.byref(need))):
+                assert fn() == -6 and need.value == len(want)
+            assert g.read_window(fa.ROWS_5M, cap=4).tobytes() == want.tobytes()  # (the binding asks again with room)
+            assert g.close_window(fa.ROWS_5M).tobytes() == want.tobytes()
+            assert len(g.read_window(fa.ROWS_5M)) == 0
+
+
+def test_a_failing_member_fails_the_call_for_everyone_and_drops_nothing(gpu_lib, fa, po):
+    n = 120_000
+    buf, off, parts = _partitions(po, n, seed=821, nparts=2, zipf_log2=20)
+    kw = dict(framed=True, key_sets=7, cms_width_log2=14)
+    with fa.FlowAgg(topk_capacity_log2=18, **kw) as a, fa.FlowAgg(topk_capacity_log2=8, **kw) as b, fa.FlowAgg(topk_capacity_log2=18, **kw) as whole:
+        a.ingest(*parts[0])
+        b.ingest(*parts[1])  # far more distinct addresses than 2^8 slots: its top-k cannot be answered
+        whole.ingest(buf, off)
+        with fa.FlowGroup([a, b]) as g:
+            with pytest.raises(fa.FlowAggError) as ei:
+                g.topk(fa.FA_KEYS_SRCADDR_CMS, 10)
+            assert ei.value.code == -5 and "member 1" in str(ei.value)
+            assert b"member 1" in fa.lib().fa_last_error(a._h)  # the other member reports it too
+            # the group is still usable for what does not need the failed piece, and nothing was dropped
+            assert g.read_window(fa.ROWS_5M).tobytes() == whole.read_window().tobytes()
+            sk = whole.cms_read(fa.FA_KEYS_SRCADDR_CMS)
+            g.allreduce_sketches()
+            assert a.cms_read(fa.FA_KEYS_SRCADDR_CMS).tobytes() == sk.tobytes()
+
+
+def test_group_create_checks_its_members(gpu_lib, fa):
+    with fa.FlowAgg(key_sets=1) as a, fa.FlowAgg(key_sets=9) as b, fa.FlowAgg(key_sets=1, subwindow_secs=60) as c:
+        for bad in ([a, b], [a, c], [a, a], []):
+            with pytest.raises(fa.FlowAggError) as ei:
+                fa.FlowGroup(bad)
+            assert ei.value.code == -1
+        with pytest.raises(fa.FlowAggError) as ei:  # RCCL wants a GPU per member
+            fa.FlowGroup([a, fa.FlowAgg(key_sets=1)], transport=fa.GROUP_RCCL)
+        assert ei.value.code == -8
+        with fa.FlowGroup([a]) as g:
+            with pytest.raises(fa.FlowAggError):
+                g.allreduce_sketches()  # no sketch key set
+            with pytest.raises(fa.FlowAggError):
+                g.close_window(fa.ROWS_PORT_SRC)  # not a windowed kind
+
+
+def test_group_over_rccl_world_1(gpu_lib, fa, po):
+    """FA_GROUP_RCCL through a real ncclCommInitAll - one member, the box has one GPU: communicator creation, the grouped
+    ncclAllReduce into the merged view and the teardown run; world > 1 needs the 8-GPU node."""
+    n = 80_000
+    buf, off, _ = _partitions(po, n, seed=831, nparts=1)
+    kw = dict(framed=True, key_sets=7, cms_width_log2=14, topk_capacity_log2=16)
+    with fa.FlowAgg(**kw) as a, fa.FlowAgg(**kw) as whole:
+        a.ingest(buf, off)
+        whole.ingest(buf, off)
+        with fa.FlowGroup([a], transport=fa.GROUP_RCCL) as g:
+            assert g.transport == fa.GROUP_RCCL
+            g.allreduce_sketches()
+            st = a.device_state()
+            assert st.cms_src_merged and a.cms_read(fa.FA_KEYS_SRCADDR_CMS).tobytes() == whole.cms_read(fa.FA_KEYS_SRCADDR_CMS).tobytes()
+            assert g.topk(fa.FA_KEYS_DSTADDR_CMS, 50).tobytes() == whole.topk(fa.FA_KEYS_DSTADDR_CMS, 50).tobytes()
+            assert g.read_window(fa.ROWS_5M).tobytes() == whole.read_window().tobytes()

@@ -127,8 +127,47 @@ def test_partition_logs_to_rowbinary_equal_oracle(gpu_lib, exe, fa, po, tmp_path
     assert met["insert_count"] == n + 1 and met["flowagg_records_bad"] == 1
     blob = open(rb, "rb").read()
     assert len(blob) == met["flowagg_rows_out"] * 70
-    parts = fa.rowbinary_to_rows(blob)  # partial rows, one set per partition - what SummingMergeTree collapses
-    merged = fa.dist.merge_rows_host([parts])
+    rows = fa.rowbinary_to_rows(blob)  # merged over the partitions by the group close: one row per key, window after window
     ref = po.Rollup(300)
     ref.ingest(buf, off, 1)
-    assert merged.tobytes() == ref.rows().tobytes()
+    assert rows.tobytes() == ref.rows().tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nparts", [2, 8])
+def test_group_close_through_the_host_program(gpu_lib, exe, fa, po, tmp_path, nparts):
+    """`-gpu.devices > 1` in the reference's shape: ONE process, a thread per claimed partition (inserter.go:176), a ctx per
+    partition - here all on GPU 0 - and the window close of the whole topic through fa_group_*: the RowBinary stream, the
+    (SrcAddr,DstPort,Proto) rows and the top-k equal the oracle's results over ALL partitions."""
+    n = 200_000
+    buf, off, paths = _partition_logs(po, tmp_path, n, nparts, mode=po.GEN_ZIPF, seed=77)
+    rb, app, topk, m = tmp_path / "flows_5m.rowbinary", tmp_path / "app.rows", tmp_path / "topk.tsv", tmp_path / "metrics.txt"
+    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-flush.count=40000", "-key.sets=15", "-out.rowbinary=%s" % rb, "-out.app=%s" % app,
+                        "-out.topk=%s" % topk, "-topk.k=50", "-metrics.dump=%s" % m, "-gpu.devices=1", "-gpu.transport=peer"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "group of %d context(s)" % nparts in r.stderr
+    met = _metrics(m)
+    assert met["insert_count"] == n and met["flowagg_records_bad"] == 0
+    ref = po.Rollup(300)
+    ref.ingest(buf, off, 1)
+    assert fa.rowbinary_to_rows(open(rb, "rb").read()).tobytes() == ref.rows().tobytes()
+    # (SrcAddr,DstPort,Proto): hash-partitioned shares per window, back to back - sorted they are the oracle's rollup
+    rows, status = po.decode_batch(buf, off, 1)
+    want = po.rollup_app(rows, status)
+    got = np.fromfile(app, dtype=fa.ROW_APP_DTYPE)
+    addr = np.ascontiguousarray(got["src_addr"])
+    order = np.lexsort((got["proto"], got["dst_port"], addr[:, 8:].copy().view(">u8").reshape(-1), addr[:, :8].copy().view(">u8").reshape(-1),
+                        got["timeslot"], got["date"]))
+    assert got[order].tobytes() == want.tobytes()
+    # top-k of the merged sketch (library defaults: depth 4, width 2^20, seed 0) == the CPU sketch of the whole stream, every
+    # distinct address ranked by its estimate, ties by key
+    with np.errstate(over="ignore"):
+        w = rows["bytes"] * rows["sampling_rate"]
+    lines = [l.split("\t") for l in open(topk).read().splitlines()]
+    for which, col in (("src", "src_addr"), ("dst", "dst_addr")):
+        sk = po.cms_sketch_numpy(rows[col], w, 4, 20, 0)
+        keys = np.unique(np.ascontiguousarray(rows[col]), axis=0)
+        est = po.cms_estimates_numpy(sk, keys, 4, 20, 0)
+        ranked = sorted(zip((-est.astype(object)).tolist(), [bytes(k) for k in keys]))[:50]
+        mine = [(bytes.fromhex(k), int(v)) for tag, k, v in lines if tag == which]
+        assert mine == [(k, -e) for e, k in ranked]
