@@ -355,23 +355,110 @@ __global__ void wmerge_kernel(const WRow* rows, uint32_t n, KArgs a) {
 }
 
 // ---- heavy hitters ---------------------------------------------------------------------------
-// One row per stored key: its Count-Min estimate = min over the sketch rows (>= the exact
-// sum(Bytes*SamplingRate), viz-ch.json:233).  The host sorts, removes duplicate keys and cuts at k.
-__global__ void topk_rows_kernel(const KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth,
-                                 uint32_t wl2, uint64_t seed, TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += gridDim.x * blockDim.x) {
-        if ((ks[i].tag & KS_READY) == 0) continue;
-        const unsigned long long lo = ks[i].lo, hi = ks[i].hi;
-        unsigned long long best = ~0ull;
-        uint64_t h, h2;
-        cms_hash2(lo, hi, seed, h, h2);
-        const CmsKey k = cms_key(h, h2, wl2);
-        for (uint32_t r = 0; r < depth; r++) {
-            const unsigned long long v = cms[((size_t)r << wl2) + cms_column(k, r, wl2)];
-            best = v < best ? v : best;
+// One row per stored key: its Count-Min estimate = min over the sketch rows (>= the exact sum(Bytes*SamplingRate),
+// viz-ch.json:233).  The merge behind it (rows_merge_t<RK_TOPK_*>) orders by weight and cuts at k.
+// A read wants k rows out of millions (BASELINE config 3: 8 M distinct addresses in a set of 2^26 slots), and round 4 handed
+// EVERY row to the sort - one returning atomic per row on one counter word (8 M same-address memory-side atomics) and a radix
+// sort of 8 M rows to keep 100: 12 ms per call.  Now the set is scanned twice:
+//   topk_hist_kernel   estimates -> a histogram over 2048 monotone bins (64 octaves x 32 steps), per workgroup in LDS;
+//   topk_thresh_kernel the bin that holds rank k: everything in a lower bin is strictly lighter than k rows above it;
+//   topk_rows_kernel   rows of the bins >= that one only - a few hundred more than k on a skewed stream -, positions claimed
+//                      once per wave and round (ballot + one atomic).
+// Exact: the selection holds every row that can be among the first k in (weight DESC, key) order.  k = 0 (all rows) skips the
+// first two kernels.  A stream whose estimates all fall into one bin selects everything: the old cost, the same result.
+constexpr int TK_U = 4;
+__device__ __forceinline__ unsigned long long topk_estimate(unsigned long long lo, unsigned long long hi, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed) {
+    unsigned long long best = ~0ull;
+    uint64_t h, h2;
+    cms_hash2(lo, hi, seed, h, h2);
+    const CmsKey k = cms_key(h, h2, wl2);
+    for (uint32_t r = 0; r < depth; r++) {
+        const unsigned long long v = cms[((size_t)r << wl2) + cms_column(k, r, wl2)];
+        best = v < best ? v : best;
+    }
+    return best;
+}
+__global__ __launch_bounds__(256) void topk_hist_kernel(const KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed,
+                                                        unsigned int* hist) {
+    __shared__ unsigned int lh[TK_BINS];
+    for (uint32_t b = threadIdx.x; b < TK_BINS; b += blockDim.x) lh[b] = 0u;
+    __syncthreads();
+    const uint32_t nthr = gridDim.x * blockDim.x;
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nslots; i0 += TK_U * nthr) {
+        ulonglong2 tl[TK_U];
+        unsigned long long hi[TK_U];
+#pragma unroll
+        for (int u = 0; u < TK_U; u++) {  // (all loads first: the scan is bound by a load's round trip, not by bandwidth)
+            const KeySlot* sp = &ks[min(i0 + (uint32_t)u * nthr, nslots - 1u)];
+            tl[u] = *reinterpret_cast<const ulonglong2*>(&sp->tag);
+            hi[u] = sp->hi;
         }
-        const unsigned int j = atomicAdd(&ctr->ks_rows, 1u);
-        if (j < rows_cap) rows[j] = TopkRow{lo, hi, best};
+#pragma unroll
+        for (int u = 0; u < TK_U; u++)
+            if (i0 + (uint32_t)u * nthr < nslots && (tl[u].x & KS_READY)) atomicAdd(&lh[topk_bin(topk_estimate(tl[u].y, hi[u], cms, depth, wl2, seed))], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < TK_BINS; b += blockDim.x)
+        if (lh[b]) atomicAdd(&hist[b], lh[b]);
+}
+// sel[0] = the lowest bin to keep (the bin that holds rank k from the top), sel[1] = rows in the bins >= it, sel[2] = all rows
+__global__ __launch_bounds__(256) void topk_thresh_kernel(const unsigned int* hist, uint32_t k, unsigned int* sel) {
+    __shared__ unsigned int lh[TK_BINS];
+    for (uint32_t b = threadIdx.x; b < TK_BINS; b += blockDim.x) lh[b] = hist[b];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0, bin = 0, kept = 0;
+        bool found = false;
+        for (int b = (int)TK_BINS - 1; b >= 0; b--) {
+            run += lh[b];
+            if (!found && run >= k) {
+                found = true;
+                bin = (unsigned int)b;
+                kept = run;
+            }
+        }
+        sel[0] = found ? bin : 0u;
+        sel[1] = found ? kept : run;
+        sel[2] = run;
+    }
+}
+__global__ __launch_bounds__(256) void topk_rows_kernel(const KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed,
+                                                        uint32_t min_bin, TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
+    const uint32_t nthr = gridDim.x * blockDim.x, lane = __lane_id();
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nslots; i0 += TK_U * nthr) {
+        ulonglong2 tl[TK_U];
+        unsigned long long hi[TK_U], est[TK_U], m[TK_U];
+        bool sel[TK_U];
+        uint32_t total = 0;
+#pragma unroll
+        for (int u = 0; u < TK_U; u++) {
+            const KeySlot* sp = &ks[min(i0 + (uint32_t)u * nthr, nslots - 1u)];
+            tl[u] = *reinterpret_cast<const ulonglong2*>(&sp->tag);
+            hi[u] = sp->hi;
+        }
+#pragma unroll
+        for (int u = 0; u < TK_U; u++) {
+            sel[u] = i0 + (uint32_t)u * nthr < nslots && (tl[u].x & KS_READY);
+            est[u] = 0;
+            if (sel[u]) {
+                est[u] = topk_estimate(tl[u].y, hi[u], cms, depth, wl2, seed);
+                sel[u] = topk_bin(est[u]) >= min_bin;
+            }
+            m[u] = __builtin_amdgcn_ballot_w64(sel[u]);
+            total += (uint32_t)__builtin_popcountll(m[u]);
+        }
+        if (total != 0u) {  // (wave-uniform)
+            const uint32_t leader = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+            unsigned int base = 0;
+            if (lane == leader) base = atomicAdd(&ctr->ks_rows, total);
+            base = (unsigned int)__builtin_amdgcn_readlane((int)base, (int)leader);
+#pragma unroll
+            for (int u = 0; u < TK_U; u++) {
+                const unsigned int j = base + (unsigned int)__builtin_popcountll(m[u] & ((1ull << lane) - 1ull));
+                base += (unsigned int)__builtin_popcountll(m[u]);
+                if (sel[u] && j < rows_cap) rows[j] = TopkRow{tl[u].y, hi[u], est[u]};
+            }
+        }
     }
 }
 

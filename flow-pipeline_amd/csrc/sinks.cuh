@@ -126,6 +126,18 @@ constexpr unsigned long long KS_CLAIMED = 1ull << 63, KS_READY = 1ull << 62;
 struct TopkRow {
     unsigned long long lo, hi, weight;
 };
+// fa_topk's pre-selection (maintenance.cuh, topk_hist_kernel): a monotone map of an estimate onto 2048 bins - values below 64
+// exactly, above that 32 steps per octave (e = 6: bins 64..95 ... e = 63: bins 1888..1919).  a <= b => topk_bin(a) <= topk_bin(b).
+constexpr uint32_t TK_BINS = 2048;
+__host__ __device__ __forceinline__ uint32_t topk_bin(unsigned long long est) {
+    if (est < 64ull) return (uint32_t)est;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t e = 63u - (uint32_t)__clzll((long long)est);
+#else
+    const uint32_t e = 63u - (uint32_t)__builtin_clzll(est);
+#endif
+    return ((e - 4u) << 5) | ((uint32_t)(est >> (e - 5u)) & 31u);
+}
 
 struct ColumnPtrs {
     uint64_t *time_received, *time_flow_start, *sampling_rate, *bytes, *packets;

@@ -50,6 +50,29 @@ int main() {
     if (!cms_scatterable(4, 20) || !cms_scatterable(4, 14) || !cms_scatterable(3, 12) || cms_scatterable(5, 20) || cms_scatterable(4, 11) ||
         !cms_scatterable(16, 18) || cms_scatterable(16, 19))
         fails++;
+    // fa_topk's pre-selection bins: monotone over the whole u64 range, below TK_BINS, exact below 64
+    {
+        uint32_t prev = 0;
+        for (unsigned long long v = 0; v < 70000; v++) {
+            const uint32_t b = topk_bin(v);
+            if (b < prev || b >= TK_BINS || (v < 64 && b != v)) fails++;
+            prev = b;
+        }
+        for (int e = 6; e < 64; e++)
+            for (int d = -3; d <= 3; d++)
+                for (int m = 0; m < 32; m++) {
+                    const unsigned long long v = (1ull << e) + ((unsigned long long)m << (e - 5)) + (unsigned long long)(long long)d;
+                    if (v < (1ull << e) && e == 63) continue;
+                    if (topk_bin(v - 1) > topk_bin(v) || topk_bin(v) >= TK_BINS) fails++;
+                    checked++;
+                }
+        if (topk_bin(~0ull) != 1919u || topk_bin(64) != 64u || topk_bin(63) != 63u) fails++;
+        for (int it = 0; it < 2000000; it++) {
+            unsigned long long a = rnd() >> (rnd() & 63), b = rnd() >> (rnd() & 63);
+            if (a > b) { const unsigned long long t = a; a = b; b = t; }
+            if (topk_bin(a) > topk_bin(b)) fails++;
+        }
+    }
     printf("checked=%llu\n", (unsigned long long)checked);
     printf(fails ? "FAILED (%llu)\n" : "OK\n", (unsigned long long)fails);
     return fails ? 1 : 0;
