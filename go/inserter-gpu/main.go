@@ -26,7 +26,11 @@
 //              GPU holds and has not emitted is lost with the process);
 //     a fatal sink error closes every partition's windows (best effort) before exit,
 //     and a claim that ends (rebalance) emits its partition's windows at once;
-//   - one fa_ctx per claimed partition, no global mutex (inserter.go:84,115);
+//   - one fa_ctx per claimed partition (partition p on GPU p % -gpu.devices), no global mutex on the ingest path
+//     (inserter.go:84,115): flushes hold a read lock.  The contexts of a session form ONE group (fa_group_*, ABI 7) and
+//     windows are closed for the whole topic under the write lock: flows_5m rows merged over the partitions in HBM (peer
+//     copies over xGMI, or RCCL with -gpu.transport=rccl), the heavy hitters of the merged sketches at the end of a
+//     session (-out.topk).  Same logic as flow-pipeline_amd/host/inserter_gpu.cpp, which is built and GPU-tested;
 //   - insert_count is actually incremented (registered but never Inc()'d at
 //     inserter.go:44-49).
 package main
@@ -89,6 +93,9 @@ var (
 	KeySets     = flag.Int("key.sets", 1, "fa key_sets mask (1 = flows_5m rollup; see include/flowagg.h)")
 	OutRowBin   = flag.String("out.rowbinary", "", "Append closed flows_5m rows to this file as ClickHouse RowBinary")
 	MarkAfter   = flag.Bool("mark.after.close", true, "Commit a batch's offsets only after every window it touched has been emitted")
+	GpuTransport = flag.String("gpu.transport", "peer", "Window-close exchange between the GPUs: peer (hipMemcpyPeer over xGMI) or rccl (sketches by ncclAllReduce)")
+	OutTopk      = flag.String("out.topk", "", "At the end of a session write the top -topk.k SrcAddr / DstAddr of the merged Count-Min sketches here (key.sets 2 / 4)")
+	TopkK        = flag.Int("topk.k", 100, "Rows of -out.topk per sketch")
 
 	Inserts = prometheus.NewCounter(prometheus.CounterOpts{Name: "insert_count", Help: "Flow messages aggregated on the GPU."})
 )
@@ -114,6 +121,10 @@ type state struct {
 	ready chan bool
 	lock  sync.Mutex
 	parts map[int32]*partitionState
+	// the window close of the whole topic (include/flowagg.h, ABI 7): a group call uses EVERY member context, so flushes
+	// (fa_ingest on one goroutine's own context) hold closeMu for reading and a close holds it for writing
+	group   *C.fa_group
+	closeMu sync.RWMutex
 }
 
 func (s *state) metricsHTTP() {
@@ -138,22 +149,26 @@ func newPartition(partition int32) *partitionState {
 }
 
 // flush = inserter.go:90-111 with the per-row db.Exec loop replaced by one fa_ingest.
-func (p *partitionState) flush(session sarama.ConsumerGroupSession) {
+func (p *partitionState) flush(s *state, session sarama.ConsumerGroupSession) {
 	n := len(p.offsets) - 1
 	if n == 0 {
 		return
 	}
 	log.Infof("Processed %d records in the last iteration.", n)
+	s.closeMu.RLock() // (not while the group closes a window)
 	// fa_ingest copies into library-owned pinned memory before returning (cgo: C keeps no Go pointers)
 	rc := C.fa_ingest(p.ctx, (*C.uint8_t)(unsafe.Pointer(&p.buf[0])), C.size_t(len(p.buf)),
 		(*C.uint64_t)(unsafe.Pointer(&p.offsets[0])), C.size_t(n))
+	var open []uint32
+	if rc == 0 && *MarkAfter {
+		open = p.openTimeslots() // the batch's records can only sit in timeslots that are open now
+	}
+	s.closeMu.RUnlock() // (released before a fatal error: sinkFatal's last-resort close wants the write lock)
 	if rc != 0 {
 		sinkFatal("fa_ingest: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
 	}
 	Inserts.Add(float64(n))
 	if *MarkAfter {
-		// the batch's records can only sit in timeslots that are open now
-		open := p.openTimeslots()
 		set := make(map[uint32]bool, len(open))
 		for _, ts := range open {
 			set[ts] = true
@@ -214,22 +229,33 @@ func (p *partitionState) markEmitted(session sarama.ConsumerGroupSession) {
 	p.unmarked = p.unmarked[done:]
 }
 
-// A sink error is fatal like the reference's failed db.Exec (inserter.go:102-105) - but the other partitions'
-// contexts hold aggregates too.  A context is not thread-safe, so nobody closes another goroutine's windows: the
-// failing goroutine raises `dying`, every ConsumeClaim loop notices it within a second, emits what its own context
-// holds (closeWindows(all)) and returns; the failing goroutine waits for them (bounded) and then exits the process.
+// A sink error is fatal like the reference's failed db.Exec (inserter.go:102-105) - but the contexts hold aggregates.
+// The failing goroutine raises `dying`; every ConsumeClaim loop notices it within a second, hands its buffered messages to
+// its context and returns; the failing goroutine waits for them (bounded), then - unless the error came out of a group
+// call itself - closes every window of the group once more (best effort) and exits the process.
 var (
-	dying        int32 // 1 once a sink error has been seen
-	activeClaims int32 // goroutines inside ConsumeClaim
+	dying        int32  // 1 once a sink error has been seen
+	activeClaims int32  // goroutines inside ConsumeClaim
+	inEmergency  int32  // the last-resort close is running: a failure inside it exits at once
+	theState     *state // (main sets it)
 )
 
 func sinkFatal(format string, args ...interface{}) {
 	msg := fmt.Sprintf(format, args...)
+	if atomic.LoadInt32(&inEmergency) != 0 {
+		log.Fatal(msg)
+	}
 	if atomic.CompareAndSwapInt32(&dying, 0, 1) {
 		log.Error(msg)
 		deadline := time.Now().Add(10 * time.Second)
 		for atomic.LoadInt32(&activeClaims) > 1 && time.Now().Before(deadline) {
 			time.Sleep(50 * time.Millisecond)
+		}
+		// (TryLock: when this goroutine failed INSIDE a group call it holds the lock already - nothing more to emit then)
+		if theState != nil && !strings.HasPrefix(msg, "fa_group_") && theState.closeMu.TryLock() {
+			theState.closeMu.Unlock()
+			atomic.StoreInt32(&inEmergency, 1)
+			theState.closeWindows(time.Now().UTC(), true)
 		}
 		log.Fatal(msg)
 	}
@@ -238,25 +264,41 @@ func sinkFatal(format string, args ...interface{}) {
 	runtime.Goexit()
 }
 
-// closeWindows emits finished flows_5m rows (create.sh:70-90) as one RowBinary payload per window
-// (`INSERT INTO flows_5m FORMAT RowBinary`) instead of the reference's per-row db.Exec
-// (inserter.go:100-106).  Same logic as flow-pipeline_amd/host/inserter_gpu.cpp, which is built and tested.
-func (p *partitionState) closeWindows(now time.Time, all bool) {
+// closeWindows emits the finished flows_5m windows of the WHOLE topic (create.sh:70-90), merged over the partitions in
+// HBM, as one RowBinary payload per window (`INSERT INTO flows_5m FORMAT RowBinary`) instead of the reference's per-row
+// db.Exec (inserter.go:100-106).  One row per key: what flows_5m holds once its SummingMergeTree has merged the
+// per-partition inserts, and 1 / partitions of the rows to insert.  Same logic as flow-pipeline_amd/host/inserter_gpu.cpp.
+func (s *state) closeWindows(now time.Time, all bool) {
+	s.closeMu.Lock()
+	defer s.closeMu.Unlock()
+	if s.group == nil {
+		return
+	}
 	// any error below is a sink error and fatal, like the reference's failed db.Exec (inserter.go:102-105)
-	slots := p.openTimeslots()
-	for _, ts := range slots {
+	slots := make([]C.uint32_t, 64)
+	var ns C.size_t
+	rc := C.fa_group_open_timeslots(s.group, &slots[0], C.size_t(len(slots)), &ns)
+	if rc == C.FA_ERR_CAPACITY {
+		slots = make([]C.uint32_t, int(ns))
+		rc = C.fa_group_open_timeslots(s.group, &slots[0], C.size_t(len(slots)), &ns)
+	}
+	if rc != 0 {
+		sinkFatal("fa_group_open_timeslots: %d %s", int(rc), C.GoString(C.fa_group_last_error(s.group)))
+	}
+	for _, cts := range slots[:int(ns)] {
+		ts := uint32(cts)
 		if !all && int64(ts)+int64(*WindowSecs)+int64(*CloseLagSec) > now.Unix() {
 			continue
 		}
 		rows := make([]C.fa_row5m, 1<<16)
 		var nr C.size_t
-		rc := C.fa_close_window(p.ctx, C.uint32_t(ts), &rows[0], C.size_t(len(rows)), &nr)
-		if rc == C.FA_ERR_CAPACITY {
+		rc := C.fa_group_close_window(s.group, C.FA_ROWS_5M, C.uint32_t(ts), unsafe.Pointer(&rows[0]), C.size_t(len(rows)), &nr)
+		if rc == C.FA_ERR_CAPACITY { // (nothing was removed: ask again with room)
 			rows = make([]C.fa_row5m, int(nr))
-			rc = C.fa_close_window(p.ctx, C.uint32_t(ts), &rows[0], C.size_t(len(rows)), &nr)
+			rc = C.fa_group_close_window(s.group, C.FA_ROWS_5M, C.uint32_t(ts), unsafe.Pointer(&rows[0]), C.size_t(len(rows)), &nr)
 		}
 		if rc != 0 {
-			sinkFatal("fa_close_window: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
+			sinkFatal("fa_group_close_window: %d %s", int(rc), C.GoString(C.fa_group_last_error(s.group)))
 		}
 		log.Infof("flows_5m timeslot %d: %d rows", ts, int(nr))
 		if *OutRowBin != "" && nr > 0 {
@@ -265,34 +307,107 @@ func (p *partitionState) closeWindows(now time.Time, all bool) {
 			if rc := C.fa_rows_to_rowbinary(&rows[0], nr, (*C.uint8_t)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)), &nb); rc != 0 {
 				sinkFatal("fa_rows_to_rowbinary: %d", int(rc))
 			}
-			f, err := os.OpenFile(*OutRowBin, os.O_APPEND|os.O_CREATE|os.O_WRONLY, 0644)
-			if err != nil {
-				sinkFatal("%v", err)
-			}
-			if _, err = f.Write(buf[:int(nb)]); err != nil {
-				sinkFatal("%v", err)
-			}
-			f.Close()
+			appendFile(*OutRowBin, buf[:int(nb)])
 		}
 	}
 }
 
-func (s *state) Setup(sarama.ConsumerGroupSession) error {
+func appendFile(path string, b []byte) {
+	f, err := os.OpenFile(path, os.O_APPEND|os.O_CREATE|os.O_WRONLY, 0644)
+	if err != nil {
+		sinkFatal("%v", err)
+	}
+	if _, err = f.Write(b); err != nil {
+		sinkFatal("%v", err)
+	}
+	f.Close()
+}
+
+// writeTopk: the heavy hitters of the whole topic (viz-ch.json:233,479) - the members' sketches all-reduced over the GPUs,
+// every member's distinct addresses ranked by the MERGED estimate, the first k of their union.
+func (s *state) writeTopk() {
+	if *OutTopk == "" || s.group == nil {
+		return
+	}
+	for _, ks := range []struct {
+		mask C.uint32_t
+		name string
+	}{{C.FA_KEYS_SRCADDR_CMS, "src"}, {C.FA_KEYS_DSTADDR_CMS, "dst"}} {
+		if C.uint32_t(*KeySets)&ks.mask == 0 {
+			continue
+		}
+		rows := make([]C.fa_topk_row, *TopkK)
+		var nt C.size_t
+		if rc := C.fa_group_topk(s.group, ks.mask, C.size_t(len(rows)), &rows[0], C.size_t(len(rows)), &nt); rc != 0 {
+			sinkFatal("fa_group_topk: %d %s", int(rc), C.GoString(C.fa_group_last_error(s.group)))
+		}
+		var sb strings.Builder
+		for _, r := range rows[:int(nt)] {
+			fmt.Fprintf(&sb, "%s\t%x\t%d\n", ks.name, C.GoBytes(unsafe.Pointer(&r.key[0]), 16), uint64(r.weight))
+		}
+		appendFile(*OutTopk, []byte(sb.String()))
+	}
+}
+
+// Setup: the session knows its claims - one context per claimed partition and ONE group over them for the window close.
+func (s *state) Setup(session sarama.ConsumerGroupSession) error {
+	s.lock.Lock()
+	defer s.lock.Unlock()
+	var ctxs []*C.fa_ctx
+	for _, parts := range session.Claims() {
+		for _, partition := range parts {
+			p := newPartition(partition)
+			s.parts[partition] = p
+			ctxs = append(ctxs, p.ctx)
+		}
+	}
+	if len(ctxs) > 0 {
+		flags := C.uint32_t(C.FA_GROUP_PEER)
+		if *GpuTransport == "rccl" {
+			flags = C.FA_GROUP_RCCL
+		}
+		// (the array of context pointers is only read during the call: C memory, cgo's pointer rules)
+		arr := (**C.fa_ctx)(C.malloc(C.size_t(len(ctxs)) * C.size_t(unsafe.Sizeof(ctxs[0]))))
+		copy(unsafe.Slice(arr, len(ctxs)), ctxs)
+		rc := C.fa_group_create(arr, C.size_t(len(ctxs)), flags, &s.group)
+		C.free(unsafe.Pointer(arr))
+		if rc != 0 {
+			log.Fatalf("fa_group_create: %d %s", int(rc), C.GoString(C.fa_group_last_error(nil)))
+		}
+		log.Infof("window close: group of %d context(s) over %d GPU(s)", len(ctxs), *GpuDevices)
+	}
 	close(s.ready)
 	return nil
 }
 
-func (s *state) Cleanup(sarama.ConsumerGroupSession) error { return nil }
+// Cleanup runs when every ConsumeClaim of the session has returned (rebalance / shutdown): whoever owns the partitions
+// next starts from the committed offsets, so everything the GPUs still hold goes to the sink now, the batches are
+// committed, and the session's group and contexts go away.
+func (s *state) Cleanup(session sarama.ConsumerGroupSession) error {
+	s.closeWindows(time.Now().UTC(), true)
+	s.writeTopk()
+	s.lock.Lock()
+	defer s.lock.Unlock()
+	if s.group != nil {
+		C.fa_group_destroy(s.group)
+		s.group = nil
+	}
+	for part, p := range s.parts {
+		p.markEmitted(session)
+		C.fa_destroy(p.ctx)
+		delete(s.parts, part)
+	}
+	return nil
+}
 
 // ConsumeClaim: sarama runs one goroutine per claimed partition (inserter.go:176).
 func (s *state) ConsumeClaim(session sarama.ConsumerGroupSession, claim sarama.ConsumerGroupClaim) error {
 	s.lock.Lock()
 	p, ok := s.parts[claim.Partition()]
-	if !ok {
-		p = newPartition(claim.Partition())
-		s.parts[claim.Partition()] = p
-	}
 	s.lock.Unlock()
+	if !ok {
+		return fmt.Errorf("partition %d was not claimed in Setup", claim.Partition())
+	}
 	// one OS thread per partition for the life of the claim: the library selects the ctx's GPU at every entry
 	// point anyway, but HIP keeps per-thread state (current device, error state) - a goroutine that hops between OS
 	// threads would drag other partitions' state along
@@ -304,33 +419,30 @@ func (s *state) ConsumeClaim(session sarama.ConsumerGroupSession, claim sarama.C
 	alive := time.NewTicker(time.Second)
 	defer alive.Stop()
 	for {
-		if atomic.LoadInt32(&dying) != 0 { // another partition hit a sink error: emit what this context holds, then stop
-			p.flush(session)
-			p.closeWindows(time.Now().UTC(), true)
-			p.markEmitted(session)
+		if atomic.LoadInt32(&dying) != 0 { // another partition hit a sink error: hand over what is buffered, then stop (Cleanup emits)
+			p.flush(s, session)
 			return nil
 		}
 		select {
 		case <-alive.C:
 		case message, open := <-claim.Messages():
 			if !open {
-				// the claim ends (rebalance / shutdown): whoever owns the partition next starts from the committed
-				// offsets, so what this context holds goes to the sink now and its batches are committed
-				p.flush(session)
-				p.closeWindows(time.Now().UTC(), true)
-				p.markEmitted(session)
+				// the claim ends (rebalance / shutdown): the session's Cleanup emits every window of the group and commits
+				p.flush(s, session)
 				return nil
 			}
 			p.buf = append(p.buf, message.Value...)
 			p.offsets = append(p.offsets, uint64(len(p.buf)))
 			p.pending = append(p.pending, message)
 			if len(p.pending) >= *FlushCount { // inserter.go:118-120
-				p.flush(session)
+				p.flush(s, session)
 			}
 		case <-timer.C: // inserter.go:189-191
-			p.flush(session)
-			p.closeWindows(time.Now().UTC(), false)
+			p.flush(s, session)
+			s.closeWindows(time.Now().UTC(), false) // (the whole topic's finished windows: whichever goroutine's timer fires first)
+			s.closeMu.RLock()
 			p.markEmitted(session)
+			s.closeMu.RUnlock()
 			timer.Reset(*FlushTime)
 		}
 	}
@@ -342,6 +454,7 @@ func main() {
 	log.SetLevel(lvl)
 
 	s := &state{ready: make(chan bool), parts: make(map[int32]*partitionState)}
+	theState = s
 	go s.metricsHTTP()
 
 	config := sarama.NewConfig()
@@ -376,10 +489,5 @@ func main() {
 	if err = client.Close(); err != nil {
 		log.Fatal(fmt.Sprintf("Error closing client: %v", err))
 	}
-	for _, p := range s.parts {
-		// what the GPU still holds must reach the sink before the contexts go away (the C++ twin: CloseAllAtEnd);
-		// claims that ended have emitted already (ConsumeClaim), this is the safety net
-		p.closeWindows(time.Now().UTC(), true)
-		C.fa_destroy(p.ctx)
-	}
+	// (what the GPUs held went to the sink in the last session's Cleanup, which also destroyed the group and the contexts)
 }
