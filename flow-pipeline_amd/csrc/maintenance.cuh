@@ -366,25 +366,43 @@ __global__ void wmerge_kernel(const WRow* rows, uint32_t n, KArgs a) {
 //                      once per wave and round (ballot + one atomic).
 // Exact: the selection holds every row that can be among the first k in (weight DESC, key) order.  k = 0 (all rows) skips the
 // first two kernels.  A stream whose estimates all fall into one bin selects everything: the old cost, the same result.
-constexpr int TK_U = 4;
+// The set is sparse (an eighth of its slots hold a key at BASELINE config 3's load) and an estimate is a chain of hashes and
+// `depth` random sketch reads: evaluated where the key was loaded, a wave ran that chain 4 x per round for a handful of lanes
+// each (1.3 ms per scan of 2 GiB).  Now a round's keys are first compacted into a wave-private LDS list and the estimates
+// run densely, one key per lane, the sketch reads of a key issued together.
+constexpr int TK_U = 8;
 __device__ __forceinline__ unsigned long long topk_estimate(unsigned long long lo, unsigned long long hi, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed) {
     unsigned long long best = ~0ull;
     uint64_t h, h2;
     cms_hash2(lo, hi, seed, h, h2);
     const CmsKey k = cms_key(h, h2, wl2);
-    for (uint32_t r = 0; r < depth; r++) {
-        const unsigned long long v = cms[((size_t)r << wl2) + cms_column(k, r, wl2)];
-        best = v < best ? v : best;
+    for (uint32_t r0 = 0; r0 < depth; r0 += 4) {
+        unsigned long long v[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {  // (rows beyond depth repeat the last one: four independent loads in flight)
+            const uint32_t r = min(r0 + q, depth - 1u);
+            v[q] = cms[((size_t)r << wl2) + cms_column(k, r, wl2)];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) best = v[q] < best ? v[q] : best;
     }
     return best;
 }
-__global__ __launch_bounds__(256) void topk_hist_kernel(const KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed,
-                                                        unsigned int* hist) {
-    __shared__ unsigned int lh[TK_BINS];
-    for (uint32_t b = threadIdx.x; b < TK_BINS; b += blockDim.x) lh[b] = 0u;
-    __syncthreads();
-    const uint32_t nthr = gridDim.x * blockDim.x;
-    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nslots; i0 += TK_U * nthr) {
+// ROWS = false: histogram of the estimates' bins (hist).  ROWS = true: the rows whose bin is >= min_bin (rows, ctr->ks_rows).
+template <bool ROWS>
+__global__ __launch_bounds__(256) void topk_scan_kernel(const KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed,
+                                                        uint32_t min_bin, unsigned int* hist, TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
+    __shared__ unsigned int lh[ROWS ? 1 : TK_BINS];
+    __shared__ ulonglong2 cand[4][TK_U * 64];  // per wave: the (lo, hi) of the round's keys, compacted
+    if constexpr (!ROWS) {
+        for (uint32_t b = threadIdx.x; b < TK_BINS; b += blockDim.x) lh[b] = 0u;
+        __syncthreads();
+    }
+    const uint32_t nthr = gridDim.x * blockDim.x, lane = __lane_id(), wave = threadIdx.x >> 6;
+    ulonglong2* mine = cand[wave];
+    // (wave-uniform trip count - the ballots below want every lane: nslots is a power of two >= 256, a wave's 64 slots are in or out together)
+    for (uint32_t w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); w0 < nslots; w0 += TK_U * nthr) {
+        const uint32_t i0 = w0 + lane;
         ulonglong2 tl[TK_U];
         unsigned long long hi[TK_U];
 #pragma unroll
@@ -393,71 +411,78 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const KeySlot* ks, uint3
             tl[u] = *reinterpret_cast<const ulonglong2*>(&sp->tag);
             hi[u] = sp->hi;
         }
-#pragma unroll
-        for (int u = 0; u < TK_U; u++)
-            if (i0 + (uint32_t)u * nthr < nslots && (tl[u].x & KS_READY)) atomicAdd(&lh[topk_bin(topk_estimate(tl[u].y, hi[u], cms, depth, wl2, seed))], 1u);
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < TK_BINS; b += blockDim.x)
-        if (lh[b]) atomicAdd(&hist[b], lh[b]);
-}
-// sel[0] = the lowest bin to keep (the bin that holds rank k from the top), sel[1] = rows in the bins >= it, sel[2] = all rows
-__global__ __launch_bounds__(256) void topk_thresh_kernel(const unsigned int* hist, uint32_t k, unsigned int* sel) {
-    __shared__ unsigned int lh[TK_BINS];
-    for (uint32_t b = threadIdx.x; b < TK_BINS; b += blockDim.x) lh[b] = hist[b];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int run = 0, bin = 0, kept = 0;
-        bool found = false;
-        for (int b = (int)TK_BINS - 1; b >= 0; b--) {
-            run += lh[b];
-            if (!found && run >= k) {
-                found = true;
-                bin = (unsigned int)b;
-                kept = run;
-            }
-        }
-        sel[0] = found ? bin : 0u;
-        sel[1] = found ? kept : run;
-        sel[2] = run;
-    }
-}
-__global__ __launch_bounds__(256) void topk_rows_kernel(const KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed,
-                                                        uint32_t min_bin, TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
-    const uint32_t nthr = gridDim.x * blockDim.x, lane = __lane_id();
-    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nslots; i0 += TK_U * nthr) {
-        ulonglong2 tl[TK_U];
-        unsigned long long hi[TK_U], est[TK_U], m[TK_U];
-        bool sel[TK_U];
         uint32_t total = 0;
 #pragma unroll
         for (int u = 0; u < TK_U; u++) {
-            const KeySlot* sp = &ks[min(i0 + (uint32_t)u * nthr, nslots - 1u)];
-            tl[u] = *reinterpret_cast<const ulonglong2*>(&sp->tag);
-            hi[u] = sp->hi;
+            const bool ready = i0 + (uint32_t)u * nthr < nslots && (tl[u].x & KS_READY);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(ready);
+            if (ready) mine[total + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_ulonglong2(tl[u].y, hi[u]);
+            total += (uint32_t)__builtin_popcountll(m);
         }
-#pragma unroll
-        for (int u = 0; u < TK_U; u++) {
-            sel[u] = i0 + (uint32_t)u * nthr < nslots && (tl[u].x & KS_READY);
-            est[u] = 0;
-            if (sel[u]) {
-                est[u] = topk_estimate(tl[u].y, hi[u], cms, depth, wl2, seed);
-                sel[u] = topk_bin(est[u]) >= min_bin;
+        for (uint32_t base = 0; base < total; base += 64u) {  // (wave-uniform)
+            const bool have = base + lane < total;
+            unsigned long long est = 0;
+            ulonglong2 key = make_ulonglong2(0, 0);
+            if (have) {
+                key = mine[base + lane];
+                est = topk_estimate(key.x, key.y, cms, depth, wl2, seed);
             }
-            m[u] = __builtin_amdgcn_ballot_w64(sel[u]);
-            total += (uint32_t)__builtin_popcountll(m[u]);
+            if constexpr (!ROWS) {
+                if (have) atomicAdd(&lh[topk_bin(est)], 1u);
+            } else {
+                const bool sel = have && topk_bin(est) >= min_bin;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(sel);
+                if (m != 0ull) {
+                    const uint32_t leader = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+                    unsigned int at = 0;
+                    if (lane == leader) at = atomicAdd(&ctr->ks_rows, (unsigned int)__builtin_popcountll(m));
+                    at = (unsigned int)__builtin_amdgcn_readlane((int)at, (int)leader) + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (sel && at < rows_cap) rows[at] = TopkRow{key.x, key.y, est};
+                }
+            }
         }
-        if (total != 0u) {  // (wave-uniform)
-            const uint32_t leader = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
-            unsigned int base = 0;
-            if (lane == leader) base = atomicAdd(&ctr->ks_rows, total);
-            base = (unsigned int)__builtin_amdgcn_readlane((int)base, (int)leader);
+    }
+    if constexpr (!ROWS) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < TK_BINS; b += blockDim.x)
+            if (lh[b]) atomicAdd(&hist[b], lh[b]);
+    }
+}
+// sel[0] = the lowest bin to keep (the bin that holds rank k from the top), sel[1] = rows in the bins >= it, sel[2] = all rows
+__global__ __launch_bounds__(256) void topk_thresh_kernel(const unsigned int* hist, uint32_t k, unsigned int* sel) {
+    __shared__ unsigned int part[256];
+    constexpr uint32_t PER = TK_BINS / 256;
+    unsigned int h[PER], sum = 0;
 #pragma unroll
-            for (int u = 0; u < TK_U; u++) {
-                const unsigned int j = base + (unsigned int)__builtin_popcountll(m[u] & ((1ull << lane) - 1ull));
-                base += (unsigned int)__builtin_popcountll(m[u]);
-                if (sel[u] && j < rows_cap) rows[j] = TopkRow{tl[u].y, hi[u], est[u]};
+    for (uint32_t q = 0; q < PER; q++) {
+        h[q] = hist[threadIdx.x * PER + q];
+        sum += h[q];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    // rows in the chunks above this thread's; the chunk that takes the running count to k owns the threshold bin
+    unsigned int above = 0, all = 0;
+    for (uint32_t t = 0; t < 256; t++) {
+        const unsigned int v = part[t];
+        all += v;
+        if (t > threadIdx.x) above += v;
+    }
+    if (above < k && above + sum >= k) {
+        unsigned int run = above;
+        for (int q = (int)PER - 1; q >= 0; q--) {
+            run += h[q];
+            if (run >= k) {
+                sel[0] = threadIdx.x * PER + (uint32_t)q;
+                sel[1] = run;
+                break;
             }
+        }
+    }
+    if (threadIdx.x == 0) {
+        sel[2] = all;
+        if (all < k) {  // fewer rows than asked for: everything
+            sel[0] = 0u;
+            sel[1] = all;
         }
     }
 }
