@@ -54,7 +54,7 @@ class Config(C.Structure):
         ("table_capacity_log2", C.c_uint32), ("cms_depth", C.c_uint32),
         ("cms_width_log2", C.c_uint32), ("cms_seed", C.c_uint64), ("key_sets", C.c_uint32),
         ("framed", C.c_int32), ("max_batch_records", C.c_uint32), ("topk_capacity_log2", C.c_uint32),
-        ("wide_capacity_log2", C.c_uint32), ("reserved", C.c_uint32 * 3),
+        ("wide_capacity_log2", C.c_uint32), ("topk_mode", C.c_uint32), ("topk_track", C.c_uint32), ("reserved", C.c_uint32 * 1),
     ]
 
 
@@ -129,6 +129,7 @@ EXPORTS = [
     "fa_group_allreduce_sketches", "fa_group_topk", "fa_group_stats",
 ]
 GROUP_PEER, GROUP_RCCL = 0, 1
+TOPK_EXACT, TOPK_CANDIDATES = 0, 1
 # row kinds of the device-resident window close (include/flowagg.h, ABI 5)
 ROWS_5M, ROWS_APP, ROWS_PORT_SRC, ROWS_PORT_DST, ROWS_MINUTE, ROWS_TOPK_SRC, ROWS_TOPK_DST = range(7)
 
@@ -336,11 +337,11 @@ class FlowAgg:
 
     def __init__(self, device=0, window_secs=300, subwindow_secs=0, table_capacity_log2=20,
                  key_sets=FA_KEYS_AS_PAIR, framed=True, cms_depth=4, cms_width_log2=20,
-                 cms_seed=0x5EED, max_batch_records=0, topk_capacity_log2=0, wide_capacity_log2=0):
+                 cms_seed=0x5EED, max_batch_records=0, topk_capacity_log2=0, wide_capacity_log2=0, topk_mode=0, topk_track=0):
         self._L = lib()
         self.cfg = Config(device, window_secs, subwindow_secs, table_capacity_log2, cms_depth,
                           cms_width_log2, cms_seed, key_sets, 1 if framed else 0, max_batch_records,
-                          topk_capacity_log2, wide_capacity_log2)
+                          topk_capacity_log2, wide_capacity_log2, topk_mode, topk_track)
         h = C.c_void_p()
         rc = self._L.fa_create(C.byref(self.cfg), C.byref(h))
         if rc:

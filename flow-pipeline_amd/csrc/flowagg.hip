@@ -194,6 +194,11 @@ struct fa_ctx {
     KeySlot* ks_src = nullptr;  // distinct-address sets (fa_topk)
     KeySlot* ks_dst = nullptr;
     uint32_t ks_log2 = 20;
+    // candidates mode (cfg.topk_mode = FA_TOPK_CANDIDATES; maintenance.cuh "candidates mode"): one bit per sketch counter, rebuilt
+    // behind every ingest launch; the sets then hold candidates only
+    uint32_t* cand_bits[2] = {nullptr, nullptr};
+    size_t cand_bits_bytes = 0;
+    CandState* cand_state = nullptr;  // [2]
 
     // wide key sets (wide.cuh): one table + the dense port histograms
     WSlot* wtab = nullptr;
@@ -259,6 +264,9 @@ static KArgs make_args(fa_ctx* c) {
     a.ks_src = c->ks_src;
     a.ks_dst = c->ks_dst;
     a.ks_mask = (1u << c->ks_log2) - 1;
+    a.cand_src = c->cand_bits[0];
+    a.cand_dst = c->cand_bits[1];
+    a.cms_nrep = c->cand_state ? 1u : CMS_REPLICAS;
     a.cols = c->cols;
     a.dbg = c->dbg;
     a.tile_recs = BLOCK;
@@ -321,13 +329,14 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (cfg.key_sets == 0) cfg.key_sets = FA_KEYS_AS_PAIR;
     if (cfg.topk_capacity_log2 == 0) cfg.topk_capacity_log2 = 20;
     if (cfg.wide_capacity_log2 == 0) cfg.wide_capacity_log2 = 20;
+    if (cfg.topk_track == 0) cfg.topk_track = 1024;
     if (cfg.max_batch_records == 0) cfg.max_batch_records = AGG_MAX_BATCH;
     if (cfg.max_batch_records > AGG8_MAX_BATCH) cfg.max_batch_records = AGG8_MAX_BATCH;  // (launches of wide tuples are split at 2^24)
     uint32_t gran = cfg.subwindow_secs ? cfg.subwindow_secs : cfg.window_secs;
     if (cfg.device < 0 || cfg.device >= ndev || gran < 60 || 86400 % gran != 0 ||
         cfg.window_secs % gran != 0 || 86400 % cfg.window_secs != 0 || cfg.table_capacity_log2 < 10 ||
         cfg.table_capacity_log2 > 30 || cfg.cms_depth > 16 || cfg.cms_width_log2 < 4 ||
-        cfg.cms_width_log2 > 28 || (cfg.key_sets & ~63u) || cfg.topk_capacity_log2 < 8 || cfg.topk_capacity_log2 > 30 ||
+        cfg.cms_width_log2 > 28 || (cfg.key_sets & ~63u) || cfg.topk_mode > FA_TOPK_CANDIDATES || cfg.topk_capacity_log2 < 8 || cfg.topk_capacity_log2 > 30 ||
         cfg.wide_capacity_log2 < 8 || cfg.wide_capacity_log2 > 30) {
         g_create_error = "fa_create: invalid configuration";
         return FA_ERR_ARG;
@@ -411,6 +420,16 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
         if (cfg.key_sets & FA_KEYS_DSTADDR_CMS) {
             if ((e = hipMalloc(&c->ks_dst, ks_bytes)) != hipSuccess) return bail("hipMalloc(key set)", e);
             if ((e = hipMemsetAsync(c->ks_dst, 0, ks_bytes, c->stream)) != hipSuccess) return bail("memset", e);
+        }
+        if (cfg.topk_mode == FA_TOPK_CANDIDATES) {
+            c->cand_bits_bytes = std::max<size_t>(c->cms_words / 8, 8) + 8;
+            for (int d = 0; d < 2; d++)
+                if (cfg.key_sets & (d ? FA_KEYS_DSTADDR_CMS : FA_KEYS_SRCADDR_CMS)) {
+                    if ((e = hipMalloc(&c->cand_bits[d], c->cand_bits_bytes)) != hipSuccess) return bail("hipMalloc(candidate bits)", e);
+                    if ((e = hipMemsetAsync(c->cand_bits[d], 0, c->cand_bits_bytes, c->stream)) != hipSuccess) return bail("memset", e);
+                }
+            if ((e = hipMalloc(&c->cand_state, 2 * sizeof(CandState))) != hipSuccess) return bail("hipMalloc(candidate state)", e);
+            if ((e = hipMemsetAsync(c->cand_state, 0, 2 * sizeof(CandState), c->stream)) != hipSuccess) return bail("memset", e);
         }
     }
     if (cfg.key_sets & FA_KEYS_WIDE) {
@@ -546,6 +565,9 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->cms_dst_m);
     (void)hipFree(c->ks_src);
     (void)hipFree(c->ks_dst);
+    (void)hipFree(c->cand_bits[0]);
+    (void)hipFree(c->cand_bits[1]);
+    (void)hipFree(c->cand_state);
     (void)hipFree(c->wtab);
     (void)hipFree(c->wspill);
     (void)hipFree(c->port_hist);

@@ -122,6 +122,8 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     uint64_t cw = 0, ws = 0, wd = 0, slo = 0, shi = 0, dlo = 0, dhi = 0, sh1 = 0, sh2 = 0, dh1 = 0, dh2 = 0;
     bool on_s = false, on_d = false, vs = false, vd = false;
     const bool keys_on = !(FA_DBG(a, DBG_NO_KEYSET));
+    const bool cand = a.cand_src != nullptr || a.cand_dst != nullptr;  // (wave-uniform: kernel arguments)
+    uint32_t cw0s = 0, cw0d = 0;
     KsProbe ps{}, pd{};
     if (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
         // (this half - folds, hashes, hot-address cache, the distinct sets' home-slot loads ISSUED - runs in front of the
@@ -154,8 +156,13 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             if (vs && hot_add(*hot, 0u, slo, shi, sh1, ws, ws != cw)) vs = false;
             if (vd && hot_add(*hot, 1u, dlo, dhi, dh1, wd, wd != cw)) vd = false;
         }
-        if (vs && keys_on) ps = keyset_probe(a, a.ks_src, sh1);
-        if (vd && keys_on) pd = keyset_probe(a, a.ks_dst, dh1);
+        if (cand) {  // candidates mode: the row-0 words of the candidate bits instead of the sets' home slots (L2-resident)
+            if (vs && keys_on) cw0s = cand_word(a.cand_src, a.cms_wl2, 0, cms_column(cms_key(sh1, sh2, a.cms_wl2), 0, a.cms_wl2));
+            if (vd && keys_on) cw0d = cand_word(a.cand_dst, a.cms_wl2, 0, cms_column(cms_key(dh1, dh2, a.cms_wl2), 0, a.cms_wl2));
+        } else {
+            if (vs && keys_on) ps = keyset_probe(a, a.ks_src, sh1);
+            if (vd && keys_on) pd = keyset_probe(a, a.ks_dst, dh1);
+        }
     }
     if (ks_on<KEYSETS>(a, FA_KEYS_AS_PAIR)) {
         // the two key words and the 32-bit key hash (three quarter-rate multiplies) are only needed by the hot-key table, the wide
@@ -268,11 +275,19 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 if (on_s) cms_scatter(a, *cl, list, 0u, vs, ws, sh1, sh2);
                 if (on_d) cms_scatter(a, *cl, list, 1u, vd, wd, dh1, dh2);
             } else {
-                if (vs) cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, ws);
-                if (vd) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, wd);
+                if (vs) cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, ws, a.cms_nrep);
+                if (vd) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, wd, a.cms_nrep);
             }
         }
-        if (keys_on) keyset_finish2(a, vs, ps, sh1, slo, shi, vd, pd, dh1, dlo, dhi);
+        if (keys_on && !cand) keyset_finish2(a, vs, ps, sh1, slo, shi, vd, pd, dh1, dlo, dhi);
+        if (keys_on && cand) {  // the few addresses whose estimate stood above the threshold at the last boundary join the candidates
+            const bool is = vs && cand_pass(a.cand_src, a.cms_depth, a.cms_wl2, cms_key(sh1, sh2, a.cms_wl2), cw0s);
+            const bool id = vd && cand_pass(a.cand_dst, a.cms_depth, a.cms_wl2, cms_key(dh1, dh2, a.cms_wl2), cw0d);
+            if (FA_ANY(is || id)) {
+                if (is) keyset_insert_h(a, a.ks_src, slo, shi, sh1);
+                if (id) keyset_insert_h(a, a.ks_dst, dlo, dhi, dh1);
+            }
+        }
     }
     if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb, tb_base, wpart_cnt);
 }
@@ -810,8 +825,8 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
             const unsigned long long lo = hot->lo[set][sl], hi = hot->hi[set][sl];
             if (hit) {
                 const uint32_t key[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-                cms_add(set ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, key, hot->w[set][sl]);
-                if (!(FA_DBG(a, DBG_NO_KEYSET))) keyset_insert(a, set ? a.ks_dst : a.ks_src, key);
+                cms_add(set ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, key, hot->w[set][sl], a.cms_nrep);
+                if (!(FA_DBG(a, DBG_NO_KEYSET))) keyset_offer(a, (uint32_t)set, key);
             }
             if (a.hot_seed_tag) {  // the next launch's entries: the ones that were hit, minus the lightest of a full set (every other launch)
                 const size_t at = (size_t)blockIdx.x * (CMS_SETS * HOT_SLOTS) + i;
@@ -929,12 +944,12 @@ __device__ __forceinline__ void exotic_pass(const KArgs& a) {
         }
         uint64_t w = r.bytes * r.sampling_rate;
         if (ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS)) {
-            cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
-            keyset_insert(a, a.ks_src, r.src);
+            cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w, a.cms_nrep);
+            keyset_offer(a, 0u, r.src);
         }
         if (ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS)) {
-            cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
-            keyset_insert(a, a.ks_dst, r.dst);
+            cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w, a.cms_nrep);
+            keyset_offer(a, 1u, r.dst);
         }
         if (KEYSETS & FA_KEYS_WIDE) wide_sink_slow<KEYSETS>(a, r, tb);
     }
@@ -1000,12 +1015,12 @@ __global__ __launch_bounds__(BLOCK) void deferred_kernel(KArgs a) {
         if (sure && (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) {
             const uint64_t w = r.bytes * r.sampling_rate;
             if (ks_on<KEYSETS>(a, FA_KEYS_SRCADDR_CMS)) {
-                cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w);
-                keyset_insert(a, a.ks_src, r.src);
+                cms_add(a.cms_src, a.cms_depth, a.cms_wl2, a.cms_seed, r.src, w, a.cms_nrep);
+                keyset_offer(a, 0u, r.src);
             }
             if (ks_on<KEYSETS>(a, FA_KEYS_DSTADDR_CMS)) {
-                cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w);
-                keyset_insert(a, a.ks_dst, r.dst);
+                cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, w, a.cms_nrep);
+                keyset_offer(a, 1u, r.dst);
             }
         }
         if (sure && (KEYSETS & FA_KEYS_WIDE)) wide_sink_slow<KEYSETS>(a, r, tb);

@@ -390,18 +390,17 @@ __device__ __forceinline__ unsigned long long topk_estimate(unsigned long long l
 }
 // ROWS = false: histogram of the estimates' bins (hist).  ROWS = true: the rows whose bin is >= min_bin (rows, ctr->ks_rows).
 template <bool ROWS>
-__global__ __launch_bounds__(256) void topk_scan_kernel(const KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed,
-                                                        uint32_t min_bin, unsigned int* hist, TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
-    __shared__ unsigned int lh[ROWS ? 1 : TK_BINS];
-    __shared__ ulonglong2 cand[4][TK_U * 64];  // per wave: the (lo, hi) of the round's keys, compacted
+__device__ __forceinline__ void topk_scan_body(unsigned int* lh, ulonglong2 (*cand)[TK_U * 64], uint32_t block, uint32_t nblocks, const KeySlot* ks, uint32_t nslots,
+                                               const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed, uint32_t min_bin, unsigned int* hist,
+                                               TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
     if constexpr (!ROWS) {
         for (uint32_t b = threadIdx.x; b < TK_BINS; b += blockDim.x) lh[b] = 0u;
         __syncthreads();
     }
-    const uint32_t nthr = gridDim.x * blockDim.x, lane = __lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t nthr = nblocks * blockDim.x, lane = __lane_id(), wave = threadIdx.x >> 6;
     ulonglong2* mine = cand[wave];
     // (wave-uniform trip count - the ballots below want every lane: nslots is a power of two >= 256, a wave's 64 slots are in or out together)
-    for (uint32_t w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); w0 < nslots; w0 += TK_U * nthr) {
+    for (uint32_t w0 = block * blockDim.x + (threadIdx.x & ~63u); w0 < nslots; w0 += TK_U * nthr) {
         const uint32_t i0 = w0 + lane;
         ulonglong2 tl[TK_U];
         unsigned long long hi[TK_U];
@@ -448,9 +447,15 @@ __global__ __launch_bounds__(256) void topk_scan_kernel(const KeySlot* ks, uint3
             if (lh[b]) atomicAdd(&hist[b], lh[b]);
     }
 }
+template <bool ROWS>
+__global__ __launch_bounds__(256) void topk_scan_kernel(const KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed,
+                                                        uint32_t min_bin, unsigned int* hist, TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
+    __shared__ unsigned int lh[ROWS ? 1 : TK_BINS];
+    __shared__ ulonglong2 cand[4][TK_U * 64];  // per wave: the (lo, hi) of the round's keys, compacted
+    topk_scan_body<ROWS>(lh, cand, blockIdx.x, gridDim.x, ks, nslots, cms, depth, wl2, seed, min_bin, hist, rows, rows_cap, ctr);
+}
 // sel[0] = the lowest bin to keep (the bin that holds rank k from the top), sel[1] = rows in the bins >= it, sel[2] = all rows
-__global__ __launch_bounds__(256) void topk_thresh_kernel(const unsigned int* hist, uint32_t k, unsigned int* sel) {
-    __shared__ unsigned int part[256];
+__device__ __forceinline__ void topk_thresh_body(unsigned int* part, const unsigned int* hist, uint32_t k, unsigned int* sel) {
     constexpr uint32_t PER = TK_BINS / 256;
     unsigned int h[PER], sum = 0;
 #pragma unroll
@@ -486,6 +491,75 @@ __global__ __launch_bounds__(256) void topk_thresh_kernel(const unsigned int* hi
         }
     }
 }
+__global__ __launch_bounds__(256) void topk_thresh_kernel(const unsigned int* hist, uint32_t k, unsigned int* sel) {
+    __shared__ unsigned int part[256];
+    topk_thresh_body(part, hist, k, sel);
+}
+
+// ---- candidates mode (fa_config.topk_mode = FA_TOPK_CANDIDATES): the launch boundary -----------------------------------------
+// The exact mode keeps EVERY address (2 x 2 GiB of sets at BASELINE config 3, one random 64-byte HBM line per address instance
+// in the ingest kernel).  The standard Count-Min heavy-hitter contract keeps candidates only; made deterministic per launch:
+//   R_t = R_(t-1)  u  { x in launch t : estimate_(t-1)(x) >= theta_(t-1) }
+//   theta_t = max( floor of the bin (topk_bin) that holds rank K among the estimates_t of R_t   [0 while |R_t| < K],
+//                  N_t >> (log2 slots of the set - 2),   1 )                N_t = total weight = sum of sketch row 0
+// estimate_t = the sketch after launch t.  A key joins on its first occurrence AFTER a boundary at which its estimate stood
+// above the threshold - independent of the order of records inside a launch, restated in the test oracle
+// (topk_candidates).  Behind launch t:  cand_scan_kernel (estimates of R_t -> histogram; sum of row 0) and cand_bits_kernel
+// (theta_t; one bit per counter: counter >= theta_t).  The ingest kernel of launch t + 1 tests an address against the bits of
+// all its counters - that IS estimate_t(x) >= theta_t - and only then touches the set.
+struct CandState {
+    unsigned int hist[TK_BINS];
+    unsigned int sel[4];       // [0] bin of rank K, [1] candidates in the bins >= it, [2] candidates held
+    unsigned long long total;  // N_t
+    unsigned long long theta;  // theta_t (written by cand_bits_kernel: fa_stats / tests)
+};
+constexpr uint32_t CAND_SCAN_BLOCKS = 256;
+// grid (CAND_SCAN_BLOCKS, sketches): y = 0 SrcAddr, 1 DstAddr (a sketch that is off has ks == nullptr)
+__global__ __launch_bounds__(256) void cand_scan_kernel(const KeySlot* ks0, const KeySlot* ks1, uint32_t nslots, const unsigned long long* cms0, const unsigned long long* cms1,
+                                                        uint32_t depth, uint32_t wl2, uint64_t seed, CandState* st) {
+    __shared__ unsigned int lh[TK_BINS];
+    __shared__ ulonglong2 cand[4][TK_U * 64];
+    const KeySlot* ks = blockIdx.y ? ks1 : ks0;
+    const unsigned long long* cms = blockIdx.y ? cms1 : cms0;
+    if (!ks) return;
+    CandState* my = st + blockIdx.y;
+    topk_scan_body<false>(lh, cand, blockIdx.x, gridDim.x, ks, nslots, cms, depth, wl2, seed, 0u, my->hist, nullptr, 0u, nullptr);
+    unsigned long long sum = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ((size_t)1 << wl2); i += (size_t)gridDim.x * blockDim.x) sum += cms[i];
+    sum = wave_sum_u64(sum);
+    if (__lane_id() == 0 && sum) atomicAdd(&my->total, sum);
+}
+__global__ __launch_bounds__(256) void cand_bits_kernel(const KeySlot* ks0, const KeySlot* ks1, const unsigned long long* cms0, const unsigned long long* cms1, uint32_t depth,
+                                                        uint32_t wl2, uint32_t track, uint32_t floor_shift, CandState* st, uint32_t* bits0, uint32_t* bits1) {
+    __shared__ unsigned int part[256];
+    __shared__ unsigned int sel[4];
+    const KeySlot* ks = blockIdx.y ? ks1 : ks0;
+    const unsigned long long* cms = blockIdx.y ? cms1 : cms0;
+    uint32_t* bits = blockIdx.y ? bits1 : bits0;
+    if (!ks) return;
+    CandState* my = st + blockIdx.y;
+    topk_thresh_body(part, my->hist, track, sel);  // (every workgroup for itself: 8 KiB of histogram out of L2)
+    __syncthreads();
+    unsigned long long theta = sel[2] >= track ? topk_bin_floor(sel[0]) : 0ull;
+    const unsigned long long fl = my->total >> floor_shift;
+    theta = theta > fl ? theta : fl;
+    theta = theta ? theta : 1ull;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        my->theta = theta;
+        my->sel[0] = sel[0];
+        my->sel[1] = sel[1];
+        my->sel[2] = sel[2];
+    }
+    // one bit per counter; a wave takes 64 consecutive counters per step (coalesced), the ballot is their 64 bits
+    const size_t ncnt = (size_t)depth << wl2;
+    const uint32_t lane = __lane_id();
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t c0 = wave * 64; c0 < ncnt; c0 += nwaves * 64) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(c0 + lane < ncnt && cms[c0 + lane] >= theta);
+        if (lane == 0) *reinterpret_cast<unsigned long long*>(&bits[c0 >> 5]) = m;
+    }
+}
+
 
 // keys found by other GPUs / Kafka partitions join this context's candidate set (window close)
 __global__ void keyset_merge_kernel(const uint4* keys, uint32_t n, KeySlot* tab, KArgs a) {

@@ -138,6 +138,11 @@ __host__ __device__ __forceinline__ uint32_t topk_bin(unsigned long long est) {
 #endif
     return ((e - 4u) << 5) | ((uint32_t)(est >> (e - 5u)) & 31u);
 }
+__host__ __device__ __forceinline__ unsigned long long topk_bin_floor(uint32_t b) {  // the smallest estimate that maps to bin b
+    if (b < 64u) return b;
+    const uint32_t e = (b >> 5) + 4u;
+    return (1ull << e) | ((unsigned long long)(b & 31u) << (e - 5u));
+}
 
 struct ColumnPtrs {
     uint64_t *time_received, *time_flow_start, *sampling_rate, *bytes, *packets;
@@ -166,6 +171,14 @@ struct KArgs {
     uint64_t cms_seed;
     KeySlot* ks_src;  // distinct SrcAddr / DstAddr values seen (nullptr when the key set is off)
     KeySlot* ks_dst;
+    // fa_config.topk_mode = FA_TOPK_CANDIDATES: the sets hold CANDIDATES only - addresses whose Count-Min estimate at the previous
+    // launch boundary was >= the threshold of that boundary (maintenance.cuh, cand_*_kernel).  One bit per sketch counter
+    // ("counter >= threshold"), depth rows of 2^cms_wl2 bits: an address passes when the bits of all its counters are set -
+    // exactly estimate >= threshold.  512 KiB per sketch at 4 x 2^20: L2-resident, against one random 64-byte HBM line per
+    // address instance for the exact-universe sets.  nullptr: every address ever seen is kept (the exact mode).
+    const uint32_t* cand_src;
+    const uint32_t* cand_dst;
+    uint32_t cms_nrep;  // sketch copies the atomic paths spread over (CMS_REPLICAS; 1 in candidates mode: the boundary reads copy 0)
     uint32_t ks_mask;
     ColumnPtrs cols;
     uint32_t tile_recs;  // records per tile (<= BLOCK), chosen by the host from the mean record size
@@ -281,18 +294,18 @@ __host__ __device__ __forceinline__ uint32_t cms_column(const CmsKey& k, uint32_
 // 1.9 M updates of the top Zipf-1.1 key per launch cost ~19 ms on one copy); u64 sums commute, so the folded
 // sketch is bit-identical to a single-copy one.
 constexpr uint32_t CMS_REPLICAS = 8;
-__device__ __forceinline__ void cms_add_key(unsigned long long* cms, uint32_t depth, uint32_t wl2, const CmsKey& k, uint64_t w) {
+__device__ __forceinline__ void cms_add_key(unsigned long long* cms, uint32_t depth, uint32_t wl2, const CmsKey& k, uint64_t w, uint32_t nrep) {
     if (w == 0) return;
-    unsigned long long* copy = cms + (size_t)(blockIdx.x % CMS_REPLICAS) * ((size_t)depth << wl2);
+    unsigned long long* copy = cms + (size_t)(blockIdx.x % nrep) * ((size_t)depth << wl2);
     for (uint32_t r = 0; r < depth; r++) atomicAdd(&copy[((size_t)r << wl2) + cms_column(k, r, wl2)], (unsigned long long)w);
 }
 __device__ __forceinline__ void cms_add(unsigned long long* cms, uint32_t depth, uint32_t wl2,
-                                        uint64_t seed, const uint32_t key[4], uint64_t w) {
+                                        uint64_t seed, const uint32_t key[4], uint64_t w, uint32_t nrep) {
     if (w == 0) return;
     uint64_t lo = (uint64_t)key[1] << 32 | key[0], hi = (uint64_t)key[3] << 32 | key[2];
     uint64_t h, h2;
     cms_hash2(lo, hi, seed, h, h2);
-    cms_add_key(cms, depth, wl2, cms_key(h, h2, wl2), w);
+    cms_add_key(cms, depth, wl2, cms_key(h, h2, wl2), w, nrep);
 }
 // ---- Count-Min scatter sink --------------------------------------------------------------------------
 // Memory-side atomics retire ~24 G/s whatever their scope (tools/atomics_bench.hip): at depth 4 and two sketches that is
@@ -319,7 +332,7 @@ __host__ __device__ __forceinline__ bool cms_scatterable(uint32_t depth, uint32_
 // a tuple that found no room in its segment (a heavy hitter's partition): atomics
 __device__ __forceinline__ void cms_atomic_tuple(const KArgs& a, uint32_t p, const uint4& t) {
     const unsigned long long w = (unsigned long long)t.w << 32 | t.z;
-    cms_add_key((p >> 8) ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, CmsKey{p & (CMS_NPART - 1u), t.x, t.y}, w);
+    cms_add_key((p >> 8) ? a.cms_dst : a.cms_src, a.cms_depth, a.cms_wl2, CmsKey{p & (CMS_NPART - 1u), t.x, t.y}, w, a.cms_nrep);
 }
 // Full CMS bins leave as whole 64-byte chunks: lane group g (4 lanes) takes the g-th filled bin, each lane copies
 // 16 bytes (one tuple) - up to 16 chunks per store instruction.  Same hand-over protocol as bins_flush.  A chunk that
@@ -645,6 +658,36 @@ __device__ __forceinline__ void keyset_finish2(const KArgs& a, bool vs, const Ks
             }
         }
     }
+}
+// ---- candidates mode: is this address a candidate? ---------------------------------------------------------------------------
+// bits: depth rows of 2^wl2 bits, bit (r, column) = "counter (r, column) was >= the threshold at the last launch boundary".
+// (flat counter index = row << wl2 | column; bit i lives in word i >> 5)
+__device__ __forceinline__ uint32_t cand_word(const uint32_t* bits, uint32_t wl2, uint32_t row, uint32_t col) { return bits[(((size_t)row << wl2) + col) >> 5]; }
+// (the row-0 word is loaded by the caller ahead of time: cand_word(bits, wl2, 0, cms_column(k, 0, wl2)))
+__device__ __forceinline__ bool cand_pass(const uint32_t* bits, uint32_t depth, uint32_t wl2, const CmsKey& k, uint32_t word0) {
+    if (!((word0 >> (cms_column(k, 0, wl2) & 31u)) & 1u)) return false;  // (all but ~0.1 % of the addresses stop here)
+    for (uint32_t r = 1; r < depth; r++) {
+        const uint32_t col = cms_column(k, r, wl2);
+        if (!((cand_word(bits, wl2, r, col) >> ((((size_t)r << wl2) + col) & 31u)) & 1u)) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ void keyset_insert_h(const KArgs& a, KeySlot* tab, unsigned long long lo, unsigned long long hi, uint64_t h1) {
+    const KsProbe p = keyset_probe(a, tab, h1);
+    keyset_finish(a, tab, p, h1, lo, hi);
+}
+// an address the ingest paths saw (set = 0 SrcAddr, 1 DstAddr): kept - always in the exact mode, when it passes the
+// candidate test in candidates mode.  (fa_topk_merge_keys inserts unconditionally: keyset_insert.)
+__device__ __forceinline__ void keyset_offer(const KArgs& a, uint32_t set, const uint32_t key[4]) {
+    const uint64_t lo = (uint64_t)key[1] << 32 | key[0], hi = (uint64_t)key[3] << 32 | key[2];
+    uint64_t h1, h2;
+    cms_hash2(lo, hi, a.cms_seed, h1, h2);
+    const uint32_t* bits = set ? a.cand_dst : a.cand_src;
+    if (bits) {
+        const CmsKey k = cms_key(h1, h2, a.cms_wl2);
+        if (!cand_pass(bits, a.cms_depth, a.cms_wl2, k, cand_word(bits, a.cms_wl2, 0, cms_column(k, 0, a.cms_wl2)))) return;
+    }
+    keyset_insert_h(a, set ? a.ks_dst : a.ks_src, lo, hi, h1);
 }
 __device__ __forceinline__ void keyset_insert(const KArgs& a, KeySlot* tab, const uint32_t key[4]) {
     const unsigned long long lo = (unsigned long long)key[1] << 32 | key[0], hi = (unsigned long long)key[3] << 32 | key[2];

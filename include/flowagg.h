@@ -81,8 +81,24 @@ typedef struct {
     uint32_t topk_capacity_log2;  /* slots of each distinct-address set behind fa_topk (32 B each); 0 -> 20 */
     uint32_t wide_capacity_log2;  /* slots of the wide-key table (64 B each) behind FA_KEYS_ADDR_PORT_PROTO /
                                      PORT_HIST / MINUTE_SERIES; 0 -> 20; grows by itself like the flows_5m table */
-    uint32_t reserved[3];
+    uint32_t topk_mode;           /* ABI 7.  FA_TOPK_EXACT (0): fa_topk ranks EVERY address ever ingested (the ranking the dashboards
+                                     compute, viz-ch.json:233,479) - the distinct-address sets hold every key (2^(universe + 1) slots)
+                                     and the ingest path looks each non-repeating address up in them.
+                                     FA_TOPK_CANDIDATES (1): the standard Count-Min heavy-hitter contract, made deterministic per
+                                     ingest launch ("batch" t = one launch, fa_stats.kernel_launches):
+                                       R_t = R_(t-1) u { x in batch t : estimate_(t-1)(x) >= theta_(t-1) },
+                                       theta_t = max(lower edge of the estimate bin (64 octaves x 32 steps) that holds rank
+                                                 topk_track among R_t's estimates [0 while |R_t| < topk_track],
+                                                 total weight_t >> (topk_capacity_log2 - 2), 1);
+                                     fa_topk ranks R - every key whose estimate stood at or above the running topk_track-th
+                                     estimate at a batch boundary and that occurred again afterwards: on a stream whose heavy
+                                     hitters recur in every batch the same rows as the exact mode (BASELINE config 3: checked),
+                                     without the 2 x 2 GiB of sets in the ingest path.  Nothing is admitted during the first
+                                     batch of a ctx.  Restated in oracle/pyoracle.py (topk_candidates). */
+    uint32_t topk_track;          /* candidates mode: the rank the threshold follows (fa_topk serves k <= topk_track); 0 -> 1024 */
+    uint32_t reserved[1];
 } fa_config;
+enum { FA_TOPK_EXACT = 0, FA_TOPK_CANDIDATES = 1 };
 
 /* One flows_5m row, scalar columns (create.sh:70-90). */
 typedef struct {

@@ -394,6 +394,57 @@ def cms_estimates_numpy(sketch: np.ndarray, keys16: np.ndarray, depth: int, widt
     return est
 
 
+def topk_bin(est):
+    """fa_topk's monotone estimate bins (csrc/sinks.cuh topk_bin): values below 64 exactly, above that 32 steps per octave."""
+    est = np.asarray(est, dtype=np.uint64)
+    out = est.astype(np.int64).copy()
+    big = est >= 64
+    if big.any():
+        v = est[big]
+        e = np.array([int(x).bit_length() - 1 for x in v.tolist()], dtype=np.uint64)
+        out[big] = (((e - np.uint64(4)) << np.uint64(5)) | ((v >> (e - np.uint64(5))) & np.uint64(31))).astype(np.int64)
+    return out
+
+
+def topk_bin_floor(b: int) -> int:
+    """The smallest estimate that maps to bin b (csrc/maintenance.cuh topk_bin_floor)."""
+    if b < 64:
+        return b
+    e = (b >> 5) + 4
+    return (1 << e) | ((b & 31) << (e - 5))
+
+
+def topk_candidates(batches, depth, width_log2, seed, track=1024, capacity_log2=20):
+    """The heavy-hitter contract of fa_config.topk_mode = FA_TOPK_CANDIDATES (include/flowagg.h), restated: batches = the
+    ingest launches in order, each (keys uint8[n,16], weights uint64[n]) of its good records.
+      R_t = R_(t-1) u { x in batch t : estimate_(t-1)(x) >= theta_(t-1) }          (nothing is admitted in the first batch)
+      theta_t = max(lower edge of the topk_bin that holds rank `track` among estimates_t(R_t) [0 while |R_t| < track],
+                    N_t >> (max(capacity_log2, 8) - 2), 1),   N_t = total weight so far = sum of sketch row 0 (mod 2^64)
+    -> (sketch, candidates uint8[m,16] sorted, their final estimates, thetas per boundary)."""
+    sketch = np.zeros(depth << width_log2, dtype=np.uint64)
+    cand = np.zeros((0, 16), dtype=np.uint8)
+    theta = None
+    thetas = []
+    for keys, w in batches:
+        keys = np.ascontiguousarray(keys, dtype=np.uint8).reshape(-1, 16)
+        if theta is not None and len(keys):
+            uniq = np.unique(keys, axis=0)
+            est_prev = cms_estimates_numpy(sketch, uniq, depth, width_log2, seed)
+            cand = np.unique(np.concatenate([cand, uniq[est_prev >= np.uint64(theta)]]), axis=0)
+        with np.errstate(over="ignore"):
+            sketch = sketch + cms_sketch_numpy(keys, w, depth, width_log2, seed)
+        theta_k = 0
+        if len(cand) >= track:
+            bins = np.sort(topk_bin(cms_estimates_numpy(sketch, cand, depth, width_log2, seed)))[::-1]
+            theta_k = topk_bin_floor(int(bins[track - 1]))
+        with np.errstate(over="ignore"):
+            total = int(sketch[:1 << width_log2].sum(dtype=np.uint64))
+        theta = max(theta_k, total >> (max(capacity_log2, 8) - 2), 1)
+        thetas.append(theta)
+    est = cms_estimates_numpy(sketch, cand, depth, width_log2, seed) if len(cand) else np.zeros(0, dtype=np.uint64)
+    return sketch, cand, est, thetas
+
+
 def cms_columns(a, h1, width_log2: int, row: int):
     """Columns of row `row` for keys given by their two hashes (a = mix64(lo ^ mix64(seed + phi)), h1 = mix64(a ^ hi)):
     the prefix-partitioned sketch of flow_oracle.c (fo_cms_column), vectorised.  -> int64 array."""

@@ -67,6 +67,10 @@ int main() {
                     checked++;
                 }
         if (topk_bin(~0ull) != 1919u || topk_bin(64) != 64u || topk_bin(63) != 63u) fails++;
+        for (uint32_t b = 0; b < 1920u; b++) {  // the lower edge of every bin (the candidates mode's threshold)
+            const unsigned long long f = topk_bin_floor(b);
+            if (topk_bin(f) != b || (f && topk_bin(f - 1) >= b)) fails++;
+        }
         for (int it = 0; it < 2000000; it++) {
             unsigned long long a = rnd() >> (rnd() & 63), b = rnd() >> (rnd() & 63);
             if (a > b) { const unsigned long long t = a; a = b; b = t; }

@@ -303,3 +303,28 @@ def test_readme_samples_oracle(po, fa):
     r = po.Rollup(300)
     assert r.ingest(buf, off, 1) == 0
     readme_render(fa, fx, rows, r.rows())
+
+
+def test_candidates_contract_restatement_finds_the_heavy_hitters(po):
+    """oracle/pyoracle.py topk_candidates (fa_config.topk_mode = FA_TOPK_CANDIDATES): on a skewed stream cut into batches the
+    candidates hold far fewer keys than the stream has addresses, nothing joins during the first batch, and the first 50 of their
+    ranking are the first 50 of the ranking of every address; thresholds never fall below the total-weight floor."""
+    n, nb, depth, wl2, seed = 120_000, 6, 4, 14, 7
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=97, n_total=n, zipf_log2_universe=14)
+    rows = po.gen_rows(gp, 0, n)
+    with np.errstate(over="ignore"):
+        w = rows["bytes"] * rows["sampling_rate"]
+    step = n // nb
+    batches = [(rows["src_addr"][i * step:(i + 1) * step], w[i * step:(i + 1) * step]) for i in range(nb)]
+    sk, cand, est, thetas = po.topk_candidates(batches, depth, wl2, seed, track=256, capacity_log2=12)
+    assert np.array_equal(sk, po.cms_sketch_numpy(rows["src_addr"], w, depth, wl2, seed))
+    keys = np.unique(np.ascontiguousarray(rows["src_addr"]), axis=0)
+    full = sorted(zip((-po.cms_estimates_numpy(sk, keys, depth, wl2, seed).astype(object)).tolist(), [bytes(k) for k in keys]))
+    mine = sorted(zip((-est.astype(object)).tolist(), [bytes(k) for k in cand]))
+    assert 100 <= len(cand) < len(keys) // 4 and mine[:50] == full[:50]
+    _, c1, _, t1 = po.topk_candidates(batches[:1], depth, wl2, seed, track=256, capacity_log2=12)
+    assert len(c1) == 0 and t1[0] >= 1
+    total = 0
+    for (_, bw), th in zip(batches, thetas):
+        total = (total + int(bw.sum(dtype=np.uint64))) & (2**64 - 1)
+        assert th >= max(total >> 10, 1)

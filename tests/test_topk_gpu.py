@@ -1,0 +1,103 @@
+"""fa_topk: the pre-selection of the rows that can rank among the first k (maintenance.cuh, topk_scan_kernel) and the
+candidates mode (fa_config.topk_mode = FA_TOPK_CANDIDATES) against its restatement in oracle/pyoracle.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ranked(keys, est):
+    return sorted(zip((-est.astype(object)).tolist(), [bytes(k) for k in keys]))
+
+
+@pytest.mark.parametrize("zipf_log2,wl2", [(12, 12), (16, 14)])
+def test_topk_is_a_prefix_of_the_full_ranking_for_every_k(gpu_lib, fa, po, zipf_log2, wl2):
+    """k rows out of many: whatever the histogram's threshold bin selects, the first k rows are the first k of the ranking of
+    EVERY distinct address (ties by key) - also when most estimates fall into a few bins (small sketch, heavy ties)."""
+    n = 150_000
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=1201, n_total=n, zipf_log2_universe=zipf_log2)
+    buf, off = po.gen_records(gp, 0, n)
+    rows = po.gen_rows(gp, 0, n)
+    with np.errstate(over="ignore"):
+        w = rows["bytes"] * rows["sampling_rate"]
+    depth, seed = 4, 0xABCD
+    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=zipf_log2 + 2) as agg:
+        agg.ingest(buf, off)
+        for col, ks in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+            sk = po.cms_sketch_numpy(rows[col], w, depth, wl2, seed)
+            keys = np.unique(np.ascontiguousarray(rows[col]), axis=0)
+            want = _ranked(keys, po.cms_estimates_numpy(sk, keys, depth, wl2, seed))
+            full = agg.topk(ks, 1 << 22)
+            assert [(bytes(r["key"]), int(r["weight"])) for r in full] == [(k, -e) for e, k in want]
+            for k in (1, 2, 7, 64, 100, 1000, len(want) - 1, len(want), len(want) + 5):
+                got = agg.topk(ks, k)
+                assert got.tobytes() == full[:k].tobytes(), k
+
+
+def _batches(po, n, nb, seed, zipf_log2, junk=False):
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=seed, n_total=n, zipf_log2_universe=zipf_log2)
+    step = n // nb
+    out = []
+    for b in range(nb):
+        buf, off = po.gen_records(gp, b * step, step)
+        rows = po.gen_rows(gp, b * step, step)
+        if junk and b == 1:  # records only the complete parser takes (3-byte tag in front) and a malformed one
+            raw = bytes(buf)
+            extra = bytes.fromhex("05c33ec43e7001")  # unknown fields in front of ... nothing projected: an all-zero record, address ::
+            raw += extra + bytes.fromhex("0570ffffffff")
+            off = np.concatenate([off, [int(off[-1]) + len(extra), int(off[-1]) + len(extra) + 6]]).astype(np.uint64)
+            buf = np.frombuffer(raw, dtype=np.uint8)
+            z = np.zeros(1, dtype=rows.dtype)
+            rows = np.concatenate([rows, z])
+        out.append((buf, off, rows))
+    return out
+
+
+@pytest.mark.parametrize("n,nb,zipf_log2,wl2,track,cap", [(480_000, 6, 14, 14, 64, 12), (60_000, 12, 12, 12, 32, 10), (480_000, 4, 16, 16, 1024, 14)])
+def test_candidates_mode_equals_its_restatement(gpu_lib, fa, po, n, nb, zipf_log2, wl2, track, cap):
+    """Every launch is a batch of the contract: the candidates the library holds after the stream, their estimates and the
+    ranking == oracle/pyoracle.py topk_candidates - through the scatter sink (80 k-record launches), the direct sink (5 k) and
+    the deferred parsers; sketches bit-exact as in the exact mode."""
+    depth, seed = 4, 0x5EED
+    bs = _batches(po, n, nb, 1301 + nb, zipf_log2, junk=True)
+    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=cap,
+                    topk_mode=fa.TOPK_CANDIDATES, topk_track=track) as agg:
+        for buf, off, _ in bs:
+            agg.ingest(buf, off)
+        st = agg.stats()
+        assert st["kernel_launches"] == nb and st["records_bad"] == 1
+        for col, ks in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+            batches = []
+            for _, _, rows in bs:
+                with np.errstate(over="ignore"):
+                    batches.append((rows[col], rows["bytes"] * rows["sampling_rate"]))
+            sk, cand, est, thetas = po.topk_candidates(batches, depth, wl2, seed, track=track, capacity_log2=cap)
+            assert np.array_equal(agg.cms_read(ks).reshape(-1), sk)
+            want = _ranked(cand, est)
+            got = agg.topk(ks, 1 << 20)
+            assert len(cand) >= 16 and thetas[-1] > 1
+            assert [(bytes(r["key"]), int(r["weight"])) for r in got] == [(k, -e) for e, k in want], col
+            assert agg.topk(ks, 10).tobytes() == got[:10].tobytes()
+        # a reset starts the contract over: nothing is admitted during the next first batch
+        agg.cms_reset(fa.FA_KEYS_SRCADDR_CMS)
+        agg.ingest(bs[0][0], bs[0][1])
+        assert len(agg.topk(fa.FA_KEYS_SRCADDR_CMS, 10)) == 0
+        agg.ingest(bs[1][0], bs[1][1])
+        assert len(agg.topk(fa.FA_KEYS_SRCADDR_CMS, 10)) == 10
+
+
+def test_candidates_mode_finds_the_exact_modes_top_k_on_a_skewed_stream(gpu_lib, fa, po):
+    """The two contracts differ in what they keep, not - on a stream whose heavy hitters recur in every batch - in what they
+    report: top 100 of the candidates == top 100 of every address."""
+    n, nb = 1_200_000, 8
+    bs = _batches(po, n, nb, 1401, 18)
+    kw = dict(framed=True, key_sets=7, cms_width_log2=16)
+    with fa.FlowAgg(topk_capacity_log2=20, **kw) as exact, fa.FlowAgg(topk_capacity_log2=14, topk_mode=fa.TOPK_CANDIDATES, **kw) as cand:
+        for buf, off, _ in bs:
+            exact.ingest(buf, off)
+            cand.ingest(buf, off)
+        for ks in (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS):
+            assert np.array_equal(exact.cms_read(ks), cand.cms_read(ks))
+            assert cand.topk(ks, 100).tobytes() == exact.topk(ks, 100).tobytes()
+            assert len(cand.topk(ks, 1 << 20)) < len(exact.topk(ks, 1 << 20)) // 8
+        assert cand.read_window().tobytes() == exact.read_window().tobytes()

@@ -76,6 +76,10 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--topk-log2", type=int, default=0, help="slots of each distinct-address set (default: universe + 2)")
     ap.add_argument("--timing-only", action="store_true", help="A/B runs: ingest and print the path numbers, skip the CPU-side checks")
+    ap.add_argument("--no-assert", action="store_true", help="ablation builds (FA_DEBUG_FLAGS: results are wrong by design): no result checks")
+    ap.add_argument("--topk-mode", default="exact", choices=["exact", "candidates"],
+                    help="exact: every address is kept and ranked (2^(universe + 2) slots per set); candidates: the Count-Min heavy-hitter "
+                         "contract (include/flowagg.h, fa_config.topk_mode) - sets of 2^16 slots, nothing of them in the ingest path")
     args = ap.parse_args()
     import torch
     fa = _pkg.load()
@@ -90,8 +94,10 @@ def main():
     gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=3, n_total=n, span_secs=900, zipf_log2_universe=L, zipf_s_x100=110)
     out = {"config": "BASELINE configs[2]: 1xMI355X, Count-Min heavy hitters SrcAddr/DstAddr, %d framed FlowMessages, Zipf-1.1 over 2^%d addresses, "
                      "regenerated in %d-record chunks; sketch depth %d x 2^%d x u64 per key set" % (n, L, args.chunk, depth, wl2)}
-    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=args.topk_log2 or L + 2,
-                    max_batch_records=args.chunk) as agg:
+    cand = args.topk_mode == "candidates"
+    out["topk_mode"] = args.topk_mode
+    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=args.topk_log2 or (16 if cand else L + 2),
+                    max_batch_records=args.chunk, topk_mode=fa.TOPK_CANDIDATES if cand else fa.TOPK_EXACT) as agg:
         cap = args.chunk * 96 + 4096
         d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
         d_off = torch.empty(args.chunk + 1, dtype=torch.int32, device=dev)
@@ -129,9 +135,9 @@ def main():
                 agg.topk(k, 100)
                 tk.append((time.perf_counter() - t0) * 1e3)
         out["topk100_ms_per_call"] = [round(v, 3) for v in tk]
-        out["distinct_addresses"] = [int(len(agg.topk(k, 1 << 30))) for k in KS] if not args.timing_only else None
+        out["addresses_held"] = [int(len(agg.topk(k, 1 << 30))) for k in KS] if (cand or not args.timing_only) else None
         rows = agg.read_window()
-    assert int(rows["count"].sum()) == n and st1["records_ok"] == n and st1["records_bad"] == 0
+    assert args.no_assert or (int(rows["count"].sum()) == n and st1["records_ok"] == n and st1["records_bad"] == 0)
     launches = st1["kernel_launches"] - st0["kernel_launches"]
     path_s = (st1["batch_ns_total"] - st0["batch_ns_total"]) * 1e-9
     out.update({
