@@ -196,6 +196,12 @@ struct fa_ctx {
     uint32_t ks_log2 = 20;
     // candidates mode (cfg.topk_mode = FA_TOPK_CANDIDATES; maintenance.cuh "candidates mode"): one bit per sketch counter, rebuilt
     // behind every ingest launch; the sets then hold candidates only
+    // fa_topk: a bin the k-th estimate of a sketch is known to reach (rows_host.inc: the k-th row of the last read; valid for
+    // k' <= tk_lb_k on the same view - own sketch or merged - until fa_cms_reset)
+    uint32_t tk_lb_bin[2] = {0, 0};
+    size_t tk_lb_k[2] = {0, 0};
+    bool tk_lb_merged[2] = {false, false};
+    unsigned short* cand_chunkmax = nullptr;  // candidates mode: scratch of the boundary's scan (2 sets)
     uint32_t* cand_bits[2] = {nullptr, nullptr};
     size_t cand_bits_bytes = 0;
     CandState* cand_state = nullptr;  // [2]
@@ -428,6 +434,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
                     if ((e = hipMalloc(&c->cand_bits[d], c->cand_bits_bytes)) != hipSuccess) return bail("hipMalloc(candidate bits)", e);
                     if ((e = hipMemsetAsync(c->cand_bits[d], 0, c->cand_bits_bytes, c->stream)) != hipSuccess) return bail("memset", e);
                 }
+            if ((e = hipMalloc(&c->cand_chunkmax, 2 * ((sizeof(unsigned short) << c->ks_log2 >> 6) + 256))) != hipSuccess) return bail("hipMalloc(candidate scan scratch)", e);
             if ((e = hipMalloc(&c->cand_state, 2 * sizeof(CandState))) != hipSuccess) return bail("hipMalloc(candidate state)", e);
             if ((e = hipMemsetAsync(c->cand_state, 0, 2 * sizeof(CandState), c->stream)) != hipSuccess) return bail("memset", e);
         }
@@ -568,6 +575,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->cand_bits[0]);
     (void)hipFree(c->cand_bits[1]);
     (void)hipFree(c->cand_state);
+    (void)hipFree(c->cand_chunkmax);
     (void)hipFree(c->wtab);
     (void)hipFree(c->wspill);
     (void)hipFree(c->port_hist);

@@ -371,12 +371,17 @@ __global__ void wmerge_kernel(const WRow* rows, uint32_t n, KArgs a) {
 // each (1.3 ms per scan of 2 GiB).  Now a round's keys are first compacted into a wave-private LDS list and the estimates
 // run densely, one key per lane, the sketch reads of a key issued together.
 constexpr int TK_U = 8;
-__device__ __forceinline__ unsigned long long topk_estimate(unsigned long long lo, unsigned long long hi, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed) {
-    unsigned long long best = ~0ull;
+enum { TK_HIST = 0, TK_ROWS = 1, TK_ONE = 2 };
+// the key's sketch coordinates and its row-0 counter (an upper bound of the estimate; in set order the row-0 columns of a
+// partition come in ascending order - these reads stay in cache - while the rows behind them are random 64-byte fabric requests)
+__device__ __forceinline__ unsigned long long topk_row0(unsigned long long lo, unsigned long long hi, const unsigned long long* cms, uint32_t wl2, uint64_t seed, CmsKey& k) {
     uint64_t h, h2;
     cms_hash2(lo, hi, seed, h, h2);
-    const CmsKey k = cms_key(h, h2, wl2);
-    for (uint32_t r0 = 0; r0 < depth; r0 += 4) {
+    k = cms_key(h, h2, wl2);
+    return cms[cms_column(k, 0, wl2)];
+}
+__device__ __forceinline__ unsigned long long topk_rest(unsigned long long best, const CmsKey& k, const unsigned long long* cms, uint32_t depth, uint32_t wl2) {
+    for (uint32_t r0 = 1; r0 < depth; r0 += 4) {
         unsigned long long v[4];
 #pragma unroll
         for (uint32_t q = 0; q < 4; q++) {  // (rows beyond depth repeat the last one: four independent loads in flight)
@@ -388,17 +393,35 @@ __device__ __forceinline__ unsigned long long topk_estimate(unsigned long long l
     }
     return best;
 }
-// ROWS = false: histogram of the estimates' bins (hist).  ROWS = true: the rows whose bin is >= min_bin (rows, ctr->ks_rows).
-template <bool ROWS>
-__device__ __forceinline__ void topk_scan_body(unsigned int* lh, ulonglong2 (*cand)[TK_U * 64], uint32_t block, uint32_t nblocks, const KeySlot* ks, uint32_t nslots,
-                                               const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed, uint32_t min_bin, unsigned int* hist,
-                                               TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
-    if constexpr (!ROWS) {
+__device__ __forceinline__ unsigned long long topk_estimate(unsigned long long lo, unsigned long long hi, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed) {
+    CmsKey k;
+    const unsigned long long u0 = topk_row0(lo, hi, cms, wl2, seed, k);
+    return topk_rest(u0, k, cms, depth, wl2);
+}
+struct TopkLds {
+    ulonglong2 key[4][TK_U * 64];  // per wave: the (lo, hi) of the round's keys, compacted
+    uint32_t slot[4][TK_U * 64];   // ... and where they sit
+    unsigned int wmax[4][TK_U];    // the largest bin of each of the wave's TK_U chunks of 64 slots
+};
+// One scan of the set (modes):
+//   TK_HIST  estimates -> histogram of their bins; the estimate is left in the slot's spare word (KeySlot::pad) and the largest
+//            bin of every chunk of 64 slots in chunkmax - what topk_pick_kernel needs to find the selected rows without a second
+//            scan.  lb_bin > 0: a bin the k-th estimate is known to reach (the previous read's k-th row: estimates and sets only
+//            grow) - a key whose ROW-0 counter already lies below it is counted in bin 0 and costs one cached read.
+//   TK_ONE   the rows whose bin is >= lb_bin, in one pass (no histogram): k = 0 reads (lb_bin = 0), and reads whose lb_bin is
+//            known - almost every key stops at its row-0 counter.
+template <int M>
+__device__ __forceinline__ void topk_scan_body(unsigned int* lh, TopkLds& L, uint32_t block, uint32_t nblocks, KeySlot* ks, uint32_t nslots, const unsigned long long* cms,
+                                               uint32_t depth, uint32_t wl2, uint64_t seed, uint32_t lb_bin, unsigned int* hist, unsigned short* chunkmax, TopkRow* rows,
+                                               uint32_t rows_cap, Counters* ctr) {
+    const uint32_t nthr = nblocks * blockDim.x, lane = __lane_id(), wave = threadIdx.x >> 6;
+    if constexpr (M == TK_HIST) {
         for (uint32_t b = threadIdx.x; b < TK_BINS; b += blockDim.x) lh[b] = 0u;
+        if (lane < (uint32_t)TK_U) L.wmax[wave][lane] = 0u;
         __syncthreads();
     }
-    const uint32_t nthr = nblocks * blockDim.x, lane = __lane_id(), wave = threadIdx.x >> 6;
-    ulonglong2* mine = cand[wave];
+    ulonglong2* mine = L.key[wave];
+    uint32_t* mslot = L.slot[wave];
     // (wave-uniform trip count - the ballots below want every lane: nslots is a power of two >= 256, a wave's 64 slots are in or out together)
     for (uint32_t w0 = block * blockDim.x + (threadIdx.x & ~63u); w0 < nslots; w0 += TK_U * nthr) {
         const uint32_t i0 = w0 + lane;
@@ -415,21 +438,36 @@ __device__ __forceinline__ void topk_scan_body(unsigned int* lh, ulonglong2 (*ca
         for (int u = 0; u < TK_U; u++) {
             const bool ready = i0 + (uint32_t)u * nthr < nslots && (tl[u].x & KS_READY);
             const unsigned long long m = __builtin_amdgcn_ballot_w64(ready);
-            if (ready) mine[total + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = make_ulonglong2(tl[u].y, hi[u]);
+            if (ready) {
+                const uint32_t at = total + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                mine[at] = make_ulonglong2(tl[u].y, hi[u]);
+                mslot[at] = i0 + (uint32_t)u * nthr;
+            }
             total += (uint32_t)__builtin_popcountll(m);
         }
         for (uint32_t base = 0; base < total; base += 64u) {  // (wave-uniform)
             const bool have = base + lane < total;
             unsigned long long est = 0;
             ulonglong2 key = make_ulonglong2(0, 0);
+            uint32_t slot = 0, bin = 0;
+            bool full = false;  // the estimate was worked out (its row-0 counter did not already rule the key out)
             if (have) {
                 key = mine[base + lane];
-                est = topk_estimate(key.x, key.y, cms, depth, wl2, seed);
+                slot = mslot[base + lane];
+                CmsKey k;
+                est = topk_row0(key.x, key.y, cms, wl2, seed, k);
+                full = topk_bin(est) >= lb_bin;
+                if (full) est = topk_rest(est, k, cms, depth, wl2);
+                bin = full ? topk_bin(est) : 0u;
             }
-            if constexpr (!ROWS) {
-                if (have) atomicAdd(&lh[topk_bin(est)], 1u);
+            if constexpr (M == TK_HIST) {
+                if (have) atomicAdd(&lh[bin], 1u);
+                if (full) {
+                    ks[slot].pad = est;
+                    atomicMax(&L.wmax[wave][((slot - w0) / nthr) & (TK_U - 1)], bin);
+                }
             } else {
-                const bool sel = have && topk_bin(est) >= min_bin;
+                const bool sel = full && bin >= lb_bin;
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(sel);
                 if (m != 0ull) {
                     const uint32_t leader = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
@@ -440,19 +478,52 @@ __device__ __forceinline__ void topk_scan_body(unsigned int* lh, ulonglong2 (*ca
                 }
             }
         }
+        if constexpr (M == TK_HIST) {  // the chunks' largest bins (wave-private LDS: in order behind the atomics above)
+            if (lane < (uint32_t)TK_U) {
+                const uint32_t c0 = w0 + lane * nthr;
+                if (c0 < nslots) chunkmax[c0 >> 6] = (unsigned short)L.wmax[wave][lane];
+                L.wmax[wave][lane] = 0u;
+            }
+        }
     }
-    if constexpr (!ROWS) {
+    if constexpr (M == TK_HIST) {
         __syncthreads();
         for (uint32_t b = threadIdx.x; b < TK_BINS; b += blockDim.x)
             if (lh[b]) atomicAdd(&hist[b], lh[b]);
     }
 }
-template <bool ROWS>
-__global__ __launch_bounds__(256) void topk_scan_kernel(const KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed,
-                                                        uint32_t min_bin, unsigned int* hist, TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
-    __shared__ unsigned int lh[ROWS ? 1 : TK_BINS];
-    __shared__ ulonglong2 cand[4][TK_U * 64];  // per wave: the (lo, hi) of the round's keys, compacted
-    topk_scan_body<ROWS>(lh, cand, blockIdx.x, gridDim.x, ks, nslots, cms, depth, wl2, seed, min_bin, hist, rows, rows_cap, ctr);
+template <int M>
+__global__ __launch_bounds__(256) void topk_scan_kernel(KeySlot* ks, uint32_t nslots, const unsigned long long* cms, uint32_t depth, uint32_t wl2, uint64_t seed,
+                                                        uint32_t lb_bin, unsigned int* hist, unsigned short* chunkmax, TopkRow* rows, uint32_t rows_cap, Counters* ctr) {
+    __shared__ unsigned int lh[M == TK_HIST ? TK_BINS : 1];
+    __shared__ TopkLds L;
+    topk_scan_body<M>(lh, L, blockIdx.x, gridDim.x, ks, nslots, cms, depth, wl2, seed, lb_bin, hist, chunkmax, rows, rows_cap, ctr);
+}
+// behind TK_HIST + topk_thresh_kernel: the rows of the bins >= min_bin, found through the chunks' largest bins (2 bytes per 64
+// slots instead of the 2 KiB they occupy) and the estimates TK_HIST left in the slots
+__global__ __launch_bounds__(256) void topk_pick_kernel(const KeySlot* ks, uint32_t nslots, const unsigned short* chunkmax, uint32_t min_bin, TopkRow* rows, uint32_t rows_cap,
+                                                        Counters* ctr) {
+    const uint32_t lane = __lane_id(), nchunks = nslots >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t cbase = wave * 64u; cbase < nchunks; cbase += nwaves * 64u) {
+        const uint32_t cm = cbase + lane < nchunks ? chunkmax[cbase + lane] : 0u;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(cm >= min_bin && cm != 0u);
+        while (todo != 0ull) {  // (wave-uniform)
+            const uint32_t c = cbase + (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const KeySlot* sp = &ks[(size_t)c * 64u + lane];
+            const ulonglong2 tl = *reinterpret_cast<const ulonglong2*>(&sp->tag);
+            const ulonglong2 hp = *reinterpret_cast<const ulonglong2*>(&sp->hi);  // hi, pad (= the estimate)
+            const bool sel = (tl.x & KS_READY) && topk_bin(hp.y) >= min_bin;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(sel);
+            if (m != 0ull) {
+                unsigned int at = 0;
+                if (lane == 0) at = atomicAdd(&ctr->ks_rows, (unsigned int)__builtin_popcountll(m));
+                at = (unsigned int)__builtin_amdgcn_readfirstlane((int)at) + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                if (sel && at < rows_cap) rows[at] = TopkRow{tl.y, hp.x, hp.y};
+            }
+        }
+    }
 }
 // sel[0] = the lowest bin to keep (the bin that holds rank k from the top), sel[1] = rows in the bins >= it, sel[2] = all rows
 __device__ __forceinline__ void topk_thresh_body(unsigned int* part, const unsigned int* hist, uint32_t k, unsigned int* sel) {
@@ -515,15 +586,15 @@ struct CandState {
 };
 constexpr uint32_t CAND_SCAN_BLOCKS = 256;
 // grid (CAND_SCAN_BLOCKS, sketches): y = 0 SrcAddr, 1 DstAddr (a sketch that is off has ks == nullptr)
-__global__ __launch_bounds__(256) void cand_scan_kernel(const KeySlot* ks0, const KeySlot* ks1, uint32_t nslots, const unsigned long long* cms0, const unsigned long long* cms1,
-                                                        uint32_t depth, uint32_t wl2, uint64_t seed, CandState* st) {
+__global__ __launch_bounds__(256) void cand_scan_kernel(KeySlot* ks0, KeySlot* ks1, uint32_t nslots, const unsigned long long* cms0, const unsigned long long* cms1,
+                                                        uint32_t depth, uint32_t wl2, uint64_t seed, CandState* st, unsigned short* chunkmax) {
     __shared__ unsigned int lh[TK_BINS];
-    __shared__ ulonglong2 cand[4][TK_U * 64];
-    const KeySlot* ks = blockIdx.y ? ks1 : ks0;
+    __shared__ TopkLds L;
+    KeySlot* ks = blockIdx.y ? ks1 : ks0;
     const unsigned long long* cms = blockIdx.y ? cms1 : cms0;
     if (!ks) return;
     CandState* my = st + blockIdx.y;
-    topk_scan_body<false>(lh, cand, blockIdx.x, gridDim.x, ks, nslots, cms, depth, wl2, seed, 0u, my->hist, nullptr, 0u, nullptr);
+    topk_scan_body<TK_HIST>(lh, L, blockIdx.x, gridDim.x, ks, nslots, cms, depth, wl2, seed, 0u, my->hist, chunkmax + (size_t)blockIdx.y * (nslots >> 6), nullptr, 0u, nullptr);
     unsigned long long sum = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ((size_t)1 << wl2); i += (size_t)gridDim.x * blockDim.x) sum += cms[i];
     sum = wave_sum_u64(sum);

@@ -29,9 +29,24 @@ def test_topk_is_a_prefix_of_the_full_ranking_for_every_k(gpu_lib, fa, po, zipf_
             want = _ranked(keys, po.cms_estimates_numpy(sk, keys, depth, wl2, seed))
             full = agg.topk(ks, 1 << 22)
             assert [(bytes(r["key"]), int(r["weight"])) for r in full] == [(k, -e) for e, k in want]
-            for k in (1, 2, 7, 64, 100, 1000, len(want) - 1, len(want), len(want) + 5):
+            ks_up = (1, 2, 7, 64, 100, 1000, len(want) - 1, len(want), len(want) + 5)
+            for k in ks_up + ks_up[::-1] + (100, 100):  # (descending: the reads that know a bin the k-th estimate reaches - one pass)
                 got = agg.topk(ks, k)
                 assert got.tobytes() == full[:k].tobytes(), k
+        # more records: estimates and sets have grown, the remembered bins are still lower bounds
+        agg.ingest(buf[:int(off[n // 2])], off[:n // 2 + 1])
+        for col, ks in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+            sk = po.cms_sketch_numpy(np.concatenate([rows[col], rows[col][:n // 2]]), np.concatenate([w, w[:n // 2]]), depth, wl2, seed)
+            keys = np.unique(np.ascontiguousarray(rows[col]), axis=0)
+            want = _ranked(keys, po.cms_estimates_numpy(sk, keys, depth, wl2, seed))
+            for k in (100, 7, 1000):
+                assert [(bytes(r["key"]), int(r["weight"])) for r in agg.topk(ks, k)] == [(kk, -e) for e, kk in want[:k]], k
+        agg.cms_reset(fa.FA_KEYS_SRCADDR_CMS)  # everything starts over: a remembered bin would be far too high
+        agg.ingest(buf[:int(off[2000])], off[:2001])
+        sk = po.cms_sketch_numpy(rows["src_addr"][:2000], w[:2000], depth, wl2, seed)
+        keys = np.unique(np.ascontiguousarray(rows["src_addr"][:2000]), axis=0)
+        want = _ranked(keys, po.cms_estimates_numpy(sk, keys, depth, wl2, seed))
+        assert [(bytes(r["key"]), int(r["weight"])) for r in agg.topk(fa.FA_KEYS_SRCADDR_CMS, 50)] == [(kk, -e) for e, kk in want[:50]]
 
 
 def _batches(po, n, nb, seed, zipf_log2, junk=False):
@@ -43,9 +58,9 @@ def _batches(po, n, nb, seed, zipf_log2, junk=False):
         rows = po.gen_rows(gp, b * step, step)
         if junk and b == 1:  # records only the complete parser takes (3-byte tag in front) and a malformed one
             raw = bytes(buf)
-            extra = bytes.fromhex("05c33ec43e7001")  # unknown fields in front of ... nothing projected: an all-zero record, address ::
+            extra = bytes.fromhex("0480800101")  # field 2048 (a 3-byte tag: only the complete parser decides it): valid, nothing projected - an all-zero record, address ::
             raw += extra + bytes.fromhex("0570ffffffff")
-            off = np.concatenate([off, [int(off[-1]) + len(extra), int(off[-1]) + len(extra) + 6]]).astype(np.uint64)
+            off = np.concatenate([off, [int(off[-1]) + len(extra), int(off[-1]) + len(extra) + 6]]).astype(np.uint64)  # (+ a malformed one: a 5-byte frame whose varint never ends)
             buf = np.frombuffer(raw, dtype=np.uint8)
             z = np.zeros(1, dtype=rows.dtype)
             rows = np.concatenate([rows, z])

@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--topk-log2", type=int, default=0, help="slots of each distinct-address set (default: universe + 2)")
     ap.add_argument("--timing-only", action="store_true", help="A/B runs: ingest and print the path numbers, skip the CPU-side checks")
+    ap.add_argument("--topk-track", type=int, default=0, help="candidates mode: the rank the admission threshold follows (0: the library's default)")
     ap.add_argument("--no-assert", action="store_true", help="ablation builds (FA_DEBUG_FLAGS: results are wrong by design): no result checks")
     ap.add_argument("--topk-mode", default="exact", choices=["exact", "candidates"],
                     help="exact: every address is kept and ranked (2^(universe + 2) slots per set); candidates: the Count-Min heavy-hitter "
@@ -97,7 +98,7 @@ def main():
     cand = args.topk_mode == "candidates"
     out["topk_mode"] = args.topk_mode
     with fa.FlowAgg(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=args.topk_log2 or (16 if cand else L + 2),
-                    max_batch_records=args.chunk, topk_mode=fa.TOPK_CANDIDATES if cand else fa.TOPK_EXACT) as agg:
+                    max_batch_records=args.chunk, topk_mode=fa.TOPK_CANDIDATES if cand else fa.TOPK_EXACT, topk_track=args.topk_track) as agg:
         cap = args.chunk * 96 + 4096
         d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
         d_off = torch.empty(args.chunk + 1, dtype=torch.int32, device=dev)
