@@ -108,6 +108,7 @@ ROW_APP_DTYPE = np.dtype([
     ("date", "<u4"), ("timeslot", "<u4"), ("src_addr", "u1", 16), ("dst_port", "<u4"), ("proto", "<u4"),
     ("bytes", "<u8"), ("packets", "<u8"), ("count", "<u8"),
 ])
+ROW_APP48_DTYPE = np.dtype([("src_addr", "u1", 16), ("dst_port", "<u4"), ("proto", "<u4"), ("bytes", "<u8"), ("packets", "<u8"), ("count", "<u8")])
 PORT_ROW_DTYPE = np.dtype([("port", "<u4"), ("_pad", "<u4"), ("weight", "<u8"), ("count", "<u8")])
 MINUTE_ROW_DTYPE = np.dtype([("minute", "<u4"), ("_pad", "<u4"), ("weight", "<u8"), ("count", "<u8")])
 assert ROW5M_DTYPE.itemsize == 48 and FLOW_ROW_DTYPE.itemsize == 120
@@ -126,7 +127,7 @@ EXPORTS = [
     "fa_row_bytes", "fa_rows_device", "fa_rows_merge_device", "fa_rows_fetch", "fa_drop_window", "fa_rows_partition_device", "fa_drop_range",
     "fa_group_create", "fa_group_destroy", "fa_group_last_error", "fa_group_size", "fa_group_transport", "fa_group_open_timeslots",
     "fa_group_read_window", "fa_group_close_window", "fa_group_read_window_partitioned", "fa_group_close_window_partitioned",
-    "fa_group_allreduce_sketches", "fa_group_topk", "fa_group_stats",
+    "fa_group_allreduce_sketches", "fa_group_topk", "fa_group_stats", "fa_read_window_app48", "fa_close_window_app48",
 ]
 GROUP_PEER, GROUP_RCCL = 0, 1
 TOPK_EXACT, TOPK_CANDIDATES = 0, 1
@@ -243,6 +244,8 @@ def lib():
     L.fa_rows_partition_device.argtypes = [vp, C.c_int, vp, sz, u32, C.POINTER(vp), szp]
     L.fa_drop_window.argtypes = [vp, C.c_int, u32]
     L.fa_drop_range.argtypes = [vp, C.c_int, u32, u32]
+    L.fa_read_window_app48.argtypes = [vp, u32, vp, sz, szp, C.POINTER(u32)]
+    L.fa_close_window_app48.argtypes = [vp, u32, vp, sz, szp, C.POINTER(u32)]
     L.fa_group_create.argtypes = [C.POINTER(vp), sz, u32, C.POINTER(vp)]
     L.fa_group_destroy.argtypes = [vp]
     L.fa_group_destroy.restype = None
@@ -508,6 +511,22 @@ class FlowAgg:
         rows = self.read_window_app(timeslot, out=out)
         self.drop_window(ROWS_APP, timeslot)
         return rows
+
+    def read_window_app48(self, timeslot: int, out: np.ndarray | None = None, close=False):
+        """ONE window's (SrcAddr,DstPort,Proto) rows without the date / timeslot they share: 48-byte rows -> (rows, date)."""
+        fn = self._L.fa_close_window_app48 if close else self._L.fa_read_window_app48
+        n, date = C.c_size_t(), C.c_uint32()
+        cap = len(out) if out is not None else 1 << 12
+        while True:
+            if out is None or len(out) < cap or out.dtype != ROW_APP48_DTYPE:
+                out = np.empty(cap, dtype=ROW_APP48_DTYPE)
+            rc = fn(self._h, timeslot, out.ctypes.data, len(out), C.byref(n), C.byref(date))
+            if rc == -6:
+                cap = n.value
+                out = None
+                continue
+            self._chk(rc)
+            return out[:n.value], date.value
 
     def merge_rows_app(self, rows: np.ndarray):
         r = np.ascontiguousarray(rows, dtype=ROW_APP_DTYPE)

@@ -321,6 +321,16 @@ int fa_rows_to_rowbinary(const fa_row5m* rows, size_t n, uint8_t* out, size_t ca
 int fa_read_window_app(fa_ctx*, uint32_t timeslot, fa_row_app* out, size_t cap, size_t* n_out);
 int fa_close_window_app(fa_ctx*, uint32_t timeslot, fa_row_app* out, size_t cap, size_t* n_out);
 int fa_merge_rows_app(fa_ctx*, const fa_row_app* rows, size_t n);
+/* ABI 7: ONE window's rows without the (date, timeslot) every one of them carries - 48 instead of 56 bytes per row over PCIe, which
+ * is what a window close of this key set costs (BASELINE config 5: 16.6 M rows per window).  timeslot: a window start (not
+ * 0xFFFFFFFF); sliding windows are folded as in fa_read_window_app; same order.  *date_out = toDate(timeslot). */
+typedef struct {
+    uint8_t src_addr[16];
+    uint32_t dst_port, proto;
+    uint64_t bytes, packets, count;
+} fa_row_app48;
+int fa_read_window_app48(fa_ctx*, uint32_t timeslot, fa_row_app48* out, size_t cap, size_t* n_out, uint32_t* date_out);
+int fa_close_window_app48(fa_ctx*, uint32_t timeslot, fa_row_app48* out, size_t cap, size_t* n_out, uint32_t* date_out);
 
 /* ---- dashboard read side (not windowed: the dashboard picks $timeFilter) ----- */
 /* dst = 0: GROUP BY SrcPort, 1: GROUP BY DstPort.  Every port that occurred, ORDER BY weight DESC

@@ -259,3 +259,30 @@ def test_app_scatter_sink_equals_oracle(gpu_lib, fa, po, monkeypatch, variant, z
     _same(got_app, want_app, APP_COLS)
     # (wide_used = rows of the hash table: the library's own choice may keep a stream that opens a row per record in its log)
     assert (st["wide_used"] <= len(want_app) if variant == "default" else st["wide_used"] == len(want_app)) and st["records_ok"] == n
+
+
+def test_one_windows_rows_as_48_byte_rows(gpu_lib, fa, po):
+    """fa_read_window_app48 / fa_close_window_app48: the rows of fa_read_window_app without the date / timeslot they share -
+    tumbling and sliding windows, table and log, the close removes what fa_close_window_app removes."""
+    n = 200_000
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=4801, n_total=n, zipf_log2_universe=14, span_secs=900)
+    buf, off = po.gen_records(gp, 0, n)
+    for sub in (0, 60):
+        with fa.FlowAgg(framed=True, key_sets=9, subwindow_secs=sub) as agg, fa.FlowAgg(framed=True, key_sets=9, subwindow_secs=sub) as twin:
+            agg.ingest(buf, off)
+            twin.ingest(buf, off)
+            t0 = int(agg.open_timeslots()[0])
+            for ts in [t0, t0 + 300] + ([t0 + 120] if sub else []):
+                want = agg.read_window_app(ts)
+                got, date = agg.read_window_app48(ts)
+                assert len(got) == len(want) > 0 and date == ts // 86400
+                for f in ("src_addr", "dst_port", "proto", "bytes", "packets", "count"):
+                    assert np.array_equal(got[f], want[f]), f
+                assert (want["timeslot"] == ts).all() and (want["date"] == date).all()
+            with pytest.raises(fa.FlowAggError):
+                agg.read_window_app48(fa.ALL_TIMESLOTS)
+            got, _ = agg.read_window_app48(t0, close=True)
+            assert np.array_equal(got["count"], twin.close_window_app(t0)["count"])
+            assert agg.read_window_app().tobytes() == twin.read_window_app().tobytes()
+            small = np.empty(3, dtype=fa.ROW_APP48_DTYPE)  # too small a buffer: the binding asks again with room
+            assert len(agg.read_window_app48(t0 + 300, out=small)[0]) == len(twin.read_window_app(t0 + 300))

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--span", type=int, default=1800, help="seconds of event time the stream covers (6 windows)")
     ap.add_argument("--wide-log2", type=int, default=26, help="slots of the (SrcAddr,DstPort,Proto) table, log2 (round 3 ran 2^28 for the scatter sink; with the log only the first launch's 16.6 M rows ever reach the table)")
     ap.add_argument("--universe-log2", type=int, default=24)
+    ap.add_argument("--rows48", action="store_true", help="window reads through fa_read_window_app48: 48-byte rows (the date / timeslot a window's rows share stay behind)")
     ap.add_argument("--pinned-out", action="store_true", help="the consumer's row buffer is page-locked: window reads are one copy-engine transfer")
     ap.add_argument("--table-log2", type=int, default=24, help="slots of the flows_5m table, log2 (3.9 M groups at the default span)")
     args = ap.parse_args()
@@ -139,12 +140,18 @@ def main():
         # (a consumer keeps ONE row buffer per kind: fresh pages - 930 MB per window - cost more than the copy into them)
         nreuse = int(st1["wide_used"] + st1["wide_log_records"]) // max(len(aligned) - 1, 1) + (1 << 20)
         reuse = fa.FlowAgg.pinned_rows(fa.ROWS_APP, nreuse) if args.pinned_out else np.empty(nreuse, dtype=fa.ROW_APP_DTYPE)
+        if args.rows48:
+            reuse = reuse.view(np.uint8)[:nreuse * 48].view(fa.ROW_APP48_DTYPE)
+            out["row_format"] = "fa_row_app48 (48 bytes: the window's date and timeslot are returned once)"
         reuse.view(np.uint8)[::4096] = 0
+
+        def read_app(ts):
+            return agg.read_window_app48(ts, out=reuse)[0] if args.rows48 else agg.read_window_app(ts, out=reuse)
         out["row_buffer"] = "page-locked (one copy-engine transfer per read)" if args.pinned_out else "pageable (relayed through the ctx's pinned slots)"
         sums = []
         for ts in aligned:
             tw = time.perf_counter()
-            app = agg.read_window_app(ts, out=reuse)
+            app = read_app(ts)
             app_ms.append((time.perf_counter() - tw) * 1e3)
             sums.append((int(app["count"].sum()), int(app["bytes"].sum(dtype=np.uint64)), len(app)))
             cnt += sums[-1][0]
@@ -157,7 +164,7 @@ def main():
         close_ms, closes_ok = [], True
         for i, ts in enumerate(aligned):
             tw = time.perf_counter()
-            app = agg.read_window_app(ts, out=reuse)
+            app = read_app(ts)
             agg.drop_range(fa.ROWS_APP, ts, ts + 300)  # (a tumbling consumer: the window's five sub-buckets in one pass)
             close_ms.append((time.perf_counter() - tw) * 1e3)
             closes_ok = closes_ok and (int(app["count"].sum()), int(app["bytes"].sum(dtype=np.uint64)), len(app)) == sums[i]
