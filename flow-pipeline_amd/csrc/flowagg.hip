@@ -634,6 +634,14 @@ extern "C" int fa_stats(fa_ctx* c, fa_stats_t* out) {
     c->stats.wide_log_watermark_moves = c->wlog_wm_moves;
     c->stats.wide_log_nomem_folds = c->wlog_nomem_folds;
     c->stats.wide_log_mode = (c->wide_mode == 3 || (c->wide_mode == 0 && c->wide_defer)) ? 1 : 0;
+    if (c->cand_state && rc == FA_OK) {
+        CandState h[2];
+        if (hipMemcpy(h, c->cand_state, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int d = 0; d < 2; d++) {
+                c->stats.topk_theta[d] = h[d].theta;
+                c->stats.topk_candidates[d] = h[d].sel[2];
+            }
+    }
     *out = c->stats;
     return rc;
 }

@@ -194,6 +194,10 @@ typedef struct {
     uint64_t wide_log_watermark_moves; /* times a close moved a pending chunk's watermark instead of folding it */
     uint64_t wide_log_nomem_folds;   /* chunks folded early because another pair of segment buffers could not be allocated */
     uint64_t wide_log_mode;          /* 1: the next launch keeps its (SrcAddr,DstPort,Proto) tuples in the log */
+    /* ABI 7 - candidates mode (fa_config.topk_mode = FA_TOPK_CANDIDATES), SrcAddr then DstAddr: the admission threshold of the last
+     * launch boundary and the candidates held at it (0 in the exact mode) */
+    uint64_t topk_theta[2];
+    uint64_t topk_candidates[2];
 } fa_stats_t;
 
 typedef struct {
