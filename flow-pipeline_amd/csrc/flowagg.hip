@@ -335,7 +335,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (cfg.key_sets == 0) cfg.key_sets = FA_KEYS_AS_PAIR;
     if (cfg.topk_capacity_log2 == 0) cfg.topk_capacity_log2 = 20;
     if (cfg.wide_capacity_log2 == 0) cfg.wide_capacity_log2 = 20;
-    if (cfg.topk_track == 0) cfg.topk_track = 1024;
+    if (cfg.topk_track == 0) cfg.topk_track = 256;
     if (cfg.max_batch_records == 0) cfg.max_batch_records = AGG_MAX_BATCH;
     if (cfg.max_batch_records > AGG8_MAX_BATCH) cfg.max_batch_records = AGG8_MAX_BATCH;  // (launches of wide tuples are split at 2^24)
     uint32_t gran = cfg.subwindow_secs ? cfg.subwindow_secs : cfg.window_secs;

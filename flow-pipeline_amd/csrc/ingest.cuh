@@ -286,6 +286,14 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             if (FA_ANY(is || id)) {
                 if (is) keyset_insert_h(a, a.ks_src, slo, shi, sh1);
                 if (id) keyset_insert_h(a, a.ks_dst, dlo, dhi, dh1);
+                // an address that stands above the threshold is heavy by definition: it moves into the workgroup's hot-address
+                // cache now (the usual admission wants it twice in one wave-tile), so that its next instances here are one LDS
+                // add each instead of four cached loads and a look into the set; the launch's end offers it to the set once
+                // (its weight of THIS record has left as a tuple above: the entry starts at 0)
+                if (hot && !(FA_DBG(a, DBG_NO_HOT))) {
+                    if (is) (void)hot_add(*hot, 0u, slo, shi, sh1, 0ull, true);
+                    if (id) (void)hot_add(*hot, 1u, dlo, dhi, dh1, 0ull, true);
+                }
             }
         }
     }

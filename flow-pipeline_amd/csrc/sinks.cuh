@@ -570,32 +570,37 @@ __device__ __forceinline__ bool keyset_step(const KArgs& a, KeySlot* tab, unsign
     // a new key in nearly every tile); a claimed-not-ready view: ask the memory side first
     const unsigned long long seen = s == &tab[i1] && (c0.x & KS_READY) ? c1.x : c0.x;
     unsigned long long t = seen == 0ull ? atomicCAS(&s->tag, 0ull, mytag) : __hip_atomic_load(&s->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (seen == 0ull && t == 0ull) {  // claimed: publish the key, then mark it readable
+    bool won = seen == 0ull && t == 0ull;
+    if (!won && t == 0ull) {  // (the plain view showed a claim the memory side does not have)
+        t = atomicCAS(&s->tag, 0ull, mytag);
+        won = t == 0ull;
+    }
+    if (won) {  // claimed: publish the key, then mark it readable
         const unsigned long long o1 = atomicExch(&s->lo, lo), o2 = atomicExch(&s->hi, hi);
         if ((o1 & o2) != ~0ull) atomicOr(&s->tag, KS_READY);  // (always true: orders the OR behind both writes)
-        return true;
     }
+    // Several lanes of ONE wave may carry the same new key (a heavy hitter's first tile; every instance of a fresh candidate in
+    // candidates mode): one of them wins the claim above, the others wait below for its READY bit - and the winner only sets it
+    // if its block has run by then.  In the C++ model the two are unrelated threads and round 4's form (early returns out of
+    // both branches) left their order to the block layout: in the workgroup-tile kernel the losers came first, spun their 4096
+    // rounds against a lane that could not run, gave up and stored the key AGAIN one slot further - 16 copies per heavy key
+    // (found by the candidates mode's threshold, which counts the set's rows), and milliseconds of spinning in a kernel's
+    // first launch.  The ballot is a convergent operation: the publish block cannot sink below it, the wait cannot rise above.
+    const unsigned long long claimers = __builtin_amdgcn_ballot_w64(won);
+    asm volatile("" ::"s"(claimers) : "memory");
+    if (won) return true;
     if (t == (mytag | KS_READY)) {
         const unsigned long long l = __hip_atomic_load(&s->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long q = __hip_atomic_load(&s->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return l == lo && q == hi;  // (false: equal tag, different key)
     }
-    if (t != 0 && t != mytag) return false;  // somebody else's slot
-    if (t == 0) {
-        t = atomicCAS(&s->tag, 0ull, mytag);
-        if (t == 0) {  // claimed: publish the key, then mark it readable
-            const unsigned long long o1 = atomicExch(&s->lo, lo), o2 = atomicExch(&s->hi, hi);
-            if ((o1 & o2) != ~0ull) atomicOr(&s->tag, KS_READY);  // (always true: orders the OR behind both writes)
-            return true;
-        }
-    }
-    // (claimers of this wave have published by now; owners in other waves are a few instructions away)
-    if ((t | KS_READY) == (mytag | KS_READY)) {
-        for (int spin = 0; spin < 4096 && !(t & KS_READY); spin++) t = atomicOr(&s->tag, 0ull);
-        if (t & KS_READY) {
-            const unsigned long long l = atomicAdd(&s->lo, 0ull), q = atomicAdd(&s->hi, 0ull);  // memory-side reads
-            return l == lo && q == hi;
-        }
+    if ((t | KS_READY) != (mytag | KS_READY)) return false;  // somebody else's slot
+    // an equal tag whose key is still being written: by a lane of this wave (it has published: above) or of another wave (a
+    // few instructions away)
+    for (int spin = 0; spin < 4096 && !(t & KS_READY); spin++) t = atomicOr(&s->tag, 0ull);
+    if (t & KS_READY) {
+        const unsigned long long l = atomicAdd(&s->lo, 0ull), q = atomicAdd(&s->hi, 0ull);  // memory-side reads
+        return l == lo && q == hi;
     }
     return false;
 }
