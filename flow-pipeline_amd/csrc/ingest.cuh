@@ -156,7 +156,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             if (vs && hot_add(*hot, 0u, slo, shi, sh1, ws, ws != cw)) vs = false;
             if (vd && hot_add(*hot, 1u, dlo, dhi, dh1, wd, wd != cw)) vd = false;
         }
-        if (cand) {  // candidates mode: the row-0 words of the candidate bits instead of the sets' home slots (L2-resident)
+        if (cand) {  // candidates mode: the row-0 word of the candidate bits instead of the sets' home slots (L2-resident)
             if (vs && keys_on) cw0s = cand_word(a.cand_src, a.cms_wl2, 0, cms_column(cms_key(sh1, sh2, a.cms_wl2), 0, a.cms_wl2));
             if (vd && keys_on) cw0d = cand_word(a.cand_dst, a.cms_wl2, 0, cms_column(cms_key(dh1, dh2, a.cms_wl2), 0, a.cms_wl2));
         } else {
@@ -280,20 +280,18 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             }
         }
         if (keys_on && !cand) keyset_finish2(a, vs, ps, sh1, slo, shi, vd, pd, dh1, dlo, dhi);
-        if (keys_on && cand) {  // the few addresses whose estimate stood above the threshold at the last boundary join the candidates
+        if (keys_on && cand) {
+            // the few addresses whose estimate stood above the threshold at the last boundary join the candidates.  What this costs
+            // is the gathers, not the set (same-box ablation, measurement build, 16.67 M records per launch: no test at all
+            // 0.940 ms; the row-0 word of every address instance +0.117; all four rows' words loaded ahead of the sink +0.216 -
+            // slower than the exact mode's 1.147; the rows behind the first and the look into the set only for what passes row 0:
+            // +0.04) - so only the row-0 word travels early, and a 64-lane gather of 4-byte words out of the L2 is what an
+            // address instance pays in this mode.
             const bool is = vs && cand_pass(a.cand_src, a.cms_depth, a.cms_wl2, cms_key(sh1, sh2, a.cms_wl2), cw0s);
             const bool id = vd && cand_pass(a.cand_dst, a.cms_depth, a.cms_wl2, cms_key(dh1, dh2, a.cms_wl2), cw0d);
-            if (FA_ANY(is || id)) {
+            if (FA_ANY(is || id) && !FA_DBG(a, DBG_CAND_NO_SET)) {
                 if (is) keyset_insert_h(a, a.ks_src, slo, shi, sh1);
                 if (id) keyset_insert_h(a, a.ks_dst, dlo, dhi, dh1);
-                // an address that stands above the threshold is heavy by definition: it moves into the workgroup's hot-address
-                // cache now (the usual admission wants it twice in one wave-tile), so that its next instances here are one LDS
-                // add each instead of four cached loads and a look into the set; the launch's end offers it to the set once
-                // (its weight of THIS record has left as a tuple above: the entry starts at 0)
-                if (hot && !(FA_DBG(a, DBG_NO_HOT))) {
-                    if (is) (void)hot_add(*hot, 0u, slo, shi, sh1, 0ull, true);
-                    if (id) (void)hot_add(*hot, 1u, dlo, dhi, dh1, 0ull, true);
-                }
             }
         }
     }

@@ -2,7 +2,7 @@
 library-owned device buffers - out-of-place all-reduce of the sketches into the merged view, uneven all-gather of
 every row kind's device buffer (fa_rows_device) followed by fa_rows_merge_device - must reproduce the single-rank
 results bit for bit.  (The same code with two ranks runs over the gloo transport on the shared GPU in
-test_round2_gpu.py, the device merge of two contexts' rows in test_round3_gpu.py; 8-GPU runs belong to the driver.)"""
+test_ingest_sinks_gpu.py, the device merge of two contexts' rows in test_window_close_gpu.py; 8-GPU runs belong to the driver.)"""
 import os
 import subprocess
 import sys

@@ -1,4 +1,4 @@
-"""Round-2 GPU parity tests (all through the C-ABI, bit-exact against the oracle): compact / wide scatter tuples
+"""Ingest sinks (all through the C-ABI, bit-exact against the oracle): compact / wide scatter tuples
 and the adaptive switch between them, the 67-field producer on the canonical fast path, the order-free parser in
 place, lossless table growth from a tiny table, the in-library RCCL merge (world 1), a 2-rank window close on
 one GPU over gloo (idempotent merges), and the bench harness's N>1 path."""

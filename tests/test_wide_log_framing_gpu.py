@@ -1,4 +1,4 @@
-"""Round-4 GPU tests: the adaptive wide log end to end (enter - leave - drain through both folds), its behaviour when
+"""The wide log, the partitioned close and device-side framing: the adaptive wide log end to end (enter - leave - drain through both folds), its behaviour when
 segment buffers run out, watermark closes of real timeslots, late records, the hash-partitioned window close (device
 partition == numpy restatement; two ranks on the one GPU), and window reads that leave through the pinned buffer in
 pieces.  All through the C-ABI, bit-exact against the oracle restatements."""

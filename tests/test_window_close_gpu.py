@@ -1,9 +1,9 @@
-"""Round-3 GPU tests: the device-resident window close (ABI 5: fa_rows_device / fa_rows_merge_device / fa_drop_window).
+"""The device-resident window close (ABI 5: fa_rows_device / fa_rows_merge_device / fa_drop_window).
 
 Two ctxs on the one GPU stand for two ranks: each ingests half of the Kafka partitions, their device row buffers are
 concatenated in HBM (what the RCCL all-gather leaves on every rank) and merged by the library's kernels - every row
 kind, tumbling and sliding windows - against a ctx that ingested everything and against the oracle.  The transport
-(nccl world 1, gloo with two processes) is covered in test_dist_nccl_gpu.py / test_round2_gpu.py."""
+(nccl world 1, gloo with two processes) is covered in test_dist_nccl_gpu.py / test_ingest_sinks_gpu.py."""
 import numpy as np
 import pytest
 

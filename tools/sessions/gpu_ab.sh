@@ -9,7 +9,7 @@ B="--steps 10 --warmup 3 --cpu-sample 0 --no-host-fed"
 for v in "" $VARIANTS; do
   name=${v:-base}
   if [ -n "$v" ]; then export FA_LIB_VARIANT=$v; else unset FA_LIB_VARIANT; fi
-  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_round2_gpu.py -m gpu -q -x -k "large_device or tuple_formats or segment_overflow or rollup_matches" > $OUT/pytest_$name.log 2>&1
+  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_ingest_sinks_gpu.py -m gpu -q -x -k "large_device or tuple_formats or segment_overflow or rollup_matches" > $OUT/pytest_$name.log 2>&1
   echo "$name: $(tail -1 $OUT/pytest_$name.log)"
   timeout 300 python bench.py $B $EXTRA_ARGS > $OUT/bench_${name}.json 2> $OUT/bench_${name}.err
   timeout 300 python bench.py $B --chunk 16666667 --no-verify $EXTRA_ARGS > $OUT/bench_${name}_c16.json 2> $OUT/bench_${name}_c16.err

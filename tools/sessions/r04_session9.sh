@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/r04s9
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_round4_gpu.py -m gpu -q -x > $OUT/pytest_round4.log 2>&1; tail -5 $OUT/pytest_round4.log
+timeout 900 python -m pytest tests/test_wide_log_framing_gpu.py -m gpu -q -x > $OUT/pytest_round4.log 2>&1; tail -5 $OUT/pytest_round4.log
 FA_VERBOSE=1 timeout 900 python tools/config5_run.py > $OUT/config5_100M.json 2> $OUT/config5_100M.err; echo "config5 pageable rc=$?"
 FA_VERBOSE=1 timeout 900 python tools/config5_run.py --pinned-out > $OUT/config5_100M_pinned.json 2> $OUT/config5_100M_pinned.err; echo "config5 pinned rc=$?"
 for f in config5_100M config5_100M_pinned; do echo "== $f"; grep '^{' $OUT/$f.json | tail -1 | python -c "
