@@ -101,8 +101,9 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         }
     }
     if (mine && !sure) {  // (one counter atomic per wave: the compiler folds the lanes' adds - s_bcnt1 + mbcnt)
-        unsigned int j = atomicAdd(&a.ctr->retry_count[a.par], 1u);
-        a.retry_idx[j] = rec_idx;
+        const KArgs ca = cold_args();
+        unsigned int j = atomicAdd(&ca.ctr->retry_count[ca.par], 1u);
+        ca.retry_idx[j] = rec_idx;
     }
     after_parse();
     // ---- sink ----
@@ -255,14 +256,15 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         // direct path (what is left): device-wide table, one atomic line transaction per record
         if (__builtin_amdgcn_ballot_w64(pending) != 0ull && !(FA_DBG(a, DBG_NO_GLOBAL))) {  // wave-uniform
             Slot* sp = nullptr;
+            const KArgs ca = cold_args();  // (table, mask, spill buffer, counters: not kept in SGPRs for the tiles that never get here)
             if (pending) {
                 tally.direct++;
                 if (T8 && !lt_on) {
                     pack_key(tb, r.src_as, r.dst_as, r.etype, k0, k1);
                     h = key_hash(k0, k1);
                 }
-                sp = table_find_or_claim(a, k0, k1, h);
-                if (!sp) spill_park(a, k0, k1, b, p, c);
+                sp = table_find_or_claim(ca, k0, k1, h);
+                if (!sp) spill_park(ca, k0, k1, b, p, c);
             }
             quad_atomic_update(sp, b, p, c);
         }
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
                     else tup16_unpack(tv, v);
                     uint64_t k0, k1;
                     pack_key(tb_base + v.tbr, v.src_as, v.dst_as, v.etype, k0, k1);
-                    agg_global(a, k0, k1, key_hash(k0, k1), v.bytes, v.packets, 1);
+                    agg_global(cold_args(), k0, k1, key_hash(k0, k1), v.bytes, v.packets, 1);
                     tally.direct++;
                 }
             }

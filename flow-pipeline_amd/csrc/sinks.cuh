@@ -222,6 +222,23 @@ struct KArgs {
     uint32_t late_below;    // time buckets below it were closed (flows_5m): records that still arrive for them are counted
 };
 
+// The kernel's arguments, read again from its kernarg segment - for the RARE blocks of the ingest kernels (direct path, deferral
+// lists, segment-overflow fallbacks).  Kernel arguments are loop-invariant and always loadable, so the compiler loads every one of
+// them at the kernel's entry and keeps it in an SGPR for the kernel's life: wtile_kernel<1, true> needs 106 SGPRs that way and pays
+// for it with 58 v_writelane / 139 v_readlane (SGPRs spilled to VGPR lanes), a dozen and a half of them per tile.  A block that
+// runs once in a thousand tiles reads its table pointer, mask, spill buffer and counters HERE instead - the empty asm makes the
+// segment pointer opaque, so the loads stay inside the block - and the by-value copies of those fields die early.
+// (every kernel that calls this takes its KArgs as the FIRST parameter: offset 0 of the segment)
+__device__ __forceinline__ KArgs cold_args() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const KArgs* p = (const KArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // (address space 4 -> generic: the loads below become flat loads - fine for blocks this rare)
+    asm volatile("" : "+s"(p));
+    return *p;
+#else
+    return KArgs{};  // (the host pass only parses device code)
+#endif
+}
+
 __device__ __forceinline__ WArgs wargs(const KArgs& a) {
     return WArgs{a.wtab, a.wmask, a.wmask >> a.wplog2, a.wspill, a.wspill_cap, &a.ctr->wspill_count, &a.ctr->wspill_lost, &a.ctr->wused};
 }
@@ -1015,7 +1032,7 @@ __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t
                 for (int e = 0; e < (T8 ? 2 : 1); e++) {
                     uint64_t q0, q1;
                     pack_key(tb_base + v[e].tbr, v[e].src_as, v[e].dst_as, v[e].etype, q0, q1);
-                    agg_global(a, q0, q1, key_hash(q0, q1), v[e].bytes, v[e].packets, 1);
+                    agg_global(cold_args(), q0, q1, key_hash(q0, q1), v[e].bytes, v[e].packets, 1);
                     n_direct++;
                 }
                 if (sub == 0) atomicSub(&part_cnt[fp], 1u);  // (the line was not stored: the 16-bit counter stays <= its cap)
