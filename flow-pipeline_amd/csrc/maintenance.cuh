@@ -578,12 +578,6 @@ __global__ __launch_bounds__(256) void topk_thresh_kernel(const unsigned int* hi
 // (topk_candidates).  Behind launch t:  cand_scan_kernel (estimates of R_t -> histogram; sum of row 0) and cand_bits_kernel
 // (theta_t; one bit per counter: counter >= theta_t).  The ingest kernel of launch t + 1 tests an address against the bits of
 // all its counters - that IS estimate_t(x) >= theta_t - and only then touches the set.
-struct CandState {
-    unsigned int hist[TK_BINS];
-    unsigned int sel[4];       // [0] bin of rank K, [1] candidates in the bins >= it, [2] candidates held
-    unsigned long long total;  // N_t
-    unsigned long long theta;  // theta_t (written by cand_bits_kernel: fa_stats / tests)
-};
 constexpr uint32_t CAND_SCAN_BLOCKS = 256;
 // grid (CAND_SCAN_BLOCKS, sketches): y = 0 SrcAddr, 1 DstAddr (a sketch that is off has ks == nullptr)
 __global__ __launch_bounds__(256) void cand_scan_kernel(KeySlot* ks0, KeySlot* ks1, uint32_t nslots, const unsigned long long* cms0, const unsigned long long* cms1,
@@ -627,7 +621,15 @@ __global__ __launch_bounds__(256) void cand_bits_kernel(const KeySlot* ks0, cons
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     for (size_t c0 = wave * 64; c0 < ncnt; c0 += nwaves * 64) {
         const unsigned long long m = __builtin_amdgcn_ballot_w64(c0 + lane < ncnt && cms[c0 + lane] >= theta);
-        if (lane == 0) *reinterpret_cast<unsigned long long*>(&bits[c0 >> 5]) = m;
+        if (lane == 0) {
+            *reinterpret_cast<unsigned long long*>(&bits[c0 >> 5]) = m;
+            // row 0 folded down to 4 KiB (sinks.cuh, CandState::summary): what the ingest kernel asks first, out of the CU's L1
+            if (m != 0ull && c0 < ((size_t)1 << wl2)) {
+                const uint32_t w0 = (uint32_t)(c0 >> 5) & (CAND_SUMMARY_WORDS - 1u);
+                if ((uint32_t)m) atomicOr(&my->summary[w0], (unsigned int)m);
+                if ((uint32_t)(m >> 32)) atomicOr(&my->summary[(w0 + 1u) & (CAND_SUMMARY_WORDS - 1u)], (unsigned int)(m >> 32));
+            }
+        }
     }
 }
 
