@@ -272,7 +272,6 @@ static KArgs make_args(fa_ctx* c) {
     a.ks_mask = (1u << c->ks_log2) - 1;
     a.cand_src = c->cand_bits[0];
     a.cand_dst = c->cand_bits[1];
-    a.cand_state = c->cand_state;
     a.cms_nrep = c->cand_state ? 1u : CMS_REPLICAS;
     a.cols = c->cols;
     a.dbg = c->dbg;

@@ -157,9 +157,9 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             if (vs && hot_add(*hot, 0u, slo, shi, sh1, ws, ws != cw)) vs = false;
             if (vd && hot_add(*hot, 1u, dlo, dhi, dh1, wd, wd != cw)) vd = false;
         }
-        if (cand) {  // candidates mode: the word of the folded row-0 bits (4 KiB per sketch: the CU's L1) instead of the sets' home slots
-            if (vs && keys_on) cw0s = cand_summary_word(a.cand_state, cms_column(cms_key(sh1, sh2, a.cms_wl2), 0, a.cms_wl2));
-            if (vd && keys_on) cw0d = cand_summary_word(a.cand_state + 1, cms_column(cms_key(dh1, dh2, a.cms_wl2), 0, a.cms_wl2));
+        if (cand) {  // candidates mode: the row-0 word of the candidate bits instead of the sets' home slots (L2-resident)
+            if (vs && keys_on) cw0s = cand_word(a.cand_src, a.cms_wl2, 0, cms_column(cms_key(sh1, sh2, a.cms_wl2), 0, a.cms_wl2));
+            if (vd && keys_on) cw0d = cand_word(a.cand_dst, a.cms_wl2, 0, cms_column(cms_key(dh1, dh2, a.cms_wl2), 0, a.cms_wl2));
         } else {
             if (vs && keys_on) ps = keyset_probe(a, a.ks_src, sh1);
             if (vd && keys_on) pd = keyset_probe(a, a.ks_dst, dh1);
@@ -284,28 +284,17 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         if (keys_on && !cand) keyset_finish2(a, vs, ps, sh1, slo, shi, vd, pd, dh1, dlo, dhi);
         if (keys_on && cand) {
             // the few addresses whose estimate stood above the threshold at the last boundary join the candidates.  What this costs
-            // is the gathers, not the set (same-box ablation, measurement build, 16.67 M records per launch: no test at all
-            // 0.940 ms; the row-0 word of every address instance +0.117; all four rows' words loaded ahead of the sink +0.216 -
-            // slower than the exact mode's 1.147; the rows behind the first and the look into the set only for what passes row 0:
-            // +0.04) - so only the row-0 word travels early, and a 64-lane gather of 4-byte words out of the L2 is what an
-            // address instance pays in this mode.
-            // (round 5's last step: the word that travels early is the one of the 4 KiB fold of the row-0 bits - an L1 hit; the real
-            // bits and the set are only looked at by the few instances whose folded bit is set)
-            bool is = vs && ((cw0s >> (cms_column(cms_key(sh1, sh2, a.cms_wl2), 0, a.cms_wl2) & 31u)) & 1u);
-            bool id = vd && ((cw0d >> (cms_column(cms_key(dh1, dh2, a.cms_wl2), 0, a.cms_wl2) & 31u)) & 1u);
-            if (FA_ANY(is || id)) {
-                if (is) {
-                    const CmsKey k = cms_key(sh1, sh2, a.cms_wl2);
-                    is = cand_pass(a.cand_src, a.cms_depth, a.cms_wl2, k, cand_word(a.cand_src, a.cms_wl2, 0, cms_column(k, 0, a.cms_wl2)));
-                }
-                if (id) {
-                    const CmsKey k = cms_key(dh1, dh2, a.cms_wl2);
-                    id = cand_pass(a.cand_dst, a.cms_depth, a.cms_wl2, k, cand_word(a.cand_dst, a.cms_wl2, 0, cms_column(k, 0, a.cms_wl2)));
-                }
-                if (!FA_DBG(a, DBG_CAND_NO_SET)) {
-                    if (is) keyset_insert_h(a, a.ks_src, slo, shi, sh1);
-                    if (id) keyset_insert_h(a, a.ks_dst, dlo, dhi, dh1);
-                }
+            // is the test of EVERY address instance, not the set (same-box ablation, measurement build, 16.67 M records per launch:
+            // no test at all 0.940 ms; the row-0 word of every instance +0.117; all four rows' words loaded ahead of the sink
+            // +0.216 - slower than the exact mode's 1.147; the rows behind the first and the look into the set for what passes
+            // row 0: +0.04).  Where the word comes from does not matter either: a 4 KiB fold of the row-0 bits asked first, out of
+            // the CU's L1, measured 1.1645 against the exact mode's 1.1544 ms - an instance pays the test's instructions and the
+            // values it keeps alive across the sink in a kernel that already lives on 128 VGPRs.  So: one word early, the rest late.
+            const bool is = vs && cand_pass(a.cand_src, a.cms_depth, a.cms_wl2, cms_key(sh1, sh2, a.cms_wl2), cw0s);
+            const bool id = vd && cand_pass(a.cand_dst, a.cms_depth, a.cms_wl2, cms_key(dh1, dh2, a.cms_wl2), cw0d);
+            if (FA_ANY(is || id) && !FA_DBG(a, DBG_CAND_NO_SET)) {
+                if (is) keyset_insert_h(a, a.ks_src, slo, shi, sh1);
+                if (id) keyset_insert_h(a, a.ks_dst, dlo, dhi, dh1);
             }
         }
     }

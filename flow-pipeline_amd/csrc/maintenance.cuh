@@ -621,15 +621,7 @@ __global__ __launch_bounds__(256) void cand_bits_kernel(const KeySlot* ks0, cons
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     for (size_t c0 = wave * 64; c0 < ncnt; c0 += nwaves * 64) {
         const unsigned long long m = __builtin_amdgcn_ballot_w64(c0 + lane < ncnt && cms[c0 + lane] >= theta);
-        if (lane == 0) {
-            *reinterpret_cast<unsigned long long*>(&bits[c0 >> 5]) = m;
-            // row 0 folded down to 4 KiB (sinks.cuh, CandState::summary): what the ingest kernel asks first, out of the CU's L1
-            if (m != 0ull && c0 < ((size_t)1 << wl2)) {
-                const uint32_t w0 = (uint32_t)(c0 >> 5) & (CAND_SUMMARY_WORDS - 1u);
-                if ((uint32_t)m) atomicOr(&my->summary[w0], (unsigned int)m);
-                if ((uint32_t)(m >> 32)) atomicOr(&my->summary[(w0 + 1u) & (CAND_SUMMARY_WORDS - 1u)], (unsigned int)(m >> 32));
-            }
-        }
+        if (lane == 0) *reinterpret_cast<unsigned long long*>(&bits[c0 >> 5]) = m;
     }
 }
 

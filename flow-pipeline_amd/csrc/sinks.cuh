@@ -145,19 +145,12 @@ __host__ __device__ __forceinline__ unsigned long long topk_bin_floor(uint32_t b
 }
 
 // candidates mode (maintenance.cuh "candidates mode"): the state of a sketch's launch boundary, in device memory
-constexpr uint32_t CAND_SUMMARY_WORDS = 1024;  // 2^15 bits
 struct CandState {
     unsigned int hist[TK_BINS];
     unsigned int sel[4];       // [0] bin of rank K, [1] candidates in the bins >= it, [2] candidates held
     unsigned long long total;  // N_t
     unsigned long long theta;  // theta_t (written by cand_bits_kernel: fa_stats / tests)
-    // The row-0 candidate bits (one per column: 128 KiB at 2^20 columns) folded down to 4 KiB: bit j = OR of the row-0 bits of the
-    // columns c with c mod 2^15 == j.  A clear bit says "not a candidate" for sure, and 4 KiB stay in the CU's vector L1: nine in
-    // ten address instances are turned away by an L1 hit instead of a 64-lane gather out of the L2 (which cost the candidates
-    // mode as much as the exact mode's HBM probes cost that one: profiles/r05_exp_candidates_ablation.jsonl).
-    unsigned int summary[CAND_SUMMARY_WORDS];
 };
-__device__ __forceinline__ uint32_t cand_summary_word(const CandState* st, uint32_t col0) { return st->summary[(col0 >> 5) & (CAND_SUMMARY_WORDS - 1u)]; }
 
 struct ColumnPtrs {
     uint64_t *time_received, *time_flow_start, *sampling_rate, *bytes, *packets;
@@ -193,7 +186,6 @@ struct KArgs {
     // address instance for the exact-universe sets.  nullptr: every address ever seen is kept (the exact mode).
     const uint32_t* cand_src;
     const uint32_t* cand_dst;
-    const CandState* cand_state;  // [2] (SrcAddr, DstAddr): the folded row-0 bits the ingest kernels ask first
     uint32_t cms_nrep;  // sketch copies the atomic paths spread over (CMS_REPLICAS; 1 in candidates mode: the boundary reads copy 0)
     uint32_t ks_mask;
     ColumnPtrs cols;
@@ -723,9 +715,7 @@ __device__ __forceinline__ void keyset_offer(const KArgs& a, uint32_t set, const
     const uint32_t* bits = set ? a.cand_dst : a.cand_src;
     if (bits) {
         const CmsKey k = cms_key(h1, h2, a.cms_wl2);
-        const uint32_t col0 = cms_column(k, 0, a.cms_wl2);
-        if (!((cand_summary_word(a.cand_state + set, col0) >> (col0 & 31u)) & 1u)) return;
-        if (!cand_pass(bits, a.cms_depth, a.cms_wl2, k, cand_word(bits, a.cms_wl2, 0, col0))) return;
+        if (!cand_pass(bits, a.cms_depth, a.cms_wl2, k, cand_word(bits, a.cms_wl2, 0, cms_column(k, 0, a.cms_wl2)))) return;
     }
     keyset_insert_h(a, set ? a.ks_dst : a.ks_src, lo, hi, h1);
 }
