@@ -191,7 +191,7 @@ def gpu_clocks(device):
     return out or None
 
 
-def preflight(fa, torch, dist, rank, world, local_rank, backend, xdev):
+def preflight(fa, torch, dist, rank, world, local_rank, backend, xdev, strict=False):
     """world > 1, before anything is timed: the three exchanges of a window close on tiny KNOWN data - the uneven all-gather of
     device row buffers, the all-to-all with split sizes, the in-library ncclAllReduce through a communicator made here with
     ncclCommInitRank - each checked against numpy.  The first run on an 8-GPU node can then tell a failing collective from a
@@ -289,7 +289,10 @@ def preflight(fa, torch, dist, rank, world, local_rank, backend, xdev):
             with open(dbg, errors="replace") as f:
                 tail = "".join(f.readlines()[-40:])
         sys.stderr.write("bench.py preflight FAILED on rank %d: %s\n--- NCCL_DEBUG=WARN tail (%s) ---\n%s\n" % (rank, json.dumps(res), dbg or "stderr", tail))
-        raise SystemExit(3)
+        if strict:
+            raise SystemExit(3)
+        # (not fatal by default: the line then carries preflight.ok = false with the exchange that failed, and the run's own
+        # parity leg - merged rows against the oracle's rollup of all partitions - still decides whether the result stands)
     return res
 
 
@@ -338,6 +341,7 @@ def main():
     ap.add_argument("--no-assert", action="store_true", help="ablation runs (FA_DEBUG_FLAGS): skip result checks")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --records is the WHOLE job's step, split evenly over the ranks "
                     "(default: weak - every rank is a Kafka partition with --records of its own)")
+    ap.add_argument("--strict-preflight", action="store_true", help="world > 1: a failing preflight aborts the run (default: reported in the line, the run goes on)")
     ap.add_argument("--no-preflight", action="store_true", help="world > 1: skip the check of the three window-close exchanges on known data")
     args = ap.parse_args()
 
@@ -376,7 +380,7 @@ def main():
     clocks = {"start": gpu_clocks(local_rank)} if rank == 0 else None
     pre = None
     if world > 1 and not args.no_preflight:
-        pre = preflight(fa, torch, dist, rank, world, local_rank, backend, xdev)
+        pre = preflight(fa, torch, dist, rank, world, local_rank, backend, xdev, strict=args.strict_preflight)
     # every rank = one Kafka partition with its own stream (seed 2 = config 2, + rank)
     mp = fa.mock_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000,
                         zipf_s_x100=args.zipf_s, zipf_log2_universe=args.zipf_universe_log2)

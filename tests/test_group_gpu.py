@@ -182,3 +182,30 @@ def test_group_over_rccl_world_1(gpu_lib, fa, po):
             assert st.cms_src_merged and a.cms_read(fa.FA_KEYS_SRCADDR_CMS).tobytes() == whole.cms_read(fa.FA_KEYS_SRCADDR_CMS).tobytes()
             assert g.topk(fa.FA_KEYS_DSTADDR_CMS, 50).tobytes() == whole.topk(fa.FA_KEYS_DSTADDR_CMS, 50).tobytes()
             assert g.read_window(fa.ROWS_5M).tobytes() == whole.read_window().tobytes()
+
+
+def test_group_topk_in_candidates_mode(gpu_lib, fa, po):
+    """Members that keep candidates only: every member admits by ITS sketch and threshold, the group ranks the union by the MERGED
+    estimate - on a skewed stream whose heavy hitters recur in every batch of every partition the rows of a single ctx that keeps
+    every address; the merged views equal its sketch; fa_group_stats reports the highest threshold and the candidates held."""
+    n, nparts, nb = 960_000, 4, 6
+    buf, off, parts = _partitions(po, n, seed=905, nparts=nparts, zipf_log2=18)
+    kw = dict(framed=True, key_sets=7, cms_width_log2=16)
+    members = [fa.FlowAgg(topk_capacity_log2=14, topk_mode=fa.TOPK_CANDIDATES, topk_track=128, **kw) for _ in range(nparts)]
+    whole = fa.FlowAgg(topk_capacity_log2=20, **kw)
+    try:
+        for m, (b, o) in zip(members, parts):
+            step = (len(o) - 1) // nb
+            for i in range(nb):  # six launches per member: candidates join from the second on
+                lo, hi = i * step, (len(o) - 1 if i == nb - 1 else (i + 1) * step)
+                m.ingest(b[int(o[lo]):int(o[hi])], o[lo:hi + 1] - o[lo])
+        whole.ingest(buf, off)
+        with fa.FlowGroup(members) as g:
+            for ks in (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS):
+                assert g.topk(ks, 50).tobytes() == whole.topk(ks, 50).tobytes()
+                assert members[1].cms_read(ks).tobytes() == whole.cms_read(ks).tobytes()
+            st = g.stats()
+            assert st["records_ok"] == n and st["topk_theta_src"] > 1 and 50 <= st["topk_candidates_src"] < 4 * (1 << 14)
+    finally:
+        for m in members + [whole]:
+            m.close()
