@@ -116,3 +116,38 @@ def test_candidates_mode_finds_the_exact_modes_top_k_on_a_skewed_stream(gpu_lib,
             assert cand.topk(ks, 100).tobytes() == exact.topk(ks, 100).tobytes()
             assert len(cand.topk(ks, 1 << 20)) < len(exact.topk(ks, 1 << 20)) // 8
         assert cand.read_window().tobytes() == exact.read_window().tobytes()
+
+
+@pytest.mark.parametrize("depth,wl2,track,cap", [(1, 4, 8, 14), (3, 9, 16, 12), (5, 20, 64, 12), (16, 8, 32, 14), (2, 5, 4, 14)])
+def test_odd_sketch_geometries_in_both_topk_modes(gpu_lib, fa, po, depth, wl2, track, cap):
+    """Sketches that do not go through the scatter sink (too narrow, too deep: every update is an atomic), rows beyond the fourth in
+    the estimates, fewer than 64 counters per row in the candidate bits: the exact mode's reads are prefixes of the full ranking,
+    the candidates mode equals its restatement."""
+    n, nb, seed = 200_000, 5, 0xC0FFEE
+    bs = _batches(po, n, nb, 1500 + depth, 12)
+    rows_all = np.concatenate([r for _, _, r in bs])
+    with np.errstate(over="ignore"):
+        w_all = rows_all["bytes"] * rows_all["sampling_rate"]
+    kw = dict(framed=True, key_sets=7, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed)
+    with fa.FlowAgg(topk_capacity_log2=15, **kw) as exact, fa.FlowAgg(topk_capacity_log2=cap, topk_mode=fa.TOPK_CANDIDATES, topk_track=track, **kw) as cand:
+        for buf, off, _ in bs:
+            exact.ingest(buf, off)
+            cand.ingest(buf, off)
+        for col, ks in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+            sk = po.cms_sketch_numpy(rows_all[col], w_all, depth, wl2, seed)
+            assert np.array_equal(exact.cms_read(ks).reshape(-1), sk) and np.array_equal(cand.cms_read(ks).reshape(-1), sk)
+            keys = np.unique(np.ascontiguousarray(rows_all[col]), axis=0)
+            want = _ranked(keys, po.cms_estimates_numpy(sk, keys, depth, wl2, seed))
+            full = exact.topk(ks, 1 << 20)
+            assert [(bytes(r["key"]), int(r["weight"])) for r in full] == [(k, -e) for e, k in want]
+            for k in (5, 100, 1000, 100, 5):
+                assert exact.topk(ks, k).tobytes() == full[:k].tobytes(), k
+            batches = []
+            for _, _, rows in bs:
+                with np.errstate(over="ignore"):
+                    batches.append((rows[col], rows["bytes"] * rows["sampling_rate"]))
+            _, cset, cest, thetas = po.topk_candidates(batches, depth, wl2, seed, track=track, capacity_log2=cap)
+            got = cand.topk(ks, 1 << 20)
+            assert [(bytes(r["key"]), int(r["weight"])) for r in got] == [(k, -e) for e, k in _ranked(cset, cest)], (col, len(got), len(cset))
+            st = cand.stats()
+            assert st["topk_theta_" + ("src" if col == "src_addr" else "dst")] == thetas[-1]
