@@ -23,7 +23,8 @@
 //     whole topic - flows_5m rows merged over the partitions in HBM, (SrcAddr,DstPort,Proto) rows hash-partitioned over
 //     the GPUs, sketches all-reduced, top-k of the merged sketch.  Flushes (fa_ingest, one goroutine's ctx) hold a read
 //     lock, a close the write lock: a group call uses every member;
-//   - insert_count is actually incremented.
+//   - insert_count is actually incremented;
+//   - -gpu.table.log2 / -gpu.keyset.log2 / -gpu.wide.log2 size a context's tables (fa_config; 0 = the library's defaults).
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -38,6 +39,11 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "../../include/flowagg.h"
 
@@ -60,6 +66,7 @@ struct Flags {
     std::string OutRowBinary, OutTsv, OffsetsOut, MetricsDump;
     std::string OutApp, OutTopk, GpuTransport = "peer";  // raw fa_row_app records / "src|dst <hex key> <weight>" lines; peer | rccl
     long TopkK = 100;
+    long TableLog2 = 0, KeysetLog2 = 0, WideLog2 = 0;  // fa_config capacities (0 = the library's defaults)
     bool DryRun = false;  // test double for the host logic: batches are logged, nothing is computed
     bool CloseAllAtEnd = true;
 };
@@ -134,7 +141,8 @@ static Flags parse_flags(int argc, char** argv) {
     std::map<std::string, long*> ints = {
         {"flush.count", &f.FlushCount}, {"postgres.port", &f.PostgresPort}, {"gpu.devices", &f.GpuDevices},
         {"window.secs", &f.WindowSecs}, {"window.lag", &f.CloseLagSec},
-        {"key.sets", &f.KeySets}, {"topk.k", &f.TopkK}};
+        {"key.sets", &f.KeySets}, {"topk.k", &f.TopkK}, {"gpu.table.log2", &f.TableLog2}, {"gpu.keyset.log2", &f.KeysetLog2},
+        {"gpu.wide.log2", &f.WideLog2}};
     std::map<std::string, bool*> bools = {{"proto.fixedlen", &f.ProtoFixed}, {"sink.dryrun", &f.DryRun},
                                           {"window.closeall", &f.CloseAllAtEnd}};
     for (int i = 1; i < argc; i++) {
@@ -185,16 +193,22 @@ struct ConsumerGroupSession {
     }
 };
 
+struct MappedLog {  // a read-only view of a partition log file (lives until exit)
+    const uint8_t* data = nullptr;
+    size_t size = 0;
+    const uint8_t& operator[](size_t i) const { return data[i]; }
+};
+
 // One claimed partition: a message stream.  next() returns false when the claim is closed.
 class ConsumerGroupClaim {
 public:
-    ConsumerGroupClaim(int32_t part, std::vector<uint8_t> log, bool len32) : part_(part), log_(std::move(log)), len32_(len32) {}
+    ConsumerGroupClaim(int32_t part, MappedLog log, bool len32) : part_(part), log_(log), len32_(len32) {}
     int32_t Partition() const { return part_; }
     bool next(ConsumerMessage& m) {
-        if (pos_ >= log_.size()) return false;
+        if (pos_ >= log_.size) return false;
         size_t start = pos_, len = 0;
         if (len32_) {
-            if (log_.size() - pos_ < 4) fatal("partition %d: truncated length prefix at byte %zu", part_, pos_);
+            if (log_.size - pos_ < 4) fatal("partition %d: truncated length prefix at byte %zu", part_, pos_);
             uint32_t l;
             memcpy(&l, &log_[pos_], 4);
             start = pos_ + 4;
@@ -203,14 +217,14 @@ public:
             uint64_t v = 0;
             size_t p = pos_;
             for (int i = 0;; i++) {
-                if (i >= 10 || p >= log_.size()) fatal("partition %d: bad varint frame at byte %zu", part_, pos_);
+                if (i >= 10 || p >= log_.size) fatal("partition %d: bad varint frame at byte %zu", part_, pos_);
                 uint8_t b = log_[p++];
                 v |= (uint64_t)(b & 0x7f) << (7 * i);
                 if (!(b & 0x80)) break;
             }
             len = (p - pos_) + v;
         }
-        if (len > log_.size() - start) fatal("partition %d: message at byte %zu runs past the end of the log", part_, pos_);
+        if (len > log_.size - start) fatal("partition %d: message at byte %zu runs past the end of the log", part_, pos_);
         m = ConsumerMessage{part_, off_++, &log_[start], len};
         pos_ = start + len;
         return true;
@@ -218,7 +232,7 @@ public:
 
 private:
     int32_t part_;
-    std::vector<uint8_t> log_;
+    MappedLog log_;
     bool len32_;
     size_t pos_ = 0;
     int64_t off_ = 0;
@@ -296,7 +310,8 @@ struct PartitionState {
     fa_ctx* ctx = nullptr;
     std::vector<uint8_t> buf;       // message values back to back
     std::vector<uint64_t> offsets;  // n+1 entries
-    std::vector<ConsumerMessage> pending;
+    size_t pending = 0;             // messages in buf
+    ConsumerMessage last{};         // the newest of them: offsets of one partition are monotone, marking it commits the batch
 };
 
 class State : public ConsumerGroupHandler {
@@ -317,6 +332,9 @@ public:
                 cfg.window_secs = (uint32_t)f_.WindowSecs;
                 cfg.subwindow_secs = 0;  // the sink stores tumbling windows (what flows_5m holds, create.sh:96)
                 cfg.key_sets = (uint32_t)f_.KeySets;
+                cfg.table_capacity_log2 = (uint32_t)f_.TableLog2;
+                cfg.topk_capacity_log2 = (uint32_t)f_.KeysetLog2;
+                cfg.wide_capacity_log2 = (uint32_t)f_.WideLog2;
                 cfg.framed = f_.ProtoFixed ? 1 : 0;
                 int rc = fa_create(&cfg, &p->ctx);
                 if (rc != 0) fatal("fa_create: %d %s", rc, fa_last_error(nullptr));
@@ -343,9 +361,9 @@ public:
         while (claim.next(m)) {
             p->buf.insert(p->buf.end(), m.Value, m.Value + m.Len);
             p->offsets.push_back(p->buf.size());
-            p->pending.push_back(m);
-            if ((long)p->pending.size() >= f_.FlushCount) flush(*p, session);  // inserter.go:118-120
-            if (std::chrono::steady_clock::now() >= deadline) {                // inserter.go:189-191
+            p->last = m;
+            if ((long)++p->pending >= f_.FlushCount) flush(*p, session);  // inserter.go:118-120
+            if (std::chrono::steady_clock::now() >= deadline) {           // inserter.go:189-191
                 flush(*p, session);
                 closeWindows((int64_t)time(nullptr), false);
                 deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(f_.FlushTime);
@@ -361,7 +379,7 @@ public:
         if (n == 0) return;
         logf(3, "Processed %zu records in the last iteration.", n);
         if (f_.DryRun) {
-            logf(2, "dryrun flush partition=%d records=%zu bytes=%zu", p.pending.front().Partition, n, p.buf.size());
+            logf(2, "dryrun flush partition=%d records=%zu bytes=%zu", p.last.Partition, n, p.buf.size());
         } else {
             std::shared_lock<std::shared_mutex> rd(close_mu_);  // (not while the group closes a window: that uses every ctx)
             // fa_ingest copies into library-owned pinned memory before returning
@@ -370,10 +388,11 @@ public:
         }
         Inserts += n;
         Flushes += 1;
-        for (auto& m : p.pending) session.MarkMessage(m, "");  // after the sink accepted the batch
+        session.MarkMessage(p.last, "");  // after the sink accepted the batch; one mark per batch (the reference marks every message,
+                                          // inserter.go:188 - same committed offset, without 8 threads meeting on the session's lock per message)
         p.buf.clear();
         p.offsets.assign(1, 0);
-        p.pending.clear();
+        p.pending = 0;
     }
 
     // emits the finished windows of the WHOLE topic to the bulk-load sinks: flows_5m rows (create.sh:70-90) merged over the
@@ -466,15 +485,22 @@ private:
     uint64_t bad_ = 0;
 };
 
-static std::vector<uint8_t> read_file(const std::string& path) {
-    FILE* fp = fopen(path.c_str(), "rb");
-    if (!fp) fatal("cannot open %s", path.c_str());
-    std::vector<uint8_t> v;
-    uint8_t tmp[1 << 16];
-    size_t n;
-    while ((n = fread(tmp, 1, sizeof tmp, fp)) > 0) v.insert(v.end(), tmp, tmp + n);
-    fclose(fp);
-    return v;
+// a partition log, mapped (the page cache is the only copy; a Kafka client would hand out its fetch buffers the same way)
+static MappedLog map_file(const std::string& path) {
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) fatal("cannot open %s", path.c_str());
+    struct stat st;
+    if (fstat(fd, &st) != 0) fatal("cannot stat %s", path.c_str());
+    MappedLog m;
+    m.size = (size_t)st.st_size;
+    if (m.size) {
+        void* p = mmap(nullptr, m.size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p == MAP_FAILED) fatal("cannot map %s", path.c_str());
+        madvise(p, m.size, MADV_SEQUENTIAL);
+        m.data = (const uint8_t*)p;
+    }
+    close(fd);
+    return m;
 }
 
 int main(int argc, char** argv) {
@@ -498,7 +524,7 @@ int main(int argc, char** argv) {
     while (i <= f.InputFiles.size()) {
         size_t j = f.InputFiles.find(',', i);
         if (j == std::string::npos) j = f.InputFiles.size();
-        if (j > i) claims.push_back(std::make_unique<ConsumerGroupClaim>(part++, read_file(f.InputFiles.substr(i, j - i)), f.InputFormat == "len32"));
+        if (j > i) claims.push_back(std::make_unique<ConsumerGroupClaim>(part++, map_file(f.InputFiles.substr(i, j - i)), f.InputFormat == "len32"));
         i = j + 1;
     }
     for (auto& c : claims) session.claims.push_back(c->Partition());

@@ -96,6 +96,9 @@ var (
 	GpuTransport = flag.String("gpu.transport", "peer", "Window-close exchange between the GPUs: peer (hipMemcpyPeer over xGMI) or rccl (sketches by ncclAllReduce)")
 	OutTopk      = flag.String("out.topk", "", "At the end of a session write the top -topk.k SrcAddr / DstAddr of the merged Count-Min sketches here (key.sets 2 / 4)")
 	TopkK        = flag.Int("topk.k", 100, "Rows of -out.topk per sketch")
+	TableLog2    = flag.Int("gpu.table.log2", 0, "log2 slots of a context's flows_5m table (0 = library default)")
+	KeysetLog2   = flag.Int("gpu.keyset.log2", 0, "log2 slots of a context's distinct-address sets (0 = library default)")
+	WideLog2     = flag.Int("gpu.wide.log2", 0, "log2 slots of a context's (SrcAddr,DstPort,Proto) table (0 = library default)")
 
 	Inserts = prometheus.NewCounter(prometheus.CounterOpts{Name: "insert_count", Help: "Flow messages aggregated on the GPU."})
 )
@@ -138,6 +141,9 @@ func newPartition(partition int32) *partitionState {
 	cfg.device = C.int32_t(int(partition) % *GpuDevices)
 	cfg.window_secs = C.uint32_t(*WindowSecs)
 	cfg.key_sets = C.uint32_t(*KeySets)
+	cfg.table_capacity_log2 = C.uint32_t(*TableLog2)
+	cfg.topk_capacity_log2 = C.uint32_t(*KeysetLog2)
+	cfg.wide_capacity_log2 = C.uint32_t(*WideLog2)
 	if *ProtoFixed {
 		cfg.framed = 1
 	}
@@ -175,9 +181,9 @@ func (p *partitionState) flush(s *state, session sarama.ConsumerGroupSession) {
 		}
 		p.unmarked = append(p.unmarked, batchMark{last: p.pending[len(p.pending)-1], slots: set})
 	} else {
-		for _, m := range p.pending {
-			session.MarkMessage(m, "") // after fa_ingest accepted the batch (the reference's timing)
-		}
+		// after fa_ingest accepted the batch; one mark per batch - offsets of a partition are monotone, so the last message
+		// commits what the reference's per-message marks (inserter.go:188) commit
+		session.MarkMessage(p.pending[len(p.pending)-1], "")
 	}
 	p.buf, p.offsets, p.pending = p.buf[:0], p.offsets[:1], p.pending[:0]
 }
