@@ -528,14 +528,21 @@ int main(int argc, char** argv) {
         i = j + 1;
     }
     for (auto& c : claims) session.claims.push_back(c->Partition());
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     if (s.Setup(session) != 0) fatal("Setup failed");
+    const double setup_s = since(t_start);
     logf(2, "inserter-gpu up and running: %zu partition(s), flush.count=%ld flush.dur=%gs", claims.size(), f.FlushCount, f.FlushTime);
     std::vector<std::thread> workers;
     for (auto& c : claims) workers.emplace_back([&s, &session, &c] { s.ConsumeClaim(session, *c); });
+    const auto t_consume = std::chrono::steady_clock::now();
     for (auto& t : workers) t.join();
+    const double consume_s = since(t_consume);
+    const auto t_finish = std::chrono::steady_clock::now();
     s.finish(session);
     if (s.Cleanup(session) != 0) fatal("Cleanup failed");
     out.close();
+    logf(2, "phases: setup %.3f s, consume %.3f s, last close + top-k + teardown %.3f s", setup_s, consume_s, since(t_finish));
 
     if (!f.OffsetsOut.empty()) {
         FILE* fp = fopen(f.OffsetsOut.c_str(), "w");

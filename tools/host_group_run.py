@@ -51,12 +51,13 @@ def main():
         rb, app, topk, met = (os.path.join(tmp, x) for x in ("flows_5m.rowbinary", "app.rows", "topk.tsv", "metrics.txt"))
         t = time.perf_counter()
         r = subprocess.run([os.path.join(host, "inserter_gpu"), "-input.files=" + ",".join(paths), "-flush.count=%d" % args.flush, "-flush.dur=1h", "-key.sets=15",
-                            "-out.rowbinary=" + rb, "-out.app=" + app, "-out.topk=" + topk, "-topk.k=100", "-metrics.dump=" + met, "-gpu.devices=1", "-gpu.keyset.log2=22", "-gpu.wide.log2=25", "-loglevel=warning"],
+                            "-out.rowbinary=" + rb, "-out.app=" + app, "-out.topk=" + topk, "-topk.k=100", "-metrics.dump=" + met, "-gpu.devices=1", "-gpu.keyset.log2=22", "-gpu.wide.log2=25", "-loglevel=info"],
                            capture_output=True, text=True)
         out["host_wall_s"] = time.perf_counter() - t
         if r.returncode != 0:
             print(json.dumps(dict(out, error=r.stderr[-2000:])))
             sys.exit(1)
+        out["host_phases"] = [l.split('msg="')[1].rstrip('"') for l in r.stderr.splitlines() if "phases:" in l]
         metrics = {l.split()[0]: int(l.split()[1]) for l in open(met) if not l.startswith("#")}
         rows = fa.rowbinary_to_rows(open(rb, "rb").read()) if os.path.getsize(rb) < (1 << 28) else None
         app_rows = np.fromfile(app, dtype=fa.ROW_APP_DTYPE)
