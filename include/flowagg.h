@@ -94,7 +94,11 @@ typedef struct {
                                      estimate at a batch boundary and that occurred again afterwards: on a stream whose heavy
                                      hitters recur in every batch the same rows as the exact mode (BASELINE config 3: checked),
                                      without the 2 x 2 GiB of sets in the ingest path.  Nothing is admitted during the first
-                                     batch of a ctx.  Restated in oracle/pyoracle.py (topk_candidates). */
+                                     batch of a ctx.  Restated in oracle/pyoracle.py (topk_candidates).  Sizing: the weight term
+                                     of theta bounds R by the keys whose ESTIMATE reaches total >> (topk_capacity_log2 - 2) - at
+                                     most 2^(topk_capacity_log2 - 2) true ones plus what the sketch's noise (about
+                                     total >> cms_width_log2 per counter) lifts over it: keep cms_width_log2 >= topk_capacity_log2
+                                     - 1, or a stream of many light keys fills R and fa_topk reports FA_ERR_TABLE_FULL. */
     uint32_t topk_track;          /* candidates mode: the rank the threshold follows (fa_topk serves k <= topk_track); 0 -> 256.
                                      Addresses above the threshold take the slower path through the set: the cost grows with it
                                      (BASELINE config 3: 1.02 / 1.16 / 1.20 ms per launch at 16 / 128 / 1024) */

@@ -4,6 +4,8 @@ The reference's consumer is one process with a goroutine per claimed partition (
 partition has its own ctx - all of them on the one GPU of the test box, which exercises everything but the xGMI hop: the
 peer-copy transport degrades to device copies - and the group's results are compared, byte for byte, with ONE ctx that
 ingested every partition, with the oracle's rollup of the whole stream, and with the host-side merges dist.py's tests use."""
+import os
+
 import numpy as np
 import pytest
 
@@ -209,3 +211,94 @@ def test_group_topk_in_candidates_mode(gpu_lib, fa, po):
     finally:
         for m in members + [whole]:
             m.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FA_FUZZ_SEEDS", "10"))))  # (soak runs: FA_FUZZ_SEEDS=100)
+def test_random_sessions_of_a_group_against_a_model(gpu_lib, fa, po, seed):
+    """What a consumer does to a group over a day, drawn at random: batches into the members (with offsets, or as a bare framed
+    chain the library cuts itself), closes of the oldest window of the whole topic in both forms, reads, top-k of either contract
+    in between, a sketch reset - against a model kept in numpy (rows of the batches merged the way SummingMergeTree would, rows
+    of a closed window taken out; late records open their window again)."""
+    rng = np.random.default_rng(7000 + seed)
+    nm = int(rng.integers(1, 5))
+    nb = int(rng.integers(3, 9))
+    n = int(rng.integers(60_000, 400_000))
+    depth, wl2, cseed = int(rng.integers(2, 5)), int(rng.integers(15, 18)), int(rng.integers(1, 1 << 30))
+    candidates = bool(rng.integers(0, 2))
+    gp = po.gen_params(mode=int(rng.choice([po.GEN_ZIPF, po.GEN_ASPAIRS, po.GEN_GOFLOW])), framed=1, seed=7100 + seed, n_total=n,
+                       span_secs=int(rng.choice([600, 1500])), zipf_log2_universe=int(rng.integers(8, 15)), zipf_s_x100=110)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, status = po.decode_batch(buf, off, 1)
+    assert status.sum() == 0
+    with np.errstate(over="ignore"):
+        wgt = rows["bytes"] * rows["sampling_rate"]
+    bounds = [0] + sorted(int(c) for c in rng.choice(np.arange(1, n), size=nb - 1, replace=False)) + [n]
+    kw = dict(framed=True, key_sets=15, cms_depth=depth, cms_width_log2=wl2, cms_seed=cseed, topk_capacity_log2=16 if candidates else 20,
+              topk_mode=fa.TOPK_CANDIDATES if candidates else fa.TOPK_EXACT, topk_track=64, wide_capacity_log2=int(rng.integers(10, 20)),
+              table_capacity_log2=int(rng.integers(10, 18)), max_batch_records=max(b - a for a, b in zip(bounds, bounds[1:])))
+    members = [fa.FlowAgg(**kw) for _ in range(nm)]
+    live5 = np.zeros(0, dtype=fa.ROW5M_DTYPE)
+    live_app = np.zeros(0, dtype=fa.ROW_APP_DTYPE)
+    seen = np.zeros(n, dtype=bool)  # records the sketches hold
+    per_member = [[] for _ in range(nm)]  # candidates mode: every member follows the contract over ITS launches
+    try:
+        with fa.FlowGroup(members) as g:
+            for i, (a, b) in enumerate(zip(bounds, bounds[1:])):
+                m = int(rng.integers(0, nm))
+                piece, o = buf[int(off[a]):int(off[b])], off[a:b + 1] - off[a]
+                if rng.integers(0, 3) == 0:
+                    members[m].ingest(piece, None)  # a framed chain: cut by the library (on the device from 1 MiB)
+                else:
+                    members[m].ingest(piece, o)
+                ref = po.Rollup(300)
+                ref.ingest(piece, o, 1)
+                live5 = fa.dist.merge_rows_host([live5, ref.rows()])
+                live_app = fa.dist.merge_rows_app_host([live_app, po.rollup_app(rows[a:b], status[a:b], 300).astype(fa.ROW_APP_DTYPE)])
+                seen[a:b] = True
+                per_member[m].append((a, b))
+                op = int(rng.integers(0, 5))
+                if op == 0 and len(live5):  # the oldest window of the topic leaves, flows_5m merged, (SrcAddr,DstPort,Proto) by owner
+                    ts = int(g.open_timeslots()[0])
+                    assert ts == int(live5["timeslot"].min())
+                    got5 = g.close_window(fa.ROWS_5M, ts)
+                    assert got5.tobytes() == live5[live5["timeslot"] == ts].tobytes(), (seed, i)
+                    live5 = live5[live5["timeslot"] != ts]
+                    gota, shares = g.close_window_partitioned(fa.ROWS_APP, ts)
+                    assert sum(shares) == len(gota)
+                    assert fa.dist.merge_rows_app_host([gota]).tobytes() == live_app[live_app["timeslot"] == ts].tobytes(), (seed, i)
+                    assert len(fa.dist.merge_rows_app_host([gota])) == len(gota)  # a key in exactly one share
+                    live_app = live_app[live_app["timeslot"] != ts]
+                elif op == 1:
+                    assert g.read_window(fa.ROWS_5M).tobytes() == live5.tobytes(), (seed, i)
+                elif op == 2 and not candidates:  # the whole topic's heavy hitters: exact with respect to the merged sketch
+                    for col, ks in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+                        sk = po.cms_sketch_numpy(rows[col][seen], wgt[seen], depth, wl2, cseed)
+                        keys = np.unique(np.ascontiguousarray(rows[col][seen]), axis=0)
+                        est = po.cms_estimates_numpy(sk, keys, depth, wl2, cseed)
+                        want = sorted(zip((-est.astype(object)).tolist(), [bytes(k) for k in keys]))[:50]
+                        assert [(bytes(r["key"]), int(r["weight"])) for r in g.topk(ks, 50)] == [(k, -e) for e, k in want], (seed, i, col)
+                elif op == 3 and not candidates and i + 1 < nb:  # every member's sketches and distinct-address sets start over
+                    for mem in members:
+                        mem.cms_reset(fa.FA_KEYS_SRCADDR_CMS)
+                        mem.cms_reset(fa.FA_KEYS_DSTADDR_CMS)
+                    seen[:] = False
+            st = g.stats()
+            assert st["records_ok"] == n and st["records_bad"] == 0
+            assert g.read_window(fa.ROWS_5M).tobytes() == live5.tobytes()
+            gota, _ = g.read_window_partitioned(fa.ROWS_APP)
+            assert fa.dist.merge_rows_app_host([gota]).tobytes() == live_app.tobytes()
+            g.allreduce_sketches()
+            for col, ks in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+                sk = po.cms_sketch_numpy(rows[col][seen], wgt[seen], depth, wl2, cseed)
+                assert np.array_equal(members[int(rng.integers(0, nm))].cms_read(ks).reshape(-1), sk), (seed, col)
+                if candidates:  # the union of the members' candidate sets, ranked by the merged estimate
+                    cand = [po.topk_candidates([(rows[col][a:b], wgt[a:b]) for a, b in per_member[m]], depth, wl2, cseed, track=64, capacity_log2=16)[1]
+                            for m in range(nm) if per_member[m]]
+                    keys = np.unique(np.concatenate(cand), axis=0) if cand else np.zeros((0, 16), dtype=np.uint8)
+                    est = po.cms_estimates_numpy(sk, keys, depth, wl2, cseed) if len(keys) else np.zeros(0, dtype=np.uint64)
+                    want = sorted(zip((-est.astype(object)).tolist(), [bytes(k) for k in keys]))
+                    got = g.topk(ks, 1 << 16)
+                    assert [(bytes(r["key"]), int(r["weight"])) for r in got] == [(k, -e) for e, k in want], (seed, col, len(got), len(want))
+    finally:
+        for mem in members:
+            mem.close()
