@@ -175,6 +175,7 @@ struct fa_ctx {
     size_t fs_off_cap = 0;
     void* wl_scratch = nullptr;      // window reads of log chunks: per-segment counts, their scan, hipcub storage
     size_t wl_scratch_cap = 0;
+    void* read_clk = nullptr;        // FA_VERBOSE: the ReadClock of the read in progress (collect's own phases report into it)
     void* part_buf = nullptr;        // fa_rows_partition_device: the rows grouped by destination rank
     size_t part_cap = 0;
     unsigned int* part_cnt = nullptr;  // [3][RPART_MAX_WORLD]: counts, starts, cursors

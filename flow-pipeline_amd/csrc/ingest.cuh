@@ -633,7 +633,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
     __shared__ uint32_t part_cnt[NPART_MAX];
     __shared__ uint32_t flush_scratch[WAVES * 16];
     constexpr bool HAS_APP = (KEYSETS & FA_KEYS_ADDR_PORT_PROTO) != 0;
-    __shared__ uint32_t wpart_cnt[HAS_APP ? (1u << WIDE_PLOG2_MAX) : 1u];  // tuples per region of the wide table (scatter sink, wagg.cuh)
+    __shared__ uint32_t wpart_cnt[HAS_APP ? (1u << WIDE_PLOG2_MAX) + 2u : 1u];  // tuples per region of the wide table (scatter sink, wagg.cuh) + their bucket range (min, ~max)
     __shared__ LdsTable<LDS_SLOTS> lt;
     __shared__ LdsMinutes lm;
 
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
     }
     if (KEYSETS & FA_KEYS_MINUTE_SERIES) lds_minutes_clear(lm);
     if (HAS_APP)
-        for (int i = tid; i < (1 << WIDE_PLOG2_MAX); i += WBLOCK) wpart_cnt[i] = 0;
+        for (int i = tid; i < (1 << WIDE_PLOG2_MAX) + 2; i += WBLOCK) wpart_cnt[i] = i < (1 << WIDE_PLOG2_MAX) ? 0u : 0xffffffffu;
     CmsLds* const cl = (HAS_CMS && a.cseg) ? cms_lds.get() : nullptr;
     HotAddrs* const hot = (HAS_CMS && (a.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) ? hot_lds.get() : nullptr;
     if (HAS_CMS && cl)
@@ -889,6 +889,10 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
     if (HAS_APP && a.wseg) {  // how many wide tuples this workgroup left in each region's segment
         __syncthreads();
         for (int i = tid; i < (1 << a.wplog2); i += WBLOCK) a.wseg_counts[(size_t)i * a.nwg + blockIdx.x] = min(wpart_cnt[i], a.wcapq);
+        if (tid == 0 && wpart_cnt[1u << WIDE_PLOG2_MAX] != 0xffffffffu) {  // (sinks.cuh, wide_sink_wave)
+            atomicMin(&a.ctr->wtb_min, wpart_cnt[1u << WIDE_PLOG2_MAX]);
+            atomicMin(&a.ctr->wtb_nmax, wpart_cnt[(1u << WIDE_PLOG2_MAX) + 1u]);
+        }
     }
     if (KEYSETS & FA_KEYS_AS_PAIR) {
         __syncthreads();

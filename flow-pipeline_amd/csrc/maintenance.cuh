@@ -153,14 +153,20 @@ __device__ __forceinline__ bool wrow_selected(const unsigned long long w[4], uin
     if (!((kind_mask >> kind) & 1u)) return false;
     return kind != WK_APP || (tb >= tb_lo && tb < tb_hi);
 }
-// A wave looks at WX_U x 64 slots per round (each slot with four independent 16-byte loads) and takes the positions of
-// the round's rows with ONE returning atomic: the scan itself runs at 6 TB/s (tools/micro/scan64.hip), what it waits
-// for is that round trip (41 ms for a 16 GiB table with one atomic per selected row).
+// A workgroup of 16 waves looks at WX_U x 1024 slots per round (each slot with four independent 16-byte loads) and takes the
+// positions of the round's rows with ONE returning atomic: the scan itself runs at 6 TB/s (tools/micro/scan64.hip), what it
+// waits for is that round trip - 41 ms for a 16 GiB table with one atomic per selected row; with one per wave and round (rounds
+// 2-4) a table that holds a row in most rounds still paid 262 k same-address round trips, 2.3 ms for BASELINE config 5's first
+// window (1.2 M rows in 2^26 slots) beside a 0.7 ms scan.
 constexpr int WX_U = 4;
-__global__ __launch_bounds__(256) void wextract_kernel(const WSlot* tab, uint32_t nslots, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, WRow* rows,
-                                                       uint32_t rows_cap, Counters* ctr) {
-    const uint32_t nthr = gridDim.x * blockDim.x, lane = __lane_id();
-    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nslots; i0 += WX_U * nthr) {
+constexpr int WX_BLOCK = 1024;
+__global__ __launch_bounds__(WX_BLOCK) void wextract_kernel(const WSlot* tab, uint32_t nslots, uint32_t kind_mask, uint32_t tb_lo, uint32_t tb_hi, WRow* rows,
+                                                            uint32_t rows_cap, Counters* ctr) {
+    __shared__ uint32_t wave_total[WX_BLOCK / 64];
+    __shared__ uint32_t wg_base;
+    const uint32_t nthr = gridDim.x * blockDim.x, lane = __lane_id(), wave = threadIdx.x >> 6;
+    for (uint32_t b0 = blockIdx.x * blockDim.x; b0 < nslots; b0 += WX_U * nthr) {  // (the trip count is the workgroup's: barriers inside)
+        const uint32_t i0 = b0 + threadIdx.x;
         uint4 q[WX_U][4];
         bool sel[WX_U];
         unsigned long long m[WX_U];
@@ -177,17 +183,32 @@ __global__ __launch_bounds__(256) void wextract_kernel(const WSlot* tab, uint32_
             const unsigned long long w[4] = {(unsigned long long)q[u][0].y << 32 | q[u][0].x, (unsigned long long)q[u][0].w << 32 | q[u][0].z,
                                              (unsigned long long)q[u][1].y << 32 | q[u][1].x, (unsigned long long)q[u][1].w << 32 | q[u][1].z};
             const unsigned long long v2 = (unsigned long long)q[u][3].y << 32 | q[u][3].x;
+            // (i0 + u * nthr < 2^32: nslots <= 2^30 and the last round overshoots by less than WX_U * nthr)
             sel[u] = i0 + (uint32_t)u * nthr < nslots && w[0] != 0 && w[1] != 0 && w[2] != 0 && w[3] != 0 && v2 != 0 &&
                      wrow_selected(w, kind_mask, tb_lo, tb_hi);
             m[u] = __builtin_amdgcn_ballot_w64(sel[u]);
             total += (uint32_t)__builtin_popcountll(m[u]);
         }
-        if (total != 0u) {  // (wave-uniform)
-            const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-            const uint32_t leader = (uint32_t)__builtin_ctzll(act);
-            unsigned int base = 0;
-            if (lane == leader) base = atomicAdd(&ctr->wrows_count, total);
-            base = (unsigned int)__builtin_amdgcn_readlane((int)base, (int)leader);
+        if (lane == 0) wave_total[wave] = total;
+        __syncthreads();
+        if (threadIdx.x < 64) {  // wave 0: the workgroup's rows of this round, one atomic
+            const uint32_t t = lane < WX_BLOCK / 64 ? wave_total[lane] : 0u;
+            uint32_t incl = t;
+#pragma unroll
+            for (int o = 1; o < WX_BLOCK / 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                if (lane >= (uint32_t)o) incl += up;
+            }
+            const uint32_t wg_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, WX_BLOCK / 64 - 1);
+            uint32_t base = 0;
+            if (lane == 0 && wg_total != 0u) base = atomicAdd(&ctr->wrows_count, wg_total);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+            if (lane < WX_BLOCK / 64) wave_total[lane] = base + incl - t;  // (exclusive: where this wave's rows start)
+            if (lane == 0) wg_base = wg_total;
+        }
+        __syncthreads();
+        if (wg_base != 0u && total != 0u) {  // (wave-uniform)
+            unsigned int base = wave_total[wave];
 #pragma unroll
             for (int u = 0; u < WX_U; u++) {
                 const unsigned int j = base + (unsigned int)__builtin_popcountll(m[u] & ((1ull << lane) - 1ull));
@@ -205,6 +226,7 @@ __global__ __launch_bounds__(256) void wextract_kernel(const WSlot* tab, uint32_
                 }
             }
         }
+        __syncthreads();  // (wave_total / wg_base are the next round's again)
     }
 }
 // ---- wide log (FA_WIDE=log): launches whose (SrcAddr,DstPort,Proto) tuples still sit in their scatter segments ----------

@@ -107,7 +107,10 @@ struct Counters {
     // the deferral lists' fill levels come in two copies: batch B appends under copy B & 1 and its deferred kernel
     // clears the OTHER copy for batch B + 1 (no memset dispatches, no reset race inside one kernel)
     unsigned int exotic_count[2], retry_count[2];
-    unsigned int spill_count, rows_count, tb_base, ks_overflow, ks_rows, pad;
+    unsigned int spill_count, rows_count, ks_overflow, ks_rows;
+    // the launch's time base and, behind it, the bucket range of the (SrcAddr,DstPort,Proto) tuples the launch left in its segments
+    // (smallest bucket, ~largest bucket; both start at ~0 before every launch): copied into a wide-log chunk as one piece
+    unsigned int tb_base, wtb_min, wtb_nmax, pad;
     unsigned long long t_wait, t_work, t_tiles, t_total;  // DBG_TIMING: core-clock cycles of wave 0 of every workgroup
     unsigned long long wfold_n;  // tuples of wide-log chunks folded into the table so far (beside wused: do folds still open rows?)
     unsigned long long wused, wspill_lost;  // wide table (wide.cuh)
@@ -902,6 +905,7 @@ __device__ __forceinline__ void wide_sink_wave(const KArgs& a, LdsMinutes& lm, c
     const uint64_t wgt = r.bytes * r.sampling_rate;
     if (ks_on<KEYSETS>(a, FA_KEYS_ADDR_PORT_PROTO)) {
         WSlot* sp = nullptr;
+        bool logged = false;  // this lane's update left as a tuple in a segment
         if (sure) {
             WKey k;
             app_key(a, r, tb, k);
@@ -921,11 +925,39 @@ __device__ __forceinline__ void wide_sink_wave(const KArgs& a, LdsMinutes& lm, c
                     done = true;
                 }
             }
+            logged = done;
             if (!done) {
                 sp = wtable_find_or_claim(t, k, h);
                 if (!sp) wspill_park(t, k, r.bytes, r.packets, 1);
             }
         }
+#ifndef FA_NO_WRANGE  // (A/B of the bookkeeping's cost only: reads of log chunks need it)
+        if (wpart_cnt) {
+            // the bucket range of the tuples this workgroup leaves in the segments (two LDS words behind the region counts): a close
+            // compares its range with the chunk's and knows when nothing of a chunk is left - without a scan of the chunk.  A tile's
+            // records almost always share one bucket: one lane's LDS atomics then.
+            const unsigned long long dm = __builtin_amdgcn_ballot_w64(logged);
+            if (dm != 0ull) {
+                const uint32_t first = (uint32_t)__builtin_ctzll(dm);
+                const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tb, (int)first);
+                uint32_t lo = t0, hi = t0;
+                if (__builtin_amdgcn_ballot_w64(logged && tb != t0) != 0ull) {
+                    lo = logged ? tb : 0xffffffffu;
+                    hi = logged ? tb : 0u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+                        hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+                    }
+                }
+                if (__lane_id() == first) {
+                    uint32_t* wrange = wpart_cnt + (1u << WIDE_PLOG2_MAX);
+                    atomicMin(&wrange[0], lo);
+                    atomicMin(&wrange[1], ~hi);
+                }
+            }
+        }
+#endif
         if (__builtin_amdgcn_ballot_w64(sp != nullptr) != 0ull) quad_atomic_update_at<4>((uint64_t)sp, r.bytes, r.packets, 1);
     }
     if (ks_on<KEYSETS>(a, FA_KEYS_PORT_HIST)) {

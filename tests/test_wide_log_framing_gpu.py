@@ -46,6 +46,7 @@ def test_adaptive_wide_log_enters_leaves_and_drains_both_ways(gpu_lib, fa, po, m
     D  NEW keys: log mode again, and now the folds make the table grow - chunks scattered for the old geometry go through the
        atomic replay.
     After every phase the rows are the oracle's."""
+    monkeypatch.setenv("FA_WLOG_RANGE_CHECK", "1")
     monkeypatch.delenv("FA_WIDE", raising=False)
     monkeypatch.setenv("FA_WIDE_LOG_CHUNKS", "2")
     step = 400_000

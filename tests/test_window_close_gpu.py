@@ -432,6 +432,7 @@ def test_wide_log_mode_equals_the_oracle(gpu_lib, fa, po, monkeypatch, chunks, c
     (wagg_kernel, or the atomic replay once the table has grown - cap_log2 10).  Whatever the mix: rows == the oracle's."""
     monkeypatch.setenv("FA_WIDE", "log")
     monkeypatch.setenv("FA_WIDE_LOG_CHUNKS", str(chunks))
+    monkeypatch.setenv("FA_WLOG_RANGE_CHECK", "1")  # the chunks' bucket ranges as the ingest kernel kept them == a scan of the chunks
     n, parts = 240_000, 4
     gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=77, n_total=n, zipf_log2_universe=12, span_secs=900)
     buf, off = po.gen_records(gp, 0, n)
@@ -478,3 +479,37 @@ def test_wide_log_mode_equals_the_oracle(gpu_lib, fa, po, monkeypatch, chunks, c
         st = agg.stats()
         assert st["records_bad"] == 0 and st["records_ok"] == n + step
         assert st["wave_tile_launches"] == parts + 1  # (every launch went through the scatter sink: its tuples were a chunk)
+
+
+@pytest.mark.parametrize("sub", [0, 60])
+def test_wide_log_bucket_ranges_of_a_stream_out_of_time_order(gpu_lib, fa, po, monkeypatch, sub):
+    """Kafka partitions are close to time-ordered, the ingest kernel's bookkeeping of a chunk's bucket range has a short way for a
+    tile whose records share a bucket - here the records arrive in random order (every tile spans all windows): the ranges still
+    equal a scan of the chunks (FA_WLOG_RANGE_CHECK), the closes in window order still return the oracle's rows and leave nothing."""
+    monkeypatch.setenv("FA_WIDE", "log")
+    monkeypatch.setenv("FA_WLOG_RANGE_CHECK", "1")
+    n, parts = 200_000, 4
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=177, n_total=n, zipf_log2_universe=12, span_secs=1200)
+    buf0, off0 = po.gen_records(gp, 0, n)
+    raw = bytes(buf0)
+    order = np.random.default_rng(5).permutation(n)
+    recs = [raw[int(off0[k]):int(off0[k + 1])] for k in order]
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in recs])
+    buf = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    rows, status = po.decode_batch(buf, off, 1)
+    assert status.sum() == 0
+    gran = sub or 300
+    with fa.FlowAgg(framed=True, key_sets=9, subwindow_secs=sub, wide_capacity_log2=18, max_batch_records=n // parts) as agg:
+        step = n // parts
+        for i in range(parts):
+            a, b = i * step, (i + 1) * step
+            agg.ingest(buf[int(off[a]):int(off[b])], off[a:b + 1] - off[a])
+        assert agg.stats()["wide_log_chunks"] >= 1
+        if sub:  # sliding form: one read of everything (the ranges are fetched - and checked - by the first read)
+            assert agg.read_window_app(fa.ALL_TIMESLOTS).tobytes() == po.rollup_app(rows, status, gran).astype(fa.ROW_APP_DTYPE).tobytes()
+        else:
+            for ts in [int(t) for t in agg.open_timeslots()]:
+                want = po.rollup_app(rows, status, 300, window=300, timeslot=ts).astype(fa.ROW_APP_DTYPE)
+                assert agg.close_window_app(ts).tobytes() == want.tobytes(), ts
+            assert len(agg.read_window_app(fa.ALL_TIMESLOTS)) == 0
