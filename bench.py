@@ -396,6 +396,8 @@ def main():
     wire_bytes = 0
     i0 = 0
     rec_cap = fa.mock_record_cap(mode)
+    # (device offsets are 32-bit: a chunk stays below 4 GiB of wire bytes - GoFlow-shaped records are twice mocker's)
+    args.chunk = min(args.chunk, ((1 << 32) - (1 << 24)) // rec_cap)
     while i0 < n_rec:
         m = min(args.chunk, n_rec - i0)
         cap = m * rec_cap + 4096

@@ -66,7 +66,7 @@ class Stats(C.Structure):
         "compact_tuple_launches", "records_misfit_compact", "decode_ns_total", "decode_launches",
         "records_late", "wide_log_chunks", "wide_log_bytes", "wide_log_records", "wide_log_recorded", "wide_log_folded",
         "wide_log_replayed", "wide_log_dropped", "wide_log_watermark_moves", "wide_log_nomem_folds", "wide_log_mode",
-        "topk_theta_src", "topk_theta_dst", "topk_candidates_src", "topk_candidates_dst")]
+        "topk_theta_src", "topk_theta_dst", "topk_candidates_src", "topk_candidates_dst", "learnt_order_launches")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

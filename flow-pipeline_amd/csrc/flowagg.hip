@@ -132,6 +132,8 @@ struct fa_ctx {
     int t8_mode = 0;              // env FA_TUPLE: 0 adaptive, 1 always compact ("8"), 2 always wide ("16")
     uint64_t t8_wide_until = 0;   // batches counter value up to which wide tuples are used
     uint64_t seen_misfit8 = 0, seen_ok = 0;  // counter values at the last look
+    uint64_t seen_retried = 0, seq_until = 0;  // launches before batch seq_until run the learnt-field-order variant (format_feedback)
+    int seq_mode = 0;                          // FA_SEQ: 1 always, 2 never
     uint64_t seen_agg_groups = 0, seen_agg_launches = 0;
     uint32_t agg_passes_forced = 0;  // env FA_AGG_PASSES (tests, A/B)
     uint32_t agg_passes = 1;      // agg8_kernel passes for the next launch (1, 2, 4, 8): groups per launch / (partitions x passes) <= half the LDS table
@@ -371,6 +373,7 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
     if (const char* d = getenv("FA_STAGE_THREADS")) c->stage_threads = (unsigned)std::min(64, std::max(1, atoi(d)));
     c->stage_threads = std::min(c->stage_threads, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* d = getenv("FA_TUPLE")) c->t8_mode = !strcmp(d, "8") ? 1 : !strcmp(d, "16") ? 2 : 0;
+    if (const char* d = getenv("FA_SEQ")) c->seq_mode = !strcmp(d, "1") ? 1 : !strcmp(d, "0") ? 2 : 0;  // learnt-field-order kernel: always / never (default: by the counters)
     auto bail = [&](const char* what, hipError_t e) {
         g_create_error = std::string("fa_create: ") + what + ": " + hipGetErrorString(e);
         fa_destroy(c);
@@ -648,6 +651,14 @@ extern "C" int fa_stats(fa_ctx* c, fa_stats_t* out) {
 }
 
 // ---- synthetic producer ------------------------------------------------------------------------
+// (the offsets are 32-bit: the lengths are summed in 64 bits first, a call that would write 4 GiB or more is refused)
+__global__ __launch_bounds__(256) void mock_len_sum_kernel(const uint32_t* len, uint32_t n, unsigned long long* out) {
+    unsigned long long s = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += len[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += (unsigned long long)__shfl_xor((long long)s, o);
+    if (__lane_id() == 0 && s) atomicAdd(out, s);
+}
 extern "C" int fa_mock_generate_device(fa_ctx* c, const fa_mock_params* g, uint64_t i0, uint64_t n, void* d_buf,
                                        size_t cap, void* d_off, uint64_t* bytes_out) {
     FA_ON_DEVICE(c);
@@ -657,11 +668,19 @@ extern "C" int fa_mock_generate_device(fa_ctx* c, const fa_mock_params* g, uint6
     uint32_t* len = nullptr;
     void* tmp = nullptr;
     size_t tmp_bytes = 0;
-    HIPCHK(c, hipMalloc(&len, (n + 1) * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc(&len, (n + 1) * sizeof(uint32_t) + 16));
     int rc = FA_OK;
+    bool too_big = false;
     do {
         hipLaunchKernelGGL(gen_len_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, *g, i0, (uint32_t)n, len);
         if (hipMemsetAsync(len + n, 0, 4, c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
+        unsigned long long* sum64 = reinterpret_cast<unsigned long long*>(len + ((n + 1 + 1) & ~(uint64_t)1));  // (8-byte aligned, behind the lengths)
+        unsigned long long h_sum = 0;
+        if (hipMemsetAsync(sum64, 0, 8, c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
+        hipLaunchKernelGGL(mock_len_sum_kernel, dim3(1024), dim3(256), 0, c->stream, (const uint32_t*)len, (uint32_t)n, sum64);
+        if (hipMemcpyAsync(&h_sum, sum64, 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
+        if (h_sum >= (1ull << 32) - 64) { rc = FA_ERR_ARG; too_big = true; if (bytes_out) *bytes_out = h_sum; break; }
         (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, len, off, (int)(n + 1), c->stream);
         if (hipMalloc(&tmp, tmp_bytes) != hipSuccess) { rc = FA_ERR_NOMEM; break; }
         if (hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, len, off, (int)(n + 1), c->stream) != hipSuccess) { rc = FA_ERR_HIP; break; }
@@ -678,6 +697,7 @@ extern "C" int fa_mock_generate_device(fa_ctx* c, const fa_mock_params* g, uint6
     (void)hipFree(tmp);
     if (rc == FA_ERR_HIP) c->err = std::string("fa_mock_generate_device: ") + hipGetErrorString(hipGetLastError());
     if (rc == FA_ERR_CAPACITY) c->err = "fa_mock_generate_device: buffer too small (needs bytes + 32 slack)";
+    if (too_big) c->err = "fa_mock_generate_device: 4 GiB or more of records in one call (device offsets are 32-bit): generate fewer records per call";
     return rc;
 }
 

@@ -32,7 +32,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                                           LaneTally& tally, uint32_t& pmode, uint32_t& lt_seen, uint32_t& lt_hits,
                                           uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook(),
                                           CmsLds* cl = nullptr, uint32_t* cms_scratch = nullptr, HotAddrs* hot = nullptr,
-                                          uint32_t* wpart_cnt = nullptr) {
+                                          uint32_t* wpart_cnt = nullptr, uint32_t* seq = nullptr) {
     constexpr uint32_t TB = bin_cap<T8, bin_line(KEYSETS)>();
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false, framed_ok = false;
@@ -58,6 +58,10 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     //  3 parse_fast: any field order, duplicates, unknown fields - IN PLACE, while the bytes still sit in the wave's
     //    LDS tile.  Only what that one cannot decide either (varints above 2^42 in projected fields, groups, 3-byte
     //    tags; broken frames) is deferred to deferred_kernel, which reads it back from HBM one record per lane.
+    //  4 parse_seq in front of parse_fast (lean variants: `seq`, 26 words of LDS per wave): a producer that does not marshal
+    //    in field order still marshals every record the same way - once most of a tile needed parse_fast the wave takes the
+    //    field list of that tile's longest record (seq_learn) and walks the following tiles with it, parse_fast only for what
+    //    that refuses; a tile it mostly refuses makes the wave learn again (four times per launch at most).
     // A tier runs only for the lanes the tier before left unsure (wave-uniform branches: a stream of one kind pays one
     // ballot per tile for the tiers it never needs); a wave moves its starting tier up when more than half of a tile
     // needed the next one.
@@ -88,6 +92,12 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
             }
             if (pmode < 2u && most(need && sure)) pmode = 2u;
         }
+        if (pmode == 4u && seq != nullptr && !FA_DBG(a, DBG_NO_SECOND)) {
+            if (framed_ok) {
+                sure = parse_seq<COLS>(src, pos, end, r, seq + 2, fa_uniform(seq[0]));
+                if (!FA_DBG(a, DBG_LOOP_PARSER)) tally.second += sure ? 1u : 0u;
+            }
+        }
         const bool need_fast = framed_ok && !sure;
         if (FA_ANY(need_fast) && !FA_DBG(a, DBG_NO_SECOND)) {
             if (need_fast) {
@@ -97,7 +107,23 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 if (!sure) rec_clear(r);
             }
             // most of a tile needed the order-free parser and it worked: start with it from now on
-            if (pmode != 3u && most(need_fast && sure)) pmode = 3u;
+            if (pmode < 3u && most(need_fast && sure)) pmode = 3u;
+            if (seq != nullptr && pmode >= 3u && most(need_fast && sure)) {
+                // ... behind the field order of the tile's longest record (proto3 omits zero values: the longest has them all)
+                pmode = 3u;
+                if (fa_uniform(seq[1]) < 4u) {
+                    const uint32_t len = (need_fast && sure) ? end - pos : 0u;
+                    uint32_t mx = len;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+                    const uint32_t who = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(len == mx));
+                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)who), e0 = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)who);
+                    const uint32_t k = seq_learn(src, p0, e0, seq + 2);  // (every lane, the same record, the same words)
+                    seq[0] = k;
+                    seq[1] = fa_uniform(seq[1]) + 1u;
+                    if (k) pmode = 4u;
+                }
+            }
         }
     }
     if (mine && !sure) {  // (one counter atomic per wave: the compiler folds the lanes' adds - s_bcnt1 + mbcnt)
@@ -615,7 +641,10 @@ struct HotAddrsOpt<false> {
     __device__ __forceinline__ HotAddrs* get() { return nullptr; }
 };
 
-template <uint32_t KEYSETS, bool T8>
+// SEQ: the variant with the learnt-field-order tier (lane_work tier 4) - a kernel of its own, launched while the counters say that
+// most records need the order-free parser (maintain_host.inc, format_feedback): in the common kernel the tier's code cost the
+// streams that never use it (GoFlow shape: +1.3 % per launch, same box, through the register allocation alone).
+template <uint32_t KEYSETS, bool T8, bool SEQ = false>
 __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) void wtile_kernel(KArgs a) {
     constexpr uint32_t BL = bin_line(KEYSETS);
     constexpr uint32_t TB = bin_cap<T8, BL>();
@@ -636,9 +665,16 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
     __shared__ uint32_t wpart_cnt[HAS_APP ? (1u << WIDE_PLOG2_MAX) + 2u : 1u];  // tuples per region of the wide table (scatter sink, wagg.cuh) + their bucket range (min, ~max)
     __shared__ LdsTable<LDS_SLOTS> lt;
     __shared__ LdsMinutes lm;
+    // the field order a wave has learnt (lane_work tier 4): [0] steps, [1] times learnt, then the steps.  The flows_5m variant has the
+    // LDS (two workgroups per CU leave it 1.7 KiB) and the registers for it; config 5's pair has the LDS but pays for the tier with
+    // spills in its tile loop (scratch 28 -> 84 bytes per lane), the sketch variants have neither.
+    constexpr bool HAS_SEQ = SEQ && KEYSETS == FA_KEYS_AS_PAIR;
+    static_assert(!SEQ || KEYSETS == FA_KEYS_AS_PAIR, "the learnt-order variant exists for the flows_5m rollup alone");
+    __shared__ uint32_t seq_all[HAS_SEQ ? WAVES * (SEQ_MAX + 2) : 1];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (HAS_SEQ && lane < 2) seq_all[wave * (SEQ_MAX + 2) + lane] = 0;
     if (KEYSETS & FA_KEYS_AS_PAIR) {
         lds_table_clear(lt);
         for (int i = tid; i < NPART_MAX; i += WBLOCK) {
@@ -768,7 +804,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
         uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
         lane_work<MODE_INGEST, KEYSETS, COLS, T8>(a, lt, lm, part_cnt, tile, staged, cur.q0 - cbase, cur.q1 - cbase, cur.r0 + lane, tb_base, tally,
                                                   pmode, lt_seen, lt_hits, bins, bin_cnt, fill, NoHook(), cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0), hot,
-                                                  (HAS_APP && a.wseg) ? wpart_cnt : nullptr);
+                                                  (HAS_APP && a.wseg) ? wpart_cnt : nullptr, HAS_SEQ ? seq_all + wave * (SEQ_MAX + 2) : nullptr);
         // (sketch variants, round 3: starting the next tile's DMA right behind the parse - the sink is long there and does
         // not look at the tile's bytes - measured +1.8 %, like the following for the lean variants)
         // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt

@@ -626,6 +626,187 @@ FA_HD bool parse_tmpl(const Src& s, uint32_t pos, uint32_t end, Rec& r) {
     return c.pos == end;
 }
 
+// ---- learnt field order -----------------------------------------------------------------------------------
+// A producer that does not marshal in field-number order (proto3 allows any order) still marshals every record the same way.
+// seq_learn takes the field list of ONE record the order-free parser was sure about; parse_seq is the template walk over that
+// list, with the tags at run time instead of at compile time: per step one tag compare, the cheapest exact decode for the
+// field's shape (the canonical walk's steps: canon_short / canon_long / canon_addr / canon_skip), the cursor moves only over a
+// field validated completely - a record is "sure" iff it is exactly a sub-sequence of the learnt list (zero-valued fields are
+// omitted by proto3: their step simply does not move), every field at most once.  Anything else - another field, another
+// order, a duplicate, a value outside the step's range - is "not sure" and goes to parse_fast, like from every other tier.
+// A step word: tag (1 or 2 bytes, little endian) | kind << 16 | column << 20.
+constexpr uint32_t SEQ_MAX = 24;
+enum : uint32_t { SQ_SHORT = 0, SQ_LONG = 1, SQ_ADDR = 2, SQ_SKIP = 3 };
+enum : uint32_t {
+    SQC_NONE = 0, SQC_TIME_RECEIVED, SQC_SAMPLING_RATE, SQC_SEQUENCE_NUM, SQC_SRC_ADDR, SQC_DST_ADDR, SQC_BYTES, SQC_PACKETS,
+    SQC_SAMPLER, SQC_SRC_AS, SQC_DST_AS, SQC_PROTO, SQC_SRC_PORT, SQC_DST_PORT, SQC_ETYPE, SQC_TIME_FLOW_START
+};
+FA_HD uint32_t fa_uniform(uint32_t v) {  // a value every lane of the wave holds: into a scalar register
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return v;
+#endif
+}
+// the step of a tag: the shapes parse_canon uses for the schema's projected fields (pb-ext/flow.proto:16-64), a skip for any other
+FA_HD uint32_t seq_step_of(uint32_t tag) {
+    switch (tag) {
+    case 0x10u: return tag | SQ_LONG << 16 | SQC_TIME_RECEIVED << 20;
+    case 0x18u: return tag | SQ_SHORT << 16 | SQC_SAMPLING_RATE << 20;
+    case 0x20u: return tag | SQ_LONG << 16 | SQC_SEQUENCE_NUM << 20;
+    case 0x32u: return tag | SQ_ADDR << 16 | SQC_SRC_ADDR << 20;
+    case 0x3au: return tag | SQ_ADDR << 16 | SQC_DST_ADDR << 20;
+    case 0x48u: return tag | SQ_SHORT << 16 | SQC_BYTES << 20;
+    case 0x50u: return tag | SQ_SHORT << 16 | SQC_PACKETS << 20;
+    case 0x5au: return tag | SQ_ADDR << 16 | SQC_SAMPLER << 20;
+    case 0x70u: return tag | SQ_SHORT << 16 | SQC_SRC_AS << 20;
+    case 0x78u: return tag | SQ_SHORT << 16 | SQC_DST_AS << 20;
+    case 0x01a0u: return tag | SQ_SHORT << 16 | SQC_PROTO << 20;
+    case 0x01a8u: return tag | SQ_SHORT << 16 | SQC_SRC_PORT << 20;
+    case 0x01b0u: return tag | SQ_SHORT << 16 | SQC_DST_PORT << 20;
+    case 0x01f0u: return tag | SQ_SHORT << 16 | SQC_ETYPE << 20;
+    case 0x02b0u: return tag | SQ_LONG << 16 | SQC_TIME_FLOW_START << 20;
+    default: return tag | SQ_SKIP << 16 | SQC_NONE << 20;
+    }
+}
+// The field list of the record at [pos, end) -> steps[0 .. n); 0: nothing learnt (more than SEQ_MAX fields, a tag twice, a tag
+// of 3 bytes, a field that is not a plain varint / fixed / bytes field with a one-byte length, a record that does not end on a
+// field boundary).  Every lane of a wave runs this on the SAME record (pos and end are wave-uniform): a scalar loop.
+template <class Src>
+FA_HD uint32_t seq_learn(const Src& s, uint32_t pos, uint32_t end, uint32_t* steps) {
+    uint32_t n = 0;
+    while (pos < end) {
+        if (n == SEQ_MAX) return 0u;
+        const uint64_t w = window64(s, pos);
+        const uint32_t w0 = (uint32_t)w;
+        const uint32_t two = (w0 >> 7) & 1u;
+        if (two && ((w0 >> 15) & 1u)) return 0u;          // a tag of 3+ bytes
+        if (two && ((w0 >> 8) & 0x7fu) == 0u) return 0u;  // a non-minimal 2-byte tag
+        const uint32_t tag = two ? (w0 & 0xffffu) : (w0 & 0xffu);  // (as the walks compare it: the tag's bytes, little endian)
+        const uint32_t wt = tag & 7u;
+        if ((tag >> 3) == 0u && !two) return 0u;  // field number 0
+        const uint64_t v = w >> (8u << two);
+        uint32_t vl;
+        uint64_t val;
+        const bool var_ok = varint6(v, vl, val);
+        uint32_t body;
+        if (wt == 0u) {
+            if (!var_ok) return 0u;
+            body = vl;
+        } else if (wt == 1u) {
+            body = 8u;
+        } else if (wt == 5u) {
+            body = 4u;
+        } else if (wt == 2u) {
+            if (!var_ok || vl != 1u) return 0u;
+            body = 1u + (uint32_t)val;
+        } else {
+            return 0u;
+        }
+        for (uint32_t k = 0; k < n; k++)
+            if ((steps[k] & 0xffffu) == tag) return 0u;
+        steps[n++] = seq_step_of(tag);
+        pos += 1u + two + body;
+    }
+    return pos == end ? n : 0u;
+}
+// runtime-tag forms of the canonical walk's steps (same checks, same value ranges)
+template <class Src>
+FA_HD bool sq_short(const Src& s, Cursor& c, uint32_t end, uint32_t tag, uint32_t tl, uint32_t& val) {
+    const bool m = (c.x & (tl == 1u ? 0xffu : 0xffffu)) == tag;
+    const uint32_t v = fa_alignbyte(c.y, c.x, tl);  // value bytes 0..3
+    const uint32_t sb = fa_ffbl(~v & 0x80808080u);
+    const uint32_t pn = c.pos + (sb >> 3) + (tl + 1u);  // sb = 0xffffffff (no stop) -> far beyond end
+    const bool ok = m && pn <= end;
+    val = varint28(v, sb);
+    c.pos = ok ? pn : c.pos;
+    cur_load(s, c);
+    return ok;
+}
+template <class Src>
+FA_HD bool sq_long(const Src& s, Cursor& c, uint32_t end, uint32_t tag, uint32_t tl, uint64_t& val) {
+    const bool m = (c.x & (tl == 1u ? 0xffu : 0xffffu)) == tag;
+    const uint32_t s0 = fa_ffbl(~c.x & (tl == 1u ? 0x80808000u : 0x80800000u));
+    const uint32_t s1 = fa_ffbl(~c.y & 0x80808080u) | 32u;  // stays 0xffffffff when there is no stop
+    const uint32_t sb = s0 < s1 ? s0 : s1;
+    const uint32_t pn = c.pos + (sb >> 3) + 1u;
+    const bool ok = m && pn <= end;
+    const uint32_t lo = fa_alignbyte(c.y, c.x, tl);
+    const uint32_t hi = c.y >> (8u * tl);
+    const uint32_t sv = (sb - 8u * tl) & 63u;
+    const uint64_t keep = (2ull << sv) - 1ull;
+    const uint32_t a = varint28(lo & (uint32_t)keep, 31u);
+    const uint32_t b = varint28(hi & (uint32_t)(keep >> 32), 31u);
+    val = (uint64_t)a | ((uint64_t)b << 28);
+    c.pos = ok ? pn : c.pos;
+    cur_load(s, c);
+    return ok;
+}
+template <class Src>
+FA_HD bool sq_addr(const Src& s, Cursor& c, uint32_t end, uint32_t tag, uint32_t a16[4]) {
+    const bool m = (c.x & 0xffu) == tag;
+    const uint32_t len = (c.x >> 8) & 0xffu;
+    const uint32_t pn = c.pos + 2u + len;
+    const bool ok = m && len <= 16u && pn <= end;
+    load_fixed16(s, c.pos + 2u, len > 16u ? 16u : len, a16);
+    c.pos = ok ? pn : c.pos;
+    cur_load(s, c);
+    return ok;
+}
+// r must be cleared by the caller.  steps / n: what seq_learn left (wave-uniform).
+template <uint32_t COLS, class Src>
+FA_HD bool parse_seq(const Src& s, uint32_t pos, uint32_t end, Rec& r, const uint32_t* steps, uint32_t n) {
+    Cursor c;
+    c.pos = pos;
+    cur_load(s, c);
+    uint32_t next = n ? steps[0] : 0u;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t st = fa_uniform(next);
+        next = steps[i + 1 < n ? i + 1 : i];  // (the next step's word is on its way while this one runs)
+        const uint32_t tag = st & 0xffffu, kind = (st >> 16) & 7u, col = st >> 20;
+        const uint32_t tl = tag > 0xffu ? 2u : 1u;
+        if (kind == SQ_SHORT) {
+            uint32_t v;
+            const bool ok = sq_short(s, c, end, tag, tl, v);
+            switch (col) {
+            case SQC_SAMPLING_RATE: if (COLS & COL_SAMPLING_RATE) r.sampling_rate = ok ? (uint64_t)v : r.sampling_rate; break;
+            case SQC_BYTES: if (COLS & COL_BYTES) r.bytes = ok ? (uint64_t)v : r.bytes; break;
+            case SQC_PACKETS: if (COLS & COL_PACKETS) r.packets = ok ? (uint64_t)v : r.packets; break;
+            case SQC_SRC_AS: if (COLS & COL_SRC_AS) r.src_as = ok ? v : r.src_as; break;
+            case SQC_DST_AS: if (COLS & COL_DST_AS) r.dst_as = ok ? v : r.dst_as; break;
+            case SQC_PROTO: if (COLS & COL_PROTO) r.proto = ok ? v : r.proto; break;
+            case SQC_SRC_PORT: if (COLS & COL_SRC_PORT) r.src_port = ok ? v : r.src_port; break;
+            case SQC_DST_PORT: if (COLS & COL_DST_PORT) r.dst_port = ok ? v : r.dst_port; break;
+            case SQC_ETYPE: if (COLS & COL_ETYPE) r.etype = ok ? v : r.etype; break;
+            default: break;
+            }
+        } else if (kind == SQ_LONG) {
+            uint64_t v;
+            const bool ok = sq_long(s, c, end, tag, tl, v);
+            switch (col) {
+            case SQC_TIME_RECEIVED: if (COLS & COL_TIME_RECEIVED) r.time_received = ok ? v : r.time_received; break;
+            case SQC_SEQUENCE_NUM: if (COLS & COL_SEQUENCE_NUM) r.sequence_num = ok ? (uint32_t)v : r.sequence_num; break;
+            case SQC_TIME_FLOW_START: if (COLS & COL_TIME_FLOW_START) r.time_flow_start = ok ? v : r.time_flow_start; break;
+            default: break;
+            }
+        } else if (kind == SQ_ADDR) {
+            uint32_t a16[4];
+            const bool ok = sq_addr(s, c, end, tag, a16);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((COLS & COL_SRC_ADDR) && col == SQC_SRC_ADDR) r.src[k] = ok ? a16[k] : r.src[k];
+                if ((COLS & COL_DST_ADDR) && col == SQC_DST_ADDR) r.dst[k] = ok ? a16[k] : r.dst[k];
+                if ((COLS & COL_SAMPLER_ADDRESS) && col == SQC_SAMPLER) r.sampler[k] = ok ? a16[k] : r.sampler[k];
+            }
+        } else {
+            const bool go = (c.x & (tl == 1u ? 0xffu : 0xffffu)) == tag;
+            if (tl == 1u) canon_skip<false>(s, c, end, go);
+            else canon_skip<true>(s, c, end, go);
+        }
+    }
+    return c.pos == end;
+}
+
 // ---- generic parser (complete semantics) -----------------------------------
 struct ByteRd {
     const uint8_t* p;

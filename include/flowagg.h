@@ -204,6 +204,9 @@ typedef struct {
      * launch boundary and the candidates held at it (0 in the exact mode) */
     uint64_t topk_theta[2];
     uint64_t topk_candidates[2];
+    /* launches of the kernel variant that learns a producer's field order per wave (flows_5m alone; chosen while most records of
+     * the last launches needed the order-free parser - a producer that does not marshal in field-number order) */
+    uint64_t learnt_order_launches;
 } fa_stats_t;
 
 typedef struct {

@@ -48,8 +48,13 @@ static bool same(const Rec& r, const fo_row& o, uint32_t cols) {
 }
 
 struct Stats {
-    uint64_t cases = 0, canon_sure = 0, full_sure = 0, fast_sure = 0, oracle_ok = 0, fail = 0, tm_sure = 0, tg_sure = 0;
+    uint64_t cases = 0, canon_sure = 0, full_sure = 0, fast_sure = 0, oracle_ok = 0, fail = 0, tm_sure = 0, tg_sure = 0, seq_sure = 0, seq_learnt = 0;
 };
+// the learnt field order (wire.cuh, seq_learn / parse_seq): relearnt now and then from a record parse_fast was sure about, tried
+// on every record - "sure" => the oracle's columns, whatever list is held
+static uint32_t g_steps[SEQ_MAX];
+static uint32_t g_nsteps = 0;
+static bool g_random_relearn = true;
 
 static void hexdump(const uint8_t* p, size_t n) {
     for (size_t i = 0; i < n; i++) printf("%02x", p[i]);
@@ -122,6 +127,7 @@ static void check(const uint8_t* payload, size_t n, Stats& st, bool must_be_cano
             if (st.fail++ < 10) { printf("parse_tmpl not sure on its own producer's record (shape %d): ", must_tmpl); hexdump(payload, n); }
         }
     }
+    bool fast_sure_now = false;
     {
         Rec r;
         rec_clear(r);
@@ -129,6 +135,37 @@ static void check(const uint8_t* payload, size_t n, Stats& st, bool must_be_cano
         st.fast_sure += sure;
         if (sure && (orc != FO_OK || !same(r, want, COL_ALL))) {
             if (st.fail++ < 10) { printf("parse_fast mismatch (oracle=%d): ", orc); hexdump(payload, n); }
+        }
+        fast_sure_now = sure;
+    }
+    bool seq_sure_now = false;
+    if (g_nsteps) {
+        Rec ra, rb;
+        rec_clear(ra);
+        rec_clear(rb);
+        const bool sa = parse_seq<COL_ALL>(src, shift, shift + (uint32_t)n, ra, g_steps, g_nsteps);
+        const bool sb = parse_seq<COLS_AS_ROLLUP>(src, shift, shift + (uint32_t)n, rb, g_steps, g_nsteps);
+        st.seq_sure += sa;
+        seq_sure_now = sa;
+        if ((sa && (orc != FO_OK || !same(ra, want, COL_ALL))) || (sb && (orc != FO_OK || !same(rb, want, COLS_AS_ROLLUP))) || sa != sb) {
+            if (st.fail++ < 10) {
+                printf("parse_seq mismatch (all=%d rollup=%d oracle=%d, %u steps:", sa, sb, orc, g_nsteps);
+                for (uint32_t k = 0; k < g_nsteps; k++) printf(" %x", g_steps[k]);
+                printf("): ");
+                hexdump(payload, n);
+            }
+        }
+    }
+    // learn (again): the kernel's policy - a record the order-free parser took and the held list did not, when its list is at least
+    // as long (proto3 omits zero values: a list learnt from a record that lacks a field refuses every record that has it) - and,
+    // outside the one-producer streams, at random (whatever list is held, "sure" must mean exact)
+    if (fast_sure_now && (g_nsteps == 0 || !seq_sure_now || (g_random_relearn && (rnd() & 63) == 0))) {
+        uint32_t steps[SEQ_MAX];
+        const uint32_t k = seq_learn(src, shift, shift + (uint32_t)n, steps);
+        if (k && (k >= g_nsteps || g_random_relearn)) {
+            memcpy(g_steps, steps, sizeof steps);
+            g_nsteps = k;
+            st.seq_learnt++;
         }
     }
     {
@@ -230,7 +267,7 @@ static size_t random_schema_record(uint8_t* out, bool canonical, bool small, boo
 
 int main(int argc, char** argv) {
     const uint64_t iters = argc > 1 ? strtoull(argv[1], 0, 0) : 200000;
-    Stats gen, goflow, canon, noncanon, mut, small, wide67, wide67nc;
+    Stats gen, goflow, canon, noncanon, mut, small, wide67, wide67nc, reversed;
     // 1. generator output, all modes: must be accepted by parse_canon
     for (uint32_t mode = 0; mode < 5; mode++) {  // MOCKER, ASPAIRS, ZIPF, GOFLOW (full walk only), DISTINCT
         fo_gen_params gp;
@@ -256,6 +293,21 @@ int main(int argc, char** argv) {
             check(tmp, n, mut, false);
         }
     }
+    // 2b. ASPAIRS values marshalled in DESCENDING field order (generator mode 5): no canonical walk takes them; the order learnt
+    // from the first record takes every one
+    {
+        fo_gen_params gp;
+        memset(&gp, 0, sizeof gp);
+        gp.mode = 5; gp.framed = 0; gp.seed = 11; gp.n_total = iters; gp.t0 = 1600000200; gp.span_secs = 900; gp.per_sec = 4;
+        std::vector<uint8_t> buf(iters * 200 + 1024);
+        std::vector<uint64_t> off(iters + 1);
+        const size_t w = fo_gen_records(&gp, 0, iters, buf.data(), buf.size(), off.data());
+        if (w == (size_t)-1) { printf("generator overflow\n"); return 2; }
+        g_nsteps = 0;
+        g_random_relearn = false;
+        for (uint64_t i = 0; i < iters; i++) check(buf.data() + off[i], off[i + 1] - off[i], reversed, false);
+        g_random_relearn = true;
+    }
     // 3. random records over the whole schema
     for (uint64_t i = 0; i < iters; i++) {
         uint8_t tmp[1024];
@@ -272,19 +324,20 @@ int main(int argc, char** argv) {
         if (n < 900) check(tmp, n, wide67nc, false);
     }
     auto pr = [](const char* name, const Stats& s) {
-        printf("%-28s cases=%llu oracle_ok=%llu canon_sure=%llu full_sure=%llu fast_sure=%llu tmpl_mocker_sure=%llu tmpl_goflow_sure=%llu FAIL=%llu\n", name, (unsigned long long)s.cases,
+        printf("%-28s cases=%llu oracle_ok=%llu canon_sure=%llu full_sure=%llu fast_sure=%llu tmpl_mocker_sure=%llu tmpl_goflow_sure=%llu seq_sure=%llu seq_learnt=%llu FAIL=%llu\n", name, (unsigned long long)s.cases,
                (unsigned long long)s.oracle_ok, (unsigned long long)s.canon_sure, (unsigned long long)s.full_sure, (unsigned long long)s.fast_sure,
-               (unsigned long long)s.tm_sure, (unsigned long long)s.tg_sure, (unsigned long long)s.fail);
+               (unsigned long long)s.tm_sure, (unsigned long long)s.tg_sure, (unsigned long long)s.seq_sure, (unsigned long long)s.seq_learnt, (unsigned long long)s.fail);
     };
     pr("generator (4 modes)", gen);
     pr("generator (goflow)", goflow);
+    pr("generator (reversed)", reversed);
     pr("mutated generator output", mut);
     pr("random schema, canonical small", small);
     pr("random schema, canonical", canon);
     pr("random schema, non-canonical", noncanon);
     pr("67-field, canonical small", wide67);
     pr("67-field, mixed", wide67nc);
-    const uint64_t fails = goflow.fail + gen.fail + mut.fail + canon.fail + noncanon.fail + small.fail + wide67.fail + wide67nc.fail;
+    const uint64_t fails = reversed.fail + goflow.fail + gen.fail + mut.fail + canon.fail + noncanon.fail + small.fail + wide67.fail + wide67nc.fail;
     printf(fails ? "FAILED\n" : "OK\n");
     return fails ? 1 : 0;
 }

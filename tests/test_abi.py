@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(fa):
 
 def test_struct_layouts_match_header(fa):
     assert C.sizeof(fa.Config) == 64
-    assert C.sizeof(fa.Stats) == 280
+    assert C.sizeof(fa.Stats) == 288
     assert C.sizeof(fa.MockParams) == 48
     assert fa.ROW5M_DTYPE.itemsize == 48 and fa.FLOW_ROW_DTYPE.itemsize == 120
 

@@ -607,3 +607,19 @@ def test_readme_samples_on_device(gpu_lib, fa, po):
         agg.ingest(buf, off)
         rows = agg.close_window()
     readme_render(fa, fx, decoded, rows)
+
+
+def test_mock_generator_refuses_a_call_of_4_gib(gpu_lib, fa):
+    """Device offsets are 32-bit: a generator call whose records add up to 4 GiB or more is refused with the size it would have
+    written (found by `bench.py --mode goflow` at the default chunk: 33 M records of 165 bytes wrapped the offsets silently)."""
+    import torch
+    n = 30_000_000  # x ~156 bytes = 4.7 GB
+    mp = fa.mock_params(mode=fa.MOCK_GOFLOW, framed=1, seed=3, n_total=n, span_secs=900, per_sec=400_000)
+    d_buf = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    d_off = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    with fa.FlowAgg(framed=True) as agg:
+        with pytest.raises(fa.FlowAggError) as e:
+            agg.mock_generate_device(mp, 0, n, d_buf.data_ptr(), d_buf.numel(), d_off.data_ptr())
+        assert e.value.code == -1 and "4 GiB" in str(e.value)  # FA_ERR_ARG
+        small = agg.mock_generate_device(mp, 0, 16, d_buf.data_ptr(), d_buf.numel(), d_off.data_ptr())  # (the ctx is fine)
+        assert 16 * 100 < small < 16 * 200

@@ -34,6 +34,10 @@ def test_parsers_fuzz_against_oracle(po):
     assert f["tmpl_mocker_sure"] == f["cases"] and f["tmpl_goflow_sure"] == f["cases"], lines["generator (4 modes)"]
     f = dict(kv.split("=") for kv in lines["generator (goflow)"].split() if "=" in kv)
     assert f["tmpl_goflow_sure"] == f["cases"] and f["tmpl_mocker_sure"] == "0", lines["generator (goflow)"]
+    # descending field order: no ordered walk takes a record, the learnt order takes every one (the first is what it learns from)
+    f = dict(kv.split("=") for kv in lines["generator (reversed)"].split() if "=" in kv)
+    assert f["canon_sure"] == "0" and f["full_sure"] == "0" and f["fast_sure"] == f["cases"] and f["FAIL"] == "0", lines["generator (reversed)"]
+    assert int(f["seq_sure"]) >= int(f["cases"]) - 20 and 1 <= int(f["seq_learnt"]) <= 10, lines["generator (reversed)"]
     # the 67-field producer (pb-ext/flow.pb.go:57-147): the FULL canonical walk must take every record
     for name in ("generator (goflow)", "67-field, canonical small"):
         f = dict(kv.split("=") for kv in lines[name].split() if "=" in kv)

@@ -554,3 +554,69 @@ def test_random_configurations_against_the_oracle(gpu_lib, fa, po, seed):
                 k_read = int(rng.choice([10, 300, 1 << 20]))
                 got_top = agg.topk(key_set, k_read)
                 assert [(bytes(r["key"]), int(r["weight"])) for r in got_top] == [(k, -e) for e, k in want_top[:k_read]], (col, k_read, cfg, kw)
+
+
+def test_learnt_field_order_kernel_is_chosen_by_the_counters_and_exact(gpu_lib, fa, po):
+    """A producer that marshals in DESCENDING field order (valid proto3 no ordered walk accepts): after the first launches the
+    library runs the kernel variant whose waves learn the field order of a tile's longest record and walk the next tiles with it
+    (ingest.cuh tier 4; order-free parser only for what that refuses) - rows == the oracle's all along; canonical records again:
+    back to the common kernel; records of BOTH orders mixed in one stream and a few mutated ones: still the oracle's rows."""
+    n = 400_000
+    gp = po.gen_params(mode=po.GEN_REVERSED, framed=1, seed=321, n_total=n, span_secs=900)
+    buf, off = po.gen_records(gp, 0, n)
+    gq = po.gen_params(mode=po.GEN_ASPAIRS, framed=1, seed=322, n_total=n, span_secs=900)
+    bufq, offq = po.gen_records(gq, 0, n)
+    ref = po.Rollup(300)
+    with fa.FlowAgg(framed=True, table_capacity_log2=18) as agg:
+        for _ in range(4):
+            agg.ingest(buf, off)
+            ref.ingest(buf, off, 1)
+            agg.sync()
+        st = agg.stats()
+        assert st["records_ok"] == 4 * n and st["records_bad"] == 0 and st["learnt_order_launches"] >= 2, st
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+        # interleaved: every other record canonical (a tile's waves meet both; whatever the learnt list refuses takes the order-free parser)
+        raw, rawq = bytes(buf), bytes(bufq)
+        recs = []
+        for k in range(60_000):
+            recs.append(raw[int(off[k]):int(off[k + 1])] if k & 1 else rawq[int(offq[k]):int(offq[k + 1])])
+        rng = np.random.default_rng(9)
+        mixed = np.frombuffer(b"".join(recs), dtype=np.uint8).copy()
+        offm = np.zeros(len(recs) + 1, dtype=np.uint64)
+        offm[1:] = np.cumsum([len(r) for r in recs])
+        for r in rng.choice(len(recs), size=40, replace=False):
+            a, b = int(offm[r]), int(offm[r + 1])
+            mixed[int(rng.integers(a + 2, b))] = int(rng.integers(0, 256))
+        agg.ingest(mixed, offm)
+        ref.ingest(mixed, offm, 1)
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+        before = agg.stats()["learnt_order_launches"]
+        for _ in range(70):  # canonical records: the verdict runs out after 64 launches
+            agg.ingest(bufq[:int(offq[20_000])], offq[:20_001])
+            ref.ingest(bufq[:int(offq[20_000])], offq[:20_001], 1)
+        agg.sync()
+        agg.ingest(bufq, offq)
+        ref.ingest(bufq, offq, 1)
+        st = agg.stats()
+        assert st["learnt_order_launches"] - before <= 66, st
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+
+
+@pytest.mark.parametrize("force", ["1", "0"])
+def test_learnt_field_order_kernel_forced_on_every_generator_mode(gpu_lib, fa, po, monkeypatch, force):
+    """FA_SEQ=1: the learnt-order variant from the first launch on, on every producer shape (on canonical streams its tier never
+    runs; on the reversed one it does); FA_SEQ=0: never.  Rows == the oracle's either way."""
+    monkeypatch.setenv("FA_SEQ", force)
+    n = 150_000
+    for mode in (po.GEN_MOCKER, po.GEN_ASPAIRS, po.GEN_GOFLOW, po.GEN_REVERSED):
+        gp = po.gen_params(mode=mode, framed=1, seed=400 + mode, n_total=n, span_secs=900)
+        buf, off = po.gen_records(gp, 0, n)
+        ref = po.Rollup(300)
+        ref.ingest(buf, off, 1)
+        ref.ingest(buf, off, 1)
+        with fa.FlowAgg(framed=True, table_capacity_log2=18) as agg:
+            agg.ingest(buf, off)
+            agg.ingest(buf, off)
+            st = agg.stats()
+            assert st["records_ok"] == 2 * n and (st["learnt_order_launches"] == 2) == (force == "1"), (mode, st)
+            assert agg.read_window().tobytes() == ref.rows().tobytes(), mode
