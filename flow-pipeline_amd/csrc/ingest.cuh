@@ -26,7 +26,9 @@ struct LaneTally {
     uint32_t tick = 0;  // tiles this wave has taken through the sketch path (wave-uniform)
 };
 // T8: this launch writes compact 8-byte tuples (wave-tile kernel only; table.cuh)
-template <int MODE, uint32_t KEYSETS, uint32_t COLS, bool T8 = false, class Hook = NoHook>
+// CANDM: the top-k contract known at compile time (wave-tile variants of their own: 0 exact, 1 candidates) or read from the launch
+// arguments (-1)
+template <int MODE, uint32_t KEYSETS, uint32_t COLS, bool T8 = false, int CANDM = -1, class Hook = NoHook>
 __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& lt, LdsMinutes& lm, uint32_t* part_cnt, const uint32_t* tile,
                                           bool mine, uint32_t pos, uint32_t end, uint32_t rec_idx, uint32_t tb_base,
                                           LaneTally& tally, uint32_t& pmode, uint32_t& lt_seen, uint32_t& lt_hits,
@@ -149,7 +151,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     uint64_t cw = 0, ws = 0, wd = 0, slo = 0, shi = 0, dlo = 0, dhi = 0, sh1 = 0, sh2 = 0, dh1 = 0, dh2 = 0;
     bool on_s = false, on_d = false, vs = false, vd = false;
     const bool keys_on = !(FA_DBG(a, DBG_NO_KEYSET));
-    const bool cand = a.cand_src != nullptr || a.cand_dst != nullptr;  // (wave-uniform: kernel arguments)
+    const bool cand = CANDM >= 0 ? CANDM == 1 : (a.cand_src != nullptr || a.cand_dst != nullptr);  // (wave-uniform: kernel arguments)
     uint32_t cw0s = 0, cw0d = 0;
     KsProbe ps{}, pd{};
     if (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
@@ -297,7 +299,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
     }
     if (KEYSETS & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)) {
         if (!(FA_DBG(a, DBG_NO_CMS))) {
-            if (cl && a.cseg) {  // scatter sink: no atomics (whole wave: the bin flushes need every lane)
+            if (cl && (CANDM >= 0 || a.cseg)) {  // scatter sink: no atomics (whole wave: the bin flushes need every lane)
                 // (bin lists: the wave's tile buffer is dead by now - behind the 768 bytes the folds used)
                 uint32_t* list = const_cast<uint32_t*>(tile) + 256;
                 if (on_s) cms_scatter(a, *cl, list, 0u, vs, ws, sh1, sh2);
@@ -644,7 +646,7 @@ struct HotAddrsOpt<false> {
 // SEQ: the variant with the learnt-field-order tier (lane_work tier 4) - a kernel of its own, launched while the counters say that
 // most records need the order-free parser (maintain_host.inc, format_feedback): in the common kernel the tier's code cost the
 // streams that never use it (GoFlow shape: +1.3 % per launch, same box, through the register allocation alone).
-template <uint32_t KEYSETS, bool T8, bool SEQ = false>
+template <uint32_t KEYSETS, bool T8, bool SEQ = false, int CANDM = -1>
 __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) void wtile_kernel(KArgs a) {
     constexpr uint32_t BL = bin_line(KEYSETS);
     constexpr uint32_t TB = bin_cap<T8, BL>();
@@ -685,8 +687,10 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
     if (KEYSETS & FA_KEYS_MINUTE_SERIES) lds_minutes_clear(lm);
     if (HAS_APP)
         for (int i = tid; i < (1 << WIDE_PLOG2_MAX) + 2; i += WBLOCK) wpart_cnt[i] = i < (1 << WIDE_PLOG2_MAX) ? 0u : 0xffffffffu;
-    CmsLds* const cl = (HAS_CMS && a.cseg) ? cms_lds.get() : nullptr;
-    HotAddrs* const hot = (HAS_CMS && (a.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS))) ? hot_lds.get() : nullptr;
+    // (the per-contract variants are launched with the sketch scatter sink only: its segments' presence is a constant there, the
+    // atomic fallback of odd sketch geometries compiles out of their tile loop)
+    CmsLds* const cl = (HAS_CMS && (CANDM >= 0 || a.cseg)) ? cms_lds.get() : nullptr;
+    HotAddrs* const hot = (HAS_CMS && (KEYSETS != KS_ALL || (a.key_sets & (FA_KEYS_SRCADDR_CMS | FA_KEYS_DSTADDR_CMS)))) ? hot_lds.get() : nullptr;
     if (HAS_CMS && cl)
         for (int i = tid; i < (int)(CMS_SETS * CMS_NPART); i += WBLOCK) {
             cl->bin_cnt[i] = 0;
@@ -802,7 +806,7 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
             rest = rest && !hopeless;
         }
         uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
-        lane_work<MODE_INGEST, KEYSETS, COLS, T8>(a, lt, lm, part_cnt, tile, staged, cur.q0 - cbase, cur.q1 - cbase, cur.r0 + lane, tb_base, tally,
+        lane_work<MODE_INGEST, KEYSETS, COLS, T8, CANDM>(a, lt, lm, part_cnt, tile, staged, cur.q0 - cbase, cur.q1 - cbase, cur.r0 + lane, tb_base, tally,
                                                   pmode, lt_seen, lt_hits, bins, bin_cnt, fill, NoHook(), cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0), hot,
                                                   (HAS_APP && a.wseg) ? wpart_cnt : nullptr, HAS_SEQ ? seq_all + wave * (SEQ_MAX + 2) : nullptr);
         // (sketch variants, round 3: starting the next tile's DMA right behind the parse - the sink is long there and does
