@@ -171,6 +171,9 @@ struct fa_ctx {
     size_t m_scratch_cap = 0;
     void* m_out[2] = {nullptr, nullptr};  // merged rows; rows in emit order
     size_t m_out_cap[2] = {0, 0};
+    void* cut_buf = nullptr;         // fa_read_window_app48 into page-locked memory: the window's rows cut in two by key (rows_host.inc)
+    size_t cut_cap = 0;
+    hipStream_t copy_stream = nullptr;  // ... the first half's rows leave on it while the second half is sorted
     void* fs_scratch = nullptr;      // device-side framing (framing.cuh): block starts (two copies), counts, bases, error flags, counters
     size_t fs_scratch_cap = 0;
     void* fs_off = nullptr;          // ... the offsets it produces
@@ -562,6 +565,8 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->rc_buf);
     (void)hipFree(c->rw_buf);
     (void)hipFree(c->m_scratch);
+    (void)hipFree(c->cut_buf);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)hipFree(c->m_out[0]);
     (void)hipFree(c->m_out[1]);
     (void)hipFree(c->fs_scratch);

@@ -372,6 +372,55 @@ __global__ __launch_bounds__(256) void row_app48_kernel(const RowApp* rows, uint
     }
 }
 
+// fa_read_window_app48 in two halves (rows_host.inc, rows_read_app48): the most significant key word of a window's rows - the first
+// eight address bytes in comparison order - sampled for a pivot, and the kernel that cuts the rows at it
+__global__ __launch_bounds__(256) void app_key_sample_kernel(const RowApp* rows, uint32_t n, uint32_t stride, unsigned long long* out, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = RowOps<RK_APP>::key(rows[min((unsigned long long)i * stride, (unsigned long long)n - 1ull)], 2, 0xffffffffu);
+}
+// The cut: rows whose key word lies below the pivot to the front of `out` (cnt[0] of them when the kernel is done), the others to its
+// end, backwards (cnt[1]) - in any order inside a half, both are sorted next.  A 1024-thread workgroup takes the places of a round's
+// rows with two returning atomics (hipcub::DevicePartition::If took 4.4 ms for 16.6 M 56-byte rows; this is one read and one write).
+constexpr int APP_CUT_BLOCK = 1024;
+__global__ __launch_bounds__(APP_CUT_BLOCK) void app_cut_kernel(const RowApp* in, uint32_t n, unsigned long long pivot, RowApp* out, unsigned int* cnt) {
+    __shared__ uint32_t wcnt[2][APP_CUT_BLOCK / 64];
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * APP_CUT_BLOCK; base < n; base += gridDim.x * APP_CUT_BLOCK) {  // (the trip count is the workgroup's)
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        RowApp r = in[valid ? i : n - 1u];
+        const bool below = valid && RowOps<RK_APP>::key(r, 2, 0xffffffffu) < pivot;
+        const unsigned long long ma = __builtin_amdgcn_ballot_w64(below), mb = __builtin_amdgcn_ballot_w64(valid && !below);
+        if (lane == 0) {
+            wcnt[0][wave] = (uint32_t)__builtin_popcountll(ma);
+            wcnt[1][wave] = (uint32_t)__builtin_popcountll(mb);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            constexpr uint32_t NW = APP_CUT_BLOCK / 64;
+            const uint32_t half = lane >= 32 ? 1u : 0u, w = lane & 31u;
+            const uint32_t t = w < NW ? wcnt[half][w] : 0u;
+            uint32_t incl = t;
+#pragma unroll
+            for (int o = 1; o < (int)NW; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 32);
+                if (w >= (uint32_t)o) incl += up;
+            }
+            const uint32_t tot = (uint32_t)__shfl((int)incl, (int)(NW - 1u), 32);
+            uint32_t b = 0;
+            if (w == 0 && tot) b = atomicAdd(&cnt[half], tot);
+            b = (uint32_t)__shfl((int)b, 0, 32);
+            if (w < NW) wcnt[half][w] = b + incl - t;  // where this wave's rows of this half start
+        }
+        __syncthreads();
+        const uint32_t below_lanes = (uint32_t)__builtin_popcountll(ma & ((1ull << lane) - 1ull));
+        const uint32_t other_lanes = (uint32_t)__builtin_popcountll(mb & ((1ull << lane) - 1ull));
+        if (below) out[wcnt[0][wave] + below_lanes] = r;
+        else if (valid) out[n - 1u - (wcnt[1][wave] + other_lanes)] = r;
+        __syncthreads();
+    }
+}
+
 // window close of a group of contexts (group_host.inc): member r's slice of a sketch = its own slice + the same slice of every
 // other member, staged back to back (stride words apart) in the member's exchange buffer.  Plain 16-byte loads and stores,
 // every word read once: n x slice bytes at the copy rate.  own / stage / out are 16-byte aligned, w is even or the tail is

@@ -1,6 +1,7 @@
 """GPU parity for the wide key sets: (SrcAddr,DstPort,Proto) rollup (BASELINE config 5's second key set),
 the dashboards' GROUP BY SrcPort/DstPort and per-minute series (viz-ch.json:74,358,604).  Through the
 C-ABI, bit-exact against the oracle restatements (oracle/pyoracle.py) on the same seeded inputs."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -286,3 +287,39 @@ def test_one_windows_rows_as_48_byte_rows(gpu_lib, fa, po):
             assert agg.read_window_app().tobytes() == twin.read_window_app().tobytes()
             small = np.empty(3, dtype=fa.ROW_APP48_DTYPE)  # too small a buffer: the binding asks again with room
             assert len(agg.read_window_app48(t0 + 300, out=small)[0]) == len(twin.read_window_app(t0 + 300))
+
+
+@pytest.mark.parametrize("sub,mode", [(0, "zipf"), (60, "zipf"), (0, "one_block")])
+def test_48_byte_rows_in_two_halves_into_page_locked_memory(gpu_lib, fa, po, monkeypatch, sub, mode):
+    """A large window read into PAGE-LOCKED memory leaves in two halves cut by key (the first half's copy overlaps the second half's
+    sort; FA_APP48_SPLIT sets the threshold - 2^22 rows in production): byte-identical to the one-piece read, for tumbling and
+    sliding windows, with sixteen addresses in all (a lopsided cut), when the buffer is too small (the
+    caller learns how many rows to make room for), and for the close."""
+    monkeypatch.setenv("FA_APP48_SPLIT", "8192")
+    n = 300_000
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=4901, n_total=n, zipf_log2_universe=16 if mode == "zipf" else 4, span_secs=600)
+    buf, off = po.gen_records(gp, 0, n)
+
+    def pinned48(rows):
+        return fa.FlowAgg.pinned_rows(fa.ROWS_APP, rows).view(np.uint8)[: rows * fa.ROW_APP48_DTYPE.itemsize].view(fa.ROW_APP48_DTYPE)
+
+    with fa.FlowAgg(framed=True, key_sets=9, subwindow_secs=sub, wide_capacity_log2=20) as agg, \
+            fa.FlowAgg(framed=True, key_sets=9, subwindow_secs=sub, wide_capacity_log2=20) as twin:
+        agg.ingest(buf, off)
+        twin.ingest(buf, off)
+        t0 = int(agg.open_timeslots()[0])
+        for ts in [t0, t0 + 300] + ([t0 + 120] if sub else []):
+            want, date_w = twin.read_window_app48(ts)  # (pageable buffer: in one piece)
+            assert len(want) > 8192 or mode == "one_block"
+            out = pinned48(len(want) + 10)
+            got, date = agg.read_window_app48(ts, out=out)
+            assert date == date_w and got.tobytes() == want.tobytes(), (ts, len(got), len(want))
+            if len(want) > 8192:
+                with pytest.raises(fa.FlowAggError) as e:  # straight through the C-ABI: the binding would ask again by itself
+                    agg._chk(agg._L.fa_read_window_app48(agg._h, ts, pinned48(len(want) // 3).ctypes.data, len(want) // 3, C.byref(C.c_size_t()), C.byref(C.c_uint32())))
+                assert e.value.code == -6
+                assert agg.read_window_app48(ts, out=pinned48(len(want) // 3))[0].tobytes() == want.tobytes()  # ... and gets every row
+        want, _ = twin.read_window_app48(t0, close=True)
+        got, _ = agg.read_window_app48(t0, out=pinned48(len(want)), close=True)
+        assert got.tobytes() == want.tobytes()
+        assert agg.read_window_app().tobytes() == twin.read_window_app().tobytes()
