@@ -59,6 +59,24 @@ def test_flag_surface_matches_the_reference(exe):
     assert r.returncode == 2 and "flag provided but not defined: -no.such.flag" in r.stderr  # Go's flag package wording
     r = subprocess.run([exe, "-flush.dur=abc", "-input.files=x"], capture_output=True, text=True)
     assert r.returncode == 1 and "invalid value" in r.stderr
+    # the additive flags (GPU placement, table sizes, sinks) parse as well
+    extra = ["-gpu.devices=8", "-gpu.transport=rccl", "-gpu.table.log2=22", "-gpu.keyset.log2=24", "-gpu.wide.log2=26", "-key.sets=15",
+             "-out.rowbinary=/dev/null", "-out.app=/dev/null", "-out.topk=/dev/null", "-topk.k=10", "-window.secs=300", "-window.lag=30"]
+    r = subprocess.run([exe] + extra, capture_output=True, text=True)
+    assert r.returncode == 1 and "no Kafka client in this build" in r.stderr
+
+
+def test_an_empty_partition_log_and_a_mapped_one(exe, po, tmp_path):
+    """Partition logs are mapped, not copied: an empty file is a claim without messages, the others are consumed to their last byte."""
+    n = 3000
+    _, _, paths = _partition_logs(po, tmp_path, n, 2)
+    empty = tmp_path / "empty.log"
+    empty.write_bytes(b"")
+    m = tmp_path / "metrics.txt"
+    r = subprocess.run([exe, "-input.files=%s,%s,%s" % (paths[0], empty, paths[1]), "-sink.dryrun", "-flush.count=1000", "-metrics.dump=%s" % m],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert _metrics(m)["insert_count"] == n
 
 
 def test_flush_by_count_and_marking(exe, po, tmp_path):
