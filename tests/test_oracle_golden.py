@@ -328,3 +328,24 @@ def test_candidates_contract_restatement_finds_the_heavy_hitters(po):
     for (_, bw), th in zip(batches, thetas):
         total = (total + int(bw.sum(dtype=np.uint64))) & (2**64 - 1)
         assert th >= max(total >> 10, 1)
+
+
+def test_topk_contract_fixture(po):
+    """tests/golden/topk_contract.json (make_topk_contract.py): the estimate-bin map at fixed values and the candidates contract on a
+    seeded stream - thresholds per boundary, candidates held, the ranking's digest.  The restatement may not drift from it; the
+    library is compared with the restatement on the GPU (tests/test_topk_gpu.py)."""
+    import hashlib
+    import importlib.util
+    fx = json.load(open(os.path.join(GOLDEN, "topk_contract.json")))
+    for v in fx["bins"]:
+        e, b = int(v["estimate"]), v["bin"]
+        assert int(po.topk_bin(np.array([e], dtype=np.uint64))[0]) == b and po.topk_bin_floor(b) == int(v["floor"])
+        assert po.topk_bin_floor(b) <= e and (b == 1919 or po.topk_bin_floor(b + 1) > e)  # (the map is monotone: floor(b) <= e < floor(b + 1))
+    spec = importlib.util.spec_from_file_location("make_topk_contract", os.path.join(GOLDEN, "make_topk_contract.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    c = fx["candidates"]
+    again = mk.case(n=c["records"], nb=c["batches"], depth=c["depth"], wl2=c["width_log2"], seed=c["seed"], track=c["track"], cap=c["capacity_log2"],
+                    gen_seed=c["generator_seed"])
+    assert again == c
+    assert hashlib.sha256(b"").hexdigest() != c["sets"]["src_addr"]["ranking_sha256"] and c["sets"]["src_addr"]["candidates"] >= c["track"]

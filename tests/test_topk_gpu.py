@@ -151,3 +151,32 @@ def test_odd_sketch_geometries_in_both_topk_modes(gpu_lib, fa, po, depth, wl2, t
             assert [(bytes(r["key"]), int(r["weight"])) for r in got] == [(k, -e) for e, k in _ranked(cset, cest)], (col, len(got), len(cset))
             st = cand.stats()
             assert st["topk_theta_" + ("src" if col == "src_addr" else "dst")] == thetas[-1]
+
+
+def test_candidates_mode_equals_the_golden_fixture(gpu_lib, fa, po):
+    """tests/golden/topk_contract.json pins the candidates contract on a seeded stream (thresholds, candidates held, the ranking's
+    digest; the restatement is pinned to it on the CPU): the library, fed the same stream in the same launches, lands on it."""
+    import hashlib
+    import json
+    import os
+    c = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "topk_contract.json")))["candidates"]
+    n, nb = c["records"], c["batches"]
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=c["generator_seed"], n_total=n, zipf_log2_universe=c["zipf_log2_universe"])
+    buf, off = po.gen_records(gp, 0, n)
+    step = n // nb
+    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=c["depth"], cms_width_log2=c["width_log2"], cms_seed=c["seed"], topk_capacity_log2=c["capacity_log2"],
+                    topk_mode=fa.TOPK_CANDIDATES, topk_track=c["track"], max_batch_records=step) as agg:
+        for i in range(nb):
+            a, b = i * step, (i + 1) * step
+            agg.ingest(buf[int(off[a]):int(off[b])], off[a:b + 1] - off[a])
+        st = agg.stats()
+        assert st["kernel_launches"] == nb
+        for col, ks, tag in (("src_addr", fa.FA_KEYS_SRCADDR_CMS, "src"), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS, "dst")):
+            want = c["sets"][col]
+            got = agg.topk(ks, 1 << 16)
+            assert st["topk_theta_" + tag] == want["thetas"][-1] and len(got) == want["candidates"]
+            h = hashlib.sha256()
+            for r in got:
+                h.update(bytes(r["key"]) + int(r["weight"]).to_bytes(8, "little"))
+            assert h.hexdigest() == want["ranking_sha256"]
+            assert [[bytes(r["key"]).hex(), int(r["weight"])] for r in got[:5]] == want["first"]
