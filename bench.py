@@ -20,6 +20,18 @@ Rank 0 prints ONE JSON line (see the contract in the task description):
                 timed region, on every rank; N>1: also the rows merged across ranks at window close against the
                 oracle's rollup of all partitions;
   host_fed      the PCIe-inclusive rate through fa_ingest (host buffers) - a secondary figure, never `value`.
+  ms_per_step_all / ms_per_step_median / settle
+                the headline's K steps are timed in ONE bracket (the contract: `value`, `ms_per_step`); before it an untimed
+                settle phase runs steps until two consecutive ones agree within 1 % (a fresh box starts at sclk 155 MHz), and
+                behind it the same K steps run once more, each with its own fence: per-step times and their median.
+  secondary     (N = 1, default workload) the other BASELINE configurations and the consumer on the SAME driver clock, each with
+                its own parity booleans against the oracle and `ok`: config3_exact / config3_candidates (configs[2], 200 M
+                records), config5 (configs[4] single-GPU shape, 100 M records: ingest fraction AND close time of one run),
+                group8 (8 contexts in one process through fa_group_*), host_consume (the C++ consumer, 8 partition logs of
+                config 2's stream).  --no-secondary skips them; they never change metric / value / config.
+  group_preflight
+                (N > 1) rank 0 creates one small ctx on EVERY visible device and runs the in-process group close (fa_group_*:
+                peer copies AND ncclCommInitAll) on known partitions against the oracle - reported, never fatal.
 Other workloads (side measurements, their JSON goes to profiles/): --mode zipf --key-sets 7 (config 3 shape),
 --key-sets 9 (config 5 shape), --mode goflow / reversed (67-field producer / order-free parser), --stage decode
 (projection only).
@@ -296,6 +308,521 @@ def preflight(fa, torch, dist, rank, world, local_rank, backend, xdev, strict=Fa
     return res
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# secondary blocks (N = 1): the other BASELINE configurations on the driver's clock.  Every block: its own contexts, its own
+# parity booleans against the oracle (oracle/ = the checker, never the thing measured), `ok` = all of them.
+def _universe_keys(L, dst):
+    """(lo, hi) of the Zipf generator's address for every (v6, rank): index = rank + (v6 << L)  (csrc/gen.cuh gen_zipf_key)."""
+    rank = np.arange(1 << L, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        a = mix64(rank * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x2222 if dst else 0x1111))
+        b = mix64(a ^ np.uint64(0xD1B54A32D192ED03))
+    lo = np.concatenate([a & np.uint64(0xFFFFFFFF), a])   # v4: the low 4 bytes of a, rest zero; v6: a || b
+    hi = np.concatenate([np.zeros(1 << L, dtype=np.uint64), b])
+    return lo, hi
+
+
+def _sketch_columns(a, h1, wl2, row):
+    pbits = min(8, wl2 - 4)
+    sub = wl2 - pbits
+    with np.errstate(over="ignore"):
+        prefix = (h1 & np.uint64((1 << pbits) - 1)).astype(np.int64)
+        l1 = (h1 >> np.uint64(32)).astype(np.uint32)
+        l2 = ((a | np.uint64(1)) >> np.uint64(32)).astype(np.uint32) | np.uint32(1)
+        low = ((l1 + np.uint32(row) * l2) >> np.uint32(32 - sub)).astype(np.int64)
+    return (prefix << sub) | low
+
+
+def _estimates(cms, lo, hi, depth, wl2, seed):
+    with np.errstate(over="ignore"):
+        s0 = mix64(np.array([(seed + 0x9E3779B97F4A7C15) & (2**64 - 1)], dtype=np.uint64))[0]
+        a = mix64(lo ^ s0)
+        h1 = mix64(a ^ hi)
+        best = np.full(len(lo), np.uint64(2**64 - 1), dtype=np.uint64)
+        for r in range(depth):
+            best = np.minimum(best, cms[_sketch_columns(a, h1, wl2, r) + (r << wl2)])
+    return best
+
+
+def _want_top100(cms, L, dst, depth, wl2, seed):
+    """The first 100 rows of the ranking of EVERY address of the universe by the CPU sketch's estimate (weight DESC, key bytes)."""
+    lo, hi = _universe_keys(L, dst)
+    est = _estimates(cms, lo, hi, depth, wl2, seed)
+    c400 = np.argpartition(est, len(est) - 400)[-400:]
+    uniq = {}
+    for i in c400:  # (two ranks may share a 4-byte IPv4 form: one address, listed once)
+        uniq[lo[i].tobytes() + hi[i].tobytes()] = int(est[i])
+    return sorted(uniq.items(), key=lambda kv: (-kv[1], kv[0]))[:100]
+
+
+class _Zipf3:
+    """The CPU side of BASELINE configs[2] / [3] (seed 3, Zipf-1.1 over 2^24 addresses), computed once for every block that
+    ingests this stream: both Count-Min sketches of the whole stream and the top-100 of the whole universe."""
+
+    def __init__(self, po, n, L=24, depth=4, wl2=20, seed=0x5EED):
+        self.n, self.L, self.depth, self.wl2, self.seed = n, L, depth, wl2, seed
+        self.threads = max(1, min(64, effective_cpus()[0]))
+        t = time.perf_counter()
+        gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=3, n_total=n, span_secs=1800, zipf_log2_universe=L, zipf_s_x100=110)
+        self.gp = gp
+        self.c_src = np.zeros(depth << wl2, dtype=np.uint64)
+        self.c_dst = np.zeros(depth << wl2, dtype=np.uint64)
+        po.cms_stream(gp, 0, n, self.threads, depth, wl2, seed, self.c_src, self.c_dst)
+        self.want = [_want_top100(c, L, d, depth, wl2, seed) for d, c in enumerate((self.c_src, self.c_dst))]
+        self.seconds = time.perf_counter() - t
+
+    def tops_ok(self, tops):
+        return all([(bytes(r["key"]), int(r["weight"])) for r in top] == want for top, want in zip(tops, self.want))
+
+
+def sec_config3(fa, po, torch, dev, ref, cand, chunk=16_666_667):
+    """BASELINE configs[2]: Count-Min heavy hitters over SrcAddr / DstAddr beside the flows_5m rollup (key_sets 7), `ref.n` framed
+    records regenerated in HBM chunk by chunk; both sketches bit-exact against the CPU sketch of the whole stream, top-100 == the
+    ranking of the whole universe, count() of the rollup == records (viz-ch.json:233,479)."""
+    n, L = ref.n, ref.L
+    KS = (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS)
+    mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=3, n_total=n, span_secs=1800, zipf_log2_universe=L, zipf_s_x100=110)
+    out = {"workload": "BASELINE configs[2]: %d framed FlowMessages, Zipf-1.1 over 2^%d addresses, key sets flows_5m + both Count-Min sketches "
+                       "(%d x 2^%d x u64), top-k mode %s" % (n, L, ref.depth, ref.wl2, "candidates" if cand else "exact")}
+    t_all = time.perf_counter()
+    with fa.FlowAgg(framed=True, key_sets=7, cms_depth=ref.depth, cms_width_log2=ref.wl2, cms_seed=ref.seed, topk_capacity_log2=16 if cand else L + 2,
+                    max_batch_records=chunk, topk_mode=fa.TOPK_CANDIDATES if cand else fa.TOPK_EXACT) as agg:
+        cap = chunk * 96 + 4096
+        d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(chunk + 1, dtype=torch.int32, device=dev)
+        wire = 0
+        series, prev = [], 0
+        for i0 in range(0, n, chunk):
+            m = min(chunk, n - i0)
+            w = agg.mock_generate_device(mp, i0, m, d_buf.data_ptr(), cap, d_off.data_ptr())
+            agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
+            agg.sync()  # (the one generator buffer is reused)
+            ns = agg.stats()["batch_ns_total"]
+            series.append((ns - prev) * 1e-6)
+            prev = ns
+            wire += w
+        st = agg.stats()
+        sk = [agg.cms_read(k).reshape(-1) for k in KS]
+        tops = [agg.topk(k, 100) for k in KS]  # (the first read pays the buffers)
+        tk = []
+        for k in KS:
+            for _ in range(3):
+                t = time.perf_counter()
+                agg.topk(k, 100)
+                tk.append((time.perf_counter() - t) * 1e3)
+        rows = agg.read_window()
+    launches = int(st["kernel_launches"])
+    path_s = st["batch_ns_total"] * 1e-9
+    steady = series[len(series) // 2:]  # (the sets fill up during the first launches)
+    out.update({
+        "records": n, "wire_bytes": wire, "launches": launches,
+        "path_ms_per_launch": path_s / launches * 1e3, "frac": wire / path_s / (HBM_PEAK_GBS * 1e9),
+        "path_ms_per_launch_second_half": float(np.mean(steady)), "frac_second_half": wire / launches / (float(np.mean(steady)) * 1e-3) / (HBM_PEAK_GBS * 1e9),
+        "records_per_s_device_path": n / path_s, "path_ms_series": [round(x, 4) for x in series],
+        "topk100_ms_per_call": [round(v, 3) for v in tk], "topk100_ms_median": float(np.median(tk)),
+        "sketches_bit_exact": bool(np.array_equal(sk[0], ref.c_src) and np.array_equal(sk[1], ref.c_dst)),
+        "top100_equals_ranking_of_the_whole_universe": bool(ref.tops_ok(tops)),
+        "rollup_count_equals_records": bool(int(rows["count"].sum()) == n and st["records_ok"] == n and st["records_bad"] == 0),
+    })
+    out["ok"] = bool(out["sketches_bit_exact"] and out["top100_equals_ranking_of_the_whole_universe"] and out["rollup_count_equals_records"])
+    out["seconds"] = time.perf_counter() - t_all
+    return out
+
+
+def sec_config5(fa, po, torch, dev, n=100_000_000, chunk=16_666_667, span=1800):
+    """BASELINE configs[4], single-GPU shape: flows_5m + (SrcAddr,DstPort,Proto) over 60-s sub-buckets, Zipf-0.8, seed 5.  Ingest
+    fraction AND close times of the SAME run (48-byte rows into a page-locked buffer - what the consumer keeps).  Parity: every
+    aligned flows_5m window against the C oracle's rollup (checksum of keys and sums, row count); one SLIDING window byte for
+    byte; every (SrcAddr,DstPort,Proto) window: strictly ascending keys (every key once) and the linear checksum of its rows ==
+    the oracle's over the window's records (oracle/flow_oracle.h fo_app_checksum_stream), count() == the window's records."""
+    threads = max(1, min(64, effective_cpus()[0]))
+    mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=5, n_total=n, span_secs=span, zipf_log2_universe=24, zipf_s_x100=80)
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=5, n_total=n, span_secs=span, zipf_log2_universe=24, zipf_s_x100=80)
+    ks = fa.FA_KEYS_AS_PAIR | fa.FA_KEYS_ADDR_PORT_PROTO
+    out = {"workload": "BASELINE configs[4], single-GPU shape: (SrcAS,DstAS) + (SrcAddr,DstPort,Proto), 60-s sub-buckets, 5-min windows, %d framed "
+                       "FlowMessages, Zipf-0.8, seed 5, %d s of event time" % (n, span)}
+    t_all = time.perf_counter()
+    with fa.FlowAgg(framed=True, key_sets=ks, window_secs=300, subwindow_secs=60, wide_capacity_log2=26, table_capacity_log2=24, max_batch_records=chunk) as agg:
+        cap = chunk * 96 + 4096
+        d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+        d_off = torch.empty(chunk + 1, dtype=torch.int32, device=dev)
+        wire = 0
+        for i0 in range(0, n, chunk):
+            m = min(chunk, n - i0)
+            w = agg.mock_generate_device(mp, i0, m, d_buf.data_ptr(), cap, d_off.data_ptr())
+            agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
+            agg.sync()
+            wire += w
+        st = agg.stats()
+        del d_buf, d_off
+        launches = int(st["kernel_launches"])
+        path_s = st["batch_ns_total"] * 1e-9
+        out.update({"records": n, "wire_bytes": wire, "launches": launches, "path_ms_per_launch": path_s / launches * 1e3,
+                    "frac": wire / path_s / (HBM_PEAK_GBS * 1e9), "records_per_s_device_path": n / path_s})
+        ok_ing = st["records_ok"] == n and st["records_bad"] == 0
+        aligned = [fa.T0 + 300 * k for k in range((span + 299) // 300)]
+        wins = [agg.read_window(ts) for ts in aligned]
+        allrows = np.concatenate(wins)
+        ref = po.bench_rollup(gp, 0, n, threads)
+        out["flows_5m_rows"] = int(len(allrows))
+        out["flows_5m_aligned_windows_bit_exact"] = bool(ref["bad"] == 0 and ref["groups"] == len(allrows) and rows_checksum(allrows) == ref["checksum"]
+                                                       and int(allrows["count"].sum()) == n and ok_ing)
+        # one sliding window [t0 + 420, t0 + 720): byte for byte against the oracle's rollup of exactly its records
+        start = fa.T0 + 420
+        got = agg.read_window(start)
+        ia = -(-(start - fa.T0) * n // span)
+        ib = -(-(start + 300 - fa.T0) * n // span)
+        part = po.bench_rollup_ex(gp, ia, ib - ia, threads, want_rows=True)["rows"]  # rows per ALIGNED timeslot: folded into the window below
+        key = np.stack([part[c].astype(np.uint64) for c in ("src_as", "dst_as", "etype")], axis=1)
+        order = np.lexsort((key[:, 2], key[:, 1], key[:, 0]))
+        part, key = part[order], key[order]
+        first = np.ones(len(part), dtype=bool)
+        first[1:] = (key[1:] != key[:-1]).any(axis=1)
+        starts = np.nonzero(first)[0]
+        folded = part[starts].copy()
+        with np.errstate(over="ignore"):
+            for c in ("bytes", "packets", "count"):
+                folded[c] = np.add.reduceat(part[c], starts)
+        folded["timeslot"], folded["date"] = start, start // 86400
+        out["sliding_window_rows"] = int(len(got))
+        out["sliding_window_bit_exact"] = bool(got.tobytes() == folded.tobytes())
+        # (SrcAddr,DstPort,Proto): read every aligned window, then close them oldest first - 48-byte rows, page-locked buffer
+        want_sum, want_cnt, outside = po.app_checksum_stream(gp, 0, n, threads, 300, fa.T0, len(aligned))
+        nreuse = int(st["wide_used"] + st["wide_log_records"]) // max(len(aligned) - 1, 1) + (1 << 20)
+        reuse = fa.FlowAgg.pinned_rows(fa.ROWS_APP, nreuse).view(np.uint8)[:nreuse * 48].view(fa.ROW_APP48_DTYPE)
+        read_ms, close_ms, app_ok, nrows = [], [], outside == 0, 0
+        for i, ts in enumerate(aligned):
+            t = time.perf_counter()
+            app, date = agg.read_window_app48(ts, out=reuse)
+            read_ms.append((time.perf_counter() - t) * 1e3)
+            nrows += len(app)
+            app_ok = app_ok and date == ts // 86400 and int(app["count"].sum()) == int(want_cnt[i]) and po.app_rows_checksum(app, timeslot=ts) == int(want_sum[i]) \
+                and po.app_rows_strictly_ascending(app)
+        sums = []
+        for i, ts in enumerate(aligned):
+            t = time.perf_counter()
+            app, _ = agg.read_window_app48(ts, out=reuse)
+            agg.drop_range(fa.ROWS_APP, ts, ts + 300)  # (a tumbling consumer: the window's five sub-buckets in one pass)
+            close_ms.append((time.perf_counter() - t) * 1e3)
+            sums.append((len(app), int(app["count"].sum())))
+            app_ok = app_ok and int(app["count"].sum()) == int(want_cnt[i])
+        left = len(agg.read_window_app())
+    out.update({"app_rows": nrows, "app_windows_bit_exact_by_linear_checksum_and_strict_order": bool(app_ok),
+                "read_app_window_ms": [round(x, 2) for x in read_ms], "close_app_window_ms": [round(x, 2) for x in close_ms],
+                "close_ms_median": float(np.median(close_ms)), "close_ms_first": close_ms[0],
+                "row_format": "fa_row_app48 into a page-locked buffer (one copy-engine transfer per half window)",
+                "app_rows_left_after_all_closes": int(left)})
+    out["ok"] = bool(out["flows_5m_aligned_windows_bit_exact"] and out["sliding_window_bit_exact"] and app_ok and left == 0)
+    out["seconds"] = time.perf_counter() - t_all
+    return out
+
+
+def sec_group8(fa, po, torch, dev, ref, members=8, chunk=8_333_334, cand=True):
+    """8 contexts in ONE process (the reference consumer's shape: a goroutine per claimed partition, inserter.go:167-196) on this
+    box's one GPU, each its partition of the configs[2]/[3] stream with flows_5m + both sketches + (SrcAddr,DstPort,Proto); the
+    windows of the whole topic closed through fa_group_*: flows_5m merged, (SrcAddr,DstPort,Proto) hash-partitioned, sketches
+    all-reduced, top-100.  What one GPU cannot show: xGMI (the peer copies are device copies here)."""
+    n, nm, L = ref.n, members, ref.L
+    threads = ref.threads
+    mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=3, n_total=n, span_secs=1800, zipf_log2_universe=L, zipf_s_x100=110)
+    ks = fa.FA_KEYS_AS_PAIR | fa.FA_KEYS_SRCADDR_CMS | fa.FA_KEYS_DSTADDR_CMS | fa.FA_KEYS_ADDR_PORT_PROTO
+    out = {"workload": "BASELINE configs[3] + [4] shapes through fa_group_* on one GPU: %d contexts in one process, %d-record Zipf-1.1 stream (seed 3, 1800 s), "
+                       "key sets flows_5m + both sketches + (SrcAddr,DstPort,Proto); top-k mode %s" % (nm, n, "candidates" if cand else "exact")}
+    t_all = time.perf_counter()
+    kw = dict(framed=True, key_sets=ks, cms_depth=ref.depth, cms_width_log2=ref.wl2, cms_seed=ref.seed, max_batch_records=chunk, wide_capacity_log2=24, table_capacity_log2=22,
+              topk_capacity_log2=16 if cand else L + 1, topk_mode=fa.TOPK_CANDIDATES if cand else fa.TOPK_EXACT)
+    ms = [fa.FlowAgg(**kw) for _ in range(nm)]
+    try:
+        with fa.FlowGroup(ms) as g:  # (the group exists while its members ingest: they reserve their exchange buffers as their rows come into being)
+            cap = chunk * 96 + 4096
+            d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+            d_off = torch.empty(chunk + 1, dtype=torch.int32, device=dev)
+            wire = 0
+            for c, i0 in enumerate(range(0, n, chunk)):  # chunk c belongs to partition c % members (every partition spans the whole time range)
+                m = min(chunk, n - i0)
+                agg = ms[c % nm]
+                w = agg.mock_generate_device(mp, i0, m, d_buf.data_ptr(), cap, d_off.data_ptr())
+                agg.ingest_device(d_buf.data_ptr(), w, d_off.data_ptr(), m)
+                agg.sync()
+                wire += w
+            del d_buf, d_off
+            st = g.stats()
+            ok_ing = st["records_ok"] == n and st["records_bad"] == 0
+            out.update({"records": n, "wire_bytes": wire, "members": nm, "device_path_ms_sum_over_members": st["batch_ns_total"] * 1e-6,
+                        "frac_ingest_sum_over_members": wire / (st["batch_ns_total"] * 1e-9) / (HBM_PEAK_GBS * 1e9)})
+            slots = [int(t) for t in g.open_timeslots()]
+            t = time.perf_counter()
+            wins = [g.read_window(fa.ROWS_5M, ts, cap=1 << 20) for ts in slots]
+            out["read_5m_window_merged_ms_mean"] = 1e3 * (time.perf_counter() - t) / max(len(slots), 1)
+            allrows = np.concatenate(wins)
+            want_sum, want_cnt, outside = po.app_checksum_stream(ref.gp, 0, n, threads, 300, slots[0], (slots[-1] - slots[0]) // 300 + 1)
+            app_ms, app_ok, nrows, buf_rows = [], outside == 0, 0, 1 << 22
+            for ts in slots:
+                t = time.perf_counter()
+                rows, shares = g.read_window_partitioned(fa.ROWS_APP, ts, cap=buf_rows)
+                app_ms.append((time.perf_counter() - t) * 1e3)
+                buf_rows = max(buf_rows, len(rows) + (1 << 16))
+                nrows += len(rows)
+                k = (ts - slots[0]) // 300
+                bounds = np.cumsum([0] + shares)
+                samp = np.arange(len(rows))[::211]
+                owner = fa.dist.partition_rows_host(rows[::211], fa.ROWS_APP, nm)
+                app_ok = app_ok and int(rows["count"].sum()) == int(want_cnt[k]) and po.app_rows_checksum(rows) == int(want_sum[k]) \
+                    and all(po.app_rows_strictly_ascending(rows[bounds[r]:bounds[r + 1]]) for r in range(nm)) \
+                    and bool((np.searchsorted(bounds, samp, side="right") - 1 == owner).all())
+            out["read_app_window_partitioned_ms"] = [round(x, 1) for x in app_ms]
+            out["read_app_window_partitioned_ms_median"] = float(np.median(app_ms))
+            out["read_app_first_over_median"] = app_ms[0] / float(np.median(app_ms))
+            t = time.perf_counter()
+            g.allreduce_sketches()
+            out["allreduce_both_sketches_ms"] = 1e3 * (time.perf_counter() - t)
+            sk = [ms[nm - 1].cms_read(k).reshape(-1) for k in (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS)]  # any member: the merged view
+            t = time.perf_counter()
+            tops = [g.topk(k, 100) for k in (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS)]
+            out["topk100_both_sketches_first_ms"] = 1e3 * (time.perf_counter() - t)
+            t = time.perf_counter()
+            tops2 = [g.topk(k, 100) for k in (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS)]
+            out["topk100_both_sketches_again_ms"] = 1e3 * (time.perf_counter() - t)
+            t = time.perf_counter()
+            closed = g.close_window(fa.ROWS_5M, slots[0], cap=1 << 20)
+            closed_app, _ = g.close_window_partitioned(fa.ROWS_APP, slots[0], cap=buf_rows)
+            out["close_oldest_window_both_key_sets_ms"] = 1e3 * (time.perf_counter() - t)
+            left = g.read_window(fa.ROWS_5M, cap=1 << 22)
+            out["table_bytes_per_member"] = {"distinct_address_sets": 2 * 32 << (16 if cand else L + 1), "sketches": 2 * 8 * ref.depth << ref.wl2}
+    finally:
+        for m in ms:
+            m.close()
+    r5 = po.bench_rollup_ex(ref.gp, 0, n, threads, groups_hint=len(allrows))
+    out["flows_5m_rows"], out["app_rows"] = int(len(allrows)), nrows
+    out["flows_5m_merged_equals_oracle_rollup_of_all_partitions"] = bool(r5["bad"] == 0 and r5["groups"] == len(allrows) and r5["checksum"] == rows_checksum(allrows)
+                                                                           and int(allrows["count"].sum()) == n and ok_ing)
+    out["closed_window_equals_its_read"] = bool(closed.tobytes() == wins[0].tobytes() and int(left["count"].sum()) == n - int(closed["count"].sum())
+                                                and int(closed_app["count"].sum()) == int(want_cnt[0]))
+    out["app_windows_bit_exact_by_linear_checksum_and_strict_order"] = bool(app_ok)
+    out["merged_sketches_bit_exact"] = bool(np.array_equal(sk[0], ref.c_src) and np.array_equal(sk[1], ref.c_dst))
+    out["top100_equals_ranking_of_the_whole_universe"] = bool(ref.tops_ok(tops) and tops[0].tobytes() == tops2[0].tobytes() and tops[1].tobytes() == tops2[1].tobytes())
+    out["ok"] = bool(out["flows_5m_merged_equals_oracle_rollup_of_all_partitions"] and out["closed_window_equals_its_read"] and app_ok
+                     and out["merged_sketches_bit_exact"] and out["top100_equals_ranking_of_the_whole_universe"])
+    out["seconds"] = time.perf_counter() - t_all
+    return out
+
+
+def sec_host_consume(fa, po, torch, dev, n=64_000_000, nparts=8, flush_count=262144):
+    """The C++ consumer (flow-pipeline_amd/host/inserter_gpu: the reference's ConsumeClaim / flush / MarkMessage shape,
+    inserter.go:113-196, one thread per claimed partition, ONE process) on BASELINE config 2's stream: 8 partition logs, key set
+    flows_5m.  `value` = records / the consume phase (every partition thread from its first message to its last flush; log
+    mapping, context setup and the last window close are reported beside it).  Parity: its RowBinary output decoded == the C
+    oracle's rollup of ALL partitions (row count, checksum of keys and sums), insert_count == records."""
+    import shutil
+    import subprocess
+    import tempfile
+    host = os.path.join(ROOT, "flow-pipeline_amd", "host")
+    exe = os.path.join(host, "inserter_gpu")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", host], stdout=subprocess.DEVNULL)
+    out = {"workload": "inserter_gpu (C++ host, one process, %d partition threads) on BASELINE configs[1]'s stream: %d framed FlowMessages in %d partition logs, "
+                       "key set flows_5m, -flush.count %d" % (nparts, n, nparts, flush_count)}
+    t_all = time.perf_counter()
+    mp = fa.mock_params(mode=fa.MOCK_ASPAIRS, framed=1, seed=2, n_total=n, span_secs=900, per_sec=400_000)
+    gp = po.gen_params(mode=po.GEN_ASPAIRS, framed=1, seed=2, n_total=n, span_secs=900, per_sec=400_000)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > n * 96 + (1 << 30) else "/tmp"
+    tmp = tempfile.mkdtemp(prefix="fa_bench_logs_", dir=base)
+    try:
+        # partition p = records [p * n / parts, (p + 1) * n / parts): generated in HBM (the product's generator), written as the log
+        # of message values back to back (-proto.fixedlen=true: every value carries its length prefix, mocker.go:98-101)
+        per = n // nparts
+        paths = []
+        wire = 0
+        t = time.perf_counter()
+        with fa.FlowAgg(device=dev.index or 0, framed=True) as gen:
+            cap = per * 96 + 4096
+            d_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+            d_off = torch.empty(per + 1, dtype=torch.int32, device=dev)
+            for p in range(nparts):
+                m = per if p < nparts - 1 else n - per * (nparts - 1)
+                w = gen.mock_generate_device(mp, p * per, m, d_buf.data_ptr(), cap, d_off.data_ptr())
+                path = os.path.join(tmp, "p%d.log" % p)
+                d_buf[:w].cpu().numpy().tofile(path)
+                paths.append(path)
+                wire += w
+            del d_buf, d_off
+        out["generate_logs_s"] = time.perf_counter() - t
+        out["logs_dir"] = base
+        rb, met, ph = (os.path.join(tmp, x) for x in ("flows_5m.rowbinary", "metrics.txt", "phases.json"))
+        t = time.perf_counter()
+        r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-flush.count=%d" % flush_count, "-flush.dur=1h", "-key.sets=1", "-out.rowbinary=" + rb,
+                            "-metrics.dump=" + met, "-phases.out=" + ph, "-gpu.devices=1", "-gpu.table.log2=20", "-loglevel=info"], capture_output=True, text=True)
+        out["host_wall_s"] = time.perf_counter() - t
+        if r.returncode != 0:
+            out.update({"ok": False, "error": r.stderr[-1500:]})
+            return out
+        phases = json.load(open(ph))
+        metrics = {l.split()[0]: int(l.split()[1]) for l in open(met) if not l.startswith("#")}
+        rows = fa.rowbinary_to_rows_fast(np.fromfile(rb, dtype=np.uint8))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    threads = max(1, min(64, effective_cpus()[0]))
+    ref = po.bench_rollup_ex(gp, 0, n, threads, groups_hint=len(rows))
+    parts = phases["partitions"]
+    out.update({
+        "records": n, "wire_bytes": wire, "value": n / phases["consume_s"], "unit": "FlowMessages/s (consume phase)",
+        "wire_GBps_consume": wire / phases["consume_s"] / 1e9, "consume_s": phases["consume_s"], "setup_s": phases["setup_s"], "finish_s": phases["finish_s"],
+        "records_per_s_wall_of_the_process": n / out["host_wall_s"],
+        "phases_mean_per_partition_thread_s": {k: float(np.mean([p[k] for p in parts])) for k in ("take_s", "fa_ingest_s", "lock_wait_s", "mark_s", "close_s")},
+        "batches": int(sum(p["batches"] for p in parts)), "copied_bytes": int(sum(p["copied_bytes"] for p in parts)),
+        "insert_count_equals_records": bool(metrics.get("insert_count") == n),
+        "rowbinary_equals_oracle_rollup_of_all_partitions": bool(ref["bad"] == 0 and ref["groups"] == len(rows) and ref["checksum"] == rows_checksum(rows)
+                                                                     and int(rows["count"].sum()) == n),
+        "flows_5m_rows": int(len(rows)), "phases_by_partition": parts,
+    })
+    out["ok"] = bool(out["insert_count_equals_records"] and out["rowbinary_equals_oracle_rollup_of_all_partitions"])
+    out["seconds"] = time.perf_counter() - t_all
+    return out
+
+
+def run_secondary(fa, po, torch, dev, args):
+    """Every block on its own: a failing block reports {"ok": false, "error": ...}, the others still run."""
+    import traceback
+    sec = {}
+    t0 = time.perf_counter()
+
+    def guard(name, fn, *a, **kw):
+        if time.perf_counter() - t0 > args.secondary_budget:
+            sec[name] = {"ok": False, "skipped": "the secondary blocks' time budget (%d s) was spent" % args.secondary_budget}
+            return
+        try:
+            sec[name] = fn(*a, **kw)
+        except Exception as e:  # noqa: BLE001 - reported in the line, never fatal for the headline
+            sec[name] = {"ok": False, "error": "%s: %s" % (type(e).__name__, e), "traceback": traceback.format_exc()[-1200:]}
+        torch.cuda.empty_cache()
+
+    guard("host_consume", sec_host_consume, fa, po, torch, dev, n=args.secondary_host_records)
+    guard("config5", sec_config5, fa, po, torch, dev, n=args.secondary_config5_records)
+    ref = None
+    try:
+        ref = _Zipf3(po, args.secondary_config3_records)
+        sec["zipf_stream_cpu_side_seconds"] = ref.seconds
+    except Exception as e:  # noqa: BLE001
+        sec["zipf_stream_cpu_side_error"] = "%s: %s" % (type(e).__name__, e)
+    if ref is not None:
+        guard("config3_exact", sec_config3, fa, po, torch, dev, ref, False)
+        guard("config3_candidates", sec_config3, fa, po, torch, dev, ref, True)
+        guard("group8", sec_group8, fa, po, torch, dev, ref)
+    else:
+        for k in ("config3_exact", "config3_candidates", "group8"):
+            sec[k] = {"ok": False, "error": "the CPU side of the Zipf stream failed"}
+    sec["seconds"] = time.perf_counter() - t0
+    sec["ok"] = all(sec[k].get("ok") for k in ("config3_exact", "config3_candidates", "config5", "group8", "host_consume"))
+    return sec
+
+
+def group_preflight_body():
+    """Runs in a process of its own (`bench.py --group-preflight-only`, started by rank 0 at N > 1 with a timeout): ONE process, a
+    small ctx on EVERY visible device - the shape of the consumer the reference defines (inserter.go:167-196, :176; shard unit
+    compose/docker-compose-clickhouse-mock.yml:18) - known partitions in, and the in-process window close of the whole topic
+    through fa_group_* with both transports (peer copies over xGMI; ncclCommInitAll + grouped ncclAllReduce) against the oracle:
+    all-reduced sketches, top-k, flows_5m rows merged, (SrcAddr,DstPort,Proto) rows hash-partitioned, a real close."""
+    import torch
+    fa = _pkg.load()
+    po = _pkg.load_oracle()
+    ndev = torch.cuda.device_count()
+    res = {"devices": ndev, "ok": False}
+    res["can_access_peer"] = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(ndev)] for i in range(ndev)]
+    n, L, depth, wl2, seed = 30_000 * max(ndev, 1), 12, 4, 14, 0x5EED
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=77, n_total=n, zipf_log2_universe=L, span_secs=600)
+    buf, off = po.gen_records(gp, 0, n)
+    raw = bytes(buf)
+    parts = []
+    for p in range(ndev):  # record i belongs to Kafka partition i % devices
+        recs = [raw[int(off[k]):int(off[k + 1])] for k in range(p, n, ndev)]
+        o = np.zeros(len(recs) + 1, dtype=np.uint64)
+        o[1:] = np.cumsum([len(r) for r in recs])
+        parts.append((np.frombuffer(b"".join(recs), dtype=np.uint8), o))
+    rows, status = po.decode_batch(buf, off, 1)
+    ref = po.Rollup(300)
+    assert ref.ingest(buf, off, 1) == 0
+    want5 = ref.rows()
+    want_app = po.rollup_app(rows, status)
+    with np.errstate(over="ignore"):
+        w = rows["bytes"] * rows["sampling_rate"]
+    want_sk, want_top = {}, {}
+    for col, ks in (("src_addr", fa.FA_KEYS_SRCADDR_CMS), ("dst_addr", fa.FA_KEYS_DSTADDR_CMS)):
+        sk = po.cms_sketch_numpy(rows[col], w, depth, wl2, seed)
+        keys = np.unique(np.ascontiguousarray(rows[col]), axis=0)
+        est = po.cms_estimates_numpy(sk, keys, depth, wl2, seed)
+        want_sk[ks] = sk.reshape(-1)
+        want_top[ks] = sorted(zip((-est.astype(object)).tolist(), [bytes(k) for k in keys]))[:50]
+
+    def sorted_app(r):
+        addr = np.ascontiguousarray(r["src_addr"])
+        hi = addr[:, :8].copy().view(">u8").reshape(-1)
+        lo = addr[:, 8:].copy().view(">u8").reshape(-1)
+        return r[np.lexsort((r["proto"], r["dst_port"], lo, hi, r["timeslot"], r["date"]))]
+
+    all_ok = True
+    for name, transport in (("peer", fa.GROUP_PEER), ("rccl", fa.GROUP_RCCL)):
+        t0 = time.perf_counter()
+        r = {}
+        members = []
+        try:
+            members = [fa.FlowAgg(device=d, framed=True, key_sets=15, cms_depth=depth, cms_width_log2=wl2, cms_seed=seed, topk_capacity_log2=L + 3) for d in range(ndev)]
+            for m, (b, o) in zip(members, parts):
+                m.ingest(b, o)
+            with fa.FlowGroup(members, transport) as g:
+                r["transport"] = "rccl" if g.transport == fa.GROUP_RCCL else "peer"
+                g.allreduce_sketches()
+                r["allreduce_sketches"] = bool(all(np.array_equal(m.cms_read(ks).reshape(-1), want_sk[ks]) for m in members for ks in want_sk))
+                r["topk"] = bool(all([(bytes(x["key"]), int(x["weight"])) for x in g.topk(ks, 50)] == [(k, -e) for e, k in want_top[ks]] for ks in want_top))
+                r["read_window_5m"] = bool(g.read_window(fa.ROWS_5M).tobytes() == want5.tobytes())
+                got, shares = g.read_window_partitioned(fa.ROWS_APP)
+                owner = fa.dist.partition_rows_host(got, fa.ROWS_APP, ndev)
+                r["read_window_app_partitioned"] = bool(sorted_app(got).tobytes() == want_app.tobytes() and owner.tolist() == np.repeat(np.arange(ndev), shares).tolist())
+                ts0 = int(g.open_timeslots()[0])
+                r["close_window_5m"] = bool(g.close_window(fa.ROWS_5M, ts0).tobytes() == want5[want5["timeslot"] == ts0].tobytes()
+                                            and g.read_window(fa.ROWS_5M).tobytes() == want5[want5["timeslot"] != ts0].tobytes())
+                got, _ = g.close_window_partitioned(fa.ROWS_APP, ts0)
+                r["close_window_app_partitioned"] = bool(sorted_app(got).tobytes() == want_app[want_app["timeslot"] == ts0].tobytes()
+                                                         and sorted_app(g.read_window_partitioned(fa.ROWS_APP)[0]).tobytes() == want_app[want_app["timeslot"] != ts0].tobytes())
+            r["ok"] = all(v for k, v in r.items() if k != "transport")
+        except Exception as e:  # noqa: BLE001 - reported: which transport, which step
+            r["ok"] = False
+            r["error"] = "%s: %s" % (type(e).__name__, e)
+            if name == "rccl" and ndev < 2 and "UNSUPPORTED" in str(e):
+                r["ok"] = None  # (one device: FA_GROUP_RCCL needs a GPU per member - nothing to check here)
+        finally:
+            for m in members:
+                m.close()
+        r["seconds"] = time.perf_counter() - t0
+        res[name] = r
+        all_ok = all_ok and r["ok"] is not False
+    res["ok"] = bool(all_ok)
+    print("GROUP_PREFLIGHT " + json.dumps(res))
+
+
+def group_preflight(timeout_s=240):
+    """Rank 0, N > 1: the in-process group close on every visible device, in a process of its own (a hang or a crash of the first
+    multi-device run of fa_group_* must not take the bench with it).  Reported in the line, never fatal."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    if os.environ.get("FA_BENCH_SHARE_GPU"):
+        env["FA_GROUP_PREFLIGHT_NOTE"] = "dry run on a shared GPU"
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--group-preflight-only"], env=env, capture_output=True, text=True, timeout=timeout_s)
+        for line in r.stdout.splitlines():
+            if line.startswith("GROUP_PREFLIGHT "):
+                res = json.loads(line[len("GROUP_PREFLIGHT "):])
+                break
+        else:
+            res = {"ok": False, "error": "no result (exit code %d)" % r.returncode, "stderr_tail": r.stderr[-1500:]}
+    except subprocess.TimeoutExpired as e:
+        res = {"ok": False, "error": "timed out after %d s (killed)" % timeout_s, "stderr_tail": (e.stderr or b"")[-1500:].decode(errors="replace") if isinstance(e.stderr, bytes) else str(e.stderr)[-1500:]}
+    res["seconds_with_process_start"] = time.perf_counter() - t0
+    return res
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (the driver's N=1
     command shape with another N must not die at argument parsing).  One rank per GPU over RCCL; on a box with fewer
@@ -343,7 +870,18 @@ def main():
                     "(default: weak - every rank is a Kafka partition with --records of its own)")
     ap.add_argument("--strict-preflight", action="store_true", help="world > 1: a failing preflight aborts the run (default: reported in the line, the run goes on)")
     ap.add_argument("--no-preflight", action="store_true", help="world > 1: skip the check of the three window-close exchanges on known data")
+    ap.add_argument("--group-preflight-only", action="store_true", help="(internal) run the in-process group close on every visible device and print its result")
+    ap.add_argument("--no-group-preflight", action="store_true", help="world > 1: skip rank 0's in-process fa_group_* check on every visible device")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the secondary blocks (configs 3 and 5, the 8-context group close, the C++ consumer)")
+    ap.add_argument("--secondary-budget", type=int, default=240, help="seconds after which no further secondary block is started")
+    ap.add_argument("--secondary-config3-records", type=int, default=200_000_000)
+    ap.add_argument("--secondary-config5-records", type=int, default=100_000_000)
+    ap.add_argument("--secondary-host-records", type=int, default=64_000_000)
+    ap.add_argument("--settle-max-steps", type=int, default=400, help="untimed settle phase: at most this many steps (it ends when two consecutive steps agree within 1 %%)")
     args = ap.parse_args()
+    if args.group_preflight_only:
+        group_preflight_body()
+        return
 
     import torch
     import torch.distributed as dist
@@ -381,6 +919,13 @@ def main():
     pre = None
     if world > 1 and not args.no_preflight:
         pre = preflight(fa, torch, dist, rank, world, local_rank, backend, xdev, strict=args.strict_preflight)
+    gpre = None
+    if world > 1 and not args.no_group_preflight:
+        # the product's OTHER multi-GPU form - one process, a ctx per device, fa_group_* - has never run on more than one device:
+        # rank 0 runs it on every visible device in a process of its own while the other ranks wait
+        if rank == 0:
+            gpre = group_preflight()
+        dist.barrier()
     # every rank = one Kafka partition with its own stream (seed 2 = config 2, + rank)
     mp = fa.mock_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000,
                         zipf_s_x100=args.zipf_s, zipf_log2_universe=args.zipf_universe_log2)
@@ -423,6 +968,25 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def timed_step():
+        t = time.perf_counter()
+        step()
+        fence()
+        return (time.perf_counter() - t) * 1e3
+
+    # Untimed settle phase: a fresh box idles at sclk 155 MHz and the timed region is 40 ms - steps run (each with its own
+    # fence) until two consecutive ones agree within 1 % (and at least 8: the first steps also size segment buffers and learn
+    # the stream), at most --settle-max-steps.  N > 1: every rank runs the same number (the slowest rank's criterion).
+    settle_ms = []
+    for i in range(max(args.settle_max_steps, 0)):
+        settle_ms.append(timed_step())
+        done = len(settle_ms) >= 8 and abs(settle_ms[-1] - settle_ms[-2]) <= 0.01 * settle_ms[-1]
+        if world > 1:
+            t = torch.tensor([0 if done else 1], dtype=torch.int64, device=xdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            done = int(t.item()) == 0
+        if done:
+            break
     for _ in range(args.warmup):
         step()
     fence()
@@ -433,6 +997,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     st1 = agg.stats()
+    # the same K steps once more, each with its own fence (sync overhead included: ~20 us of a 2 ms step) - not `value`
+    per_step_ms = [timed_step() for _ in range(args.steps)]
+    extra_steps = len(settle_ms) + len(per_step_ms)
     if clocks is not None:
         clocks["end"] = gpu_clocks(local_rank)
     if world > 1:
@@ -450,6 +1017,10 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step_median": float(np.median(per_step_ms)) if per_step_ms else None,
+        "ms_per_step_all": [round(x, 4) for x in per_step_ms],
+        "settle": {"steps": len(settle_ms), "first_ms": round(settle_ms[0], 4) if settle_ms else None, "last_ms": round(settle_ms[-1], 4) if settle_ms else None,
+                   "rule": "untimed steps until two consecutive ones agree within 1 % (>= 8, <= --settle-max-steps)"},
         "higher_is_better": True,
         "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None,
@@ -512,7 +1083,7 @@ def main():
         else:
             topk_rows = agg.topk(fa.FA_KEYS_SRCADDR_CMS, 100)
             topk_note = "exact ranking of this rank's sketch over its distinct-address set"
-    total_steps = args.warmup + args.steps
+    total_steps = args.warmup + args.steps + extra_steps
     ok_total = int(merged["count"].sum())
     expect = n_rec * total_steps * world
     assert args.no_assert or ok_total == expect, "merged count() %d != records ingested %d" % (ok_total, expect)
@@ -527,6 +1098,8 @@ def main():
         out["clocks"] = clocks
     if pre is not None:
         out["preflight"] = pre
+    if gpre is not None:
+        out["group_preflight"] = gpre
     out["config"] = {
         "workload": ("BASELINE configs[1]: 1xMI355X per rank, %d mocker-shaped framed FlowMessages, "
                      "64k SrcAS/DstAS pairs x 2 ETypes x 3 five-minute windows, sum(Bytes,Packets)+count() group-by" % n_rec)
@@ -668,9 +1241,13 @@ def main():
         out["host_fed"] = {"value": nh / dt, "unit": "FlowMessages/s", "wire_GBps": hb.nbytes / dt / 1e9,
                            "what": "fa_ingest from pageable host memory (%d records per call): multi-threaded copy into pinned "
                                    "staging + H2D over PCIe + kernels; link ceiling ~63 GB/s" % nh}
+    agg.close()
+    del chunks
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and default_workload and not args.no_secondary and not args.no_assert:
+        out["secondary"] = run_secondary(fa, _pkg.load_oracle(), torch, dev, args)
     if rank == 0:
         print(json.dumps(out))
-    agg.close()
     if world > 1:
         dist.destroy_process_group()
 

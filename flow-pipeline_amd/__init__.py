@@ -66,7 +66,8 @@ class Stats(C.Structure):
         "compact_tuple_launches", "records_misfit_compact", "decode_ns_total", "decode_launches",
         "records_late", "wide_log_chunks", "wide_log_bytes", "wide_log_records", "wide_log_recorded", "wide_log_folded",
         "wide_log_replayed", "wide_log_dropped", "wide_log_watermark_moves", "wide_log_nomem_folds", "wide_log_mode",
-        "topk_theta_src", "topk_theta_dst", "topk_candidates_src", "topk_candidates_dst", "learnt_order_launches")]
+        "topk_theta_src", "topk_theta_dst", "topk_candidates_src", "topk_candidates_dst", "learnt_order_launches",
+        "host_ingest_ns", "host_stage_wait_ns", "host_stage_copy_ns")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -334,6 +335,31 @@ def rowbinary_to_rows(blob: bytes) -> np.ndarray:
             raise ValueError("ETypeMap values differ from the scalar columns")
         out.append((date, ts, sa, da, arr[0], 0, b, pk, c))
     return np.array(out, dtype=ROW5M_DTYPE)
+
+
+_ROWBINARY_DTYPE = np.dtype([  # one flows_5m row of fa_rows_to_rowbinary (create.sh:70-90 column list), packed: 70 bytes
+    ("date", "<u2"), ("timeslot", "<u4"), ("src_as", "<u4"), ("dst_as", "<u4"),
+    ("n_etype", "u1"), ("m_etype", "<u4"), ("n_bytes", "u1"), ("m_bytes", "<u8"), ("n_packets", "u1"), ("m_packets", "<u8"), ("n_count", "u1"), ("m_count", "<u8"),
+    ("bytes", "<u8"), ("packets", "<u8"), ("count", "<u8")])
+assert _ROWBINARY_DTYPE.itemsize == 70
+
+
+def rowbinary_to_rows_fast(blob) -> np.ndarray:
+    """rowbinary_to_rows for large outputs (numpy, no Python loop): the rows of fa_rows_to_rowbinary all have the same shape
+    (one element per ETypeMap array) - anything else raises."""
+    b = np.frombuffer(blob, dtype=np.uint8) if isinstance(blob, (bytes, bytearray)) else np.ascontiguousarray(blob, dtype=np.uint8)
+    if b.size % 70:
+        raise ValueError("not a whole number of 70-byte flows_5m RowBinary rows")
+    r = b.view(_ROWBINARY_DTYPE)
+    if not ((r["n_etype"] == 1) & (r["n_bytes"] == 1) & (r["n_packets"] == 1) & (r["n_count"] == 1)).all():
+        raise ValueError("ETypeMap arrays hold exactly one element")
+    if not ((r["m_bytes"] == r["bytes"]) & (r["m_packets"] == r["packets"]) & (r["m_count"] == r["count"])).all():
+        raise ValueError("ETypeMap values differ from the scalar columns")
+    out = np.zeros(len(r), dtype=ROW5M_DTYPE)
+    for f in ("date", "timeslot", "src_as", "dst_as", "bytes", "packets", "count"):
+        out[f] = r[f]
+    out["etype"] = r["m_etype"]
+    return out
 
 
 class FlowAgg:
@@ -626,7 +652,7 @@ class FlowAgg:
 
 
 class FlowGroup:
-    """The window close of several contexts inside ONE process (ABI 7, fa_group_*): one FlowAgg per (Kafka partition, GPU),
+    """The window close of several contexts inside ONE process (ABI 7+, fa_group_*): one FlowAgg per (Kafka partition, GPU),
     results merged in HBM.  The multi-process twin is flow-pipeline_amd.dist (one rank per GPU under torchrun)."""
 
     def __init__(self, members, transport=GROUP_PEER):

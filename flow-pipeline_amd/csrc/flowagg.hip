@@ -12,7 +12,10 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -184,6 +187,11 @@ struct fa_ctx {
     void* part_buf = nullptr;        // fa_rows_partition_device: the rows grouped by destination rank
     size_t part_cap = 0;
     unsigned int* part_cnt = nullptr;  // [3][RPART_MAX_WORLD]: counts, starts, cursors
+    // fa_group_*: the buffer the group's exchange writes into (peer copies from the other members), owned by the ctx so that it
+    // can be reserved where the rows it will hold come into being (reserve_window_read) instead of inside the first close
+    void* xch_buf = nullptr;
+    size_t xch_cap = 0;
+    uint32_t group_members = 0;        // > 0 while the ctx is a member of a group (of that many contexts)
     void* h_rows = nullptr;          // pinned: rows on their way to the caller
     size_t h_rows_cap = 0;
     hipEvent_t copy_ev[2] = {nullptr, nullptr};  // the two halves of h_rows while a large result leaves in pieces (rows_host.inc)
@@ -574,6 +582,7 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->wl_scratch);
     (void)hipFree(c->part_buf);
     (void)hipFree(c->part_cnt);
+    (void)hipFree(c->xch_buf);
     if (c->h_rows) (void)hipHostFree(c->h_rows);
     (void)hipFree(c->cms_src);
     (void)hipFree(c->cms_dst);

@@ -428,7 +428,7 @@ struct TopkLds {
 // One scan of the set (modes):
 //   TK_HIST  estimates -> histogram of their bins; the estimate is left in the slot's spare word (KeySlot::pad) and the largest
 //            bin of every chunk of 64 slots in chunkmax - what topk_pick_kernel needs to find the selected rows without a second
-//            scan.  lb_bin > 0: a bin the k-th estimate is known to reach (the previous read's k-th row: estimates and sets only
+//            scan (stored as bin + 1; 0 = the chunk holds no estimated key).  lb_bin > 0: a bin the k-th estimate is known to reach (the previous read's k-th row: estimates and sets only
 //            grow) - a key whose ROW-0 counter already lies below it is counted in bin 0 and costs one cached read.
 //   TK_ONE   the rows whose bin is >= lb_bin, in one pass (no histogram): k = 0 reads (lb_bin = 0), and reads whose lb_bin is
 //            known - almost every key stops at its row-0 counter.
@@ -486,7 +486,7 @@ __device__ __forceinline__ void topk_scan_body(unsigned int* lh, TopkLds& L, uin
                 if (have) atomicAdd(&lh[bin], 1u);
                 if (full) {
                     ks[slot].pad = est;
-                    atomicMax(&L.wmax[wave][((slot - w0) / nthr) & (TK_U - 1)], bin);
+                    atomicMax(&L.wmax[wave][((slot - w0) / nthr) & (TK_U - 1)], bin + 1u);  // (bin + 1: 0 = no estimated key in the chunk)
                 }
             } else {
                 const bool sel = full && bin >= lb_bin;
@@ -529,7 +529,9 @@ __global__ __launch_bounds__(256) void topk_pick_kernel(const KeySlot* ks, uint3
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t cbase = wave * 64u; cbase < nchunks; cbase += nwaves * 64u) {
         const uint32_t cm = cbase + lane < nchunks ? chunkmax[cbase + lane] : 0u;
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(cm >= min_bin && cm != 0u);
+        // (chunkmax holds bin + 1: a chunk whose keys all estimate to 0 - zero-weight addresses, Bytes * SamplingRate == 0 - is not an
+        // empty chunk; with the threshold in bin 0 - fewer than k keys, or a k-th estimate of 0 - those rows are part of the answer)
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(cm > min_bin);
         while (todo != 0ull) {  // (wave-uniform)
             const uint32_t c = cbase + (uint32_t)__builtin_ctzll(todo);
             todo &= todo - 1ull;

@@ -24,7 +24,16 @@
 //     the GPUs, sketches all-reduced, top-k of the merged sketch.  Flushes (fa_ingest, one goroutine's ctx) hold a read
 //     lock, a close the write lock: a group call uses every member;
 //   - insert_count is actually incremented;
-//   - -gpu.table.log2 / -gpu.keyset.log2 / -gpu.wide.log2 size a context's tables (fa_config; 0 = the library's defaults).
+//   - -gpu.table.log2 / -gpu.keyset.log2 / -gpu.wide.log2 size a context's tables (fa_config; 0 = the library's defaults);
+//   - batches: -flush.count is the reference's trigger (inserter.go:118-120).  One fa_ingest is a PCIe transfer and a handful of
+//     kernel launches whatever its size, so while the claim has more messages READY (sarama: len(claim.Messages()) > 0) a batch
+//     that reached -flush.count keeps growing up to -gpu.batch.bytes (default 64 MiB; 0 = flush exactly at -flush.count);
+//     a consumer that has drained its claim flushes at once, and -flush.dur bounds the wait as in the reference (:189-191).
+//     Messages that lie back to back in the client's fetch buffer (a partition log does; a Kafka record batch's values do not,
+//     there are record headers between them) are handed over in place - fa_ingest copies into its pinned staging anyway;
+//   - -topk.mode exact|candidates (fa_config.topk_mode): candidates (64 k slots per set) is the default with more than one claimed
+//     partition - the exact mode's sets hold EVERY address (2 x 32 B x 2^-gpu.keyset.log2 per partition);
+//   - a key set without a sink (-key.sets includes 8, no -out.app) is closed all the same: its windows are dropped, not kept.
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -67,6 +76,11 @@ struct Flags {
     std::string OutApp, OutTopk, GpuTransport = "peer";  // raw fa_row_app records / "src|dst <hex key> <weight>" lines; peer | rccl
     long TopkK = 100;
     long TableLog2 = 0, KeysetLog2 = 0, WideLog2 = 0;  // fa_config capacities (0 = the library's defaults)
+    long BatchBytes = 64l << 20;   // -gpu.batch.bytes: how far a batch may grow beyond -flush.count while messages are ready (0: not at all)
+    std::string TopkMode = "auto"; // exact | candidates | auto (candidates with more than one claimed partition)
+    long TopkTrack = 0;            // fa_config.topk_track (0 = the library's default)
+    std::string PhasesOut;         // -phases.out: where the time of the consume loop went, per partition thread (JSON)
+    bool Prefault = true;          // -input.prefault: map partition logs with MAP_POPULATE (a Kafka client's fetch buffers are resident too)
     bool DryRun = false;  // test double for the host logic: batches are logged, nothing is computed
     bool CloseAllAtEnd = true;
 };
@@ -137,14 +151,14 @@ static Flags parse_flags(int argc, char** argv) {
         {"postgres.host", &f.PostgresHost}, {"postgres.dbname", &f.PostgresDbName}, {"input.files", &f.InputFiles},
         {"input.format", &f.InputFormat}, {"out.rowbinary", &f.OutRowBinary}, {"out.tsv", &f.OutTsv},
         {"offsets.out", &f.OffsetsOut}, {"metrics.dump", &f.MetricsDump}, {"out.app", &f.OutApp}, {"out.topk", &f.OutTopk},
-        {"gpu.transport", &f.GpuTransport}};
+        {"gpu.transport", &f.GpuTransport}, {"topk.mode", &f.TopkMode}, {"phases.out", &f.PhasesOut}};
     std::map<std::string, long*> ints = {
         {"flush.count", &f.FlushCount}, {"postgres.port", &f.PostgresPort}, {"gpu.devices", &f.GpuDevices},
         {"window.secs", &f.WindowSecs}, {"window.lag", &f.CloseLagSec},
         {"key.sets", &f.KeySets}, {"topk.k", &f.TopkK}, {"gpu.table.log2", &f.TableLog2}, {"gpu.keyset.log2", &f.KeysetLog2},
-        {"gpu.wide.log2", &f.WideLog2}};
+        {"gpu.wide.log2", &f.WideLog2}, {"gpu.batch.bytes", &f.BatchBytes}, {"topk.track", &f.TopkTrack}};
     std::map<std::string, bool*> bools = {{"proto.fixedlen", &f.ProtoFixed}, {"sink.dryrun", &f.DryRun},
-                                          {"window.closeall", &f.CloseAllAtEnd}};
+                                          {"window.closeall", &f.CloseAllAtEnd}, {"input.prefault", &f.Prefault}};
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         if (a.size() < 2 || a[0] != '-') fatal("unexpected argument %s", a.c_str());
@@ -204,9 +218,17 @@ class ConsumerGroupClaim {
 public:
     ConsumerGroupClaim(int32_t part, MappedLog log, bool len32) : part_(part), log_(log), len32_(len32) {}
     int32_t Partition() const { return part_; }
+    // more messages buffered on the client side, i.e. next() would not block (sarama: len(claim.Messages()) > 0)
+    bool ready() const { return pos_ < log_.size; }
     bool next(ConsumerMessage& m) {
         if (pos_ >= log_.size) return false;
         size_t start = pos_, len = 0;
+        if (!len32_ && log_.size - pos_ > 128 && !(log_[pos_] & 0x80)) {  // a one-byte length prefix, the whole message inside the log
+            len = 1 + (size_t)log_[pos_];
+            m = ConsumerMessage{part_, off_++, &log_[start], len};
+            pos_ = start + len;
+            return true;
+        }
         if (len32_) {
             if (log_.size - pos_ < 4) fatal("partition %d: truncated length prefix at byte %zu", part_, pos_);
             uint32_t l;
@@ -306,13 +328,48 @@ private:
 };
 
 // one aggregation context per claimed partition (fa_ctx is not thread-safe; distinct ctxs are independent)
+struct Phases {  // seconds of one partition thread, by what it was doing
+    double take = 0;     // claim.next() + batch bookkeeping (offsets, the zero-copy run or the copy into the batch buffer)
+    double ingest = 0;   // inside fa_ingest: wait for a staging slot, copy into pinned memory, enqueue H2D + kernels
+    double lock = 0;     // waiting for the read lock (a window close holds the write lock)
+    double mark = 0;     // session.MarkMessage + counters
+    double close = 0;    // closeWindows called from this thread's timer
+    uint64_t batches = 0, records = 0, bytes = 0, copied_bytes = 0;
+};
 struct PartitionState {
     fa_ctx* ctx = nullptr;
-    std::vector<uint8_t> buf;       // message values back to back
+    // the pending batch: message values back to back - in place in the client's fetch buffer while every message follows the
+    // previous one there (run != nullptr), copied into buf from the first one that does not
+    const uint8_t* run = nullptr;
+    size_t run_len = 0;
+    std::vector<uint8_t> buf;
     std::vector<uint64_t> offsets;  // n+1 entries
-    size_t pending = 0;             // messages in buf
+    size_t pending = 0;             // messages in the batch
     ConsumerMessage last{};         // the newest of them: offsets of one partition are monotone, marking it commits the batch
+    Phases ph;
+    size_t bytes() const { return run ? run_len : buf.size(); }
+    void append(const ConsumerMessage& m) {
+        if (pending == 0 && buf.empty()) {
+            run = m.Value;
+            run_len = m.Len;
+        } else if (run && m.Value == run + run_len) {
+            run_len += m.Len;
+        } else {
+            if (run) {
+                buf.assign(run, run + run_len);
+                ph.copied_bytes += run_len;
+                run = nullptr;
+                run_len = 0;
+            }
+            buf.insert(buf.end(), m.Value, m.Value + m.Len);
+            ph.copied_bytes += m.Len;
+        }
+        offsets.push_back(bytes());
+        last = m;
+        pending++;
+    }
 };
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 class State : public ConsumerGroupHandler {
 public:
@@ -335,6 +392,11 @@ public:
                 cfg.table_capacity_log2 = (uint32_t)f_.TableLog2;
                 cfg.topk_capacity_log2 = (uint32_t)f_.KeysetLog2;
                 cfg.wide_capacity_log2 = (uint32_t)f_.WideLog2;
+                // candidates: the sets hold what can rank (2^16 slots unless -gpu.keyset.log2 says otherwise), not every address
+                const bool cand = f_.TopkMode == "candidates" || (f_.TopkMode == "auto" && session.claims.size() > 1);
+                cfg.topk_mode = cand ? FA_TOPK_CANDIDATES : FA_TOPK_EXACT;
+                cfg.topk_track = (uint32_t)f_.TopkTrack;
+                if (cand && !f_.KeysetLog2) cfg.topk_capacity_log2 = 16;
                 cfg.framed = f_.ProtoFixed ? 1 : 0;
                 int rc = fa_create(&cfg, &p->ctx);
                 if (rc != 0) fatal("fa_create: %d %s", rc, fa_last_error(nullptr));
@@ -346,8 +408,9 @@ public:
             const uint32_t flags = f_.GpuTransport == "rccl" ? FA_GROUP_RCCL : FA_GROUP_PEER;
             int rc = fa_group_create(ctxs.data(), ctxs.size(), flags, &group_);
             if (rc != 0) fatal("fa_group_create: %d %s", rc, fa_group_last_error(nullptr));
-            logf(2, "window close: group of %zu context(s) over %ld GPU(s), transport %s", ctxs.size(), f_.GpuDevices,
-                 fa_group_transport(group_) == FA_GROUP_RCCL ? "rccl" : "peer copies");
+            logf(2, "window close: group of %zu context(s) over %ld GPU(s), transport %s, top-k mode %s", ctxs.size(), f_.GpuDevices,
+                 fa_group_transport(group_) == FA_GROUP_RCCL ? "rccl" : "peer copies",
+                 f_.TopkMode == "candidates" || (f_.TopkMode == "auto" && session.claims.size() > 1) ? "candidates" : "exact");
         }
         return 0;
     }
@@ -357,18 +420,32 @@ public:
     int ConsumeClaim(ConsumerGroupSession& session, ConsumerGroupClaim& claim) override {
         PartitionState* p = partition(claim.Partition());
         auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(f_.FlushTime);
+        const size_t flush_count = (size_t)f_.FlushCount, batch_bytes = (size_t)std::max(0l, f_.BatchBytes);
         ConsumerMessage m;
+        double t_mark = now_s();
+        auto lap = [&](double& acc) {  // the time since the last lap goes to `acc`
+            const double t = now_s();
+            acc += t - t_mark;
+            t_mark = t;
+        };
         while (claim.next(m)) {
-            p->buf.insert(p->buf.end(), m.Value, m.Value + m.Len);
-            p->offsets.push_back(p->buf.size());
-            p->last = m;
-            if ((long)++p->pending >= f_.FlushCount) flush(*p, session);  // inserter.go:118-120
-            if (std::chrono::steady_clock::now() >= deadline) {           // inserter.go:189-191
+            p->append(m);
+            // inserter.go:118-120 - and, beyond the reference, a batch keeps growing while the claim has messages ready (header)
+            if (p->pending >= flush_count && (p->bytes() >= batch_bytes || !claim.ready())) {
+                lap(p->ph.take);
                 flush(*p, session);
+                t_mark = now_s();
+            }
+            if ((p->pending & 15) == 0 && std::chrono::steady_clock::now() >= deadline) {  // inserter.go:189-191 (the clock is read every 16 messages)
+                lap(p->ph.take);
+                flush(*p, session);
+                t_mark = now_s();
                 closeWindows((int64_t)time(nullptr), false);
+                lap(p->ph.close);
                 deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(f_.FlushTime);
             }
         }
+        lap(p->ph.take);
         flush(*p, session);  // claim closed
         return 0;
     }
@@ -377,22 +454,35 @@ public:
     void flush(PartitionState& p, ConsumerGroupSession& session) {
         const size_t n = p.offsets.size() - 1;
         if (n == 0) return;
+        const uint8_t* data = p.run ? p.run : p.buf.data();
+        const size_t len = p.bytes();
         logf(3, "Processed %zu records in the last iteration.", n);
+        double t0 = now_s();
         if (f_.DryRun) {
-            logf(2, "dryrun flush partition=%d records=%zu bytes=%zu", p.last.Partition, n, p.buf.size());
+            logf(2, "dryrun flush partition=%d records=%zu bytes=%zu", p.last.Partition, n, len);
         } else {
             std::shared_lock<std::shared_mutex> rd(close_mu_);  // (not while the group closes a window: that uses every ctx)
+            const double t1 = now_s();
+            p.ph.lock += t1 - t0;
             // fa_ingest copies into library-owned pinned memory before returning
-            int rc = fa_ingest(p.ctx, p.buf.data(), p.buf.size(), p.offsets.data(), n);
+            int rc = fa_ingest(p.ctx, data, len, p.offsets.data(), n);
             if (rc != 0) fatal("fa_ingest: %d %s", rc, fa_last_error(p.ctx));  // sink error is fatal, inserter.go:102-105
+            t0 = now_s();
+            p.ph.ingest += t0 - t1;
         }
         Inserts += n;
         Flushes += 1;
         session.MarkMessage(p.last, "");  // after the sink accepted the batch; one mark per batch (the reference marks every message,
                                           // inserter.go:188 - same committed offset, without 8 threads meeting on the session's lock per message)
+        p.ph.batches += 1;
+        p.ph.records += n;
+        p.ph.bytes += len;
+        p.run = nullptr;
+        p.run_len = 0;
         p.buf.clear();
         p.offsets.assign(1, 0);
         p.pending = 0;
+        p.ph.mark += now_s() - t0;
     }
 
     // emits the finished windows of the WHOLE topic to the bulk-load sinks: flows_5m rows (create.sh:70-90) merged over the
@@ -425,6 +515,12 @@ public:
                 app.resize(na);
                 logf(2, "(SrcAddr,DstPort,Proto) timeslot %u: %zu rows", ts, na);
                 out_.writeApp(app);
+            } else if ((uint32_t)f_.KeySets & FA_KEYS_ADDR_PORT_PROTO) {
+                // the key set is on but nobody takes its rows: the window is closed all the same (dropped on every member) -
+                // kept, the wide table / wide log would grow for the life of the session
+                for (auto& kv : parts_)
+                    if (kv.second->ctx && (rc = fa_drop_window(kv.second->ctx, FA_ROWS_APP, ts)) != 0)
+                        fatal("fa_drop_window(FA_ROWS_APP): %d %s", rc, fa_last_error(kv.second->ctx));
             }
             std::vector<fa_row5m> rows(1 << 16);
             size_t nr = 0;
@@ -467,6 +563,31 @@ public:
             if (kv.second->ctx) fa_destroy(kv.second->ctx);
     }
     uint64_t bad() const { return bad_; }
+    // where the consume loop's time went, per partition thread (-phases.out; the "phases:" log line carries the sums)
+    std::string phasesJson(double setup_s, double consume_s, double finish_s) {
+        std::string js = "{\"setup_s\": " + std::to_string(setup_s) + ", \"consume_s\": " + std::to_string(consume_s) + ", \"finish_s\": " + std::to_string(finish_s) +
+                         ", \"partitions\": [";
+        bool first = true;
+        for (auto& kv : parts_) {
+            const Phases& h = kv.second->ph;
+            char b[512];
+            snprintf(b, sizeof b, "%s{\"partition\": %d, \"take_s\": %.6f, \"fa_ingest_s\": %.6f, \"lock_wait_s\": %.6f, \"mark_s\": %.6f, \"close_s\": %.6f, "
+                     "\"batches\": %llu, \"records\": %llu, \"bytes\": %llu, \"copied_bytes\": %llu}", first ? "" : ", ", kv.first, h.take, h.ingest, h.lock, h.mark, h.close,
+                     (unsigned long long)h.batches, (unsigned long long)h.records, (unsigned long long)h.bytes, (unsigned long long)h.copied_bytes);
+            js += b;
+            first = false;
+        }
+        return js + "]}";
+    }
+    Phases phasesSum() {
+        Phases t;
+        for (auto& kv : parts_) {
+            const Phases& h = kv.second->ph;
+            t.take += h.take, t.ingest += h.ingest, t.lock += h.lock, t.mark += h.mark, t.close += h.close;
+            t.batches += h.batches, t.records += h.records, t.bytes += h.bytes, t.copied_bytes += h.copied_bytes;
+        }
+        return t;
+    }
 
 private:
     PartitionState* partition(int32_t part) {
@@ -486,7 +607,7 @@ private:
 };
 
 // a partition log, mapped (the page cache is the only copy; a Kafka client would hand out its fetch buffers the same way)
-static MappedLog map_file(const std::string& path) {
+static MappedLog map_file(const std::string& path, bool prefault) {
     int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) fatal("cannot open %s", path.c_str());
     struct stat st;
@@ -494,7 +615,7 @@ static MappedLog map_file(const std::string& path) {
     MappedLog m;
     m.size = (size_t)st.st_size;
     if (m.size) {
-        void* p = mmap(nullptr, m.size, PROT_READ, MAP_PRIVATE, fd, 0);
+        void* p = mmap(nullptr, m.size, PROT_READ, MAP_PRIVATE | (prefault ? MAP_POPULATE : 0), fd, 0);
         if (p == MAP_FAILED) fatal("cannot map %s", path.c_str());
         madvise(p, m.size, MADV_SEQUENTIAL);
         m.data = (const uint8_t*)p;
@@ -512,11 +633,13 @@ int main(int argc, char** argv) {
     if (f.InputFormat == "framed" && !f.ProtoFixed) fatal("-input.format=framed needs -proto.fixedlen=true (bare values are not self-delimiting)");
     if (f.FlushCount < 1) fatal("-flush.count must be >= 1");
     if (f.GpuTransport != "peer" && f.GpuTransport != "rccl") fatal("-gpu.transport must be peer or rccl");
+    if (f.TopkMode != "auto" && f.TopkMode != "exact" && f.TopkMode != "candidates") fatal("-topk.mode must be exact, candidates or auto");
 
     RowWriter out;
     out.open(f);
     State s(f, out);
     ConsumerGroupSession session;
+    const auto t_start = std::chrono::steady_clock::now();  // (setup = mapping the partition logs + contexts + group)
 
     std::vector<std::unique_ptr<ConsumerGroupClaim>> claims;
     int32_t part = 0;
@@ -524,11 +647,10 @@ int main(int argc, char** argv) {
     while (i <= f.InputFiles.size()) {
         size_t j = f.InputFiles.find(',', i);
         if (j == std::string::npos) j = f.InputFiles.size();
-        if (j > i) claims.push_back(std::make_unique<ConsumerGroupClaim>(part++, map_file(f.InputFiles.substr(i, j - i)), f.InputFormat == "len32"));
+        if (j > i) claims.push_back(std::make_unique<ConsumerGroupClaim>(part++, map_file(f.InputFiles.substr(i, j - i), f.Prefault), f.InputFormat == "len32"));
         i = j + 1;
     }
     for (auto& c : claims) session.claims.push_back(c->Partition());
-    const auto t_start = std::chrono::steady_clock::now();
     auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     if (s.Setup(session) != 0) fatal("Setup failed");
     const double setup_s = since(t_start);
@@ -542,7 +664,22 @@ int main(int argc, char** argv) {
     s.finish(session);
     if (s.Cleanup(session) != 0) fatal("Cleanup failed");
     out.close();
-    logf(2, "phases: setup %.3f s, consume %.3f s, last close + top-k + teardown %.3f s", setup_s, consume_s, since(t_finish));
+    const double finish_s = since(t_finish);
+    logf(2, "phases: setup %.3f s, consume %.3f s, last close + top-k + teardown %.3f s", setup_s, consume_s, finish_s);
+    {
+        const Phases t = s.phasesSum();
+        const double nthr = claims.empty() ? 1.0 : (double)claims.size();
+        logf(2, "consume loop, mean per partition thread: take %.3f s, fa_ingest %.3f s, lock wait %.3f s, mark %.3f s, timer closes %.3f s; %llu batches, %.1f MiB per batch, "
+                "%.1f %% of the bytes copied into a batch buffer (the rest handed over in place)",
+             t.take / nthr, t.ingest / nthr, t.lock / nthr, t.mark / nthr, t.close / nthr, (unsigned long long)t.batches,
+             t.batches ? (double)t.bytes / (double)t.batches / 1048576.0 : 0.0, t.bytes ? 100.0 * (double)t.copied_bytes / (double)t.bytes : 0.0);
+    }
+    if (!f.PhasesOut.empty()) {
+        FILE* fp = fopen(f.PhasesOut.c_str(), "w");
+        if (!fp) fatal("cannot open %s", f.PhasesOut.c_str());
+        fprintf(fp, "%s\n", s.phasesJson(setup_s, consume_s, finish_s).c_str());
+        fclose(fp);
+    }
 
     if (!f.OffsetsOut.empty()) {
         FILE* fp = fopen(f.OffsetsOut.c_str(), "w");

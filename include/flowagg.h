@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FA_ABI_VERSION 7
+#define FA_ABI_VERSION 8
 
 typedef struct fa_ctx fa_ctx;
 
@@ -90,6 +90,11 @@ typedef struct {
                                        theta_t = max(lower edge of the estimate bin (64 octaves x 32 steps) that holds rank
                                                  topk_track among R_t's estimates [0 while |R_t| < topk_track],
                                                  total weight_t >> (topk_capacity_log2 - 2), 1);
+                                     (Launch boundaries are the library's: one fa_ingest / fa_ingest_device call is ONE launch
+                                     unless it exceeds max_batch_records or 2^24 wide-tuple records, or is the first large call
+                                     of a ctx with FA_KEYS_ADDR_PORT_PROTO - those are split.  R is therefore a function of the
+                                     stream, the caller's batches AND the configuration; what is guaranteed for every split is
+                                     the containment below, and bit-for-bit reproducibility for a fixed configuration.)
                                      fa_topk ranks R - every key whose estimate stood at or above the running topk_track-th
                                      estimate at a batch boundary and that occurred again afterwards: on a stream whose heavy
                                      hitters recur in every batch the same rows as the exact mode (BASELINE config 3: checked),
@@ -207,6 +212,12 @@ typedef struct {
     /* launches of the kernel variant that learns a producer's field order per wave (flows_5m alone; chosen while most records of
      * the last launches needed the order-free parser - a producer that does not marshal in field-number order) */
     uint64_t learnt_order_launches;
+    /* ABI 8 - where the HOST time of fa_ingest (host buffers) goes, summed over the calls, in nanoseconds: the whole call, of it the
+     * wait for a free staging slot (the transfer and the kernels of the call before the last still hold it: the GPU / PCIe side is
+     * behind) and the copy into page-locked staging incl. the offsets' narrowing to 32 bits (the consumer's cores are behind) */
+    uint64_t host_ingest_ns;
+    uint64_t host_stage_wait_ns;
+    uint64_t host_stage_copy_ns;
 } fa_stats_t;
 
 typedef struct {
@@ -422,7 +433,11 @@ int fa_stats(fa_ctx*, fa_stats_t* out);
  * partial results (flows_5m has: create.sh:70-90 - its rows MAY leave per partition; merged they are fewer and final).
  * A group is that close: the members' results are produced, exchanged and merged in HBM - peer copies between the GPUs
  * (hipMemcpyPeerAsync over xGMI; members on one GPU: device copies), or RCCL for the dense sketches - and one result
- * leaves.  Every result equals, bit for bit, what ONE ctx that ingested all partitions returns from the matching call.
+ * leaves.  Every result equals, bit for bit, what ONE ctx that ingested all partitions returns from the matching call - with one
+ * qualification: in FA_TOPK_CANDIDATES mode every member admits candidates by ITS OWN sketch and threshold (the contract is per
+ * ctx and per ingest launch), and the group ranks the UNION of the members' candidates by the merged estimate; a single ctx over
+ * all partitions would admit by the merged stream's thresholds.  Both hold every key that stood above its partition's running
+ * topk_track-th estimate; they are not the same set in general (equal on streams whose heavy hitters are heavy in every partition).
  * The multi-PROCESS twin (one rank per GPU under torchrun) is flow-pipeline_amd/dist.py over the same ABI 5/6 steps.
  * Threading: a group call uses every member ctx (on host threads of its own, one per member); the caller must not run any
  * other call on a member at the same time (ingest goroutines take a read lock, the closing goroutine the write lock).
@@ -434,8 +449,11 @@ enum {
     FA_GROUP_RCCL = 1  /* sketches by ncclAllReduce over communicators made with ncclCommInitAll (librccl.so is bound
                           lazily; needs every member on its own GPU - FA_ERR_UNSUPPORTED otherwise); rows still by peer copies */
 };
-/* ctxs: n contexts (1 <= n <= 1024) with the same window / key-set / sketch configuration, any placement over the GPUs.
- * The contexts stay the caller's: destroy the group first, then them. */
+/* ctxs: n contexts (1 <= n <= 1024) with the same window / key-set / sketch / top-k configuration (FA_ERR_ARG otherwise), any
+ * placement over the GPUs; a ctx is a member of at most one group at a time.  The contexts stay the caller's: destroy the group
+ * first, then them.  What a close needs beyond the members' own buffers (merged sketch views, exchange and partition buffers) is
+ * reserved here for members that already hold rows, and - for members that ingest afterwards - when a launch's rows come into
+ * being, not inside the first close.  n - 1 host threads live as long as the group. */
 int fa_group_create(fa_ctx* const* ctxs, size_t n, uint32_t flags, fa_group** out);
 void fa_group_destroy(fa_group*);
 const char* fa_group_last_error(const fa_group*); /* group may be NULL: last create error */

@@ -142,6 +142,12 @@ void fo_gen_row(const fo_gen_params*, uint64_t i, fo_row* out);
  * sum(Bytes*SamplingRate) GROUP BY address (viz-ch.json:233,479) - the address of (rank, v6) is fo_zipf_key(). */
 void fo_cms_stream(const fo_gen_params* g, uint64_t i0, uint64_t n, int threads, uint32_t depth, uint32_t width_log2,
                    uint64_t seed, uint64_t* cms_src, uint64_t* cms_dst, uint64_t* exact_src, uint64_t* exact_dst);
+/* BASELINE config 5 at full scale: a checksum of the (Date,Timeslot,SrcAddr,DstPort,Proto) rollup (create.sh:92-110's Date /
+ * Timeslot rule on the second key set) that is linear in the sums, so that it can be computed over the RECORDS without
+ * grouping them: per timeslot slot0 + k*gran (k < nslots)  out_sum[k] += sum h(key) * (3*Bytes + 5*Packets + 7),
+ * out_cnt[k] += records.  Returns the records that fell outside the slots.  pyoracle.app_rows_checksum is the rows' side. */
+uint64_t fo_app_checksum_stream(const fo_gen_params* g, uint64_t i0, uint64_t n, int threads, uint32_t gran, uint32_t slot0,
+                                uint32_t nslots, uint64_t* out_sum, uint64_t* out_cnt);
 /* The 16-byte address the ZIPF generator gives rank `rank` (dst = 0: SrcAddr, 1: DstAddr; v6 = 0: 4-byte IPv4 form). */
 void fo_zipf_key(uint64_t rank, int dst, int v6, uint8_t out[16]);
 

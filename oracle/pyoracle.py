@@ -205,6 +205,62 @@ def cms_stream(gp: GenParams, i0: int, n: int, threads: int, depth: int, width_l
                     None if exact_src is None else exact_src.ctypes.data, None if exact_dst is None else exact_dst.ctypes.data)
 
 
+def app_checksum_stream(gp: GenParams, i0: int, n: int, threads: int, gran: int, slot0: int, nslots: int):
+    """-> (checksum per timeslot, records per timeslot, records outside): fo_app_checksum_stream - the linear checksum of the
+    (SrcAddr,DstPort,Proto) rollup over generator records [i0, i0+n), no group-by (flow_oracle.h)."""
+    L = lib()
+    L.fo_app_checksum_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.fo_app_checksum_stream.restype = C.c_uint64
+    sums = np.zeros(nslots, dtype=np.uint64)
+    cnts = np.zeros(nslots, dtype=np.uint64)
+    outside = L.fo_app_checksum_stream(C.byref(gp), i0, n, threads, gran, slot0, nslots, sums.ctypes.data, cnts.ctypes.data)
+    return sums, cnts, int(outside)
+
+
+def _mix64(z):
+    z = z.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xbf58476d1ce4e5b9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94d049bb133111eb)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+def app_rows_checksum(rows, timeslot=None):
+    """The rows' side of app_checksum_stream: sum h(key) * (3*bytes + 5*packets + 7*count) mod 2^64 over (SrcAddr,DstPort,Proto)
+    rows (ROW_APP_DTYPE, or 48-byte rows without date / timeslot when `timeslot` names the window they belong to)."""
+    if len(rows) == 0:
+        return 0
+    addr = np.ascontiguousarray(rows["src_addr"]).view("<u8").reshape(-1, 2)
+    ts = rows["timeslot"].astype(np.uint64) if timeslot is None else np.full(len(rows), timeslot, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = _mix64(((ts << np.uint64(32)) | rows["dst_port"].astype(np.uint64)) ^ np.uint64(0x9E3779B97F4A7C15))
+        h = _mix64(h ^ addr[:, 0])
+        h = _mix64(h ^ addr[:, 1])
+        h = _mix64(h ^ rows["proto"].astype(np.uint64))
+        v = rows["bytes"] * np.uint64(3) + rows["packets"] * np.uint64(5) + rows["count"] * np.uint64(7)
+        return int((h * v).sum(dtype=np.uint64))
+
+
+def app_rows_strictly_ascending(rows) -> bool:
+    """Every key once, in the emit order of fa_read_window_app: (timeslot,) SrcAddr bytes, DstPort, Proto strictly ascending."""
+    if len(rows) < 2:
+        return True
+    addr = np.ascontiguousarray(rows["src_addr"])
+    cols = [addr[:, :8].copy().view(">u8").reshape(-1).astype(np.uint64), addr[:, 8:].copy().view(">u8").reshape(-1).astype(np.uint64),
+            rows["dst_port"].astype(np.uint64), rows["proto"].astype(np.uint64)]
+    if "timeslot" in rows.dtype.names:
+        cols.insert(0, rows["timeslot"].astype(np.uint64))
+    lt = np.zeros(len(rows) - 1, dtype=bool)   # decided "ascending" by an earlier column
+    eq = np.ones(len(rows) - 1, dtype=bool)    # equal in every earlier column
+    for c in cols:
+        lt |= eq & (c[:-1] < c[1:])
+        eq &= c[:-1] == c[1:]
+    return bool(lt.all())
+
+
 def zipf_key(rank: int, dst: int, v6: int) -> bytes:
     out = C.create_string_buffer(16)
     L = lib()

@@ -24,12 +24,12 @@ def test_library_exports_every_declared_symbol(fa):
     for n in names:
         assert hasattr(L, n), "libflowagg.so does not export %s" % n
     assert sorted(fa.EXPORTS) == names, "python binding and header disagree"
-    assert fa.lib().fa_abi_version() == 7
+    assert fa.lib().fa_abi_version() == 8
 
 
 def test_struct_layouts_match_header(fa):
     assert C.sizeof(fa.Config) == 64
-    assert C.sizeof(fa.Stats) == 288
+    assert C.sizeof(fa.Stats) == 312  # ABI 8: + host_ingest_ns, host_stage_wait_ns, host_stage_copy_ns
     assert C.sizeof(fa.MockParams) == 48
     assert fa.ROW5M_DTYPE.itemsize == 48 and fa.FLOW_ROW_DTYPE.itemsize == 120
 

@@ -61,9 +61,12 @@ def test_flag_surface_matches_the_reference(exe):
     assert r.returncode == 1 and "invalid value" in r.stderr
     # the additive flags (GPU placement, table sizes, sinks) parse as well
     extra = ["-gpu.devices=8", "-gpu.transport=rccl", "-gpu.table.log2=22", "-gpu.keyset.log2=24", "-gpu.wide.log2=26", "-key.sets=15",
-             "-out.rowbinary=/dev/null", "-out.app=/dev/null", "-out.topk=/dev/null", "-topk.k=10", "-window.secs=300", "-window.lag=30"]
+             "-out.rowbinary=/dev/null", "-out.app=/dev/null", "-out.topk=/dev/null", "-topk.k=10", "-window.secs=300", "-window.lag=30",
+             "-gpu.batch.bytes=1048576", "-topk.mode=candidates", "-topk.track=64", "-phases.out=/dev/null", "-input.prefault=false"]
     r = subprocess.run([exe] + extra, capture_output=True, text=True)
     assert r.returncode == 1 and "no Kafka client in this build" in r.stderr
+    r = subprocess.run([exe, "-topk.mode=best", "-input.files=x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "-topk.mode must be" in r.stderr
 
 
 def test_an_empty_partition_log_and_a_mapped_one(exe, po, tmp_path):
@@ -83,7 +86,8 @@ def test_flush_by_count_and_marking(exe, po, tmp_path):
     n, nparts = 10500, 2
     _, _, paths = _partition_logs(po, tmp_path, n, nparts)
     m, o = tmp_path / "metrics.txt", tmp_path / "offsets.txt"
-    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-sink.dryrun", "-flush.count=1000", "-flush.dur=1h",
+    # -gpu.batch.bytes=0: the reference's rule alone (inserter.go:118-120) - a flush exactly every -flush.count messages
+    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-sink.dryrun", "-flush.count=1000", "-flush.dur=1h", "-gpu.batch.bytes=0",
                         "-metrics.dump=%s" % m, "-offsets.out=%s" % o], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     met = _metrics(m)
@@ -92,6 +96,34 @@ def test_flush_by_count_and_marking(exe, po, tmp_path):
     assert [l.split() for l in open(o)] == [["0", "5250"], ["1", "5250"]]  # every message marked, after its flush
     sizes = sorted(int(l.split("records=")[1].split()[0]) for l in r.stderr.splitlines() if "dryrun flush" in l)
     assert sizes == [250, 250] + [1000] * 10
+
+
+def test_batches_grow_while_the_claim_has_messages_ready(exe, po, tmp_path):
+    """Beyond the reference: a batch that reached -flush.count keeps growing while the claim has more messages buffered, up to
+    -gpu.batch.bytes (one fa_ingest is a PCIe transfer and a handful of launches whatever its size); a partition log is always
+    "ready", so the byte bound alone cuts the batches - in place (no copy) while the messages lie back to back."""
+    import json
+    n, nparts = 10500, 2
+    buf, off, paths = _partition_logs(po, tmp_path, n, nparts)
+    m, o, ph = tmp_path / "metrics.txt", tmp_path / "offsets.txt", tmp_path / "phases.json"
+    bound = 64 * 1024
+    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-sink.dryrun", "-flush.count=500", "-flush.dur=1h", "-gpu.batch.bytes=%d" % bound,
+                        "-metrics.dump=%s" % m, "-offsets.out=%s" % o, "-phases.out=%s" % ph], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert _metrics(m)["insert_count"] == n
+    assert [l.split() for l in open(o)] == [["0", "5250"], ["1", "5250"]]
+    flushes = [(int(l.split("records=")[1].split()[0]), int(l.split("bytes=")[1].split('"')[0])) for l in r.stderr.splitlines() if "dryrun flush" in l]
+    assert sum(f[0] for f in flushes) == n and sum(f[1] for f in flushes) == len(buf)
+    full = [f for f in flushes if f[1] >= bound]
+    assert len(full) >= len(flushes) - nparts          # every batch but a claim's last reached the byte bound ...
+    assert all(f[1] < bound + 256 and f[0] >= 500 for f in full)  # ... by less than one message, and never below -flush.count
+    phases = json.load(open(ph))
+    assert [p["partition"] for p in phases["partitions"]] == [0, 1]
+    assert sum(p["records"] for p in phases["partitions"]) == n and sum(p["bytes"] for p in phases["partitions"]) == len(buf)
+    assert all(p["copied_bytes"] == 0 for p in phases["partitions"])  # framed values lie back to back in the log: handed over in place
+    # default bound (64 MiB): one batch per claim here
+    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-sink.dryrun", "-flush.count=1000", "-flush.dur=1h", "-metrics.dump=%s" % m], capture_output=True, text=True)
+    assert r.returncode == 0 and _metrics(m)["flowagg_flushes"] == nparts and _metrics(m)["insert_count"] == n
 
 
 def test_flush_by_timer_and_len32_bare_records(exe, po, tmp_path):
@@ -138,7 +170,7 @@ def test_partition_logs_to_rowbinary_equal_oracle(gpu_lib, exe, fa, po, tmp_path
     with open(paths[1], "ab") as f:
         f.write(bytes.fromhex("05" + "70ffffffff"))
     rb, m = tmp_path / "flows_5m.rowbinary", tmp_path / "metrics.txt"
-    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-flush.count=%d" % flush, "-out.rowbinary=%s" % rb,
+    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-flush.count=%d" % flush, "-gpu.batch.bytes=0", "-out.rowbinary=%s" % rb,
                         "-metrics.dump=%s" % m, "-gpu.devices=1"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     met = _metrics(m)
@@ -160,10 +192,10 @@ def test_group_close_through_the_host_program(gpu_lib, exe, fa, po, tmp_path, np
     n = 200_000
     buf, off, paths = _partition_logs(po, tmp_path, n, nparts, mode=po.GEN_ZIPF, seed=77)
     rb, app, topk, m = tmp_path / "flows_5m.rowbinary", tmp_path / "app.rows", tmp_path / "topk.tsv", tmp_path / "metrics.txt"
-    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-flush.count=40000", "-key.sets=15", "-out.rowbinary=%s" % rb, "-out.app=%s" % app,
-                        "-out.topk=%s" % topk, "-topk.k=50", "-metrics.dump=%s" % m, "-gpu.devices=1", "-gpu.transport=peer"], capture_output=True, text=True)
+    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-flush.count=40000", "-gpu.batch.bytes=0", "-key.sets=15", "-out.rowbinary=%s" % rb, "-out.app=%s" % app,
+                        "-out.topk=%s" % topk, "-topk.k=50", "-topk.mode=exact", "-metrics.dump=%s" % m, "-gpu.devices=1", "-gpu.transport=peer"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    assert "group of %d context(s)" % nparts in r.stderr
+    assert "group of %d context(s)" % nparts in r.stderr and "top-k mode exact" in r.stderr
     met = _metrics(m)
     assert met["insert_count"] == n and met["flowagg_records_bad"] == 0
     ref = po.Rollup(300)
@@ -189,3 +221,34 @@ def test_group_close_through_the_host_program(gpu_lib, exe, fa, po, tmp_path, np
         ranked = sorted(zip((-est.astype(object)).tolist(), [bytes(k) for k in keys]))[:50]
         mine = [(bytes.fromhex(k), int(v)) for tag, k, v in lines if tag == which]
         assert mine == [(k, -e) for e, k in ranked]
+
+
+@pytest.mark.gpu
+def test_default_topk_mode_of_a_multi_partition_host_and_unsunk_app_windows(gpu_lib, exe, fa, po, tmp_path):
+    """More than one claimed partition: the candidates contract by default (64 k slots per set instead of every address) - its rows carry
+    the merged sketch's estimates, in rank order, and on a skewed stream start with the exact ranking's first rows.  And: the
+    (SrcAddr,DstPort,Proto) key set without -out.app is closed all the same (windows dropped), the flows_5m output is unaffected."""
+    n, nparts = 400_000, 4
+    buf, off, paths = _partition_logs(po, tmp_path, n, nparts, mode=po.GEN_ZIPF, seed=78)
+    rb, topk, m = tmp_path / "flows_5m.rowbinary", tmp_path / "topk.tsv", tmp_path / "metrics.txt"
+    r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-flush.count=10000", "-gpu.batch.bytes=0", "-key.sets=15", "-out.rowbinary=%s" % rb,
+                        "-out.topk=%s" % topk, "-topk.k=50", "-metrics.dump=%s" % m, "-gpu.devices=1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "top-k mode candidates" in r.stderr
+    ref = po.Rollup(300)
+    ref.ingest(buf, off, 1)
+    assert fa.rowbinary_to_rows(open(rb, "rb").read()).tobytes() == ref.rows().tobytes()
+    rows, status = po.decode_batch(buf, off, 1)
+    with np.errstate(over="ignore"):
+        w = rows["bytes"] * rows["sampling_rate"]
+    lines = [l.split("\t") for l in open(topk).read().splitlines()]
+    for which, col in (("src", "src_addr"), ("dst", "dst_addr")):
+        sk = po.cms_sketch_numpy(rows[col], w, 4, 20, 0)
+        keys = np.unique(np.ascontiguousarray(rows[col]), axis=0)
+        est = po.cms_estimates_numpy(sk, keys, 4, 20, 0)
+        ranked = sorted(zip((-est.astype(object)).tolist(), [bytes(k) for k in keys]))
+        exact = {k: -e for e, k in ranked}
+        mine = [(bytes.fromhex(k), int(v)) for tag, k, v in lines if tag == which]
+        assert len(mine) >= 10 and all(exact.get(k) == v for k, v in mine)          # candidates, with the merged sketch's estimates
+        assert mine == sorted(mine, key=lambda kv: (-kv[1], kv[0]))                   # in rank order
+        assert mine[:5] == [(k, -e) for e, k in ranked[:5]]                           # the heaviest hitters recur in every batch: found

@@ -349,3 +349,32 @@ def test_topk_contract_fixture(po):
                     gen_seed=c["generator_seed"])
     assert again == c
     assert hashlib.sha256(b"").hexdigest() != c["sets"]["src_addr"]["ranking_sha256"] and c["sets"]["src_addr"]["candidates"] >= c["track"]
+
+
+def test_linear_app_checksum_equals_the_grouped_rollups(po):
+    """fo_app_checksum_stream (bench.py's config-5 / group checks at 100 M records, where a CPU group-by of the (SrcAddr,DstPort,
+    Proto) rows takes minutes): the checksum over RECORDS == the same checksum over the rows of pyoracle.rollup_app, window by
+    window; it moves when a sum moves between keys or a row is split; strict order is what rules the split out."""
+    n = 120_000
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=5, n_total=n, span_secs=900, zipf_log2_universe=12, zipf_s_x100=80)
+    buf, off = po.gen_records(gp, 0, n)
+    rows, st = po.decode_batch(buf, off, framed=1)
+    app = po.rollup_app(rows, st)
+    sums, cnts, outside = po.app_checksum_stream(gp, 0, n, 3, 300, po.T0, 3)
+    assert outside == 0 and int(cnts.sum()) == n
+    for k in range(3):
+        w = app[app["timeslot"] == po.T0 + 300 * k]
+        assert len(w) and po.app_rows_checksum(w) == int(sums[k]) and int(w["count"].sum()) == int(cnts[k])
+        assert po.app_rows_strictly_ascending(w)
+        bad = w.copy()
+        bad["bytes"][0] += 1
+        bad["bytes"][1] -= 1  # the same total, another key
+        assert po.app_rows_checksum(bad) != int(sums[k])
+        split = np.concatenate([w[:1], w])  # a key twice: the linear checksum cannot see a row split in two halves ...
+        split["bytes"][0] = split["bytes"][1] // 2
+        split["bytes"][1] -= split["bytes"][0]
+        split["packets"][0] = split["count"][0] = 0
+        assert po.app_rows_checksum(split) == int(sums[k]) and not po.app_rows_strictly_ascending(split)  # ... the order check does
+    # slots that do not cover the stream: the rest is counted outside
+    _, c2, out2 = po.app_checksum_stream(gp, 0, n, 2, 300, po.T0 + 300, 1)
+    assert out2 == n - int(cnts[1]) and int(c2[0]) == int(cnts[1])

@@ -180,3 +180,48 @@ def test_candidates_mode_equals_the_golden_fixture(gpu_lib, fa, po):
                 h.update(bytes(r["key"]) + int(r["weight"]).to_bytes(8, "little"))
             assert h.hexdigest() == want["ranking_sha256"]
             assert [[bytes(r["key"]).hex(), int(r["weight"])] for r in got[:5]] == want["first"]
+
+
+def _zero_weight_records(fa, n_heavy, n_zero, scatter_pad=0):
+    """Hand-made framed records: n_heavy addresses with Bytes * SamplingRate > 0 and n_zero addresses whose records all carry
+    SamplingRate = 0 (the dashboards' weight, viz-ch.json:233, is then 0: still a row of GROUP BY SrcAddr)."""
+    ev = fa.schema.encode_varint
+    recs, keys, weights = [], [], []
+    for i in range(n_heavy + n_zero):
+        addr = bytes([10, i >> 16 & 255, i >> 8 & 255, i & 255]) + bytes(12)
+        rate = 0 if i >= n_heavy else 1 + i % 7
+        nbytes = 100 + i
+        p = b"\x10" + ev(fa.T0 + 1)                       # TimeReceived (2)
+        if rate:
+            p += b"\x18" + ev(rate)                        # SamplingRate (3): proto3 leaves a zero out
+        p += b"\x32\x10" + addr + b"\x3a\x10" + addr      # SrcAddr (6), DstAddr (7)
+        p += b"\x48" + ev(nbytes) + b"\x50" + ev(1)       # Bytes (9), Packets (10)
+        p += b"\x70" + ev(65000) + b"\x78" + ev(65001)    # SrcAS (14), DstAS (15)
+        p += b"\xf0\x01" + ev(0x800)                       # Etype (30)
+        recs.append(fa.schema.frame(p))
+        keys.append(addr)
+        weights.append(rate * nbytes)
+    recs = recs * (1 + scatter_pad)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.uint64)
+    return np.frombuffer(b"".join(recs), dtype=np.uint8), off, keys, [w * (1 + scatter_pad) for w in weights]
+
+
+@pytest.mark.parametrize("n_heavy,n_zero,pad", [(40, 300, 0), (0, 500, 0), (3000, 5000, 9)])
+def test_topk_keeps_zero_weight_addresses(gpu_lib, fa, n_heavy, n_zero, pad):
+    """an address whose estimate is 0 is still a row of the ranking.  With the threshold in bin 0 (fewer than k
+    keys, or a k-th estimate of 0) the histogram path must return those rows too: fa_topk(k) == the first k rows of fa_topk(all)
+    == the ranking of every distinct address, through the direct sink (small batch) and the scatter sink (80 k records)."""
+    buf, off, keys, weights = _zero_weight_records(fa, n_heavy, n_zero, scatter_pad=pad)
+    with fa.FlowAgg(framed=True, key_sets=7, cms_width_log2=16, topk_capacity_log2=15) as agg:  # (2^16 columns: no collisions among <= 8000 keys would be luck -
+        agg.ingest(buf, off)                                                                   #  the expectation below is computed from the sketch itself)
+        assert agg.stats()["records_bad"] == 0
+        for ks in (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS):
+            est = {k: agg.cms_query(ks, k) for k in keys}
+            assert all(est[k] >= w for k, w in zip(keys, weights))
+            want = sorted(((-e, k) for k, e in est.items()))
+            full = agg.topk(ks, 1 << 15)
+            assert [(bytes(r["key"]), int(r["weight"])) for r in full] == [(k, -e) for e, k in want]
+            nz = sum(1 for e in est.values() if e)
+            for k in (1, max(nz - 1, 1), nz, nz + 1, nz + 50, len(keys) - 1, len(keys), len(keys) + 10, nz + 1, 1):
+                got = agg.topk(ks, k)
+                assert got.tobytes() == full[:k].tobytes(), (k, len(got), nz)
