@@ -1244,7 +1244,7 @@ def main():
     agg.close()
     del chunks
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and default_workload and not args.no_secondary and not args.no_assert:
+    if rank == 0 and world == 1 and default_workload and not (args.no_secondary or args.no_assert or args.no_verify or args.cpu_sample <= 0):  # (measurement runs of the tools skip them)
         out["secondary"] = run_secondary(fa, _pkg.load_oracle(), torch, dev, args)
     if rank == 0:
         print(json.dumps(out))

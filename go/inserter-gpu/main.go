@@ -27,7 +27,7 @@
 //     a fatal sink error closes every partition's windows (best effort) before exit,
 //     and a claim that ends (rebalance) emits its partition's windows at once;
 //   - one fa_ctx per claimed partition (partition p on GPU p % -gpu.devices), no global mutex on the ingest path
-//     (inserter.go:84,115): flushes hold a read lock.  The contexts of a session form ONE group (fa_group_*, ABI 7) and
+//     (inserter.go:84,115): flushes hold a read lock.  The contexts of a session form ONE group (fa_group_*, ABI 7+) and
 //     windows are closed for the whole topic under the write lock: flows_5m rows merged over the partitions in HBM (peer
 //     copies over xGMI, or RCCL with -gpu.transport=rccl), the heavy hitters of the merged sketches at the end of a
 //     session (-out.topk).  Same logic as flow-pipeline_amd/host/inserter_gpu.cpp, which is built and GPU-tested;
@@ -99,6 +99,9 @@ var (
 	TableLog2    = flag.Int("gpu.table.log2", 0, "log2 slots of a context's flows_5m table (0 = library default)")
 	KeysetLog2   = flag.Int("gpu.keyset.log2", 0, "log2 slots of a context's distinct-address sets (0 = library default)")
 	WideLog2     = flag.Int("gpu.wide.log2", 0, "log2 slots of a context's (SrcAddr,DstPort,Proto) table (0 = library default)")
+	BatchBytes   = flag.Int("gpu.batch.bytes", 64<<20, "A batch that reached -flush.count keeps growing while the claim has messages ready, up to this many bytes (0 = flush exactly at -flush.count)")
+	TopkMode     = flag.String("topk.mode", "auto", "Top-k contract (fa_config.topk_mode): exact | candidates | auto (candidates with more than one claimed partition)")
+	TopkTrack    = flag.Int("topk.track", 0, "Candidates mode: the rank the admission threshold follows (0 = library default)")
 
 	Inserts = prometheus.NewCounter(prometheus.CounterOpts{Name: "insert_count", Help: "Flow messages aggregated on the GPU."})
 )
@@ -136,7 +139,13 @@ func (s *state) metricsHTTP() {
 	log.Fatal(http.ListenAndServe(*MetricsAddr, nil))
 }
 
-func newPartition(partition int32) *partitionState {
+// candidates: the distinct-address sets hold what can rank (2^16 slots unless -gpu.keyset.log2 says otherwise) instead of every
+// address ever seen (2 x 32 B x 2^-gpu.keyset.log2 per partition) - the default once a process serves several partitions
+func topkCandidates(claims int) bool {
+	return *TopkMode == "candidates" || (*TopkMode == "auto" && claims > 1)
+}
+
+func newPartition(partition int32, claims int) *partitionState {
 	cfg := C.fa_config{}
 	cfg.device = C.int32_t(int(partition) % *GpuDevices)
 	cfg.window_secs = C.uint32_t(*WindowSecs)
@@ -144,6 +153,13 @@ func newPartition(partition int32) *partitionState {
 	cfg.table_capacity_log2 = C.uint32_t(*TableLog2)
 	cfg.topk_capacity_log2 = C.uint32_t(*KeysetLog2)
 	cfg.wide_capacity_log2 = C.uint32_t(*WideLog2)
+	cfg.topk_track = C.uint32_t(*TopkTrack)
+	if topkCandidates(claims) {
+		cfg.topk_mode = C.FA_TOPK_CANDIDATES
+		if *KeysetLog2 == 0 {
+			cfg.topk_capacity_log2 = 16
+		}
+	}
 	if *ProtoFixed {
 		cfg.framed = 1
 	}
@@ -166,12 +182,16 @@ func (p *partitionState) flush(s *state, session sarama.ConsumerGroupSession) {
 	rc := C.fa_ingest(p.ctx, (*C.uint8_t)(unsafe.Pointer(&p.buf[0])), C.size_t(len(p.buf)),
 		(*C.uint64_t)(unsafe.Pointer(&p.offsets[0])), C.size_t(n))
 	var open []uint32
+	var openErr error
 	if rc == 0 && *MarkAfter {
-		open = p.openTimeslots() // the batch's records can only sit in timeslots that are open now
+		open, openErr = p.openTimeslots() // the batch's records can only sit in timeslots that are open now
 	}
-	s.closeMu.RUnlock() // (released before a fatal error: sinkFatal's last-resort close wants the write lock)
+	s.closeMu.RUnlock() // (released before ANY fatal error: sinkFatal's last-resort close wants the write lock)
 	if rc != 0 {
 		sinkFatal("fa_ingest: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
+	}
+	if openErr != nil {
+		sinkFatal("%v", openErr)
 	}
 	Inserts.Add(float64(n))
 	if *MarkAfter {
@@ -189,8 +209,9 @@ func (p *partitionState) flush(s *state, session sarama.ConsumerGroupSession) {
 }
 
 // openTimeslots lists the windows the context holds; retried with the size the library reports (a backlog
-// replay can hold hundreds of windows).  Errors are sink errors.
-func (p *partitionState) openTimeslots() []uint32 {
+// replay can hold hundreds of windows).  Errors are sink errors - RETURNED, not raised: the callers hold closeMu for reading,
+// and sinkFatal's last-resort close needs it for writing (it must be released first).
+func (p *partitionState) openTimeslots() ([]uint32, error) {
 	slots := make([]C.uint32_t, 64)
 	var ns C.size_t
 	rc := C.fa_open_timeslots(p.ctx, &slots[0], C.size_t(len(slots)), &ns)
@@ -199,22 +220,27 @@ func (p *partitionState) openTimeslots() []uint32 {
 		rc = C.fa_open_timeslots(p.ctx, &slots[0], C.size_t(len(slots)), &ns)
 	}
 	if rc != 0 {
-		sinkFatal("fa_open_timeslots: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
+		return nil, fmt.Errorf("fa_open_timeslots: %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
 	}
 	out := make([]uint32, int(ns))
 	for i := range out {
 		out[i] = uint32(slots[i])
 	}
-	return out
+	return out, nil
 }
 
-// markEmitted commits the batches (oldest first) none of whose windows is open any more.
-func (p *partitionState) markEmitted(session sarama.ConsumerGroupSession) {
+// markEmitted commits the batches (oldest first) none of whose windows is open any more.  The caller holds closeMu for reading
+// (or nothing runs beside it: Cleanup); an error comes back to be raised once the lock is released.
+func (p *partitionState) markEmitted(session sarama.ConsumerGroupSession) error {
 	if len(p.unmarked) == 0 || session == nil {
-		return
+		return nil
 	}
 	open := make(map[uint32]bool)
-	for _, ts := range p.openTimeslots() {
+	slots, err := p.openTimeslots()
+	if err != nil {
+		return err
+	}
+	for _, ts := range slots {
 		open[ts] = true
 	}
 	done := 0
@@ -233,6 +259,7 @@ func (p *partitionState) markEmitted(session sarama.ConsumerGroupSession) {
 		done++
 	}
 	p.unmarked = p.unmarked[done:]
+	return nil
 }
 
 // A sink error is fatal like the reference's failed db.Exec (inserter.go:102-105) - but the contexts hold aggregates.
@@ -306,6 +333,15 @@ func (s *state) closeWindows(now time.Time, all bool) {
 		if rc != 0 {
 			sinkFatal("fa_group_close_window: %d %s", int(rc), C.GoString(C.fa_group_last_error(s.group)))
 		}
+		// a key set without a sink is closed all the same: (SrcAddr,DstPort,Proto) windows have no output in this shim - kept,
+		// the wide table / wide log would grow for the life of the session (inserter_gpu.cpp writes them with -out.app)
+		if C.uint32_t(*KeySets)&C.FA_KEYS_ADDR_PORT_PROTO != 0 {
+			for _, p := range s.parts {
+				if rc := C.fa_drop_window(p.ctx, C.FA_ROWS_APP, C.uint32_t(ts)); rc != 0 {
+					sinkFatal("fa_group_close_window: fa_drop_window(FA_ROWS_APP): %d %s", int(rc), C.GoString(C.fa_last_error(p.ctx)))
+				}
+			}
+		}
 		log.Infof("flows_5m timeslot %d: %d rows", ts, int(nr))
 		if *OutRowBin != "" && nr > 0 {
 			buf := make([]byte, int(nr)*C.FA_ROWBINARY_ROW5M_BYTES)
@@ -360,9 +396,13 @@ func (s *state) Setup(session sarama.ConsumerGroupSession) error {
 	s.lock.Lock()
 	defer s.lock.Unlock()
 	var ctxs []*C.fa_ctx
+	claims := 0
+	for _, parts := range session.Claims() {
+		claims += len(parts)
+	}
 	for _, parts := range session.Claims() {
 		for _, partition := range parts {
-			p := newPartition(partition)
+			p := newPartition(partition, claims)
 			s.parts[partition] = p
 			ctxs = append(ctxs, p.ctx)
 		}
@@ -380,7 +420,11 @@ func (s *state) Setup(session sarama.ConsumerGroupSession) error {
 		if rc != 0 {
 			log.Fatalf("fa_group_create: %d %s", int(rc), C.GoString(C.fa_group_last_error(nil)))
 		}
-		log.Infof("window close: group of %d context(s) over %d GPU(s)", len(ctxs), *GpuDevices)
+		mode := "exact"
+		if topkCandidates(claims) {
+			mode = "candidates"
+		}
+		log.Infof("window close: group of %d context(s) over %d GPU(s), top-k mode %s", len(ctxs), *GpuDevices, mode)
 	}
 	close(s.ready)
 	return nil
@@ -399,7 +443,9 @@ func (s *state) Cleanup(session sarama.ConsumerGroupSession) error {
 		s.group = nil
 	}
 	for part, p := range s.parts {
-		p.markEmitted(session)
+		if err := p.markEmitted(session); err != nil {
+			log.Error(err) // (the windows went out above; the offsets stay uncommitted: at-least-once)
+		}
 		C.fa_destroy(p.ctx)
 		delete(s.parts, part)
 	}
@@ -440,15 +486,22 @@ func (s *state) ConsumeClaim(session sarama.ConsumerGroupSession, claim sarama.C
 			p.buf = append(p.buf, message.Value...)
 			p.offsets = append(p.offsets, uint64(len(p.buf)))
 			p.pending = append(p.pending, message)
-			if len(p.pending) >= *FlushCount { // inserter.go:118-120
+			// inserter.go:118-120 - and, beyond the reference: one fa_ingest is a PCIe transfer and a handful of kernel launches
+			// whatever its size, so a batch that reached -flush.count keeps growing while the claim has more messages buffered
+			// (len of the channel: the next receive would not block), up to -gpu.batch.bytes; a drained claim flushes at once and
+			// -flush.dur bounds the wait as before.  (Measured on the C++ twin, inserter_gpu.cpp: profiles/r06_host_phases.json.)
+			if len(p.pending) >= *FlushCount && (len(p.buf) >= *BatchBytes || len(claim.Messages()) == 0) {
 				p.flush(s, session)
 			}
 		case <-timer.C: // inserter.go:189-191
 			p.flush(s, session)
 			s.closeWindows(time.Now().UTC(), false) // (the whole topic's finished windows: whichever goroutine's timer fires first)
 			s.closeMu.RLock()
-			p.markEmitted(session)
+			err := p.markEmitted(session)
 			s.closeMu.RUnlock()
+			if err != nil {
+				sinkFatal("%v", err)
+			}
 			timer.Reset(*FlushTime)
 		}
 	}

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd /tmp
 for f in ${FLAGS:-0 16 1 17}; do
   FA_LIB_VARIANT=ablate FA_DEBUG_FLAGS=$f rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/f$f -o p -- \
-    python $ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-verify --no-host-fed --no-assert $BENCH_ARGS > $OUT/f$f.log 2>&1
+    python $ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-verify --no-host-fed --no-assert --no-secondary --settle-max-steps 4 $BENCH_ARGS > $OUT/f$f.log 2>&1
 done
 cd $ROOT
 python - <<'PY'
