@@ -555,13 +555,26 @@ def sec_group8(fa, po, torch, dev, ref, members=8, chunk=8_333_334, cand=True):
             wins = [g.read_window(fa.ROWS_5M, ts, cap=1 << 20) for ts in slots]
             out["read_5m_window_merged_ms_mean"] = 1e3 * (time.perf_counter() - t) / max(len(slots), 1)
             allrows = np.concatenate(wins)
-            want_sum, want_cnt, outside = po.app_checksum_stream(ref.gp, 0, n, threads, 300, slots[0], (slots[-1] - slots[0]) // 300 + 1)
-            app_ms, app_ok, nrows, buf_rows = [], outside == 0, 0, 1 << 22
+            # (SrcAddr,DstPort,Proto), hash-partitioned: first every window TIMED, back to back into one reused buffer (the checks
+            # below are seconds of numpy per window - with them in between every read would start from an idle GPU at 160 MHz),
+            # then every window once more for the checks
+            import ctypes as C
+            nslot = (slots[-1] - slots[0]) // 300 + 1
+            want_sum, want_cnt, outside = po.app_checksum_stream(ref.gp, 0, n, threads, 300, slots[0], nslot)
+            buf_rows = int(want_cnt.max()) + (1 << 16)  # (rows <= records of the window)
+            reuse = np.empty(buf_rows, dtype=fa.ROW_APP_DTYPE)
+            reuse.view(np.uint8)[::4096] = 0  # (pages touched before the clock starts: a consumer keeps its row buffer)
+            shares_c = (C.c_size_t * nm)()
+            nr = C.c_size_t()
+            app_ms = []
             for ts in slots:
                 t = time.perf_counter()
-                rows, shares = g.read_window_partitioned(fa.ROWS_APP, ts, cap=buf_rows)
+                rc = g._L.fa_group_read_window_partitioned(g._h, fa.ROWS_APP, ts, reuse.ctypes.data, buf_rows, shares_c, C.byref(nr))
                 app_ms.append((time.perf_counter() - t) * 1e3)
-                buf_rows = max(buf_rows, len(rows) + (1 << 16))
+                g._chk(rc)
+            app_ok, nrows = outside == 0, 0
+            for ts in slots:
+                rows, shares = g.read_window_partitioned(fa.ROWS_APP, ts, cap=buf_rows)
                 nrows += len(rows)
                 k = (ts - slots[0]) // 300
                 bounds = np.cumsum([0] + shares)
@@ -570,6 +583,7 @@ def sec_group8(fa, po, torch, dev, ref, members=8, chunk=8_333_334, cand=True):
                 app_ok = app_ok and int(rows["count"].sum()) == int(want_cnt[k]) and po.app_rows_checksum(rows) == int(want_sum[k]) \
                     and all(po.app_rows_strictly_ascending(rows[bounds[r]:bounds[r + 1]]) for r in range(nm)) \
                     and bool((np.searchsorted(bounds, samp, side="right") - 1 == owner).all())
+                del rows
             out["read_app_window_partitioned_ms"] = [round(x, 1) for x in app_ms]
             out["read_app_window_partitioned_ms_median"] = float(np.median(app_ms))
             out["read_app_first_over_median"] = app_ms[0] / float(np.median(app_ms))

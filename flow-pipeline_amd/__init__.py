@@ -130,6 +130,7 @@ EXPORTS = [
     "fa_group_create", "fa_group_destroy", "fa_group_last_error", "fa_group_size", "fa_group_transport", "fa_group_open_timeslots",
     "fa_group_read_window", "fa_group_close_window", "fa_group_read_window_partitioned", "fa_group_close_window_partitioned",
     "fa_group_allreduce_sketches", "fa_group_topk", "fa_group_stats", "fa_read_window_app48", "fa_close_window_app48",
+    "fa_reserve_ingest",
 ]
 GROUP_PEER, GROUP_RCCL = 0, 1
 TOPK_EXACT, TOPK_CANDIDATES = 0, 1
@@ -209,6 +210,7 @@ def lib():
     L.fa_ingest.argtypes = [vp, vp, sz, vp, sz]
     L.fa_ingest_device.argtypes = [vp, vp, sz, vp, sz]
     L.fa_sync.argtypes = [vp]
+    L.fa_reserve_ingest.argtypes = [vp, sz, sz]
     L.fa_decode.argtypes = [vp, vp, sz, vp, sz, vp]
     L.fa_decode_device.argtypes = [vp, vp, sz, vp, sz, C.POINTER(Columns)]
     L.fa_open_timeslots.argtypes = [vp, vp, sz, szp]
@@ -412,6 +414,10 @@ class FlowAgg:
 
     def sync(self):
         self._chk(self._L.fa_sync(self._h))
+
+    def reserve_ingest(self, nbytes: int, records: int):
+        """Allocates the pinned staging slots (and their device twins) for host batches of up to nbytes / records now."""
+        self._chk(self._L.fa_reserve_ingest(self._h, nbytes, records))
 
     # -- decode / projection -----------------------------------------------------
     def decode(self, buf, offsets) -> np.ndarray:

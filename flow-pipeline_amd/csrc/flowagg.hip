@@ -7,6 +7,7 @@
 // ClickHouse semantics of compose/clickhouse/create.sh:5-110.
 // There is deliberately no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>

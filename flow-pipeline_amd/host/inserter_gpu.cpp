@@ -335,6 +335,11 @@ struct Phases {  // seconds of one partition thread, by what it was doing
     double mark = 0;     // session.MarkMessage + counters
     double close = 0;    // closeWindows called from this thread's timer
     uint64_t batches = 0, records = 0, bytes = 0, copied_bytes = 0;
+    // of fa_ingest, by the library's account (fa_stats_t, ABI 8): waiting for a free staging slot (the transfer / kernels of the
+    // call before the last still hold it: the GPU / PCIe side is behind), the copy into page-locked staging; the rest of the
+    // call is enqueueing (H2D, kernels, events) and the launch bookkeeping.  device_path: hipEvent time of the launches.
+    double lib_ingest = 0, lib_wait = 0, lib_copy = 0, device_path = 0;
+    uint64_t launches = 0;
 };
 struct PartitionState {
     fa_ctx* ctx = nullptr;
@@ -400,6 +405,12 @@ public:
                 cfg.framed = f_.ProtoFixed ? 1 : 0;
                 int rc = fa_create(&cfg, &p->ctx);
                 if (rc != 0) fatal("fa_create: %d %s", rc, fa_last_error(nullptr));
+                // the staging a batch of -gpu.batch.bytes needs is page-locked here, not inside the consume loop
+                if (f_.BatchBytes > 0) {
+                    const size_t bytes = (size_t)f_.BatchBytes + (64u << 10), recs = std::min<size_t>(bytes / 48, (size_t)1 << 24);
+                    if ((rc = fa_reserve_ingest(p->ctx, bytes, recs)) != 0) fatal("fa_reserve_ingest: %d %s", rc, fa_last_error(p->ctx));
+                    p->offsets.reserve(recs + 1);
+                }
                 ctxs.push_back(p->ctx);
             }
             parts_[part] = std::move(p);
@@ -551,6 +562,16 @@ public:
                     top.resize(nt);
                     out_.writeTopk(ks == FA_KEYS_SRCADDR_CMS ? "src" : "dst", top);
                 }
+            for (auto& kv : parts_) {  // the library's own account of its fa_ingest calls (ABI 8)
+                fa_stats_t ps;
+                if (kv.second->ctx && fa_stats(kv.second->ctx, &ps) == 0) {
+                    kv.second->ph.lib_ingest = ps.host_ingest_ns * 1e-9;
+                    kv.second->ph.lib_wait = ps.host_stage_wait_ns * 1e-9;
+                    kv.second->ph.lib_copy = ps.host_stage_copy_ns * 1e-9;
+                    kv.second->ph.launches = ps.kernel_launches;
+                    kv.second->ph.device_path = ps.batch_ns_total * 1e-9;
+                }
+            }
             fa_stats_t st;
             if (fa_group_stats(group_, &st) == 0) {
                 logf(2, "topic: records_ok=%llu records_bad=%llu", (unsigned long long)st.records_ok, (unsigned long long)st.records_bad);
@@ -570,10 +591,12 @@ public:
         bool first = true;
         for (auto& kv : parts_) {
             const Phases& h = kv.second->ph;
-            char b[512];
+            char b[1024];
             snprintf(b, sizeof b, "%s{\"partition\": %d, \"take_s\": %.6f, \"fa_ingest_s\": %.6f, \"lock_wait_s\": %.6f, \"mark_s\": %.6f, \"close_s\": %.6f, "
-                     "\"batches\": %llu, \"records\": %llu, \"bytes\": %llu, \"copied_bytes\": %llu}", first ? "" : ", ", kv.first, h.take, h.ingest, h.lock, h.mark, h.close,
-                     (unsigned long long)h.batches, (unsigned long long)h.records, (unsigned long long)h.bytes, (unsigned long long)h.copied_bytes);
+                     "\"batches\": %llu, \"records\": %llu, \"bytes\": %llu, \"copied_bytes\": %llu, \"lib_ingest_s\": %.6f, \"lib_stage_wait_s\": %.6f, "
+                     "\"lib_stage_copy_s\": %.6f, \"launches\": %llu, \"device_path_s\": %.6f}", first ? "" : ", ", kv.first, h.take, h.ingest, h.lock, h.mark, h.close,
+                     (unsigned long long)h.batches, (unsigned long long)h.records, (unsigned long long)h.bytes, (unsigned long long)h.copied_bytes, h.lib_ingest, h.lib_wait,
+                     h.lib_copy, (unsigned long long)h.launches, h.device_path);
             js += b;
             first = false;
         }
@@ -585,6 +608,7 @@ public:
             const Phases& h = kv.second->ph;
             t.take += h.take, t.ingest += h.ingest, t.lock += h.lock, t.mark += h.mark, t.close += h.close;
             t.batches += h.batches, t.records += h.records, t.bytes += h.bytes, t.copied_bytes += h.copied_bytes;
+            t.lib_ingest += h.lib_ingest, t.lib_wait += h.lib_wait, t.lib_copy += h.lib_copy, t.device_path += h.device_path, t.launches += h.launches;
         }
         return t;
     }
@@ -670,9 +694,11 @@ int main(int argc, char** argv) {
         const Phases t = s.phasesSum();
         const double nthr = claims.empty() ? 1.0 : (double)claims.size();
         logf(2, "consume loop, mean per partition thread: take %.3f s, fa_ingest %.3f s, lock wait %.3f s, mark %.3f s, timer closes %.3f s; %llu batches, %.1f MiB per batch, "
-                "%.1f %% of the bytes copied into a batch buffer (the rest handed over in place)",
+                "%.1f %% of the bytes copied into a batch buffer (the rest handed over in place); of fa_ingest: wait for a staging slot %.3f s, copy into "
+                "page-locked staging %.3f s; device path %.3f s in %llu launches",
              t.take / nthr, t.ingest / nthr, t.lock / nthr, t.mark / nthr, t.close / nthr, (unsigned long long)t.batches,
-             t.batches ? (double)t.bytes / (double)t.batches / 1048576.0 : 0.0, t.bytes ? 100.0 * (double)t.copied_bytes / (double)t.bytes : 0.0);
+             t.batches ? (double)t.bytes / (double)t.batches / 1048576.0 : 0.0, t.bytes ? 100.0 * (double)t.copied_bytes / (double)t.bytes : 0.0,
+             t.lib_wait / nthr, t.lib_copy / nthr, t.device_path / nthr, (unsigned long long)t.launches);
     }
     if (!f.PhasesOut.empty()) {
         FILE* fp = fopen(f.PhasesOut.c_str(), "w");

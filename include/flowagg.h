@@ -253,6 +253,11 @@ int fa_ingest(fa_ctx*, const uint8_t* buf, size_t len, const uint64_t* offsets, 
  * <= 1 GiB) uses it too; smaller host buffers are walked on the host. */
 int fa_ingest_device(fa_ctx*, const void* d_buf, size_t len, const void* d_offsets, size_t n);
 
+/* ABI 8, optional: allocates NOW what the first fa_ingest calls of a ctx would allocate inside the consumer's loop - both
+ * page-locked staging slots and their device twins, the deferral lists - for batches of up to `bytes` wire bytes in `records`
+ * records (page-locking 2 x 64 MiB costs tens of milliseconds).  A consumer calls it in Setup with its batch bound. */
+int fa_reserve_ingest(fa_ctx*, size_t bytes, size_t records);
+
 int fa_sync(fa_ctx*);
 
 /* ---- decode + project only (flows / flows_raw columns) ------------------- */
