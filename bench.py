@@ -621,7 +621,7 @@ def sec_group8(fa, po, torch, dev, ref, members=8, chunk=8_333_334, cand=True):
     return out
 
 
-def sec_host_consume(fa, po, torch, dev, n=64_000_000, nparts=8, flush_count=262144):
+def sec_host_consume(fa, po, torch, dev, n=64_000_000, nparts=8, flush_count=262144, extra=()):
     """The C++ consumer (flow-pipeline_amd/host/inserter_gpu: the reference's ConsumeClaim / flush / MarkMessage shape,
     inserter.go:113-196, one thread per claimed partition, ONE process) on BASELINE config 2's stream: 8 partition logs, key set
     flows_5m.  `value` = records / the consume phase (every partition thread from its first message to its last flush; log
@@ -665,7 +665,7 @@ def sec_host_consume(fa, po, torch, dev, n=64_000_000, nparts=8, flush_count=262
         rb, met, ph = (os.path.join(tmp, x) for x in ("flows_5m.rowbinary", "metrics.txt", "phases.json"))
         t = time.perf_counter()
         r = subprocess.run([exe, "-input.files=" + ",".join(paths), "-flush.count=%d" % flush_count, "-flush.dur=1h", "-key.sets=1", "-out.rowbinary=" + rb,
-                            "-metrics.dump=" + met, "-phases.out=" + ph, "-gpu.devices=1", "-gpu.table.log2=20", "-loglevel=info"], capture_output=True, text=True)
+                            "-metrics.dump=" + met, "-phases.out=" + ph, "-gpu.devices=1", "-gpu.table.log2=20", "-loglevel=info"] + list(extra), capture_output=True, text=True)
         out["host_wall_s"] = time.perf_counter() - t
         if r.returncode != 0:
             out.update({"ok": False, "error": r.stderr[-1500:]})
@@ -682,7 +682,9 @@ def sec_host_consume(fa, po, torch, dev, n=64_000_000, nparts=8, flush_count=262
         "records": n, "wire_bytes": wire, "value": n / phases["consume_s"], "unit": "FlowMessages/s (consume phase)",
         "wire_GBps_consume": wire / phases["consume_s"] / 1e9, "consume_s": phases["consume_s"], "setup_s": phases["setup_s"], "finish_s": phases["finish_s"],
         "records_per_s_wall_of_the_process": n / out["host_wall_s"],
-        "phases_mean_per_partition_thread_s": {k: float(np.mean([p[k] for p in parts])) for k in ("take_s", "fa_ingest_s", "lock_wait_s", "mark_s", "close_s")},
+        "phases_mean_per_partition_thread_s": {k: float(np.mean([p[k] for p in parts])) for k in ("take_s", "fa_ingest_s", "lock_wait_s", "mark_s", "close_s",
+                                                                                                   "lib_stage_wait_s", "lib_stage_copy_s", "device_path_s")},
+        "take_ns_per_record": float(np.mean([p["take_s"] / max(p["records"], 1) for p in parts])) * 1e9,
         "batches": int(sum(p["batches"] for p in parts)), "copied_bytes": int(sum(p["copied_bytes"] for p in parts)),
         "insert_count_equals_records": bool(metrics.get("insert_count") == n),
         "rowbinary_equals_oracle_rollup_of_all_partitions": bool(ref["bad"] == 0 and ref["groups"] == len(rows) and ref["checksum"] == rows_checksum(rows)

@@ -12,9 +12,6 @@
 #ifndef FA_LT_KEEP
 #define FA_LT_KEEP 8u
 #endif
-#ifndef FA_KS_LATE
-#define FA_KS_LATE 1  // wave-tile sketch variants: distinct-set probes / candidate words are looked at behind the next tile's DMA (0: right behind the sink, A/B)
-#endif
 namespace fa {
 
 // ---- per-lane work on a staged record (called by every lane of the workgroup) ------
@@ -28,16 +25,6 @@ struct LaneTally {
     uint32_t ok = 0, direct = 0, second = 0, misfit8 = 0, late = 0;
     uint32_t tick = 0;  // tiles this wave has taken through the sketch path (wave-uniform)
 };
-// What the sketch path leaves undone when the caller wants to finish it LATER (wave-tile kernel): the distinct-set probes of the
-// tile (exact mode) or its candidate test (candidates mode) - random reads that were issued in front of the flows_5m sink and
-// whose answers, looked at right behind the sink, cost the wave a memory round trip of waiting per tile, followed by a second
-// one for the next tile's DMA.  The wave-tile kernel issues that DMA first and looks at the answers then: ONE wait for both.
-struct KsDefer {
-    KsProbe ps, pd;
-    uint64_t sh1, sh2, slo, shi, dh1, dh2, dlo, dhi;
-    uint32_t cw0s, cw0d;
-    bool vs, vd, cand, on;
-};
 // T8: this launch writes compact 8-byte tuples (wave-tile kernel only; table.cuh)
 // CANDM: the top-k contract known at compile time (wave-tile variants of their own: 0 exact, 1 candidates) or read from the launch
 // arguments (-1)
@@ -47,7 +34,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                                           LaneTally& tally, uint32_t& pmode, uint32_t& lt_seen, uint32_t& lt_hits,
                                           uint4* bins, uint32_t* bin_cnt, uint32_t& fill_out, Hook&& after_parse = Hook(),
                                           CmsLds* cl = nullptr, uint32_t* cms_scratch = nullptr, HotAddrs* hot = nullptr,
-                                          uint32_t* wpart_cnt = nullptr, uint32_t* seq = nullptr, KsDefer* kd = nullptr) {
+                                          uint32_t* wpart_cnt = nullptr, uint32_t* seq = nullptr) {
     constexpr uint32_t TB = bin_cap<T8, bin_line(KEYSETS)>();
     // ---- parse (divergent: only lanes that own a staged record) ----
     bool sure = false, framed_ok = false;
@@ -324,20 +311,8 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                 if (vd) cms_add(a.cms_dst, a.cms_depth, a.cms_wl2, a.cms_seed, r.dst, wd, a.cms_nrep);
             }
         }
-        if (kd) {  // (the caller finishes the distinct sets / the candidate test behind its next DMA: ks_finish)
-            kd->on = keys_on;
-            kd->cand = cand;
-            kd->vs = vs;
-            kd->vd = vd;
-            kd->ps = ps;
-            kd->pd = pd;
-            kd->sh1 = sh1, kd->sh2 = sh2, kd->slo = slo, kd->shi = shi;
-            kd->dh1 = dh1, kd->dh2 = dh2, kd->dlo = dlo, kd->dhi = dhi;
-            kd->cw0s = cw0s, kd->cw0d = cw0d;
-        } else if (keys_on && !cand) {
-            keyset_finish2(a, vs, ps, sh1, slo, shi, vd, pd, dh1, dlo, dhi);
-        }
-        if (!kd && keys_on && cand) {
+        if (keys_on && !cand) keyset_finish2(a, vs, ps, sh1, slo, shi, vd, pd, dh1, dlo, dhi);
+        if (keys_on && cand) {
             // the few addresses whose estimate stood above the threshold at the last boundary join the candidates.  What this costs
             // is the test of EVERY address instance, not the set (same-box ablation, measurement build, 16.67 M records per launch:
             // no test at all 0.940 ms; the row-0 word of every instance +0.117; all four rows' words loaded ahead of the sink
@@ -354,24 +329,6 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
         }
     }
     if (KEYSETS & FA_KEYS_WIDE) wide_sink_wave<KEYSETS>(a, lm, r, sure, tb, tb_base, wpart_cnt);
-}
-
-// the second half of lane_work's sketch path, for the caller that asked for it back (KsDefer): whole wave
-template <int CANDM>
-__device__ __forceinline__ void ks_finish(const KArgs& a, const KsDefer& k) {
-    if (!k.on) return;
-    const bool cand = CANDM >= 0 ? CANDM == 1 : k.cand;
-    if (!cand) {
-        keyset_finish2(a, k.vs, k.ps, k.sh1, k.slo, k.shi, k.vd, k.pd, k.dh1, k.dlo, k.dhi);
-        return;
-    }
-    // (see the candidates branch of lane_work for what this test costs and why one word is asked early, the rest late)
-    const bool is = k.vs && cand_pass(a.cand_src, a.cms_depth, a.cms_wl2, cms_key(k.sh1, k.sh2, a.cms_wl2), k.cw0s);
-    const bool id = k.vd && cand_pass(a.cand_dst, a.cms_depth, a.cms_wl2, cms_key(k.dh1, k.dh2, a.cms_wl2), k.cw0d);
-    if (FA_ANY(is || id) && !FA_DBG(a, DBG_CAND_NO_SET)) {
-        if (is) keyset_insert_h(a, a.ks_src, k.slo, k.shi, k.sh1);
-        if (id) keyset_insert_h(a, a.ks_dst, k.dlo, k.dhi, k.dh1);
-    }
 }
 
 // End-of-kernel counters: one global atomic per WORKGROUP.  All waves of the grid finish at about the same
@@ -851,14 +808,9 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
             rest = rest && !hopeless;
         }
         uint32_t fill = 0xffffffffu;  // the bin this lane fills in this round
-        // (the sketch variants of the scatter sink take the distinct-set / candidate answers back and look at them behind the next
-        // tile's DMA - ks_finish below; the generic variant, which also serves the wide key sets, keeps them inside lane_work)
-        constexpr bool KS_LATE = HAS_CMS && KEYSETS != KS_ALL && FA_KS_LATE;
-        KsDefer kd;
-        kd.on = false;
         lane_work<MODE_INGEST, KEYSETS, COLS, T8, CANDM>(a, lt, lm, part_cnt, tile, staged, cur.q0 - cbase, cur.q1 - cbase, cur.r0 + lane, tb_base, tally,
                                                   pmode, lt_seen, lt_hits, bins, bin_cnt, fill, NoHook(), cl, cms_scratch_all + (HAS_CMS ? wave * 16 : 0), hot,
-                                                  (HAS_APP && a.wseg) ? wpart_cnt : nullptr, HAS_SEQ ? seq_all + wave * (SEQ_MAX + 2) : nullptr, KS_LATE ? &kd : nullptr);
+                                                  (HAS_APP && a.wseg) ? wpart_cnt : nullptr, HAS_SEQ ? seq_all + wave * (SEQ_MAX + 2) : nullptr);
         // (sketch variants, round 3: starting the next tile's DMA right behind the parse - the sink is long there and does
         // not look at the tile's bytes - measured +1.8 %, like the following for the lean variants)
         // full bins leave BEFORE the next DMA is issued: behind it their stores would sit in the in-order vmcnt
@@ -869,7 +821,6 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
             live = rest;
             cur_lo = (uint32_t)__builtin_amdgcn_readlane((int)cur.q0, (int)__builtin_ctzll(restm));
             issue_dma(cur_lo, cur_hi);
-            if (KS_LATE) ks_finish<CANDM>(a, kd);
             continue;
         }
         t2_have = false;
@@ -879,9 +830,6 @@ __global__ __launch_bounds__(wtile_block<KEYSETS>(), wt_lean(KEYSETS) ? 6 : 4) v
         live = lane < cur.nrec;
         issue_dma(cur_lo, cur_hi);  // next tile (the buffer is free: every read of the old tile has returned)
         nxt = tile_load(t2);
-        // the answers of this tile's distinct-set probes / candidate words: looked at HERE, with the next tile's DMA (and the
-        // offsets of the one after it) already on their way - the wait for them is the wait for the DMA
-        if (KS_LATE) ks_finish<CANDM>(a, kd);
     }
     // what is left in the bins (fewer than a line each) goes to the back part of the segments
     if ((KEYSETS & FA_KEYS_AS_PAIR) && a.seg) {

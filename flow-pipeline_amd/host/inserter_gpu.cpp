@@ -220,6 +220,35 @@ public:
     int32_t Partition() const { return part_; }
     // more messages buffered on the client side, i.e. next() would not block (sarama: len(claim.Messages()) > 0)
     bool ready() const { return pos_ < log_.size; }
+    const uint8_t* peek() const { return pos_ < log_.size ? &log_[pos_] : nullptr; }  // where the next message's value starts
+    // The messages that are READY, taken in one go (what a sarama consumer does when it drains len(claim.Messages()) without
+    // blocking; librdkafka: consume_batch): as many as fit `max_msgs` / stop once `bytes_so_far` + their bytes reaches
+    // `byte_bound`, but only while each one starts where the previous one ended in the client's fetch buffer - the batch then is a
+    // byte range, handed to the sink in place.  ends[i] = bytes_so_far + bytes of messages 0..i (the sink's offsets array); `last`
+    // = the newest message taken.  Returns the count (0: the next message is not contiguous / not a short frame - take it with
+    // next()).  The loop is a dependent chain (a message's length byte tells where the next one starts): one prefetch ahead keeps
+    // the lines coming.
+    size_t next_run(size_t max_msgs, size_t bytes_so_far, size_t byte_bound, const uint8_t* expect_at, uint64_t* ends, ConsumerMessage& last) {
+        if (len32_ || pos_ >= log_.size || (expect_at && expect_at != &log_[pos_])) return 0;
+        const uint8_t* const base = log_.data;
+        const size_t safe_end = log_.size > 256 ? log_.size - 256 : 0;  // (one-byte prefixes only, whole message inside the log)
+        size_t pos = pos_, n = 0, bytes = bytes_so_far, prev = pos_;
+        while (n < max_msgs && pos < safe_end && bytes < byte_bound) {
+            const uint8_t b = base[pos];
+            if (b & 0x80) break;
+            __builtin_prefetch(base + pos + 1024);
+            prev = pos;
+            pos += 1u + (size_t)b;
+            bytes += 1u + (size_t)b;
+            ends[n++] = bytes;
+        }
+        if (n) {
+            last = ConsumerMessage{part_, off_ + (int64_t)n - 1, base + prev, pos - prev};
+            off_ += (int64_t)n;
+            pos_ = pos;
+        }
+        return n;
+    }
     bool next(ConsumerMessage& m) {
         if (pos_ >= log_.size) return false;
         size_t start = pos_, len = 0;
@@ -348,15 +377,46 @@ struct PartitionState {
     const uint8_t* run = nullptr;
     size_t run_len = 0;
     std::vector<uint8_t> buf;
-    std::vector<uint64_t> offsets;  // n+1 entries
+    // offsets[0 .. pending]: where message i starts in the batch, offsets[pending] = its bytes (a plain array: the bulk path
+    // writes into it directly, and a vector would zero what it hands out)
+    std::unique_ptr<uint64_t[]> offsets;
+    size_t offsets_cap = 0;
     size_t pending = 0;             // messages in the batch
     ConsumerMessage last{};         // the newest of them: offsets of one partition are monotone, marking it commits the batch
     Phases ph;
     size_t bytes() const { return run ? run_len : buf.size(); }
+    bool empty() const { return pending == 0; }
+    // in place so far (or empty): the bulk path may go on; -> where the next message has to start (nullptr: anywhere)
+    bool in_place() const { return pending == 0 || run != nullptr; }
+    const uint8_t* run_end() const { return pending == 0 ? nullptr : run + run_len; }
+    uint64_t* offsets_room(size_t more) {  // room for `more` offsets behind the batch; -> where they go
+        if (pending + 1 + more > offsets_cap) {
+            const size_t cap = std::max<size_t>(2 * offsets_cap, pending + 1 + more + 4096);
+            std::unique_ptr<uint64_t[]> grown(new uint64_t[cap]);
+            if (offsets_cap) memcpy(grown.get(), offsets.get(), (pending + 1) * sizeof(uint64_t));
+            else grown[0] = 0;
+            offsets = std::move(grown);
+            offsets_cap = cap;
+        }
+        return offsets.get() + pending + 1;
+    }
+    // `n` contiguous messages, the first at `first`, the newest `lastm`, were written behind the batch by
+    // ConsumerGroupClaim::next_run (their ends are in the offsets already)
+    void took_run(size_t n, const uint8_t* first, const ConsumerMessage& lastm) {
+        if (!n) return;
+        if (pending == 0) {
+            run = first;
+            buf.clear();
+        }
+        pending += n;
+        run_len = (size_t)offsets[pending];
+        last = lastm;
+    }
     void append(const ConsumerMessage& m) {
-        if (pending == 0 && buf.empty()) {
+        if (pending == 0) {
             run = m.Value;
             run_len = m.Len;
+            buf.clear();
         } else if (run && m.Value == run + run_len) {
             run_len += m.Len;
         } else {
@@ -369,9 +429,15 @@ struct PartitionState {
             buf.insert(buf.end(), m.Value, m.Value + m.Len);
             ph.copied_bytes += m.Len;
         }
-        offsets.push_back(bytes());
+        *offsets_room(1) = bytes();
         last = m;
         pending++;
+    }
+    void reset() {
+        run = nullptr;
+        run_len = 0;
+        buf.clear();
+        pending = 0;
     }
 };
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -386,7 +452,7 @@ public:
         std::vector<fa_ctx*> ctxs;
         for (int32_t part : session.claims) {
             auto p = std::make_unique<PartitionState>();
-            p->offsets.assign(1, 0);
+            (void)p->offsets_room(1);  // (offsets[0] = 0)
             if (!f_.DryRun) {
                 fa_config cfg;
                 memset(&cfg, 0, sizeof cfg);
@@ -409,9 +475,12 @@ public:
                 if (f_.BatchBytes > 0) {
                     const size_t bytes = (size_t)f_.BatchBytes + (64u << 10), recs = std::min<size_t>(bytes / 48, (size_t)1 << 24);
                     if ((rc = fa_reserve_ingest(p->ctx, bytes, recs)) != 0) fatal("fa_reserve_ingest: %d %s", rc, fa_last_error(p->ctx));
-                    p->offsets.reserve(recs + 1);
                 }
                 ctxs.push_back(p->ctx);
+            }
+            if (f_.BatchBytes > 0) {  // the batch's offsets: allocated and touched here, not page by page inside the consume loop
+                const size_t recs = std::min<size_t>(((size_t)f_.BatchBytes + (64u << 10)) / 48, (size_t)1 << 24);
+                memset(p->offsets_room(recs + 1), 0, (recs + 1) * sizeof(uint64_t));
             }
             parts_[part] = std::move(p);
         }
@@ -439,7 +508,33 @@ public:
             acc += t - t_mark;
             t_mark = t;
         };
-        while (claim.next(m)) {
+        for (;;) {
+            // the bulk path: every message that is ready and lies right behind the batch in the client's buffer, up to the next
+            // decision point - the -flush.count trip, beyond it the byte bound, the clock every 4096 messages
+            if (p->in_place()) {
+                const bool below = p->pending < flush_count;
+                const size_t want = below ? std::min<size_t>(4096, flush_count - p->pending) : 4096;
+                const uint8_t* first = claim.peek();
+                const size_t got = claim.next_run(want, p->bytes(), below ? (size_t)-1 : std::max<size_t>(batch_bytes, 1), p->run_end(), p->offsets_room(want), m);
+                if (got) {
+                    p->took_run(got, first, m);
+                    if (p->pending >= flush_count && (p->bytes() >= batch_bytes || !claim.ready())) {
+                        lap(p->ph.take);
+                        flush(*p, session);
+                        t_mark = now_s();
+                    }
+                    if (std::chrono::steady_clock::now() >= deadline) {  // inserter.go:189-191
+                        lap(p->ph.take);
+                        flush(*p, session);
+                        t_mark = now_s();
+                        closeWindows((int64_t)time(nullptr), false);
+                        lap(p->ph.close);
+                        deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(f_.FlushTime);
+                    }
+                    continue;
+                }
+            }
+            if (!claim.next(m)) break;
             p->append(m);
             // inserter.go:118-120 - and, beyond the reference, a batch keeps growing while the claim has messages ready (header)
             if (p->pending >= flush_count && (p->bytes() >= batch_bytes || !claim.ready())) {
@@ -463,7 +558,7 @@ public:
 
     // flush = inserter.go:90-111 with the per-row db.Exec loop replaced by one fa_ingest
     void flush(PartitionState& p, ConsumerGroupSession& session) {
-        const size_t n = p.offsets.size() - 1;
+        const size_t n = p.pending;
         if (n == 0) return;
         const uint8_t* data = p.run ? p.run : p.buf.data();
         const size_t len = p.bytes();
@@ -476,7 +571,7 @@ public:
             const double t1 = now_s();
             p.ph.lock += t1 - t0;
             // fa_ingest copies into library-owned pinned memory before returning
-            int rc = fa_ingest(p.ctx, data, len, p.offsets.data(), n);
+            int rc = fa_ingest(p.ctx, data, len, p.offsets.get(), n);
             if (rc != 0) fatal("fa_ingest: %d %s", rc, fa_last_error(p.ctx));  // sink error is fatal, inserter.go:102-105
             t0 = now_s();
             p.ph.ingest += t0 - t1;
@@ -488,11 +583,7 @@ public:
         p.ph.batches += 1;
         p.ph.records += n;
         p.ph.bytes += len;
-        p.run = nullptr;
-        p.run_len = 0;
-        p.buf.clear();
-        p.offsets.assign(1, 0);
-        p.pending = 0;
+        p.reset();
         p.ph.mark += now_s() - t0;
     }
 

@@ -162,10 +162,33 @@ def test_group_create_checks_its_members(gpu_lib, fa):
             fa.FlowGroup([a, fa.FlowAgg(key_sets=1)], transport=fa.GROUP_RCCL)
         assert ei.value.code == -8
         with fa.FlowGroup([a]) as g:
+            with pytest.raises(fa.FlowAggError) as ei:  # a ctx is a member of one group at a time
+                fa.FlowGroup([a, fa.FlowAgg(key_sets=1)])
+            assert ei.value.code == -1 and "already a member" in str(ei.value)
             with pytest.raises(fa.FlowAggError):
                 g.allreduce_sketches()  # no sketch key set
             with pytest.raises(fa.FlowAggError):
                 g.close_window(fa.ROWS_PORT_SRC)  # not a windowed kind
+
+
+def test_group_create_wants_one_topk_contract(gpu_lib, fa):
+    """a group ranks by ONE top-k contract - mixed exact / candidates members are refused, and so are candidates members
+    whose thresholds would follow different ranks or set sizes (the capacity is part of theta); in the exact mode the capacity
+    is only a size.  A ctx leaves its group when the group is destroyed."""
+    kw = dict(key_sets=7, cms_width_log2=14)
+    with fa.FlowAgg(topk_capacity_log2=12, **kw) as ex, fa.FlowAgg(topk_capacity_log2=14, **kw) as ex2, \
+            fa.FlowAgg(topk_mode=fa.TOPK_CANDIDATES, topk_capacity_log2=12, **kw) as ca, \
+            fa.FlowAgg(topk_mode=fa.TOPK_CANDIDATES, topk_capacity_log2=12, topk_track=64, **kw) as ca_track, \
+            fa.FlowAgg(topk_mode=fa.TOPK_CANDIDATES, topk_capacity_log2=13, **kw) as ca_cap, \
+            fa.FlowAgg(topk_mode=fa.TOPK_CANDIDATES, topk_capacity_log2=12, **kw) as ca2:
+        for bad in ([ex, ca], [ca, ca_track], [ca, ca_cap]):
+            with pytest.raises(fa.FlowAggError) as ei:
+                fa.FlowGroup(bad)
+            assert ei.value.code == -1 and "top-k" in str(ei.value)
+        with fa.FlowGroup([ex, ex2]) as g:
+            assert g.transport == fa.GROUP_PEER
+        with fa.FlowGroup([ca, ca2]), fa.FlowGroup([ex, ex2]):  # (released above: members again)
+            pass
 
 
 def test_group_over_rccl_world_1(gpu_lib, fa, po):

@@ -412,6 +412,10 @@ def test_bench_launches_its_own_ranks(gpu_lib):
     assert par["ok"] and par["ranks_ok"] == [True, True] and par["records_verified"] == 6_000_000
     assert par["merged_rows_equal_oracle_rollup_of_all_partitions"] == [True, True]
     assert len(out["roofline"]["per_rank_path_ms"]) == 2 and "cpu_baseline" not in out
+    # rank 0's in-process group close on every visible device (one here), in a process of its own: both transports against the oracle
+    gp = out["group_preflight"]
+    assert gp["ok"] and gp["devices"] >= 1 and gp["peer"]["ok"] and gp["peer"]["topk"] and gp["peer"]["close_window_app_partitioned"], gp
+    assert out["ms_per_step_all"] and len(out["ms_per_step_all"]) == 2 and out["settle"]["steps"] >= 1
     # without the sharing switch the same command refuses to oversubscribe the GPU instead of hanging in RCCL
     env.pop("FA_BENCH_SHARE_GPU")
     import torch
@@ -419,6 +423,27 @@ def test_bench_launches_its_own_ranks(gpu_lib):
         r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                            timeout=300, env=env, cwd=ROOT)
         assert r.returncode != 0 and "FA_BENCH_SHARE_GPU" in (r.stderr + r.stdout)
+
+
+def test_reserve_ingest_and_host_phase_stats(gpu_lib, fa, po):
+    """fa_reserve_ingest (ABI 8) sizes the staging a consumer's batches need up front; the rows do not depend on it, and the
+    library accounts for the host time of its fa_ingest calls (fa_stats_t.host_*_ns)."""
+    n = 300_000
+    gp = po.gen_params(mode=po.GEN_ASPAIRS, framed=1, seed=31, n_total=n)
+    buf, off = po.gen_records(gp, 0, n)
+    ref = po.Rollup(300)
+    assert ref.ingest(buf, off, 1) == 0
+    with fa.FlowAgg(framed=True) as a, fa.FlowAgg(framed=True) as b:
+        a.reserve_ingest(len(buf) + 1024, n)
+        with pytest.raises(fa.FlowAggError):
+            a.reserve_ingest(1 << 33, n)  # a batch is < 4 GiB
+        for agg in (a, b):
+            for lo in range(0, n, 100_000):
+                o = off[lo:lo + 100_001]
+                agg.ingest(buf[int(o[0]):int(o[-1])], o - o[0])
+            assert agg.read_window().tobytes() == ref.rows().tobytes()
+            st = agg.stats()
+            assert st["host_ingest_ns"] > 0 and st["host_stage_copy_ns"] > 0 and st["host_ingest_ns"] >= st["host_stage_copy_ns"] + st["host_stage_wait_ns"]
 
 
 def test_bench_side_measurements_run(gpu_lib):

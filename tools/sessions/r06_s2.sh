@@ -34,3 +34,17 @@ for l in open("gpurun_out/s2/side_measurements.jsonl"):
     d = json.loads(l); r = d["roofline"]
     print(d["config"]["workload"][:90], "| frac", round(r["frac"], 4), "| kernel", round(r.get("dominant_kernel", {}).get("frac", 0), 4), "| G rec/s", round(d["value"] / 1e9, 2))
 PY
+# config 3, same box: the library before / after "probe answers behind the next DMA" (FA_KS_LATE), both top-k modes
+for rep in 1 2 3; do
+  for mode in exact candidates; do
+    for v in base new; do
+      if [ $v = base ]; then export FA_LIB_VARIANT=base; else unset FA_LIB_VARIANT; fi
+      python tools/config3_run.py --records 200000000 --timing-only --topk-mode $mode 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(json.dumps({'exp':'ks_late','lib':'$v','mode':'$mode','rep':$rep,'path_ms_per_launch':d['path_ms_per_launch'],'last_third':d['path_ms_last_third_mean'],'frac':d['roofline_frac_path']}))" >> $O/exp_ks_late.jsonl
+    done
+  done
+done
+unset FA_LIB_VARIANT
+cat $O/exp_ks_late.jsonl
