@@ -85,7 +85,9 @@ def main():
             cnt = by = nrows = 0
             owned_ok = True
             app_ms = []
-            buf_rows = 1 << 22
+            # (rows of a window <= its records; a buffer that is too small costs a whole close: the library reports the size it needs
+            # only after collect + exchange + merge - round 5's "first close 2x the median" was mostly this retry)
+            buf_rows = 2 * n // max(len(slots), 1) + (1 << 20)
             for ts in slots:
                 t = time.perf_counter()
                 rows, shares = g.read_window_partitioned(fa.ROWS_APP, ts, cap=buf_rows)
