@@ -310,11 +310,11 @@ public:
     }
     bool wantsApp() const { return app_ != nullptr; }
     bool wantsTopk() const { return topk_ != nullptr; }
-    void writeApp(const std::vector<fa_row_app>& rows) {  // (SrcAddr,DstPort,Proto) rows of a closed window, as they are
-        if (rows.empty() || !app_) return;
+    void writeApp(const fa_row_app* rows, size_t n) {  // (SrcAddr,DstPort,Proto) rows of a closed window, as they are
+        if (!n || !app_) return;
         std::lock_guard<std::mutex> g(mu_);
-        if (fwrite(rows.data(), sizeof(fa_row_app), rows.size(), app_) != rows.size()) fatal("short write on the app-rows sink");
-        RowsOut += rows.size();
+        if (fwrite(rows, sizeof(fa_row_app), n, app_) != n) fatal("short write on the app-rows sink");
+        RowsOut += n;
     }
     void writeTopk(const char* which, const std::vector<fa_topk_row>& rows) {
         if (!topk_) return;
@@ -325,20 +325,22 @@ public:
             fprintf(topk_, "\t%llu\n", (unsigned long long)r.weight);
         }
     }
-    void write(const std::vector<fa_row5m>& rows) {
-        if (rows.empty()) return;
+    void write(const fa_row5m* rows, size_t nrows) {
+        if (!nrows) return;
         std::lock_guard<std::mutex> g(mu_);
         if (rb_) {
-            std::vector<uint8_t> buf(rows.size() * FA_ROWBINARY_ROW5M_BYTES);
+            rbuf_.resize(nrows * FA_ROWBINARY_ROW5M_BYTES);
             size_t n = 0;
-            if (fa_rows_to_rowbinary(rows.data(), rows.size(), buf.data(), buf.size(), &n) != 0) fatal("fa_rows_to_rowbinary failed");
-            if (fwrite(buf.data(), 1, n, rb_) != n) fatal("short write on the RowBinary sink");
+            if (fa_rows_to_rowbinary(rows, nrows, rbuf_.data(), rbuf_.size(), &n) != 0) fatal("fa_rows_to_rowbinary failed");
+            if (fwrite(rbuf_.data(), 1, n, rb_) != n) fatal("short write on the RowBinary sink");
         }
         if (tsv_)
-            for (auto& r : rows)
+            for (size_t i = 0; i < nrows; i++) {
+                const fa_row5m& r = rows[i];
                 fprintf(tsv_, "%u\t%u\t%u\t%u\t%u\t%llu\t%llu\t%llu\n", r.date, r.timeslot, r.src_as, r.dst_as, r.etype,
                         (unsigned long long)r.bytes, (unsigned long long)r.packets, (unsigned long long)r.count);
-        RowsOut += rows.size();
+            }
+        RowsOut += nrows;
     }
     void close() {
         if (rb_) fclose(rb_);
@@ -350,6 +352,7 @@ public:
 
 private:
     std::mutex mu_;
+    std::vector<uint8_t> rbuf_;
     FILE* rb_ = nullptr;
     FILE* tsv_ = nullptr;
     FILE* app_ = nullptr;
@@ -606,17 +609,19 @@ public:
             const uint32_t ts = slots[i];
             if (!all && (int64_t)ts + gran + f_.CloseLagSec > now) continue;
             if (out_.wantsApp() && ((uint32_t)f_.KeySets & FA_KEYS_ADDR_PORT_PROTO)) {
-                std::vector<fa_row_app> app(1 << 16);
+                // (the row buffer is the session's: a buffer that is too small costs the close twice - the library knows the size it
+                // needs only after collect + exchange + merge - so it keeps the largest window seen, with room to spare)
+                std::vector<fa_row_app>& app = app_rows_;
+                if (app.size() < (1u << 16)) app.resize(1u << 16);
                 size_t na = 0;
                 rc = fa_group_close_window_partitioned(group_, FA_ROWS_APP, ts, app.data(), app.size(), nullptr, &na);
                 if (rc == FA_ERR_CAPACITY) {
-                    app.resize(na);
+                    app.resize(na + na / 4);
                     rc = fa_group_close_window_partitioned(group_, FA_ROWS_APP, ts, app.data(), app.size(), nullptr, &na);
                 }
                 if (rc != 0) fatal("fa_group_close_window_partitioned: %d %s", rc, fa_group_last_error(group_));
-                app.resize(na);
                 logf(2, "(SrcAddr,DstPort,Proto) timeslot %u: %zu rows", ts, na);
-                out_.writeApp(app);
+                out_.writeApp(app.data(), na);
             } else if ((uint32_t)f_.KeySets & FA_KEYS_ADDR_PORT_PROTO) {
                 // the key set is on but nobody takes its rows: the window is closed all the same (dropped on every member) -
                 // kept, the wide table / wide log would grow for the life of the session
@@ -624,17 +629,17 @@ public:
                     if (kv.second->ctx && (rc = fa_drop_window(kv.second->ctx, FA_ROWS_APP, ts)) != 0)
                         fatal("fa_drop_window(FA_ROWS_APP): %d %s", rc, fa_last_error(kv.second->ctx));
             }
-            std::vector<fa_row5m> rows(1 << 16);
+            std::vector<fa_row5m>& rows = rows5m_;
+            if (rows.size() < (1u << 16)) rows.resize(1u << 16);
             size_t nr = 0;
             rc = fa_group_close_window(group_, FA_ROWS_5M, ts, rows.data(), rows.size(), &nr);
             if (rc == FA_ERR_CAPACITY) {
-                rows.resize(nr);
+                rows.resize(nr + nr / 4);
                 rc = fa_group_close_window(group_, FA_ROWS_5M, ts, rows.data(), rows.size(), &nr);
             }
             if (rc != 0) fatal("fa_group_close_window: %d %s", rc, fa_group_last_error(group_));
-            rows.resize(nr);
             logf(2, "flows_5m timeslot %u: %zu rows", ts, nr);
-            out_.write(rows);
+            out_.write(rows.data(), nr);
         }
     }
 
@@ -719,6 +724,8 @@ private:
     std::map<int32_t, std::unique_ptr<PartitionState>> parts_;
     fa_group* group_ = nullptr;
     uint64_t bad_ = 0;
+    std::vector<fa_row_app> app_rows_;  // row buffers of the window close (under close_mu_): kept between closes
+    std::vector<fa_row5m> rows5m_;
 };
 
 // a partition log, mapped (the page cache is the only copy; a Kafka client would hand out its fetch buffers the same way)

@@ -131,6 +131,7 @@ type state struct {
 	// (fa_ingest on one goroutine's own context) hold closeMu for reading and a close holds it for writing
 	group   *C.fa_group
 	closeMu sync.RWMutex
+	rows5m  []C.fa_row5m // row buffer of the window close (under closeMu): kept between closes
 }
 
 func (s *state) metricsHTTP() {
@@ -323,11 +324,17 @@ func (s *state) closeWindows(now time.Time, all bool) {
 		if !all && int64(ts)+int64(*WindowSecs)+int64(*CloseLagSec) > now.Unix() {
 			continue
 		}
-		rows := make([]C.fa_row5m, 1<<16)
+		// (the row buffer is the session's: a buffer that is too small costs the close twice - the library knows the size it needs
+		// only after collect + exchange + merge - so it keeps the largest window seen, with room to spare)
+		if len(s.rows5m) < 1<<16 {
+			s.rows5m = make([]C.fa_row5m, 1<<16)
+		}
+		rows := s.rows5m
 		var nr C.size_t
 		rc := C.fa_group_close_window(s.group, C.FA_ROWS_5M, C.uint32_t(ts), unsafe.Pointer(&rows[0]), C.size_t(len(rows)), &nr)
 		if rc == C.FA_ERR_CAPACITY { // (nothing was removed: ask again with room)
-			rows = make([]C.fa_row5m, int(nr))
+			s.rows5m = make([]C.fa_row5m, int(nr)+int(nr)/4)
+			rows = s.rows5m
 			rc = C.fa_group_close_window(s.group, C.FA_ROWS_5M, C.uint32_t(ts), unsafe.Pointer(&rows[0]), C.size_t(len(rows)), &nr)
 		}
 		if rc != 0 {
