@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per launch from rocprofv3 PMC passes of THIS command line (tools/profile.sh; PMC counters cannot be
 # read from inside the process).  Quoted only for the default workload AND when the file was produced by the very
 # sources this process runs (source_hash stamp).
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_traffic.json")
 SOA_BYTES_PER_RECORD = 5 * 8 + 7 * 4 + 3 * 16 + 1  # fa_columns: 15 columns + status byte
 
 
@@ -65,7 +65,7 @@ def pmc_traffic(fa, default_workload):
     with open(TRAFFIC_FILE) as f:
         t = json.load(f)
     if t.get("source_hash") != fa.source_hash():
-        return None, None, "profiles/r05_traffic.json was measured on other sources (%s != %s)" % (t.get("source_hash"), fa.source_hash())
+        return None, None, "profiles/r06_traffic.json was measured on other sources (%s != %s)" % (t.get("source_hash"), fa.source_hash())
     k = t.get("kernels", {})
     total = sum(v.get("traffic_bytes", 0.0) for v in k.values())
     return total or None, k, None
@@ -1149,7 +1149,7 @@ def main():
         "unit": "GB/s",
         "frac": achieved_path / HBM_PEAK_GBS,
         "traffic": traffic,
-        "traffic_source": ("profiles/r05_traffic.json (sources %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch, summed over the path's kernels; "
+        "traffic_source": ("profiles/r06_traffic.json (sources %s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per launch, summed over the path's kernels; "
                            "FETCH_SIZE calibrated on known byte counts (tools/micro/fetch_calib.hip): streaming reads x2, random 64-byte requests x1" % fa.source_hash()) if traffic else traffic_note,
         "kernel": ("decode+aggregate path of one launch: fa::wtile_kernel<%s, %s> + fa::deferred_kernel + %s" % (ks_name, t8, agg_name)) if wave
                   else "decode+aggregate path of one launch: fa::tile_kernel<MODE_INGEST, %s> + fa::deferred_kernel" % ks_name,

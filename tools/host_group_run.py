@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--partitions", type=int, default=8)
     ap.add_argument("--flush", type=int, default=262144)
     ap.add_argument("--universe-log2", type=int, default=20)
+    ap.add_argument("--topk-mode", default="auto", choices=["auto", "exact", "candidates"], help="auto = the program's default: candidates with more than one partition")
     args = ap.parse_args()
     fa = _pkg.load()
     po = _pkg.load_oracle()
@@ -51,7 +52,8 @@ def main():
         rb, app, topk, met = (os.path.join(tmp, x) for x in ("flows_5m.rowbinary", "app.rows", "topk.tsv", "metrics.txt"))
         t = time.perf_counter()
         r = subprocess.run([os.path.join(host, "inserter_gpu"), "-input.files=" + ",".join(paths), "-flush.count=%d" % args.flush, "-flush.dur=1h", "-key.sets=15",
-                            "-out.rowbinary=" + rb, "-out.app=" + app, "-out.topk=" + topk, "-topk.k=100", "-metrics.dump=" + met, "-gpu.devices=1", "-gpu.keyset.log2=22", "-gpu.wide.log2=25", "-loglevel=info"],
+                            "-out.rowbinary=" + rb, "-out.app=" + app, "-out.topk=" + topk, "-topk.k=100", "-metrics.dump=" + met, "-gpu.devices=1", "-gpu.wide.log2=25", "-loglevel=info",
+                            "-topk.mode=" + args.topk_mode] + (["-gpu.keyset.log2=22"] if args.topk_mode == "exact" else []),
                            capture_output=True, text=True)
         out["host_wall_s"] = time.perf_counter() - t
         if r.returncode != 0:
@@ -63,6 +65,11 @@ def main():
         app_rows = np.fromfile(app, dtype=fa.ROW_APP_DTYPE)
         lines = [l.split("\t") for l in open(topk).read().splitlines()]
     out["insert_count"] = metrics["insert_count"]
+    out["topk_mode"] = args.topk_mode
+    cand = args.topk_mode != "exact"  # (auto: more than one partition -> candidates)
+    # device tables of one partition's ctx: distinct-address sets 2 x 32 B x 2^log2, sketches 2 x 4 x 2^20 x 8 B (+ their merged views), flows_5m table 64 B x 2^20, wide 64 B x 2^25
+    out["table_bytes_per_partition"] = {"distinct_address_sets": 2 * 32 << (16 if cand else 22), "sketches_and_merged_views": 4 * 4 * 8 << 20, "flows_5m_table": 64 << 20, "wide_table": 64 << 25}
+    out["distinct_address_sets_bytes_all_partitions"] = nparts * (2 * 32 << (16 if cand else 22))
     out["records_per_s_wall_including_file_reads"] = n / out["host_wall_s"]
     threads = min(64, effective_cpus()[0])
     ref = po.bench_rollup_ex(gp, 0, n, threads, groups_hint=len(rows))
