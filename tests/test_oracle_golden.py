@@ -378,3 +378,34 @@ def test_linear_app_checksum_equals_the_grouped_rollups(po):
     # slots that do not cover the stream: the rest is counted outside
     _, c2, out2 = po.app_checksum_stream(gp, 0, n, 2, 300, po.T0 + 300, 1)
     assert out2 == n - int(cnts[1]) and int(c2[0]) == int(cnts[1])
+
+
+def test_bench_restatements_agree_with_the_oracle(po):
+    """bench.py's secondary blocks rank the whole address universe with numpy (16 M addresses x 2 forms: the C oracle's per-key
+    query would take minutes): its restatements of the generator's addresses and of the sketch's columns == the oracle's."""
+    import bench
+    L, depth, wl2, seed = 10, 4, 12, 0x5EED
+    for dst in (0, 1):
+        lo, hi = bench._universe_keys(L, dst)
+        for rank in (0, 1, 7, 513, (1 << L) - 1):
+            for v6 in (0, 1):
+                key = po.zipf_key(rank, dst, v6)
+                i = rank + (v6 << L)
+                assert lo[i].tobytes() + hi[i].tobytes() == key, (dst, rank, v6)
+    n = 50_000
+    gp = po.gen_params(mode=po.GEN_ZIPF, framed=1, seed=3, n_total=n, zipf_log2_universe=L, zipf_s_x100=110)
+    c_src = np.zeros(depth << wl2, dtype=np.uint64)
+    c_dst = np.zeros(depth << wl2, dtype=np.uint64)
+    po.cms_stream(gp, 0, n, 2, depth, wl2, seed, c_src, c_dst)
+    for dst, cms in enumerate((c_src, c_dst)):
+        lo, hi = bench._universe_keys(L, dst)
+        est = bench._estimates(cms, lo, hi, depth, wl2, seed)
+        keys = np.stack([lo, hi], axis=1).view(np.uint8).reshape(-1, 16)
+        assert np.array_equal(est, po.cms_estimates_numpy(cms.reshape(depth, -1), keys, depth, wl2, seed))
+        for i in (0, 5, 300, (1 << L) + 17):
+            assert int(est[i]) == po.cms_query(cms, depth, wl2, seed, keys[i].tobytes())
+        want = bench._want_top100(cms, L, dst, depth, wl2, seed)
+        uniq = {}
+        for k, e in zip(keys, est):
+            uniq[k.tobytes()] = int(e)
+        assert want == sorted(uniq.items(), key=lambda kv: (-kv[1], kv[0]))[:100]
