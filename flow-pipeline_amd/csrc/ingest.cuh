@@ -265,7 +265,7 @@ __device__ __forceinline__ void lane_work(const KArgs& a, LdsTable<LDS_SLOTS>& l
                         const size_t at = (size_t)part * a.region + (size_t)blockIdx.x * a.capq + (a.capq - 1u - ob);
                         if (FA_DBG(a, DBG_TUPLE_LOCAL)) {
                             reinterpret_cast<uint2*>(a.seg)[(size_t)blockIdx.x * 512u + (at & 511u)] = make_uint2(tv.x, tv.y);
-                        } else if (!(FA_DBG(a, DBG_NO_TUPLE_STORE))) {
+                        } else if (!(FA_DBG(a, DBG_NO_TUPLE_STORE | DBG_NO_SINGLES))) {
                             if (T8) reinterpret_cast<uint2*>(a.seg)[at] = make_uint2(tv.x, tv.y);
                             else a.seg[at] = tv;
                         }
