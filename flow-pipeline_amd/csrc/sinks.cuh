@@ -93,7 +93,7 @@ constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense hi
 #endif
 #define FA_DBG(a, flags) (FA_ABLATE != 0 && ((a).dbg & (flags)) != 0)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
-       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072, DBG_NO_KEYSET = 262144, DBG_NO_CMS = 524288, DBG_NO_HOT = 1048576, DBG_NO_SINGLES = 134217728 /* tuples that meet a closing bin are dropped instead of leaving as single stores: what the singles cost in WRITE_SIZE and time */, DBG_TUPLE_LOCAL = 67108864 /* tuple stores go to a 4 KiB window per workgroup (L2-resident): the store INSTRUCTIONS and their acknowledgements stay, the HBM write traffic goes */, DBG_CAND_NO_SET = 33554432 /* candidates mode: addresses above the threshold are neither looked up in nor added to the set */, DBG_AGG_ATOMIC_FLUSH = 2097152 /* exact: agg8_kernel adds its groups with atomics although it owns the region (A/B) */,
+       DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072, DBG_NO_KEYSET = 262144, DBG_NO_CMS = 524288, DBG_NO_HOT = 1048576, DBG_CMS_TUPLE_LOCAL = 268435456 /* sketch tuples of full bins go to a 4 KiB window per workgroup: their HBM writes go, everything else stays (what narrower sketch tuples could buy on the write side) */, DBG_NO_SINGLES = 134217728 /* tuples that meet a closing bin are dropped instead of leaving as single stores: what the singles cost in WRITE_SIZE and time */, DBG_TUPLE_LOCAL = 67108864 /* tuple stores go to a 4 KiB window per workgroup (L2-resident): the store INSTRUCTIONS and their acknowledgements stay, the HBM write traffic goes */, DBG_CAND_NO_SET = 33554432 /* candidates mode: addresses above the threshold are neither looked up in nor added to the set */, DBG_AGG_ATOMIC_FLUSH = 2097152 /* exact: agg8_kernel adds its groups with atomics although it owns the region (A/B) */,
        DBG_AGG8_TIMING = 8388608 /* agg8_kernel: 100 MHz ticks per workgroup - set-up / segment walk / flush */,
        DBG_CMS_TIMING = 4194304 /* cms_agg_kernel: 100 MHz ticks per workgroup - schedule + counts + flush / segment walk; the waves' own walk times (imbalance) */ };
 
@@ -390,7 +390,8 @@ __device__ __forceinline__ void cms_bins_flush(const KArgs& a, CmsLds& cl, uint3
             const uint4 tv = late ? bins4[fp * 4u + sub] : tq;
             if ((chunk + 1u) * CMS_BIN <= a.ccapf) {
                 // (cregion and ccapq are multiples of 4 tuples: every segment starts on a 64-byte boundary)
-                a.cseg[(size_t)fp * a.cregion + (size_t)blockIdx.x * a.ccapq + chunk * CMS_BIN + sub] = tv;
+                if (FA_DBG(a, DBG_CMS_TUPLE_LOCAL)) a.cseg[(size_t)blockIdx.x * 256u + ((chunk * CMS_BIN + sub) & 255u)] = tv;
+                else a.cseg[(size_t)fp * a.cregion + (size_t)blockIdx.x * a.ccapq + chunk * CMS_BIN + sub] = tv;
             } else {
                 cms_atomic_tuple(a, fp, tv);
                 if (sub == 0) atomicSub(&cl.part_cnt[fp], 1u);  // (the chunk was not stored: the 16-bit counter stays <= its cap, never carries)
