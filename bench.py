@@ -37,6 +37,7 @@ Other workloads (side measurements, their JSON goes to profiles/): --mode zipf -
 (projection only).
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -917,14 +918,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     xdev = dev if backend == "nccl" else torch.device("cpu")  # where the window-close exchange tensors live
+    gpre = None
+    if world > 1 and rank == 0 and not args.no_group_preflight:
+        # the product's OTHER multi-GPU form - one process, a ctx per device, fa_group_* - has never run on more than one device:
+        # rank 0 runs it on every visible device in a process of its own BEFORE it joins the process group (the other ranks wait in
+        # init_process_group's rendezvous, on the CPU - not inside a collective that spins on their GPUs)
+        gpre = group_preflight()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("NCCL_DEBUG", "WARN")  # (quiet unless something is wrong; the preflight shows its tail on failure)
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/fa_bench_rccl.%h.%p.log")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(minutes=30))
 
     fa = _pkg.load()
     fa.build()
@@ -935,13 +942,6 @@ def main():
     pre = None
     if world > 1 and not args.no_preflight:
         pre = preflight(fa, torch, dist, rank, world, local_rank, backend, xdev, strict=args.strict_preflight)
-    gpre = None
-    if world > 1 and not args.no_group_preflight:
-        # the product's OTHER multi-GPU form - one process, a ctx per device, fa_group_* - has never run on more than one device:
-        # rank 0 runs it on every visible device in a process of its own while the other ranks wait
-        if rank == 0:
-            gpre = group_preflight()
-        dist.barrier()
     # every rank = one Kafka partition with its own stream (seed 2 = config 2, + rank)
     mp = fa.mock_params(mode=mode, framed=1, seed=2 + rank, n_total=n_rec, span_secs=900, per_sec=400_000,
                         zipf_s_x100=args.zipf_s, zipf_log2_universe=args.zipf_universe_log2)
