@@ -168,6 +168,17 @@ func newPartition(partition int32, claims int) *partitionState {
 	if rc := C.fa_create(&cfg, &ctx); rc != 0 {
 		log.Fatalf("fa_create: %d %s", int(rc), C.GoString(C.fa_last_error(nil))) // sink error is fatal, inserter.go:102-105
 	}
+	// the staging a batch of -gpu.batch.bytes needs is page-locked here, not inside the consume loop (ABI 8)
+	if *BatchBytes > 0 {
+		bytes := C.size_t(*BatchBytes + 64<<10)
+		recs := bytes / 48
+		if recs > 1<<24 {
+			recs = 1 << 24
+		}
+		if rc := C.fa_reserve_ingest(ctx, bytes, recs); rc != 0 {
+			log.Fatalf("fa_reserve_ingest: %d %s", int(rc), C.GoString(C.fa_last_error(ctx)))
+		}
+	}
 	return &partitionState{ctx: ctx, offsets: []uint64{0}}
 }
 
