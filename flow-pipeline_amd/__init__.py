@@ -151,15 +151,37 @@ def build(force=False):
     srcs = [os.path.join(srcdir, f) for f in os.listdir(srcdir) if not f.endswith(".so")] + [
         os.path.join(_HERE, "..", "include", "flowagg.h")]
 
+    stamp = LIB_PATH + ".srchash"  # the sources the library was built from (a copy of the tree may reset every mtime)
+
+    def stamped():
+        try:
+            with open(stamp) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
     def stale():
-        return (not os.path.exists(LIB_PATH)
-                or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
+        if not os.path.exists(LIB_PATH):
+            return True
+        if stamped() == source_hash():
+            return False  # (built from exactly these sources, whatever the mtimes say)
+        return stamped() is not None or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+
+    def write_stamp():
+        try:
+            with open(stamp + ".tmp.%d" % os.getpid(), "w") as f:
+                f.write(source_hash() + "\n")
+            os.replace(stamp + ".tmp.%d" % os.getpid(), stamp)
+        except OSError:
+            pass
 
     if os.environ.get("FA_LIB_VARIANT"):  # A/B libraries are built by hand with their own EXTRA flags: never rebuilt here
         if not os.path.exists(LIB_PATH):
             raise FlowAggError(-2, "%s is not built" % LIB_PATH)
         return LIB_PATH
     if not (force or stale()):
+        if stamped() is None:
+            write_stamp()  # (a library built by hand with make, newer than its sources: remember what it was built from)
         return LIB_PATH
     with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
@@ -169,6 +191,7 @@ def build(force=False):
                 try:
                     subprocess.check_call(["make", "-C", srcdir, "-B", "OUT=" + tmp], stdout=subprocess.DEVNULL)
                     os.replace(tmp, LIB_PATH)
+                    write_stamp()
                 finally:
                     if os.path.exists(tmp):
                         os.unlink(tmp)
