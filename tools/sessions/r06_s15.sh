@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the code of this experiment was taken out of the tree after it was measured (CHANGELOG round 6 says what it was); the script documents the runs behind the jsonl in profiles/.
 # round 6, GPU session 15: wave priority in the wave-tile kernel (s_setprio 1 / 3 while a wave holds a staged tile, 0 once its next DMA is out)
 # libs: make OUT=../libflowagg_prio{1,3}.so EXTRA=-DFA_SETPRIO={1,3}
 O=gpurun_out/s15

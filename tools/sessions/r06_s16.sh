@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the code of this experiment was taken out of the tree after it was measured (CHANGELOG round 6 says what it was); the script documents the runs behind the jsonl in profiles/.
 # premise check: full store units appended to one sequential log per workgroup (measurement build, results wrong by design)
 O=gpurun_out/s16
 mkdir -p $O

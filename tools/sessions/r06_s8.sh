@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the code of this experiment was taken out of the tree after it was measured (CHANGELOG round 6 says what it was); the script documents the runs behind the jsonl in profiles/.
 # round 6, GPU session 8: how long a wave keeps offering records to the LDS hot-key table (FA_LT_KEEP: 1 hit in 8 / 32 / 64 of its
 # last 256 records) - skewed AS pairs leave agg8_kernel with one partition 2.6x the mean when the hot pairs all become tuples
 O=gpurun_out/s8
