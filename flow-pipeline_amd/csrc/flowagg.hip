@@ -178,6 +178,10 @@ struct fa_ctx {
     void* cut_buf = nullptr;         // fa_read_window_app48 into page-locked memory: the window's rows cut in two by key (rows_host.inc)
     size_t cut_cap = 0;
     hipStream_t copy_stream = nullptr;  // ... the first half's rows leave on it while the second half is sorted
+    // candidates mode: the launch boundary's two kernels (estimates of the candidates, the bits) run on a stream of their own beside
+    // the flows_5m tuple aggregation, which touches neither the sketches nor the sets (launch_tiles)
+    hipStream_t cand_stream = nullptr;
+    hipEvent_t cand_ev[2] = {nullptr, nullptr};  // sketches folded (main -> side), boundary done (side -> main)
     void* fs_scratch = nullptr;      // device-side framing (framing.cuh): block starts (two copies), counts, bases, error flags, counters
     size_t fs_scratch_cap = 0;
     void* fs_off = nullptr;          // ... the offsets it produces
@@ -444,6 +448,10 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
             if ((e = hipMemsetAsync(c->ks_dst, 0, ks_bytes, c->stream)) != hipSuccess) return bail("memset", e);
         }
         if (cfg.topk_mode == FA_TOPK_CANDIDATES) {
+            // (the boundary's side stream: created here - a stream costs milliseconds, not a thing for the first ingest launch)
+            if ((e = hipStreamCreateWithFlags(&c->cand_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate(candidates boundary)", e);
+            for (int i = 0; i < 2; i++)
+                if ((e = hipEventCreateWithFlags(&c->cand_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
             c->cand_bits_bytes = std::max<size_t>(c->cms_words / 8, 8) + 8;
             for (int d = 0; d < 2; d++)
                 if (cfg.key_sets & (d ? FA_KEYS_DSTADDR_CMS : FA_KEYS_SRCADDR_CMS)) {
@@ -576,6 +584,9 @@ extern "C" void fa_destroy(fa_ctx* c) {
     (void)hipFree(c->m_scratch);
     (void)hipFree(c->cut_buf);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->cand_stream) (void)hipStreamDestroy(c->cand_stream);
+    for (int i = 0; i < 2; i++)
+        if (c->cand_ev[i]) (void)hipEventDestroy(c->cand_ev[i]);
     (void)hipFree(c->m_out[0]);
     (void)hipFree(c->m_out[1]);
     (void)hipFree(c->fs_scratch);
