@@ -178,10 +178,10 @@ struct fa_ctx {
     void* cut_buf = nullptr;         // fa_read_window_app48 into page-locked memory: the window's rows cut in two by key (rows_host.inc)
     size_t cut_cap = 0;
     hipStream_t copy_stream = nullptr;  // ... the first half's rows leave on it while the second half is sorted
-    // candidates mode: the launch boundary's two kernels (estimates of the candidates, the bits) run on a stream of their own beside
-    // the flows_5m tuple aggregation, which touches neither the sketches nor the sets (launch_tiles)
+    // contexts with a sketch: the flows_5m tuple aggregation of a launch runs on a stream of its own BESIDE the sketch fold (and the
+    // candidates mode's boundary kernels) - it touches neither sketch nor set, they touch neither tuple segments nor table (launch_tiles)
     hipStream_t cand_stream = nullptr;
-    hipEvent_t cand_ev[2] = {nullptr, nullptr};  // sketches folded (main -> side), boundary done (side -> main)
+    hipEvent_t cand_ev[2] = {nullptr, nullptr};  // ingest + second-chance kernels done (main -> side), aggregation done (side -> main)
     void* fs_scratch = nullptr;      // device-side framing (framing.cuh): block starts (two copies), counts, bases, error flags, counters
     size_t fs_scratch_cap = 0;
     void* fs_off = nullptr;          // ... the offsets it produces
@@ -437,6 +437,11 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
             if ((e = hipMemsetAsync(c->cms_dst, 0, c->cms_words * 8 * CMS_REPLICAS, c->stream)) != hipSuccess)
                 return bail("memset", e);
         }
+        // (the side stream of the ingest path - launch_tiles: the flows_5m tuple aggregation runs on it beside the sketch fold - is
+        // created here: a stream costs milliseconds, not a thing for the first ingest launch)
+        if ((e = hipStreamCreateWithFlags(&c->cand_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate(side stream)", e);
+        for (int i = 0; i < 2; i++)
+            if ((e = hipEventCreateWithFlags(&c->cand_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         c->ks_log2 = cfg.topk_capacity_log2;
         const size_t ks_bytes = sizeof(KeySlot) << c->ks_log2;
         if (cfg.key_sets & FA_KEYS_SRCADDR_CMS) {
@@ -448,10 +453,6 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
             if ((e = hipMemsetAsync(c->ks_dst, 0, ks_bytes, c->stream)) != hipSuccess) return bail("memset", e);
         }
         if (cfg.topk_mode == FA_TOPK_CANDIDATES) {
-            // (the boundary's side stream: created here - a stream costs milliseconds, not a thing for the first ingest launch)
-            if ((e = hipStreamCreateWithFlags(&c->cand_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate(candidates boundary)", e);
-            for (int i = 0; i < 2; i++)
-                if ((e = hipEventCreateWithFlags(&c->cand_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
             c->cand_bits_bytes = std::max<size_t>(c->cms_words / 8, 8) + 8;
             for (int d = 0; d < 2; d++)
                 if (cfg.key_sets & (d ? FA_KEYS_DSTADDR_CMS : FA_KEYS_SRCADDR_CMS)) {
