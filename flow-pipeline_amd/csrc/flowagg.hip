@@ -439,9 +439,12 @@ extern "C" int fa_create(const fa_config* cfg_in, fa_ctx** out) {
         }
         // (the side stream of the ingest path - launch_tiles: the flows_5m tuple aggregation runs on it beside the sketch fold - is
         // created here: a stream costs milliseconds, not a thing for the first ingest launch)
-        if ((e = hipStreamCreateWithFlags(&c->cand_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate(side stream)", e);
-        for (int i = 0; i < 2; i++)
-            if ((e = hipEventCreateWithFlags(&c->cand_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        const bool want_side = cfg.topk_mode == FA_TOPK_CANDIDATES && (getenv("FA_AGG_SIDE") == nullptr || strcmp(getenv("FA_AGG_SIDE"), "0") != 0);
+        if (want_side) {  // (only the candidates mode uses it: every stream of a process competes for its few hardware queues)
+            if ((e = hipStreamCreateWithFlags(&c->cand_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate(side stream)", e);
+            for (int i = 0; i < 2; i++)
+                if ((e = hipEventCreateWithFlags(&c->cand_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        }
         c->ks_log2 = cfg.topk_capacity_log2;
         const size_t ks_bytes = sizeof(KeySlot) << c->ks_log2;
         if (cfg.key_sets & FA_KEYS_SRCADDR_CMS) {
