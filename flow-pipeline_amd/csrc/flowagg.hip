@@ -182,7 +182,7 @@ struct fa_ctx {
     // candidates mode's boundary kernels) - it touches neither sketch nor set, they touch neither tuple segments nor table (launch_tiles)
     hipStream_t cand_stream = nullptr;
     hipEvent_t cand_ev[2] = {nullptr, nullptr};  // ingest + second-chance kernels done (main -> side), aggregation done (side -> main)
-    void* fs_scratch = nullptr;      // device-side framing (framing.cuh): block starts (two copies), counts, bases, error flags, counters
+    void* fs_scratch = nullptr;      // device-side framing (framing.cuh): block starts, exits, counts, bases, error / trust flags, sub-block entries, counters
     size_t fs_scratch_cap = 0;
     void* fs_off = nullptr;          // ... the offsets it produces
     size_t fs_off_cap = 0;

@@ -427,6 +427,40 @@ def test_device_side_framing_refuses_what_is_not_a_chain_and_survives_odd_ones(g
         assert (st["records_ok"], st["records_bad"], st["bytes_in"]) == (sw["records_ok"], sw["records_bad"], sw["bytes_in"])
 
 
+@pytest.mark.parametrize("mode,n", [(5, 2_000), (5, 60_000), (3, 150_000)])
+def test_device_side_framing_repairs_wrong_guesses(gpu_lib, fa, po, mode, n, capfd, monkeypatch):
+    """The guesses only decide the number of rounds.  A producer that marshals its fields in descending order (generator mode 5)
+    has no plausible candidate anywhere: every block starts from its own first byte and is walked again from where its predecessor
+    ends - about a block per round, on the device while the rounds last (9 blocks), on the host beyond (260 blocks); the GoFlow-shaped
+    stream has 3-4 % of its guesses replaced, each walked again only up to the frame where the two walks meet.  Rows equal
+    the offsets path every time."""
+    import torch
+    monkeypatch.setenv("FA_VERBOSE", "1")
+    gp = po.gen_params(mode=mode, framed=1, seed=77, n_total=n, span_secs=900)
+    buf, off = po.gen_records(gp, 0, n)
+    ref = po.Rollup(300)
+    assert ref.ingest(buf, off, 1) == 0
+    d = torch.zeros(len(buf) + 64, dtype=torch.uint8, device="cuda")
+    d[:len(buf)] = torch.from_numpy(np.ascontiguousarray(buf))
+    torch.cuda.synchronize()
+    with fa.FlowAgg(framed=True) as agg:
+        capfd.readouterr()
+        agg.ingest_device(d.data_ptr(), len(buf), 0, 0)
+        agg.sync()
+        log = capfd.readouterr().err
+        assert agg.read_window().tobytes() == ref.rows().tobytes()
+        st = agg.stats()
+        assert st["records_ok"] == n and st["records_bad"] == 0
+    line = [l for l in log.splitlines() if "[flowagg framing]" in l][-1]
+    blocks = (len(buf) + 16383) // 16384
+    if mode == 5 and blocks <= 12:
+        assert "NOT" not in line and 3 < int(line.split("settled after ")[1].split()[0]) <= blocks + 1, line  # (a few blocks begin on a frame by chance)
+    elif mode == 5:
+        assert "NOT settled" in line, line
+    else:
+        assert "settled after" in line and "NOT" not in line, line
+
+
 def test_first_big_launch_is_probed_before_the_rest_follows(gpu_lib, fa, po, monkeypatch):
     """A ctx whose FIRST launch is big (>= 2^22 records) and carries the (SrcAddr,DstPort,Proto) key set: its first 2^20 + 2^17
     records go ahead as a launch of their own, the counter feedback reads them, and a stream that opens a row per record has the
