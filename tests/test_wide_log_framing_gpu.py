@@ -461,6 +461,74 @@ def test_device_side_framing_repairs_wrong_guesses(gpu_lib, fa, po, mode, n, cap
         assert "settled after" in line and "NOT" not in line, line
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FA_FUZZ_SEEDS", "12"))))
+def test_device_side_framing_random_chains(gpu_lib, fa, po, seed, capfd, monkeypatch):
+    """Chains drawn at random - runs of generated records of every producer, cut by junk frames (random bytes behind a length of
+    0 .. 40 000: no candidate is plausible near them, the blocks behind them are walked again from where their predecessor ends),
+    runs of empty frames, records in descending field order - cut on the device: rows and counters equal the offsets path with
+    the offsets of a host walk.  What matters is the repair rounds: the walk from a replaced start meets the first walk somewhere
+    (inside the same 256-byte sub-block, sub-blocks later, or never)."""
+    import torch
+    monkeypatch.setenv("FA_VERBOSE", "1")
+    rng = np.random.default_rng(4400 + seed)
+    parts = []
+    total = 0
+    want_bytes = int(rng.integers(1_200_000, 4_000_000))
+    while total < want_bytes:
+        kind = int(rng.integers(0, 10))
+        if kind < 6:
+            mode = int(rng.choice([1, 2, 3, 1, 2, 3, 1, 2, 3, 1, 2, 5]))
+            n = int(rng.integers(50, 400 if mode == 5 else 6000))  # (descending field order: no candidates - a block per round, twelve rounds)
+            gp = po.gen_params(mode=mode, framed=1, seed=int(rng.integers(1, 1 << 20)), n_total=n, span_secs=900, zipf_log2_universe=12)
+            buf, _off = po.gen_records(gp, 0, n)
+            piece = bytes(buf)
+        elif kind < 8:
+            ln = int(rng.choice([0, 1, int(rng.integers(2, 300)), int(rng.integers(300, 5000)), int(rng.integers(5000, 40000))]))
+            piece = _varint(ln) + rng.integers(0, 256, size=ln, dtype=np.uint8).tobytes()
+        elif kind < 9:
+            piece = b"\x00" * int(rng.integers(1, 700))
+        else:  # a record-sized frame of zeros behind a few ordinary ones: plausible lengths, implausible payloads
+            ln = int(rng.integers(40, 120))
+            piece = (_varint(ln) + bytes(ln)) * int(rng.integers(1, 40))
+        parts.append(piece)
+        total += len(piece)
+    stream = b"".join(parts)
+    off = [0]
+    p = 0
+    while p < len(stream):
+        v = sh = 0
+        while True:
+            b = stream[p]
+            p += 1
+            v |= (b & 0x7F) << sh
+            sh += 7
+            if not b & 0x80:
+                break
+        p += v
+        off.append(p)
+    assert p == len(stream)
+    off = np.array(off, dtype=np.uint64)
+    d = torch.zeros(len(stream) + 64, dtype=torch.uint8, device="cuda")
+    d[:len(stream)] = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy())
+    torch.cuda.synchronize()
+    kw = dict(framed=True, key_sets=9, max_batch_records=len(off))
+    with fa.FlowAgg(**kw) as agg, fa.FlowAgg(**kw) as want:
+        capfd.readouterr()
+        agg.ingest_device(d.data_ptr(), len(stream), 0, 0)
+        agg.sync()
+        log = capfd.readouterr().err
+        want.ingest(np.frombuffer(stream, dtype=np.uint8), off)
+        st, sw = agg.stats(), want.stats()
+        assert (st["records_ok"], st["records_bad"], st["bytes_in"]) == (sw["records_ok"], sw["records_bad"], sw["bytes_in"]), (seed, log)
+        assert st["records_ok"] + st["records_bad"] == len(off) - 1
+        assert agg.read_window().tobytes() == want.read_window().tobytes()
+        assert agg.read_window_app().tobytes() == want.read_window_app().tobytes()
+    assert "[flowagg framing]" in log
+    if os.environ.get("FA_FUZZ_PRINT"):  # (soak runs: how the rounds went)
+        with capfd.disabled():
+            print([l for l in log.splitlines() if "[flowagg framing]" in l][-1])
+
+
 def test_first_big_launch_is_probed_before_the_rest_follows(gpu_lib, fa, po, monkeypatch):
     """A ctx whose FIRST launch is big (>= 2^22 records) and carries the (SrcAddr,DstPort,Proto) key set: its first 2^20 + 2^17
     records go ahead as a launch of their own, the counter feedback reads them, and a stream that opens a row per record has the
