@@ -48,6 +48,7 @@ constexpr uint32_t FS_CAND = 256;   // candidate positions per block (covers rec
 constexpr int FS_PLAUSIBLE = 2;     // consecutive plausible frames a candidate needs ...
 constexpr int FS_PREFILTER = 2;     // ... and the frames from it whose first bytes have to look like frames before any is parsed (>= FS_PLAUSIBLE;
                                     // 3, 4, 6: the same guesses at the same cost, profiles/r06_framing_micro.txt)
+constexpr bool FS_TIERS = true;      // candidates whose two frames begin with the same tag byte are parsed first
 constexpr uint32_t FS_SUB = 256;    // sub-block: the emit pass walks one per lane
 constexpr uint32_t FS_NSUB = FS_BLOCK / FS_SUB;  // 64 = a wave
 constexpr uint32_t FS_STAGE = 1024; // bytes of a block the guess stages in LDS (the candidates + two frames behind the last one)
@@ -186,38 +187,44 @@ __device__ __forceinline__ bool fs_plausible_staged(const FsLds& buf, uint32_t q
 // a few bytes decide whether position p is worth a parse: two frames in a row with a length prefix of one to three bytes, a
 // payload that is not empty and ends inside [.., lim], and a first tag of field >= 1 with a wire type that exists - what
 // fs_next + fs_plausible_payload would find out first, without their loops (a first tag of several bytes passes)
+// Returns 0: no; 1: worth a parse; 2: worth a parse, and the first two frames begin with the same tag byte - what the records of one
+// producer nearly always do, and what a position inside a record (13 of 64 positions are field boundaries: they pass for a
+// prefix and a tag) nearly never does.
 template <class Bytes, int FRAMES>
-__device__ __forceinline__ bool fs_prefilter(const Bytes& buf, uint32_t p, uint32_t lim) {
+__device__ __forceinline__ uint32_t fs_prefilter(const Bytes& buf, uint32_t p, uint32_t lim) {
+    uint32_t first_tag = 0x100u, same = 0u;
 #pragma unroll
     for (int k = 0; k < FRAMES; k++) {
-        if (p >= lim) return k > 0;  // (the first frame ended where the stream - or the stage - does)
+        if (p >= lim) return k > 0 ? 1u : 0u;  // (the first frame ended where the stream - or the stage - does)
         const uint32_t b0 = buf[p], b1 = buf[p + 1], b2 = buf[p + 2];
         uint32_t v = b0 & 0x7fu, q = p + 1;
         if (b0 & 0x80u) {
             v |= (b1 & 0x7fu) << 7;
             q++;
             if (b1 & 0x80u) {
-                if (b2 & 0x80u) return false;
+                if (b2 & 0x80u) return 0u;
                 v |= b2 << 14;
                 q++;
             }
         }
-        if (v == 0) return false;
-        if (q >= lim || v > lim - q) return k >= FS_PLAUSIBLE;  // (leaves the stage: the frames that are parsed must not, the others cannot tell)
+        if (v == 0) return 0u;
+        if (q >= lim || v > lim - q) return k >= FS_PLAUSIBLE ? 1u + same : 0u;  // (leaves the stage: the frames that are parsed must not, the others cannot tell)
         const uint32_t t = buf[q];
         if (!(t & 0x80u)) {
             const uint32_t wt = t & 7u;
-            if ((t >> 3) == 0 || !(wt == 0u || wt == 1u || wt == 2u || wt == 5u)) return false;
+            if ((t >> 3) == 0 || !(wt == 0u || wt == 1u || wt == 2u || wt == 5u)) return 0u;
         }
+        if (k == 0) first_tag = t;
+        if (k == 1) same = t == first_tag ? 1u : 0u;
         p = q + v;
     }
-    return true;
+    return 1u + same;
 }
 
 // start[b] for every block b >= 1 (start[0] is 0 by definition and written by the host): the smallest plausible candidate,
 // the block's begin when none stands (the rounds below - or the host - sort that out).  The guess sees the stream end at the
 // end of the stage: a candidate whose two frames leave it does not stand (FS_STAGE - FS_CAND bytes hold two frames of 384).
-template <int PRE, int FULL>
+template <int PRE, int FULL, bool TIERS>
 __global__ __launch_bounds__(256) void fs_guess_kernel_t(const uint8_t* buf, uint32_t len, uint32_t nblocks, uint32_t* start) {
     __shared__ uint4 stage[4][(FS_STAGE + FS_STAGE_PAD) / 16];
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
@@ -228,20 +235,29 @@ __global__ __launch_bounds__(256) void fs_guess_kernel_t(const uint8_t* buf, uin
     const FsLds bytes{reinterpret_cast<const uint8_t*>(stage[wave]), begin, FS_STAGE};
     const uint32_t lim = min(len, begin + FS_STAGE);
     uint32_t guess = begin;
-    for (uint32_t r = 0; r < FS_CAND; r += 64) {
-        uint32_t p = begin + r + lane;
-        bool ok = p < lim && fs_prefilter<FsLds, PRE>(bytes, p, lim);
-        if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
-        for (int k = 0; k < FULL && ok && p < lim; k++) {
-            uint32_t payload = 0;
-            const uint32_t q = fs_next(bytes, p, lim, &payload);
-            ok = q != FS_ERR && fs_plausible_staged(bytes, payload, q);
-            p = q;
-        }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
-        if (m != 0ull) {
-            guess = begin + r + (uint32_t)__builtin_ctzll(m);
-            break;
+    bool found = false;
+    for (uint32_t r = 0; r < FS_CAND && !found; r += 64) {
+        const uint32_t p0 = begin + r + lane;
+        const uint32_t pre = p0 < lim ? fs_prefilter<FsLds, PRE>(bytes, p0, lim) : 0u;
+        if (__builtin_amdgcn_ballot_w64(pre != 0u) == 0ull) continue;
+        // the candidates whose two frames begin alike first: usually the true start alone - the others would each run the parser's
+        // loops to their own trip counts (the wave pays for the longest of every loop); then, if none of them stands, the rest
+#pragma unroll 1
+        for (uint32_t tier = TIERS ? 2u : 1u; tier >= 1u && !found; tier--) {
+            bool ok = TIERS ? pre == tier : pre != 0u;
+            if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
+            uint32_t p = p0;
+            for (int k = 0; k < FULL && ok && p < lim; k++) {
+                uint32_t payload = 0;
+                const uint32_t q = fs_next(bytes, p, lim, &payload);
+                ok = q != FS_ERR && fs_plausible_staged(bytes, payload, q);
+                p = q;
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(ok);
+            if (m != 0ull) {
+                guess = begin + r + (uint32_t)__builtin_ctzll(m);
+                found = true;
+            }
         }
     }
     if (lane == 0) start[b] = guess;

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void guess_x_kernel(const uint8_t* buf, uint32
     uint32_t guess = begin, ns = 0;
     for (uint32_t r = 0; r < FS_CAND; r += 64) {
         uint32_t p = begin + r + lane;
-        bool ok = p < lim && fs_prefilter<FsLds, NF>(bytes, p, lim);
+        bool ok = p < lim && fs_prefilter<FsLds, NF>(bytes, p, lim) != 0u;
         const unsigned long long s = __builtin_amdgcn_ballot_w64(ok);
         if (s == 0ull) continue;
         ns = (uint32_t)__builtin_popcountll(s);
@@ -233,8 +233,8 @@ int main(int argc, char** argv) {
     const int reps = 5;
     time_it("stage only (load - wait - write trips)", reps, [&] { hipLaunchKernelGGL(stage_only_kernel<false>, gw, bl, 0, 0, d, (uint32_t)total, nb, sink); }, total);
     time_it("stage only (product: loads in flight)", reps, [&] { hipLaunchKernelGGL(stage_only_kernel<true>, gw, bl, 0, 0, d, (uint32_t)total, nb, sink); }, total);
-#define GP(PRE, FULL, label)                                                                                                                      \
-    time_it(label, reps, [&] { hipLaunchKernelGGL((fs_guess_kernel_t<PRE, FULL>), gw, bl, 0, 0, d, (uint32_t)total, nb, start); }, total); \
+#define GP(PRE, FULL, TIERS, label)                                                                                                                      \
+    time_it(label, reps, [&] { hipLaunchKernelGGL((fs_guess_kernel_t<PRE, FULL, TIERS>), gw, bl, 0, 0, d, (uint32_t)total, nb, start); }, total); \
     accuracy(label);
 #define GX(NF, FULL, PIPE, label)                                                                                                                  \
     time_it(label, reps, [&] { hipLaunchKernelGGL((guess_x_kernel<NF, FULL, PIPE>), gw, bl, 0, 0, d, (uint32_t)total, nb, start, surv); }, total); \
@@ -242,13 +242,13 @@ int main(int argc, char** argv) {
     GX(2, 1, false, "guess: prefilter 2, byte-wise parse of 2")
     GX(4, 0, false, "guess: prefilter 4 only (smallest survivor)")
     CK(hipMemset(surv, 0, nb * 4));
-    GP(2, 2, "guess: prefilter 2, windowed parse of 2")
-    GP(3, 2, "guess: prefilter 3, windowed parse of 2")
-    GP(4, 2, "guess: prefilter 4, windowed parse of 2")
-    GP(4, 1, "guess: prefilter 4, windowed parse of 1")
-    GP(6, 1, "guess: prefilter 6, windowed parse of 1")
-    GP(6, 2, "guess: prefilter 6, windowed parse of 2")
-    GP(FS_PREFILTER, FS_PLAUSIBLE, "guess (product)")
+    GP(2, 2, false, "guess: prefilter 2, windowed parse of 2")
+    GP(4, 2, false, "guess: prefilter 4, windowed parse of 2")
+    GP(4, 1, false, "guess: prefilter 4, windowed parse of 1")
+    GP(6, 2, false, "guess: prefilter 6, windowed parse of 2")
+    GP(2, 2, true, "guess: prefilter 2, parse of 2, like-tagged first")
+    GP(4, 2, true, "guess: prefilter 4, parse of 2, like-tagged first")
+    GP(FS_PREFILTER, FS_PLAUSIBLE, FS_TIERS, "guess (product)")
     // leave the product's guess in place for the walk
     CK(hipMemcpy(start, truth.data(), nb * 4, hipMemcpyHostToDevice));  // (the proven chain: what the emit pass sees)
     time_it("walk (product, a lane per block)", reps, [&] { hipLaunchKernelGGL(fs_walk_kernel, gl, bl, 0, 0, d, (uint32_t)total, nb, (const uint32_t*)start, cnt, err, exits, ent8, present); }, total);
