@@ -248,6 +248,9 @@ int main(int argc, char** argv) {
     GP(6, 2, false, "guess: prefilter 6, windowed parse of 2")
     GP(2, 2, true, "guess: prefilter 2, parse of 2, like-tagged first")
     GP(4, 2, true, "guess: prefilter 4, parse of 2, like-tagged first")
+    GP(2, 1, true, "guess: prefilter 2, parse of 1, like-tagged first")
+    GP(3, 1, true, "guess: prefilter 3, parse of 1, like-tagged first")
+    GP(4, 1, true, "guess: prefilter 4, parse of 1, like-tagged first")
     GP(FS_PREFILTER, FS_PLAUSIBLE, FS_TIERS, "guess (product)")
     // leave the product's guess in place for the walk
     CK(hipMemcpy(start, truth.data(), nb * 4, hipMemcpyHostToDevice));  // (the proven chain: what the emit pass sees)
