@@ -91,6 +91,9 @@ constexpr uint32_t PORT_DENSE = 65536;  // ports below this live in the dense hi
 #ifndef FA_ABLATE
 #define FA_ABLATE 0
 #endif
+#ifndef FA_TL_WINDOW
+#define FA_TL_WINDOW 256u
+#endif
 #define FA_DBG(a, flags) (FA_ABLATE != 0 && ((a).dbg & (flags)) != 0)
 enum { DBG_NO_SINK = 1, DBG_LOOP_PARSER = 2, DBG_NO_LDS_TABLE = 4, DBG_NO_GLOBAL = 8, DBG_NO_PARSE = 16, DBG_NO_TUPLE_STORE = 32,
        DBG_AGG_NO_LDS = 64, DBG_AGG_NO_FLUSH = 128, DBG_AGG_NO_SLOW = 256, DBG_DMA_NO_NT = 512, DBG_TIMING = 1024, DBG_TUPLE_NT = 2048, DBG_TUPLE_SC = 4096, DBG_NO_LANE_OFF = 8192, DBG_SYNTH_TILES = 16384, DBG_NOT_MINE = 32768, DBG_NO_SECOND = 65536, DBG_NO_FRAME = 131072, DBG_NO_KEYSET = 262144, DBG_NO_CMS = 524288, DBG_NO_HOT = 1048576, DBG_CMS_TUPLE_LOCAL = 268435456 /* sketch tuples of full bins go to a 4 KiB window per workgroup: their HBM writes go, everything else stays (what narrower sketch tuples could buy on the write side) */, DBG_NO_SINGLES = 134217728 /* tuples that meet a closing bin are dropped instead of leaving as single stores: what the singles cost in WRITE_SIZE and time */, DBG_TUPLE_LOCAL = 67108864 /* tuple stores go to a 4 KiB window per workgroup (L2-resident): the store INSTRUCTIONS and their acknowledgements stay, the HBM write traffic goes */, DBG_CAND_NO_SET = 33554432 /* candidates mode: addresses above the threshold are neither looked up in nor added to the set */, DBG_AGG_ATOMIC_FLUSH = 2097152 /* exact: agg8_kernel adds its groups with atomics although it owns the region (A/B) */,
@@ -1060,7 +1063,10 @@ __device__ __forceinline__ void bins_flush(const KArgs& a, uint4* bins, uint32_t
                 const size_t seg0 = ((size_t)fp * a.region + (size_t)blockIdx.x * a.capq) >> (T8 ? 1 : 0);
                 // (plain stores: the L2 merges the half lines of a bin's two flushes and the back parts' single tuples before
                 // they go to HBM - streaming (nt) stores measured 6-11 % slower on BASELINE config 2, round 3)
-                if (FA_DBG(a, DBG_TUPLE_LOCAL)) a.seg[(size_t)blockIdx.x * 256u + ((line * BL + sub) & 255u)] = tv;
+                // (FA_TL_WINDOW: uint4s of the window, measurement builds only.  256 = 4 KiB: every partition's lines land on the same 2 KiB.
+                // Larger windows spread the partitions (128 uint4 apart = a launch's lines of one partition): 1024 / 4096 / 16384 / 32768 per
+                // workgroup = 8 / 32 / 128 / 256 MB over 512 workgroups - inside the L2s, their sum, the Infinity Cache, the real footprint)
+                if (FA_DBG(a, DBG_TUPLE_LOCAL)) a.seg[(size_t)blockIdx.x * FA_TL_WINDOW + ((fp * (FA_TL_WINDOW > 256u ? 128u : 0u) + line * BL + sub) & (FA_TL_WINDOW - 1u))] = tv;
                 else if (!(FA_DBG(a, DBG_NO_TUPLE_STORE))) a.seg[seg0 + line * BL + sub] = tv;
             } else {  // front part full (skewed batch): straight to the device-wide table
                 TupleVals v[2];
