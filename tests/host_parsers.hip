@@ -323,6 +323,43 @@ int main(int argc, char** argv) {
         n = random_schema_record(tmp, (rnd() & 3) != 0, (rnd() & 1) != 0, true);
         if (n < 900) check(tmp, n, wide67nc, false);
     }
+    // 5. GoFlow's field list with values of EVERY width in the short fields (4-byte AS numbers, 3-byte interface indexes, omitted
+    // fields): the GoFlow template walk must take every record whose short values are below 2^28 and may only ever answer with the
+    // oracle's columns (written for round 6's pair steps - two fields out of one window, measured 4 % slower and taken out - and kept)
+    Stats gfwide;
+    for (uint64_t i = 0; i < iters; i++) {
+        uint8_t tmp[512];
+        size_t n = 0;
+        auto vf = [&](uint32_t field, uint64_t v) {
+            if (!v) return;  // proto3 zero omission
+            n += put_varint(tmp + n, (uint64_t)field << 3);
+            n += put_varint(tmp + n, v);
+        };
+        auto bf = [&](uint32_t field, size_t len) {
+            n += put_varint(tmp + n, ((uint64_t)field << 3) | 2);
+            tmp[n++] = (uint8_t)len;
+            for (size_t j = 0; j < len; j++) tmp[n++] = (uint8_t)rnd();
+        };
+        bool fits = true;
+        auto sv = [&]() -> uint64_t {  // a short value of random width (0 .. 28 bits; 1 in 16: wider - the walk must say "not sure")
+            const uint32_t bits = (uint32_t)(rnd() % 29);
+            uint64_t v = bits ? (rnd() & ((1ull << bits) - 1)) : 0;
+            if ((rnd() & 15) == 0) { v |= 1ull << (28 + rnd() % 4); fits = false; }
+            return v;
+        };
+        const uint64_t t = 1600000000ull + rnd() % 100000000ull;
+        const size_t al = (rnd() & 1) ? 16 : 4;
+        vf(1, 1 + rnd() % 3); vf(2, t); vf(3, 1 + rnd() % 4096); vf(4, rnd() & 0xfffffff); vf(5, t);
+        bf(6, al); bf(7, al);
+        vf(9, sv()); vf(10, sv());
+        bf(11, 4); bf(12, al);
+        vf(13, sv()); vf(14, sv()); vf(15, sv()); vf(16, sv()); vf(17, sv()); vf(18, sv()); vf(19, sv()); vf(20, sv()); vf(21, sv()); vf(22, sv());
+        vf(23, sv()); vf(25, sv()); vf(26, sv());
+        vf(27, rnd() & 0xffffffffffffull | 1ull << 47); vf(28, rnd() & 0xffffffffffffull | 1ull << 47);
+        vf(29, sv()); vf(30, sv()); vf(33, sv()); vf(34, sv()); vf(35, sv()); vf(37, sv());
+        vf(38, t);
+        check(tmp, n, gfwide, false, false, fits ? 1 : -1);
+    }
     auto pr = [](const char* name, const Stats& s) {
         printf("%-28s cases=%llu oracle_ok=%llu canon_sure=%llu full_sure=%llu fast_sure=%llu tmpl_mocker_sure=%llu tmpl_goflow_sure=%llu seq_sure=%llu seq_learnt=%llu FAIL=%llu\n", name, (unsigned long long)s.cases,
                (unsigned long long)s.oracle_ok, (unsigned long long)s.canon_sure, (unsigned long long)s.full_sure, (unsigned long long)s.fast_sure,
@@ -337,7 +374,8 @@ int main(int argc, char** argv) {
     pr("random schema, non-canonical", noncanon);
     pr("67-field, canonical small", wide67);
     pr("67-field, mixed", wide67nc);
-    const uint64_t fails = reversed.fail + goflow.fail + gen.fail + mut.fail + canon.fail + noncanon.fail + small.fail + wide67.fail + wide67nc.fail;
+    pr("goflow fields, every width", gfwide);
+    const uint64_t fails = gfwide.fail + reversed.fail + goflow.fail + gen.fail + mut.fail + canon.fail + noncanon.fail + small.fail + wide67.fail + wide67nc.fail;
     printf(fails ? "FAILED\n" : "OK\n");
     return fails ? 1 : 0;
 }

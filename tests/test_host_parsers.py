@@ -34,6 +34,9 @@ def test_parsers_fuzz_against_oracle(po):
     assert f["tmpl_mocker_sure"] == f["cases"] and f["tmpl_goflow_sure"] == f["cases"], lines["generator (4 modes)"]
     f = dict(kv.split("=") for kv in lines["generator (goflow)"].split() if "=" in kv)
     assert f["tmpl_goflow_sure"] == f["cases"] and f["tmpl_mocker_sure"] == "0", lines["generator (goflow)"]
+    # GoFlow's field list with short values of every width: the template walk takes every record whose values fit (about a quarter)
+    f = dict(kv.split("=") for kv in lines["goflow fields, every width"].split() if "=" in kv)
+    assert int(f["tmpl_goflow_sure"]) * 5 >= int(f["cases"]) and f["FAIL"] == "0", lines["goflow fields, every width"]
     # descending field order: no ordered walk takes a record, the learnt order takes every one (the first is what it learns from)
     f = dict(kv.split("=") for kv in lines["generator (reversed)"].split() if "=" in kv)
     assert f["canon_sure"] == "0" and f["full_sure"] == "0" and f["fast_sure"] == f["cases"] and f["FAIL"] == "0", lines["generator (reversed)"]
