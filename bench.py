@@ -563,8 +563,8 @@ def sec_group8(fa, po, torch, dev, ref, members=8, chunk=8_333_334, cand=True):
             nslot = (slots[-1] - slots[0]) // 300 + 1
             want_sum, want_cnt, outside = po.app_checksum_stream(ref.gp, 0, n, threads, 300, slots[0], nslot)
             buf_rows = int(want_cnt.max()) + (1 << 16)  # (rows <= records of the window)
-            reuse = np.empty(buf_rows, dtype=fa.ROW_APP_DTYPE)
-            reuse.view(np.uint8)[::4096] = 0  # (pages touched before the clock starts: a consumer keeps its row buffer)
+            reuse = fa.FlowAgg.pinned_rows(fa.ROWS_APP, buf_rows)  # (page-locked, like config 5's: a consumer keeps its row buffer; a pageable one costs 5 - 30 ms more per window, box by box)
+            out["row_buffer"] = "page-locked"
             shares_c = (C.c_size_t * nm)()
             nr = C.c_size_t()
             app_ms = []
