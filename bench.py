@@ -376,10 +376,14 @@ class _Zipf3:
         return all([(bytes(r["key"]), int(r["weight"])) for r in top] == want for top, want in zip(tops, self.want))
 
 
-def sec_config3(fa, po, torch, dev, ref, cand, chunk=16_666_667):
+def sec_config3(fa, po, torch, dev, ref, cand, chunk=33_333_334):
     """BASELINE configs[2]: Count-Min heavy hitters over SrcAddr / DstAddr beside the flows_5m rollup (key_sets 7), `ref.n` framed
     records regenerated in HBM chunk by chunk; both sketches bit-exact against the CPU sketch of the whole stream, top-100 == the
-    ranking of the whole universe, count() of the rollup == records (viz-ch.json:233,479)."""
+    ranking of the whole universe, count() of the rollup == records (viz-ch.json:233,479).
+    Launches of 33.3 M records like the headline's (compact tuples: up to 2^25 - 1 per launch).  Until round 6 this block ran 16.67 M
+    per launch, the wide tuples' limit of round 2; what a launch costs whatever its size - the flush of both sketches, the launch
+    boundary's two scans in the candidates mode, the kernels' tails - then weighs twice as much: same box, 3 x, exact 0.134 - 0.135 at
+    16.67 M against 0.145 - 0.151 at 33.3 M, candidates 0.157 - 0.162 against 0.173 - 0.174 (profiles/r06_exp_config3_launch_size.jsonl)."""
     n, L = ref.n, ref.L
     KS = (fa.FA_KEYS_SRCADDR_CMS, fa.FA_KEYS_DSTADDR_CMS)
     mp = fa.mock_params(mode=fa.MOCK_ZIPF, framed=1, seed=3, n_total=n, span_secs=1800, zipf_log2_universe=L, zipf_s_x100=110)
@@ -416,7 +420,7 @@ def sec_config3(fa, po, torch, dev, ref, cand, chunk=16_666_667):
     path_s = st["batch_ns_total"] * 1e-9
     steady = series[len(series) // 2:]  # (the sets fill up during the first launches)
     out.update({
-        "records": n, "wire_bytes": wire, "launches": launches,
+        "records": n, "wire_bytes": wire, "launches": launches, "records_per_launch": min(chunk, n),
         "path_ms_per_launch": path_s / launches * 1e3, "frac": wire / path_s / (HBM_PEAK_GBS * 1e9),
         "path_ms_per_launch_second_half": float(np.mean(steady)), "frac_second_half": wire / launches / (float(np.mean(steady)) * 1e-3) / (HBM_PEAK_GBS * 1e9),
         "records_per_s_device_path": n / path_s, "path_ms_series": [round(x, 4) for x in series],

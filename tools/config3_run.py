@@ -70,7 +70,7 @@ def estimates(cms, lo, hi, depth, wl2, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--records", type=int, default=1_000_000_000)
-    ap.add_argument("--chunk", type=int, default=16_666_667)
+    ap.add_argument("--chunk", type=int, default=33_333_334, help="records per launch (until round 6: 16 666 667, the wide tuples' limit of round 2; see profiles/r06_exp_config3_launch_size.jsonl)")
     ap.add_argument("--prefix", type=int, default=100_000_000)
     ap.add_argument("--universe-log2", type=int, default=24)
     ap.add_argument("--threads", type=int, default=0)
